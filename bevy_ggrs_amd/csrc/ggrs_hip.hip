@@ -1,0 +1,895 @@
+// ggrs_hip.hip -- host runtime + C ABI of libggrs_hip.so (see include/ggrs_hip.h).
+//
+// One ggrs_world owns: a device arena carved into identical *packed state blocks* (one live
+// block + up to max_depth ring slots), the host-side ring bookkeeping (an exact mirror of
+// GgrsSnapshots<_, _>, /root/reference/src/snapshot/mod.rs:121-243, over slot indices instead
+// of HashMaps), the registered component/system tables and one HIP stream.  Every request
+// becomes kernel launches on that stream; the only host<->device synchronisation in
+// handle_requests is one checksum read-back at the end of the batch.
+//
+// There is NO CPU fallback: without a HIP device world creation fails with GGRS_E_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/ggrs_hip.h"
+#include "kernels.hpp"
+
+using namespace ggrs;
+
+namespace {
+
+constexpr uint64_t ALIGN = 256;
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct Comp {
+    std::string name;
+    uint32_t word_bytes = 4, n_words = 0;
+    std::vector<uint32_t> cks_words;     // as registered
+    bool checksummed = false;
+    std::vector<uint8_t> defaults;
+    uint32_t col_base = 0;               // index of its first column
+};
+
+struct Block {                           // one packed state block in the arena
+    uint8_t* ptr = nullptr;
+    uint64_t dirty_len = 0;              // slots that may hold non-zero mask bits
+    uint64_t len = 0;                    // host mirror of Header::len for ring slots
+};
+
+struct EventPair { hipEvent_t a, b; uint32_t cls; };
+
+}  // namespace
+
+struct ggrs_world {
+    // ---- configuration
+    int device = 0;
+    uint64_t capacity = 0, cap_pad = 0;
+    uint32_t max_depth = 0, flags = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false;
+
+    std::vector<Comp> comps;
+    std::vector<ggrs_system_desc> systems;
+    bool sealed = false;
+    std::string err;
+
+    // ---- layout of a packed state block
+    uint64_t state_bytes = 0, off_alive = 0;
+    std::vector<uint64_t> off_present, col_off;
+    std::vector<uint32_t> col_wb;
+    CopyPlan plan{};
+
+    // ---- device buffers
+    Block live;
+    std::vector<Block> slots;            // ring slot pool
+    std::vector<int> free_slots;
+    uint64_t* d_parts = nullptr; uint32_t part_stride = 0;   // [(n_cks)+1][part_stride], last = counts
+    uint64_t* d_results = nullptr; uint64_t* h_results = nullptr; uint32_t max_results = 0;
+    UnitDesc* d_units = nullptr;
+    uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
+    float* d_stage = nullptr; float* h_stage = nullptr; uint64_t stage_floats = 0, stage_used = 0;
+
+    // ---- checksum specs (device view)
+    std::vector<uint32_t> cks_comp;      // checksummed component ids in id order
+    CksArgs cks_args{};
+    bool fused_ok = false;               // schedule == particles fast path
+    bool fused_cks = false;              // ... and every checksum spec is covered by it
+    int f_T = -1, f_V = -1, f_L = -1, f_spawn = -1; uint32_t f_tw = 0, f_vw = 0;
+    bool f_cksT = false, f_cksV = false;
+    float f_g[3] = {0, 0, 0};
+
+    // pending partials produced by the last advance (valid for the live state as-is)
+    bool pending_valid = false; uint32_t pending_parts = 0;
+
+    // ---- host mirrors
+    uint64_t len = 0;
+    int32_t frame = 0;
+    bool has_confirmed = true; int32_t confirmed = 0;   // init_resource::<ConfirmedFrameCount>() == 0 (mod.rs:336)
+    uint64_t fps = 60;
+    int32_t synctest_cd = -1;
+    size_t depth = 60;                                   // DEFAULT_FPS until sync_depth (mod.rs:115)
+    std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
+
+    // ---- profiling
+    bool prof = false;
+    std::vector<EventPair> prof_events;
+    double prof_ms[GGRS_KERNEL_CLASSES] = {0, 0, 0, 0};
+    uint64_t prof_n[GGRS_KERNEL_CLASSES] = {0, 0, 0, 0};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(w, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return (w)->fail(GGRS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                              \
+    } while (0)
+
+namespace {
+
+struct ProfScope {
+    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ggrs_world* w_, uint32_t c) : w(w_), cls(c) {
+        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, w->stream); }
+    }
+    ~ProfScope() {
+        if (w->prof) { (void)hipEventRecord(b, w->stream); w->prof_events.push_back({a, b, cls}); }
+    }
+};
+
+// Computes the packed state layout from the registered components.
+void build_layout(ggrs_world* w) {
+    const uint64_t mask_bytes = align_up(w->cap_pad / 8, ALIGN);
+    uint64_t off = ALIGN;                          // header
+    w->off_alive = off; off += mask_bytes;
+    w->off_present.clear(); w->col_off.clear(); w->col_wb.clear();
+    for (size_t c = 0; c < w->comps.size(); ++c) { w->off_present.push_back(off); off += mask_bytes; }
+    for (auto& c : w->comps) {
+        c.col_base = (uint32_t)w->col_off.size();
+        for (uint32_t k = 0; k < c.n_words; ++k) {
+            w->col_off.push_back(off); w->col_wb.push_back(c.word_bytes);
+            off += align_up(w->cap_pad * c.word_bytes, ALIGN);
+        }
+    }
+    w->state_bytes = align_up(off, 4096);
+
+    CopyPlan& p = w->plan;
+    memset(&p, 0, sizeof p);
+    p.n_masks = 1 + (uint32_t)w->comps.size();
+    p.mask_off[0] = w->off_alive;
+    for (size_t c = 0; c < w->comps.size(); ++c) p.mask_off[1 + c] = w->off_present[c];
+    uint32_t nr = 0;
+    for (size_t k = 0; k < w->col_off.size(); ++k) {
+        const uint32_t wb = w->col_wb[k];
+        for (uint32_t r = 0; r < wb / 4; ++r) {
+            RowDesc& rd = p.row[nr++];
+            rd.col_off = w->col_off[k]; rd.roff = r * 4096; rd.tile_stride = TILE * wb; rd.word_bytes = wb; rd.pad = 0;
+        }
+    }
+    p.n_rows = nr;
+}
+
+uint32_t total_rows(const ggrs_world* w) {
+    uint32_t n = 0;
+    for (auto& c : w->comps) n += c.n_words * (c.word_bytes / 4);
+    return n;
+}
+
+int seal(ggrs_world* w) {
+    if (w->sealed) return GGRS_OK;
+    if (total_rows(w) > (uint32_t)MAX_ROWS) return w->fail(GGRS_E_INVALID, "too many registered words (%u rows > %d)", total_rows(w), MAX_ROWS);
+    HIPCHK(w, hipSetDevice(w->device));
+    build_layout(w);
+
+    // ---- recognise the particles fast path: [PARTICLES_UPDATE, TTL_DESPAWN] (+ optional SPAWN)
+    w->fused_ok = false; w->f_spawn = -1;
+    {
+        int upd = -1, ttl = -1, other = 0;
+        for (size_t i = 0; i < w->systems.size(); ++i) {
+            switch (w->systems[i].kind) {
+            case GGRS_SYS_PARTICLES_UPDATE: if (upd < 0) upd = (int)i; else ++other; break;
+            case GGRS_SYS_TTL_DESPAWN: if (ttl < 0) ttl = (int)i; else ++other; break;
+            case GGRS_SYS_PARTICLES_SPAWN: w->f_spawn = (int)i; break;
+            default: ++other;
+            }
+        }
+        if (upd >= 0 && ttl >= 0 && other == 0 && !(w->flags & GGRS_WORLD_UNFUSED)) {
+            const ggrs_system_desc& u = w->systems[upd]; const ggrs_system_desc& l = w->systems[ttl];
+            const Comp& T = w->comps[u.comp[0]]; const Comp& V = w->comps[u.comp[1]]; const Comp& L = w->comps[l.comp[0]];
+            if (T.word_bytes == 4 && V.word_bytes == 4 && L.word_bytes == 8 && u.word[0] + 3 <= T.n_words && u.word[1] + 3 <= V.n_words) {
+                w->fused_ok = true;
+                w->f_T = (int)u.comp[0]; w->f_V = (int)u.comp[1]; w->f_L = (int)l.comp[0];
+                w->f_tw = u.word[0]; w->f_vw = u.word[1];
+                for (int k = 0; k < 3; ++k) w->f_g[k] = u.fparam[k];
+            }
+        }
+    }
+    // ---- checksum specs
+    w->cks_comp.clear();
+    std::vector<UnitDesc> units;
+    memset(&w->cks_args, 0, sizeof w->cks_args);
+    for (uint32_t c = 0; c < w->comps.size(); ++c) {
+        Comp& cc = w->comps[c];
+        if (!cc.checksummed) continue;
+        const uint32_t k = (uint32_t)w->cks_comp.size();
+        w->cks_comp.push_back(c);
+        w->cks_args.off_present[k] = w->off_present[c];
+        w->cks_args.unit_base[k] = (uint32_t)units.size();
+        for (uint32_t wi : cc.cks_words) {
+            const uint64_t co = w->col_off[cc.col_base + wi];
+            if (cc.word_bytes == 4) units.push_back({co, 4, 0});
+            else { units.push_back({co, 8, 0}); units.push_back({co + 4, 8, 0}); }
+        }
+        w->cks_args.n_units[k] = (uint32_t)units.size() - w->cks_args.unit_base[k];
+        if (w->cks_args.n_units[k] > (uint32_t)MAX_UNITS) return w->fail(GGRS_E_INVALID, "checksum spec too long");
+    }
+    w->cks_args.n_cks = (uint32_t)w->cks_comp.size();
+    w->cks_args.off_alive = w->off_alive;
+    // does the fused step cover every spec?
+    w->fused_cks = false; w->f_cksT = w->f_cksV = false;
+    if (w->fused_ok) {
+        bool all = true;
+        for (uint32_t c : w->cks_comp) {
+            const Comp& cc = w->comps[c];
+            const uint32_t base = ((int)c == w->f_T) ? w->f_tw : w->f_vw;
+            const bool is3 = cc.cks_words.size() == 3 && cc.cks_words[0] == base && cc.cks_words[1] == base + 1 && cc.cks_words[2] == base + 2;
+            if ((int)c == w->f_T && is3 && w->f_T != w->f_V) w->f_cksT = true;
+            else if ((int)c == w->f_V && is3 && w->f_T != w->f_V) w->f_cksV = true;
+            else all = false;
+        }
+        w->fused_cks = all;
+        if (!all) w->f_cksT = w->f_cksV = false;
+    }
+
+    // ---- arena carve
+    const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
+    w->part_stride = n_tiles + 4096 / 1;            // + room for spawn partial blocks
+    const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
+    w->max_results = 1024;
+    const uint64_t res_bytes = align_up((uint64_t)w->max_results * 16, ALIGN);
+    const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
+    w->stage_floats = 1u << 20;
+    const uint64_t stage_bytes = w->stage_floats * 4;
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
+    if (w->arena) {
+        if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
+    } else {
+        HIPCHK(w, hipMalloc((void**)&w->arena, need));
+        w->arena_bytes = need; w->own_arena = true;
+    }
+    uint8_t* p = w->arena;
+    w->live.ptr = p; p += w->state_bytes;
+    w->slots.resize(w->max_depth);
+    for (uint32_t i = 0; i < w->max_depth; ++i) { w->slots[i].ptr = p; p += w->state_bytes; w->free_slots.push_back((int)(w->max_depth - 1 - i)); }
+    w->d_parts = (uint64_t*)p; p += parts_bytes;
+    w->d_results = (uint64_t*)p; p += res_bytes;
+    w->d_units = (UnitDesc*)p; p += units_bytes;
+    w->d_maskoffs = (uint64_t*)p; p += ALIGN;
+    w->d_stage = (float*)p; p += stage_bytes;
+    w->cks_args.parts = w->d_parts;
+    w->cks_args.part_cnt = w->d_parts + (uint64_t)w->cks_args.n_cks * w->part_stride;
+    w->cks_args.part_stride = w->part_stride;
+
+    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16));
+    HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
+    // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
+    // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
+    {
+        const uint64_t head = w->col_off.empty() ? w->state_bytes : w->col_off[0];
+        HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
+        for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
+    }
+    if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->sealed = true;
+    return GGRS_OK;
+}
+
+inline uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + TILE - 1) / TILE); }
+
+Header header_of(const ggrs_world* w) {
+    Header h; memset(&h, 0, sizeof h);
+    h.len = w->len; h.frame = w->frame;
+    return h;
+}
+
+int launch_copy(ggrs_world* w, const Block& src, Block& dst, uint64_t len, uint32_t cls) {
+    const uint64_t cover = std::max(std::max(src.dirty_len, dst.dirty_len), len);
+    const uint32_t g = std::max(1u, tiles_for(cover));
+    {
+        ProfScope ps(w, cls);
+        hipLaunchKernelGGL(k_copy_state, dim3(g), dim3(TPB), 0, w->stream, (const uint8_t*)src.ptr, dst.ptr, w->plan, len, header_of(w));
+    }
+    HIPCHK(w, hipGetLastError());
+    dst.dirty_len = src.dirty_len;
+    dst.len = len;
+    return GGRS_OK;
+}
+
+// Generic checksum pass over the live block -> partials
+int launch_checksum(ggrs_world* w) {
+    const uint32_t g = std::max(1u, tiles_for(w->live.dirty_len));
+    CksArgs a = w->cks_args; a.state = w->live.ptr;
+    {
+        ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+        hipLaunchKernelGGL(k_checksum, dim3(g, std::max(1u, a.n_cks)), dim3(TPB), 0, w->stream, a, (const UnitDesc*)w->d_units);
+    }
+    HIPCHK(w, hipGetLastError());
+    w->pending_valid = true; w->pending_parts = g;
+    return GGRS_OK;
+}
+
+int launch_finalize(ggrs_world* w, uint32_t result_idx) {
+    ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, w->stream, (const uint64_t*)w->d_parts,
+                       (const uint64_t*)w->cks_args.part_cnt, w->cks_args.n_cks, w->part_stride, w->pending_parts,
+                       w->len, w->d_results + 2 * (uint64_t)result_idx, (Header*)w->live.ptr);
+    HIPCHK(w, hipGetLastError());
+    return GGRS_OK;
+}
+
+// ---- ring: exact mirror of GgrsSnapshots::{push,confirm,rollback} over slot indices
+void ring_pop_front(ggrs_world* w) { w->free_slots.push_back(w->ring_slot.front()); w->ring_slot.pop_front(); w->ring_frame.pop_front(); }
+void ring_pop_back(ggrs_world* w) { w->free_slots.push_back(w->ring_slot.back()); w->ring_slot.pop_back(); w->ring_frame.pop_back(); }
+
+void ring_confirm(ggrs_world* w, int32_t confirmed) {          // mod.rs:185-202
+    while (!w->ring_frame.empty() && w->ring_frame.back() < confirmed) ring_pop_back(w);
+}
+int ring_push(ggrs_world* w, int32_t frame, int* slot_out) {    // mod.rs:147-181
+    while (!w->ring_frame.empty()) {
+        const int32_t current = w->ring_frame.front();
+        const uint32_t ad = current >= frame ? (uint32_t)current - (uint32_t)frame : (uint32_t)frame - (uint32_t)current;
+        const bool wrapped = ad > (UINT32_MAX / 2);
+        if ((current >= frame && !wrapped) || (frame >= current && wrapped)) ring_pop_front(w); else break;
+    }
+    // evict from the back first so the new slot can reuse the oldest block (same end state as
+    // push_front followed by pop_back while len > depth)
+    while (!w->ring_frame.empty() && w->ring_frame.size() + 1 > w->depth) ring_pop_back(w);
+    if (w->depth == 0) { *slot_out = -1; return GGRS_OK; }
+    if (w->free_slots.empty()) return w->fail(GGRS_E_INVALID, "ring depth %zu exceeds provisioned max_depth %u", w->depth, w->max_depth);
+    const int s = w->free_slots.back(); w->free_slots.pop_back();
+    w->ring_slot.push_front(s); w->ring_frame.push_front(frame);
+    *slot_out = s;
+    return GGRS_OK;
+}
+bool ring_rollback(ggrs_world* w, int32_t frame) {             // mod.rs:210-226
+    for (;;) {
+        if (w->ring_frame.empty()) return false;
+        if (w->ring_frame.front() != frame) ring_pop_front(w); else return true;
+    }
+}
+
+// ---- SaveWorld
+int do_save(ggrs_world* w, uint32_t result_idx) {
+    int rc = seal(w); if (rc) return rc;
+    // SaveWorldSystems::Checksum -> ChecksumPlugin::update
+    if (!w->pending_valid) { rc = launch_checksum(w); if (rc) return rc; }
+    rc = launch_finalize(w, result_idx); if (rc) return rc;
+    // SaveWorldSystems::Snapshot: sync_depth (caller) -> discard_old_snapshots -> save
+    if (w->has_confirmed) ring_confirm(w, w->confirmed);
+    int s = -1;
+    rc = ring_push(w, w->frame, &s); if (rc) return rc;
+    if (s >= 0) { rc = launch_copy(w, w->live, w->slots[s], w->len, GGRS_KERNEL_SAVE); if (rc) return rc; }
+    return GGRS_OK;
+}
+
+// ---- LoadWorld
+int do_load(ggrs_world* w, int32_t frame) {
+    int rc = seal(w); if (rc) return rc;
+    w->frame = frame;                                           // schedule_systems.rs:244-247
+    if (!ring_rollback(w, frame))
+        return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", frame);
+    Block& s = w->slots[w->ring_slot.front()];
+    // entity.rs:55-99 + component_snapshot.rs:95-123 + RollbackOrdered restore (mod.rs:342):
+    // masks, columns and len of the live block := the snapshot's
+    w->len = s.len;
+    rc = launch_copy(w, s, w->live, s.len, GGRS_KERNEL_LOAD); if (rc) return rc;
+    w->pending_valid = false;
+    return GGRS_OK;
+}
+
+// ---- spawn bookkeeping shared by the API call and the in-schedule spawn system
+int set_masks_for_range(ggrs_world* w, uint64_t first, uint64_t count, uint64_t comp_mask) {
+    if (count == 0) return GGRS_OK;
+    MaskOffs mo; uint32_t n = 0;
+    mo.off[n++] = w->off_alive;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) if ((comp_mask >> c) & 1ULL) mo.off[n++] = w->off_present[c];
+    const uint64_t words = ((first + count - 1) >> 6) - (first >> 6) + 1;
+    hipLaunchKernelGGL(k_set_mask_range, dim3((uint32_t)((words + TPB - 1) / TPB)), dim3(TPB), 0, w->stream,
+                       w->live.ptr, first, count, n, mo);
+    HIPCHK(w, hipGetLastError());
+    return GGRS_OK;
+}
+
+int fill_defaults(ggrs_world* w, uint32_t c, uint64_t first, uint64_t count) {
+    const Comp& cc = w->comps[c];
+    for (uint32_t k = 0; k < cc.n_words; ++k) {
+        uint64_t v = 0; memcpy(&v, &cc.defaults[(size_t)k * cc.word_bytes], cc.word_bytes);
+        hipLaunchKernelGGL(k_fill_col, dim3((uint32_t)((count + TPB - 1) / TPB)), dim3(TPB), 0, w->stream,
+                           w->live.ptr, w->col_off[cc.col_base + k], cc.word_bytes, first, count, v);
+    }
+    HIPCHK(w, hipGetLastError());
+    return GGRS_OK;
+}
+
+int stage_floats(ggrs_world* w, const float* src, uint64_t n, float** dev_out) {
+    if (n > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of %llu floats exceeds the staging buffer", (unsigned long long)n);
+    if (w->stage_used + n > w->stage_floats) { HIPCHK(w, hipStreamSynchronize(w->stream)); w->stage_used = 0; }
+    memcpy(w->h_stage + w->stage_used, src, n * 4);
+    HIPCHK(w, hipMemcpyAsync(w->d_stage + w->stage_used, w->h_stage + w->stage_used, n * 4, hipMemcpyHostToDevice, w->stream));
+    *dev_out = w->d_stage + w->stage_used;
+    w->stage_used += n;
+    return GGRS_OK;
+}
+
+uint32_t dt_bits_for_frame(uint64_t fps, int32_t frame) {
+    // GgrsTimePlugin::update (time.rs:63-87): runtime = frame * 1e9 / fps ns; the clock's previous
+    // elapsed is runtime(frame-1) (restored by its own snapshot on load, time.rs:111), and
+    // Time::delta_secs = Duration::as_secs_f32 = secs as f32 + nanos as f32 / 1e9 as f32.
+    const uint64_t f = (uint64_t)(int64_t)frame;
+    const uint64_t d = f * 1000000000ULL / fps - (f - 1) * 1000000000ULL / fps;
+    const uint64_t secs = d / 1000000000ULL; const uint32_t nanos = (uint32_t)(d % 1000000000ULL);
+    volatile float a = (float)secs;
+    volatile float b = (float)nanos / (float)1000000000u;
+    const float r = a + b;
+    uint32_t bits; memcpy(&bits, &r, 4);
+    return bits;
+}
+
+template <bool CT, bool CV>
+void launch_step_fused(ggrs_world* w, const StepArgs& a, uint32_t g) {
+    hipLaunchKernelGGL((k_particles_step<true, true, CT, CV>), dim3(g), dim3(TPB), 0, w->stream, a);
+}
+
+// ---- AdvanceWorld
+int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
+               uint64_t spawn_count, const float* spawn_vx, const float* spawn_vy) {
+    int rc = seal(w); if (rc) return rc;
+    w->frame += 1;                                              // schedule_systems.rs:254-259
+    if (dt_bits == 0) dt_bits = dt_bits_for_frame(w->fps, w->frame);
+    const uint32_t g = tiles_for(w->len);
+    const uint32_t n_cks = w->cks_args.n_cks;
+    uint64_t* part_cnt = w->cks_args.part_cnt;
+    w->pending_valid = false;
+
+    auto step_args = [&](const ggrs_system_desc* upd, const ggrs_system_desc* ttl) {
+        StepArgs a; memset(&a, 0, sizeof a);
+        a.state = w->live.ptr; a.off_alive = w->off_alive; a.dt_bits = dt_bits;
+        if (upd) {
+            const Comp& T = w->comps[upd->comp[0]]; const Comp& V = w->comps[upd->comp[1]];
+            a.off_pT = w->off_present[upd->comp[0]]; a.off_pV = w->off_present[upd->comp[1]];
+            for (int k = 0; k < 3; ++k) {
+                a.off_t[k] = w->col_off[T.col_base + upd->word[0] + k];
+                a.off_v[k] = w->col_off[V.col_base + upd->word[1] + k];
+                a.g[k] = upd->fparam[k];
+            }
+        }
+        if (ttl) {
+            const Comp& L = w->comps[ttl->comp[0]];
+            a.off_pL = w->off_present[ttl->comp[0]];
+            a.off_ttl = w->col_off[L.col_base + ttl->word[0]];
+        }
+        return a;
+    };
+
+    if (g > 0) {
+        if (w->fused_ok) {
+            const ggrs_system_desc *upd = nullptr, *ttl = nullptr;
+            for (auto& s : w->systems) { if (s.kind == GGRS_SYS_PARTICLES_UPDATE) upd = &s; if (s.kind == GGRS_SYS_TTL_DESPAWN) ttl = &s; }
+            StepArgs a = step_args(upd, ttl);
+            // partial columns in checksum-spec order
+            for (uint32_t k = 0; k < n_cks; ++k) {
+                if ((int)w->cks_comp[k] == w->f_T) a.part_T = w->d_parts + (uint64_t)k * w->part_stride;
+                if ((int)w->cks_comp[k] == w->f_V) a.part_V = w->d_parts + (uint64_t)k * w->part_stride;
+            }
+            a.part_cnt = part_cnt;
+            ProfScope ps(w, GGRS_KERNEL_ADVANCE);
+            const bool ck = w->fused_cks;
+            if (ck && w->f_cksT && w->f_cksV) launch_step_fused<true, true>(w, a, g);
+            else if (ck && w->f_cksT) launch_step_fused<true, false>(w, a, g);
+            else if (ck && w->f_cksV) launch_step_fused<false, true>(w, a, g);
+            else if (ck) {   // no component checksums at all: still produce the live count
+                hipLaunchKernelGGL((k_particles_step<true, true, false, false>), dim3(g), dim3(TPB), 0, w->stream, a);
+            } else hipLaunchKernelGGL((k_particles_step<true, true, false, false>), dim3(g), dim3(TPB), 0, w->stream, a);
+            if (ck && (w->f_cksT || w->f_cksV)) { w->pending_valid = true; w->pending_parts = g; }
+        } else {
+            for (auto& s : w->systems) {
+                ProfScope ps(w, GGRS_KERNEL_ADVANCE);
+                switch (s.kind) {
+                case GGRS_SYS_PARTICLES_UPDATE: {
+                    StepArgs a = step_args(&s, nullptr);
+                    hipLaunchKernelGGL((k_particles_step<true, false, false, false>), dim3(g), dim3(TPB), 0, w->stream, a);
+                } break;
+                case GGRS_SYS_TTL_DESPAWN: {
+                    StepArgs a = step_args(nullptr, &s);
+                    hipLaunchKernelGGL((k_particles_step<false, true, false, false>), dim3(g), dim3(TPB), 0, w->stream, a);
+                } break;
+                case GGRS_SYS_ADD_U32: {
+                    const Comp& C = w->comps[s.comp[0]];
+                    hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((w->len + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, w->live.ptr,
+                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], w->len);
+                } break;
+                case GGRS_SYS_SAT_SUB_DESPAWN: {
+                    const Comp& C = w->comps[s.comp[0]];
+                    const uint64_t lp = align_up(w->len, 64);
+                    hipLaunchKernelGGL(k_sat_sub_despawn, dim3((uint32_t)((lp + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, w->live.ptr,
+                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp);
+                } break;
+                default: break;
+                }
+            }
+        }
+        HIPCHK(w, hipGetLastError());
+    }
+
+    // Commands are deferred: spawns materialise after every system of the frame ran (set.rs:118-134)
+    for (auto& s : w->systems) {
+        if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
+        bool pressed = false;                                   // spawn_pressed, particles.rs:254-256
+        for (uint32_t k = 0; k < n_inputs; ++k) pressed |= (inputs[k] & (uint8_t)s.iparam[1]) != 0;
+        if (!pressed || spawn_count == 0) continue;
+        if (w->len + spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)spawn_count, (unsigned long long)w->capacity);
+        const uint32_t cT = s.comp[0], cV = s.comp[1], cL = s.comp[2];
+        const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
+        const uint64_t first = w->len;
+        float *dvx = nullptr, *dvy = nullptr;
+        rc = stage_floats(w, spawn_vx, spawn_count, &dvx); if (rc) return rc;
+        rc = stage_floats(w, spawn_vy, spawn_count, &dvy); if (rc) return rc;
+        rc = fill_defaults(w, cT, first, spawn_count); if (rc) return rc;
+        SpawnArgs a; memset(&a, 0, sizeof a);
+        a.state = w->live.ptr;
+        for (int k = 0; k < 3; ++k) {
+            a.off_t[k] = w->col_off[T.col_base + k]; a.off_v[k] = w->col_off[V.col_base + k];
+            memcpy(&a.t_default[k], &T.defaults[(size_t)(w->fused_ok ? w->f_tw + k : k) * 4], 4);
+        }
+        a.off_ttl = w->col_off[L.col_base + 0];
+        a.vx = dvx; a.vy = dvy; a.first = first; a.count = spawn_count; a.ttl = (uint64_t)s.iparam[0];
+        const uint32_t gs = (uint32_t)((spawn_count + TPB - 1) / TPB);
+        const bool keep = w->pending_valid && (w->pending_parts + gs <= w->part_stride);
+        // partial slots appended after the step's (scratch at the tail when partials are not kept)
+        const uint32_t pbase = keep ? w->pending_parts : (w->part_stride - std::min(gs, w->part_stride));
+        uint64_t* scratch = w->d_parts;   // column 0 exists whenever n_cks > 0; else counts column
+        a.part_T = a.part_V = (n_cks ? scratch : part_cnt) + pbase;
+        a.cks_T = a.cks_V = 0;
+        if (keep) {
+            for (uint32_t k = 0; k < n_cks; ++k) {
+                if ((int)w->cks_comp[k] == w->f_T && w->f_cksT) { a.part_T = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_T = 1; }
+                if ((int)w->cks_comp[k] == w->f_V && w->f_cksV) { a.part_V = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_V = 1; }
+            }
+        }
+        a.part_cnt = part_cnt + pbase;
+        if (gs > w->part_stride) return w->fail(GGRS_E_CAPACITY, "spawn too large for partial buffer");
+        hipLaunchKernelGGL(k_spawn_particles, dim3(gs), dim3(TPB), 0, w->stream, a);
+        HIPCHK(w, hipGetLastError());
+        rc = set_masks_for_range(w, first, spawn_count, (1ULL << cT) | (1ULL << cV) | (1ULL << cL)); if (rc) return rc;
+        w->len += spawn_count;
+        w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+        if (keep) w->pending_parts += gs; else w->pending_valid = false;
+    }
+    return GGRS_OK;
+}
+
+int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
+    if (n_results) HIPCHK(w, hipMemcpyAsync(w->h_results, w->d_results, (size_t)n_results * 16, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->stage_used = 0;
+    if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
+    return GGRS_OK;
+}
+
+void apply_synctest_confirmed(ggrs_world* w) {
+    // handle_requests, schedule_systems.rs:204-220: SyncTest => current_frame - check_distance, if >= 0
+    if (w->synctest_cd < 0) return;
+    const int32_t c = w->frame - w->synctest_cd;
+    if (c >= 0) { w->has_confirmed = true; w->confirmed = c; }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int ggrs_hip_abi_version(void) { return GGRS_HIP_ABI_VERSION; }
+
+int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
+    if (!d || !out || d->capacity == 0) return GGRS_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || d->device >= n) return GGRS_E_NO_DEVICE;
+    if (hipSetDevice(d->device) != hipSuccess) return GGRS_E_NO_DEVICE;
+    ggrs_world* w = new ggrs_world();
+    w->device = d->device; w->capacity = d->capacity; w->cap_pad = align_up(d->capacity, TILE);
+    w->max_depth = d->max_depth ? d->max_depth : 8; w->flags = d->flags;
+    w->depth = w->max_depth;
+    if (d->stream) w->stream = (hipStream_t)d->stream;
+    else {
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return GGRS_E_HIP; }
+        w->own_stream = true;
+    }
+    if (d->arena && d->arena_bytes) { w->arena = (uint8_t*)d->arena; w->arena_bytes = d->arena_bytes; }
+    *out = w;
+    return GGRS_OK;
+}
+int ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggrs_world** out) {
+    ggrs_world_desc d; memset(&d, 0, sizeof d);
+    d.device = device; d.capacity = capacity; d.max_depth = max_depth;
+    return ggrs_hip_world_create_ex(&d, out);
+}
+uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_components, uint32_t bytes_per_slot) {
+    const uint64_t cap_pad = align_up(capacity, TILE);
+    const uint64_t mask = align_up(cap_pad / 8, ALIGN);
+    // each 4-byte word column is 256-B aligned; bytes_per_slot/4 bounds the column count
+    const uint64_t state = align_up(ALIGN + (1 + (uint64_t)n_components) * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
+    const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN);
+    return (uint64_t)(max_depth + 1) * state + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+}
+void ggrs_hip_world_destroy(ggrs_world* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (w->h_results) (void)hipHostFree(w->h_results);
+    if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->own_arena && w->arena) (void)hipFree(w->arena);
+    if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+const char* ggrs_hip_last_error(ggrs_world* w) { return w ? w->err.c_str() : "null world"; }
+
+int ggrs_hip_register_component(ggrs_world* w, const char* name, uint32_t word_bytes, uint32_t n_words, uint32_t* comp_id) {
+    if (!w || !name) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "register_component after the world was sealed");
+    if (w->comps.size() >= GGRS_MAX_COMPONENTS || n_words == 0 || n_words > GGRS_MAX_WORDS || (word_bytes != 4 && word_bytes != 8))
+        return w->fail(GGRS_E_INVALID, "bad component shape");
+    Comp c; c.name = name; c.word_bytes = word_bytes; c.n_words = n_words;
+    c.defaults.assign((size_t)word_bytes * n_words, 0);
+    w->comps.push_back(c);
+    if (comp_id) *comp_id = (uint32_t)w->comps.size() - 1;
+    return GGRS_OK;
+}
+int ggrs_hip_set_component_default(ggrs_world* w, uint32_t c, const void* words) {
+    if (!w || c >= w->comps.size() || !words) return GGRS_E_INVALID;
+    memcpy(w->comps[c].defaults.data(), words, w->comps[c].defaults.size());
+    return GGRS_OK;
+}
+int ggrs_hip_checksum_component(ggrs_world* w, uint32_t c, const uint32_t* word_idx, uint32_t n) {
+    if (!w || c >= w->comps.size()) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "checksum_component after the world was sealed");
+    Comp& cc = w->comps[c];
+    cc.cks_words.clear();
+    for (uint32_t k = 0; k < n; ++k) { if (word_idx[k] >= cc.n_words) return w->fail(GGRS_E_INVALID, "word index out of range"); cc.cks_words.push_back(word_idx[k]); }
+    if (n * (cc.word_bytes / 4) > GGRS_MAX_CKS_UNITS) return w->fail(GGRS_E_INVALID, "checksum spec too long");
+    cc.checksummed = true;
+    return GGRS_OK;
+}
+int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* d) {
+    if (!w || !d) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "add_system after the world was sealed");
+    if (w->systems.size() >= GGRS_MAX_SYSTEMS) return w->fail(GGRS_E_INVALID, "too many systems");
+    const uint32_t nc = (uint32_t)w->comps.size();
+    auto comp_ok = [&](uint32_t c, uint32_t wb, uint32_t word, uint32_t span) { return c < nc && w->comps[c].word_bytes == wb && word + span <= w->comps[c].n_words; };
+    bool ok = false;
+    switch (d->kind) {
+    case GGRS_SYS_PARTICLES_UPDATE: ok = comp_ok(d->comp[0], 4, d->word[0], 3) && comp_ok(d->comp[1], 4, d->word[1], 3); break;
+    case GGRS_SYS_TTL_DESPAWN: ok = comp_ok(d->comp[0], 8, d->word[0], 1); break;
+    case GGRS_SYS_PARTICLES_SPAWN: ok = comp_ok(d->comp[0], 4, 0, 3) && comp_ok(d->comp[1], 4, 0, 3) && comp_ok(d->comp[2], 8, 0, 1); break;
+    case GGRS_SYS_ADD_U32: case GGRS_SYS_SAT_SUB_DESPAWN: ok = comp_ok(d->comp[0], 4, d->word[0], 1); break;
+    default: ok = false;
+    }
+    if (!ok) return w->fail(GGRS_E_INVALID, "system %u does not match the registered components", d->kind);
+    w->systems.push_back(*d);
+    return GGRS_OK;
+}
+int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
+
+int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (w->len + count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)w->capacity);
+    const uint64_t first = w->len;
+    if (first_slot) *first_slot = first;
+    if (count == 0) return GGRS_OK;
+    uint32_t ci = 0;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) {
+        if (!((comp_mask >> c) & 1ULL)) continue;
+        const Comp& cc = w->comps[c];
+        bool any_null = false;
+        for (uint32_t k = 0; k < cc.n_words; ++k) if (!cols || !cols[ci + k]) any_null = true;
+        if (any_null) { rc = fill_defaults(w, c, first, count); if (rc) return rc; }
+        for (uint32_t k = 0; k < cc.n_words; ++k) {
+            const void* src = cols ? cols[ci + k] : nullptr;
+            if (src) HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + k] + first * cc.word_bytes, src, (size_t)count * cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+        }
+        ci += cc.n_words;
+    }
+    rc = set_masks_for_range(w, first, count, comp_mask); if (rc) return rc;
+    w->len += count;
+    w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+    w->pending_valid = false;
+    HIPCHK(w, hipStreamSynchronize(w->stream));     // host buffers may be freed on return
+    return GGRS_OK;
+}
+int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
+    hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_alive, slot, 0);
+    HIPCHK(w, hipGetLastError());
+    w->pending_valid = false;
+    return GGRS_OK;
+}
+int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const void* words) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size() || slot >= w->len || !words) return w->fail(GGRS_E_INVALID, "bad insert_component arguments");
+    const Comp& cc = w->comps[c];
+    for (uint32_t k = 0; k < cc.n_words; ++k)
+        HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + k] + slot * cc.word_bytes, (const uint8_t*)words + (size_t)k * cc.word_bytes, cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+    hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 1);
+    HIPCHK(w, hipGetLastError());
+    w->pending_valid = false;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return GGRS_OK;
+}
+int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size() || slot >= w->len) return w->fail(GGRS_E_INVALID, "bad remove_component arguments");
+    hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 0);
+    HIPCHK(w, hipGetLastError());
+    w->pending_valid = false;
+    return GGRS_OK;
+}
+int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, const void* src) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
+    const Comp& cc = w->comps[c];
+    HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + word] + first * cc.word_bytes, src, (size_t)count * cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->pending_valid = false;
+    return GGRS_OK;
+}
+int ggrs_hip_download_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, void* dst) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !dst) return w->fail(GGRS_E_INVALID, "bad download_word arguments");
+    const Comp& cc = w->comps[c];
+    HIPCHK(w, hipMemcpyAsync(dst, w->live.ptr + w->col_off[cc.col_base + word] + first * cc.word_bytes, (size_t)count * cc.word_bytes, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return GGRS_OK;
+}
+static int download_mask(ggrs_world* w, uint64_t off, uint64_t* dst, uint64_t n) {
+    const uint64_t have = w->cap_pad / 64;
+    const uint64_t m = n < have ? n : have;
+    HIPCHK(w, hipMemcpyAsync(dst, w->live.ptr + off, m * 8, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (uint64_t k = m; k < n; ++k) dst[k] = 0;
+    return GGRS_OK;
+}
+int ggrs_hip_download_alive(ggrs_world* w, uint64_t* dst, uint64_t n) {
+    if (!w || !dst) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    return download_mask(w, w->off_alive, dst, n);
+}
+int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t n) {
+    if (!w || !dst) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size()) return w->fail(GGRS_E_INVALID, "bad component");
+    return download_mask(w, w->off_present[c], dst, n);
+}
+int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p) {
+    if (!w || !p) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (c >= w->comps.size() || word >= w->comps[c].n_words) return w->fail(GGRS_E_INVALID, "bad column");
+    *p = w->live.ptr + w->col_off[w->comps[c].col_base + word];
+    return GGRS_OK;
+}
+uint64_t ggrs_hip_len(ggrs_world* w) { return w ? w->len : 0; }
+int ggrs_hip_active_count(ggrs_world* w, uint64_t* out) {
+    if (!w || !out) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    const uint64_t n = (w->live.dirty_len + 63) / 64;
+    std::vector<uint64_t> m(n ? n : 1, 0);
+    if (n) { rc = download_mask(w, w->off_alive, m.data(), n); if (rc) return rc; }
+    uint64_t a = 0; for (uint64_t k = 0; k < n; ++k) a += (uint64_t)__builtin_popcountll(m[k]);
+    *out = a;
+    return GGRS_OK;
+}
+
+int32_t ggrs_hip_frame(ggrs_world* w) { return w ? w->frame : 0; }
+int ggrs_hip_set_frame(ggrs_world* w, int32_t f) { if (!w) return GGRS_E_INVALID; w->frame = f; return GGRS_OK; }
+int ggrs_hip_set_depth(ggrs_world* w, uint32_t d) {
+    if (!w) return GGRS_E_INVALID;
+    if (d > w->max_depth) return w->fail(GGRS_E_INVALID, "depth %u exceeds provisioned max_depth %u", d, w->max_depth);
+    w->depth = d;
+    return GGRS_OK;
+}
+int ggrs_hip_set_confirmed(ggrs_world* w, int has, int32_t f) { if (!w) return GGRS_E_INVALID; w->has_confirmed = has != 0; w->confirmed = f; return GGRS_OK; }
+int ggrs_hip_has_snapshot(ggrs_world* w, int32_t f) {
+    if (!w) return 0;
+    for (int32_t x : w->ring_frame) if (x == f) return 1;
+    return 0;
+}
+uint64_t ggrs_hip_snapshot_count(ggrs_world* w) { return w ? w->ring_frame.size() : 0; }
+int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t cd) { if (!w) return GGRS_E_INVALID; w->synctest_cd = cd; return GGRS_OK; }
+
+int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = do_save(w, 0); if (rc) return rc;
+    return read_back(w, 1, out);
+}
+int ggrs_hip_load(ggrs_world* w, int32_t frame) { return w ? do_load(w, frame) : GGRS_E_INVALID; }
+int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
+                     uint64_t spawn_count, const float* vx, const float* vy) {
+    return w ? do_advance(w, dt_bits, inputs, n_inputs, spawn_count, vx, vy) : GGRS_E_INVALID;
+}
+
+int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
+    if (!w || (!reqs && n)) return GGRS_E_INVALID;
+    uint32_t ns = 0;
+    int rc = GGRS_OK;
+    for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
+        const ggrs_request& r = reqs[i];
+        apply_synctest_confirmed(w);
+        switch (r.kind) {
+        case GGRS_REQ_SAVE:
+            if (ns >= w->max_results && w->sealed) {      // flush a full result page
+                rc = read_back(w, ns, checksums_out); if (rc) break;
+                checksums_out += 2 * (uint64_t)ns; ns = 0;
+            }
+            rc = do_save(w, ns); ++ns; break;
+        case GGRS_REQ_LOAD: rc = do_load(w, r.frame); break;
+        case GGRS_REQ_ADVANCE: rc = do_advance(w, r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy); break;
+        default: rc = w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+        }
+    }
+    if (rc) { if (w->stream) (void)hipStreamSynchronize(w->stream); return rc; }
+    return read_back(w, ns, checksums_out);
+}
+int ggrs_hip_synchronize(ggrs_world* w) {
+    if (!w) return GGRS_E_INVALID;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return GGRS_OK;
+}
+
+uint64_t ggrs_hip_state_bytes(ggrs_world* w) { if (!w || seal(w)) return 0; return w->state_bytes; }
+int ggrs_hip_live_state_ptr(ggrs_world* w, void** p) {
+    if (!w || !p) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    // keep the header current so an exported block is self-describing
+    Header h = header_of(w);
+    HIPCHK(w, hipMemcpyAsync(w->live.ptr, &h, 16, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    *p = w->live.ptr;
+    return GGRS_OK;
+}
+int ggrs_hip_adopt_live_state(ggrs_world* w) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    Header h;
+    HIPCHK(w, hipMemcpyAsync(&h, w->live.ptr, sizeof h, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    if (h.len > w->capacity) return w->fail(GGRS_E_INVALID, "adopted state has len %llu > capacity", (unsigned long long)h.len);
+    w->len = h.len; w->frame = h.frame;
+    w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+    w->pending_valid = false;
+    return GGRS_OK;
+}
+
+int ggrs_hip_profile_enable(ggrs_world* w, int on) {
+    if (!w) return GGRS_E_INVALID;
+    w->prof = on != 0;
+    if (on) { for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } w->prof_events.clear();
+              for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; } }
+    return GGRS_OK;
+}
+int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out) {
+    if (!w || !ms_out || !launches_out) return GGRS_E_INVALID;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (auto& e : w->prof_events) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);
+        w->prof_ms[e.cls] += ms; w->prof_n[e.cls] += 1;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    w->prof_events.clear();
+    for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { ms_out[i] = w->prof_ms[i]; launches_out[i] = w->prof_n[i]; }
+    return GGRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,489 @@
+// kernels.hpp -- gfx950 (CDNA4, wave64) device code of the rollback re-simulation engine.
+//
+// Everything here is HBM-bound element-wise integer/f32 work over SoA word columns: no MFMA
+// (there is no contraction anywhere on this path).  Design rules applied:
+//   * one workgroup (256 threads = 4 waves) owns one TILE of 1024 consecutive slots in EVERY
+//     kernel, and tile t is always blockIdx t.  Workgroup b lands on XCD b % 8, so the same
+//     XCD (and its private 4 MiB L2) touches the same slots in load -> advance -> save chains;
+//   * every column access is 16 B per lane (dwordx4), 1 KiB per wave instruction, all loads
+//     of a tile issued before the first store;
+//   * Rollback-entity liveness is a 1 bit/slot mask; despawn masks are built with wave64
+//     __ballot and a scalar bit-interleave, live counts with popcount;
+//   * f32 integration uses explicit __fmul_rn/__fadd_rn: Rust never contracts a*b+c, and the
+//     checksum hashes the raw f32 bits, so results must be bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ggrs {
+
+constexpr int TILE = 1024;     // slots per workgroup
+constexpr int TPB = 256;       // threads per workgroup (4 waves of 64)
+constexpr int MAX_ROWS = 96;   // 4 KiB copy rows per tile (a 4-byte column = 1 row, 8-byte = 2)
+constexpr int MAX_MASKS = 17;  // alive + one presence mask per component
+constexpr int MAX_UNITS = 32;
+
+// ------------------------------------------------------------------ SeaHash (seahash 4.1)
+// Reference call sites: snapshot/mod.rs:318-320, component_checksum.rs:77-95,
+// entity_checksum.rs:35-43.  Arithmetic restated from the crate's published algorithm.
+constexpr uint64_t SEA_P = 0x6eed0e9da4d94a4fULL;
+constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cULL,
+                   SEA_K2 = 0x6fe2e5aaf078ebc9ULL, SEA_K3 = 0x14f994a4c5259381ULL;
+
+__host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) {
+    x *= SEA_P;
+    x ^= (x >> 32) >> (x >> 60);
+    x *= SEA_P;
+    return x;
+}
+// SeaHasher::new(); write_u32(x); write_u32(y); write_u32(z); finish()  (12 bytes: one full
+// word + a 4-byte tail) -- particles.rs:107-120 / 207-222.
+__host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, uint32_t z) {
+    uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32)));
+    uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z);
+    return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL);
+}
+// SeaHasher::new(); write_u64(order); write_u64(inner); finish()  -- component_checksum.rs:81-90
+__host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) {
+    uint64_t B = sea_diffuse(SEA_K0 ^ order);
+    uint64_t C = sea_diffuse(SEA_K1 ^ inner);
+    return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL);
+}
+// SeaHasher::new(); write_u64(x); finish()  -- component_checksum.rs:92-95
+__host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) {
+    uint64_t A = sea_diffuse(SEA_K0 ^ x);
+    return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL);
+}
+// generic stream over n u32 units (all writes on this path are multiples of 4 bytes)
+struct SeaStream {
+    uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0;
+    uint32_t lo = 0; bool have_lo = false;
+    __host__ __device__ __forceinline__ void unit(uint32_t u) {
+        if (!have_lo) { lo = u; have_lo = true; return; }
+        uint64_t a = sea_diffuse(s0 ^ ((uint64_t)lo | ((uint64_t)u << 32)));
+        s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; have_lo = false;
+    }
+    __host__ __device__ __forceinline__ uint64_t finish() const {
+        uint64_t a = have_lo ? sea_diffuse(s0 ^ (uint64_t)lo) : s0;
+        return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + (have_lo ? 4ULL : 0ULL)));
+    }
+};
+
+// ------------------------------------------------------------------ kernel argument blocks
+struct RowDesc {          // one 4 KiB-per-tile copy row of the packed state block
+    uint64_t col_off;     // byte offset of the column inside the state block
+    uint32_t roff;        // byte offset of this row inside the column's tile (0 or 4096)
+    uint32_t tile_stride; // bytes one tile of this column spans (TILE * word_bytes)
+    uint32_t word_bytes;
+    uint32_t pad;
+};
+struct CopyPlan {
+    uint32_t n_rows, n_masks;
+    uint64_t mask_off[MAX_MASKS];
+    RowDesc row[MAX_ROWS];
+};
+struct Header {           // first 256 B of every packed state block
+    uint64_t len;         // RollbackOrdered::len -- slots ever spawned
+    int32_t frame;        // RollbackFrameCount the block was saved at
+    uint32_t pad0;
+    uint64_t active;      // live Rollback entities (filled by k_finalize)
+    uint64_t checksum[2];
+};
+
+struct StepArgs {         // fused GgrsSchedule step of the particles workload
+    uint8_t* state;
+    uint64_t off_alive, off_pT, off_pV, off_pL;
+    uint64_t off_t[3], off_v[3], off_ttl;
+    uint32_t dt_bits; float g[3];
+    uint64_t* part_T; uint64_t* part_V; uint64_t* part_cnt;
+};
+
+struct UnitDesc { uint64_t off; uint32_t stride; uint32_t pad; };
+struct CksArgs {          // generic component checksum
+    const uint8_t* state;
+    uint64_t off_alive;
+    uint32_t n_cks; uint32_t part_stride;
+    uint64_t off_present[16];
+    uint32_t n_units[16];
+    uint32_t unit_base[16];
+    uint64_t* parts;      // [n_cks][part_stride]
+    uint64_t* part_cnt;   // [part_stride]
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint64_t wave_xor(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o, 64);
+    return v;
+}
+// bit i of x (16 bits) -> bit 4*i
+__device__ __forceinline__ uint64_t spread4(uint64_t x) {
+    x &= 0xFFFFULL;
+    x = (x | (x << 24)) & 0x000000FF000000FFULL;
+    x = (x | (x << 12)) & 0x000F000F000F000FULL;
+    x = (x | (x << 6)) & 0x0303030303030303ULL;
+    x = (x | (x << 3)) & 0x1111111111111111ULL;
+    return x;
+}
+
+// ------------------------------------------------------------------ k_copy_state
+// SaveWorld's Snapshot set (component_snapshot.rs:66-84, entity.rs:39-51, ring push
+// mod.rs:147-181) and LoadWorld's Entity+Data sets (entity.rs:55-99,
+// component_snapshot.rs:95-123, ring rollback mod.rs:210-226) both reduce to: copy every
+// registered word column over [0, len) plus the liveness/presence masks between the live
+// block and a ring slot.  Algorithmic traffic: 2 x (bytes per slot) per entity.
+__global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ src,
+                                                    uint8_t* __restrict__ dst, CopyPlan plan,
+                                                    uint64_t len, Header hdr) {
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    constexpr int B = 8;
+    for (uint32_t r0 = 0; r0 < plan.n_rows; r0 += B) {
+        uint4 v[B];
+        bool ok[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            ok[j] = false;
+            if (r0 + j < plan.n_rows) {
+                const RowDesc rd = plan.row[r0 + j];
+                const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+                ok[j] = pos < len * rd.word_bytes;
+                if (ok[j]) v[j] = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (ok[j]) {
+                const RowDesc rd = plan.row[r0 + j];
+                const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+                *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = v[j];
+            }
+        }
+    }
+    // masks: 16 u64 words per tile per mask (copied whole, so stale bits beyond the source's
+    // len are cleared in the destination)
+    if (tid < 16u * plan.n_masks) {
+        const uint32_t m = tid >> 4, wi = tid & 15u;
+        const uint64_t o = plan.mask_off[m] + ((uint64_t)t * 16 + wi) * 8;
+        *reinterpret_cast<uint64_t*>(dst + o) = *reinterpret_cast<const uint64_t*>(src + o);
+    }
+    if (t == 0 && tid == 0) *reinterpret_cast<Header*>(dst) = hdr;
+}
+
+// ------------------------------------------------------------------ k_particles_step
+// The GgrsSchedule of examples/stress_tests/particles.rs:233-240 as one pass:
+//   update_particles  (particles.rs:272-280)  v += g*dt ; x += v*dt     (unfused mul, add)
+//   despawn_particles (particles.rs:282-289)  ttl -= 1 ; ttl == 0 -> despawn
+// and, because translation and velocity are already in registers, the per-entity part of
+// ComponentChecksumPlugin::update (component_checksum.rs:77-90) for the NEXT SaveWorld:
+// per-workgroup XOR partials + live count, folded later by k_finalize.
+// Algorithmic traffic: 64 B per live entity (12+12+8 read, same written).
+template <bool UPD, bool TTL, bool CKS_T, bool CKS_V>
+__global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;     // first of this lane's 4 slots
+    const uint64_t w0 = (uint64_t)t * 16 + wave * 4;                 // first mask word of this wave
+    const uint32_t sh = (lane & 15u) * 4;
+    const uint64_t wi = w0 + (lane >> 4);
+
+    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.state + a.off_alive + wi * 8);
+    const uint32_t n_alive = (uint32_t)(alive_w >> sh) & 0xFu;
+    uint32_t n_T = 0, n_V = 0, n_L = 0;
+    if (UPD || CKS_T) n_T = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pT + wi * 8) >> sh) & 0xFu;
+    if (UPD || CKS_V) n_V = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pV + wi * 8) >> sh) & 0xFu;
+    if (TTL) n_L = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pL + wi * 8) >> sh) & 0xFu;
+
+    const uint32_t m_upd = UPD ? (n_alive & n_T & n_V) : 0u;   // Query<(&mut Transform,&mut Velocity)>
+    const uint32_t m_ttl = TTL ? (n_alive & n_L) : 0u;         // Query<(Entity,&mut Ttl)>
+    const uint32_t need_T = m_upd | (CKS_T ? (n_alive & n_T) : 0u);
+    const uint32_t need_V = m_upd | (CKS_V ? (n_alive & n_V) : 0u);
+
+    float4 tx[3], vv[3];
+    ulonglong2 tl[2];
+    // ---- issue every load of the tile before the first dependent use
+    if (need_T) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.state + a.off_t[k] + e0 * 4);
+    }
+    if (need_V) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.state + a.off_v[k] + e0 * 4);
+    }
+    if (m_ttl) {
+        tl[0] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8);
+        tl[1] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16);
+    }
+
+    // ---- update_particles
+    if (m_upd) {
+        const float dt = __uint_as_float(a.dt_bits);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gd = __fmul_rn(a.g[k], dt);           // gravity * time_step
+            float* x = reinterpret_cast<float*>(&tx[k]);
+            float* v = reinterpret_cast<float*>(&vv[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((m_upd >> j) & 1u) {
+                    const float nv = __fadd_rn(v[j], gd);             // **velocity += ...
+                    v[j] = nv;
+                    x[j] = __fadd_rn(x[j], __fmul_rn(nv, dt));        // translation += **velocity * time_step
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            *reinterpret_cast<float4*>(a.state + a.off_t[k] + e0 * 4) = tx[k];
+            *reinterpret_cast<float4*>(a.state + a.off_v[k] + e0 * 4) = vv[k];
+        }
+    }
+
+    // ---- despawn_particles
+    uint32_t kill = 0;
+    if (m_ttl) {
+        uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((m_ttl >> j) & 1u) {
+                q[j] -= 1;                                   // usize, wrapping
+                if (q[j] == 0) kill |= 1u << j;
+            }
+        }
+        *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8) = tl[0];
+        *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16) = tl[1];
+    }
+    const uint32_t n_new = n_alive & ~kill;
+
+    // ---- new liveness words for this wave's 256 slots: 4 ballots + scalar bit-interleave
+    uint32_t cnt = 0;
+    if (TTL) {
+        const uint64_t b0 = __ballot((n_new >> 0) & 1u), b1 = __ballot((n_new >> 1) & 1u),
+                       b2 = __ballot((n_new >> 2) & 1u), b3 = __ballot((n_new >> 3) & 1u);
+        const bool any_kill = __ballot(kill != 0) != 0;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+            cnt += (uint32_t)__popcll(nw);
+            if (lane == (uint32_t)w) mine = nw;
+        }
+        if (any_kill && lane < 4)
+            *reinterpret_cast<uint64_t*>(a.state + a.off_alive + (w0 + lane) * 8) = mine;
+    } else if (CKS_T || CKS_V) {
+        cnt = (uint32_t)__popcll(__ballot(n_new & 1u)) + (uint32_t)__popcll(__ballot(n_new & 2u)) +
+              (uint32_t)__popcll(__ballot(n_new & 4u)) + (uint32_t)__popcll(__ballot(n_new & 8u));
+    }
+
+    // ---- checksum partials of the post-step state
+    if (CKS_T || CKS_V) {
+        uint64_t hT = 0, hV = 0;
+        const uint32_t c_T = CKS_T ? (n_new & n_T) : 0u, c_V = CKS_V ? (n_new & n_V) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t order = e0 + j;                   // RollbackOrdered::order == slot
+            if ((c_T >> j) & 1u)
+                hT ^= sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                 __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                 __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+            if ((c_V >> j) & 1u)
+                hV ^= sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                 __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                 __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+        }
+        __shared__ uint64_t sT[4], sV[4];
+        __shared__ uint32_t sC[4];
+        if (CKS_T) hT = wave_xor(hT);
+        if (CKS_V) hV = wave_xor(hV);
+        if (lane == 0) { sT[wave] = hT; sV[wave] = hV; sC[wave] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            if (CKS_T) a.part_T[t] = sT[0] ^ sT[1] ^ sT[2] ^ sT[3];
+            if (CKS_V) a.part_V[t] = sV[0] ^ sV[1] ^ sV[2] ^ sV[3];
+            a.part_cnt[t] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_checksum (generic)
+// ComponentChecksumPlugin::update (component_checksum.rs:67-108) for any registered spec,
+// plus the live count EntityChecksumPlugin needs (entity_checksum.rs:40).  grid = (tiles, n_cks)
+// (n_cks == 0 still launches y = 1 for the count).  One slot per lane per step, so one ballot
+// is exactly one mask word.
+__global__ __launch_bounds__(TPB) void k_checksum(CksArgs a, const UnitDesc* __restrict__ units) {
+    const uint32_t t = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t h = 0;
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t e = (uint64_t)t * TILE + (uint64_t)i * TPB + tid;
+        const uint64_t wi = e >> 6;
+        const uint64_t aw = *reinterpret_cast<const uint64_t*>(a.state + a.off_alive + wi * 8);
+        if (k == 0 && lane == 0) cnt += (uint32_t)__popcll(aw);
+        if (a.n_cks == 0) continue;
+        const uint64_t pw = *reinterpret_cast<const uint64_t*>(a.state + a.off_present[k] + wi * 8);
+        if (((aw & pw) >> (e & 63)) & 1ULL) {
+            SeaStream s;
+            const uint32_t n = a.n_units[k], ub = a.unit_base[k];
+#pragma unroll 1
+            for (uint32_t u = 0; u < n; ++u) {
+                const UnitDesc ud = units[ub + u];
+                s.unit(*reinterpret_cast<const uint32_t*>(a.state + ud.off + e * ud.stride));
+            }
+            h ^= sea_pair(e, s.finish());
+        }
+    }
+    __shared__ uint64_t sH[4];
+    __shared__ uint32_t sC[4];
+    h = wave_xor(h);
+    if (lane == 0) { sH[wave] = h; sC[wave] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.n_cks) a.parts[(uint64_t)k * a.part_stride + t] = sH[0] ^ sH[1] ^ sH[2] ^ sH[3];
+        if (k == 0) a.part_cnt[t] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
+    }
+}
+
+// ------------------------------------------------------------------ k_finalize
+// Hash each component's XOR once more (component_checksum.rs:92-95), add the entity part
+// (entity_checksum.rs:29-52), XOR-fold all parts (checksum.rs:88-99).  One workgroup.
+__global__ __launch_bounds__(TPB) void k_finalize(const uint64_t* __restrict__ parts,
+                                                  const uint64_t* __restrict__ part_cnt,
+                                                  uint32_t n_cks, uint32_t part_stride, uint32_t n_parts,
+                                                  uint64_t total_len, uint64_t* __restrict__ out,
+                                                  Header* __restrict__ live_hdr) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint64_t sx[4];
+    __shared__ uint64_t acc;
+    if (tid == 0) acc = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k <= n_cks; ++k) {          // k == n_cks: the count column
+        uint64_t v = 0;
+        const uint64_t* p = (k < n_cks) ? parts + (uint64_t)k * part_stride : part_cnt;
+        for (uint32_t i = tid; i < n_parts; i += TPB) { if (k < n_cks) v ^= p[i]; else v += p[i]; }
+        if (k < n_cks) v = wave_xor(v);
+        else {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        }
+        if (lane == 0) sx[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            if (k < n_cks) acc ^= sea_one(sx[0] ^ sx[1] ^ sx[2] ^ sx[3]);
+            else {
+                const uint64_t active = sx[0] + sx[1] + sx[2] + sx[3];
+                acc ^= sea_pair(active, total_len);      // hash(active, total) has the same shape
+                live_hdr->active = active;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = acc; out[1] = 0;       // `as u128` of a u64: upper half is always 0
+        live_hdr->checksum[0] = acc; live_hdr->checksum[1] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ generic systems
+// benches/bench.rs:30-46 (increment_foos ...), tests/component_rollback.rs:24-28
+__global__ __launch_bounds__(TPB) void k_add_u32(uint8_t* state, uint64_t off_alive, uint64_t off_present,
+                                                 uint64_t off_col, uint32_t delta, uint64_t len) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= len) return;
+    const uint64_t m = *reinterpret_cast<const uint64_t*>(state + off_alive + (e >> 6) * 8) &
+                       *reinterpret_cast<const uint64_t*>(state + off_present + (e >> 6) * 8);
+    if ((m >> (e & 63)) & 1ULL) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(state + off_col + e * 4);
+        *p = *p + delta;
+    }
+}
+// tests/synctest.rs:37-44 decrease_health: saturating_sub then despawn at 0.  One slot per
+// lane: the wave's ballot IS the new 64-bit liveness word.
+__global__ __launch_bounds__(TPB) void k_sat_sub_despawn(uint8_t* state, uint64_t off_alive, uint64_t off_present,
+                                                         uint64_t off_col, uint32_t amount, uint64_t len_pad64) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= len_pad64) return;                       // whole waves only (len padded to 64)
+    const uint64_t aw = *reinterpret_cast<const uint64_t*>(state + off_alive + (e >> 6) * 8);
+    const uint64_t pw = *reinterpret_cast<const uint64_t*>(state + off_present + (e >> 6) * 8);
+    bool alive = (aw >> (e & 63)) & 1ULL;
+    if (alive && ((pw >> (e & 63)) & 1ULL)) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(state + off_col + e * 4);
+        const uint32_t v = *p >= amount ? *p - amount : 0u;
+        *p = v;
+        if (v == 0) alive = false;
+    }
+    const uint64_t nw = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0 && nw != aw) *reinterpret_cast<uint64_t*>(state + off_alive + (e >> 6) * 8) = nw;
+}
+
+// ------------------------------------------------------------------ spawn / mask edits
+// Set liveness + presence bits for slots [first, first+count) (Rollback on_add hook,
+// rollback.rs:45-59).  One mask word per thread; each word is owned by exactly one thread.
+struct MaskOffs { uint64_t off[MAX_MASKS]; };
+__global__ __launch_bounds__(TPB) void k_set_mask_range(uint8_t* state, uint64_t first, uint64_t count,
+                                                        uint32_t n_masks, MaskOffs mask_off_set) {
+    const uint64_t w_first = first >> 6, w_last = (first + count - 1) >> 6;
+    const uint64_t wi = w_first + (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (wi > w_last) return;
+    const uint64_t lo = wi * 64, hi = lo + 64;
+    const uint64_t a = first > lo ? first : lo, b = (first + count) < hi ? (first + count) : hi;
+    const uint32_t nb = (uint32_t)(b - a);
+    const uint64_t bits = (nb == 64 ? ~0ULL : ((1ULL << nb) - 1ULL)) << (a - lo);
+    for (uint32_t m = 0; m < n_masks; ++m) {
+        uint64_t* p = reinterpret_cast<uint64_t*>(state + mask_off_set.off[m] + wi * 8);
+        *p |= bits;
+    }
+}
+__global__ void k_edit_mask_bit(uint8_t* state, uint64_t mask_off, uint64_t slot, int value) {
+    uint64_t* p = reinterpret_cast<uint64_t*>(state + mask_off + (slot >> 6) * 8);
+    if (value) *p |= 1ULL << (slot & 63); else *p &= ~(1ULL << (slot & 63));
+}
+// Fill one column over [first, first+count) with a constant word (component defaults).
+__global__ __launch_bounds__(TPB) void k_fill_col(uint8_t* state, uint64_t col_off, uint32_t word_bytes,
+                                                  uint64_t first, uint64_t count, uint64_t value) {
+    const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= count) return;
+    if (word_bytes == 4) *reinterpret_cast<uint32_t*>(state + col_off + (first + i) * 4) = (uint32_t)value;
+    else *reinterpret_cast<uint64_t*>(state + col_off + (first + i) * 8) = value;
+}
+// spawn_particles (particles.rs:258-270) payload: Velocity(vx, vy, 0.0), Ttl(ttl); Transform gets
+// its default through k_fill_col.  Also emits checksum partials for the new rows so a fused
+// step's pending partials stay complete.
+struct SpawnArgs {
+    uint8_t* state;
+    uint64_t off_t[3], off_v[3], off_ttl;
+    uint32_t t_default[3];
+    const float* vx; const float* vy;
+    uint64_t first, count, ttl;
+    uint64_t* part_T; uint64_t* part_V; uint64_t* part_cnt;   // slots [0, gridDim.x)
+    int cks_T, cks_V;
+};
+__global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * TPB + tid;
+    uint64_t hT = 0, hV = 0;
+    uint32_t cnt = 0;
+    if (i < a.count) {
+        const uint64_t e = a.first + i;
+        const float vx = a.vx[i], vy = a.vy[i];
+        *reinterpret_cast<float*>(a.state + a.off_v[0] + e * 4) = vx;
+        *reinterpret_cast<float*>(a.state + a.off_v[1] + e * 4) = vy;
+        *reinterpret_cast<float*>(a.state + a.off_v[2] + e * 4) = 0.0f;
+        *reinterpret_cast<uint64_t*>(a.state + a.off_ttl + e * 8) = a.ttl;
+        if (a.cks_T) hT = sea_pair(e, sea_inner3(a.t_default[0], a.t_default[1], a.t_default[2]));
+        if (a.cks_V) hV = sea_pair(e, sea_inner3(__float_as_uint(vx), __float_as_uint(vy), 0u));
+        cnt = 1;
+    }
+    __shared__ uint64_t sT[4], sV[4];
+    __shared__ uint32_t sC[4];
+    hT = wave_xor(hT); hV = wave_xor(hV);
+    cnt = (uint32_t)__popcll(__ballot(cnt));
+    if (lane == 0) { sT[wave] = hT; sV[wave] = hV; sC[wave] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        a.part_T[blockIdx.x] = sT[0] ^ sT[1] ^ sT[2] ^ sT[3];
+        a.part_V[blockIdx.x] = sV[0] ^ sV[1] ^ sV[2] ^ sV[3];
+        a.part_cnt[blockIdx.x] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
+    }
+}
+
+}  // namespace ggrs

@@ -1,0 +1,235 @@
+/* ggrs_hip.h -- C ABI of libggrs_hip.so: the MI355X (gfx950) rollback re-simulation engine.
+ *
+ * This is the drop-in boundary for bevy_ggrs's snapshot-and-resimulate hot path.  The
+ * reference (pure Rust, /root/reference) has no FFI of its own; each entry point below
+ * names the Rust-level seam it replaces (file:line relative to /root/reference).  A thin
+ * Rust shim binds these with `extern "C"` and keeps the reference's
+ * names: GgrsPlugin, RollbackApp::rollback_component_with_*, GgrsSchedule, ReadInputs.
+ *
+ * Conventions
+ *   - every function returns int: 0 = GGRS_OK, negative = error; no exceptions, no panics
+ *     (where the reference panics -- e.g. rollback to a missing frame, snapshot/mod.rs:213 --
+ *     an error code is returned and ggrs_hip_last_error() holds the text);
+ *   - plain pointers and sizes only; the library owns all device memory, the caller owns
+ *     every host buffer it passes in (it may be freed as soon as the call returns);
+ *   - one ggrs_world = one HIP stream; NOT thread-safe (the reference's caller is an
+ *     exclusive system holding &mut World, src/lib.rs:252-257);
+ *   - no callbacks into the host;
+ *   - registered component data lives as SoA *word columns* in HBM: a component is
+ *     n_words words of word_bytes (4 or 8) bytes; column w of component c is a dense
+ *     array indexed by slot.  slot == RollbackOrdered insertion index
+ *     (snapshot/rollback.rs:69-88): stable, never reused.
+ */
+#ifndef GGRS_HIP_H
+#define GGRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGRS_HIP_ABI_VERSION 1
+
+/* limits */
+#define GGRS_MAX_COMPONENTS 16
+#define GGRS_MAX_WORDS      16
+#define GGRS_MAX_CKS_UNITS  32
+#define GGRS_MAX_SYSTEMS    16
+#define GGRS_MAX_PLAYERS    16
+
+/* error codes */
+#define GGRS_OK             0
+#define GGRS_E_INVALID     -1   /* bad argument / bad call order                                  */
+#define GGRS_E_NO_SNAPSHOT -2   /* LoadGameState for a frame not in the ring (mod.rs:213 panic)   */
+#define GGRS_E_CAPACITY    -3   /* spawn beyond the world's slot capacity                          */
+#define GGRS_E_HIP         -4   /* a HIP runtime call failed; see ggrs_hip_last_error             */
+#define GGRS_E_NO_DEVICE   -5   /* no gfx950 device visible: the product path has no CPU fallback */
+
+typedef struct ggrs_world ggrs_world;
+
+/* -------------------------------------------------------------------------------------------
+ * World lifetime.  Replaces the Bevy World's archetype storage for registered components plus
+ * every GgrsSnapshots<_, _> resource (snapshot/mod.rs:97-119).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t  device;        /* HIP device ordinal                                             */
+    uint32_t max_depth;     /* ring slots to provision (>= any depth later set)                */
+    uint64_t capacity;      /* max slots (Rollback entities ever spawned)                      */
+    void*    stream;        /* hipStream_t to run on, or NULL: the library creates its own     */
+    void*    arena;         /* optional caller-provided device memory (e.g. a torch tensor)    */
+    uint64_t arena_bytes;   /*   size of that arena; 0 = library calls hipMalloc               */
+    uint32_t flags;         /* GGRS_WORLD_* bits                                               */
+    uint32_t reserved;
+} ggrs_world_desc;
+
+#define GGRS_WORLD_DEFAULT      0u
+#define GGRS_WORLD_NO_GRAPH     1u   /* never capture request batches into hipGraphs           */
+#define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
+
+int  ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggrs_world** out);
+int  ggrs_hip_world_create_ex(const ggrs_world_desc* desc, ggrs_world** out);
+/* bytes of device memory a world of this shape needs (for sizing a caller-provided arena);
+ * call after registration with out-of-band numbers: total bytes/slot of all registered words. */
+uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_components,
+                              uint32_t bytes_per_slot);
+void ggrs_hip_world_destroy(ggrs_world* w);
+const char* ggrs_hip_last_error(ggrs_world* w);
+int  ggrs_hip_abi_version(void);
+
+/* -------------------------------------------------------------------------------------------
+ * Registration (build time).  All registration must precede the first spawn/save.
+ * ------------------------------------------------------------------------------------------- */
+
+/* RollbackApp::rollback_component_with_copy / _with_clone (snapshot/rollback_app.rs:34-36,52-54;
+ * CopyStrategy/CloneStrategy, snapshot/strategy.rs:43-83 -- bitwise for POD). */
+int ggrs_hip_register_component(ggrs_world* w, const char* name, uint32_t word_bytes,
+                                uint32_t n_words, uint32_t* comp_id);
+
+/* value given to a freshly spawned entity's component when the spawner passes no data
+ * (e.g. Transform::default for `Sprite`-required Transform, particles.rs:262). */
+int ggrs_hip_set_component_default(ggrs_world* w, uint32_t comp_id, const void* words);
+
+/* RollbackApp::checksum_component / checksum_component_with_hash (rollback_app.rs:99-101,
+ * 119-121; ComponentChecksumPlugin, snapshot/component_checksum.rs:67-108).  The per-entity
+ * custom hasher is SeaHash over the listed words, in order, each written as word_bytes
+ * little-endian bytes (== derive(Hash) over those fields, or particles.rs:207-222). */
+int ggrs_hip_checksum_component(ggrs_world* w, uint32_t comp_id, const uint32_t* word_idx,
+                                uint32_t n_idx);
+
+/* Kernel-backed systems of the GgrsSchedule (lib.rs:76, 247-251): add_systems(GgrsSchedule, ..).
+ * Systems run in registration order; despawns/spawns are deferred to the end of the frame like
+ * Bevy Commands (snapshot/set.rs:118-134). */
+#define GGRS_SYS_PARTICLES_UPDATE 1u /* particles.rs:272-280  comp[0]=Transform comp[1]=Velocity
+                                        word[0]=translation.x word[1]=velocity.x fparam=gravity  */
+#define GGRS_SYS_TTL_DESPAWN      2u /* particles.rs:282-289  comp[0]=Ttl(u64) word[0]             */
+#define GGRS_SYS_PARTICLES_SPAWN  3u /* particles.rs:254-270  comp[0..2]=Transform,Velocity,Ttl
+                                        iparam[0]=ttl iparam[1]=input mask (INPUT_SPAWN)           */
+#define GGRS_SYS_ADD_U32          4u /* benches/bench.rs:30-46 comp[0],word[0] += iparam[0]        */
+#define GGRS_SYS_SAT_SUB_DESPAWN  5u /* tests/synctest.rs:37-44 saturating_sub(iparam[0]), ==0 despawn */
+
+typedef struct {
+    uint32_t kind;
+    uint32_t comp[4];
+    uint32_t word[4];
+    int64_t  iparam[2];
+    float    fparam[4];
+} ggrs_system_desc;
+
+int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* desc);
+
+/* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */
+int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);
+
+/* -------------------------------------------------------------------------------------------
+ * Entities and host<->device column traffic.
+ * ------------------------------------------------------------------------------------------- */
+
+/* commands.spawn((.., Rollback)) x count: Rollback on_add hook -> RollbackOrdered::push
+ * (snapshot/rollback.rs:45-59,69-74).  comp_mask bit c = the bundle has component c.
+ * cols: for each component in comp_mask (ascending id), n_words host pointers to `count`
+ * words each (NULL pointer or NULL cols = component default). */
+int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols,
+                   uint64_t* first_slot);
+int ggrs_hip_despawn(ggrs_world* w, uint64_t slot);                       /* commands.entity(e).despawn() */
+int ggrs_hip_insert_component(ggrs_world* w, uint32_t comp_id, uint64_t slot, const void* words);
+int ggrs_hip_remove_component(ggrs_world* w, uint32_t comp_id, uint64_t slot);
+
+int ggrs_hip_upload_word(ggrs_world* w, uint32_t comp_id, uint32_t word, uint64_t first,
+                         uint64_t count, const void* host_src);
+int ggrs_hip_download_word(ggrs_world* w, uint32_t comp_id, uint32_t word, uint64_t first,
+                           uint64_t count, void* host_dst);
+int ggrs_hip_download_alive(ggrs_world* w, uint64_t* host_dst, uint64_t n_words64);
+int ggrs_hip_download_present(ggrs_world* w, uint32_t comp_id, uint64_t* host_dst, uint64_t n_words64);
+/* device address of a live column (for zero-copy interop, e.g. RCCL through torch tensors) */
+int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr);
+
+uint64_t ggrs_hip_len(ggrs_world* w);            /* RollbackOrdered::len (rollback.rs:91-93)   */
+int      ggrs_hip_active_count(ggrs_world* w, uint64_t* out);   /* live Rollback entities    */
+
+/* -------------------------------------------------------------------------------------------
+ * Frame counters and the snapshot ring (snapshot/mod.rs:68-86, 121-274).
+ * ------------------------------------------------------------------------------------------- */
+int32_t ggrs_hip_frame(ggrs_world* w);                           /* RollbackFrameCount       */
+int  ggrs_hip_set_frame(ggrs_world* w, int32_t frame);
+int  ggrs_hip_set_depth(ggrs_world* w, uint32_t depth);          /* sync_depth, mod.rs:263-273 */
+int  ggrs_hip_set_confirmed(ggrs_world* w, int has, int32_t confirmed_frame); /* ConfirmedFrameCount;
+                                              applied by discard_old_snapshots before each save */
+int  ggrs_hip_has_snapshot(ggrs_world* w, int32_t frame);        /* peek(frame).is_some(): 1/0 */
+uint64_t ggrs_hip_snapshot_count(ggrs_world* w);
+
+/* -------------------------------------------------------------------------------------------
+ * Request execution (handle_requests, src/schedule_systems.rs:170-289).
+ * ------------------------------------------------------------------------------------------- */
+
+/* SaveWorld (snapshot/set.rs:104-107): Checksum systems -> ChecksumPlugin::update fold
+ * (snapshot/checksum.rs:88-99) -> Snapshot systems push at RollbackFrameCount
+ * (component_snapshot.rs:66-84, entity.rs:39-51).  checksum_out = Checksum(u128) as {lo, hi}. */
+int ggrs_hip_save(ggrs_world* w, uint64_t checksum_out[2]);
+
+/* LoadWorld (set.rs:92-103): RollbackFrameCount = frame (schedule_systems.rs:244-247), ring
+ * rollback (mod.rs:210-226), entity reconcile (entity.rs:55-99) and component restore
+ * (component_snapshot.rs:95-123). */
+int ggrs_hip_load(ggrs_world* w, int32_t frame);
+
+/* AdvanceWorld (set.rs:108-134): RollbackFrameCount += 1 (schedule_systems.rs:254-259),
+ * GgrsTimePlugin::update (time.rs:63-87; dt_bits==0 -> derived from the frame number and
+ * RollbackFrameRate), then the registered GgrsSchedule systems. */
+int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
+                     uint64_t spawn_count, const float* spawn_vx, const float* spawn_vy);
+
+#define GGRS_REQ_SAVE    1u   /* GgrsRequest::SaveGameState  (schedule_systems.rs:223-237) */
+#define GGRS_REQ_LOAD    2u   /* GgrsRequest::LoadGameState  (schedule_systems.rs:238-250) */
+#define GGRS_REQ_ADVANCE 3u   /* GgrsRequest::AdvanceFrame   (schedule_systems.rs:251-268) */
+
+typedef struct {
+    uint32_t kind;            /* GGRS_REQ_*                                                    */
+    int32_t  frame;           /* SAVE: frame handed to cell.save; LOAD: frame to restore       */
+    uint32_t dt_bits;         /* ADVANCE: f32 bits of Time::delta_secs, 0 = derive (time.rs)   */
+    uint32_t n_inputs;        /* ADVANCE: PlayerInputs length                                  */
+    const uint8_t* inputs;    /* ADVANCE: one input byte per player (status ignored)           */
+    uint64_t spawn_count;     /* ADVANCE: rows the PARTICLES_SPAWN system appends if pressed   */
+    const float* spawn_vx;    /*   host arrays of spawn_count f32 (host-side ParticleRng draw) */
+    const float* spawn_vy;
+} ggrs_request;
+
+/* Executes a whole request list as one device submission (one stream sync at the end).
+ * Before each request the session-derived ConfirmedFrameCount rule for SyncTest sessions can be
+ * applied by the library (schedule_systems.rs:204-220) when check_distance >= 0 is set through
+ * ggrs_hip_set_synctest_check_distance; otherwise the caller sets it via ggrs_hip_set_confirmed.
+ * checksums_out receives {lo,hi} per SAVE request, in request order. */
+int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n,
+                             uint64_t* checksums_out);
+int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t check_distance /* <0: off */);
+
+/* Blocks until all work submitted on the world's stream has finished. */
+int ggrs_hip_synchronize(ggrs_world* w);
+
+/* -------------------------------------------------------------------------------------------
+ * Speculative fan-out support (BASELINE config 5): export / import one snapshot's bytes so a
+ * confirmed frame can be broadcast rank->rank (RCCL) and adopted without touching the host.
+ * ------------------------------------------------------------------------------------------- */
+/* bytes of one packed world state (all columns [0,capacity), masks, header) */
+uint64_t ggrs_hip_state_bytes(ggrs_world* w);
+/* device pointer of the LIVE packed state block (contiguous; valid until destroy) */
+int ggrs_hip_live_state_ptr(ggrs_world* w, void** dev_ptr);
+/* after bytes were written into the live state block by an external producer (collective),
+ * re-read its header so host-side bookkeeping (len, frame) matches */
+int ggrs_hip_adopt_live_state(ggrs_world* w);
+
+/* -------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): per-kernel-class HIP-event timing on the world's stream.
+ * ------------------------------------------------------------------------------------------- */
+#define GGRS_KERNEL_SAVE     0u
+#define GGRS_KERNEL_LOAD     1u
+#define GGRS_KERNEL_ADVANCE  2u
+#define GGRS_KERNEL_CHECKSUM 3u
+#define GGRS_KERNEL_CLASSES  4u
+int ggrs_hip_profile_enable(ggrs_world* w, int on);
+/* total milliseconds and launch count per class since enable; sizes GGRS_KERNEL_CLASSES */
+int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGRS_HIP_H */

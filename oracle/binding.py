@@ -1,0 +1,148 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libggrs_oracle.so) -- TEST INFRASTRUCTURE.
+
+Exposes the same Python surface as bevy_ggrs_amd.World so a test can drive the HIP path and the
+oracle with one script and compare.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; nothing under bevy_ggrs_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from bevy_ggrs_amd._ffi import Request, SystemDesc
+from bevy_ggrs_amd.world import WorldBase
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libggrs_oracle.so")
+
+FLAT, REFSHAPED = 0, 1
+
+
+def build(force: bool = False):
+    src = os.path.join(_HERE, "ggrs_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    sig = {
+        "gor_seahash_buffer": (C.c_uint64, [P, C.c_uint64]),
+        "gor_seahash_stream": (C.c_uint64, [P, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint32]),
+        "gor_diffuse": (C.c_uint64, [C.c_uint64]),
+        "gor_inner_hash_units": (C.c_uint64, [C.POINTER(C.c_uint32), C.c_uint32]),
+        "gor_entity_part": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "gor_finalize_part": (C.c_uint64, [C.c_uint64]),
+        "gor_entity_checksum": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "gor_dt_bits": (C.c_uint32, [C.c_uint64, C.c_int32]),
+        "gor_ring_create": (P, [C.c_uint64]),
+        "gor_ring_destroy": (None, [P]),
+        "gor_ring_set_depth": (None, [P, C.c_uint64]),
+        "gor_ring_push": (None, [P, C.c_int32, C.c_uint32]),
+        "gor_ring_confirm": (None, [P, C.c_int32]),
+        "gor_ring_rollback": (C.c_int, [P, C.c_int32]),
+        "gor_ring_get": (C.c_int, [P, C.POINTER(C.c_uint32)]),
+        "gor_ring_peek": (C.c_int, [P, C.c_int32, C.POINTER(C.c_uint32)]),
+        "gor_ring_len": (C.c_uint64, [P]),
+        "gor_world_create": (P, [C.c_uint64, C.c_uint32, C.c_int]),
+        "gor_world_destroy": (None, [P]),
+        "gor_last_error": (C.c_char_p, [P]),
+        "gor_register_component": (C.c_int, [P, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "gor_set_component_default": (C.c_int, [P, C.c_uint32, P]),
+        "gor_checksum_component": (C.c_int, [P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
+        "gor_add_system": (C.c_int, [P, C.POINTER(SystemDesc)]),
+        "gor_spawn": (C.c_int, [P, C.c_uint64, C.c_uint64, C.POINTER(P), C.POINTER(C.c_uint64)]),
+        "gor_despawn": (C.c_int, [P, C.c_uint64]),
+        "gor_insert_component": (C.c_int, [P, C.c_uint32, C.c_uint64, P]),
+        "gor_remove_component": (C.c_int, [P, C.c_uint32, C.c_uint64]),
+        "gor_upload_word": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P]),
+        "gor_download_word": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P]),
+        "gor_download_alive": (C.c_int, [P, P, C.c_uint64]),
+        "gor_download_present": (C.c_int, [P, C.c_uint32, P, C.c_uint64]),
+        "gor_len": (C.c_uint64, [P]),
+        "gor_active_count": (C.c_uint64, [P]),
+        "gor_frame": (C.c_int32, [P]),
+        "gor_set_frame": (None, [P, C.c_int32]),
+        "gor_set_frame_rate": (None, [P, C.c_uint64]),
+        "gor_set_depth": (None, [P, C.c_uint32]),
+        "gor_set_confirmed": (None, [P, C.c_int, C.c_int32]),
+        "gor_has_snapshot": (C.c_int, [P, C.c_int32]),
+        "gor_snapshot_count": (C.c_uint64, [P]),
+        "gor_save": (C.c_int, [P, C.POINTER(C.c_uint64)]),
+        "gor_load": (C.c_int, [P, C.c_int32]),
+        "gor_advance": (C.c_int, [P, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint64,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "gor_handle_requests": (C.c_int, [P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64)]),
+        "gor_bench_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "gor_num_threads": (C.c_int, []),
+        "gor_set_num_threads": (None, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class OracleWorld(WorldBase):
+    _lib = lib
+    _prefix = "gor_"
+
+    def __init__(self, capacity: int, max_depth: int = 8, mode: int = FLAT):
+        self._p = C.c_void_p(lib.gor_world_create(capacity, max_depth, mode))
+        self._comps = []
+        self.capacity = capacity
+        self.mode = mode
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib.gor_world_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def active_count(self) -> int:
+        return int(lib.gor_active_count(self._p))
+
+    def set_synctest_check_distance(self, cd: int):
+        self._cd = cd   # the oracle applies the rule in Python (see tests/common.py)
+
+    def bench_synctest(self, d: int, warm_ticks: int, ticks: int) -> float:
+        return float(lib.gor_bench_synctest(self._p, d, warm_ticks, ticks))
+
+
+class OracleRing:
+    """GgrsSnapshots<u32, u32> (src/snapshot/mod.rs:357) for the 11 known-answer tests."""
+
+    def __init__(self, depth: int):
+        self._p = C.c_void_p(lib.gor_ring_create(depth))
+
+    def __del__(self):
+        if self._p: lib.gor_ring_destroy(self._p); self._p = None
+
+    def push(self, frame, v): lib.gor_ring_push(self._p, frame, v)
+    def confirm(self, frame): lib.gor_ring_confirm(self._p, frame)
+
+    def rollback(self, frame):
+        if lib.gor_ring_rollback(self._p, frame) != 0:
+            raise RuntimeError(f"Could not rollback to {frame}: no snapshot at that moment could be found.")
+
+    def get(self):
+        out = C.c_uint32(0)
+        if lib.gor_ring_get(self._p, C.byref(out)) != 0: raise RuntimeError("no snapshot available")
+        return out.value
+
+    def peek(self, frame):
+        out = C.c_uint32(0)
+        return out.value if lib.gor_ring_peek(self._p, frame, C.byref(out)) == 0 else None
+
+    def __len__(self): return int(lib.gor_ring_len(self._p))

@@ -1,0 +1,135 @@
+"""Shared fixtures: the stress_test (particles) world of examples/stress_tests/particles.rs
+built on either backend, the synthetic inputs of BASELINE.md section 3, and a backend-neutral
+SyncTest driver (run_synctest, src/schedule_systems.rs:85-118)."""
+from __future__ import annotations
+
+import numpy as np
+
+import bevy_ggrs_amd as bg
+from bevy_ggrs_amd.session import SyncTestSession
+
+INPUT_SPAWN = 1 << 4           # particles.rs:75
+TRANSFORM_DEFAULT = np.array([0, 0, 0, 0, 0, 0, 1, 1, 1, 1], dtype=np.float32)  # t(3) rot xyzw(4) scale(3)
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def build_particles(world, *, with_spawn=False, ttl_init=300, checksum=True):
+    """particles.rs:187-240 restricted to the 3 registered components of SURVEY.md section 8."""
+    T = world.register_component("Transform", 4, 10)
+    V = world.register_component("Velocity", 4, 3)
+    L = world.register_component("Ttl", 8, 1)
+    world.set_component_default(T, TRANSFORM_DEFAULT)
+    if checksum:
+        world.checksum_component(V, [0, 1, 2])        # checksum_component_with_hash::<Velocity>()
+        world.checksum_component(T, [0, 1, 2])        # checksum_component::<Transform>(translation)
+    world.add_system(bg.SYS_PARTICLES_UPDATE, comp=(T, V), word=(0, 0), fparam=(0.0, -200.0, 0.0))
+    world.add_system(bg.SYS_TTL_DESPAWN, comp=(L,), word=(0,))
+    if with_spawn:
+        world.add_system(bg.SYS_PARTICLES_SPAWN, comp=(T, V, L), iparam=(ttl_init, INPUT_SPAWN))
+    return T, V, L
+
+
+def synthetic_particles(n, ttl="throughput", seed=123):
+    """Velocity=(u1,u2,0), u~U[-200,200) from default_rng(123); Transform default."""
+    rng = np.random.default_rng(seed)
+    vel = rng.uniform(-200, 200, (n, 2)).astype(np.float32)
+    if ttl == "throughput":
+        t = np.full(n, 1 << 40, dtype=np.uint64)
+    elif ttl == "despawn":
+        t = (1 + (np.arange(n, dtype=np.uint64) % 300)).astype(np.uint64)
+    else:
+        t = np.full(n, int(ttl), dtype=np.uint64)
+    return vel, t
+
+
+def spawn_particles(world, ids, n, vel, ttl):
+    T, V, L = ids
+    tcols = [np.full(n, f32bits(TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
+    vcols = [f32bits(vel[:, 0]), f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
+    return world.spawn(n, {T: tcols, V: vcols, L: [ttl]})
+
+
+def snapshot_state(world, ids):
+    """Everything observable: (len, alive, per-component (present&alive, words of live entities))."""
+    n = world.len
+    alive = world.alive_mask(n)
+    out = {"len": n, "frame": world.frame, "alive": alive}
+    for cid in ids:
+        _, wb, nw = world._comps[cid]
+        pres = world.present_mask(cid, n) & alive
+        out[f"present{cid}"] = pres
+        for k in range(nw):
+            col = world.download_word(cid, k, 0, n)
+            out[f"c{cid}w{k}"] = np.where(pres, col, 0)
+    return out
+
+
+def assert_states_equal(a, b, ctx=""):
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            if not np.array_equal(a[k], b[k]):
+                bad = np.nonzero(a[k] != b[k])[0]
+                raise AssertionError(f"{ctx} state field {k} differs at {bad[:8]} ({bad.size} slots): {a[k][bad[:4]]} vs {b[k][bad[:4]]}")
+        else:
+            assert a[k] == b[k], (ctx, k, a[k], b[k])
+
+
+class SyncTestDriver:
+    """run_synctest + handle_requests over any backend world (schedule_systems.rs:85-118,170-289)."""
+
+    def __init__(self, world, check_distance, num_players=1, max_prediction=None, input_delay=0):
+        self.world = world
+        mp = max_prediction if max_prediction is not None else max(8, check_distance + 1)
+        self.sess = SyncTestSession(num_players, check_distance, mp, input_delay)
+        self.cd = check_distance
+        self.lib_rule = hasattr(world, "_lib") and world._prefix == "ggrs_hip_"
+        world.set_depth(mp)                       # sync_depth: MaxPredictionWindow (mod.rs:263-273)
+        if self.lib_rule:
+            world.set_synctest_check_distance(check_distance)
+        self.all_checksums = []                   # (frame, checksum) of every save, in order
+
+    def _confirm_rule(self):
+        # schedule_systems.rs:204-220 (applied per request; the oracle has no built-in rule)
+        c = self.world.frame - self.cd
+        if c >= 0:
+            self.world.set_confirmed(c)
+
+    def tick(self, inputs=(0,), spawn_fn=None):
+        """spawn_fn(frame) -> (vx, vy): the ParticleRng draw of the frame being advanced.  It must
+        be a pure function of the frame: ParticleRng is a rollback resource
+        (particles.rs:201), so a resimulated frame redraws the same values."""
+        for h, v in enumerate(inputs):
+            self.sess.add_local_input(h, v)
+        reqs = self.sess.advance_frame()
+        if spawn_fn is not None:
+            cur = self.world.frame
+            for r in reqs:
+                if isinstance(r, bg.LoadGameState):
+                    cur = r.frame
+                elif isinstance(r, bg.AdvanceFrame):
+                    if any(i & INPUT_SPAWN for i in r.inputs):
+                        r.spawn_vx, r.spawn_vy = spawn_fn(cur)
+                    cur += 1
+        if self.lib_rule:
+            cs = self.world.handle_requests(reqs)
+        else:
+            cs = []
+            for r in reqs:
+                self._confirm_rule()
+                cs += self.world.handle_requests([r])
+        self.sess.record_checksums(cs)
+        saves = [r for r in reqs if isinstance(r, bg.SaveGameState)]
+        self.all_checksums += [(s.frame, c) for s, c in zip(saves, cs)]
+        return cs
+
+
+def frame_spawn_fn(rate=100, seed=99):
+    """Deterministic per-frame spawn payload (stands in for the rolled-back ParticleRng)."""
+    def fn(frame):
+        r = np.random.default_rng([seed, frame])
+        return (r.uniform(-200, 200, rate).astype(np.float32), r.uniform(-200, 200, rate).astype(np.float32))
+    return fn

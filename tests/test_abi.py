@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every symbol include/ggrs_hip.h declares (no compute
+calls: there is no GPU in the CPU test tier)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import bevy_ggrs_amd as bg
+from bevy_ggrs_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ggrs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggrs_hip_\w+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    syms = _declared_symbols()
+    assert len(syms) >= 35
+    lib = C.CDLL(_ffi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in ggrs_hip.h but not exported"
+        assert s in _ffi.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_ffi.SIGNATURES) == set(syms)
+
+
+def test_abi_version_and_struct_sizes():
+    assert _ffi.lib.ggrs_hip_abi_version() == 1
+    assert C.sizeof(_ffi.Request) == 48
+    assert C.sizeof(_ffi.SystemDesc) == 72
+    assert C.sizeof(_ffi.WorldDesc) == 48
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(bg.GgrsHipError) as e:
+        bg.World(128)
+    assert e.value.code == bg.GGRS_E_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bevy_ggrs_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("the CPU oracle", "").replace("CPU\n oracle", "") or f == "world.py", (dp, f)

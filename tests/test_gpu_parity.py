@@ -1,0 +1,160 @@
+"""HIP path vs CPU oracle through the C ABI, bit-exact (integer checksums, masks, counters, and
+f32 columns compared as raw bits: the checksum hashes f32 bits, so 1 ULP is already a failure)."""
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+from oracle.binding import FLAT, OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(capacity, depth=16, flags=0):
+    return bg.World(capacity, max_depth=depth, flags=flags), OracleWorld(capacity, depth, FLAT)
+
+
+def _run(world, n, cd, ticks, ttl_mode="despawn", with_spawn=True, ttl_init=40, spawn_every=3, rate=100):
+    vel, ttl = cm.synthetic_particles(n, ttl=ttl_mode)
+    ids = cm.build_particles(world, with_spawn=with_spawn, ttl_init=ttl_init)
+    cm.spawn_particles(world, ids, n, vel, ttl)
+    drv = cm.SyncTestDriver(world, cd)
+    fn = cm.frame_spawn_fn(rate)
+    for t in range(ticks):
+        drv.tick((cm.INPUT_SPAWN if (with_spawn and t % spawn_every == 1) else 0,), spawn_fn=fn)
+    return drv.all_checksums, cm.snapshot_state(world, ids)
+
+
+@pytest.mark.parametrize("n,cd,ticks", [(1, 2, 12), (63, 1, 10), (1000, 2, 20), (1025, 7, 24), (10_000, 8, 30), (100_000, 8, 14)])
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_UNFUSED])
+def test_particles_synctest_checksums_and_state(n, cd, ticks, flags):
+    cap = n + 100 * ticks + 64
+    g, o = _pair(cap, 16, flags)
+    a = _run(g, n, cd, ticks)
+    b = _run(o, n, cd, ticks)
+    assert len(a[0]) == len(b[0]) > 0
+    for (fa, ca), (fb, cb) in zip(a[0], b[0]):
+        assert fa == fb and ca == cb, f"frame {fa}: gpu {ca:#x} oracle {cb:#x}"
+    cm.assert_states_equal(a[1], b[1], f"n={n} cd={cd}")
+
+
+def test_600_frames_bit_exact_f32():
+    """every f32 bit-equal over >= 600 frames (no FMA contraction,
+    -0.0 + 0.0 handling, dt alternation)."""
+    n = 5000
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    vel[::7, 0] = -0.0                              # x += +0.0 must turn -0.0 into +0.0
+    vel[::11, 1] = np.float32(1e-38)                # subnormal-adjacent inputs
+    worlds = _pair(n)
+    cs = []
+    for w in worlds:
+        ids = cm.build_particles(w)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        out = []
+        for f in range(600):
+            w.advance()
+            if f % 50 == 49: out.append(w.save())
+        cs.append((out, cm.snapshot_state(w, ids)))
+    assert cs[0][0] == cs[1][0]
+    cm.assert_states_equal(cs[0][1], cs[1][1], "600 frames")
+
+
+def test_empty_world_and_ragged_sizes():
+    for n in (0, 1, 64, 65, 1023, 1024, 1025, 4097):
+        g, o = _pair(max(n, 1) + 10)
+        res = []
+        for w in (g, o):
+            ids = cm.build_particles(w)
+            if n:
+                vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+                cm.spawn_particles(w, ids, n, vel, ttl)
+            c0 = w.save(); w.advance(); c1 = w.save(); w.load(0); c2 = w.save()
+            res.append((c0, c1, c2, cm.snapshot_state(w, ids)))
+        assert res[0][:3] == res[1][:3], n
+        assert res[0][0] == res[0][2], "load(0) then save must reproduce the frame-0 checksum"
+        cm.assert_states_equal(res[0][3], res[1][3], f"n={n}")
+
+
+def test_disjoint_components_and_presence_masks():
+    """benches/bench.rs:68-95 foo_bar_baz: entities with disjoint component sets; plus
+    insert/remove of a component across a rollback (component_snapshot.rs:106-115)."""
+    res = []
+    for w in _pair(4000):
+        foo = w.register_component("Foo", 4, 1); bar = w.register_component("Bar", 4, 1); baz = w.register_component("Baz", 4, 1)
+        for c in (foo, bar, baz): w.checksum_component(c, [0])
+        w.add_system(bg.SYS_ADD_U32, comp=(foo,), word=(0,), iparam=(1,))
+        w.add_system(bg.SYS_ADD_U32, comp=(bar,), word=(0,), iparam=(-1 & 0xFFFFFFFF,))
+        w.add_system(bg.SYS_ADD_U32, comp=(baz,), word=(0,), iparam=(1,))
+        v = np.arange(1000, dtype=np.uint32)
+        w.spawn(1000, {foo: [v]}); w.spawn(1000, {bar: [v]}); w.spawn(1000, {baz: [v]})
+        out = [w.save()]                              # frame 0
+        w.advance(); out.append(w.save())             # frame 1
+        w.remove_component(foo, 5); w.insert_component(bar, 5, np.array([77], np.uint32)); w.despawn(1500)
+        w.advance(); out.append(w.save())             # frame 2
+        w.load(1); out.append(w.save())               # back: foo present on 5 again, bar absent, 1500 alive
+        w.advance(); out.append(w.save())
+        res.append((out, cm.snapshot_state(w, (foo, bar, baz))))
+    assert res[0][0] == res[1][0]
+    assert res[0][0][1] == res[0][0][3]
+    cm.assert_states_equal(res[0][1], res[1][1], "disjoint")
+
+
+def test_generic_checksum_u64_words_and_mixed_specs():
+    """checksum spec over a u64 column (Ttl) and a non-prefix word subset -> generic k_checksum."""
+    res = []
+    n = 3000
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    for w in _pair(n):
+        T, V, L = cm.build_particles(w, checksum=False)
+        w2 = w
+        # registration is still open (no spawn yet)
+        w2.checksum_component(L, [0])
+        w2.checksum_component(T, [2, 0, 9, 6])
+        cm.spawn_particles(w, (T, V, L), n, vel, ttl)
+        out = []
+        for _ in range(5):
+            w.advance(); out.append(w.save())
+        res.append(out)
+    assert res[0] == res[1]
+
+
+def test_errors_match_reference_panics():
+    g = bg.World(100, max_depth=4)
+    g.register_component("X", 4, 1)
+    g.save()
+    with pytest.raises(bg.GgrsHipError) as e:
+        g.load(99)                                   # mod.rs:213 panic -> GGRS_E_NO_SNAPSHOT
+    assert e.value.code == bg.GGRS_E_NO_SNAPSHOT and "Could not rollback to 99" in str(e.value)
+    assert g.snapshot_count() == 0                   # the reference's loop popped everything first
+    with pytest.raises(bg.GgrsHipError) as e:
+        g.spawn(101, {0: None})
+    assert e.value.code == bg.GGRS_E_CAPACITY
+    with pytest.raises(bg.GgrsHipError):
+        g.register_component("late", 4, 1)           # registration after seal
+
+
+def test_full_size_properties_1m():
+    """BASELINE config 3 (1M x 3 components, depth 8): size-independent properties instead of
+    the (slow) oracle: resimulation reproduces every first-recorded checksum (the SyncTest
+    driver would raise MismatchedChecksum), load(f)+save == saved checksum, and fused ==
+    unfused kernels."""
+    n = 1_000_000
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    outs = []
+    for flags in (0, bg.GGRS_WORLD_UNFUSED):
+        w = bg.World(n, max_depth=9, flags=flags)
+        ids = cm.build_particles(w)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+        for _ in range(12):
+            drv.tick((0,))
+        outs.append(drv.all_checksums)
+        first = {}
+        for f, c in drv.all_checksums:
+            assert first.setdefault(f, c) == c
+        f_old = w.frame - 3
+        want = first[f_old]
+        w.load(f_old)
+        assert w.save() == want
+        w.close()
+    assert outs[0] == outs[1]
