@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- rollback-resim entity-frames/sec on the stress_test workload (BASELINE.json).
+
+One "step" = one SyncTest tick at depth D = 8 over N_ENT = 1M particles x 3 registered
+components (Transform 40 B + Velocity 12 B + Ttl 8 B = 60 B/entity):
+    [LoadGameState(F-8), Advance, (SaveGameState, Advance) x 7, SaveGameState(F), Advance]
+  = 1 LoadWorld + 8 SaveWorld(+checksum) + 9 AdvanceWorld          
+executed by libggrs_hip.so as ONE ggrs_hip_handle_requests call per tick.  Inputs are resident
+in HBM before the timed region; the only host traffic per tick is the 8 x 16 B checksum read-back
+that the reference's `cell.save(frame, None, Some(checksum))` needs.
+
+  value     = entities x 9 advances x steps / seconds      (whole job, all ranks)
+  roofline  = dominant kernel k_copy_state (SaveWorld snapshot copy, 8 of the 18 launches and
+              960 of the 1656 algorithmic bytes per entity-tick): 120 B x entities per launch
+              / its mean duration from HIP events on the world's stream.
+  cpu_baseline = the oracle's REFERENCE-SHAPED variant (kind "port"), 1 thread, bounded sample.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): speculative fan-out -- rank 0's
+confirmed snapshot is broadcast over RCCL/xGMI, each rank re-simulates its own predicted-input
+branch for D frames, checksums are all-gathered.  Weak scaling (per-GPU work fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ENTITY = 60          # registered payload R
+SAVE_BYTES = 2 * BYTES_PER_ENTITY      # read live + write ring
+ADV_BYTES = 64                 # r/w translation 12 + velocity 12 + ttl 8
+TICK_BYTES = lambda d: SAVE_BYTES + SAVE_BYTES * d + ADV_BYTES * (d + 1)   # 1656 at d = 8
+
+
+def build_world(bg, cm, n, depth, stream=0, flags=0):
+    w = bg.World(n, max_depth=depth + 1, stream=stream, flags=flags)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    w.set_depth(depth + 1)
+    w.set_synctest_check_distance(depth)
+    return w, ids
+
+
+def tick_requests(bg, w, depth):
+    """Steady-state SyncTest tick as a reusable ctypes array; frames patched per tick."""
+    reqs = [bg.LoadGameState(0), bg.AdvanceFrame((0,))]
+    for _ in range(depth - 1):
+        reqs += [bg.SaveGameState(0), bg.AdvanceFrame((0,))]
+    reqs += [bg.SaveGameState(0), bg.AdvanceFrame((0,))]
+    arr, keep, n_save = w.build_requests(reqs)
+    out = (C.c_uint64 * (2 * n_save))()
+    save_idx = [i for i, r in enumerate(reqs) if isinstance(r, bg.SaveGameState)]
+
+    def run(F):
+        arr[0].frame = F - depth
+        for k, i in enumerate(save_idx):
+            arr[i].frame = F - depth + 1 + k
+        w.handle_requests_raw(arr, len(reqs), out)
+        return out
+    return run, keep
+
+
+def warm_ring(bg, w, depth):
+    """Frames 0..depth: plain Save+Advance ticks so that Load(F-depth) has a snapshot."""
+    for _ in range(depth + 1):
+        w.handle_requests([bg.SaveGameState(w.frame), bg.AdvanceFrame((0,))])
+
+
+def cpu_baseline(n, depth, budget_ticks):
+    from oracle.binding import REFSHAPED, OracleWorld, lib
+    import common as cm
+    w = OracleWorld(n, depth + 1, REFSHAPED)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    w.set_depth(depth + 1)
+    lib.gor_set_num_threads(1)
+    secs = w.bench_synctest(depth, depth + 1, budget_ticks)
+    return {"value": n * (depth + 1) * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{budget_ticks} steady-state SyncTest ticks (depth {depth}) of the same {n}-entity x 3-component "
+                      f"world on the oracle's reference-shaped storage (per-save HashMap rebuild), {secs:.1f} s",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--entities", type=int, default=1_000_000)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ticks", type=int, default=3)
+    ap.add_argument("--unfused", action="store_true")
+    ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    import bevy_ggrs_amd as bg
+    import common as cm
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (4 if args.nt else 0)
+
+    if world_size == 1:
+        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags)
+        warm_ring(bg, w, D)
+        run, _keep = tick_requests(bg, w, D)
+        for _ in range(W):
+            run(w.frame)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            run(w.frame)
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        live = w.active_count()
+        # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
+        w.profile_enable(True)
+        for _ in range(min(K, 50)):
+            run(w.frame)
+        prof = w.profile_read()
+        w.profile_enable(False)
+        total_entities = live
+    else:
+        from bevy_ggrs_amd.fanout import SpeculativeFanout
+        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags)
+        fan = SpeculativeFanout(w, dist, depth=D, device=torch.device("cuda", dev))
+        for _ in range(W):
+            fan.step()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fan.step()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        t = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+        live = w.active_count()
+        cnt = torch.tensor([live], dtype=torch.int64, device=f"cuda:{dev}")
+        dist.all_reduce(cnt)
+        total_entities = int(cnt.item())
+        w.profile_enable(True)
+        for _ in range(min(K, 20)):
+            fan.step()
+        prof = w.profile_read()
+        w.profile_enable(False)
+
+    value = total_entities * (D + 1) * K / secs
+    save_ms, save_n = prof["save"]
+    adv_ms, adv_n = prof["advance"]
+    load_ms, load_n = prof["load"]
+    save_avg_s = save_ms / max(save_n, 1) * 1e-3
+    achieved = SAVE_BYTES * live / save_avg_s / 1e9 if save_n else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_copy_state_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak",
+        "value": value, "unit": "entity-frames/s", "n_gpus": world_size, "steps": K, "warmup": W,
+        "ms_per_step": secs / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+        "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
+                               f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
+                   "entities_per_gpu": live, "depth": D,
+                   "parallelism": "single GPU" if world_size == 1 else f"speculative fan-out, 1 branch per rank x {world_size} ranks",
+                   "fused": not args.unfused},
+        "roofline": {"bound": "hbm", "kernel": "k_copy_state (SaveWorld)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": SAVE_BYTES * live,
+                     "avg_launch_us": save_avg_s * 1e6, "launches_timed": save_n,
+                     "other_kernels": {
+                         "k_particles_step (AdvanceWorld)": {"avg_launch_us": adv_ms / max(adv_n, 1) * 1e3,
+                                                            "achieved_GBps": ADV_BYTES * live / (adv_ms / max(adv_n, 1) * 1e-3) / 1e9 if adv_n else 0.0},
+                         "k_copy_state (LoadWorld)": {"avg_launch_us": load_ms / max(load_n, 1) * 1e3,
+                                                     "achieved_GBps": SAVE_BYTES * live / (load_ms / max(load_n, 1) * 1e-3) / 1e9 if load_n else 0.0}},
+                     "whole_tick_achieved_GBps": TICK_BYTES(D) * live * K / secs / 1e9 * (1 if world_size == 1 else 1),
+                     "whole_tick_frac": TICK_BYTES(D) * live * K / secs / 1e9 / HBM_PEAK_GBS},
+    }
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(n, D, args.cpu_ticks)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

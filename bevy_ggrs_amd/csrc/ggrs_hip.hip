@@ -98,6 +98,7 @@ struct ggrs_world {
     std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
 
     // ---- profiling
+    bool nt_copy = false;               // non-temporal loads/stores in k_copy_state (A/B knob)
     bool prof = false;
     std::vector<EventPair> prof_events;
     double prof_ms[GGRS_KERNEL_CLASSES] = {0, 0, 0, 0};
@@ -287,12 +288,17 @@ Header header_of(const ggrs_world* w) {
     return h;
 }
 
-int launch_copy(ggrs_world* w, const Block& src, Block& dst, uint64_t len, uint32_t cls) {
+FinalizeArgs no_finalize() { FinalizeArgs f; memset(&f, 0, sizeof f); return f; }
+
+int launch_copy(ggrs_world* w, const Block& src, Block& dst, uint64_t len, uint32_t cls, const FinalizeArgs& fin) {
     const uint64_t cover = std::max(std::max(src.dirty_len, dst.dirty_len), len);
     const uint32_t g = std::max(1u, tiles_for(cover));
     {
         ProfScope ps(w, cls);
-        hipLaunchKernelGGL(k_copy_state, dim3(g), dim3(TPB), 0, w->stream, (const uint8_t*)src.ptr, dst.ptr, w->plan, len, header_of(w));
+        if (w->nt_copy)
+            hipLaunchKernelGGL((k_copy_state<true>), dim3(g), dim3(TPB), 0, w->stream, (const uint8_t*)src.ptr, dst.ptr, w->plan, len, header_of(w), fin);
+        else
+            hipLaunchKernelGGL((k_copy_state<false>), dim3(g), dim3(TPB), 0, w->stream, (const uint8_t*)src.ptr, dst.ptr, w->plan, len, header_of(w), fin);
     }
     HIPCHK(w, hipGetLastError());
     dst.dirty_len = src.dirty_len;
@@ -313,13 +319,14 @@ int launch_checksum(ggrs_world* w) {
     return GGRS_OK;
 }
 
-int launch_finalize(ggrs_world* w, uint32_t result_idx) {
-    ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, w->stream, (const uint64_t*)w->d_parts,
-                       (const uint64_t*)w->cks_args.part_cnt, w->cks_args.n_cks, w->part_stride, w->pending_parts,
-                       w->len, w->d_results + 2 * (uint64_t)result_idx, (Header*)w->live.ptr);
-    HIPCHK(w, hipGetLastError());
-    return GGRS_OK;
+FinalizeArgs finalize_args(ggrs_world* w, uint32_t result_idx) {
+    FinalizeArgs f; memset(&f, 0, sizeof f);
+    f.parts = w->d_parts; f.part_cnt = w->cks_args.part_cnt;
+    f.n_cks = w->cks_args.n_cks; f.part_stride = w->part_stride; f.n_parts = w->pending_parts; f.enabled = 1;
+    f.total_len = w->len;
+    f.out = w->d_results + 2 * (uint64_t)result_idx;
+    f.live_hdr = (Header*)w->live.ptr;
+    return f;
 }
 
 // ---- ring: exact mirror of GgrsSnapshots::{push,confirm,rollback} over slot indices
@@ -358,12 +365,19 @@ int do_save(ggrs_world* w, uint32_t result_idx) {
     int rc = seal(w); if (rc) return rc;
     // SaveWorldSystems::Checksum -> ChecksumPlugin::update
     if (!w->pending_valid) { rc = launch_checksum(w); if (rc) return rc; }
-    rc = launch_finalize(w, result_idx); if (rc) return rc;
+    // ChecksumPlugin::update (fold) runs inside workgroup 0 of the snapshot copy kernel
+    const FinalizeArgs fin = finalize_args(w, result_idx);
     // SaveWorldSystems::Snapshot: sync_depth (caller) -> discard_old_snapshots -> save
     if (w->has_confirmed) ring_confirm(w, w->confirmed);
     int s = -1;
     rc = ring_push(w, w->frame, &s); if (rc) return rc;
-    if (s >= 0) { rc = launch_copy(w, w->live, w->slots[s], w->len, GGRS_KERNEL_SAVE); if (rc) return rc; }
+    if (s >= 0) { rc = launch_copy(w, w->live, w->slots[s], w->len, GGRS_KERNEL_SAVE, fin); if (rc) return rc; }
+    else {
+        // depth 0: nothing is stored, but the checksum is still due -> copy live onto itself
+        // (no rows: len 0) just to run the fold
+        Block self = w->live;
+        rc = launch_copy(w, w->live, self, 0, GGRS_KERNEL_SAVE, fin); if (rc) return rc;
+    }
     return GGRS_OK;
 }
 
@@ -377,7 +391,7 @@ int do_load(ggrs_world* w, int32_t frame) {
     // entity.rs:55-99 + component_snapshot.rs:95-123 + RollbackOrdered restore (mod.rs:342):
     // masks, columns and len of the live block := the snapshot's
     w->len = s.len;
-    rc = launch_copy(w, s, w->live, s.len, GGRS_KERNEL_LOAD); if (rc) return rc;
+    rc = launch_copy(w, s, w->live, s.len, GGRS_KERNEL_LOAD, no_finalize()); if (rc) return rc;
     w->pending_valid = false;
     return GGRS_OK;
 }
@@ -596,6 +610,7 @@ int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
     w->device = d->device; w->capacity = d->capacity; w->cap_pad = align_up(d->capacity, TILE);
     w->max_depth = d->max_depth ? d->max_depth : 8; w->flags = d->flags;
     w->depth = w->max_depth;
+    w->nt_copy = (d->flags & GGRS_WORLD_NT_COPY) != 0;
     if (d->stream) w->stream = (hipStream_t)d->stream;
     else {
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return GGRS_E_HIP; }

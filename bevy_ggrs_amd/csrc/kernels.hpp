@@ -126,37 +126,105 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
     return x;
 }
 
+// ------------------------------------------------------------------ finalize (device function)
+// Hash each component's XOR once more (component_checksum.rs:92-95), add the entity part
+// (entity_checksum.rs:29-52), XOR-fold all parts (checksum.rs:88-99).  Runs inside workgroup 0
+// of the SaveWorld copy kernel (the partials were completed by the previous kernel on the
+// stream), so a SaveWorld is ONE launch.
+struct FinalizeArgs {
+    const uint64_t* parts;      // [n_cks][part_stride]
+    const uint64_t* part_cnt;   // [part_stride]
+    uint32_t n_cks, part_stride, n_parts, enabled;
+    uint64_t total_len;
+    uint64_t* out;              // {lo, hi} of Checksum(u128)
+    Header* live_hdr;
+};
+constexpr int MAX_CKS = 16;
+
+__device__ __forceinline__ void finalize_block(const FinalizeArgs& f, uint64_t* checksum_out) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint64_t fin_sx[MAX_CKS + 1];
+    // one partial column per wave at a time (wave-uniform control flow, loads pipelined)
+    for (uint32_t k = wave; k <= f.n_cks; k += 4) {
+        const bool is_cnt = (k == f.n_cks);
+        const uint64_t* __restrict__ p = is_cnt ? f.part_cnt : f.parts + (uint64_t)k * f.part_stride;
+        uint64_t x = 0, sum = 0;
+#pragma unroll 8
+        for (uint32_t i = lane; i < f.n_parts; i += 64) { const uint64_t v = p[i]; x ^= v; sum += v; }
+        x = wave_xor(x);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) fin_sx[k] = is_cnt ? sum : x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t total = 0;
+        for (uint32_t k = 0; k < f.n_cks; ++k) total ^= sea_one(fin_sx[k]);
+        const uint64_t active = fin_sx[f.n_cks];
+        total ^= sea_pair(active, f.total_len);      // hash(active, total): same shape as pair()
+        f.out[0] = total; f.out[1] = 0;              // `as u128` of a u64: upper half always 0
+        f.live_hdr->active = active;
+        f.live_hdr->checksum[0] = total; f.live_hdr->checksum[1] = 0;
+        checksum_out[0] = total; checksum_out[1] = active;
+    }
+}
+
 // ------------------------------------------------------------------ k_copy_state
 // SaveWorld's Snapshot set (component_snapshot.rs:66-84, entity.rs:39-51, ring push
 // mod.rs:147-181) and LoadWorld's Entity+Data sets (entity.rs:55-99,
 // component_snapshot.rs:95-123, ring rollback mod.rs:210-226) both reduce to: copy every
 // registered word column over [0, len) plus the liveness/presence masks between the live
 // block and a ring slot.  Algorithmic traffic: 2 x (bytes per slot) per entity.
+//
+// Full tiles take a branch-free path: rows are moved in straight-line batches of 8/4/2/1
+// (every load of a batch in flight before its first store -- a per-lane predicate around a
+// load makes hipcc drain vmcnt after every single load).  Only the last, ragged tile uses the
+// predicated path.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int B, bool NT>
+__device__ __forceinline__ void copy_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                          const CopyPlan& plan, uint32_t r0, uint32_t t, uint32_t tid) {
+    u32x4 v[B];
+    uint64_t pos[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const RowDesc rd = plan.row[r0 + j];
+        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        if (NT) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + pos[j]));
+        else v[j] = *reinterpret_cast<const u32x4*>(src + pos[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(dst + pos[j]));
+        else *reinterpret_cast<u32x4*>(dst + pos[j]) = v[j];
+    }
+}
+
+template <bool NT>
 __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ src,
                                                     uint8_t* __restrict__ dst, CopyPlan plan,
-                                                    uint64_t len, Header hdr) {
+                                                    uint64_t len, Header hdr, FinalizeArgs fin) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x;
-    constexpr int B = 8;
-    for (uint32_t r0 = 0; r0 < plan.n_rows; r0 += B) {
-        uint4 v[B];
-        bool ok[B];
-#pragma unroll
-        for (int j = 0; j < B; ++j) {
-            ok[j] = false;
-            if (r0 + j < plan.n_rows) {
-                const RowDesc rd = plan.row[r0 + j];
-                const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
-                ok[j] = pos < len * rd.word_bytes;
-                if (ok[j]) v[j] = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < B; ++j) {
-            if (ok[j]) {
-                const RowDesc rd = plan.row[r0 + j];
-                const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
-                *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = v[j];
-            }
+    __shared__ uint64_t cks[2];
+    if (t == 0 && fin.enabled) finalize_block(fin, cks);       // workgroup-uniform branch
+
+    const uint32_t n_rows = plan.n_rows;
+    if (((uint64_t)t + 1) * TILE <= len) {
+        uint32_t r = 0;
+        for (; r + 8 <= n_rows; r += 8) copy_rows<8, NT>(src, dst, plan, r, t, tid);
+        if (r + 4 <= n_rows) { copy_rows<4, NT>(src, dst, plan, r, t, tid); r += 4; }
+        if (r + 2 <= n_rows) { copy_rows<2, NT>(src, dst, plan, r, t, tid); r += 2; }
+        if (r < n_rows) copy_rows<1, NT>(src, dst, plan, r, t, tid);
+    } else {
+        for (uint32_t r = 0; r < n_rows; ++r) {
+            const RowDesc rd = plan.row[r];
+            const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+            if (pos < len * rd.word_bytes)
+                *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
         }
     }
     // masks: 16 u64 words per tile per mask (copied whole, so stale bits beyond the source's
@@ -166,7 +234,13 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
         const uint64_t o = plan.mask_off[m] + ((uint64_t)t * 16 + wi) * 8;
         *reinterpret_cast<uint64_t*>(dst + o) = *reinterpret_cast<const uint64_t*>(src + o);
     }
-    if (t == 0 && tid == 0) *reinterpret_cast<Header*>(dst) = hdr;
+    if (t == 0) {
+        if (fin.enabled) __syncthreads();
+        if (tid == 0) {
+            if (fin.enabled) { hdr.checksum[0] = cks[0]; hdr.checksum[1] = 0; hdr.active = cks[1]; }
+            *reinterpret_cast<Header*>(dst) = hdr;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ k_particles_step
@@ -175,8 +249,12 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
 //   despawn_particles (particles.rs:282-289)  ttl -= 1 ; ttl == 0 -> despawn
 // and, because translation and velocity are already in registers, the per-entity part of
 // ComponentChecksumPlugin::update (component_checksum.rs:77-90) for the NEXT SaveWorld:
-// per-workgroup XOR partials + live count, folded later by k_finalize.
+// per-workgroup XOR partials + live count, folded later by finalize_block.
 // Algorithmic traffic: 64 B per live entity (12+12+8 read, same written).
+//
+// All 4 mask loads and all 8 column loads of a lane are issued unconditionally and together
+// (slots up to the padded capacity are always mapped); per-entity conditions are selects, and
+// only wave-uniform conditions guard the stores.
 template <bool UPD, bool TTL, bool CKS_T, bool CKS_V>
 __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -184,37 +262,37 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     const uint64_t w0 = (uint64_t)t * 16 + wave * 4;                 // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
     const uint64_t wi = w0 + (lane >> 4);
+    constexpr bool NEED_T = UPD || CKS_T, NEED_V = UPD || CKS_V;
 
+    // ---- every load of the tile, back to back
     const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.state + a.off_alive + wi * 8);
-    const uint32_t n_alive = (uint32_t)(alive_w >> sh) & 0xFu;
-    uint32_t n_T = 0, n_V = 0, n_L = 0;
-    if (UPD || CKS_T) n_T = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pT + wi * 8) >> sh) & 0xFu;
-    if (UPD || CKS_V) n_V = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pV + wi * 8) >> sh) & 0xFu;
-    if (TTL) n_L = (uint32_t)(*reinterpret_cast<const uint64_t*>(a.state + a.off_pL + wi * 8) >> sh) & 0xFu;
-
-    const uint32_t m_upd = UPD ? (n_alive & n_T & n_V) : 0u;   // Query<(&mut Transform,&mut Velocity)>
-    const uint32_t m_ttl = TTL ? (n_alive & n_L) : 0u;         // Query<(Entity,&mut Ttl)>
-    const uint32_t need_T = m_upd | (CKS_T ? (n_alive & n_T) : 0u);
-    const uint32_t need_V = m_upd | (CKS_V ? (n_alive & n_V) : 0u);
-
+    uint64_t pT_w = 0, pV_w = 0, pL_w = 0;
+    if (NEED_T) pT_w = *reinterpret_cast<const uint64_t*>(a.state + a.off_pT + wi * 8);
+    if (NEED_V) pV_w = *reinterpret_cast<const uint64_t*>(a.state + a.off_pV + wi * 8);
+    if (TTL) pL_w = *reinterpret_cast<const uint64_t*>(a.state + a.off_pL + wi * 8);
     float4 tx[3], vv[3];
     ulonglong2 tl[2];
-    // ---- issue every load of the tile before the first dependent use
-    if (need_T) {
+    if (NEED_T) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.state + a.off_t[k] + e0 * 4);
     }
-    if (need_V) {
+    if (NEED_V) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.state + a.off_v[k] + e0 * 4);
     }
-    if (m_ttl) {
+    if (TTL) {
         tl[0] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8);
         tl[1] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16);
     }
 
-    // ---- update_particles
-    if (m_upd) {
+    const uint32_t n_alive = (uint32_t)(alive_w >> sh) & 0xFu;
+    const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu,
+                   n_L = (uint32_t)(pL_w >> sh) & 0xFu;
+    const uint32_t m_upd = UPD ? (n_alive & n_T & n_V) : 0u;   // Query<(&mut Transform,&mut Velocity)>
+    const uint32_t m_ttl = TTL ? (n_alive & n_L) : 0u;         // Query<(Entity,&mut Ttl)>
+
+    // ---- update_particles (selects, no per-lane branches)
+    if (UPD) {
         const float dt = __uint_as_float(a.dt_bits);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -223,33 +301,37 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
             float* v = reinterpret_cast<float*>(&vv[k]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if ((m_upd >> j) & 1u) {
-                    const float nv = __fadd_rn(v[j], gd);             // **velocity += ...
-                    v[j] = nv;
-                    x[j] = __fadd_rn(x[j], __fmul_rn(nv, dt));        // translation += **velocity * time_step
-                }
+                const bool on = (m_upd >> j) & 1u;
+                const float nv = __fadd_rn(v[j], gd);                       // **velocity += ...
+                const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));        // translation += **velocity * time_step
+                v[j] = on ? nv : v[j];
+                x[j] = on ? nx : x[j];
             }
         }
+        if (__ballot(m_upd != 0) != 0) {                      // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            *reinterpret_cast<float4*>(a.state + a.off_t[k] + e0 * 4) = tx[k];
-            *reinterpret_cast<float4*>(a.state + a.off_v[k] + e0 * 4) = vv[k];
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<float4*>(a.state + a.off_t[k] + e0 * 4) = tx[k];
+                *reinterpret_cast<float4*>(a.state + a.off_v[k] + e0 * 4) = vv[k];
+            }
         }
     }
 
     // ---- despawn_particles
     uint32_t kill = 0;
-    if (m_ttl) {
+    if (TTL) {
         uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if ((m_ttl >> j) & 1u) {
-                q[j] -= 1;                                   // usize, wrapping
-                if (q[j] == 0) kill |= 1u << j;
-            }
+            const bool on = (m_ttl >> j) & 1u;
+            const uint64_t nq = q[j] - 1;                    // usize, wrapping
+            q[j] = on ? nq : q[j];
+            kill |= (on && nq == 0) ? (1u << j) : 0u;
         }
-        *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8) = tl[0];
-        *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16) = tl[1];
+        if (__ballot(m_ttl != 0) != 0) {
+            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8) = tl[0];
+            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16) = tl[1];
+        }
     }
     const uint32_t n_new = n_alive & ~kill;
 
@@ -281,14 +363,18 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t order = e0 + j;                   // RollbackOrdered::order == slot
-            if ((c_T >> j) & 1u)
-                hT ^= sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
-                                                 __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
-                                                 __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
-            if ((c_V >> j) & 1u)
-                hV ^= sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
-                                                 __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
-                                                 __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+            if (CKS_T) {
+                const uint64_t h = sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                              __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                              __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+                hT ^= ((c_T >> j) & 1u) ? h : 0ULL;
+            }
+            if (CKS_V) {
+                const uint64_t h = sea_pair(order, sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                              __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                              __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+                hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
+            }
         }
         __shared__ uint64_t sT[4], sV[4];
         __shared__ uint32_t sC[4];
@@ -340,46 +426,6 @@ __global__ __launch_bounds__(TPB) void k_checksum(CksArgs a, const UnitDesc* __r
     if (tid == 0) {
         if (a.n_cks) a.parts[(uint64_t)k * a.part_stride + t] = sH[0] ^ sH[1] ^ sH[2] ^ sH[3];
         if (k == 0) a.part_cnt[t] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
-    }
-}
-
-// ------------------------------------------------------------------ k_finalize
-// Hash each component's XOR once more (component_checksum.rs:92-95), add the entity part
-// (entity_checksum.rs:29-52), XOR-fold all parts (checksum.rs:88-99).  One workgroup.
-__global__ __launch_bounds__(TPB) void k_finalize(const uint64_t* __restrict__ parts,
-                                                  const uint64_t* __restrict__ part_cnt,
-                                                  uint32_t n_cks, uint32_t part_stride, uint32_t n_parts,
-                                                  uint64_t total_len, uint64_t* __restrict__ out,
-                                                  Header* __restrict__ live_hdr) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    __shared__ uint64_t sx[4];
-    __shared__ uint64_t acc;
-    if (tid == 0) acc = 0;
-    __syncthreads();
-    for (uint32_t k = 0; k <= n_cks; ++k) {          // k == n_cks: the count column
-        uint64_t v = 0;
-        const uint64_t* p = (k < n_cks) ? parts + (uint64_t)k * part_stride : part_cnt;
-        for (uint32_t i = tid; i < n_parts; i += TPB) { if (k < n_cks) v ^= p[i]; else v += p[i]; }
-        if (k < n_cks) v = wave_xor(v);
-        else {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        }
-        if (lane == 0) sx[wave] = v;
-        __syncthreads();
-        if (tid == 0) {
-            if (k < n_cks) acc ^= sea_one(sx[0] ^ sx[1] ^ sx[2] ^ sx[3]);
-            else {
-                const uint64_t active = sx[0] + sx[1] + sx[2] + sx[3];
-                acc ^= sea_pair(active, total_len);      // hash(active, total) has the same shape
-                live_hdr->active = active;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        out[0] = acc; out[1] = 0;       // `as u128` of a u64: upper half is always 0
-        live_hdr->checksum[0] = acc; live_hdr->checksum[1] = 0;
     }
 }
 

@@ -66,6 +66,7 @@ typedef struct {
 #define GGRS_WORLD_DEFAULT      0u
 #define GGRS_WORLD_NO_GRAPH     1u   /* never capture request batches into hipGraphs           */
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
+#define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 
 int  ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggrs_world** out);
 int  ggrs_hip_world_create_ex(const ggrs_world_desc* desc, ggrs_world** out);
