@@ -150,9 +150,20 @@ def main():
         w.profile_enable(False)
         total_entities = live
     else:
-        from bevy_ggrs_amd.fanout import SpeculativeFanout
-        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags)
-        fan = SpeculativeFanout(w, dist, depth=D, device=torch.device("cuda", dev))
+        from bevy_ggrs_amd.fanout import HipStateExchange, SpeculativeFanout, make_torch_world
+        # every rank provisions the same world shape; only rank 0 owns the confirmed world, the
+        # others receive it through ONE RCCL broadcast of the packed state block
+        tdev = torch.device("cuda", dev)
+        w, arena = make_torch_world(bg, n, D + 2, 3, BYTES_PER_ENTITY, tdev, flags=flags)
+        ids = cm.build_particles(w)
+        if rank == 0:
+            vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+            cm.spawn_particles(w, ids, n, vel, ttl)
+        else:
+            w.spawn(0, {})                                   # seals the world (layout fixed)
+        fan = SpeculativeFanout(w, dist, depth=D, exchange=HipStateExchange(w, arena),
+                                branches_per_rank=1)
+        fan.sync_confirmed(0)
         for _ in range(W):
             fan.step()
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()

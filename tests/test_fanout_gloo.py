@@ -1,0 +1,180 @@
+"""N > 1 path on CPU: SpeculativeFanout's control flow (branch assignment, request lists,
+replicated confirmed advance, the single all-gather, desync detection) with world_size 2 over
+gloo.  The worlds here are oracle worlds (test infrastructure); the packed-state broadcast is
+replaced by a host-side exchange with the same contract.  The HIP/RCCL exchange itself is
+covered by tests/test_gpu_fanout.py (world_size 1 over nccl on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class HostExchange:
+    """Same contract as bevy_ggrs_amd.fanout.HipStateExchange, over host arrays + gloo."""
+
+    def __init__(self, world, ids):
+        self.world, self.ids = world, ids
+
+    def broadcast(self, d, src):
+        w = self.world
+        box = [None]
+        if d.get_rank() == src:
+            n = w.len
+            st = {"len": n, "frame": w.frame, "alive": w.alive_mask(n)}
+            for cid in self.ids:
+                _, wb, nw = w._comps[cid]
+                st[f"p{cid}"] = w.present_mask(cid, n)
+                for k in range(nw):
+                    st[f"c{cid}w{k}"] = w.download_word(cid, k, 0, n)
+            box = [st]
+        d.broadcast_object_list(box, src=src)
+        st = box[0]
+        if d.get_rank() != src:
+            n = st["len"]
+            assert w.len <= n
+            if w.len < n:
+                w.spawn(n - w.len, {cid: None for cid in self.ids})
+            for cid in self.ids:
+                _, wb, nw = w._comps[cid]
+                for k in range(nw):
+                    w.upload_word(cid, k, 0, st[f"c{cid}w{k}"])
+                for s in np.nonzero(~st[f"p{cid}"])[0]:
+                    w.remove_component(cid, int(s))
+            for s in np.nonzero(~st["alive"])[0]:
+                w.despawn(int(s))
+            w.set_frame(st["frame"])
+
+    def all_gather_u64(self, d, values):
+        t = torch.from_numpy(values.view(np.int64).copy())
+        out = [torch.empty_like(t) for _ in range(d.get_world_size())]
+        d.all_gather(out, t)
+        return torch.stack(out).numpy().view(np.uint64)
+
+
+def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        import common as cm
+        from bevy_ggrs_amd.fanout import DesyncDetected, SpeculativeFanout
+        from bevy_ggrs_amd import SaveGameState as bg_SaveGameState
+        from oracle.binding import OracleWorld
+        cap = n + 100 * (steps + D + 2) * 2
+        w = OracleWorld(cap, D + 1)
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
+        if rank == 0:                              # only the root owns the confirmed world
+            vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+            cm.spawn_particles(w, ids, n, vel, ttl)
+            for _ in range(3):
+                w.advance((0,))
+        fn = cm.frame_spawn_fn(50)
+        # branches: even ids press INPUT_SPAWN; the confirmed input presses on odd frames
+        fan = SpeculativeFanout(w, dist, D, HostExchange(w, ids), branches_per_rank=bpr,
+                                branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
+                                confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
+                                spawn_fn=fn)
+        out = []
+        err = None
+        for s in range(steps):
+            if corrupt and s == corrupt and rank == 1:
+                # replica drifts: a live particle's velocity changes and the confirmed snapshot is re-saved
+                w.upload_word(ids[1], 0, 250, np.array([0x3f800000], dtype=np.uint32))
+                w.handle_requests([bg_SaveGameState(w.frame)])
+            try:
+                out.append(fan.step())
+            except DesyncDetected as e:
+                err = ("desync", e.frame, len(set(e.checksums)))
+                break
+        q.put((rank, out, err, cm.snapshot_state(w, ids) if err is None else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world_size, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    args = (world_size, port, kw["n"], kw["D"], kw["bpr"], kw["steps"], kw.get("corrupt", 0), q)
+    procs = [ctx.Process(target=_worker, args=(r,) + args) for r in range(world_size)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def _serial_reference(n, D, n_branches, steps):
+    """The same fan-out computed by ONE process walking every branch (no collectives)."""
+    import common as cm
+    from oracle.binding import OracleWorld
+    import bevy_ggrs_amd as bg
+    cap = n + 100 * (steps + D + 2) * 2
+    w = OracleWorld(cap, D + 1)
+    ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    for _ in range(3):
+        w.advance((0,))
+    w.set_depth(D + 1)
+    fn = cm.frame_spawn_fn(50)
+
+    def adv(frame, inp):
+        a = bg.AdvanceFrame((inp,))
+        if inp & cm.INPUT_SPAWN:
+            a.spawn_vx, a.spawn_vy = fn(frame)
+        return a
+    w.set_confirmed(w.frame)
+    w.handle_requests([bg.SaveGameState(w.frame)])
+    C = w.frame
+    out = []
+    for _ in range(steps):
+        per_branch = {}
+        for b in range(n_branches):
+            reqs = [bg.LoadGameState(C)]
+            for i in range(D):
+                reqs += [adv(C + i, cm.INPUT_SPAWN if b % 2 == 0 else 0), bg.SaveGameState(C + i + 1)]
+            per_branch[b] = w.handle_requests(reqs)
+        cs = w.handle_requests([bg.LoadGameState(C), adv(C, cm.INPUT_SPAWN if C % 2 == 1 else 0), bg.SaveGameState(C + 1)])
+        C += 1
+        w.set_confirmed(C)
+        out.append({"confirmed_frame": C, "confirmed_checksum": cs[0], "branch_checksums": per_branch})
+    return out, cm.snapshot_state(w, ids)
+
+
+@pytest.mark.parametrize("bpr", [1, 3])
+def test_fanout_two_ranks_matches_serial_walk(bpr):
+    n, D, steps = 700, 4, 6
+    res = _run(2, n=n, D=D, bpr=bpr, steps=steps)
+    ref, ref_state = _serial_reference(n, D, 2 * bpr, steps)
+    import common as cm
+    for rank, out, err, state in res:
+        assert err is None
+        assert len(out) == steps
+        for got, want in zip(out, ref):
+            assert got["confirmed_frame"] == want["confirmed_frame"]
+            assert got["confirmed_checksum"] == want["confirmed_checksum"]
+            assert got["branch_checksums"] == want["branch_checksums"]      # every rank sees every branch
+        cm.assert_states_equal(state, ref_state, f"rank {rank}")
+    # branches with different inputs really diverge, same inputs agree
+    last = res[0][1][-1]["branch_checksums"]
+    assert last[0] != last[1]
+    if bpr == 3:
+        assert last[0] == last[2] == last[4] and last[1] == last[3] == last[5]
+    # adoption happens on the rank whose last branch predicted the confirmed input
+    assert any(o["adopted"] for _, out, _, _ in res for o in out)
+
+
+def test_fanout_detects_replica_desync():
+    res = _run(2, n=300, D=3, bpr=1, steps=5, corrupt=2)
+    for rank, out, err, _ in res:
+        assert err is not None and err[0] == "desync" and err[2] == 2, (rank, err)
+        assert len(out) == 2
