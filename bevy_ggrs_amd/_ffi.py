@@ -21,6 +21,8 @@ GGRS_E_NO_DEVICE = -5
 GGRS_WORLD_DEFAULT = 0
 GGRS_WORLD_NO_GRAPH = 1
 GGRS_WORLD_UNFUSED = 2
+GGRS_WORLD_NT_COPY = 4
+GGRS_WORLD_NO_GROUPS = 8
 
 SYS_PARTICLES_UPDATE = 1
 SYS_TTL_DESPAWN = 2
@@ -30,7 +32,7 @@ SYS_SAT_SUB_DESPAWN = 5
 
 REQ_SAVE, REQ_LOAD, REQ_ADVANCE = 1, 2, 3
 
-KERNEL_SAVE, KERNEL_LOAD, KERNEL_ADVANCE, KERNEL_CHECKSUM, KERNEL_CLASSES = 0, 1, 2, 3, 4
+KERNEL_SAVE, KERNEL_LOAD, KERNEL_ADVANCE, KERNEL_CHECKSUM, KERNEL_TICK, KERNEL_CLASSES = 0, 1, 2, 3, 4, 5
 
 
 class WorldDesc(C.Structure):
@@ -97,12 +99,34 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime():
+    """ONE HIP runtime per process.  torch wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, referenced by torch as plain `libamdhip64.so`); libggrs_hip.so needs
+    `libamdhip64.so.7`.  If our library is loaded before torch, the loader would map /opt/rocm's copy
+    for us and torch's copy for torch -- two runtimes, and the second one to initialise sees no
+    device.  Mapping torch's copy first (when torch is installed; it is not imported here) makes both
+    resolve to the same file regardless of import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C bevy_ggrs_amd/csrc`). "
             "bevy_ggrs_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol

@@ -84,6 +84,11 @@ struct ggrs_world {
     int f_T = -1, f_V = -1, f_L = -1, f_spawn = -1; uint32_t f_tw = 0, f_vw = 0;
     bool f_cksT = false, f_cksV = false;
     float f_g[3] = {0, 0, 0};
+    // fused request groups (k_tick): the schedule is exactly the particles systems over three
+    // distinct components and every checksum spec is one the kernel computes in registers
+    bool tick_ok = false; uint32_t f_lw = 0;
+    TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
+    uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
 
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
@@ -101,8 +106,8 @@ struct ggrs_world {
     bool nt_copy = false;               // non-temporal loads/stores in k_copy_state (A/B knob)
     bool prof = false;
     std::vector<EventPair> prof_events;
-    double prof_ms[GGRS_KERNEL_CLASSES] = {0, 0, 0, 0};
-    uint64_t prof_n[GGRS_KERNEL_CLASSES] = {0, 0, 0, 0};
+    double prof_ms[GGRS_KERNEL_CLASSES] = {};
+    uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -236,8 +241,39 @@ int seal(ggrs_world* w) {
         if (!all) w->f_cksT = w->f_cksV = false;
     }
 
+    // ---- fused request groups
+    w->tick_ok = false;
+    if (w->fused_ok && !(w->flags & GGRS_WORLD_NO_GROUPS) && w->f_T != w->f_V && w->f_T != w->f_L && w->f_V != w->f_L &&
+        (w->fused_cks || w->cks_comp.empty())) {
+        for (auto& sd : w->systems) if (sd.kind == GGRS_SYS_TTL_DESPAWN) w->f_lw = sd.word[0];
+        TickArgs& a = w->tick_proto;
+        memset(&a, 0, sizeof a);
+        const Comp& T = w->comps[w->f_T]; const Comp& V = w->comps[w->f_V]; const Comp& L = w->comps[w->f_L];
+        a.off_alive = w->off_alive;
+        a.off_pT = w->off_present[w->f_T]; a.off_pV = w->off_present[w->f_V]; a.off_pL = w->off_present[w->f_L];
+        for (int k = 0; k < 3; ++k) {
+            a.off_t[k] = w->col_off[T.col_base + w->f_tw + k];
+            a.off_v[k] = w->col_off[V.col_base + w->f_vw + k];
+            a.g[k] = w->f_g[k];
+        }
+        a.off_ttl = w->col_off[L.col_base + w->f_lw];
+        for (uint32_t c = 0; c < w->comps.size(); ++c)
+            if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
+        for (size_t k = 0; k < w->col_off.size(); ++k) {
+            const uint64_t co = w->col_off[k];
+            bool owned = (co == a.off_ttl);
+            for (int j = 0; j < 3; ++j) owned |= (co == a.off_t[j]) || (co == a.off_v[j]);
+            if (owned) continue;
+            const uint32_t wb = w->col_wb[k];
+            for (uint32_t r = 0; r < wb / 4; ++r) a.rest[a.n_rest_rows++] = RowLite{co, r * 4096, TILE * wb};
+        }
+        w->tick_ok = true;
+    }
+
     // ---- arena carve
     const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
+    w->tick_part_stride = 4 * n_tiles;
+    const uint64_t tick_parts_bytes = align_up((uint64_t)MAX_TICK_SAVES * 3 * w->tick_part_stride * 8, ALIGN);
     w->part_stride = n_tiles + 4096 / 1;            // + room for spawn partial blocks
     const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
     w->max_results = 1024;
@@ -245,7 +281,7 @@ int seal(ggrs_world* w) {
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
-    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
@@ -257,6 +293,7 @@ int seal(ggrs_world* w) {
     w->slots.resize(w->max_depth);
     for (uint32_t i = 0; i < w->max_depth; ++i) { w->slots[i].ptr = p; p += w->state_bytes; w->free_slots.push_back((int)(w->max_depth - 1 - i)); }
     w->d_parts = (uint64_t*)p; p += parts_bytes;
+    w->d_tick_parts = (uint64_t*)p; p += tick_parts_bytes;
     w->d_results = (uint64_t*)p; p += res_bytes;
     w->d_units = (UnitDesc*)p; p += units_bytes;
     w->d_maskoffs = (uint64_t*)p; p += ALIGN;
@@ -444,6 +481,58 @@ uint32_t dt_bits_for_frame(uint64_t fps, int32_t frame) {
     return bits;
 }
 
+// Commands are deferred: spawns materialise after every system of the frame ran (set.rs:118-134).
+int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, uint64_t spawn_count,
+                      const float* spawn_vx, const float* spawn_vy) {
+    int rc = GGRS_OK;
+    const uint32_t n_cks = w->cks_args.n_cks;
+    uint64_t* part_cnt = w->cks_args.part_cnt;
+    for (auto& s : w->systems) {
+        if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
+        bool pressed = false;                                   // spawn_pressed, particles.rs:254-256
+        for (uint32_t k = 0; k < n_inputs; ++k) pressed |= (inputs[k] & (uint8_t)s.iparam[1]) != 0;
+        if (!pressed || spawn_count == 0) continue;
+        if (w->len + spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)spawn_count, (unsigned long long)w->capacity);
+        const uint32_t cT = s.comp[0], cV = s.comp[1], cL = s.comp[2];
+        const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
+        const uint64_t first = w->len;
+        float *dvx = nullptr, *dvy = nullptr;
+        rc = stage_floats(w, spawn_vx, spawn_count, &dvx); if (rc) return rc;
+        rc = stage_floats(w, spawn_vy, spawn_count, &dvy); if (rc) return rc;
+        rc = fill_defaults(w, cT, first, spawn_count); if (rc) return rc;
+        SpawnArgs a; memset(&a, 0, sizeof a);
+        a.state = w->live.ptr;
+        for (int k = 0; k < 3; ++k) {
+            a.off_t[k] = w->col_off[T.col_base + k]; a.off_v[k] = w->col_off[V.col_base + k];
+            memcpy(&a.t_default[k], &T.defaults[(size_t)(w->fused_ok ? w->f_tw + k : k) * 4], 4);
+        }
+        a.off_ttl = w->col_off[L.col_base + 0];
+        a.vx = dvx; a.vy = dvy; a.first = first; a.count = spawn_count; a.ttl = (uint64_t)s.iparam[0];
+        const uint32_t gs = (uint32_t)((spawn_count + TPB - 1) / TPB);
+        const bool keep = w->pending_valid && (w->pending_parts + gs <= w->part_stride);
+        // partial slots appended after the step's (scratch at the tail when partials are not kept)
+        const uint32_t pbase = keep ? w->pending_parts : (w->part_stride - std::min(gs, w->part_stride));
+        uint64_t* scratch = w->d_parts;   // column 0 exists whenever n_cks > 0; else counts column
+        a.part_T = a.part_V = (n_cks ? scratch : part_cnt) + pbase;
+        a.cks_T = a.cks_V = 0;
+        if (keep) {
+            for (uint32_t k = 0; k < n_cks; ++k) {
+                if ((int)w->cks_comp[k] == w->f_T && w->f_cksT) { a.part_T = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_T = 1; }
+                if ((int)w->cks_comp[k] == w->f_V && w->f_cksV) { a.part_V = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_V = 1; }
+            }
+        }
+        a.part_cnt = part_cnt + pbase;
+        if (gs > w->part_stride) return w->fail(GGRS_E_CAPACITY, "spawn too large for partial buffer");
+        hipLaunchKernelGGL(k_spawn_particles, dim3(gs), dim3(TPB), 0, w->stream, a);
+        HIPCHK(w, hipGetLastError());
+        rc = set_masks_for_range(w, first, spawn_count, (1ULL << cT) | (1ULL << cV) | (1ULL << cL)); if (rc) return rc;
+        w->len += spawn_count;
+        w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+        if (keep) w->pending_parts += gs; else w->pending_valid = false;
+    }
+    return GGRS_OK;
+}
+
 template <bool CT, bool CV>
 void launch_step_fused(ggrs_world* w, const StepArgs& a, uint32_t g) {
     hipLaunchKernelGGL((k_particles_step<true, true, CT, CV>), dim3(g), dim3(TPB), 0, w->stream, a);
@@ -530,51 +619,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
         HIPCHK(w, hipGetLastError());
     }
 
-    // Commands are deferred: spawns materialise after every system of the frame ran (set.rs:118-134)
-    for (auto& s : w->systems) {
-        if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
-        bool pressed = false;                                   // spawn_pressed, particles.rs:254-256
-        for (uint32_t k = 0; k < n_inputs; ++k) pressed |= (inputs[k] & (uint8_t)s.iparam[1]) != 0;
-        if (!pressed || spawn_count == 0) continue;
-        if (w->len + spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)spawn_count, (unsigned long long)w->capacity);
-        const uint32_t cT = s.comp[0], cV = s.comp[1], cL = s.comp[2];
-        const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
-        const uint64_t first = w->len;
-        float *dvx = nullptr, *dvy = nullptr;
-        rc = stage_floats(w, spawn_vx, spawn_count, &dvx); if (rc) return rc;
-        rc = stage_floats(w, spawn_vy, spawn_count, &dvy); if (rc) return rc;
-        rc = fill_defaults(w, cT, first, spawn_count); if (rc) return rc;
-        SpawnArgs a; memset(&a, 0, sizeof a);
-        a.state = w->live.ptr;
-        for (int k = 0; k < 3; ++k) {
-            a.off_t[k] = w->col_off[T.col_base + k]; a.off_v[k] = w->col_off[V.col_base + k];
-            memcpy(&a.t_default[k], &T.defaults[(size_t)(w->fused_ok ? w->f_tw + k : k) * 4], 4);
-        }
-        a.off_ttl = w->col_off[L.col_base + 0];
-        a.vx = dvx; a.vy = dvy; a.first = first; a.count = spawn_count; a.ttl = (uint64_t)s.iparam[0];
-        const uint32_t gs = (uint32_t)((spawn_count + TPB - 1) / TPB);
-        const bool keep = w->pending_valid && (w->pending_parts + gs <= w->part_stride);
-        // partial slots appended after the step's (scratch at the tail when partials are not kept)
-        const uint32_t pbase = keep ? w->pending_parts : (w->part_stride - std::min(gs, w->part_stride));
-        uint64_t* scratch = w->d_parts;   // column 0 exists whenever n_cks > 0; else counts column
-        a.part_T = a.part_V = (n_cks ? scratch : part_cnt) + pbase;
-        a.cks_T = a.cks_V = 0;
-        if (keep) {
-            for (uint32_t k = 0; k < n_cks; ++k) {
-                if ((int)w->cks_comp[k] == w->f_T && w->f_cksT) { a.part_T = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_T = 1; }
-                if ((int)w->cks_comp[k] == w->f_V && w->f_cksV) { a.part_V = w->d_parts + (uint64_t)k * w->part_stride + pbase; a.cks_V = 1; }
-            }
-        }
-        a.part_cnt = part_cnt + pbase;
-        if (gs > w->part_stride) return w->fail(GGRS_E_CAPACITY, "spawn too large for partial buffer");
-        hipLaunchKernelGGL(k_spawn_particles, dim3(gs), dim3(TPB), 0, w->stream, a);
-        HIPCHK(w, hipGetLastError());
-        rc = set_masks_for_range(w, first, spawn_count, (1ULL << cT) | (1ULL << cV) | (1ULL << cL)); if (rc) return rc;
-        w->len += spawn_count;
-        w->live.dirty_len = std::max(w->live.dirty_len, w->len);
-        if (keep) w->pending_parts += gs; else w->pending_valid = false;
-    }
-    return GGRS_OK;
+    return run_spawn_systems(w, inputs, n_inputs, spawn_count, spawn_vx, spawn_vy);
 }
 
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
@@ -590,6 +635,112 @@ void apply_synctest_confirmed(ggrs_world* w) {
     if (w->synctest_cd < 0) return;
     const int32_t c = w->frame - w->synctest_cd;
     if (c >= 0) { w->has_confirmed = true; w->confirmed = c; }
+}
+
+// ---- fused request groups: [Load?] (Save | Advance)* as ONE k_tick launch + one finalize ----
+bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
+    if (r.spawn_count == 0) return false;
+    for (auto& s : w->systems) {
+        if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
+        for (uint32_t k = 0; k < r.n_inputs; ++k) if (r.inputs[k] & (uint8_t)s.iparam[1]) return true;
+    }
+    return false;
+}
+
+template <bool NT>
+void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick<true, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick<true, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick<false, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+}
+
+int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
+    uint32_t i = 0, ns = 0;                      // ns: results pending in d_results
+    int rc = GGRS_OK;
+    while (i < n) {
+        TickArgs a = w->tick_proto;
+        Block* src = &w->live;
+        uint64_t cover = w->live.dirty_len;
+        a.src_is_live = 1;
+        Block* dsts[MAX_TICK_SAVES];
+        const ggrs_request* spawn_req = nullptr;
+        // ---- LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
+        if (reqs[i].kind == GGRS_REQ_LOAD) {
+            apply_synctest_confirmed(w);
+            w->frame = reqs[i].frame;
+            if (!ring_rollback(w, reqs[i].frame))
+                return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
+            src = &w->slots[w->ring_slot.front()];
+            w->len = src->len;
+            cover = std::max(cover, src->dirty_len);
+            a.src_is_live = 0;
+            ++i;
+        }
+        // ---- gather the ops that follow, doing the host-side bookkeeping in request order
+        while (i < n && a.n_ops < (uint32_t)MAX_TICK_OPS) {
+            const ggrs_request& r = reqs[i];
+            if (r.kind == GGRS_REQ_LOAD) break;
+            if (r.kind == GGRS_REQ_SAVE) {
+                if (a.n_saves == (uint32_t)MAX_TICK_SAVES || ns + a.n_saves == w->max_results) break;
+                apply_synctest_confirmed(w);
+                if (w->has_confirmed) ring_confirm(w, w->confirmed);        // discard_old_snapshots
+                int sl = -1;
+                rc = ring_push(w, w->frame, &sl); if (rc) return rc;        // GgrsSnapshots::push
+                Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
+                dsts[a.n_saves] = d;
+                a.save_dst[a.n_saves] = d ? d->ptr : nullptr;
+                a.save_frame[a.n_saves] = w->frame;
+                if (d) { cover = std::max(cover, d->dirty_len); d->len = w->len; }
+                ++a.n_ops; ++a.n_saves;                                     // op bit stays 0: Save
+            } else if (r.kind == GGRS_REQ_ADVANCE) {
+                if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
+                apply_synctest_confirmed(w);
+                w->frame += 1;                                              // schedule_systems.rs:254-259
+                a.dt_bits[a.n_steps++] = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+                a.op_bits |= 1ULL << a.n_ops; ++a.n_ops;                     // op bit 1: Advance
+                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }   // Commands flush ends the group
+            } else {
+                return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+            }
+            ++i;
+        }
+        // ---- one pass over the tiles
+        cover = std::max(cover, w->len);
+        const uint32_t g = std::max(1u, tiles_for(cover));
+        a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
+        a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
+        if (a.n_ops || !a.src_is_live) {
+            ProfScope ps(w, GGRS_KERNEL_TICK);
+            if (w->nt_copy) launch_tick<true>(w, a, g); else launch_tick<false>(w, a, g);
+        }
+        HIPCHK(w, hipGetLastError());
+        const uint64_t new_dirty = std::max(src->dirty_len, w->len);
+        for (uint32_t k = 0; k < a.n_saves; ++k) if (dsts[k]) dsts[k]->dirty_len = new_dirty;
+        w->live.dirty_len = new_dirty;
+        w->pending_valid = false;
+        if (a.n_saves) {
+            TickFinArgs f; memset(&f, 0, sizeof f);
+            f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = 4 * g;
+            f.cks_T = w->f_cksT; f.cks_V = w->f_cksV; f.total_len = w->len;
+            f.out = w->d_results + 2 * (uint64_t)ns;
+            {
+                ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+                hipLaunchKernelGGL(k_tick_finalize, dim3(a.n_saves), dim3(FIN_TPB), 0, w->stream, f);
+            }
+            HIPCHK(w, hipGetLastError());
+            ns += a.n_saves;
+        }
+        if (spawn_req) {
+            rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
+            if (rc) return rc;
+        }
+        if (ns == w->max_results) {                                        // flush a full result page
+            rc = read_back(w, ns, checksums_out); if (rc) return rc;
+            checksums_out += 2 * (uint64_t)ns; ns = 0;
+        }
+    }
+    return read_back(w, ns, checksums_out);
 }
 
 }  // namespace
@@ -630,7 +781,8 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t mask = align_up(cap_pad / 8, ALIGN);
     // each 4-byte word column is 256-B aligned; bytes_per_slot/4 bounds the column count
     const uint64_t state = align_up(ALIGN + (1 + (uint64_t)n_components) * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
-    const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN);
+    const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
+                           align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE) * 8, ALIGN);
     return (uint64_t)(max_depth + 1) * state + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
@@ -826,25 +978,45 @@ int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t cd) { if (!w) re
 
 int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
     if (!w) return GGRS_E_INVALID;
-    int rc = do_save(w, 0); if (rc) return rc;
+    int rc = seal(w); if (rc) return rc;
+    if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_SAVE; r.frame = w->frame; return run_request_groups(w, &r, 1, out); }
+    rc = do_save(w, 0); if (rc) return rc;
     return read_back(w, 1, out);
 }
-int ggrs_hip_load(ggrs_world* w, int32_t frame) { return w ? do_load(w, frame) : GGRS_E_INVALID; }
+int ggrs_hip_load(ggrs_world* w, int32_t frame) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_LOAD; r.frame = frame; return run_request_groups(w, &r, 1, nullptr); }
+    return do_load(w, frame);
+}
 int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
                      uint64_t spawn_count, const float* vx, const float* vy) {
-    return w ? do_advance(w, dt_bits, inputs, n_inputs, spawn_count, vx, vy) : GGRS_E_INVALID;
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (w->tick_ok) {
+        ggrs_request r; memset(&r, 0, sizeof r);
+        r.kind = GGRS_REQ_ADVANCE; r.dt_bits = dt_bits; r.inputs = inputs; r.n_inputs = n_inputs;
+        r.spawn_count = spawn_count; r.spawn_vx = vx; r.spawn_vy = vy;
+        return run_request_groups(w, &r, 1, nullptr);
+    }
+    return do_advance(w, dt_bits, inputs, n_inputs, spawn_count, vx, vy);
 }
 
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (w->tick_ok) {
+        rc = run_request_groups(w, reqs, n, checksums_out);
+        if (rc && w->stream) (void)hipStreamSynchronize(w->stream);
+        return rc;
+    }
     uint32_t ns = 0;
-    int rc = GGRS_OK;
     for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
         const ggrs_request& r = reqs[i];
         apply_synctest_confirmed(w);
         switch (r.kind) {
         case GGRS_REQ_SAVE:
-            if (ns >= w->max_results && w->sealed) {      // flush a full result page
+            if (ns >= w->max_results) {                   // flush a full result page
                 rc = read_back(w, ns, checksums_out); if (rc) break;
                 checksums_out += 2 * (uint64_t)ns; ns = 0;
             }

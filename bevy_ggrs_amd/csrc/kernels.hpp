@@ -49,6 +49,13 @@ __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t i
     uint64_t C = sea_diffuse(SEA_K1 ^ inner);
     return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL);
 }
+// the same with B = diffuse(K0 ^ order) precomputed: it depends on the slot only, so one value serves
+// every checksummed component of the entity and every Save of a fused group
+__host__ __device__ __forceinline__ uint64_t sea_order_lane(uint64_t order) { return sea_diffuse(SEA_K0 ^ order); }
+__host__ __device__ __forceinline__ uint64_t sea_pair_pre(uint64_t B, uint64_t inner) {
+    uint64_t C = sea_diffuse(SEA_K1 ^ inner);
+    return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL);
+}
 // SeaHasher::new(); write_u64(x); finish()  -- component_checksum.rs:92-95
 __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) {
     uint64_t A = sea_diffuse(SEA_K0 ^ x);
@@ -387,6 +394,321 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
             if (CKS_V) a.part_V[t] = sV[0] ^ sV[1] ^ sV[2] ^ sV[3];
             a.part_cnt[t] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
         }
+    }
+}
+
+// ------------------------------------------------------------------ k_tick (fused request group)
+// handle_requests (schedule_systems.rs:170-289) receives the WHOLE request list of a ggrs tick at
+// once, and every request of the particles world is tile-local: LoadWorld, SaveWorld's snapshot
+// copy, the per-entity half of the checksum and the GgrsSchedule step only ever touch a slot's own
+// words.  So a run of requests  [Load?] (Save | Advance)*  executes as ONE pass over the tiles:
+//   * the tile's state is read ONCE (from the ring slot being loaded, or from the live block),
+//   * it stays in registers while the ops are replayed in request order -- a Save stores the
+//     registers to its ring slot and emits that frame's checksum partials, an Advance runs
+//     update_particles + despawn_particles on the registers,
+//   * the live block is written ONCE at the end.
+// Compulsory HBM traffic of a SyncTest tick at depth D drops from 1656 B/entity (one kernel per
+// request: every Save re-reads the live block, every Advance re-reads and re-writes it) to
+// 60 (read snapshot) + 60*D (write D snapshots) + 60 (write live) = 600 B at D = 8.  No work is
+// skipped: every snapshot is written in full, every checksum is computed, every frame stepped.
+//
+// Aliasing: a Save's ring slot may be the slot the group was loaded from (ring depth 1); this is
+// safe because every location is read by the lane that later writes it, and all reads of a
+// location precede its first write (pointers are deliberately not __restrict__).
+constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
+struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; };
+struct TickArgs {
+    const uint8_t* src;                    // ring slot (group starts with LoadGameState) or live
+    uint8_t* live;
+    uint8_t* save_dst[MAX_TICK_SAVES];     // nullptr: ring depth 0, checksum only
+    int32_t save_frame[MAX_TICK_SAVES];
+    uint32_t dt_bits[MAX_TICK_STEPS];
+    uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
+    uint32_t n_ops, n_saves, n_steps, src_is_live;
+    uint64_t len;
+    uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
+    float g[3];
+    uint32_t n_rest_rows, n_rest_masks, part_stride, pad;
+    uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE
+    uint64_t rest_mask_off[MAX_MASKS];     // presence masks of components the schedule does not touch
+    RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
+};
+
+template <bool NT, class V>
+__device__ __forceinline__ void st16(uint8_t* p, const V& v) {
+    static_assert(sizeof(V) == 16, "16-byte register tuple");
+    const u32x4 x = reinterpret_cast<const u32x4&>(v);
+    if (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = x;
+}
+
+template <int B, bool NT>
+__device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_t t, uint32_t tid) {
+    u32x4 v[B];
+    uint64_t pos[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const RowLite rd = a.rest[r0 + j];
+        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const u32x4*>(a.src + pos[j]);
+    // gfx9 counts loads AND stores in vmcnt: land the loads once here, or the compiler throttles
+    // every store of the fan-out loop behind a conservative vmcnt(B-1)
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
+    for (uint32_t k = 0; k < a.n_saves; ++k) {
+        uint8_t* dst = a.save_dst[k];
+        if (!dst) continue;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(dst + pos[j]));
+            else *reinterpret_cast<u32x4*>(dst + pos[j]) = v[j];
+        }
+    }
+    if (!a.src_is_live) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) *reinterpret_cast<u32x4*>(a.live + pos[j]) = v[j];
+    }
+}
+
+template <bool CKS_T, bool CKS_V, bool NT>
+__global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool in_len = (uint64_t)t * TILE < a.len;               // workgroup-uniform
+    const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
+    const uint64_t w0 = (uint64_t)t * 16 + wave * 4;              // first mask word of this wave
+    const uint32_t sh = (lane & 15u) * 4;
+    const uint64_t wi = w0 + (lane >> 4);
+
+    // ---- every load of the schedule-owned state, back to back
+    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi * 8);
+    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi * 8);
+    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi * 8);
+    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi * 8);
+    float4 tx[3], vv[3];
+    ulonglong2 tl[2];
+    if (in_len) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + e0 * 4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + e0 * 4);
+        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + e0 * 8);
+        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + e0 * 8 + 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
+        tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
+    }
+
+    // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
+    if (tid < 16u * a.n_rest_masks) {
+        const uint32_t m = tid >> 4, mw = tid & 15u;
+        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)t * 16 + mw) * 8;
+        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
+        for (uint32_t k = 0; k < a.n_saves; ++k)
+            if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
+        if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+    }
+    if (in_len && (a.n_saves || !a.src_is_live)) {
+        // batches of up to 8 rows: while this phase runs only the schedule-owned state is live in
+        // registers (the hash temporaries come later), so 32 more VGPRs are free.  The particles world
+        // has 7 such rows: ONE batch, one wait shared with the state loads above, then stores only.
+        const uint32_t n_rows = a.n_rest_rows;
+        for (uint32_t r = 0; r < n_rows; r += 8) {
+            switch (n_rows - r) {
+            case 1: fan_rows<1, NT>(a, r, t, tid); break;
+            case 2: fan_rows<2, NT>(a, r, t, tid); break;
+            case 3: fan_rows<3, NT>(a, r, t, tid); break;
+            case 4: fan_rows<4, NT>(a, r, t, tid); break;
+            case 5: fan_rows<5, NT>(a, r, t, tid); break;
+            case 6: fan_rows<6, NT>(a, r, t, tid); break;
+            case 7: fan_rows<7, NT>(a, r, t, tid); break;
+            default: fan_rows<8, NT>(a, r, t, tid); break;
+            }
+        }
+    }
+
+    uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
+    const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu,
+                   n_L = (uint32_t)(pL_w >> sh) & 0xFu;
+
+    // diffuse(K0 ^ order), order == slot (RollbackOrdered::order): shared by both components and all Saves
+    uint64_t ordB[4];
+    if (CKS_T || CKS_V) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
+    }
+
+    uint32_t si = 0, sj = 0;
+    for (uint32_t i = 0; i < a.n_ops; ++i) {
+        if (!((a.op_bits >> i) & 1ULL)) {
+            // ---------------- SaveWorld: snapshot (component_snapshot.rs:66-84, entity.rs:39-51)
+            uint8_t* dst = a.save_dst[si];
+            const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
+                           b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
+            const uint32_t cnt = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (dst) {
+                if (in_len) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        st16<NT>(dst + a.off_t[k] + e0 * 4, tx[k]);
+                        st16<NT>(dst + a.off_v[k] + e0 * 4, vv[k]);
+                    }
+                    st16<NT>(dst + a.off_ttl + e0 * 8, tl[0]);
+                    st16<NT>(dst + a.off_ttl + e0 * 8 + 16, tl[1]);
+                }
+                uint64_t mine = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                        (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+                    if (lane == (uint32_t)w) mine = nw;
+                }
+                if (lane < 4) *reinterpret_cast<uint64_t*>(dst + a.off_alive + (w0 + lane) * 8) = mine;
+                if ((lane & 15u) == 0) {
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pT + wi * 8) = pT_w;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pV + wi * 8) = pV_w;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pL + wi * 8) = pL_w;
+                }
+                if (t == 0 && tid == 0) {
+                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
+                    h.checksum[0] = 0; h.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = h;
+                }
+            }
+            // ---------------- SaveWorld: per-entity half of the checksum (component_checksum.rs:77-90)
+            uint64_t hT = 0, hV = 0;
+            if (CKS_T || CKS_V) {
+                const uint32_t c_T = CKS_T ? (alive4 & n_T) : 0u, c_V = CKS_V ? (alive4 & n_V) : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (CKS_T) {
+                        const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                                      __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                                      __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+                        hT ^= ((c_T >> j) & 1u) ? h : 0ULL;
+                    }
+                    if (CKS_V) {
+                        const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                                      __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                                      __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+                        hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
+                    }
+                }
+                if (CKS_T) hT = wave_xor(hT);
+                if (CKS_V) hV = wave_xor(hV);
+            }
+            if (lane == 0) {
+                uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
+                p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = cnt;
+            }
+            ++si;
+        } else {
+            // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
+            const float dt = __uint_as_float(a.dt_bits[sj]);
+            ++sj;
+            const uint32_t m_upd = alive4 & n_T & n_V;     // Query<(&mut Transform, &mut Velocity)>
+            const uint32_t m_ttl = alive4 & n_L;           // Query<(Entity, &mut Ttl)>
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float gd = __fmul_rn(a.g[k], dt);    // gravity * time_step
+                float* x = reinterpret_cast<float*>(&tx[k]);
+                float* v = reinterpret_cast<float*>(&vv[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = (m_upd >> j) & 1u;
+                    const float nv = __fadd_rn(v[j], gd);                     // **velocity += ...
+                    const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));      // translation += **velocity * time_step
+                    v[j] = on ? nv : v[j];
+                    x[j] = on ? nx : x[j];
+                }
+            }
+            uint32_t kill = 0;
+            uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = (m_ttl >> j) & 1u;
+                const uint64_t nq = q[j] - 1;              // usize, wrapping
+                q[j] = on ? nq : q[j];
+                kill |= (on && nq == 0) ? (1u << j) : 0u;
+            }
+            alive4 &= ~kill;                               // despawn is deferred to the end of the frame
+        }
+    }
+
+    // ---- the live block, written once
+    if (!a.src_is_live || a.n_steps) {
+        if (in_len) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<float4*>(a.live + a.off_t[k] + e0 * 4) = tx[k];
+                *reinterpret_cast<float4*>(a.live + a.off_v[k] + e0 * 4) = vv[k];
+            }
+            *reinterpret_cast<ulonglong2*>(a.live + a.off_ttl + e0 * 8) = tl[0];
+            *reinterpret_cast<ulonglong2*>(a.live + a.off_ttl + e0 * 8 + 16) = tl[1];
+        }
+        const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
+                       b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
+        uint64_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+            if (lane == (uint32_t)w) mine = nw;
+        }
+        if (lane < 4) *reinterpret_cast<uint64_t*>(a.live + a.off_alive + (w0 + lane) * 8) = mine;
+        if (!a.src_is_live && (lane & 15u) == 0) {
+            *reinterpret_cast<uint64_t*>(a.live + a.off_pT + wi * 8) = pT_w;
+            *reinterpret_cast<uint64_t*>(a.live + a.off_pV + wi * 8) = pV_w;
+            *reinterpret_cast<uint64_t*>(a.live + a.off_pL + wi * 8) = pL_w;
+        }
+    }
+}
+
+// Folds the per-wave partials of every Save of a fused group: one workgroup per Save.
+// component_checksum.rs:92-95 (hash the XOR once more), entity_checksum.rs:29-52,
+// checksum.rs:88-99 (XOR of all parts; upper 64 bits of the u128 are always 0).
+struct TickFinArgs {
+    const uint64_t* parts; uint32_t part_stride, n_parts, cks_T, cks_V;
+    uint64_t total_len;
+    uint64_t* out;                         // {lo, hi} per Save
+};
+constexpr int FIN_TPB = 1024;
+__global__ __launch_bounds__(FIN_TPB) void k_tick_finalize(TickFinArgs f) {
+    const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t* pT = f.parts + (uint64_t)k * 3 * f.part_stride;
+    const uint64_t* pV = pT + f.part_stride;
+    const uint64_t* pC = pV + f.part_stride;
+    uint64_t xT = 0, xV = 0, sum = 0;
+    // 4 independent strided loads per array per trip: the partials sit in other XCDs' L2 / HBM, so the
+    // fold is latency-bound unless every load of a thread is in flight at once
+    for (uint32_t i0 = tid; i0 < f.n_parts; i0 += 4 * FIN_TPB) {
+        uint64_t t[4], v[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * FIN_TPB;
+            const bool in = i < f.n_parts;
+            const uint32_t ii = in ? i : i0;
+            t[u] = pT[ii]; v[u] = pV[ii]; c[u] = pC[ii];
+            if (!in) { t[u] = 0; v[u] = 0; c[u] = 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xT ^= t[u]; xV ^= v[u]; sum += c[u]; }
+    }
+    xT = wave_xor(xT); xV = wave_xor(xV);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __shared__ uint64_t s[3][FIN_TPB / 64];
+    if (lane == 0) { s[0][wave] = xT; s[1][wave] = xV; s[2][wave] = sum; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t aT = 0, aV = 0, active = 0;
+        for (int w = 0; w < FIN_TPB / 64; ++w) { aT ^= s[0][w]; aV ^= s[1][w]; active += s[2][w]; }
+        uint64_t total = 0;
+        if (f.cks_T) total ^= sea_one(aT);
+        if (f.cks_V) total ^= sea_one(aV);
+        total ^= sea_pair(active, f.total_len);
+        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
     }
 }
 

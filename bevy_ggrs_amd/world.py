@@ -284,5 +284,5 @@ class World(WorldBase):
         ms = (C.c_double * _ffi.KERNEL_CLASSES)()
         n = (C.c_uint64 * _ffi.KERNEL_CLASSES)()
         self._check(self._lib.ggrs_hip_profile_read(self._p, ms, n))
-        names = ["save", "load", "advance", "checksum"]
+        names = ["save", "load", "advance", "checksum", "tick"]
         return {names[i]: (float(ms[i]), int(n[i])) for i in range(_ffi.KERNEL_CLASSES)}

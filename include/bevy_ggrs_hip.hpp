@@ -1,0 +1,485 @@
+// bevy_ggrs_hip.hpp -- host-side mirror of bevy_ggrs's plugin interface over the C ABI of
+// libggrs_hip.so (include/ggrs_hip.h).  Header-only C++17.
+//
+// The reference (/root/reference, Rust) cannot be built in this image, so the host side above the
+// C ABI is written in C++ with the reference's own names, argument meaning and error behaviour for
+// the snapshot-and-resimulate path:
+//
+//   reference (file:line)                                         here
+//   GgrsConfig<Input, Address, State>        src/lib.rs:45-60     bevy_ggrs::GgrsConfig<...>
+//   GgrsPlugin<C>                            src/lib.rs:200-260   bevy_ggrs::GgrsPlugin<C>
+//   GgrsSchedule / ReadInputs labels         src/lib.rs:76,151    bevy_ggrs::GgrsSchedule / ReadInputs
+//   Session<C>, PlayerInputs, LocalInputs,   src/lib.rs:81-147    same names
+//   LocalPlayers, SyncTestMismatch
+//   RollbackFrameRate                        src/time.rs:20       same
+//   RollbackFrameCount / ConfirmedFrameCount src/snapshot/mod.rs:70,80   App::rollback_frame_count() ...
+//   RollbackApp::rollback_component_with_*   src/snapshot/rollback_app.rs:31-133   App member functions
+//   run_ggrs_schedules / run_synctest /      src/schedule_systems.rs:19-118,170-289  App::update / handle_requests
+//   handle_requests
+//   ggrs::SessionBuilder / SyncTestSession   (un-vendored `ggrs`, Cargo.toml:23; restated)  same names
+//
+// User systems in the reference are arbitrary Rust closures; on this path a GgrsSchedule system is a
+// *kernel-backed* system descriptor (bevy_ggrs::systems::*) executed inside libggrs_hip.so.
+// P2P / spectator sessions (UDP, inside ggrs) are out of scope.
+//
+// `Backend` abstracts the C ABI so the host logic can be exercised on CPU in tests/ (tests/cpp binds
+// it to the oracle); the default and only product backend is HipBackend == libggrs_hip.so.
+#pragma once
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "ggrs_hip.h"
+
+namespace bevy_ggrs {
+
+using Frame = int32_t;                 // ggrs::Frame
+using PlayerHandle = size_t;           // ggrs::PlayerHandle
+constexpr Frame NULL_FRAME = -1;       // ggrs::NULL_FRAME
+constexpr size_t DEFAULT_FPS = 60;     // src/lib.rs:62
+
+enum class InputStatus { Confirmed, Predicted, Disconnected };
+enum class PlayerType { Local, Remote, Spectator };
+
+// ---------------------------------------------------------------- src/lib.rs:45-60
+template <class InputT, class AddressT = size_t, class StateT = uint8_t>
+struct GgrsConfig {
+    using Input = InputT;
+    using Address = AddressT;
+    using State = StateT;
+};
+
+struct GgrsSchedule {};                // src/lib.rs:76
+struct ReadInputs {};                  // src/lib.rs:151
+struct RollbackFrameRate { size_t fps = DEFAULT_FPS; };   // src/time.rs:20
+
+struct SyncTestMismatch {              // src/lib.rs:133-139
+    Frame current_frame;
+    std::vector<Frame> mismatched_frames;
+};
+
+template <class C> using PlayerInputs = std::vector<std::pair<typename C::Input, InputStatus>>;  // src/lib.rs:98
+template <class C> using LocalInputs = std::unordered_map<PlayerHandle, typename C::Input>;      // src/lib.rs:143
+struct LocalPlayers { std::vector<PlayerHandle> handles; };                                       // src/lib.rs:147
+
+// ---------------------------------------------------------------- ggrs (restated)
+struct GgrsError : std::runtime_error {
+    enum Kind { InvalidRequest, MismatchedChecksum, PredictionThreshold, NotSynchronized };
+    Kind kind;
+    Frame current_frame = NULL_FRAME;
+    std::vector<Frame> mismatched_frames;
+    GgrsError(Kind k, const std::string& what) : std::runtime_error(what), kind(k) {}
+};
+
+struct u128 {                          // Checksum(u128), src/snapshot/checksum.rs:49
+    uint64_t lo = 0, hi = 0;
+    bool operator==(const u128& o) const { return lo == o.lo && hi == o.hi; }
+    bool operator!=(const u128& o) const { return !(*this == o); }
+};
+
+struct GameStateCell {                 // ggrs::GameStateCell: only frame + checksum are used (schedule_systems.rs:235-236)
+    Frame frame = NULL_FRAME;
+    std::optional<u128> checksum;
+    void save(Frame f, std::nullptr_t, std::optional<u128> cs) { frame = f; checksum = cs; }
+};
+
+template <class C>
+struct GgrsRequest {
+    enum Kind { SaveGameState = GGRS_REQ_SAVE, LoadGameState = GGRS_REQ_LOAD, AdvanceFrame = GGRS_REQ_ADVANCE } kind;
+    Frame frame = NULL_FRAME;          // Save / Load
+    GameStateCell* cell = nullptr;     // Save
+    PlayerInputs<C> inputs;            // Advance
+};
+
+// SyncTestSession::advance_frame, restated from ggrs (parity-unpinned by reference vectors; the
+// reference tests that constrain it: tests/synctest.rs:84-153, tests/component_rollback.rs).
+template <class C>
+class SyncTestSession {
+  public:
+    using Input = typename C::Input;
+    SyncTestSession(size_t num_players, size_t check_distance, size_t max_prediction, size_t input_delay)
+        : num_players_(num_players), check_distance_(check_distance), max_prediction_(max_prediction),
+          input_delay_(input_delay), cells_(std::max(max_prediction, check_distance) + 2) {}
+
+    size_t num_players() const { return num_players_; }
+    size_t max_prediction() const { return max_prediction_; }
+    size_t check_distance() const { return check_distance_; }
+    Frame current_frame() const { return current_frame_; }
+
+    void add_local_input(PlayerHandle handle, Input input) {
+        if (handle >= num_players_) throw GgrsError(GgrsError::InvalidRequest, "The player handle you provided is not referring to a local player.");
+        local_inputs_[handle] = input;
+    }
+
+    std::vector<GgrsRequest<C>> advance_frame() {
+        std::vector<GgrsRequest<C>> requests;
+        const Frame cur = current_frame_;
+        const Frame d = (Frame)check_distance_;
+        if (d > 0 && cur > d) {
+            std::vector<Frame> mismatched;
+            for (Frame f = cur - d; f <= cur; ++f) if (!checksums_consistent(f)) mismatched.push_back(f);
+            if (!mismatched.empty()) {
+                GgrsError e(GgrsError::MismatchedChecksum, "Detected checksum mismatch during rollback on frame " + std::to_string(cur));
+                e.current_frame = cur; e.mismatched_frames = mismatched;
+                throw e;
+            }
+            // adjust_gamestate: roll back d frames and resimulate
+            const Frame frame_to = cur - d;
+            GgrsRequest<C> load; load.kind = GgrsRequest<C>::LoadGameState; load.frame = frame_to;
+            requests.push_back(load);
+            current_frame_ = frame_to;
+            for (Frame i = 0; i < d; ++i) {
+                if (i > 0) requests.push_back(save_request());
+                requests.push_back(advance_request(inputs_for(current_frame_)));
+                current_frame_ += 1;
+            }
+        }
+        if (local_inputs_.size() != num_players_) throw GgrsError(GgrsError::InvalidRequest, "Missing local input while calling advance_frame().");
+        std::vector<Input> vals(num_players_);
+        for (auto& kv : local_inputs_) vals[kv.first] = kv.second;
+        pending_[current_frame_ + (Frame)input_delay_] = vals;
+        local_inputs_.clear();
+        if (d > 0) requests.push_back(save_request());
+        requests.push_back(advance_request(inputs_for(current_frame_)));
+        current_frame_ += 1;
+        for (auto it = history_.begin(); it != history_.end();) it = (it->first < current_frame_ - d - 2) ? history_.erase(it) : std::next(it);
+        for (auto it = pending_.begin(); it != pending_.end();) it = (it->first < current_frame_ - d - 2) ? pending_.erase(it) : std::next(it);
+        return requests;
+    }
+
+  private:
+    const std::vector<Input>& inputs_for(Frame f) {
+        auto it = history_.find(f);
+        if (it == history_.end()) {
+            auto p = pending_.find(f);
+            it = history_.emplace(f, p != pending_.end() ? p->second : std::vector<Input>(num_players_, Input{})).first;
+        }
+        return it->second;
+    }
+    GgrsRequest<C> save_request() {
+        GgrsRequest<C> r; r.kind = GgrsRequest<C>::SaveGameState; r.frame = current_frame_;
+        r.cell = &cells_[(size_t)current_frame_ % cells_.size()];
+        return r;
+    }
+    GgrsRequest<C> advance_request(const std::vector<Input>& in) {
+        GgrsRequest<C> r; r.kind = GgrsRequest<C>::AdvanceFrame;
+        for (auto& v : in) r.inputs.emplace_back(v, InputStatus::Confirmed);
+        return r;
+    }
+    bool checksums_consistent(Frame frame_to_check) {
+        const Frame oldest = current_frame_ - (Frame)check_distance_;
+        for (auto it = checksum_history_.begin(); it != checksum_history_.end();) it = (it->first < oldest) ? checksum_history_.erase(it) : std::next(it);
+        const GameStateCell& cell = cells_[(size_t)frame_to_check % cells_.size()];
+        if (cell.frame != frame_to_check) return true;
+        auto it = checksum_history_.find(cell.frame);
+        if (it != checksum_history_.end()) return it->second == cell.checksum;
+        checksum_history_[cell.frame] = cell.checksum;
+        return true;
+    }
+
+    size_t num_players_, check_distance_, max_prediction_, input_delay_;
+    Frame current_frame_ = 0;
+    std::map<PlayerHandle, Input> local_inputs_;
+    std::map<Frame, std::vector<Input>> history_, pending_;
+    std::vector<GameStateCell> cells_;
+    std::map<Frame, std::optional<u128>> checksum_history_;
+};
+
+template <class C>
+class SessionBuilder {                 // ggrs::SessionBuilder (knobs used by the reference's examples/tests)
+  public:
+    SessionBuilder& with_num_players(size_t n) { num_players_ = n; return *this; }
+    SessionBuilder& with_check_distance(size_t d) { check_distance_ = d; return *this; }
+    SessionBuilder& with_input_delay(size_t d) { input_delay_ = d; return *this; }
+    SessionBuilder& with_max_prediction_window(size_t w) { max_prediction_ = w; return *this; }
+    SessionBuilder& add_player(PlayerType, PlayerHandle h) {
+        if (h >= num_players_) throw GgrsError(GgrsError::InvalidRequest, "The player handle you provided is invalid.");
+        return *this;
+    }
+    SyncTestSession<C> start_synctest_session() const {
+        if (check_distance_ >= max_prediction_) throw GgrsError(GgrsError::InvalidRequest, "Check distance too big.");
+        return SyncTestSession<C>(num_players_, check_distance_, max_prediction_, input_delay_);
+    }
+  private:
+    size_t num_players_ = 2, check_distance_ = 2, max_prediction_ = 8, input_delay_ = 0;
+};
+
+// src/lib.rs:81-88.  P2P / Spectator variants live in ggrs's UDP layer: out of scope.
+template <class C> using Session = std::variant<std::monostate, SyncTestSession<C>>;
+
+// ---------------------------------------------------------------- components and systems
+// A rollback component on this path is plain-old-data made of 4- or 8-byte words
+// (Transform = 10 x f32, Velocity = 3 x f32, Ttl = 1 x u64).  Specialise for each type:
+//   template <> struct HipComponent<Velocity> { static constexpr const char* name = "Velocity";
+//       static constexpr uint32_t word_bytes = 4, n_words = 3; };
+template <class T> struct HipComponent;
+
+struct KernelSystem {                  // one system of the GgrsSchedule, executed by libggrs_hip.so
+    uint32_t kind = 0;
+    std::vector<std::string> comps;    // component names, resolved at build time
+    uint32_t word[4] = {0, 0, 0, 0};
+    int64_t iparam[2] = {0, 0};
+    float fparam[4] = {0, 0, 0, 0};
+};
+
+namespace systems {
+// examples/stress_tests/particles.rs:272-280
+template <class TransformT, class VelocityT>
+KernelSystem update_particles(float gx, float gy, float gz, uint32_t translation_word = 0, uint32_t velocity_word = 0) {
+    KernelSystem s; s.kind = GGRS_SYS_PARTICLES_UPDATE;
+    s.comps = {HipComponent<TransformT>::name, HipComponent<VelocityT>::name};
+    s.word[0] = translation_word; s.word[1] = velocity_word; s.fparam[0] = gx; s.fparam[1] = gy; s.fparam[2] = gz;
+    return s;
+}
+// particles.rs:282-289
+template <class TtlT> KernelSystem despawn_particles(uint32_t word = 0) {
+    KernelSystem s; s.kind = GGRS_SYS_TTL_DESPAWN; s.comps = {HipComponent<TtlT>::name}; s.word[0] = word; return s;
+}
+// particles.rs:254-270
+template <class TransformT, class VelocityT, class TtlT> KernelSystem spawn_particles(int64_t ttl, uint8_t input_mask) {
+    KernelSystem s; s.kind = GGRS_SYS_PARTICLES_SPAWN;
+    s.comps = {HipComponent<TransformT>::name, HipComponent<VelocityT>::name, HipComponent<TtlT>::name};
+    s.iparam[0] = ttl; s.iparam[1] = input_mask; return s;
+}
+// benches/bench.rs:30-46, tests/component_rollback.rs:24-28
+template <class T> KernelSystem add_u32(uint32_t delta, uint32_t word = 0) {
+    KernelSystem s; s.kind = GGRS_SYS_ADD_U32; s.comps = {HipComponent<T>::name}; s.word[0] = word; s.iparam[0] = delta; return s;
+}
+// tests/synctest.rs:37-44
+template <class T> KernelSystem saturating_sub_despawn(uint32_t amount, uint32_t word = 0) {
+    KernelSystem s; s.kind = GGRS_SYS_SAT_SUB_DESPAWN; s.comps = {HipComponent<T>::name}; s.word[0] = word; s.iparam[0] = amount; return s;
+}
+}  // namespace systems
+
+// ---------------------------------------------------------------- backend == the C ABI
+struct HipBackend {
+    ggrs_world* w = nullptr;
+    HipBackend(uint64_t capacity, uint32_t max_depth, int device) {
+        const int rc = ggrs_hip_world_create(device, capacity, max_depth, &w);
+        if (rc != GGRS_OK) throw std::runtime_error(rc == GGRS_E_NO_DEVICE ? "no gfx950 device visible: bevy_ggrs_hip has no CPU fallback" : "ggrs_hip_world_create failed");
+    }
+    ~HipBackend() { if (w) ggrs_hip_world_destroy(w); }
+    HipBackend(const HipBackend&) = delete;
+    const char* last_error() { return ggrs_hip_last_error(w); }
+    int register_component(const char* n, uint32_t wb, uint32_t nw, uint32_t* id) { return ggrs_hip_register_component(w, n, wb, nw, id); }
+    int set_component_default(uint32_t c, const void* p) { return ggrs_hip_set_component_default(w, c, p); }
+    int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return ggrs_hip_checksum_component(w, c, idx, n); }
+    int add_system(const ggrs_system_desc* d) { return ggrs_hip_add_system(w, d); }
+    int set_frame_rate(uint64_t fps) { return ggrs_hip_set_frame_rate(w, fps); }
+    int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return ggrs_hip_spawn(w, count, mask, cols, first); }
+    int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
+    int set_synctest_check_distance(int32_t cd) { return ggrs_hip_set_synctest_check_distance(w, cd); }
+    int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) { return ggrs_hip_handle_requests(w, r, n, out); }
+    int32_t frame() { return ggrs_hip_frame(w); }
+    int set_frame(int32_t f) { return ggrs_hip_set_frame(w, f); }
+    uint64_t len() { return ggrs_hip_len(w); }
+    int active_count(uint64_t* out) { return ggrs_hip_active_count(w, out); }
+    int download_word(uint32_t c, uint32_t word, uint64_t first, uint64_t count, void* dst) { return ggrs_hip_download_word(w, c, word, first, count, dst); }
+    int download_alive(uint64_t* dst, uint64_t n) { return ggrs_hip_download_alive(w, dst, n); }
+    int has_snapshot(int32_t f) { return ggrs_hip_has_snapshot(w, f); }
+    uint64_t snapshot_count() { return ggrs_hip_snapshot_count(w); }
+};
+
+// ---------------------------------------------------------------- GgrsPlugin + App
+template <class C> struct GgrsPlugin {};            // src/lib.rs:200-260 (the schedule label argument has no meaning without Bevy)
+
+template <class C, class Backend = HipBackend>
+class App {
+  public:
+    using Input = typename C::Input;
+    static_assert(sizeof(Input) == 1, "this path carries one input byte per player (GGRS_MAX_PLAYERS bytes per AdvanceFrame)");
+    using ReadInputsSystem = std::function<void(const LocalPlayers&, LocalInputs<C>&)>;
+    using SpawnSource = std::function<void(Frame, std::vector<float>& vx, std::vector<float>& vy)>;
+
+    explicit App(uint64_t capacity, uint32_t max_depth = 16, int device = 0) : be_(capacity, max_depth, device), max_depth_(max_depth) {}
+
+    // ---- App::add_plugins(GgrsPlugin::<C>::default())
+    App& add_plugins(GgrsPlugin<C>) { plugin_ = true; return *this; }
+    // ---- app.insert_resource(RollbackFrameRate(FPS)) / insert_resource(Session)
+    App& insert_resource(RollbackFrameRate r) { fps_ = r.fps; check(be_.set_frame_rate(r.fps)); return *this; }
+    App& insert_resource(SyncTestSession<C> s) {
+        session_ = std::move(s);
+        auto& ss = std::get<SyncTestSession<C>>(session_);
+        // handle_requests, schedule_systems.rs:197-220: MaxPredictionWindow = max_prediction (sync_depth,
+        // mod.rs:263-273); SyncTest: ConfirmedFrameCount = frame - check_distance
+        max_prediction_window_ = ss.max_prediction();
+        if (max_prediction_window_ > max_depth_) throw std::invalid_argument("max_prediction exceeds the ring depth provisioned for this App");
+        check(be_.set_depth((uint32_t)max_prediction_window_));
+        check(be_.set_synctest_check_distance((int32_t)ss.check_distance()));
+        return *this;
+    }
+    // ---- app.add_systems(ReadInputs, read_local_inputs) / add_systems(GgrsSchedule, system)
+    App& add_systems(ReadInputs, ReadInputsSystem f) { read_inputs_ = std::move(f); return *this; }
+    App& add_systems(GgrsSchedule, const KernelSystem& s) {
+        ggrs_system_desc d; std::memset(&d, 0, sizeof d);
+        d.kind = s.kind;
+        for (size_t k = 0; k < s.comps.size(); ++k) d.comp[k] = comp_id(s.comps[k]);
+        for (int k = 0; k < 4; ++k) { d.word[k] = s.word[k]; d.fparam[k] = s.fparam[k]; }
+        d.iparam[0] = s.iparam[0]; d.iparam[1] = s.iparam[1];
+        check(be_.add_system(&d));
+        has_spawn_system_ |= s.kind == GGRS_SYS_PARTICLES_SPAWN;
+        if (s.kind == GGRS_SYS_PARTICLES_SPAWN) spawn_mask_ = (uint8_t)s.iparam[1];
+        return *this;
+    }
+    // host-side stand-in for the rolled-back ParticleRng resource (particles.rs:125,201): must be a
+    // pure function of the frame, or SyncTest reports a mismatch -- exactly like a non-deterministic system
+    App& set_spawn_source(SpawnSource f) { spawn_source_ = std::move(f); return *this; }
+
+    // ---- RollbackApp (src/snapshot/rollback_app.rs:31-133)
+    template <class T> App& rollback_component_with_copy() { return register_component<T>(); }
+    template <class T> App& rollback_component_with_clone() { return register_component<T>(); }   // bitwise for POD (strategy.rs:62-83)
+    template <class T> App& rollback_component_with_reflect() {
+        throw std::logic_error("rollback_component_with_reflect: ReflectStrategy (strategy.rs:86-110) is dynamic reflection, out of scope for the device path");
+    }
+    template <class T> App& checksum_component_with_hash() {                                    // derive(Hash) over every field
+        std::vector<uint32_t> idx(HipComponent<T>::n_words);
+        for (uint32_t k = 0; k < idx.size(); ++k) idx[k] = k;
+        return checksum_component<T>(idx);
+    }
+    template <class T> App& checksum_component(const std::vector<uint32_t>& hashed_words) {     // the fn(&T)->u64 of the reference becomes the list of hashed words
+        check(be_.checksum_component(comp_id(HipComponent<T>::name), hashed_words.data(), (uint32_t)hashed_words.size()));
+        return *this;
+    }
+    template <class T> App& set_component_default(const void* words) { check(be_.set_component_default(comp_id(HipComponent<T>::name), words)); return *this; }
+
+    // ---- commands.spawn((bundle.., Rollback)) x count; columns in registration order of `names`, nullptr = default
+    uint64_t spawn(uint64_t count, const std::vector<std::string>& names, const std::vector<const void*>& columns = {}) {
+        uint64_t mask = 0;
+        for (auto& n : names) mask |= 1ULL << comp_id(n);
+        uint64_t first = 0;
+        check(be_.spawn(count, mask, columns.empty() ? nullptr : columns.data(), &first));
+        return first;
+    }
+
+    // ---- observers / resources
+    App& add_observer(std::function<void(const SyncTestMismatch&)> f) { on_mismatch_ = std::move(f); return *this; }
+    Frame rollback_frame_count() { return be_.frame(); }                                        // RollbackFrameCount, mod.rs:70
+    Frame confirmed_frame_count() const { return confirmed_; }                                  // ConfirmedFrameCount, mod.rs:80
+    size_t max_prediction_window() const { return max_prediction_window_; }                     // MaxPredictionWindow, lib.rs:119
+    const std::vector<u128>& last_checksums() const { return last_checksums_; }
+    Backend& backend() { return be_; }
+    uint64_t active_count() { uint64_t n = 0; check(be_.active_count(&n)); return n; }
+    template <class T, class W> std::vector<W> download(uint32_t word) {
+        static_assert(sizeof(W) == HipComponent<T>::word_bytes, "word type must match the component's word size");
+        std::vector<W> out(be_.len());
+        if (!out.empty()) check(be_.download_word(comp_id(HipComponent<T>::name), word, 0, out.size(), out.data()));
+        return out;
+    }
+
+    // ---- App::update(): run_ggrs_schedules (src/schedule_systems.rs:19-83) with
+    // TimeUpdateStrategy::ManualDuration(delta)
+    void update(std::chrono::nanoseconds delta = std::chrono::nanoseconds(1000000000ULL / 60 + 1)) {
+        if (!plugin_) throw std::logic_error("GgrsPlugin was not added");
+        const uint64_t fps_delta = run_slow_ ? 1000000000ULL * 11 / (fps_ * 10) : 1000000000ULL / fps_;
+        accumulator_ += (uint64_t)delta.count();
+        while (accumulator_ >= fps_delta) {
+            accumulator_ -= fps_delta;
+            if (auto* s = std::get_if<SyncTestSession<C>>(&session_)) run_synctest(*s);
+            else {   // no session yet: reset time data and counters (schedule_systems.rs:70-78)
+                accumulator_ = 0; run_slow_ = false; confirmed_ = -1; max_prediction_window_ = 8;
+                check(be_.set_frame(0));
+            }
+        }
+    }
+
+    // ---- handle_requests (src/schedule_systems.rs:170-289): the whole list is ONE device submission
+    void handle_requests(std::vector<GgrsRequest<C>>& requests) {
+        std::vector<ggrs_request> reqs(requests.size());
+        std::vector<std::vector<uint8_t>> input_bytes; input_bytes.reserve(requests.size());
+        std::vector<std::vector<float>> payload; payload.reserve(2 * requests.size());
+        std::vector<GgrsRequest<C>*> saves;
+        Frame cur = be_.frame();
+        for (size_t i = 0; i < requests.size(); ++i) {
+            auto& r = requests[i];
+            ggrs_request& q = reqs[i]; std::memset(&q, 0, sizeof q);
+            q.kind = (uint32_t)r.kind;
+            switch (r.kind) {
+            case GgrsRequest<C>::SaveGameState: q.frame = r.frame; saves.push_back(&r); break;
+            case GgrsRequest<C>::LoadGameState: q.frame = r.frame; cur = r.frame; break;
+            case GgrsRequest<C>::AdvanceFrame: {
+                input_bytes.emplace_back();
+                bool pressed = false;
+                for (auto& in : r.inputs) { uint8_t b; std::memcpy(&b, &in.first, 1); input_bytes.back().push_back(b); pressed |= (b & spawn_mask_) != 0; }
+                q.inputs = input_bytes.back().data(); q.n_inputs = (uint32_t)input_bytes.back().size();
+                if (has_spawn_system_ && pressed && spawn_source_) {
+                    payload.emplace_back(); payload.emplace_back();
+                    auto& vx = payload[payload.size() - 2]; auto& vy = payload[payload.size() - 1];
+                    spawn_source_(cur, vx, vy);
+                    q.spawn_count = vx.size(); q.spawn_vx = vx.data(); q.spawn_vy = vy.data();
+                }
+                cur += 1;
+            } break;
+            }
+        }
+        std::vector<uint64_t> sums(2 * saves.size() + 2);
+        const int rc = be_.handle_requests(reqs.data(), (uint32_t)reqs.size(), sums.data());
+        if (rc != GGRS_OK) throw std::runtime_error(be_.last_error());      // the reference panics here (mod.rs:213-215)
+        last_checksums_.clear();
+        for (size_t k = 0; k < saves.size(); ++k) {
+            const u128 cs{sums[2 * k], sums[2 * k + 1]};
+            saves[k]->cell->save(saves[k]->frame, nullptr, cs);             // schedule_systems.rs:231-236
+            last_checksums_.push_back(cs);
+        }
+        if (auto* s = std::get_if<SyncTestSession<C>>(&session_)) {         // schedule_systems.rs:204-220
+            const Frame c = be_.frame() - (Frame)s->check_distance();
+            if (c >= 0) confirmed_ = c;
+        }
+    }
+
+  private:
+    void check(int rc) { if (rc != GGRS_OK) throw std::runtime_error(be_.last_error()); }
+    uint32_t comp_id(const std::string& name) const {
+        auto it = comp_ids_.find(name);
+        if (it == comp_ids_.end()) throw std::invalid_argument("component " + name + " is not registered for rollback");
+        return it->second;
+    }
+    template <class T> App& register_component() {
+        uint32_t id = 0;
+        check(be_.register_component(HipComponent<T>::name, HipComponent<T>::word_bytes, HipComponent<T>::n_words, &id));
+        comp_ids_[HipComponent<T>::name] = id;
+        return *this;
+    }
+    // run_synctest, src/schedule_systems.rs:85-118
+    void run_synctest(SyncTestSession<C>& sess) {
+        LocalPlayers players;
+        for (PlayerHandle h = 0; h < sess.num_players(); ++h) players.handles.push_back(h);
+        if (!read_inputs_) throw std::logic_error("No local player inputs found. Did you insert systems into the ReadInputs schedule?");
+        LocalInputs<C> local;
+        read_inputs_(players, local);
+        for (auto& kv : local) sess.add_local_input(kv.first, kv.second);
+        try {
+            auto requests = sess.advance_frame();
+            handle_requests(requests);
+        } catch (const GgrsError& e) {
+            if (e.kind != GgrsError::MismatchedChecksum) throw;
+            if (on_mismatch_) on_mismatch_(SyncTestMismatch{e.current_frame, e.mismatched_frames});   // world.trigger(SyncTestMismatch{..})
+        }
+    }
+
+    Backend be_;
+    uint32_t max_depth_;
+    bool plugin_ = false;
+    size_t fps_ = DEFAULT_FPS;
+    Session<C> session_;
+    ReadInputsSystem read_inputs_;
+    SpawnSource spawn_source_;
+    bool has_spawn_system_ = false; uint8_t spawn_mask_ = 0;
+    std::function<void(const SyncTestMismatch&)> on_mismatch_;
+    std::unordered_map<std::string, uint32_t> comp_ids_;
+    uint64_t accumulator_ = 0; bool run_slow_ = false;
+    Frame confirmed_ = -1;
+    size_t max_prediction_window_ = 8;
+    std::vector<u128> last_checksums_;
+};
+
+}  // namespace bevy_ggrs

@@ -67,6 +67,7 @@ typedef struct {
 #define GGRS_WORLD_NO_GRAPH     1u   /* never capture request batches into hipGraphs           */
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
+#define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
 
 int  ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggrs_world** out);
 int  ggrs_hip_world_create_ex(const ggrs_world_desc* desc, ggrs_world** out);
@@ -224,8 +225,9 @@ int ggrs_hip_adopt_live_state(ggrs_world* w);
 #define GGRS_KERNEL_SAVE     0u
 #define GGRS_KERNEL_LOAD     1u
 #define GGRS_KERNEL_ADVANCE  2u
-#define GGRS_KERNEL_CHECKSUM 3u
-#define GGRS_KERNEL_CLASSES  4u
+#define GGRS_KERNEL_CHECKSUM 3u   /* standalone checksum passes and the per-group finalize   */
+#define GGRS_KERNEL_TICK     4u   /* fused request group: [Load?] (Save | Advance)* in one pass */
+#define GGRS_KERNEL_CLASSES  5u
 int ggrs_hip_profile_enable(ggrs_world* w, int on);
 /* total milliseconds and launch count per class since enable; sizes GGRS_KERNEL_CLASSES */
 int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out);

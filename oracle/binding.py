@@ -89,6 +89,9 @@ def _load():
 
 
 lib = _load()
+# the GPU box has 256 host cores; a 256-thread OpenMP team per tiny parallel region makes the
+# oracle crawl, so the checker defaults to a small team (bench.py sets its own count explicitly)
+lib.gor_set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
 
 
 class OracleWorld(WorldBase):

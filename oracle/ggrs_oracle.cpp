@@ -372,7 +372,7 @@ static uint64_t component_checksum_flat(const World& w, uint32_t c) {
     uint64_t result = 0;
     const uint32_t n = (uint32_t)cc.cks_units.size();
     const int64_t L = (int64_t)w.len;
-#pragma omp parallel for reduction(^ : result) schedule(static)
+#pragma omp parallel for reduction(^ : result) schedule(static) if (L > 65536)
     for (int64_t ii = 0; ii < L; ++ii) {
         uint64_t i = (uint64_t)ii;
         if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
@@ -475,7 +475,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
                 tx[k] = (float*)w.cols[w.col_base[ct] + s.word[0] + k].data();
                 vv[k] = (float*)w.cols[w.col_base[cv] + s.word[1] + k].data();
             }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (L > 65536)
             for (int64_t ii = 0; ii < L; ++ii) {
                 uint64_t i = (uint64_t)ii;
                 if (!bit(w.alive, i) || !bit(w.present[ct], i) || !bit(w.present[cv], i)) continue;
@@ -488,7 +488,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
             uint32_t c = s.comp[0];
             uint64_t* ttl = (uint64_t*)w.cols[w.col_base[c] + s.word[0]].data();
             const int64_t NW = (L + 63) / 64;      // one 64-slot mask word per iteration: no write races
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (L > 65536)
             for (int64_t wi = 0; wi < NW; ++wi) {
                 uint64_t m = w.alive[wi] & w.present[c][wi], kill = 0;
                 while (m) {

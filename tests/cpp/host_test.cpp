@@ -1,0 +1,263 @@
+// host_test.cpp -- the reference's integration tests, re-expressed against the C++ host mirror
+// (include/bevy_ggrs_hip.hpp).  Built twice by tests/test_cpp_host.py:
+//   -DBACKEND_ORACLE : host logic on the CPU oracle (tests only; runs without a GPU)
+//   (default)        : the product path, libggrs_hip.so on a gfx950 device
+// Every test prints "ok <name>"; `particles` additionally prints every checksum so the two
+// builds can be compared bit for bit.
+#include <atomic>
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+
+#include "bevy_ggrs_hip.hpp"
+
+using namespace bevy_ggrs;
+
+#ifdef BACKEND_ORACLE
+extern "C" {
+void* gor_world_create(uint64_t, uint32_t, int);
+void gor_world_destroy(void*);
+const char* gor_last_error(void*);
+int gor_register_component(void*, const char*, uint32_t, uint32_t, uint32_t*);
+int gor_set_component_default(void*, uint32_t, const void*);
+int gor_checksum_component(void*, uint32_t, const uint32_t*, uint32_t);
+int gor_add_system(void*, const ggrs_system_desc*);
+int gor_spawn(void*, uint64_t, uint64_t, const void* const*, uint64_t*);
+int gor_download_word(void*, uint32_t, uint32_t, uint64_t, uint64_t, void*);
+int gor_download_alive(void*, uint64_t*, uint64_t);
+uint64_t gor_len(void*);
+uint64_t gor_active_count(void*);
+int32_t gor_frame(void*);
+void gor_set_frame(void*, int32_t);
+void gor_set_frame_rate(void*, uint64_t);
+void gor_set_depth(void*, uint32_t);
+void gor_set_confirmed(void*, int, int32_t);
+int gor_has_snapshot(void*, int32_t);
+uint64_t gor_snapshot_count(void*);
+int gor_handle_requests(void*, const ggrs_request*, uint32_t, uint64_t*);
+}
+struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to oracle/_build/libggrs_oracle.so
+    void* w; int32_t cd = -1;
+    OracleBackend(uint64_t capacity, uint32_t max_depth, int) : w(gor_world_create(capacity, max_depth, 0)) {}
+    ~OracleBackend() { gor_world_destroy(w); }
+    const char* last_error() { return gor_last_error(w); }
+    int register_component(const char* n, uint32_t wb, uint32_t nw, uint32_t* id) { return gor_register_component(w, n, wb, nw, id); }
+    int set_component_default(uint32_t c, const void* p) { return gor_set_component_default(w, c, p); }
+    int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return gor_checksum_component(w, c, idx, n); }
+    int add_system(const ggrs_system_desc* d) { return gor_add_system(w, d); }
+    int set_frame_rate(uint64_t fps) { gor_set_frame_rate(w, fps); return 0; }
+    int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return gor_spawn(w, count, mask, cols, first); }
+    int set_depth(uint32_t d) { gor_set_depth(w, d); return 0; }
+    int set_synctest_check_distance(int32_t c) { cd = c; return 0; }
+    int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) {
+        uint32_t ns = 0;
+        for (uint32_t i = 0; i < n; ++i) {        // schedule_systems.rs:204-220, applied per request
+            if (cd >= 0 && gor_frame(w) - cd >= 0) gor_set_confirmed(w, 1, gor_frame(w) - cd);
+            int rc = gor_handle_requests(w, r + i, 1, out + 2 * ns);
+            if (rc) return rc;
+            if (r[i].kind == GGRS_REQ_SAVE) ++ns;
+        }
+        return 0;
+    }
+    int32_t frame() { return gor_frame(w); }
+    int set_frame(int32_t f) { gor_set_frame(w, f); return 0; }
+    uint64_t len() { return gor_len(w); }
+    int active_count(uint64_t* out) { *out = gor_active_count(w); return 0; }
+    int download_word(uint32_t c, uint32_t word, uint64_t first, uint64_t count, void* dst) { return gor_download_word(w, c, word, first, count, dst); }
+    int download_alive(uint64_t* dst, uint64_t n) { return gor_download_alive(w, dst, n); }
+    int has_snapshot(int32_t f) { return gor_has_snapshot(w, f); }
+    uint64_t snapshot_count() { return gor_snapshot_count(w); }
+};
+using Backend = OracleBackend;
+#else
+using Backend = HipBackend;
+#endif
+
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } } while (0)
+
+// ---- tests/common/mod.rs:7-55
+using Config = GgrsConfig<uint8_t, size_t>;
+using TestApp = App<Config, Backend>;
+
+static void input_system(const LocalPlayers& players, LocalInputs<Config>& inputs) {
+    for (auto h : players.handles) inputs[h] = 0;
+}
+static SyncTestSession<Config> synctest_session(size_t check_distance) {
+    return SessionBuilder<Config>().with_num_players(1).with_check_distance(check_distance).add_player(PlayerType::Local, 0).start_synctest_session();
+}
+static void base_synctest_app(TestApp& app, size_t check_distance) {
+    app.add_plugins(GgrsPlugin<Config>{});
+    app.insert_resource(synctest_session(check_distance));
+    app.add_systems(ReadInputs{}, input_system);
+}
+
+struct Health {};
+struct Counter {};
+struct Transform {};
+struct Velocity {};
+struct Ttl {};
+namespace bevy_ggrs {
+template <> struct HipComponent<Health> { static constexpr const char* name = "Health"; static constexpr uint32_t word_bytes = 4, n_words = 1; };
+template <> struct HipComponent<Counter> { static constexpr const char* name = "Counter"; static constexpr uint32_t word_bytes = 4, n_words = 1; };
+template <> struct HipComponent<Transform> { static constexpr const char* name = "Transform"; static constexpr uint32_t word_bytes = 4, n_words = 10; };
+template <> struct HipComponent<Velocity> { static constexpr const char* name = "Velocity"; static constexpr uint32_t word_bytes = 4, n_words = 3; };
+template <> struct HipComponent<Ttl> { static constexpr const char* name = "Ttl"; static constexpr uint32_t word_bytes = 8, n_words = 1; };
+}
+
+// ggrs SyncTestSession::advance_frame request order
+static void synctest_request_shape() {
+    auto s = synctest_session(2);
+    std::string shape;
+    for (int t = 0; t < 5; ++t) {
+        s.add_local_input(0, 0);
+        for (auto& r : s.advance_frame()) {
+            shape += r.kind == GgrsRequest<Config>::SaveGameState ? 'S' : r.kind == GgrsRequest<Config>::LoadGameState ? 'L' : 'A';
+            if (r.kind == GgrsRequest<Config>::SaveGameState) r.cell->save(r.frame, nullptr, u128{1, 0});
+        }
+        shape += '|';
+    }
+    CHECK(shape == "SA|SA|SA|LASASA|LASASA|");
+    bool threw = false;
+    try { SessionBuilder<Config>().with_check_distance(8).start_synctest_session(); } catch (const GgrsError&) { threw = true; }
+    CHECK(threw);                                         // check_distance >= max_prediction is rejected
+    std::puts("ok synctest_request_shape");
+}
+
+// tests/synctest.rs:60-75
+static void despawn_and_rollback_does_not_panic() {
+    TestApp app(16);
+    base_synctest_app(app, 5);
+    app.rollback_component_with_copy<Health>();
+    app.add_systems(GgrsSchedule{}, systems::saturating_sub_despawn<Health>(1));
+    const uint32_t ten = 10;
+    app.set_component_default<Health>(&ten);
+    app.spawn(1, {"Health"});                             // Startup: commands.spawn((Health::default(), Rollback))
+    for (int i = 0; i < 60; ++i) app.update();
+    CHECK(app.active_count() == 0);                       // despawned and confirmed gone
+    std::puts("ok despawn_and_rollback_does_not_panic");
+}
+
+// tests/synctest.rs:84-125: something that is NOT rolled back leaks into a checksummed component
+static void mismatch_fires_on_non_determinism() {
+    TestApp app(4096);
+    base_synctest_app(app, 2);
+    app.rollback_component_with_copy<Transform>().rollback_component_with_copy<Velocity>().rollback_component_with_copy<Ttl>();
+    app.checksum_component_with_hash<Velocity>();
+    app.add_systems(GgrsSchedule{}, systems::update_particles<Transform, Velocity>(0, -200, 0));
+    app.add_systems(GgrsSchedule{}, systems::despawn_particles<Ttl>());
+    app.add_systems(GgrsSchedule{}, systems::spawn_particles<Transform, Velocity, Ttl>(300, 1 << 4));
+    app.add_systems(ReadInputs{}, [](const LocalPlayers& p, LocalInputs<Config>& in) { for (auto h : p.handles) in[h] = 1 << 4; });
+    static std::atomic<uint32_t> global{0};               // never rolled back
+    app.set_spawn_source([](Frame, std::vector<float>& vx, std::vector<float>& vy) {
+        const float v = (float)global.fetch_add(1);
+        vx.assign(4, v); vy.assign(4, -v);
+    });
+    int fired = 0;
+    app.add_observer([&](const SyncTestMismatch& m) { ++fired; CHECK(!m.mismatched_frames.empty()); });
+    for (int i = 0; i < 10; ++i) app.update();
+    CHECK(fired > 0);
+    std::puts("ok mismatch_fires_on_non_determinism");
+}
+
+// tests/synctest.rs:130-153
+static void confirmed_frame_pruning() {
+    TestApp app(16);
+    base_synctest_app(app, 2);
+    app.rollback_component_with_copy<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.spawn(1, {"Counter"});
+    for (int i = 0; i < 20; ++i) app.update();
+    CHECK(app.confirmed_frame_count() > 0);
+    CHECK(!app.backend().has_snapshot(0));                // frame-0 snapshot pruned after confirmation
+    CHECK(app.backend().has_snapshot(app.rollback_frame_count() - 1));
+    std::puts("ok confirmed_frame_pruning");
+}
+
+// tests/component_rollback.rs:90-119: 20 ticks at cd = 2, observer panics on mismatch, value == RollbackFrameCount
+static void component_rollback_copy() {
+    TestApp app(16);
+    base_synctest_app(app, 2);
+    app.rollback_component_with_copy<Counter>().checksum_component_with_hash<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch"); });
+    app.spawn(1, {"Counter"});
+    for (int i = 0; i < 20; ++i) app.update();
+    auto v = app.download<Counter, uint32_t>(0);
+    CHECK(v.size() == 1 && (Frame)v[0] == app.rollback_frame_count() && v[0] == 20);
+    std::puts("ok component_rollback_copy");
+}
+
+// run_ggrs_schedules accumulator (src/schedule_systems.rs:19-83) + tests/time.rs:18-49
+static void fixed_timestep_accumulator() {
+    TestApp app(16);
+    base_synctest_app(app, 2);
+    app.rollback_component_with_copy<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.spawn(1, {"Counter"});
+    const uint64_t frame_ns = 1000000000ULL / 60;
+    app.update(std::chrono::nanoseconds(frame_ns / 2));   CHECK(app.rollback_frame_count() == 0);   // not enough time accumulated
+    app.update(std::chrono::nanoseconds(frame_ns / 2 + 1)); CHECK(app.rollback_frame_count() == 1);
+    app.update(std::chrono::nanoseconds(frame_ns * 5 / 2)); CHECK(app.rollback_frame_count() == 3);  // 2 whole steps, half a frame kept
+    app.update(std::chrono::nanoseconds(frame_ns / 2 + 2)); CHECK(app.rollback_frame_count() == 4);
+    TestApp idle(16);                                      // no session inserted: counters reset, nothing runs
+    idle.add_plugins(GgrsPlugin<Config>{});
+    idle.update();
+    CHECK(idle.rollback_frame_count() == 0 && idle.confirmed_frame_count() == -1 && idle.max_prediction_window() == 8);
+    std::puts("ok fixed_timestep_accumulator");
+}
+
+// examples/stress_tests/particles.rs:187-240 through the plugin API; prints every checksum
+static void particles(uint64_t n, int ticks, size_t cd) {
+    TestApp app(n + 100 * (uint64_t)ticks + 64);
+    base_synctest_app(app, cd);
+    app.insert_resource(RollbackFrameRate{60});
+    app.rollback_component_with_clone<Transform>().rollback_component_with_copy<Velocity>().rollback_component_with_copy<Ttl>();
+    app.checksum_component_with_hash<Velocity>();
+    app.checksum_component<Transform>({0, 1, 2});          // translation only (particles.rs:207-222)
+    const float tdef[10] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+    app.set_component_default<Transform>(tdef);
+    app.add_systems(GgrsSchedule{}, systems::update_particles<Transform, Velocity>(0, -200, 0));
+    app.add_systems(GgrsSchedule{}, systems::despawn_particles<Ttl>());
+    app.add_systems(GgrsSchedule{}, systems::spawn_particles<Transform, Velocity, Ttl>(40, 1 << 4));
+    int tick_no = 0;
+    app.add_systems(ReadInputs{}, [&](const LocalPlayers& p, LocalInputs<Config>& in) { for (auto h : p.handles) in[h] = (tick_no % 3 == 1) ? (1 << 4) : 0; });
+    app.set_spawn_source([](Frame f, std::vector<float>& vx, std::vector<float>& vy) {   // pure function of the frame
+        vx.resize(100); vy.resize(100);
+        uint32_t s = 0x9E3779B9u * (uint32_t)(f + 1);
+        for (int i = 0; i < 100; ++i) { s = s * 1664525u + 1013904223u; vx[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f; s = s * 1664525u + 1013904223u; vy[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f; }
+    });
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch"); });
+    std::vector<float> vx(n), vy(n), vz(n, 0.0f);
+    std::vector<uint64_t> ttl(n);
+    uint32_t s = 123;
+    for (uint64_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u; vx[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f;
+        s = s * 1664525u + 1013904223u; vy[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f;
+        ttl[i] = 1 + i % 300;
+    }
+    std::vector<const void*> cols(10, nullptr);            // Transform: defaults
+    cols.push_back(vx.data()); cols.push_back(vy.data()); cols.push_back(vz.data()); cols.push_back(ttl.data());
+    app.spawn(n, {"Transform", "Velocity", "Ttl"}, cols);
+    for (tick_no = 0; tick_no < ticks; ++tick_no) {
+        app.update();
+        for (auto& c : app.last_checksums()) std::printf("checksum %d %016llx%016llx\n", tick_no, (unsigned long long)c.hi, (unsigned long long)c.lo);
+    }
+    auto x = app.download<Transform, uint32_t>(1);
+    uint64_t fold = 0;
+    for (size_t i = 0; i < x.size(); ++i) fold = fold * 1099511628211ULL + x[i];
+    std::printf("final frame %d len %llu active %llu ty_fold %016llx\n", app.rollback_frame_count(), (unsigned long long)app.backend().len(),
+                (unsigned long long)app.active_count(), (unsigned long long)fold);
+    std::puts("ok particles");
+}
+
+int main(int argc, char** argv) {
+    const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 5000;
+    synctest_request_shape();
+    despawn_and_rollback_does_not_panic();
+    mismatch_fires_on_non_determinism();
+    confirmed_frame_pruning();
+    component_rollback_copy();
+    fixed_timestep_accumulator();
+    particles(n, 24, 7);
+    return 0;
+}

@@ -2,7 +2,7 @@
 replicated confirmed advance, the single all-gather, desync detection) with world_size 2 over
 gloo.  The worlds here are oracle worlds (test infrastructure); the packed-state broadcast is
 replaced by a host-side exchange with the same contract.  The HIP/RCCL exchange itself is
-covered by tests/test_gpu_fanout.py (world_size 1 over nccl on the GPU box)."""
+covered by tests/test_gpu_zfanout.py (world_size 1 over nccl on the GPU box)."""
 import os
 import sys
 

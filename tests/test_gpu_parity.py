@@ -26,7 +26,7 @@ def _run(world, n, cd, ticks, ttl_mode="despawn", with_spawn=True, ttl_init=40, 
 
 
 @pytest.mark.parametrize("n,cd,ticks", [(1, 2, 12), (63, 1, 10), (1000, 2, 20), (1025, 7, 24), (10_000, 8, 30), (100_000, 8, 14)])
-@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_UNFUSED])
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_NO_GROUPS, bg.GGRS_WORLD_UNFUSED])
 def test_particles_synctest_checksums_and_state(n, cd, ticks, flags):
     cap = n + 100 * ticks + 64
     g, o = _pair(cap, 16, flags)
@@ -141,7 +141,7 @@ def test_full_size_properties_1m():
     n = 1_000_000
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     outs = []
-    for flags in (0, bg.GGRS_WORLD_UNFUSED):
+    for flags in (0, bg.GGRS_WORLD_NT_COPY, bg.GGRS_WORLD_NO_GROUPS, bg.GGRS_WORLD_UNFUSED):
         w = bg.World(n, max_depth=9, flags=flags)
         ids = cm.build_particles(w)
         cm.spawn_particles(w, ids, n, vel, ttl)
@@ -157,4 +157,4 @@ def test_full_size_properties_1m():
         w.load(f_old)
         assert w.save() == want
         w.close()
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
