@@ -41,9 +41,9 @@ ADV_BYTES = 64                 # r/w translation 12 + velocity 12 + ttl 8
 TICK_BYTES = lambda d: SAVE_BYTES + SAVE_BYTES * d + ADV_BYTES * (d + 1)   # 1656 at d = 8
 
 
-def build_world(bg, cm, n, depth, stream=0, flags=0):
+def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True):
     w = bg.World(n, max_depth=depth + 1, stream=stream, flags=flags)
-    ids = cm.build_particles(w)
+    ids = cm.build_particles(w, checksum=checksum)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)
     w.set_depth(depth + 1)
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one kernel per reference system (no fusion at all)")
     ap.add_argument("--no-groups", action="store_true", help="one launch per request (no request-group fusion)")
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
+    ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
 
     import torch
@@ -131,7 +132,7 @@ def main():
     flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
 
     if world_size == 1:
-        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags)
+        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum)
         warm_ring(bg, w, D)
         run, _keep = tick_requests(bg, w, D)
         for _ in range(W):
@@ -248,7 +249,7 @@ def main():
                    "entities_per_gpu": live, "depth": D,
                    "parallelism": "single GPU" if world_size == 1 else f"speculative fan-out, 1 branch per rank x {world_size} ranks",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "nt_stores": bool(args.nt)},
+                   "nt_stores": bool(args.nt), **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:

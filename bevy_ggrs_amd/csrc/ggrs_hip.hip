@@ -294,7 +294,7 @@ int seal(ggrs_world* w) {
     for (uint32_t i = 0; i < w->max_depth; ++i) { w->slots[i].ptr = p; p += w->state_bytes; w->free_slots.push_back((int)(w->max_depth - 1 - i)); }
     w->d_parts = (uint64_t*)p; p += parts_bytes;
     w->d_tick_parts = (uint64_t*)p; p += tick_parts_bytes;
-    w->d_results = (uint64_t*)p; p += res_bytes;
+    p += res_bytes;                                  // (reserved; results live in pinned host memory, see below)
     w->d_units = (UnitDesc*)p; p += units_bytes;
     w->d_maskoffs = (uint64_t*)p; p += ALIGN;
     w->d_stage = (float*)p; p += stage_bytes;
@@ -302,7 +302,10 @@ int seal(ggrs_world* w) {
     w->cks_args.part_cnt = w->d_parts + (uint64_t)w->cks_args.n_cks * w->part_stride;
     w->cks_args.part_stride = w->part_stride;
 
-    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16));
+    // Checksum(u128) results are written by the kernels straight into pinned, device-mapped host memory:
+    // no device->host copy node per request list, one stream sync makes them visible.
+    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
+    HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
     HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
     // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
     // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
@@ -623,7 +626,6 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
 }
 
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
-    if (n_results) HIPCHK(w, hipMemcpyAsync(w->h_results, w->d_results, (size_t)n_results * 16, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->stage_used = 0;
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
@@ -753,7 +755,7 @@ extern "C" {
 int ggrs_hip_abi_version(void) { return GGRS_HIP_ABI_VERSION; }
 
 int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
-    if (!d || !out || d->capacity == 0) return GGRS_E_INVALID;
+    if (!d || !out || d->capacity == 0 || d->capacity > (1ULL << 28)) return GGRS_E_INVALID;   // 32-bit lane offsets in the kernels
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || d->device >= n) return GGRS_E_NO_DEVICE;
     if (hipSetDevice(d->device) != hipSuccess) return GGRS_E_NO_DEVICE;

@@ -434,25 +434,39 @@ struct TickArgs {
     RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
 };
 
+// Pins a wave-uniform pointer into an SGPR pair so that `sgpr_base(p) + lane_offset_u32` selects the
+// saddr form of global_load/global_store (no 64-bit VALU address arithmetic per access).  The value
+// comes back as an explicit global (address space 1) pointer: laundering a generic pointer through
+// inline asm would otherwise make the compiler fall back to flat_* instructions.
+#define GGRS_GLOBAL __attribute__((address_space(1)))
+typedef GGRS_GLOBAL uint8_t g_u8;
+__device__ __forceinline__ g_u8* sgpr_base(const uint8_t* p) {
+    uint64_t x = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(x));
+    return (g_u8*)x;
+}
+
 template <bool NT, class V>
-__device__ __forceinline__ void st16(uint8_t* p, const V& v) {
+__device__ __forceinline__ void st16(g_u8* p, const V& v) {
     static_assert(sizeof(V) == 16, "16-byte register tuple");
     const u32x4 x = reinterpret_cast<const u32x4&>(v);
-    if (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p));
-    else *reinterpret_cast<u32x4*>(p) = x;
+    if (NT) __builtin_nontemporal_store(x, (GGRS_GLOBAL u32x4*)p);
+    else *(GGRS_GLOBAL u32x4*)p = x;
 }
+__device__ __forceinline__ void st8(g_u8* p, uint64_t v) { *(GGRS_GLOBAL uint64_t*)p = v; }
 
 template <int B, bool NT>
 __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_t t, uint32_t tid) {
     u32x4 v[B];
-    uint64_t pos[B];
+    uint64_t pos[B];                          // wave-uniform part of the address (SGPRs)
+    const uint32_t lo = tid * 16u;            // per-lane part
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         const RowLite rd = a.rest[r0 + j];
-        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff;
     }
 #pragma unroll
-    for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const u32x4*>(a.src + pos[j]);
+    for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const u32x4*>(a.src + pos[j] + lo);
     // gfx9 counts loads AND stores in vmcnt: land the loads once here, or the compiler throttles
     // every store of the fan-out loop behind a conservative vmcnt(B-1)
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
@@ -461,13 +475,12 @@ __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_
         if (!dst) continue;
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(dst + pos[j]));
-            else *reinterpret_cast<u32x4*>(dst + pos[j]) = v[j];
+            st16<NT>(sgpr_base(dst + pos[j]) + lo, v[j]);
         }
     }
     if (!a.src_is_live) {
 #pragma unroll
-        for (int j = 0; j < B; ++j) *reinterpret_cast<u32x4*>(a.live + pos[j]) = v[j];
+        for (int j = 0; j < B; ++j) st16<false>(sgpr_base(a.live + pos[j]) + lo, v[j]);
     }
 }
 
@@ -476,24 +489,27 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool in_len = (uint64_t)t * TILE < a.len;               // workgroup-uniform
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
-    const uint64_t w0 = (uint64_t)t * 16 + wave * 4;              // first mask word of this wave
+    // 32-bit per-lane byte offsets (capacity is capped at 2^28 slots): every access below is
+    // "uniform 64-bit base + 32-bit lane offset", i.e. the saddr form of global_load/store
+    const uint32_t o4 = (uint32_t)e0 * 4u, o8 = (uint32_t)e0 * 8u;
+    const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
-    const uint64_t wi = w0 + (lane >> 4);
+    const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;                 // byte offset of this lane's mask word
 
     // ---- every load of the schedule-owned state, back to back
-    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi * 8);
-    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi * 8);
-    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi * 8);
-    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi * 8);
+    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
+    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
+    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
+    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
     float4 tx[3], vv[3];
     ulonglong2 tl[2];
     if (in_len) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + e0 * 4);
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + o4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + e0 * 4);
-        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + e0 * 8);
-        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + e0 * 8 + 16);
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + o4);
+        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + o8);
+        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + 16 + o8);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
@@ -539,7 +555,49 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
         for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
     }
 
+    // SaveWorld, per-entity half of the checksum (component_checksum.rs:77-90) of the registers as they
+    // are now; one partial per wave.
     uint32_t si = 0, sj = 0;
+    auto hash_save = [&](uint32_t cnt) {
+        uint64_t hT = 0, hV = 0;
+        if (CKS_T || CKS_V) {
+            const uint32_t c_T = CKS_T ? (alive4 & n_T) : 0u, c_V = CKS_V ? (alive4 & n_V) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (CKS_T) {
+                    const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                                        __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                                        __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+                    hT ^= ((c_T >> j) & 1u) ? h : 0ULL;
+                }
+                if (CKS_V) {
+                    const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                                        __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                                        __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+                    hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
+                }
+            }
+            if (CKS_T) hT = wave_xor(hT);
+            if (CKS_V) hV = wave_xor(hV);
+        }
+        if (lane == 0) {
+            // plain per-wave partial stores: agent-scope atomics (tried: 64 accumulator copies + last-block
+            // fold) cost ~1 ns EACH chip-wide on gfx950 -- 94k of them added 90 us to a 134 us kernel
+            uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
+            p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = cnt;
+        }
+    };
+    // All waves of the chip start together and run the same op sequence, so without a stagger every
+    // wave would be storing at the same time and hashing at the same time (memory idle while the ALUs
+    // hash).  Odd waves hash a Save BEFORE storing it, even waves after: at any moment half the waves
+    // of a SIMD feed the memory pipe while the other half multiply.
+    const bool hash_first = (wave & 1u) != 0;                     // wave-uniform
+
+    // every load issued above has to land before the first op anyway; saying so explicitly keeps the
+    // compiler from guarding the op loop / the final live write with conservative vmcnt waits (gfx9
+    // counts stores in vmcnt too: such a wait would drain every snapshot store in flight)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0) expcnt(7) lgkmcnt(15)
+
     for (uint32_t i = 0; i < a.n_ops; ++i) {
         if (!((a.op_bits >> i) & 1ULL)) {
             // ---------------- SaveWorld: snapshot (component_snapshot.rs:66-84, entity.rs:39-51)
@@ -547,15 +605,16 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
             const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
                            b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
             const uint32_t cnt = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (hash_first) hash_save(cnt);
             if (dst) {
                 if (in_len) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        st16<NT>(dst + a.off_t[k] + e0 * 4, tx[k]);
-                        st16<NT>(dst + a.off_v[k] + e0 * 4, vv[k]);
+                        st16<NT>(sgpr_base(dst + a.off_t[k]) + o4, tx[k]);
+                        st16<NT>(sgpr_base(dst + a.off_v[k]) + o4, vv[k]);
                     }
-                    st16<NT>(dst + a.off_ttl + e0 * 8, tl[0]);
-                    st16<NT>(dst + a.off_ttl + e0 * 8 + 16, tl[1]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl) + o8, tl[0]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl + 16) + o8, tl[1]);
                 }
                 uint64_t mine = 0;
 #pragma unroll
@@ -564,11 +623,11 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
                                         (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
                     if (lane == (uint32_t)w) mine = nw;
                 }
-                if (lane < 4) *reinterpret_cast<uint64_t*>(dst + a.off_alive + (w0 + lane) * 8) = mine;
+                if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
                 if ((lane & 15u) == 0) {
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pT + wi * 8) = pT_w;
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pV + wi * 8) = pV_w;
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pL + wi * 8) = pL_w;
+                    st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
+                    st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
+                    st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
                 }
                 if (t == 0 && tid == 0) {
                     Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
@@ -576,32 +635,7 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
                     *reinterpret_cast<Header*>(dst) = h;
                 }
             }
-            // ---------------- SaveWorld: per-entity half of the checksum (component_checksum.rs:77-90)
-            uint64_t hT = 0, hV = 0;
-            if (CKS_T || CKS_V) {
-                const uint32_t c_T = CKS_T ? (alive4 & n_T) : 0u, c_V = CKS_V ? (alive4 & n_V) : 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (CKS_T) {
-                        const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
-                                                                      __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
-                                                                      __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
-                        hT ^= ((c_T >> j) & 1u) ? h : 0ULL;
-                    }
-                    if (CKS_V) {
-                        const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
-                                                                      __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
-                                                                      __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
-                        hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
-                    }
-                }
-                if (CKS_T) hT = wave_xor(hT);
-                if (CKS_V) hV = wave_xor(hV);
-            }
-            if (lane == 0) {
-                uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
-                p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = cnt;
-            }
+            if (!hash_first) hash_save(cnt);
             ++si;
         } else {
             // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
@@ -641,11 +675,11 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
         if (in_len) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                *reinterpret_cast<float4*>(a.live + a.off_t[k] + e0 * 4) = tx[k];
-                *reinterpret_cast<float4*>(a.live + a.off_v[k] + e0 * 4) = vv[k];
+                st16<false>(sgpr_base(a.live + a.off_t[k]) + o4, tx[k]);
+                st16<false>(sgpr_base(a.live + a.off_v[k]) + o4, vv[k]);
             }
-            *reinterpret_cast<ulonglong2*>(a.live + a.off_ttl + e0 * 8) = tl[0];
-            *reinterpret_cast<ulonglong2*>(a.live + a.off_ttl + e0 * 8 + 16) = tl[1];
+            st16<false>(sgpr_base(a.live + a.off_ttl) + o8, tl[0]);
+            st16<false>(sgpr_base(a.live + a.off_ttl + 16) + o8, tl[1]);
         }
         const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
                        b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
@@ -656,22 +690,23 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
                                 (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
             if (lane == (uint32_t)w) mine = nw;
         }
-        if (lane < 4) *reinterpret_cast<uint64_t*>(a.live + a.off_alive + (w0 + lane) * 8) = mine;
+        if (lane < 4) st8(sgpr_base(a.live + a.off_alive) + (w0 + lane) * 8u, mine);
         if (!a.src_is_live && (lane & 15u) == 0) {
-            *reinterpret_cast<uint64_t*>(a.live + a.off_pT + wi * 8) = pT_w;
-            *reinterpret_cast<uint64_t*>(a.live + a.off_pV + wi * 8) = pV_w;
-            *reinterpret_cast<uint64_t*>(a.live + a.off_pL + wi * 8) = pL_w;
+            st8(sgpr_base(a.live + a.off_pT) + wi8, pT_w);
+            st8(sgpr_base(a.live + a.off_pV) + wi8, pV_w);
+            st8(sgpr_base(a.live + a.off_pL) + wi8, pL_w);
         }
     }
+
 }
 
-// Folds the per-wave partials of every Save of a fused group: one workgroup per Save.
+// Folds the per-wave partials of every Save of a fused group: one 1024-thread workgroup per Save.
 // component_checksum.rs:92-95 (hash the XOR once more), entity_checksum.rs:29-52,
 // checksum.rs:88-99 (XOR of all parts; upper 64 bits of the u128 are always 0).
 struct TickFinArgs {
     const uint64_t* parts; uint32_t part_stride, n_parts, cks_T, cks_V;
     uint64_t total_len;
-    uint64_t* out;                         // {lo, hi} per Save
+    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
 };
 constexpr int FIN_TPB = 1024;
 __global__ __launch_bounds__(FIN_TPB) void k_tick_finalize(TickFinArgs f) {
