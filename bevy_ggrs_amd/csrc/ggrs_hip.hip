@@ -13,6 +13,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -89,6 +90,7 @@ struct ggrs_world {
     bool tick_ok = false; uint32_t f_lw = 0;
     TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
     uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
+    int tick_vec = 0;                    // 0: pick per launch by size; 1 / 4: forced (GGRS_TICK_VEC, A/B knob)
 
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
@@ -272,7 +274,7 @@ int seal(ggrs_world* w) {
 
     // ---- arena carve
     const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
-    w->tick_part_stride = 4 * n_tiles;
+    w->tick_part_stride = 4 * (uint32_t)(w->cap_pad / TILE1);     // one partial per wave of the finest tiling
     const uint64_t tick_parts_bytes = align_up((uint64_t)MAX_TICK_SAVES * 3 * w->tick_part_stride * 8, ALIGN);
     w->part_stride = n_tiles + 4096 / 1;            // + room for spawn partial blocks
     const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
@@ -640,6 +642,7 @@ void apply_synctest_confirmed(ggrs_world* w) {
 }
 
 // ---- fused request groups: [Load?] (Save | Advance)* as ONE k_tick launch + one finalize ----
+constexpr uint64_t TICK_VEC1_MAX_SLOTS = 512 * 1024;   // measured crossover, see DESIGN.md section 6
 bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
     if (r.spawn_count == 0) return false;
     for (auto& s : w->systems) {
@@ -647,6 +650,14 @@ bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
         for (uint32_t k = 0; k < r.n_inputs; ++k) if (r.inputs[k] & (uint8_t)s.iparam[1]) return true;
     }
     return false;
+}
+
+template <bool NT>
+void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick1<true, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick1<false, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick1<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
 }
 
 template <bool NT>
@@ -709,12 +720,16 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         }
         // ---- one pass over the tiles
         cover = std::max(cover, w->len);
-        const uint32_t g = std::max(1u, tiles_for(cover));
+        // tile width: 1 slot/lane (256-slot tiles) for worlds that would not fill the chip with
+        // 1024-slot tiles, 4 slots/lane (16-byte accesses) for big ones
+        const int vec = w->tick_vec ? w->tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : 4);
+        const uint32_t g = vec == 1 ? std::max(1u, (uint32_t)((cover + TILE1 - 1) / TILE1)) : std::max(1u, tiles_for(cover));
         a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
-            if (w->nt_copy) launch_tick<true>(w, a, g); else launch_tick<false>(w, a, g);
+            if (vec == 1) { if (w->nt_copy) launch_tick1<true>(w, a, g); else launch_tick1<false>(w, a, g); }
+            else { if (w->nt_copy) launch_tick<true>(w, a, g); else launch_tick<false>(w, a, g); }
         }
         HIPCHK(w, hipGetLastError());
         const uint64_t new_dirty = std::max(src->dirty_len, w->len);
@@ -764,6 +779,7 @@ int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
     w->max_depth = d->max_depth ? d->max_depth : 8; w->flags = d->flags;
     w->depth = w->max_depth;
     w->nt_copy = (d->flags & GGRS_WORLD_NT_COPY) != 0;
+    if (const char* v = getenv("GGRS_TICK_VEC")) { const int x = atoi(v); if (x == 1 || x == 4) w->tick_vec = x; }
     if (d->stream) w->stream = (hipStream_t)d->stream;
     else {
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return GGRS_E_HIP; }
@@ -784,7 +800,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     // each 4-byte word column is 256-B aligned; bytes_per_slot/4 bounds the column count
     const uint64_t state = align_up(ALIGN + (1 + (uint64_t)n_components) * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
-                           align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE) * 8, ALIGN);
+                           align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     return (uint64_t)(max_depth + 1) * state + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {

@@ -700,6 +700,167 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
 
 }
 
+// ------------------------------------------------------------------ k_tick1 (one slot per lane)
+// The same fused request group with a 256-slot tile: one slot per lane, one wave == one 64-bit mask
+// word (the wave's __ballot IS the liveness word).  Four times as many, four times lighter
+// workgroups: small worlds (10k..100k entities: BASELINE configs 2, 4, 5) fill the 256 CUs instead
+// of leaving most of them idle behind a few long-running 1024-slot tiles, ~60 VGPRs give 8 waves/SIMD,
+// and with more workgroups than residency slots the read phase of late tiles overlaps the store phase
+// of early ones.  Accesses are 4 B (8 B for u64 columns) per lane: 256 B per wave instruction.
+constexpr int TILE1 = 256;
+template <bool CKS_T, bool CKS_V, bool NT>
+__global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool in_len = (uint64_t)t * TILE1 < a.len;              // workgroup-uniform
+    const uint32_t e = t * TILE1 + tid;                           // this lane's slot
+    const uint32_t o4 = e * 4u, o8 = e * 8u;
+    const uint32_t wi8 = (t * 4u + wave) * 8u;                    // this wave's mask word
+
+    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
+    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
+    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
+    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
+    float tx[3] = {0, 0, 0}, vv[3] = {0, 0, 0};
+    uint64_t ttl = 0;
+    if (in_len) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float*>(a.src + a.off_t[k] + o4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float*>(a.src + a.off_v[k] + o4);
+        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + o8);
+    }
+
+    // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
+    if (tid < 4u * a.n_rest_masks) {
+        const uint32_t m = tid >> 2, mw = tid & 3u;
+        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)t * 4 + mw) * 8;
+        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
+        for (uint32_t k = 0; k < a.n_saves; ++k)
+            if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
+        if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+    }
+    if (in_len && (a.n_saves || !a.src_is_live)) {
+        // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0 and
+        // word_bytes = tile_stride / 1024.  Up to 8 columns per batch, one wait per batch.
+        const uint32_t n_rows = a.n_rest_rows;
+        uint32_t r = 0;
+        while (r < n_rows) {
+            uint64_t v[8]; uint64_t off[8]; uint32_t wb[8];
+            int nb = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = 0; off[j] = 0; wb[j] = 0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                while (r < n_rows && a.rest[r].roff != 0) ++r;
+                if (r < n_rows) {
+                    const RowLite rd = a.rest[r]; ++r;
+                    wb[j] = rd.tile_stride >> 10; off[j] = rd.col_off; nb = j + 1;
+                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + o8);
+                    else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + o4);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): land the loads once
+            for (uint32_t k = 0; k <= a.n_saves; ++k) {
+                uint8_t* dst = k < a.n_saves ? a.save_dst[k] : (a.src_is_live ? nullptr : a.live);
+                if (!dst) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nb) {
+                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + o8) = v[j];
+                        else *reinterpret_cast<uint32_t*>(dst + off[j] + o4) = (uint32_t)v[j];
+                    }
+                }
+            }
+        }
+    }
+
+    bool alive = (alive_w >> lane) & 1ULL;
+    const bool has_T = (pT_w >> lane) & 1ULL, has_V = (pV_w >> lane) & 1ULL, has_L = (pL_w >> lane) & 1ULL;
+    uint64_t ordB = 0;
+    if (CKS_T || CKS_V) ordB = sea_order_lane(e);
+
+    uint32_t si = 0, sj = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // see k_tick: keep the op loop wait-free
+    for (uint32_t i = 0; i < a.n_ops; ++i) {
+        if (!((a.op_bits >> i) & 1ULL)) {
+            // ---------------- SaveWorld
+            uint8_t* dst = a.save_dst[si];
+            const uint64_t alive_now = __ballot(alive);           // == this wave's liveness word
+            if (dst) {
+                if (in_len) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        *reinterpret_cast<float*>(dst + a.off_t[k] + o4) = tx[k];
+                        *reinterpret_cast<float*>(dst + a.off_v[k] + o4) = vv[k];
+                    }
+                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + o8) = ttl;
+                }
+                if (lane == 0) {
+                    *reinterpret_cast<uint64_t*>(dst + a.off_alive + wi8) = alive_now;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pT + wi8) = pT_w;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pV + wi8) = pV_w;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_pL + wi8) = pL_w;
+                }
+                if (t == 0 && tid == 0) {
+                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
+                    h.checksum[0] = 0; h.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = h;
+                }
+            }
+            uint64_t hT = 0, hV = 0;
+            if (CKS_T) {
+                const uint64_t h = sea_pair_pre(ordB, sea_inner3(__float_as_uint(tx[0]), __float_as_uint(tx[1]), __float_as_uint(tx[2])));
+                hT = wave_xor((alive && has_T) ? h : 0ULL);
+            }
+            if (CKS_V) {
+                const uint64_t h = sea_pair_pre(ordB, sea_inner3(__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2])));
+                hV = wave_xor((alive && has_V) ? h : 0ULL);
+            }
+            if (lane == 0) {
+                uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
+                p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = (uint64_t)__popcll(alive_now);
+            }
+            ++si;
+        } else {
+            // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
+            const float dt = __uint_as_float(a.dt_bits[sj]);
+            ++sj;
+            const bool upd = alive && has_T && has_V, tt = alive && has_L;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float gd = __fmul_rn(a.g[k], dt);
+                const float nv = __fadd_rn(vv[k], gd);
+                const float nx = __fadd_rn(tx[k], __fmul_rn(nv, dt));
+                vv[k] = upd ? nv : vv[k];
+                tx[k] = upd ? nx : tx[k];
+            }
+            const uint64_t nq = ttl - 1;                          // usize, wrapping
+            ttl = tt ? nq : ttl;
+            alive = alive && !(tt && nq == 0);                    // despawn is deferred to the end of the frame
+        }
+    }
+
+    if (!a.src_is_live || a.n_steps) {
+        if (in_len) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<float*>(a.live + a.off_t[k] + o4) = tx[k];
+                *reinterpret_cast<float*>(a.live + a.off_v[k] + o4) = vv[k];
+            }
+            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + o8) = ttl;
+        }
+        const uint64_t alive_now = __ballot(alive);
+        if (lane == 0) {
+            *reinterpret_cast<uint64_t*>(a.live + a.off_alive + wi8) = alive_now;
+            if (!a.src_is_live) {
+                *reinterpret_cast<uint64_t*>(a.live + a.off_pT + wi8) = pT_w;
+                *reinterpret_cast<uint64_t*>(a.live + a.off_pV + wi8) = pV_w;
+                *reinterpret_cast<uint64_t*>(a.live + a.off_pL + wi8) = pL_w;
+            }
+        }
+    }
+}
+
 // Folds the per-wave partials of every Save of a fused group: one 1024-thread workgroup per Save.
 // component_checksum.rs:92-95 (hash the XOR once more), entity_checksum.rs:29-52,
 // checksum.rs:88-99 (XOR of all parts; upper 64 bits of the u128 are always 0).

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""rocprofv3 counter CSVs -> profiles/<tag>/pmc_summary.json (+ profiles/roofline_traffic.json).
+
+FETCH_SIZE and WRITE_SIZE are collected in SEPARATE `rocprofv3 --pmc` passes (they do not fit one
+pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Units are KiB per dispatch.
+Corrections, as that guide prescribes: FETCH_SIZE under-reports wide (16 B/lane) streaming reads by
+exactly 2x on gfx950 -> doubled; WRITE_SIZE is calibrated against this engine's own known byte
+count (one snapshot copy writes 60.5 MB -> reported 59 082 KiB: exact, no correction).
+
+usage: pmc_summary.py <gpurun_out/tag> <profiles/tag>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(pattern, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(pattern, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter and "ggrs" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    out = {"note": __doc__.split("usage:")[0].strip()}
+    fetch = collect(os.path.join(src, "prof_fetch", "**", "*counter_collection.csv"), "FETCH_SIZE")
+    write = collect(os.path.join(src, "prof_write", "**", "*counter_collection.csv"), "WRITE_SIZE")
+    for k in sorted(set(fetch) | set(write)):
+        d = {}
+        for name, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            v = agg.get(k, [])
+            v = v[len(v) // 2:]                       # steady state: second half of the dispatches
+            if v:
+                d[name + "_KiB_mean"] = sum(v) / len(v)
+                d["dispatches_" + name] = len(agg[k])
+        if "FETCH_SIZE_KiB_mean" in d and "WRITE_SIZE_KiB_mean" in d:
+            d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024
+        out[k] = d
+    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+    roof = {}
+    for k, d in out.items():
+        if isinstance(d, dict) and "hbm_bytes_per_launch_corrected" in d:
+            if "k_tick<" in k or k.endswith("k_tick"):
+                roof["k_tick_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+            if "k_copy_state" in k:
+                roof["k_copy_state_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+    if roof:
+        roof["source"] = os.path.join(dst, "pmc_summary.json")
+        json.dump(roof, open(os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
