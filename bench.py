@@ -5,19 +5,25 @@ One "step" = one SyncTest tick at depth D = 8 over N_ENT = 1M particles x 3 regi
 components (Transform 40 B + Velocity 12 B + Ttl 8 B = 60 B/entity):
     [LoadGameState(F-8), Advance, (SaveGameState, Advance) x 7, SaveGameState(F), Advance]
   = 1 LoadWorld + 8 SaveWorld(+checksum) + 9 AdvanceWorld          
-executed by libggrs_hip.so as ONE ggrs_hip_handle_requests call per tick.  Inputs are resident
-in HBM before the timed region; the only host traffic per tick is the 8 x 16 B checksum read-back
-that the reference's `cell.save(frame, None, Some(checksum))` needs.
+handed to libggrs_hip.so as ONE request list per tick (the C ABI's handle_requests boundary).  The
+world is resident in HBM before the timed region; per tick the host sends ~1 KB of kernel arguments
+and receives the 8 x 16 B Checksum(u128)s that the reference's `cell.save(frame, None, Some(checksum))`
+needs.  Default host API: ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums with one tick in
+flight (a shim collects right before the next advance_frame()); `--sync` blocks on every tick.
 
   value     = entities x 9 advances x steps / seconds      (whole job, all ranks)
-  roofline  = dominant kernel k_copy_state (SaveWorld snapshot copy, 8 of the 18 launches and
-              960 of the 1656 algorithmic bytes per entity-tick): 120 B x entities per launch
-              / its mean duration from HIP events on the world's stream.
+  roofline  = dominant kernel k_tick (the fused request group: read one snapshot, write D snapshots,
+              write live once): compulsory 60 x (D + 2) B x entities per launch / its mean duration
+              from HIP events recorded on the world's stream inside libggrs_hip.so; `traffic` = HBM
+              bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/roofline_traffic.json).
+              SURVEY 8d's one-kernel-per-request figure (1656 B/entity-tick) is reported as
+              per_request_equiv_*; `--no-groups` measures that path itself.
   cpu_baseline = the oracle's REFERENCE-SHAPED variant (kind "port"), 1 thread, bounded sample.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): speculative fan-out -- rank 0's
-confirmed snapshot is broadcast over RCCL/xGMI, each rank re-simulates its own predicted-input
-branch for D frames, checksums are all-gathered.  Weak scaling (per-GPU work fixed).
+confirmed snapshot is broadcast ONCE over RCCL/xGMI, then each rank re-simulates its own
+predicted-input branch for D frames and advances its replica of the confirmed frame; one
+all-gather of checksums per step.  Weak scaling (per-GPU work fixed).
 """
 from __future__ import annotations
 
@@ -61,12 +67,26 @@ def tick_requests(bg, w, depth):
     out = (C.c_uint64 * (2 * n_save))()
     save_idx = [i for i, r in enumerate(reqs) if isinstance(r, bg.SaveGameState)]
 
-    def run(F):
+    def patch(F):
         arr[0].frame = F - depth
         for k, i in enumerate(save_idx):
             arr[i].frame = F - depth + 1 + k
+
+    def run(F):
+        patch(F)
         w.handle_requests_raw(arr, len(reqs), out)
         return out
+
+    def enqueue(F):
+        """ggrs_hip_enqueue_requests: the request list is copied into kernel arguments at enqueue time,
+        so the same ctypes array can be re-patched for the next tick while this one runs."""
+        patch(F)
+        w.enqueue_requests_raw(arr, len(reqs))
+
+    def collect():
+        w.collect_checksums_raw(out, n_save)
+        return out
+    run.enqueue, run.collect = enqueue, collect
     return run, keep
 
 
@@ -105,6 +125,8 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one kernel per reference system (no fusion at all)")
     ap.add_argument("--no-groups", action="store_true", help="one launch per request (no request-group fusion)")
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
+    ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
+                    "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
 
@@ -138,11 +160,26 @@ def main():
         for _ in range(W):
             run(w.frame)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            run(w.frame)
-        torch.cuda.synchronize()
-        secs = time.perf_counter() - t0
+        if args.sync:
+            t0 = time.perf_counter()
+            for _ in range(K):
+                run(w.frame)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+        else:
+            # one tick in flight ahead of the host: enqueue tick k+1, then collect tick k's checksums
+            # (what a shim does: cell.save() right before the next advance_frame()).  Every one of the K
+            # ticks is enqueued AND collected inside the timed region.
+            w.synchronize()
+            t0 = time.perf_counter()
+            run.enqueue(w.frame)
+            for _ in range(K - 1):
+                run.enqueue(w.frame)
+                run.collect()
+            run.collect()
+            w.synchronize()
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
         live = w.active_count()
         # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
         w.profile_enable(True)
@@ -249,7 +286,7 @@ def main():
                    "entities_per_gpu": live, "depth": D,
                    "parallelism": "single GPU" if world_size == 1 else f"speculative fan-out, 1 branch per rank x {world_size} ranks",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "nt_stores": bool(args.nt), **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
+                   "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if (args.sync or world_size > 1) else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:

@@ -89,6 +89,9 @@ SIGNATURES = {
     "ggrs_hip_advance": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint64,
                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ggrs_hip_handle_requests": (C.c_int, [_P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64)]),
+    "ggrs_hip_enqueue_requests": (C.c_int, [_P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ggrs_hip_collect_checksums": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ggrs_hip_pending_batches": (C.c_uint32, [_P]),
     "ggrs_hip_set_synctest_check_distance": (C.c_int, [_P, C.c_int32]),
     "ggrs_hip_synchronize": (C.c_int, [_P]),
     "ggrs_hip_state_bytes": (C.c_uint64, [_P]),

@@ -104,6 +104,11 @@ struct ggrs_world {
     size_t depth = 60;                                   // DEFAULT_FPS until sync_depth (mod.rs:115)
     std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
 
+    // ---- asynchronous request batches (ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums)
+    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; };
+    std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
+    std::vector<hipEvent_t> event_pool;
+
     // ---- profiling
     bool nt_copy = false;               // non-temporal loads/stores in k_copy_state (A/B knob)
     bool prof = false;
@@ -668,7 +673,10 @@ void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
     else hipLaunchKernelGGL((k_tick<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
 }
 
-int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
+// res_base: first slot of the pinned result ring this list writes to.  wait == false only enqueues
+// (ggrs_hip_enqueue_requests); the list then must hold fewer Saves than the ring can take.
+int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
+                       uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
     uint32_t i = 0, ns = 0;                      // ns: results pending in d_results
     int rc = GGRS_OK;
     while (i < n) {
@@ -695,7 +703,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             const ggrs_request& r = reqs[i];
             if (r.kind == GGRS_REQ_LOAD) break;
             if (r.kind == GGRS_REQ_SAVE) {
-                if (a.n_saves == (uint32_t)MAX_TICK_SAVES || ns + a.n_saves == w->max_results) break;
+                if (a.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + a.n_saves == w->max_results)) break;
                 apply_synctest_confirmed(w);
                 if (w->has_confirmed) ring_confirm(w, w->confirmed);        // discard_old_snapshots
                 int sl = -1;
@@ -740,7 +748,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             TickFinArgs f; memset(&f, 0, sizeof f);
             f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = 4 * g;
             f.cks_T = w->f_cksT; f.cks_V = w->f_cksV; f.total_len = w->len;
-            f.out = w->d_results + 2 * (uint64_t)ns;
+            f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
             {
                 ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
                 hipLaunchKernelGGL(k_tick_finalize, dim3(a.n_saves), dim3(FIN_TPB), 0, w->stream, f);
@@ -752,11 +760,13 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
             if (rc) return rc;
         }
-        if (ns == w->max_results) {                                        // flush a full result page
+        if (wait && ns == w->max_results) {                                // flush a full result page
             rc = read_back(w, ns, checksums_out); if (rc) return rc;
             checksums_out += 2 * (uint64_t)ns; ns = 0;
         }
     }
+    if (n_saves_out) *n_saves_out = ns;
+    if (!wait) return GGRS_OK;
     return read_back(w, ns, checksums_out);
 }
 
@@ -808,6 +818,8 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
+    for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->own_arena && w->arena) (void)hipFree(w->arena);
@@ -996,6 +1008,7 @@ int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t cd) { if (!w) re
 
 int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
     if (!w) return GGRS_E_INVALID;
+    if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
     int rc = seal(w); if (rc) return rc;
     if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_SAVE; r.frame = w->frame; return run_request_groups(w, &r, 1, out); }
     rc = do_save(w, 0); if (rc) return rc;
@@ -1003,6 +1016,7 @@ int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
 }
 int ggrs_hip_load(ggrs_world* w, int32_t frame) {
     if (!w) return GGRS_E_INVALID;
+    if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
     int rc = seal(w); if (rc) return rc;
     if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_LOAD; r.frame = frame; return run_request_groups(w, &r, 1, nullptr); }
     return do_load(w, frame);
@@ -1010,6 +1024,7 @@ int ggrs_hip_load(ggrs_world* w, int32_t frame) {
 int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
                      uint64_t spawn_count, const float* vx, const float* vy) {
     if (!w) return GGRS_E_INVALID;
+    if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
     int rc = seal(w); if (rc) return rc;
     if (w->tick_ok) {
         ggrs_request r; memset(&r, 0, sizeof r);
@@ -1023,6 +1038,7 @@ int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uin
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
     int rc = seal(w); if (rc) return rc;
+    if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "handle_requests while %zu enqueued batches are uncollected", w->pending.size());
     if (w->tick_ok) {
         rc = run_request_groups(w, reqs, n, checksums_out);
         if (rc && w->stream) (void)hipStreamSynchronize(w->stream);
@@ -1047,6 +1063,66 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
     if (rc) { if (w->stream) (void)hipStreamSynchronize(w->stream); return rc; }
     return read_back(w, ns, checksums_out);
 }
+// Asynchronous pair: the request list is only ENQUEUED on the world's stream (all host-side bookkeeping --
+// frame counters, ring push/confirm/rollback -- happens now, in request order); the Checksum(u128)s are
+// fetched later, oldest batch first.  ggrs reads a SaveGameState cell no earlier than the next
+// advance_frame(), so a host shim collects right before that call and the GPU tick overlaps the rest of
+// the host's frame instead of blocking it.
+int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
+    if (!w || (!reqs && n)) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    uint32_t n_save = 0;
+    for (uint32_t i = 0; i < n; ++i) n_save += reqs[i].kind == GGRS_REQ_SAVE;
+    if (n_save > w->max_results / 4 || w->pending_results + n_save > w->max_results / 2 || w->pending.size() >= 16)
+        return w->fail(GGRS_E_INVALID, "too many uncollected checksums (%u pending + %u new): call ggrs_hip_collect_checksums", w->pending_results, n_save);
+    ggrs_world::PendingBatch b;
+    b.first = (w->res_head + n_save > w->max_results) ? 0u : w->res_head;
+    b.count = n_save;
+    if (w->tick_ok) {
+        rc = run_request_groups(w, reqs, n, nullptr, b.first, false, nullptr);
+        if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
+    } else {                                   // worlds without request-group kernels: run now, hand back later
+        b.host.assign(2 * (size_t)n_save + 2, 0);
+        uint32_t ns = 0;
+        for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
+            const ggrs_request& r = reqs[i];
+            apply_synctest_confirmed(w);
+            switch (r.kind) {
+            case GGRS_REQ_SAVE: rc = do_save(w, 0); if (!rc) rc = read_back(w, 1, &b.host[2 * (size_t)ns]); ++ns; break;
+            case GGRS_REQ_LOAD: rc = do_load(w, r.frame); break;
+            case GGRS_REQ_ADVANCE: rc = do_advance(w, r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy); break;
+            default: rc = w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+            }
+        }
+        if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
+    }
+    if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
+    b.ev = w->event_pool.back(); w->event_pool.pop_back();
+    HIPCHK(w, hipEventRecord(b.ev, w->stream));
+    w->res_head = b.first + n_save; w->pending_results += n_save;
+    if (n_saves_out) *n_saves_out = n_save;
+    w->pending.push_back(std::move(b));
+    return GGRS_OK;
+}
+int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t max_saves, uint32_t* n_saves_out) {
+    if (!w) return GGRS_E_INVALID;
+    if (w->pending.empty()) return w->fail(GGRS_E_INVALID, "no enqueued batch to collect");
+    ggrs_world::PendingBatch& b = w->pending.front();
+    if (b.count > max_saves || (b.count && !checksums_out)) return w->fail(GGRS_E_INVALID, "oldest batch holds %u checksums, room for %u", b.count, max_saves);
+    HIPCHK(w, hipEventSynchronize(b.ev));
+    if (b.count) {
+        if (!b.host.empty()) memcpy(checksums_out, b.host.data(), (size_t)b.count * 16);
+        else memcpy(checksums_out, w->h_results + 2 * (size_t)b.first, (size_t)b.count * 16);
+    }
+    if (n_saves_out) *n_saves_out = b.count;
+    w->pending_results -= b.count;
+    w->event_pool.push_back(b.ev);
+    w->pending.pop_front();
+    if (w->pending.empty()) w->stage_used = 0;       // every staged spawn payload has been consumed
+    return GGRS_OK;
+}
+uint32_t ggrs_hip_pending_batches(ggrs_world* w) { return w ? (uint32_t)w->pending.size() : 0; }
+
 int ggrs_hip_synchronize(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
     HIPCHK(w, hipStreamSynchronize(w->stream));

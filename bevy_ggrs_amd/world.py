@@ -258,6 +258,27 @@ class World(WorldBase):
     def set_synctest_check_distance(self, cd: int):
         self._check(self._lib.ggrs_hip_set_synctest_check_distance(self._p, cd))
 
+    # ---- asynchronous request batches (include/ggrs_hip.h: enqueue / collect)
+    def enqueue_requests(self, requests) -> int:
+        arr, keep, n_save = self.build_requests(requests)
+        self._check(self._lib.ggrs_hip_enqueue_requests(self._p, arr, len(requests), None))
+        return n_save
+
+    def enqueue_requests_raw(self, arr, n: int):
+        self._check(self._lib.ggrs_hip_enqueue_requests(self._p, arr, n, None))
+
+    def collect_checksums(self, max_saves: int = 256) -> list:
+        out = (C.c_uint64 * (2 * max_saves))()
+        got = C.c_uint32(0)
+        self._check(self._lib.ggrs_hip_collect_checksums(self._p, out, max_saves, C.byref(got)))
+        return [int(out[2 * i]) | (int(out[2 * i + 1]) << 64) for i in range(got.value)]
+
+    def collect_checksums_raw(self, out, max_saves: int):
+        self._check(self._lib.ggrs_hip_collect_checksums(self._p, out, max_saves, None))
+
+    def pending_batches(self) -> int:
+        return int(self._lib.ggrs_hip_pending_batches(self._p))
+
     def synchronize(self):
         self._check(self._lib.ggrs_hip_synchronize(self._p))
 

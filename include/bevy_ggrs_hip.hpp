@@ -280,6 +280,8 @@ struct HipBackend {
     int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
     int set_synctest_check_distance(int32_t cd) { return ggrs_hip_set_synctest_check_distance(w, cd); }
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) { return ggrs_hip_handle_requests(w, r, n, out); }
+    int enqueue_requests(const ggrs_request* r, uint32_t n) { return ggrs_hip_enqueue_requests(w, r, n, nullptr); }
+    int collect_checksums(uint64_t* out, uint32_t max_saves) { return ggrs_hip_collect_checksums(w, out, max_saves, nullptr); }
     int32_t frame() { return ggrs_hip_frame(w); }
     int set_frame(int32_t f) { return ggrs_hip_set_frame(w, f); }
     uint64_t len() { return ggrs_hip_len(w); }
@@ -361,6 +363,24 @@ class App {
         return first;
     }
 
+    // ---- pipelined mode: handle_requests only ENQUEUES the tick on the device; the checksums are handed
+    // to their GameStateCells right before the next advance_frame() (the first moment ggrs looks at
+    // them), so the GPU tick overlaps the rest of the host's frame.  Results are identical.
+    App& set_pipelined(bool on) { flush(); pipelined_ = on; return *this; }
+    void flush() {                         // collect every outstanding batch (oldest first)
+        while (!in_flight_.empty()) {
+            auto saves = std::move(in_flight_.front()); in_flight_.erase(in_flight_.begin());
+            std::vector<uint64_t> sums(2 * saves.size() + 2);
+            check(be_.collect_checksums(sums.data(), (uint32_t)saves.size()));
+            last_checksums_.clear();
+            for (size_t k = 0; k < saves.size(); ++k) {
+                const u128 cs{sums[2 * k], sums[2 * k + 1]};
+                saves[k].first->save(saves[k].second, nullptr, cs);
+                last_checksums_.push_back(cs);
+            }
+        }
+    }
+
     // ---- observers / resources
     App& add_observer(std::function<void(const SyncTestMismatch&)> f) { on_mismatch_ = std::move(f); return *this; }
     Frame rollback_frame_count() { return be_.frame(); }                                        // RollbackFrameCount, mod.rs:70
@@ -421,6 +441,17 @@ class App {
             } break;
             }
         }
+        if (pipelined_) {
+            if (be_.enqueue_requests(reqs.data(), (uint32_t)reqs.size()) != GGRS_OK) throw std::runtime_error(be_.last_error());
+            std::vector<std::pair<GameStateCell*, Frame>> cells;
+            for (auto* sv : saves) cells.emplace_back(sv->cell, sv->frame);
+            in_flight_.push_back(std::move(cells));
+            if (auto* s = std::get_if<SyncTestSession<C>>(&session_)) {
+                const Frame c = be_.frame() - (Frame)s->check_distance();
+                if (c >= 0) confirmed_ = c;
+            }
+            return;
+        }
         std::vector<uint64_t> sums(2 * saves.size() + 2);
         const int rc = be_.handle_requests(reqs.data(), (uint32_t)reqs.size(), sums.data());
         if (rc != GGRS_OK) throw std::runtime_error(be_.last_error());      // the reference panics here (mod.rs:213-215)
@@ -457,6 +488,7 @@ class App {
         LocalInputs<C> local;
         read_inputs_(players, local);
         for (auto& kv : local) sess.add_local_input(kv.first, kv.second);
+        flush();                               // cell.save() of the previous tick, before ggrs compares checksums
         try {
             auto requests = sess.advance_frame();
             handle_requests(requests);
@@ -480,6 +512,8 @@ class App {
     Frame confirmed_ = -1;
     size_t max_prediction_window_ = 8;
     std::vector<u128> last_checksums_;
+    bool pipelined_ = false;
+    std::vector<std::vector<std::pair<GameStateCell*, Frame>>> in_flight_;
 };
 
 }  // namespace bevy_ggrs

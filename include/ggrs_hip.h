@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 1
+#define GGRS_HIP_ABI_VERSION 2
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -203,6 +203,17 @@ typedef struct {
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n,
                              uint64_t* checksums_out);
 int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t check_distance /* <0: off */);
+
+/* Asynchronous form of the same call.  enqueue: all host-side bookkeeping (RollbackFrameCount, ring
+ * push/confirm/rollback) happens immediately and in request order, the device work is only queued on the
+ * world's stream; *n_saves_out = SAVE requests in the list.  collect: blocks until the OLDEST uncollected
+ * batch has finished and copies its checksums ({lo,hi} per SAVE, request order).  ggrs reads a
+ * SaveGameState cell (schedule_systems.rs:231-236) no earlier than the next advance_frame(), so a shim
+ * collects right before that call and the tick overlaps the rest of the host's frame.  At most 16 batches /
+ * 512 checksums may be outstanding; the synchronous calls above refuse to run while any are. */
+int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out);
+int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t max_saves, uint32_t* n_saves_out);
+uint32_t ggrs_hip_pending_batches(ggrs_world* w);
 
 /* Blocks until all work submitted on the world's stream has finished. */
 int ggrs_hip_synchronize(ggrs_world* w);

@@ -59,6 +59,19 @@ struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to 
         }
         return 0;
     }
+    std::vector<std::vector<uint64_t>> stash;          // "enqueue" on the CPU oracle = run now, hand back on collect
+    int enqueue_requests(const ggrs_request* r, uint32_t n) {
+        uint32_t ns = 0; for (uint32_t i = 0; i < n; ++i) ns += r[i].kind == GGRS_REQ_SAVE;
+        std::vector<uint64_t> out(2 * ns + 2);
+        int rc = handle_requests(r, n, out.data());
+        out.resize(2 * ns); stash.push_back(out);
+        return rc;
+    }
+    int collect_checksums(uint64_t* out, uint32_t max_saves) {
+        if (stash.empty() || stash.front().size() > 2 * (size_t)max_saves) return -1;
+        std::copy(stash.front().begin(), stash.front().end(), out); stash.erase(stash.begin());
+        return 0;
+    }
     int32_t frame() { return gor_frame(w); }
     int set_frame(int32_t f) { gor_set_frame(w, f); return 0; }
     uint64_t len() { return gor_len(w); }
@@ -207,9 +220,10 @@ static void fixed_timestep_accumulator() {
 }
 
 // examples/stress_tests/particles.rs:187-240 through the plugin API; prints every checksum
-static void particles(uint64_t n, int ticks, size_t cd) {
+static void particles(uint64_t n, int ticks, size_t cd, bool pipelined) {
     TestApp app(n + 100 * (uint64_t)ticks + 64);
     base_synctest_app(app, cd);
+    app.set_pipelined(pipelined);
     app.insert_resource(RollbackFrameRate{60});
     app.rollback_component_with_clone<Transform>().rollback_component_with_copy<Velocity>().rollback_component_with_copy<Ttl>();
     app.checksum_component_with_hash<Velocity>();
@@ -240,6 +254,7 @@ static void particles(uint64_t n, int ticks, size_t cd) {
     app.spawn(n, {"Transform", "Velocity", "Ttl"}, cols);
     for (tick_no = 0; tick_no < ticks; ++tick_no) {
         app.update();
+        if (pipelined) app.flush();                        // (a real host would only flush at the next tick)
         for (auto& c : app.last_checksums()) std::printf("checksum %d %016llx%016llx\n", tick_no, (unsigned long long)c.hi, (unsigned long long)c.lo);
     }
     auto x = app.download<Transform, uint32_t>(1);
@@ -247,7 +262,7 @@ static void particles(uint64_t n, int ticks, size_t cd) {
     for (size_t i = 0; i < x.size(); ++i) fold = fold * 1099511628211ULL + x[i];
     std::printf("final frame %d len %llu active %llu ty_fold %016llx\n", app.rollback_frame_count(), (unsigned long long)app.backend().len(),
                 (unsigned long long)app.active_count(), (unsigned long long)fold);
-    std::puts("ok particles");
+    std::puts(pipelined ? "ok particles_pipelined" : "ok particles");
 }
 
 int main(int argc, char** argv) {
@@ -258,6 +273,7 @@ int main(int argc, char** argv) {
     confirmed_frame_pruning();
     component_rollback_copy();
     fixed_timestep_accumulator();
-    particles(n, 24, 7);
+    particles(n, 24, 7, false);
+    particles(n, 24, 7, true);
     return 0;
 }

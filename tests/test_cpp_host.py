@@ -40,14 +40,17 @@ def _run(exe, n):
 
 
 EXPECTED = ["synctest_request_shape", "despawn_and_rollback_does_not_panic", "mismatch_fires_on_non_determinism",
-            "confirmed_frame_pruning", "component_rollback_copy", "fixed_timestep_accumulator", "particles"]
+            "confirmed_frame_pruning", "component_rollback_copy", "fixed_timestep_accumulator", "particles",
+            "particles_pipelined"]
 
 
 def test_cpp_host_on_oracle_backend():
     out = _run(_build("oracle"), 3000)
     for name in EXPECTED:
         assert f"ok {name}" in out
-    assert out.count("checksum ") == 8 + 16 * 7      # cd = 7: frames 0..7 save once, then 7 saves per tick
+    assert out.count("checksum ") == 2 * (8 + 16 * 7)      # cd = 7: frames 0..7 save once, then 7 saves per tick; sync + pipelined runs
+    lines = [l for l in out.splitlines() if l.startswith(("checksum", "final"))]
+    assert lines[:len(lines) // 2] == lines[len(lines) // 2:], "pipelined run must reproduce the synchronous run"
 
 
 def test_cpp_host_builds_against_the_product_library():

@@ -158,3 +158,56 @@ def test_full_size_properties_1m():
         assert w.save() == want
         w.close()
     assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+def test_async_enqueue_collect_matches_sync():
+    """ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums: same checksums and state as the
+    synchronous call, batches collected oldest-first, sync calls refused while batches are pending."""
+    n = 3000
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    out = []
+    for mode in ("sync", "async"):
+        w = bg.World(n + 2000, max_depth=9)
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=30)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(9)
+        w.set_synctest_check_distance(4)
+        fn = cm.frame_spawn_fn(50)
+        cs = []
+        lists = []
+        F = 0
+        for t in range(14):
+            reqs = []
+            if F > 4:
+                reqs.append(bg.LoadGameState(F - 4))
+                for i in range(4):
+                    if i: reqs.append(bg.SaveGameState(F - 4 + i))
+                    f = F - 4 + i
+                    a = bg.AdvanceFrame((cm.INPUT_SPAWN if f % 3 == 1 else 0,))
+                    if f % 3 == 1: a.spawn_vx, a.spawn_vy = fn(f)
+                    reqs.append(a)
+            reqs.append(bg.SaveGameState(F))
+            a = bg.AdvanceFrame((cm.INPUT_SPAWN if F % 3 == 1 else 0,))
+            if F % 3 == 1: a.spawn_vx, a.spawn_vy = fn(F)
+            reqs.append(a)
+            F += 1
+            lists.append(reqs)
+        if mode == "sync":
+            for reqs in lists: cs.append(w.handle_requests(reqs))
+        else:
+            counts = []
+            for k, reqs in enumerate(lists):
+                counts.append(w.enqueue_requests(reqs))
+                if k >= 2:                                   # keep three batches in flight
+                    cs.append(w.collect_checksums())
+            assert w.pending_batches() == 2
+            with pytest.raises(bg.GgrsHipError):
+                w.save()                                     # synchronous call while batches are pending
+            while w.pending_batches():
+                cs.append(w.collect_checksums())
+            assert [len(c) for c in cs] == counts
+            with pytest.raises(bg.GgrsHipError):
+                w.collect_checksums()                        # nothing left
+        out.append((cs, cm.snapshot_state(w, ids)))
+    assert out[0][0] == out[1][0]
+    cm.assert_states_equal(out[0][1], out[1][1], "async")
