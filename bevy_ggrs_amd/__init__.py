@@ -5,7 +5,7 @@ component columns as SoA arrays in HBM, snapshot save/restore, the deterministic
 step and the SeaHash checksum as hand-written gfx950 kernels (csrc/), driven through the C ABI
 of libggrs_hip.so (include/ggrs_hip.h).
 """
-from ._ffi import (GGRS_E_CAPACITY, GGRS_E_INVALID, GGRS_E_NO_DEVICE, GGRS_E_NO_SNAPSHOT,  # noqa: F401
+from ._ffi import (COMP_NO_ROLLBACK, COMP_ROLLBACK, DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK, GGRS_E_CAPACITY, GGRS_E_INVALID, GGRS_E_NO_DEVICE, GGRS_E_NO_SNAPSHOT,  # noqa: F401
                    GGRS_WORLD_NO_GROUPS, GGRS_WORLD_NT_COPY, GGRS_WORLD_UNFUSED, GgrsHipError, SYS_ADD_U32, SYS_PARTICLES_SPAWN,
                    SYS_PARTICLES_UPDATE, SYS_SAT_SUB_DESPAWN, SYS_TTL_DESPAWN)
 from .requests import AdvanceFrame, LoadGameState, SaveGameState  # noqa: F401

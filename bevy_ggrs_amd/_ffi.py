@@ -30,6 +30,9 @@ SYS_PARTICLES_SPAWN = 3
 SYS_ADD_U32 = 4
 SYS_SAT_SUB_DESPAWN = 5
 
+COMP_ROLLBACK, COMP_NO_ROLLBACK = 0, 1
+DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK = 0, 1
+
 REQ_SAVE, REQ_LOAD, REQ_ADVANCE = 1, 2, 3
 
 KERNEL_SAVE, KERNEL_LOAD, KERNEL_ADVANCE, KERNEL_CHECKSUM, KERNEL_TICK, KERNEL_CLASSES = 0, 1, 2, 3, 4, 5
@@ -63,12 +66,16 @@ SIGNATURES = {
     "ggrs_hip_world_destroy": (None, [_P]),
     "ggrs_hip_last_error": (C.c_char_p, [_P]),
     "ggrs_hip_register_component": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ggrs_hip_register_component_ex": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ggrs_hip_set_component_default": (C.c_int, [_P, C.c_uint32, _P]),
     "ggrs_hip_checksum_component": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
     "ggrs_hip_add_system": (C.c_int, [_P, C.POINTER(SystemDesc)]),
     "ggrs_hip_set_frame_rate": (C.c_int, [_P, C.c_uint64]),
     "ggrs_hip_spawn": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ggrs_hip_despawn": (C.c_int, [_P, C.c_uint64]),
+    "ggrs_hip_despawn_rollback": (C.c_int, [_P, C.c_uint64]),
+    "ggrs_hip_download_disabled": (C.c_int, [_P, _P, C.c_uint64]),
+    "ggrs_hip_download_despawned_frames": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "ggrs_hip_insert_component": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P]),
     "ggrs_hip_remove_component": (C.c_int, [_P, C.c_uint32, C.c_uint64]),
     "ggrs_hip_upload_word": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _P]),

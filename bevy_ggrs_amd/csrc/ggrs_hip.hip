@@ -36,6 +36,7 @@ struct Comp {
     bool checksummed = false;
     std::vector<uint8_t> defaults;
     uint32_t col_base = 0;               // index of its first column
+    bool no_rollback = false;            // GGRS_COMP_NO_ROLLBACK: lives in the side region, outside every snapshot
 };
 
 struct Block {                           // one packed state block in the arena
@@ -61,7 +62,14 @@ struct ggrs_world {
     bool sealed = false;
     std::string err;
 
-    // ---- layout of a packed state block
+    // ---- layout of a packed state block.  Offsets of non-rollback components and of the
+    // RollbackDespawned markers are ALSO relative to the live block's base but point past the ring,
+    // into the live-only side region (they are only ever applied to the live block).
+    uint64_t side_off = 0, side_bytes = 0;
+    DespawnMarks marks{};                // disabled mask + despawned-frame column (despawn.rs:45-46)
+    bool has_nr = false;                 // any GGRS_COMP_NO_ROLLBACK component
+    bool marks_possible = false;         // a RollbackDespawned marker may exist in the live world
+    int32_t dc_local = 0;                // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
     uint64_t state_bytes = 0, off_alive = 0;
     std::vector<uint64_t> off_present, col_off;
     std::vector<uint32_t> col_wb;
@@ -149,36 +157,54 @@ void build_layout(ggrs_world* w) {
     const uint64_t mask_bytes = align_up(w->cap_pad / 8, ALIGN);
     uint64_t off = ALIGN;                          // header
     w->off_alive = off; off += mask_bytes;
-    w->off_present.clear(); w->col_off.clear(); w->col_wb.clear();
-    for (size_t c = 0; c < w->comps.size(); ++c) { w->off_present.push_back(off); off += mask_bytes; }
+    w->off_present.assign(w->comps.size(), 0); w->col_off.clear(); w->col_wb.clear();
+    w->has_nr = false;
+    uint32_t ncols = 0;
+    for (auto& c : w->comps) { c.col_base = ncols; ncols += c.n_words; w->has_nr |= c.no_rollback; }
+    w->col_off.assign(ncols, 0); w->col_wb.assign(ncols, 4);
+    for (size_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback) { w->off_present[c] = off; off += mask_bytes; }
     for (auto& c : w->comps) {
-        c.col_base = (uint32_t)w->col_off.size();
         for (uint32_t k = 0; k < c.n_words; ++k) {
-            w->col_off.push_back(off); w->col_wb.push_back(c.word_bytes);
+            w->col_wb[c.col_base + k] = c.word_bytes;
+            if (c.no_rollback) continue;
+            w->col_off[c.col_base + k] = off;
             off += align_up(w->cap_pad * c.word_bytes, ALIGN);
         }
     }
     w->state_bytes = align_up(off, 4096);
+    // ---- live-only side region, placed right behind the ring blocks
+    w->side_off = (uint64_t)(w->max_depth + 1) * w->state_bytes;
+    uint64_t so = w->side_off;
+    w->marks.off_disabled = so; so += mask_bytes;
+    w->marks.off_dframe = so; so += align_up(w->cap_pad * 4, ALIGN);
+    for (size_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].no_rollback) { w->off_present[c] = so; so += mask_bytes; }
+    for (auto& c : w->comps) {
+        if (!c.no_rollback) continue;
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
+    }
+    w->side_bytes = align_up(so - w->side_off, 4096);
 
     CopyPlan& p = w->plan;
     memset(&p, 0, sizeof p);
-    p.n_masks = 1 + (uint32_t)w->comps.size();
+    p.n_masks = 1;
     p.mask_off[0] = w->off_alive;
-    for (size_t c = 0; c < w->comps.size(); ++c) p.mask_off[1 + c] = w->off_present[c];
     uint32_t nr = 0;
-    for (size_t k = 0; k < w->col_off.size(); ++k) {
-        const uint32_t wb = w->col_wb[k];
-        for (uint32_t r = 0; r < wb / 4; ++r) {
-            RowDesc& rd = p.row[nr++];
-            rd.col_off = w->col_off[k]; rd.roff = r * 4096; rd.tile_stride = TILE * wb; rd.word_bytes = wb; rd.pad = 0;
-        }
+    for (size_t c = 0; c < w->comps.size(); ++c) {
+        const Comp& cc = w->comps[c];
+        if (cc.no_rollback) continue;                       // snapshots hold rollback components only
+        p.mask_off[p.n_masks++] = w->off_present[c];
+        for (uint32_t k = 0; k < cc.n_words; ++k)
+            for (uint32_t r = 0; r < cc.word_bytes / 4; ++r) {
+                RowDesc& rd = p.row[nr++];
+                rd.col_off = w->col_off[cc.col_base + k]; rd.roff = r * 4096; rd.tile_stride = TILE * cc.word_bytes; rd.word_bytes = cc.word_bytes; rd.pad = 0;
+            }
     }
     p.n_rows = nr;
 }
 
 uint32_t total_rows(const ggrs_world* w) {
     uint32_t n = 0;
-    for (auto& c : w->comps) n += c.n_words * (c.word_bytes / 4);
+    for (auto& c : w->comps) if (!c.no_rollback) n += c.n_words * (c.word_bytes / 4);
     return n;
 }
 
@@ -203,7 +229,8 @@ int seal(ggrs_world* w) {
         if (upd >= 0 && ttl >= 0 && other == 0 && !(w->flags & GGRS_WORLD_UNFUSED)) {
             const ggrs_system_desc& u = w->systems[upd]; const ggrs_system_desc& l = w->systems[ttl];
             const Comp& T = w->comps[u.comp[0]]; const Comp& V = w->comps[u.comp[1]]; const Comp& L = w->comps[l.comp[0]];
-            if (T.word_bytes == 4 && V.word_bytes == 4 && L.word_bytes == 8 && u.word[0] + 3 <= T.n_words && u.word[1] + 3 <= V.n_words) {
+            if (T.word_bytes == 4 && V.word_bytes == 4 && L.word_bytes == 8 && u.word[0] + 3 <= T.n_words && u.word[1] + 3 <= V.n_words &&
+                !T.no_rollback && !V.no_rollback && !L.no_rollback) {
                 w->fused_ok = true;
                 w->f_T = (int)u.comp[0]; w->f_V = (int)u.comp[1]; w->f_L = (int)l.comp[0];
                 w->f_tw = u.word[0]; w->f_vw = u.word[1];
@@ -265,14 +292,17 @@ int seal(ggrs_world* w) {
         }
         a.off_ttl = w->col_off[L.col_base + w->f_lw];
         for (uint32_t c = 0; c < w->comps.size(); ++c)
-            if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
-        for (size_t k = 0; k < w->col_off.size(); ++k) {
-            const uint64_t co = w->col_off[k];
-            bool owned = (co == a.off_ttl);
-            for (int j = 0; j < 3; ++j) owned |= (co == a.off_t[j]) || (co == a.off_v[j]);
-            if (owned) continue;
-            const uint32_t wb = w->col_wb[k];
-            for (uint32_t r = 0; r < wb / 4; ++r) a.rest[a.n_rest_rows++] = RowLite{co, r * 4096, TILE * wb};
+            if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
+        for (uint32_t c = 0; c < w->comps.size(); ++c) {
+            const Comp& cc = w->comps[c];
+            if (cc.no_rollback) continue;
+            for (uint32_t k2 = 0; k2 < cc.n_words; ++k2) {
+                const uint64_t co = w->col_off[cc.col_base + k2];
+                bool owned = (co == a.off_ttl);
+                for (int j = 0; j < 3; ++j) owned |= (co == a.off_t[j]) || (co == a.off_v[j]);
+                if (owned) continue;
+                for (uint32_t r = 0; r < cc.word_bytes / 4; ++r) a.rest[a.n_rest_rows++] = RowLite{co, r * 4096, TILE * cc.word_bytes};
+            }
         }
         w->tick_ok = true;
     }
@@ -288,7 +318,7 @@ int seal(ggrs_world* w) {
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
-    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
@@ -299,6 +329,7 @@ int seal(ggrs_world* w) {
     w->live.ptr = p; p += w->state_bytes;
     w->slots.resize(w->max_depth);
     for (uint32_t i = 0; i < w->max_depth; ++i) { w->slots[i].ptr = p; p += w->state_bytes; w->free_slots.push_back((int)(w->max_depth - 1 - i)); }
+    uint8_t* const side = p; p += w->side_bytes;          // == live.ptr + side_off (build_layout)
     w->d_parts = (uint64_t*)p; p += parts_bytes;
     w->d_tick_parts = (uint64_t*)p; p += tick_parts_bytes;
     p += res_bytes;                                  // (reserved; results live in pinned host memory, see below)
@@ -317,9 +348,10 @@ int seal(ggrs_world* w) {
     // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
     // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
     {
-        const uint64_t head = w->col_off.empty() ? w->state_bytes : w->col_off[0];
+        const uint64_t head = ALIGN + (uint64_t)w->plan.n_masks * align_up(w->cap_pad / 8, ALIGN);   // header + every mask
         HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
         for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
+        HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -407,6 +439,34 @@ bool ring_rollback(ggrs_world* w, int32_t frame) {             // mod.rs:210-226
     }
 }
 
+// ---- RollbackDespawned (snapshot/despawn.rs)
+inline uint32_t blocks_for_slots(uint64_t n) { return (uint32_t)((align_up(std::max<uint64_t>(n, 1), 64) + TPB - 1) / TPB); }
+
+// LoadWorldSystems::EntityResurrect + the non-rollback side of the entity reconcile; must be queued
+// before the kernel that overwrites the live liveness mask.  w->frame is already the loaded frame.
+int launch_load_reconcile(ggrs_world* w, const Block& snap) {
+    if (!w->has_nr && !w->marks_possible) return GGRS_OK;
+    ReconcileArgs a; memset(&a, 0, sizeof a);
+    a.live = w->live.ptr; a.snap = snap.ptr; a.off_alive = w->off_alive; a.dm = w->marks; a.frame = w->frame;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].no_rollback) a.nr_present_off[a.n_nr++] = w->off_present[c];
+    const uint64_t cover = std::max(std::max(w->live.dirty_len, snap.dirty_len), w->len);
+    a.n_slots_pad64 = align_up(std::max<uint64_t>(cover, 1), 64);
+    hipLaunchKernelGGL(k_load_reconcile, dim3(blocks_for_slots(cover)), dim3(TPB), 0, w->stream, a);
+    HIPCHK(w, hipGetLastError());
+    return GGRS_OK;
+}
+// AdvanceWorldSystems::DespawnConfirmed (despawn.rs:89-112), with its Local<ConfirmedFrameCount>
+int step_despawn_confirmed(ggrs_world* w) {
+    if (w->confirmed == w->dc_local) return GGRS_OK;          // "No work necessary"
+    w->dc_local = w->confirmed;
+    if (!w->marks_possible) return GGRS_OK;                   // no marker was ever set: nothing to free
+    const uint64_t cover = std::max(w->live.dirty_len, w->len);
+    hipLaunchKernelGGL(k_despawn_confirmed, dim3(blocks_for_slots(cover)), dim3(TPB), 0, w->stream, w->live.ptr, w->marks,
+                       w->confirmed, align_up(std::max<uint64_t>(cover, 1), 64));
+    HIPCHK(w, hipGetLastError());
+    return GGRS_OK;
+}
+
 // ---- SaveWorld
 int do_save(ggrs_world* w, uint32_t result_idx) {
     int rc = seal(w); if (rc) return rc;
@@ -435,6 +495,7 @@ int do_load(ggrs_world* w, int32_t frame) {
     if (!ring_rollback(w, frame))
         return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", frame);
     Block& s = w->slots[w->ring_slot.front()];
+    rc = launch_load_reconcile(w, s); if (rc) return rc;        // LoadWorldSystems::EntityResurrect
     // entity.rs:55-99 + component_snapshot.rs:95-123 + RollbackOrdered restore (mod.rs:342):
     // masks, columns and len of the live block := the snapshot's
     w->len = s.len;
@@ -446,12 +507,16 @@ int do_load(ggrs_world* w, int32_t frame) {
 // ---- spawn bookkeeping shared by the API call and the in-schedule spawn system
 int set_masks_for_range(ggrs_world* w, uint64_t first, uint64_t count, uint64_t comp_mask) {
     if (count == 0) return GGRS_OK;
-    MaskOffs mo; uint32_t n = 0;
+    MaskOffs mo, mc; uint32_t n = 0, nc = 0;
     mo.off[n++] = w->off_alive;
     for (uint32_t c = 0; c < w->comps.size(); ++c) if ((comp_mask >> c) & 1ULL) mo.off[n++] = w->off_present[c];
+    // a fresh entity carries no RollbackDespawned marker and only the non-rollback components of its
+    // bundle (those masks are live-only: no LoadWorld copy ever cleans them)
+    if (w->marks_possible) mc.off[nc++] = w->marks.off_disabled;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].no_rollback && !((comp_mask >> c) & 1ULL)) mc.off[nc++] = w->off_present[c];
     const uint64_t words = ((first + count - 1) >> 6) - (first >> 6) + 1;
     hipLaunchKernelGGL(k_set_mask_range, dim3((uint32_t)((words + TPB - 1) / TPB)), dim3(TPB), 0, w->stream,
-                       w->live.ptr, first, count, n, mo);
+                       w->live.ptr, first, count, n, mo, nc, mc);
     HIPCHK(w, hipGetLastError());
     return GGRS_OK;
 }
@@ -554,6 +619,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
     int rc = seal(w); if (rc) return rc;
     w->frame += 1;                                              // schedule_systems.rs:254-259
     if (dt_bits == 0) dt_bits = dt_bits_for_frame(w->fps, w->frame);
+    rc = step_despawn_confirmed(w); if (rc) return rc;         // AdvanceWorldSystems::DespawnConfirmed, before Main
     const uint32_t g = tiles_for(w->len);
     const uint32_t n_cks = w->cks_args.n_cks;
     uint64_t* part_cnt = w->cks_args.part_cnt;
@@ -619,8 +685,12 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                 case GGRS_SYS_SAT_SUB_DESPAWN: {
                     const Comp& C = w->comps[s.comp[0]];
                     const uint64_t lp = align_up(w->len, 64);
+                    // despawn_rollback (despawn.rs:129-142): only an unconfirmed frame defers the despawn
+                    const int defer = (s.iparam[1] == GGRS_DESPAWN_ROLLBACK && w->confirmed < w->frame) ? 1 : 0;
+                    if (defer) w->marks_possible = true;
                     hipLaunchKernelGGL(k_sat_sub_despawn, dim3((uint32_t)((lp + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, w->live.ptr,
-                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp);
+                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp,
+                                       defer, w->frame, w->marks);
                 } break;
                 default: break;
                 }
@@ -693,6 +763,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             if (!ring_rollback(w, reqs[i].frame))
                 return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
             src = &w->slots[w->ring_slot.front()];
+            rc = launch_load_reconcile(w, *src); if (rc) return rc;          // EntityResurrect: before k_tick rewrites live liveness
             w->len = src->len;
             cover = std::max(cover, src->dirty_len);
             a.src_is_live = 0;
@@ -718,6 +789,9 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
                 if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
                 apply_synctest_confirmed(w);
                 w->frame += 1;                                              // schedule_systems.rs:254-259
+                // DespawnConfirmed only touches the live-only marker mask, which k_tick never reads and
+                // no op inside a group writes: queueing it ahead of the group's launch keeps request order
+                rc = step_despawn_confirmed(w); if (rc) return rc;
                 a.dt_bits[a.n_steps++] = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
                 a.op_bits |= 1ULL << a.n_ops; ++a.n_ops;                     // op bit 1: Advance
                 if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }   // Commands flush ends the group
@@ -811,7 +885,8 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t state = align_up(ALIGN + (1 + (uint64_t)n_components) * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
                            align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
-    return (uint64_t)(max_depth + 1) * state + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+    const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
+    return (uint64_t)(max_depth + 1) * state + side + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;
@@ -837,6 +912,15 @@ int ggrs_hip_register_component(ggrs_world* w, const char* name, uint32_t word_b
     c.defaults.assign((size_t)word_bytes * n_words, 0);
     w->comps.push_back(c);
     if (comp_id) *comp_id = (uint32_t)w->comps.size() - 1;
+    return GGRS_OK;
+}
+int ggrs_hip_register_component_ex(ggrs_world* w, const char* name, uint32_t word_bytes, uint32_t n_words, uint32_t flags, uint32_t* comp_id) {
+    if (flags & ~GGRS_COMP_NO_ROLLBACK) return w ? w->fail(GGRS_E_INVALID, "unknown component flags %u", flags) : GGRS_E_INVALID;
+    uint32_t c = 0;
+    const int rc = ggrs_hip_register_component(w, name, word_bytes, n_words, &c);
+    if (rc) return rc;
+    w->comps[c].no_rollback = (flags & GGRS_COMP_NO_ROLLBACK) != 0;
+    if (comp_id) *comp_id = c;
     return GGRS_OK;
 }
 int ggrs_hip_set_component_default(ggrs_world* w, uint32_t c, const void* words) {
@@ -910,6 +994,20 @@ int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
     w->pending_valid = false;
     return GGRS_OK;
 }
+int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot) {
+    if (!w) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
+    if (w->confirmed < w->frame) {                 // despawn.rs:129-137: insert RollbackDespawned(frame)
+        w->marks_possible = true;
+        hipLaunchKernelGGL(k_mark_despawned, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_alive, w->marks, slot, w->frame);
+    } else {                                       // despawn.rs:140-142: frame already confirmed -> plain despawn
+        hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_alive, slot, 0);
+    }
+    HIPCHK(w, hipGetLastError());
+    w->pending_valid = false;
+    return GGRS_OK;
+}
 int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const void* words) {
     if (!w) return GGRS_E_INVALID;
     int rc = seal(w); if (rc) return rc;
@@ -968,7 +1066,29 @@ int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t
     if (!w || !dst) return GGRS_E_INVALID;
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size()) return w->fail(GGRS_E_INVALID, "bad component");
-    return download_mask(w, w->off_present[c], dst, n);
+    rc = download_mask(w, w->off_present[c], dst, n); if (rc) return rc;
+    if (w->comps[c].no_rollback && n) {
+        // a non-rollback component dies with its entity: it exists while the entity is alive or
+        // disabled (its live-only presence bit is cleaned lazily, when the slot is re-created)
+        std::vector<uint64_t> a(n), d(n);
+        rc = download_mask(w, w->off_alive, a.data(), n); if (rc) return rc;
+        rc = download_mask(w, w->marks.off_disabled, d.data(), n); if (rc) return rc;
+        for (uint64_t k = 0; k < n; ++k) dst[k] &= (a[k] | d[k]);
+    }
+    return GGRS_OK;
+}
+int ggrs_hip_download_disabled(ggrs_world* w, uint64_t* dst, uint64_t n) {
+    if (!w || !dst) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    return download_mask(w, w->marks.off_disabled, dst, n);
+}
+int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t count, int32_t* frames) {
+    if (!w || !frames) return GGRS_E_INVALID;
+    int rc = seal(w); if (rc) return rc;
+    if (first + count > w->capacity) return w->fail(GGRS_E_INVALID, "bad download_despawned_frames range");
+    if (count) HIPCHK(w, hipMemcpyAsync(frames, w->live.ptr + w->marks.off_dframe + first * 4, (size_t)count * 4, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return GGRS_OK;
 }
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p) {
     if (!w || !p) return GGRS_E_INVALID;

@@ -961,30 +961,102 @@ __global__ __launch_bounds__(TPB) void k_add_u32(uint8_t* state, uint64_t off_al
     }
 }
 // tests/synctest.rs:37-44 decrease_health: saturating_sub then despawn at 0.  One slot per
-// lane: the wave's ballot IS the new 64-bit liveness word.
+// lane: the wave's ballot IS the new 64-bit liveness word.  With `defer` the despawn is
+// commands.entity(e).despawn_rollback() on an unconfirmed frame (despawn.rs:114-143): the entity is
+// disabled -- RollbackDespawned(frame) -- instead of freed.
+struct DespawnMarks { uint64_t off_disabled, off_dframe; };   // live-only side state (outside every snapshot)
 __global__ __launch_bounds__(TPB) void k_sat_sub_despawn(uint8_t* state, uint64_t off_alive, uint64_t off_present,
-                                                         uint64_t off_col, uint32_t amount, uint64_t len_pad64) {
+                                                         uint64_t off_col, uint32_t amount, uint64_t len_pad64,
+                                                         int defer, int32_t frame, DespawnMarks dm) {
     const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= len_pad64) return;                       // whole waves only (len padded to 64)
     const uint64_t aw = *reinterpret_cast<const uint64_t*>(state + off_alive + (e >> 6) * 8);
     const uint64_t pw = *reinterpret_cast<const uint64_t*>(state + off_present + (e >> 6) * 8);
     bool alive = (aw >> (e & 63)) & 1ULL;
+    bool killed = false;
     if (alive && ((pw >> (e & 63)) & 1ULL)) {
         uint32_t* p = reinterpret_cast<uint32_t*>(state + off_col + e * 4);
         const uint32_t v = *p >= amount ? *p - amount : 0u;
         *p = v;
-        if (v == 0) alive = false;
+        if (v == 0) { alive = false; killed = true; }
     }
     const uint64_t nw = __ballot(alive);
     if ((threadIdx.x & 63u) == 0 && nw != aw) *reinterpret_cast<uint64_t*>(state + off_alive + (e >> 6) * 8) = nw;
+    if (defer) {
+        const uint64_t kw = __ballot(killed);
+        if (killed) *reinterpret_cast<int32_t*>(state + dm.off_dframe + e * 4) = frame;
+        if ((threadIdx.x & 63u) == 0 && kw) *reinterpret_cast<uint64_t*>(state + dm.off_disabled + (e >> 6) * 8) |= kw;
+    }
+}
+
+// ------------------------------------------------------------------ RollbackDespawned (snapshot/despawn.rs)
+// Host-issued commands.entity(e).despawn_rollback() on an unconfirmed frame.
+__global__ void k_mark_despawned(uint8_t* state, uint64_t off_alive, DespawnMarks dm, uint64_t slot, int32_t frame) {
+    uint64_t* a = reinterpret_cast<uint64_t*>(state + off_alive + (slot >> 6) * 8);
+    const uint64_t bitm = 1ULL << (slot & 63);
+    if (!(*a & bitm)) return;
+    *a &= ~bitm;
+    *reinterpret_cast<uint64_t*>(state + dm.off_disabled + (slot >> 6) * 8) |= bitm;
+    *reinterpret_cast<int32_t*>(state + dm.off_dframe + slot * 4) = frame;
+}
+// LoadWorldSystems::EntityResurrect (resurrect_entities, despawn.rs:69-87: markers > the loaded frame
+// are removed) plus what EntitySnapshotPlugin::load's reconcile (entity.rs:55-99) means for
+// NON-rollback components: an entity that survives the load (exists now AND is in the snapshot) or
+// stays disabled keeps them; one that is freed, or re-created as a fresh Entity with the old
+// RollbackId, does not have them any more.  Runs BEFORE the load's copy overwrites the live
+// liveness mask (stream order).  One slot per lane: a wave's ballot is one mask word.
+struct ReconcileArgs {
+    uint8_t* live; const uint8_t* snap;
+    uint64_t off_alive; DespawnMarks dm;
+    uint32_t n_nr; int32_t frame;
+    uint64_t n_slots_pad64;
+    uint64_t nr_present_off[MAX_MASKS];
+};
+__global__ __launch_bounds__(TPB) void k_load_reconcile(ReconcileArgs a) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= a.n_slots_pad64) return;
+    const uint64_t wi8 = (e >> 6) * 8;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t dis = *reinterpret_cast<const uint64_t*>(a.live + a.dm.off_disabled + wi8);
+    const bool d = (dis >> lane) & 1ULL;
+    const int32_t m = d ? *reinterpret_cast<const int32_t*>(a.live + a.dm.off_dframe + e * 4) : 0;
+    const uint64_t res = __ballot(d && m > a.frame);              // despawned_frame > rollback_frame
+    if (lane == 0) {
+        const uint64_t alive_live = *reinterpret_cast<const uint64_t*>(a.live + a.off_alive + wi8);
+        const uint64_t s_alive = *reinterpret_cast<const uint64_t*>(a.snap + a.off_alive + wi8);   // zero beyond the snapshot's len
+        const uint64_t dis_after = dis & ~res;
+        if (res) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + wi8) = dis_after;
+        const uint64_t keep = ((alive_live | res) & s_alive) | dis_after;
+        for (uint32_t k = 0; k < a.n_nr; ++k) {
+            uint64_t* p = reinterpret_cast<uint64_t*>(a.live + a.nr_present_off[k] + wi8);
+            const uint64_t v = *p;
+            if (v & ~keep) *p = v & keep;
+        }
+    }
+}
+// AdvanceWorldSystems::DespawnConfirmed (despawn_confirmed_entities, despawn.rs:89-112): disabled
+// entities whose marked frame is <= ConfirmedFrameCount are freed for good.
+__global__ __launch_bounds__(TPB) void k_despawn_confirmed(uint8_t* live, DespawnMarks dm, int32_t confirmed, uint64_t n_slots_pad64) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= n_slots_pad64) return;
+    const uint64_t wi8 = (e >> 6) * 8;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t dis = *reinterpret_cast<const uint64_t*>(live + dm.off_disabled + wi8);
+    const bool d = (dis >> lane) & 1ULL;
+    const int32_t m = d ? *reinterpret_cast<const int32_t*>(live + dm.off_dframe + e * 4) : 0;
+    const uint64_t gone = __ballot(d && m <= confirmed);
+    if (lane == 0 && gone) *reinterpret_cast<uint64_t*>(live + dm.off_disabled + wi8) = dis & ~gone;
 }
 
 // ------------------------------------------------------------------ spawn / mask edits
 // Set liveness + presence bits for slots [first, first+count) (Rollback on_add hook,
-// rollback.rs:45-59).  One mask word per thread; each word is owned by exactly one thread.
+// rollback.rs:45-59) and clear the live-only masks a fresh entity does not carry (non-rollback
+// components outside its bundle, a stale RollbackDespawned marker).  One mask word per thread; each
+// word is owned by exactly one thread.
 struct MaskOffs { uint64_t off[MAX_MASKS]; };
 __global__ __launch_bounds__(TPB) void k_set_mask_range(uint8_t* state, uint64_t first, uint64_t count,
-                                                        uint32_t n_masks, MaskOffs mask_off_set) {
+                                                        uint32_t n_masks, MaskOffs mask_off_set,
+                                                        uint32_t n_clear, MaskOffs mask_off_clear) {
     const uint64_t w_first = first >> 6, w_last = (first + count - 1) >> 6;
     const uint64_t wi = w_first + (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (wi > w_last) return;
@@ -995,6 +1067,10 @@ __global__ __launch_bounds__(TPB) void k_set_mask_range(uint8_t* state, uint64_t
     for (uint32_t m = 0; m < n_masks; ++m) {
         uint64_t* p = reinterpret_cast<uint64_t*>(state + mask_off_set.off[m] + wi * 8);
         *p |= bits;
+    }
+    for (uint32_t m = 0; m < n_clear; ++m) {
+        uint64_t* p = reinterpret_cast<uint64_t*>(state + mask_off_clear.off[m] + wi * 8);
+        *p &= ~bits;
     }
 }
 __global__ void k_edit_mask_bit(uint8_t* state, uint64_t mask_off, uint64_t slot, int value) {

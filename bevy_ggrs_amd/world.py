@@ -39,9 +39,15 @@ class WorldBase:
             raise GgrsHipError(rc, msg.decode() if msg else "")
 
     # ---- registration -------------------------------------------------------------------
-    def register_component(self, name: str, word_bytes: int, n_words: int) -> int:
+    def register_component(self, name: str, word_bytes: int, n_words: int, rollback: bool = True) -> int:
+        """rollback_component_with_copy (rollback=True), or a plain device-resident component that is
+        NOT registered for rollback (rollback=False; see ggrs_hip_register_component_ex)."""
         cid = C.c_uint32(0)
-        self._check(self._fn("register_component")(self._p, name.encode(), word_bytes, n_words, C.byref(cid)))
+        if rollback:
+            self._check(self._fn("register_component")(self._p, name.encode(), word_bytes, n_words, C.byref(cid)))
+        else:
+            self._check(self._fn("register_component_ex")(self._p, name.encode(), word_bytes, n_words,
+                                                          _ffi.COMP_NO_ROLLBACK, C.byref(cid)))
         self._comps.append((name, word_bytes, n_words))
         return cid.value
 
@@ -93,6 +99,20 @@ class WorldBase:
 
     def despawn(self, slot: int):
         self._check(self._fn("despawn")(self._p, slot))
+
+    def despawn_rollback(self, slot: int):
+        """commands.entity(e).despawn_rollback() (snapshot/despawn.rs:114-143)."""
+        self._check(self._fn("despawn_rollback")(self._p, slot))
+
+    def disabled_mask(self, n_slots: Optional[int] = None) -> np.ndarray:
+        """RollbackDespawned markers of the live world (peer-local, outside every snapshot)."""
+        return self._mask("download_disabled", self.len if n_slots is None else n_slots)
+
+    def despawned_frames(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        if count is None: count = self.len - first
+        out = np.zeros(max(count, 1), dtype=np.int32)
+        if count: self._check(self._fn("download_despawned_frames")(self._p, first, count, _as_c(out)))
+        return out[:count]
 
     def insert_component(self, comp: int, slot: int, words: np.ndarray):
         arr = np.ascontiguousarray(words).view(np.uint8).reshape(-1)

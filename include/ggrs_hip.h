@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 2
+#define GGRS_HIP_ABI_VERSION 3
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -88,6 +88,16 @@ int  ggrs_hip_abi_version(void);
 int ggrs_hip_register_component(ggrs_world* w, const char* name, uint32_t word_bytes,
                                 uint32_t n_words, uint32_t* comp_id);
 
+/* A component that lives on the device next to the rollback components but is NOT registered for
+ * rollback ("static collision properties or mesh handles", snapshot/despawn.rs:3-6): it is never
+ * snapshotted or restored, it dies with its entity, and an entity that LoadWorld has to re-create
+ * (entity.rs:80-90 spawns a fresh one with the old RollbackId) comes back without it.  Such
+ * components are the reason RollbackDespawned exists; see ggrs_hip_despawn_rollback below. */
+#define GGRS_COMP_ROLLBACK     0u   /* rollback_component_with_copy / _clone                      */
+#define GGRS_COMP_NO_ROLLBACK  1u   /* plain device-resident component, outside every snapshot   */
+int ggrs_hip_register_component_ex(ggrs_world* w, const char* name, uint32_t word_bytes,
+                                   uint32_t n_words, uint32_t flags, uint32_t* comp_id);
+
 /* value given to a freshly spawned entity's component when the spawner passes no data
  * (e.g. Transform::default for `Sprite`-required Transform, particles.rs:262). */
 int ggrs_hip_set_component_default(ggrs_world* w, uint32_t comp_id, const void* words);
@@ -108,7 +118,10 @@ int ggrs_hip_checksum_component(ggrs_world* w, uint32_t comp_id, const uint32_t*
 #define GGRS_SYS_PARTICLES_SPAWN  3u /* particles.rs:254-270  comp[0..2]=Transform,Velocity,Ttl
                                         iparam[0]=ttl iparam[1]=input mask (INPUT_SPAWN)           */
 #define GGRS_SYS_ADD_U32          4u /* benches/bench.rs:30-46 comp[0],word[0] += iparam[0]        */
-#define GGRS_SYS_SAT_SUB_DESPAWN  5u /* tests/synctest.rs:37-44 saturating_sub(iparam[0]), ==0 despawn */
+#define GGRS_SYS_SAT_SUB_DESPAWN  5u /* tests/synctest.rs:37-44 saturating_sub(iparam[0]), ==0 despawn;
+                                        iparam[1] = GGRS_DESPAWN_*: how the entity is despawned      */
+#define GGRS_DESPAWN_IMMEDIATE 0   /* commands.entity(e).despawn()                                    */
+#define GGRS_DESPAWN_ROLLBACK  1   /* commands.entity(e).despawn_rollback()  (snapshot/despawn.rs:114-143) */
 
 typedef struct {
     uint32_t kind;
@@ -134,6 +147,19 @@ int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols,
                    uint64_t* first_slot);
 int ggrs_hip_despawn(ggrs_world* w, uint64_t slot);                       /* commands.entity(e).despawn() */
+/* commands.entity(e).despawn_rollback() (snapshot/despawn.rs:114-143): while the current frame is
+ * unconfirmed (ConfirmedFrameCount < RollbackFrameCount) the entity is only DISABLED -- marked
+ * RollbackDespawned(frame), invisible to every query, snapshot and checksum -- so that LoadWorld can
+ * resurrect it with its non-rollback components intact (resurrect_entities, despawn.rs:69-87: marks
+ * > the loaded frame are removed) and AdvanceWorld frees it once its frame is confirmed
+ * (despawn_confirmed_entities, despawn.rs:89-112: marks <= ConfirmedFrameCount, checked whenever that
+ * counter changed).  With the frame already confirmed this is a plain despawn.  The marks are
+ * peer-local state: they are not part of any snapshot, checksum or exported state block. */
+int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot);
+/* RollbackDespawned markers of the live world: bit i of host_dst = slot i is disabled; frames (may be
+ * NULL) receives the marked frame of slots [first, first+count) (undefined where not disabled). */
+int ggrs_hip_download_disabled(ggrs_world* w, uint64_t* host_dst, uint64_t n_words64);
+int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t count, int32_t* frames);
 int ggrs_hip_insert_component(ggrs_world* w, uint32_t comp_id, uint64_t slot, const void* words);
 int ggrs_hip_remove_component(ggrs_world* w, uint32_t comp_id, uint64_t slot);
 

@@ -52,11 +52,15 @@ def _load():
         "gor_world_destroy": (None, [P]),
         "gor_last_error": (C.c_char_p, [P]),
         "gor_register_component": (C.c_int, [P, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "gor_register_component_ex": (C.c_int, [P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
         "gor_set_component_default": (C.c_int, [P, C.c_uint32, P]),
         "gor_checksum_component": (C.c_int, [P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
         "gor_add_system": (C.c_int, [P, C.POINTER(SystemDesc)]),
         "gor_spawn": (C.c_int, [P, C.c_uint64, C.c_uint64, C.POINTER(P), C.POINTER(C.c_uint64)]),
         "gor_despawn": (C.c_int, [P, C.c_uint64]),
+        "gor_despawn_rollback": (C.c_int, [P, C.c_uint64]),
+        "gor_download_disabled": (C.c_int, [P, P, C.c_uint64]),
+        "gor_download_despawned_frames": (C.c_int, [P, C.c_uint64, C.c_uint64, P]),
         "gor_insert_component": (C.c_int, [P, C.c_uint32, C.c_uint64, P]),
         "gor_remove_component": (C.c_int, [P, C.c_uint32, C.c_uint64]),
         "gor_upload_word": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P]),

@@ -203,6 +203,7 @@ struct Comp {
     std::vector<uint32_t> cks_units;          // u32 units fed to the inner SeaHash, in order
     bool checksummed = false;
     std::vector<uint8_t> defaults;            // n_words*word_bytes default value (zeros unless set)
+    bool no_rollback = false;                 // not registered for rollback: outside every snapshot (despawn.rs:3-6)
 };
 
 static inline bool bit(const std::vector<uint64_t>& m, uint64_t i) { return (m[i >> 6] >> (i & 63)) & 1ULL; }
@@ -281,6 +282,11 @@ struct World {
     std::vector<uint64_t> alive;
     std::vector<std::vector<uint64_t>> present;
     uint64_t len = 0;                               // RollbackOrdered.len(): ids ever spawned
+    // RollbackDespawned(frame) markers (despawn.rs:45-46): a disabled entity still exists (keeps its
+    // non-rollback components) but no default query, snapshot or checksum sees it: alive bit 0.
+    std::vector<uint64_t> disabled;
+    std::vector<int32_t> dframe;
+    int32_t dc_local = 0;                           // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
 
     int32_t frame = 0;                              // RollbackFrameCount (mod.rs:70)
     bool has_confirmed = false; int32_t confirmed = 0;  // ConfirmedFrameCount (mod.rs:80)
@@ -306,6 +312,8 @@ struct World {
             for (uint32_t w = 0; w < c.n_words; ++w) cols.emplace_back((size_t)capacity * c.word_bytes, 0);
         }
         alive.assign((capacity + 63) / 64, 0);
+        disabled.assign((capacity + 63) / 64, 0);
+        dframe.assign(capacity, 0);
         present.assign(comps.size(), std::vector<uint64_t>((capacity + 63) / 64, 0));
         if (mode == 1) {
             aos.clear();
@@ -436,6 +444,40 @@ static uint64_t component_checksum_ref(const World& w, uint32_t c) {
     return finalize_part(result);
 }
 
+// ---------------- RollbackDespawned (snapshot/despawn.rs) ----------------
+// EntityCommands::despawn_rollback, despawn.rs:114-143 (a queued command: RollbackFrameCount is the
+// frame being simulated).  Unconfirmed frame -> insert RollbackDespawned(frame): the entity is
+// disabled; otherwise a plain despawn.  (Children recursion: this path has no hierarchies.)
+static inline void despawn_rollback_one(World& w, uint64_t i) {
+    if (!bit(w.alive, i)) return;
+    setbit(w.alive, i, false);
+    if (w.confirmed < w.frame) { setbit(w.disabled, i, true); w.dframe[i] = w.frame; }
+}
+// LoadWorldSystems::EntityResurrect (resurrect_entities, despawn.rs:69-87) followed by the effect
+// EntitySnapshotPlugin::load's reconcile (entity.rs:55-99) has on NON-rollback components: an
+// entity that survives (live, in the snapshot) or stays disabled keeps them; one that is despawned
+// or re-created with a fresh Entity does not have them any more.  `snap_alive(i)` = the snapshot
+// holds RollbackId i.  Must run BEFORE the mode-specific load touches w.alive.
+template <class SnapAlive>
+static void resurrect_and_reconcile(World& w, uint64_t snap_len, SnapAlive snap_alive) {
+    const uint64_t hi = snap_len > w.len ? snap_len : w.len;
+    for (uint64_t i = 0; i < hi; ++i) {
+        bool exists = bit(w.alive, i);
+        if (bit(w.disabled, i) && w.dframe[i] > w.frame) {          // despawned_frame > rollback_frame
+            setbit(w.disabled, i, false); setbit(w.alive, i, true); exists = true;
+        }
+        const bool keep = (exists && i < snap_len && snap_alive(i)) || bit(w.disabled, i);
+        if (!keep) for (uint32_t c = 0; c < w.comps.size(); ++c) if (w.comps[c].no_rollback) setbit(w.present[c], i, false);
+    }
+}
+// AdvanceWorldSystems::DespawnConfirmed (despawn_confirmed_entities, despawn.rs:89-112)
+static void despawn_confirmed(World& w) {
+    if (w.confirmed == w.dc_local) return;                          // "No work necessary"
+    w.dc_local = w.confirmed;
+    for (uint64_t i = 0; i < w.len; ++i)
+        if (bit(w.disabled, i) && w.dframe[i] <= w.confirmed) setbit(w.disabled, i, false);   // world.despawn(entity)
+}
+
 // ---------------- systems ----------------
 static inline float f32_of(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t bits_of(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
@@ -518,7 +560,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
                 uint64_t i = (uint64_t)ii;
                 if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
                 p[i] = p[i] >= d ? p[i] - d : 0;    // saturating_sub
-                if (p[i] == 0) setbit(w.alive, i, false);
+                if (p[i] == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
             }
         } break;
         default: break;
@@ -587,7 +629,7 @@ static void advance_ref(World& w, const AdvanceArgs& a) {
                 if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
                 uint32_t* p = (uint32_t*)&w.aos[c][i * st] + s.word[0];
                 *p = *p >= d ? *p - d : 0;
-                if (*p == 0) setbit(w.alive, i, false);
+                if (*p == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
             }
         } break;
         default: break;
@@ -630,7 +672,7 @@ static int world_spawn(World& w, uint64_t count, uint64_t comp_mask, const void*
         }
         for (uint64_t j = 0; j < count; ++j) setbit(w.present[c], first + j, has);
     }
-    for (uint64_t j = 0; j < count; ++j) setbit(w.alive, first + j, true);
+    for (uint64_t j = 0; j < count; ++j) { setbit(w.alive, first + j, true); setbit(w.disabled, first + j, false); }
     w.len += count;
     if (w.mode == 1) {
         ref_sync_from_flat(w, first, count);
@@ -660,15 +702,18 @@ static void world_save(World& w, uint64_t out[2]) {
         FlatSnap s;
         s.len = w.len;
         s.cols.resize(w.cols.size());
-        for (uint32_t c = 0; c < w.comps.size(); ++c)
+        for (uint32_t c = 0; c < w.comps.size(); ++c) {
+            if (w.comps[c].no_rollback) continue;
             for (uint32_t k = 0; k < w.comps[c].n_words; ++k) {
                 auto& src = w.cols[w.col_base[c] + k];
                 s.cols[w.col_base[c] + k].assign(src.begin(), src.begin() + (size_t)w.len * w.comps[c].word_bytes);
             }
+        }
         size_t nw = (w.len + 63) / 64;
         s.alive.assign(w.alive.begin(), w.alive.begin() + nw);
         s.present.resize(w.comps.size());
-        for (uint32_t c = 0; c < w.comps.size(); ++c) s.present[c].assign(w.present[c].begin(), w.present[c].begin() + nw);
+        for (uint32_t c = 0; c < w.comps.size(); ++c)
+            if (!w.comps[c].no_rollback) s.present[c].assign(w.present[c].begin(), w.present[c].begin() + nw);
         w.ring.push(w.frame, std::move(s));
     } else {
         if (w.has_confirmed) w.rring.confirm(w.confirmed);
@@ -677,6 +722,7 @@ static void world_save(World& w, uint64_t out[2]) {
         uint64_t n_alive = active_count_flat(w);
         s.comp.resize(w.comps.size());
         for (uint32_t c = 0; c < w.comps.size(); ++c) {           // ComponentSnapshotPlugin::save, component_snapshot.rs:66-84
+            if (w.comps[c].no_rollback) continue;
             uint32_t st = w.stride(c);
             s.comp[c].init(n_alive, st);
             for (uint64_t i = 0; i < w.len; ++i) {
@@ -702,11 +748,13 @@ static int world_load(World& w, int32_t frame) {
     if (w.mode == 0) {
         if (!w.ring.rollback(frame)) { w.err = "Could not rollback: no snapshot at that frame"; return -2; }
         FlatSnap& s = *w.ring.get();
+        resurrect_and_reconcile(w, s.len, [&](uint64_t i) { return bit(s.alive, i); });
         // entity.rs:55-99 + component_snapshot.rs:95-123 collapse to: masks and columns := snapshot
-        for (size_t k = 0; k < s.cols.size(); ++k) memcpy(w.cols[k].data(), s.cols[k].data(), s.cols[k].size());
+        for (size_t k = 0; k < s.cols.size(); ++k) if (!s.cols[k].empty()) memcpy(w.cols[k].data(), s.cols[k].data(), s.cols[k].size());
         std::fill(w.alive.begin(), w.alive.end(), 0);
         memcpy(w.alive.data(), s.alive.data(), s.alive.size() * 8);
         for (uint32_t c = 0; c < w.comps.size(); ++c) {
+            if (w.comps[c].no_rollback) continue;
             std::fill(w.present[c].begin(), w.present[c].end(), 0);
             memcpy(w.present[c].data(), s.present[c].data(), s.present[c].size() * 8);
         }
@@ -714,6 +762,7 @@ static int world_load(World& w, int32_t frame) {
     } else {
         if (!w.rring.rollback(frame)) { w.err = "Could not rollback: no snapshot at that frame"; return -2; }
         RefSnap& s = *w.rring.get();
+        resurrect_and_reconcile(w, s.len, [&](uint64_t i) { return s.entities.get(World::rid(i)) != nullptr; });
         // EntitySnapshotPlugin::load (entity.rs:55-99): rollback_mapping built from snapshot + live query,
         // then entity_map collected twice (HashMap then EntityHashMap).
         uint64_t hi = s.len > w.len ? s.len : w.len;
@@ -745,6 +794,7 @@ static int world_load(World& w, int32_t frame) {
         for (uint64_t i = s.len; i < w.len; ++i) setbit(w.alive, i, false);
         // ComponentSnapshotPlugin::load (component_snapshot.rs:95-123): per entity lookup
         for (uint32_t c = 0; c < w.comps.size(); ++c) {
+            if (w.comps[c].no_rollback) continue;
             uint32_t st = w.stride(c);
             for (uint64_t i = 0; i < s.len; ++i) {
                 if (!bit(w.alive, i)) { setbit(w.present[c], i, false); continue; }
@@ -767,6 +817,7 @@ static void world_advance(World& w, const AdvanceArgs& a_in) {
     w.frame += 1;                                                 // schedule_systems.rs:254-259
     AdvanceArgs a = a_in;
     if (a.dt_bits == 0) a.dt_bits = dt_bits_for_frame(w.fps, w.frame);   // GgrsTimePlugin::update, time.rs:63-87
+    despawn_confirmed(w);                                         // AdvanceWorldSystems::DespawnConfirmed, set.rs:68-70
     if (w.mode == 0) advance_flat(w, a); else advance_ref(w, a);
 }
 
@@ -821,6 +872,14 @@ int gor_register_component(void* wp, const char* name, uint32_t word_bytes, uint
     if (id) *id = (uint32_t)w.comps.size() - 1;
     return 0;
 }
+int gor_register_component_ex(void* wp, const char* name, uint32_t word_bytes, uint32_t n_words, uint32_t flags, uint32_t* id) {
+    uint32_t c = 0;
+    int rc = gor_register_component(wp, name, word_bytes, n_words, &c);
+    if (rc) return rc;
+    ((World*)wp)->comps[c].no_rollback = (flags & 1u) != 0;
+    if (id) *id = c;
+    return 0;
+}
 int gor_set_component_default(void* wp, uint32_t c, const void* words) {
     World& w = *(World*)wp;
     if (c >= w.comps.size()) return -1;
@@ -855,6 +914,23 @@ int gor_despawn(void* wp, uint64_t slot) {
     World& w = *(World*)wp; w.seal();
     if (slot >= w.len) return -1;
     setbit(w.alive, slot, false);
+    return 0;
+}
+int gor_despawn_rollback(void* wp, uint64_t slot) {
+    World& w = *(World*)wp; w.seal();
+    if (slot >= w.len) return -1;
+    despawn_rollback_one(w, slot);
+    return 0;
+}
+int gor_download_disabled(void* wp, uint64_t* dst, uint64_t n_words64) {
+    World& w = *(World*)wp; w.seal();
+    for (uint64_t k = 0; k < n_words64; ++k) dst[k] = k < w.disabled.size() ? w.disabled[k] : 0;
+    return 0;
+}
+int gor_download_despawned_frames(void* wp, uint64_t first, uint64_t count, int32_t* frames) {
+    World& w = *(World*)wp; w.seal();
+    if (first + count > w.capacity) return -1;
+    memcpy(frames, w.dframe.data() + first, (size_t)count * 4);
     return 0;
 }
 int gor_insert_component(void* wp, uint32_t c, uint64_t slot, const void* words) {
@@ -902,6 +978,9 @@ int gor_download_present(void* wp, uint32_t c, uint64_t* dst, uint64_t n_words64
     World& w = *(World*)wp; w.seal();
     if (c >= w.comps.size()) return -1;
     for (uint64_t k = 0; k < n_words64; ++k) dst[k] = k < w.present[c].size() ? w.present[c][k] : 0;
+    // a non-rollback component dies with its entity (it exists while the entity is alive or disabled)
+    if (w.comps[c].no_rollback)
+        for (uint64_t k = 0; k < n_words64 && k < w.alive.size(); ++k) dst[k] &= (w.alive[k] | w.disabled[k]);
     return 0;
 }
 uint64_t gor_len(void* wp) { return ((World*)wp)->len; }
