@@ -234,12 +234,16 @@ def main():
     def per(ms, cnt):
         return ms / max(cnt, 1) * 1e-3
 
+    # PMC-derived HBM bytes per launch: only valid for the exact workload the counters were collected on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     grouped = tick_n > 0
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            same = (tj.get("entities") == n and tj.get("depth") == D and world_size == 1 and not args.no_checksum)
+            if same:
+                traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

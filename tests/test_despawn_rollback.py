@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import bevy_ggrs_amd as bg
+from bevy_ggrs_amd.session import MismatchedChecksum
 from oracle.binding import FLAT, REFSHAPED, OracleWorld
 
 import common as cm
@@ -166,25 +167,91 @@ def test_gpu_synctest_despawn_rollback_matches_oracle(n, cd):
         cm.assert_states_equal(a, b, f"tick {t}")
 
 
+def particles_with_host_despawn(world, n=3000, ticks=12):
+    """Host-issued despawn_rollback() OUTSIDE the GgrsSchedule on the particles world (fused
+    request-group path next to live-only marker state).  The command is not part of the rolled-back
+    simulation, so the resimulation of its frame resurrects the entities (despawn.rs:69-87) and does
+    not despawn them again: SyncTest must report the mismatch (schedule_systems.rs:105-114)."""
+    ids = cm.build_particles(world)
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(world, ids, n, vel, ttl)
+    drv = cm.SyncTestDriver(world, 3)
+    trace, err = [], None
+    for t in range(ticks):
+        if t in (2, 5):
+            for slot in range(10 * t, 10 * t + 5):
+                world.despawn_rollback(slot)
+        try:
+            drv.tick((0,))
+        except MismatchedChecksum as e:
+            err = (t, e.current_frame, tuple(e.mismatched_frames))
+            break
+        trace.append(state(world, ids))
+    return drv.all_checksums, trace, err
+
+
+def particles_markers_scripted(world, n=3000):
+    """Same world, request lists whose rollbacks never cross the marked frame: deterministic."""
+    ids = cm.build_particles(world)
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(world, ids, n, vel, ttl)
+    world.set_depth(8)
+    world.set_confirmed(0)
+    out, cs = [], []
+    cs += world.handle_requests([bg.SaveGameState(0)] + [bg.AdvanceFrame((0,))] * 5)
+    for slot in range(40, 52):
+        world.despawn_rollback(slot)                     # marked with frame 5 (unconfirmed)
+    out.append(state(world, ids))
+    cs += world.handle_requests([bg.SaveGameState(5), bg.AdvanceFrame((0,)), bg.SaveGameState(6), bg.AdvanceFrame((0,))])
+    out.append(state(world, ids))
+    # back to 5: marks are not > 5, nobody is resurrected; the resimulated frame 6 must hash as before
+    cs += world.handle_requests([bg.LoadGameState(5), bg.AdvanceFrame((0,)), bg.SaveGameState(6), bg.AdvanceFrame((0,)), bg.SaveGameState(7)])
+    out.append(state(world, ids))
+    # back to 0 (< 5): everybody marked is resurrected and, without the command, stays alive
+    cs += world.handle_requests([bg.LoadGameState(0)] + [bg.AdvanceFrame((0,))] * 5 + [bg.SaveGameState(5)])
+    out.append(state(world, ids))
+    world.set_confirmed(5)
+    cs += world.handle_requests([bg.AdvanceFrame((0,)), bg.SaveGameState(6)])
+    out.append(state(world, ids))
+    return cs, out
+
+
+def check_markers_scripted(cs, out):
+    assert cs[2] == cs[3]                                # Save(6) before and after Load(5)
+    assert cs[1] != cs[5]                                # Save(5) with / without the host's despawns
+    assert out[0]["disabled"][40:52].all() and not out[0]["alive"][40:52].any()
+    assert (out[0]["dframe"][40:52] == 5).all()
+    assert out[2]["disabled"][40:52].all()
+    assert not out[3]["disabled"].any()                  # resurrected by Load(0) ...
+    ttl0 = 1 + (np.arange(3000) % 300)
+    assert np.array_equal(out[3]["alive"][40:52], ttl0[40:52] > 5)   # ... and alive unless their Ttl ran out
+
+
+def test_oracle_host_despawn_outside_schedule_is_a_synctest_mismatch():
+    cs, trace, err = particles_with_host_despawn(OracleWorld(3064, 8))
+    # despawned on frame 2 (tick 2); frames 2 and 3 are first resimulated by tick 4, checked at tick 5
+    assert err == (5, 5, (2, 3))
+    assert len(trace) == 5
+
+
+@pytest.mark.parametrize("mode", [FLAT, REFSHAPED])
+def test_oracle_particles_markers_scripted(mode):
+    cs, out = particles_markers_scripted(OracleWorld(3064, 8, mode))
+    check_markers_scripted(cs, out)
+
+
 @pytest.mark.gpu
 def test_gpu_particles_world_with_markers():
-    """The fused request-group path (k_tick) with live-only marker state next to it: host-issued
-    despawn_rollback on the particles world, rolled back and resimulated by SyncTest."""
-    n = 3000
-    res = []
-    for w in (bg.World(n + 64, max_depth=8), OracleWorld(n + 64, 8)):
-        ids = cm.build_particles(w)
-        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
-        cm.spawn_particles(w, ids, n, vel, ttl)
-        drv = cm.SyncTestDriver(w, 3)
-        trace = []
-        for t in range(12):
-            if t in (2, 5):
-                for slot in range(10 * t, 10 * t + 5):
-                    w.despawn_rollback(slot)
-            drv.tick((0,))
-            trace.append(state(w, ids))
-        res.append((drv.all_checksums, trace))
-    assert res[0][0] == res[1][0]
-    for t, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+    """The fused request-group path (k_tick) with live-only marker state next to it."""
+    got = particles_with_host_despawn(bg.World(3064, max_depth=8))
+    want = particles_with_host_despawn(OracleWorld(3064, 8))
+    assert got[2] == want[2] == (5, 5, (2, 3))
+    assert got[0] == want[0]
+    for t, (a, b) in enumerate(zip(got[1], want[1])):
         cm.assert_states_equal(a, b, f"tick {t}")
+    cs_g, out_g = particles_markers_scripted(bg.World(3064, max_depth=8))
+    cs_o, out_o = particles_markers_scripted(OracleWorld(3064, 8))
+    check_markers_scripted(cs_g, out_g)
+    assert cs_g == cs_o
+    for t, (a, b) in enumerate(zip(out_g, out_o)):
+        cm.assert_states_equal(a, b, f"step {t}")
