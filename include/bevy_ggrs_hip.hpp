@@ -16,6 +16,10 @@
 //   RollbackApp::rollback_component_with_*   src/snapshot/rollback_app.rs:31-133   App member functions
 //   run_ggrs_schedules / run_synctest /      src/schedule_systems.rs:19-118,170-289  App::update / handle_requests
 //   handle_requests
+//   RollbackApp::rollback_resource_with_*,   src/snapshot/rollback_app.rs:46-124     App member functions; resources are O(1)
+//   checksum_resource[_with_hash]            resource_snapshot.rs, resource_checksum.rs  bytes per frame and stay on the host
+//   GgrsSnapshots<For, As>                   src/snapshot/mod.rs:97-274              bevy_ggrs::GgrsSnapshots<As> (host ring for resources)
+//   checksum_hasher() == SeaHasher::new()    src/snapshot/mod.rs:318-320             bevy_ggrs::SeaHasher (seahash 4.1, restated)
 //   ggrs::SessionBuilder / SyncTestSession   (un-vendored `ggrs`, Cargo.toml:23; restated)  same names
 //
 // User systems in the reference are arbitrary Rust closures; on this path a GgrsSchedule system is a
@@ -27,6 +31,10 @@
 #pragma once
 
 #include <chrono>
+#include <deque>
+#include <memory>
+#include <typeindex>
+#include <typeinfo>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -217,6 +225,87 @@ class SessionBuilder {                 // ggrs::SessionBuilder (knobs used by th
 // src/lib.rs:81-88.  P2P / Spectator variants live in ggrs's UDP layer: out of scope.
 template <class C> using Session = std::variant<std::monostate, SyncTestSession<C>>;
 
+
+// ---------------------------------------------------------------- SeaHasher (host side)
+// checksum_hasher() (src/snapshot/mod.rs:318-320) = seahash::SeaHasher::new(), seahash "4.1" (Cargo.toml:24,
+// un-vendored): stream hasher restated from the crate's published algorithm.  Used here for the host-resident
+// ChecksumParts (resource_checksum.rs:40-44); the per-entity hashing of components runs on the device.
+// Rust's `Hash` feeds integers as little-endian bytes (u32 -> 4, u64/usize -> 8), newtype structs hash their
+// fields with no prefix, str/String -> bytes then 0xff.
+class SeaHasher {
+  public:
+    void write(const void* data, size_t n) {
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        for (size_t i = 0; i < n; ++i) {
+            tail_ |= (uint64_t)p[i] << (8 * ntail_);
+            if (++ntail_ == 8) { absorb(tail_); tail_ = 0; ntail_ = 0; written_ += 8; }
+        }
+    }
+    void write_u8(uint8_t v) { write(&v, 1); }
+    void write_u32(uint32_t v) { uint8_t b[4]; for (int i = 0; i < 4; ++i) b[i] = (uint8_t)(v >> (8 * i)); write(b, 4); }
+    void write_u64(uint64_t v) { uint8_t b[8]; for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i)); write(b, 8); }
+    void write_usize(uint64_t v) { write_u64(v); }
+    void write_i32(int32_t v) { write_u32((uint32_t)v); }
+    void write_str(const std::string& s) { write(s.data(), s.size()); write_u8(0xff); }
+    uint64_t finish() const {
+        const uint64_t a = ntail_ ? diffuse(s_[0] ^ tail_) : s_[0];
+        return diffuse(a ^ s_[1] ^ s_[2] ^ s_[3] ^ (written_ + ntail_));
+    }
+    static uint64_t diffuse(uint64_t x) {
+        const uint64_t P = 0x6eed0e9da4d94a4fULL;
+        x *= P; x ^= (x >> 32) >> (x >> 60); x *= P;
+        return x;
+    }
+  private:
+    void absorb(uint64_t word) { const uint64_t a = diffuse(s_[0] ^ word); s_[0] = s_[1]; s_[1] = s_[2]; s_[2] = s_[3]; s_[3] = a; }
+    uint64_t s_[4] = {0x16f11fe89b0d677cULL, 0xb480a793d8e6c86cULL, 0x6fe2e5aaf078ebc9ULL, 0x14f994a4c5259381ULL};
+    uint64_t tail_ = 0, written_ = 0; unsigned ntail_ = 0;
+};
+
+// ---------------------------------------------------------------- GgrsSnapshots (host side)
+// src/snapshot/mod.rs:97-274: newest snapshot at the front; `As` is the stored form.  The device ring inside
+// libggrs_hip.so follows the same rules over slot indices; this one holds the host-resident resources.
+template <class As>
+class GgrsSnapshots {
+  public:
+    GgrsSnapshots& set_depth(size_t depth) { depth_ = depth; return *this; }                    // mod.rs:121-137
+    size_t depth() const { return depth_; }
+    size_t size() const { return frames_.size(); }
+    GgrsSnapshots& push(Frame frame, As snapshot) {                                             // mod.rs:147-181
+        while (!frames_.empty()) {
+            const Frame cur = frames_.front();
+            const uint32_t gap = cur > frame ? (uint32_t)cur - (uint32_t)frame : (uint32_t)frame - (uint32_t)cur;   // i32::abs_diff
+            const bool wrapped = gap > UINT32_MAX / 2;
+            if ((cur >= frame && !wrapped) || (frame >= cur && wrapped)) { frames_.pop_front(); snaps_.pop_front(); }
+            else break;
+        }
+        frames_.push_front(frame); snaps_.push_front(std::move(snapshot));
+        while (snaps_.size() > depth_) { frames_.pop_back(); snaps_.pop_back(); }
+        return *this;
+    }
+    GgrsSnapshots& confirm(Frame confirmed_frame) {                                             // mod.rs:185-202
+        while (!frames_.empty() && frames_.back() < confirmed_frame) { frames_.pop_back(); snaps_.pop_back(); }
+        return *this;
+    }
+    GgrsSnapshots& rollback(Frame frame) {                                                      // mod.rs:210-226 (panic -> exception)
+        for (;;) {
+            if (frames_.empty()) throw std::runtime_error("Could not rollback to " + std::to_string(frame) + ": no snapshot at that moment could be found.");
+            if (frames_.front() == frame) return *this;
+            frames_.pop_front(); snaps_.pop_front();
+        }
+    }
+    const As& get() const {                                                                     // mod.rs:229-233
+        if (snaps_.empty()) throw std::runtime_error("no snapshot available - call rollback(frame) before get()");
+        return snaps_.front();
+    }
+    const As* peek(Frame frame) const {                                                         // mod.rs:236-243
+        for (size_t i = 0; i < frames_.size(); ++i) if (frames_[i] == frame) return &snaps_[i];
+        return nullptr;
+    }
+  private:
+    std::deque<As> snaps_; std::deque<Frame> frames_; size_t depth_ = DEFAULT_FPS;              // mod.rs:115
+};
+
 // ---------------------------------------------------------------- components and systems
 // A rollback component on this path is plain-old-data made of 4- or 8-byte words
 // (Transform = 10 x f32, Velocity = 3 x f32, Ttl = 1 x u64).  Specialise for each type:
@@ -302,6 +391,11 @@ class App {
     static_assert(sizeof(Input) == 1, "this path carries one input byte per player (GGRS_MAX_PLAYERS bytes per AdvanceFrame)");
     using ReadInputsSystem = std::function<void(const LocalPlayers&, LocalInputs<C>&)>;
     using SpawnSource = std::function<void(Frame, std::vector<float>& vx, std::vector<float>& vy)>;
+    // A GgrsSchedule system that runs on the HOST: it may read RollbackFrameCount / PlayerInputs and insert,
+    // mutate or remove *resources* (which live on the host); entity components are device-resident and
+    // only kernel-backed systems touch them.  Host systems run in registration order on every AdvanceFrame,
+    // after `RollbackFrameCount += 1` (schedule_systems.rs:254-268).
+    using HostSystem = std::function<void(App&, const PlayerInputs<C>&)>;
 
     explicit App(uint64_t capacity, uint32_t max_depth = 16, int device = 0) : be_(capacity, max_depth, device), max_depth_(max_depth) {}
 
@@ -337,9 +431,66 @@ class App {
     // pure function of the frame, or SyncTest reports a mismatch -- exactly like a non-deterministic system
     App& set_spawn_source(SpawnSource f) { spawn_source_ = std::move(f); return *this; }
 
+    App& add_systems(GgrsSchedule, HostSystem f) { host_systems_.push_back(std::move(f)); return *this; }
+
+    // ---- resources (host-resident).  app.insert_resource / init_resource / commands.remove_resource
+    template <class R> App& insert_resource(R value) { res_entry<R>().value = std::make_shared<R>(std::move(value)); return *this; }
+    template <class R> App& init_resource() { auto& e = res_entry<R>(); if (!e.value) e.value = std::make_shared<R>(); return *this; }
+    template <class R> App& remove_resource() { res_entry<R>().value.reset(); return *this; }
+    template <class R> R* get_resource() {                                  // Option<Res<R>> / world.get_resource::<R>()
+        auto it = resources_.find(std::type_index(typeid(R)));
+        return it == resources_.end() ? nullptr : static_cast<R*>(it->second.value.get());
+    }
+    template <class R> R& resource() {                                      // Res<R>: the reference panics when it is missing
+        R* r = get_resource<R>();
+        if (!r) throw std::runtime_error(std::string("Requested resource ") + typeid(R).name() + " does not exist");
+        return *r;
+    }
+    // rollback_resource_with_copy / _clone (rollback_app.rs:46-50,64-68 -> ResourceSnapshotPlugin,
+    // resource_snapshot.rs:70-98): SaveWorld stores Some(clone) or None, LoadWorld updates / inserts / removes.
+    template <class R> App& rollback_resource_with_copy() { return rollback_resource_with_clone<R>(); }
+    template <class R> App& rollback_resource_with_clone() {
+        auto& e = res_entry<R>();
+        e.rollback = true;
+        e.clone = [](const void* p) -> std::shared_ptr<void> { return std::make_shared<R>(*static_cast<const R*>(p)); };
+        return *this;
+    }
+    // ReflectStrategy (strategy.rs:86-110) stores reflect_clone() and applies it back: for a host value type that
+    // is the clone strategy
+    template <class R> App& rollback_resource_with_reflect() { return rollback_resource_with_clone<R>(); }
+    // checksum_resource(fn(&R) -> u64) / checksum_resource_with_hash (rollback_app.rs:109-112,124-127 ->
+    // ResourceChecksumPlugin, resource_checksum.rs:40-83).  `_with_hash` needs `void ggrs_hash(const R&, SeaHasher&)`
+    // (the `#[derive(Hash)]` of the reference) findable by ADL.
+    template <class R> App& checksum_resource(uint64_t (*hasher)(const R&)) {
+        auto& e = res_entry<R>();
+        e.hasher = [hasher](const void* p) { return hasher(*static_cast<const R*>(p)); };
+        return *this;
+    }
+    template <class R> App& checksum_resource_with_hash() {
+        auto& e = res_entry<R>();
+        e.hasher = [](const void* p) { SeaHasher h; ggrs_hash(*static_cast<const R*>(p), h); return h.finish(); };
+        return *this;
+    }
+    template <class R> App& update_resource_with_map_entities() {
+        throw std::logic_error("update_resource_with_map_entities: entity remapping (resource_map.rs) is out of scope - slots are stable, the entity map is the identity");
+    }
+
     // ---- RollbackApp (src/snapshot/rollback_app.rs:31-133)
     template <class T> App& rollback_component_with_copy() { return register_component<T>(); }
     template <class T> App& rollback_component_with_clone() { return register_component<T>(); }   // bitwise for POD (strategy.rs:62-83)
+    // rollback_immutable_component_with_* (rollback_app.rs:40-44,58-62; ImmutableComponentSnapshotPlugin::load,
+    // component_snapshot.rs:218-245): LoadWorld re-INSERTS the stored value instead of updating in place so that
+    // component hooks fire.  In a SoA column "insert" is "store the words + set the presence bit", which is what
+    // the device's LoadWorld does for every component; hooks are host callbacks and do not exist on this path.
+    template <class T> App& rollback_immutable_component_with_copy() { return register_component<T>(); }
+    template <class T> App& rollback_immutable_component_with_clone() { return register_component<T>(); }
+    template <class T> App& rollback_immutable_component_with_reflect() { return rollback_component_with_reflect<T>(); }
+    // require_rollback (rollback_app.rs:130-133,241-247): every entity spawned through App::spawn IS a Rollback
+    // entity on this path (slot == RollbackOrdered index), so the requirement always holds
+    template <class T> App& require_rollback() { comp_id(HipComponent<T>::name); return *this; }
+    template <class T> App& update_component_with_map_entities() {
+        throw std::logic_error("update_component_with_map_entities: entity remapping (component_map.rs) is out of scope - slots are stable, the entity map is the identity");
+    }
     template <class T> App& rollback_component_with_reflect() {
         throw std::logic_error("rollback_component_with_reflect: ReflectStrategy (strategy.rs:86-110) is dynamic reflection, out of scope for the device path");
     }
@@ -370,11 +521,12 @@ class App {
     void flush() {                         // collect every outstanding batch (oldest first)
         while (!in_flight_.empty()) {
             auto saves = std::move(in_flight_.front()); in_flight_.erase(in_flight_.begin());
+            auto parts = std::move(in_flight_parts_.front()); in_flight_parts_.erase(in_flight_parts_.begin());
             std::vector<uint64_t> sums(2 * saves.size() + 2);
             check(be_.collect_checksums(sums.data(), (uint32_t)saves.size()));
             last_checksums_.clear();
             for (size_t k = 0; k < saves.size(); ++k) {
-                const u128 cs{sums[2 * k], sums[2 * k + 1]};
+                const u128 cs{sums[2 * k] ^ parts[k], sums[2 * k + 1]};
                 saves[k].first->save(saves[k].second, nullptr, cs);
                 last_checksums_.push_back(cs);
             }
@@ -383,7 +535,7 @@ class App {
 
     // ---- observers / resources
     App& add_observer(std::function<void(const SyncTestMismatch&)> f) { on_mismatch_ = std::move(f); return *this; }
-    Frame rollback_frame_count() { return be_.frame(); }                                        // RollbackFrameCount, mod.rs:70
+    Frame rollback_frame_count() { return in_requests_ ? req_frame_ : be_.frame(); }                                        // RollbackFrameCount, mod.rs:70
     Frame confirmed_frame_count() const { return confirmed_; }                                  // ConfirmedFrameCount, mod.rs:80
     size_t max_prediction_window() const { return max_prediction_window_; }                     // MaxPredictionWindow, lib.rs:119
     const std::vector<u128>& last_checksums() const { return last_checksums_; }
@@ -419,13 +571,28 @@ class App {
         std::vector<std::vector<float>> payload; payload.reserve(2 * requests.size());
         std::vector<GgrsRequest<C>*> saves;
         Frame cur = be_.frame();
+        const SyncTestSession<C>* st = std::get_if<SyncTestSession<C>>(&session_);
+        std::vector<uint64_t> res_parts;           // XOR of the host-resident ChecksumParts, one per SaveGameState
+        in_requests_ = true;
+        struct Leave { bool& f; ~Leave() { f = false; } } leave{in_requests_};
         for (size_t i = 0; i < requests.size(); ++i) {
             auto& r = requests[i];
             ggrs_request& q = reqs[i]; std::memset(&q, 0, sizeof q);
             q.kind = (uint32_t)r.kind;
+            // schedule_systems.rs:197-220: ConfirmedFrameCount is refreshed before EVERY request (SyncTest:
+            // current_frame - check_distance when >= 0)
+            Frame confirmed_now = confirmed_;
+            if (st) { const Frame c = cur - (Frame)st->check_distance(); if (c >= 0) confirmed_now = c; }
+            req_frame_ = cur;
             switch (r.kind) {
-            case GgrsRequest<C>::SaveGameState: q.frame = r.frame; saves.push_back(&r); break;
-            case GgrsRequest<C>::LoadGameState: q.frame = r.frame; cur = r.frame; break;
+            case GgrsRequest<C>::SaveGameState:
+                q.frame = r.frame; saves.push_back(&r);
+                res_parts.push_back(save_resources(cur, confirmed_now));
+                break;
+            case GgrsRequest<C>::LoadGameState:
+                q.frame = r.frame; cur = r.frame; req_frame_ = cur;
+                load_resources(cur);
+                break;
             case GgrsRequest<C>::AdvanceFrame: {
                 input_bytes.emplace_back();
                 bool pressed = false;
@@ -437,15 +604,18 @@ class App {
                     spawn_source_(cur, vx, vy);
                     q.spawn_count = vx.size(); q.spawn_vx = vx.data(); q.spawn_vy = vy.data();
                 }
-                cur += 1;
+                cur += 1; req_frame_ = cur;
+                for (auto& sys : host_systems_) sys(*this, r.inputs);
             } break;
             }
         }
+        in_requests_ = false;
         if (pipelined_) {
             if (be_.enqueue_requests(reqs.data(), (uint32_t)reqs.size()) != GGRS_OK) throw std::runtime_error(be_.last_error());
             std::vector<std::pair<GameStateCell*, Frame>> cells;
             for (auto* sv : saves) cells.emplace_back(sv->cell, sv->frame);
             in_flight_.push_back(std::move(cells));
+            in_flight_parts_.push_back(std::move(res_parts));
             if (auto* s = std::get_if<SyncTestSession<C>>(&session_)) {
                 const Frame c = be_.frame() - (Frame)s->check_distance();
                 if (c >= 0) confirmed_ = c;
@@ -457,7 +627,7 @@ class App {
         if (rc != GGRS_OK) throw std::runtime_error(be_.last_error());      // the reference panics here (mod.rs:213-215)
         last_checksums_.clear();
         for (size_t k = 0; k < saves.size(); ++k) {
-            const u128 cs{sums[2 * k], sums[2 * k + 1]};
+            const u128 cs{sums[2 * k] ^ res_parts[k], sums[2 * k + 1]};       // checksum.rs:88-99: XOR of ALL parts
             saves[k]->cell->save(saves[k]->frame, nullptr, cs);             // schedule_systems.rs:231-236
             last_checksums_.push_back(cs);
         }
@@ -469,6 +639,43 @@ class App {
 
   private:
     void check(int rc) { if (rc != GGRS_OK) throw std::runtime_error(be_.last_error()); }
+    struct ResourceEntry {
+        std::shared_ptr<void> value;                                         // null: the resource is absent
+        bool rollback = false;
+        std::function<std::shared_ptr<void>(const void*)> clone;             // Strategy::store / load (bijection, strategy.rs:21)
+        std::function<uint64_t(const void*)> hasher;                         // ResourceChecksumPlugin(fn)
+        GgrsSnapshots<std::shared_ptr<void>> snapshots;                      // GgrsResourceSnapshots<R, Option<Stored>>
+        bool part_spawned = false; uint64_t part = 0;                        // its ChecksumPart entity (resource_checksum.rs:70-80)
+    };
+    template <class R> ResourceEntry& res_entry() { return resources_[std::type_index(typeid(R))]; }
+    // SaveWorld for the host-resident state: ResourceChecksumPlugin::update (Checksum set), then
+    // sync_depth -> discard_old_snapshots -> ResourceSnapshotPlugin::save (Snapshot set).  Returns the XOR of the
+    // resource ChecksumParts.  A part, once spawned, stays in the fold even while its resource is absent (the
+    // update system needs Res<R> and does not run then; its ChecksumPart entity is never despawned).
+    uint64_t save_resources(Frame frame, Frame confirmed) {
+        uint64_t fold = 0;
+        for (auto& kv : resources_) {
+            ResourceEntry& e = kv.second;
+            if (e.hasher) {
+                if (e.value) { e.part = e.hasher(e.value.get()); e.part_spawned = true; }
+                if (e.part_spawned) fold ^= e.part;
+            }
+            if (!e.rollback) continue;
+            e.snapshots.set_depth(max_prediction_window_);
+            if (confirmed >= 0) e.snapshots.confirm(confirmed);
+            e.snapshots.push(frame, e.value ? e.clone(e.value.get()) : nullptr);
+        }
+        return fold;
+    }
+    // LoadWorld (resource_snapshot.rs:81-97): (Some, Some) update, (Some, None) remove, (None, Some) insert
+    void load_resources(Frame frame) {
+        for (auto& kv : resources_) {
+            ResourceEntry& e = kv.second;
+            if (!e.rollback) continue;
+            const std::shared_ptr<void>& snap = e.snapshots.rollback(frame).get();
+            e.value = snap ? e.clone(snap.get()) : nullptr;
+        }
+    }
     uint32_t comp_id(const std::string& name) const {
         auto it = comp_ids_.find(name);
         if (it == comp_ids_.end()) throw std::invalid_argument("component " + name + " is not registered for rollback");
@@ -514,6 +721,10 @@ class App {
     std::vector<u128> last_checksums_;
     bool pipelined_ = false;
     std::vector<std::vector<std::pair<GameStateCell*, Frame>>> in_flight_;
+    std::vector<std::vector<uint64_t>> in_flight_parts_;
+    std::map<std::type_index, ResourceEntry> resources_;
+    std::vector<HostSystem> host_systems_;
+    bool in_requests_ = false; Frame req_frame_ = 0;
 };
 
 }  // namespace bevy_ggrs

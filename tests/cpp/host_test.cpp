@@ -200,6 +200,21 @@ static void component_rollback_copy() {
     std::puts("ok component_rollback_copy");
 }
 
+// tests/component_rollback.rs:131-163: #[component(immutable)] ImmutableTick, incremented by re-inserting
+// ImmutableTick(tick + 1) every frame
+static void immutable_component_copy_strategy_rolls_back() {
+    TestApp app(16);
+    base_synctest_app(app, 2);
+    app.rollback_immutable_component_with_copy<Counter>().checksum_component_with_hash<Counter>().require_rollback<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch: immutable Copy component rollback is non-deterministic"); });
+    app.spawn(1, {"Counter"});
+    for (int i = 0; i < 20; ++i) app.update();
+    auto v = app.download<Counter, uint32_t>(0);
+    CHECK(v.size() == 1 && (Frame)v[0] == app.rollback_frame_count());
+    std::puts("ok immutable_component_copy_strategy_rolls_back");
+}
+
 // run_ggrs_schedules accumulator (src/schedule_systems.rs:19-83) + tests/time.rs:18-49
 static void fixed_timestep_accumulator() {
     TestApp app(16);
@@ -217,6 +232,127 @@ static void fixed_timestep_accumulator() {
     idle.update();
     CHECK(idle.rollback_frame_count() == 0 && idle.confirmed_frame_count() == -1 && idle.max_prediction_window() == 8);
     std::puts("ok fixed_timestep_accumulator");
+}
+
+
+// ---- tests/resource_lifecycle.rs:19-32
+struct Wallet { uint32_t v; };
+struct FrameLog { uint32_t v = 0; };
+static void ggrs_hash(const FrameLog& f, SeaHasher& h) { h.write_u32(f.v); }       // #[derive(Hash)] struct FrameLog(u32)
+static void track_wallet(TestApp& app, const PlayerInputs<Config>&) {              // resource_lifecycle.rs:30-32
+    app.resource<FrameLog>().v += app.get_resource<Wallet>() ? 2u : 1u;
+}
+static void resource_app(TestApp& app) {
+    base_synctest_app(app, 4);
+    app.init_resource<FrameLog>();
+    app.rollback_resource_with_clone<Wallet>().rollback_resource_with_clone<FrameLog>().checksum_resource_with_hash<FrameLog>();
+    app.rollback_component_with_copy<Counter>();                                   // the device world needs one registered column
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.spawn(1, {"Counter"});
+}
+// tests/resource_lifecycle.rs:43-80
+static void resource_inserted_mid_session_rolls_back() {
+    TestApp app(16);
+    resource_app(app);
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem([](TestApp& a, const PlayerInputs<Config>&) { if (a.rollback_frame_count() == 3) a.insert_resource(Wallet{100}); }));
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem(track_wallet));
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch: Wallet rollback (insert) is non-deterministic"); });
+    for (int i = 0; i < 20; ++i) app.update();
+    CHECK(app.get_resource<Wallet>() != nullptr && app.resource<Wallet>().v == 100);
+    CHECK(app.rollback_frame_count() == 20);
+    CHECK(app.resource<FrameLog>().v == 2 * 1 + 18 * 2);                           // frames 1, 2 without the wallet, 3..20 with it
+    std::puts("ok resource_inserted_mid_session_rolls_back");
+}
+// tests/resource_lifecycle.rs:89-120
+static void resource_removed_mid_session_rolls_back() {
+    TestApp app(16);
+    resource_app(app);
+    app.insert_resource(Wallet{100});
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem([](TestApp& a, const PlayerInputs<Config>&) { if (a.rollback_frame_count() == 3) a.remove_resource<Wallet>(); }));
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem(track_wallet));
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch: Wallet rollback (remove) is non-deterministic"); });
+    for (int i = 0; i < 20; ++i) app.update();
+    CHECK(app.get_resource<Wallet>() == nullptr);
+    CHECK(app.resource<FrameLog>().v == 2 * 2 + 18 * 1);
+    std::puts("ok resource_removed_mid_session_rolls_back");
+}
+// the detection strategy of resource_lifecycle.rs:9-12, negated: a Wallet that is NOT registered for rollback
+// survives LoadWorld, FrameLog accumulates differently during re-simulation, SyncTestMismatch fires
+static void resource_without_rollback_fires_mismatch() {
+    TestApp app(16);
+    base_synctest_app(app, 4);
+    app.init_resource<FrameLog>();
+    app.rollback_resource_with_clone<FrameLog>().checksum_resource_with_hash<FrameLog>();
+    app.rollback_component_with_copy<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.spawn(1, {"Counter"});
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem([](TestApp& a, const PlayerInputs<Config>&) { if (a.rollback_frame_count() == 3) a.insert_resource(Wallet{100}); }));
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem(track_wallet));
+    int fired = 0;
+    app.add_observer([&](const SyncTestMismatch&) { ++fired; });
+    for (int i = 0; i < 12; ++i) app.update();
+    CHECK(fired > 0);
+    std::puts("ok resource_without_rollback_fires_mismatch");
+}
+// resource checksum parts take part in the frame checksum exactly as checksum.rs:88-99 folds them, in both the
+// synchronous and the pipelined mode
+static void resource_checksum_part_is_folded() {
+    std::vector<u128> seen[2];
+    for (int pipelined = 0; pipelined < 2; ++pipelined) {
+        TestApp app(16);
+        resource_app(app);
+        app.add_systems(GgrsSchedule{}, TestApp::HostSystem(track_wallet));
+        app.set_pipelined(pipelined != 0);
+        for (int i = 0; i < 8; ++i) { app.update(); app.flush(); for (auto& c : app.last_checksums()) seen[pipelined].push_back(c); }
+    }
+    CHECK(seen[0].size() == seen[1].size() && !seen[0].empty());
+    for (size_t i = 0; i < seen[0].size(); ++i) CHECK(seen[0][i] == seen[1][i]);
+    // the same world without the FrameLog part differs by exactly that part: SeaHasher(write_u32(v))
+    TestApp plain(16);
+    base_synctest_app(plain, 4);
+    plain.rollback_component_with_copy<Counter>();
+    plain.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    plain.spawn(1, {"Counter"});
+    plain.update();                                                                // Save(0) then Advance
+    SeaHasher h; h.write_u32(0);
+    CHECK(plain.last_checksums().size() == 1 && (plain.last_checksums()[0].lo ^ h.finish()) == seen[0][0].lo);
+    std::puts("ok resource_checksum_part_is_folded");
+}
+
+// seahash published vector + the SURVEY 8c derived vectors, on the HOST hasher of the mirror
+static void host_seahasher_known_answers() {
+    SeaHasher a; a.write("to be or not to be", 18);
+    CHECK(a.finish() == 1988685042348123509ULL);
+    SeaHasher b; b.write("to be or ", 9); b.write("not to be", 9);                 // chunking must not matter
+    CHECK(b.finish() == 1988685042348123509ULL);
+    SeaHasher c; c.write_u32(42);                                                   // ChecksumPart::from_value(&42u32), checksum.rs:38-44
+    CHECK(c.finish() == 0x352173bd5a4ba44bULL);
+    SeaHasher d; d.write_u64(1); d.write_u64(1);                                    // entity checksum (active = 1, total = 1)
+    CHECK(d.finish() == 0x7c846906b6e5a068ULL);
+    std::puts("ok host_seahasher_known_answers");
+}
+
+// src/snapshot/mod.rs:349-512, the ring's own unit tests, on the host ring that holds the resources
+static void host_ring_known_answers() {
+    using Ring = GgrsSnapshots<int>;
+    { Ring r; r.set_depth(3); for (int f = 0; f < 5; ++f) r.push(f, f * 10);              // mod.rs:369-380
+      CHECK(r.size() == 3 && !r.peek(0) && !r.peek(1) && *r.peek(2) == 20 && *r.peek(4) == 40); }
+    { Ring r; r.set_depth(8); for (int f = 0; f < 5; ++f) r.push(f, f * 10); r.push(2, 99); // mod.rs:384-394
+      CHECK(r.size() == 3 && *r.peek(2) == 99 && !r.peek(3) && !r.peek(4) && *r.peek(1) == 10); }
+    { Ring r; r.set_depth(8); r.push(0, 1); r.push(0, 2); CHECK(r.size() == 1 && *r.peek(0) == 2); }   // mod.rs:398-403
+    { Ring r; r.set_depth(8); for (int f = 0; f < 5; ++f) r.push(f, f); r.confirm(3);      // mod.rs:409-422
+      CHECK(!r.peek(0) && !r.peek(1) && !r.peek(2) && r.peek(3) && r.peek(4)); }
+    { Ring r; r.set_depth(8); for (int f = 0; f < 3; ++f) r.push(f, f); r.confirm(100); CHECK(r.size() == 0); }   // mod.rs:426-435
+    { Ring r; r.confirm(5); CHECK(r.size() == 0); }                                         // mod.rs:439-442
+    { Ring r; r.set_depth(8); for (int f = 0; f < 5; ++f) r.push(f, f * 10);               // mod.rs:448-468
+      CHECK(r.rollback(2).get() == 20); CHECK(!r.peek(3) && !r.peek(4) && r.peek(1)); }
+    { Ring r; r.set_depth(8); r.push(0, 0); r.push(1, 1); bool threw = false;              // mod.rs:472-477
+      try { r.rollback(5); } catch (const std::runtime_error&) { threw = true; } CHECK(threw); }
+    { Ring r; r.set_depth(8); r.push(INT32_MAX - 1, 1); r.push(INT32_MAX, 2); r.push(INT32_MIN, 3);   // mod.rs:485-497
+      CHECK(r.size() == 3 && *r.peek(INT32_MIN) == 3 && *r.peek(INT32_MAX) == 2); }
+    { Ring r; r.set_depth(8); r.push(INT32_MIN, 1); r.push(INT32_MAX, 2);                  // mod.rs:502-512
+      CHECK(r.size() == 1 && !r.peek(INT32_MIN) && *r.peek(INT32_MAX) == 2); }
+    std::puts("ok host_ring_known_answers");
 }
 
 // examples/stress_tests/particles.rs:187-240 through the plugin API; prints every checksum
@@ -272,7 +408,14 @@ int main(int argc, char** argv) {
     mismatch_fires_on_non_determinism();
     confirmed_frame_pruning();
     component_rollback_copy();
+    immutable_component_copy_strategy_rolls_back();
     fixed_timestep_accumulator();
+    host_seahasher_known_answers();
+    host_ring_known_answers();
+    resource_inserted_mid_session_rolls_back();
+    resource_removed_mid_session_rolls_back();
+    resource_without_rollback_fires_mismatch();
+    resource_checksum_part_is_folded();
     particles(n, 24, 7, false);
     particles(n, 24, 7, true);
     return 0;
