@@ -29,6 +29,7 @@ SYS_TTL_DESPAWN = 2
 SYS_PARTICLES_SPAWN = 3
 SYS_ADD_U32 = 4
 SYS_SAT_SUB_DESPAWN = 5
+SYS_BOX_MOVE = 6
 
 COMP_ROLLBACK, COMP_NO_ROLLBACK = 0, 1
 DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK = 0, 1

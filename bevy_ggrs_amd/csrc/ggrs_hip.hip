@@ -10,6 +10,7 @@
 // There is NO CPU fallback: without a HIP device world creation fails with GGRS_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -692,6 +693,23 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                                        w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp,
                                        defer, w->frame, w->marks);
                 } break;
+                case GGRS_SYS_BOX_MOVE: {
+                    const Comp& T = w->comps[s.comp[0]]; const Comp& V = w->comps[s.comp[1]]; const Comp& P = w->comps[s.comp[2]];
+                    BoxMoveArgs a; memset(&a, 0, sizeof a);
+                    a.state = w->live.ptr; a.off_alive = w->off_alive;
+                    a.off_pT = w->off_present[s.comp[0]]; a.off_pV = w->off_present[s.comp[1]]; a.off_pP = w->off_present[s.comp[2]];
+                    for (int k = 0; k < 3; ++k) { a.off_t[k] = w->col_off[T.col_base + s.word[0] + k]; a.off_v[k] = w->col_off[V.col_base + s.word[1] + k]; }
+                    a.off_handle = w->col_off[P.col_base + s.word[2]];
+                    a.len = w->len; a.dt_bits = dt_bits;
+                    // FRICTION.powf(dt) (box_game.rs:189-195): Rust lowers f32::powf to the platform libm's powf
+                    float dtf; memcpy(&dtf, &dt_bits, 4);
+                    const float fp = powf(s.fparam[2], dtf);
+                    memcpy(&a.friction_pow_bits, &fp, 4);
+                    a.accel = s.fparam[0]; a.max_speed = s.fparam[1]; a.half_width = s.fparam[3];
+                    a.n_inputs = std::min<uint32_t>(n_inputs, 16);
+                    for (uint32_t k = 0; k < a.n_inputs; ++k) a.inputs[k] = inputs[k];
+                    hipLaunchKernelGGL(k_box_move, dim3((uint32_t)((w->len + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, a);
+                } break;
                 default: break;
                 }
             }
@@ -950,6 +968,7 @@ int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* d) {
     case GGRS_SYS_TTL_DESPAWN: ok = comp_ok(d->comp[0], 8, d->word[0], 1); break;
     case GGRS_SYS_PARTICLES_SPAWN: ok = comp_ok(d->comp[0], 4, 0, 3) && comp_ok(d->comp[1], 4, 0, 3) && comp_ok(d->comp[2], 8, 0, 1); break;
     case GGRS_SYS_ADD_U32: case GGRS_SYS_SAT_SUB_DESPAWN: ok = comp_ok(d->comp[0], 4, d->word[0], 1); break;
+    case GGRS_SYS_BOX_MOVE: ok = comp_ok(d->comp[0], 4, d->word[0], 3) && comp_ok(d->comp[1], 4, d->word[1], 3) && comp_ok(d->comp[2], 8, d->word[2], 1); break;
     default: ok = false;
     }
     if (!ok) return w->fail(GGRS_E_INVALID, "system %u does not match the registered components", d->kind);

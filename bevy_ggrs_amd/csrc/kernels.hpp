@@ -989,6 +989,73 @@ __global__ __launch_bounds__(TPB) void k_sat_sub_despawn(uint8_t* state, uint64_
     }
 }
 
+// ------------------------------------------------------------------ box_game (examples/box_game/box_game.rs)
+// move_cube_system (box_game.rs:154-206), one slot per lane.  Query<(&mut Transform, &mut Velocity, &Player),
+// With<Rollback>>: the entity needs all three components.  Every operation is a single correctly rounded IEEE
+// op in the reference's order (Rust never contracts; the build uses -ffp-contract=off and HIP's default
+// correctly rounded fp32 divide / sqrt); glam's Vec3::clamp_length_max is
+//   len_sq = x*x + y*y + z*z;  if len_sq > max*max { max * (v / sqrt(len_sq)) } else { v }
+// and f32::clamp is two compares.  friction_pow = FRICTION.powf(dt), computed by the host's libm.
+struct BoxMoveArgs {
+    uint8_t* state;
+    uint64_t off_alive, off_pT, off_pV, off_pP;
+    uint64_t off_t[3], off_v[3], off_handle;
+    uint64_t len;
+    uint32_t dt_bits, friction_pow_bits;
+    float accel, max_speed, half_width;
+    uint32_t n_inputs;
+    uint8_t inputs[16];
+};
+constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3;   // box_game.rs:13-16
+__global__ __launch_bounds__(TPB) void k_box_move(BoxMoveArgs a) {
+    const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= a.len) return;
+    const uint64_t wi8 = (e >> 6) * 8, b = e & 63;
+    const uint64_t m = *reinterpret_cast<const uint64_t*>(a.state + a.off_alive + wi8) &
+                       *reinterpret_cast<const uint64_t*>(a.state + a.off_pT + wi8) &
+                       *reinterpret_cast<const uint64_t*>(a.state + a.off_pV + wi8) &
+                       *reinterpret_cast<const uint64_t*>(a.state + a.off_pP + wi8);
+    if (!((m >> b) & 1ULL)) return;
+    const uint64_t handle = *reinterpret_cast<const uint64_t*>(a.state + a.off_handle + e * 8);
+    if (handle >= a.n_inputs) return;                  // inputs[p.handle] would panic in the reference
+    const uint8_t in = a.inputs[handle];
+    const float dt = __uint_as_float(a.dt_bits), fp = __uint_as_float(a.friction_pow_bits);
+    float* px = reinterpret_cast<float*>(a.state + a.off_t[0] + e * 4);
+    float* pz = reinterpret_cast<float*>(a.state + a.off_t[2] + e * 4);
+    float* py = reinterpret_cast<float*>(a.state + a.off_t[1] + e * 4);
+    float* pvx = reinterpret_cast<float*>(a.state + a.off_v[0] + e * 4);
+    float* pvy = reinterpret_cast<float*>(a.state + a.off_v[1] + e * 4);
+    float* pvz = reinterpret_cast<float*>(a.state + a.off_v[2] + e * 4);
+    float vx = *pvx, vy = *pvy, vz = *pvz;
+    const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT;
+    const float adt = __fmul_rn(a.accel, dt);
+    if (up && !down) vz = __fsub_rn(vz, adt);
+    if (!up && down) vz = __fadd_rn(vz, adt);
+    if (left && !right) vx = __fsub_rn(vx, adt);
+    if (!left && right) vx = __fadd_rn(vx, adt);
+    if (!up && !down) vz = __fmul_rn(vz, fp);
+    if (!left && !right) vx = __fmul_rn(vx, fp);
+    vy = __fmul_rn(vy, fp);
+    const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
+    if (len_sq > __fmul_rn(a.max_speed, a.max_speed)) {
+        // NOT __fsqrt_rn: clang's HIP header maps it to __ocml_native_sqrt_f32 (approximate) unless
+        // OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf is the correctly rounded one (Makefile pins
+        // -fhip-fp32-correctly-rounded-divide-sqrt, the default)
+        const float l = sqrtf(len_sq);
+        vx = __fmul_rn(a.max_speed, vx / l);
+        vy = __fmul_rn(a.max_speed, vy / l);
+        vz = __fmul_rn(a.max_speed, vz / l);
+    }
+    float x = __fadd_rn(*px, __fmul_rn(vx, dt)), y = __fadd_rn(*py, __fmul_rn(vy, dt)), z = __fadd_rn(*pz, __fmul_rn(vz, dt));
+    const float lo = -a.half_width, hi = a.half_width;
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    if (z < lo) z = lo;
+    if (z > hi) z = hi;
+    *pvx = vx; *pvy = vy; *pvz = vz;
+    *px = x; *py = y; *pz = z;
+}
+
 // ------------------------------------------------------------------ RollbackDespawned (snapshot/despawn.rs)
 // Host-issued commands.entity(e).despawn_rollback() on an unconfirmed frame.
 __global__ void k_mark_despawned(uint8_t* state, uint64_t off_alive, DespawnMarks dm, uint64_t slot, int32_t frame) {

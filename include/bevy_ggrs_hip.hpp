@@ -348,6 +348,15 @@ template <class T> KernelSystem add_u32(uint32_t delta, uint32_t word = 0) {
 template <class T> KernelSystem saturating_sub_despawn(uint32_t amount, uint32_t word = 0) {
     KernelSystem s; s.kind = GGRS_SYS_SAT_SUB_DESPAWN; s.comps = {HipComponent<T>::name}; s.word[0] = word; s.iparam[0] = amount; return s;
 }
+// examples/box_game/box_game.rs:154-206 (constants :18-22): PlayerT is the plain `Player { handle: usize }`
+// component (one 8-byte word), not registered for rollback in the example
+template <class TransformT, class VelocityT, class PlayerT>
+KernelSystem move_cube_system(float acceleration = 18.0f, float max_speed = 3.0f, float friction = 0.0018f, float plane_size = 5.0f, float cube_size = 0.2f) {
+    KernelSystem s; s.kind = GGRS_SYS_BOX_MOVE;
+    s.comps = {HipComponent<TransformT>::name, HipComponent<VelocityT>::name, HipComponent<PlayerT>::name};
+    s.fparam[0] = acceleration; s.fparam[1] = max_speed; s.fparam[2] = friction; s.fparam[3] = (plane_size - cube_size) * 0.5f;
+    return s;
+}
 }  // namespace systems
 
 // ---------------------------------------------------------------- backend == the C ABI
@@ -361,6 +370,7 @@ struct HipBackend {
     HipBackend(const HipBackend&) = delete;
     const char* last_error() { return ggrs_hip_last_error(w); }
     int register_component(const char* n, uint32_t wb, uint32_t nw, uint32_t* id) { return ggrs_hip_register_component(w, n, wb, nw, id); }
+    int register_component_ex(const char* n, uint32_t wb, uint32_t nw, uint32_t flags, uint32_t* id) { return ggrs_hip_register_component_ex(w, n, wb, nw, flags, id); }
     int set_component_default(uint32_t c, const void* p) { return ggrs_hip_set_component_default(w, c, p); }
     int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return ggrs_hip_checksum_component(w, c, idx, n); }
     int add_system(const ggrs_system_desc* d) { return ggrs_hip_add_system(w, d); }
@@ -476,6 +486,15 @@ class App {
     }
 
     // ---- RollbackApp (src/snapshot/rollback_app.rs:31-133)
+    // a component that kernel systems read but that is NOT registered for rollback (box_game's `Player`,
+    // a mesh handle): device-resident, outside every snapshot, kept across LoadWorld like any non-rollback
+    // component of a surviving entity
+    template <class T> App& plain_component() {
+        uint32_t id = 0;
+        check(be_.register_component_ex(HipComponent<T>::name, HipComponent<T>::word_bytes, HipComponent<T>::n_words, GGRS_COMP_NO_ROLLBACK, &id));
+        comp_ids_[HipComponent<T>::name] = id;
+        return *this;
+    }
     template <class T> App& rollback_component_with_copy() { return register_component<T>(); }
     template <class T> App& rollback_component_with_clone() { return register_component<T>(); }   // bitwise for POD (strategy.rs:62-83)
     // rollback_immutable_component_with_* (rollback_app.rs:40-44,58-62; ImmutableComponentSnapshotPlugin::load,

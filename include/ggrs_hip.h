@@ -120,6 +120,13 @@ int ggrs_hip_checksum_component(ggrs_world* w, uint32_t comp_id, const uint32_t*
 #define GGRS_SYS_ADD_U32          4u /* benches/bench.rs:30-46 comp[0],word[0] += iparam[0]        */
 #define GGRS_SYS_SAT_SUB_DESPAWN  5u /* tests/synctest.rs:37-44 saturating_sub(iparam[0]), ==0 despawn;
                                         iparam[1] = GGRS_DESPAWN_*: how the entity is despawned      */
+#define GGRS_SYS_BOX_MOVE          6u /* examples/box_game/box_game.rs:154-206 move_cube_system
+                                        comp[0]=Transform word[0]=translation.x  comp[1]=Velocity word[1]=velocity.x
+                                        comp[2]=Player(handle: usize = one 8-byte word) word[2]
+                                        fparam = {ACCELERATION, MAX_SPEED, FRICTION, half_width}.
+                                        FRICTION.powf(dt) is evaluated once per frame on the HOST with the
+                                        platform libm (what a Linux build of the reference calls) and handed to
+                                        the kernel as bits; everything else is IEEE single ops, unfused         */
 #define GGRS_DESPAWN_IMMEDIATE 0   /* commands.entity(e).despawn()                                    */
 #define GGRS_DESPAWN_ROLLBACK  1   /* commands.entity(e).despawn_rollback()  (snapshot/despawn.rs:114-143) */
 

@@ -30,6 +30,7 @@
 // Build: g++ -O3 -march=native -fno-fast-math -ffp-contract=off -shared -fPIC
 //        (f32 results must be bit-identical to Rust semantics: no FMA contraction).
 
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -187,6 +188,7 @@ enum SystemKind : uint32_t {
     SYS_PARTICLES_SPAWN = 3,    // particles.rs:254-270
     SYS_ADD_U32 = 4,            // benches/bench.rs:30-46, tests/component_rollback.rs:24-28
     SYS_SAT_SUB_DESPAWN = 5,    // tests/synctest.rs:37-44
+    SYS_BOX_MOVE = 6,           // examples/box_game/box_game.rs:154-206
 };
 
 struct SystemDesc {            // must match include/ggrs_hip.h ggrs_system_desc
@@ -502,6 +504,38 @@ static inline void particles_update_one(float dt, const float g[3], GetW get, Se
     }
 }
 
+
+// move_cube_system, examples/box_game/box_game.rs:154-206.  fparam = {ACCELERATION, MAX_SPEED, FRICTION,
+// half_width}; INPUT_* bits box_game.rs:13-16.  Written in the reference's statement order; the build has
+// -ffp-contract=off so `a*b+c` is never fused (Rust semantics).  FRICTION.powf(dt) -> libm powf (what
+// f32::powf lowers to).  Vec3::clamp_length_max (glam, un-vendored): length_squared = x*x + y*y + z*z;
+// `if length_sq > max*max { max * (self / sqrt(length_sq)) }`.  f32::clamp: `if x < min {min}; if x > max {max}`.
+template <class GetW, class SetW>
+static inline void box_move_one(float dt, const float p[4], uint8_t input, GetW get, SetW set) {
+    const float ACCELERATION = p[0], MAX_SPEED = p[1], FRICTION = p[2], half_width = p[3];
+    float vx = get(1, 0), vy = get(1, 1), vz = get(1, 2);
+    const bool up = input & 1, down = input & 2, left = input & 4, right = input & 8;
+    if (up && !down) vz -= ACCELERATION * dt;
+    if (!up && down) vz += ACCELERATION * dt;
+    if (left && !right) vx -= ACCELERATION * dt;
+    if (!left && right) vx += ACCELERATION * dt;
+    if (!up && !down) vz *= powf(FRICTION, dt);
+    if (!left && !right) vx *= powf(FRICTION, dt);
+    vy *= powf(FRICTION, dt);
+    const float length_sq = (vx * vx + vy * vy) + vz * vz;
+    if (length_sq > MAX_SPEED * MAX_SPEED) {
+        const float l = sqrtf(length_sq);
+        vx = MAX_SPEED * (vx / l); vy = MAX_SPEED * (vy / l); vz = MAX_SPEED * (vz / l);
+    }
+    float x = get(0, 0) + vx * dt, y = get(0, 1) + vy * dt, z = get(0, 2) + vz * dt;
+    if (x < -half_width) x = -half_width;
+    if (x > half_width) x = half_width;
+    if (z < -half_width) z = -half_width;
+    if (z > half_width) z = half_width;
+    set(1, 0, vx); set(1, 1, vy); set(1, 2, vz);
+    set(0, 0, x); set(0, 1, y); set(0, 2, z);
+}
+
 static int world_spawn(World& w, uint64_t count, uint64_t comp_mask, const void* const* cols_in, uint64_t* first_out);
 
 static void advance_flat(World& w, const AdvanceArgs& a) {
@@ -561,6 +595,24 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
                 if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
                 p[i] = p[i] >= d ? p[i] - d : 0;    // saturating_sub
                 if (p[i] == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
+            }
+        } break;
+        case SYS_BOX_MOVE: {
+            uint32_t ct = s.comp[0], cv = s.comp[1], cp = s.comp[2];
+            float dt = f32_of(a.dt_bits);
+            float* tx[3]; float* vv[3];
+            for (int k = 0; k < 3; ++k) {
+                tx[k] = (float*)w.cols[w.col_base[ct] + s.word[0] + k].data();
+                vv[k] = (float*)w.cols[w.col_base[cv] + s.word[1] + k].data();
+            }
+            const uint64_t* handle = (const uint64_t*)w.cols[w.col_base[cp] + s.word[2]].data();
+            for (int64_t ii = 0; ii < L; ++ii) {
+                uint64_t i = (uint64_t)ii;
+                if (!bit(w.alive, i) || !bit(w.present[ct], i) || !bit(w.present[cv], i) || !bit(w.present[cp], i)) continue;
+                if (handle[i] >= a.n_inputs) continue;          // inputs[p.handle] out of range: the reference panics
+                box_move_one(dt, s.fparam, a.inputs[handle[i]],
+                    [&](int which, int k) { return which ? vv[k][i] : tx[k][i]; },
+                    [&](int which, int k, float v) { (which ? vv[k][i] : tx[k][i]) = v; });
             }
         } break;
         default: break;
@@ -630,6 +682,21 @@ static void advance_ref(World& w, const AdvanceArgs& a) {
                 uint32_t* p = (uint32_t*)&w.aos[c][i * st] + s.word[0];
                 *p = *p >= d ? *p - d : 0;
                 if (*p == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
+            }
+        } break;
+        case SYS_BOX_MOVE: {
+            uint32_t ct = s.comp[0], cv = s.comp[1], cp = s.comp[2];
+            float dt = f32_of(a.dt_bits);
+            uint32_t st_t = w.stride(ct), st_v = w.stride(cv), st_p = w.stride(cp);
+            for (uint64_t i = 0; i < w.len; ++i) {
+                if (!bit(w.alive, i) || !bit(w.present[ct], i) || !bit(w.present[cv], i) || !bit(w.present[cp], i)) continue;
+                float* t = (float*)&w.aos[ct][i * st_t] + s.word[0];
+                float* v = (float*)&w.aos[cv][i * st_v] + s.word[1];
+                const uint64_t handle = *((const uint64_t*)&w.aos[cp][i * st_p] + s.word[2]);
+                if (handle >= a.n_inputs) continue;
+                box_move_one(dt, s.fparam, a.inputs[handle],
+                    [&](int which, int k) { return which ? v[k] : t[k]; },
+                    [&](int which, int k, float x) { (which ? v[k] : t[k]) = x; });
             }
         } break;
         default: break;

@@ -162,3 +162,42 @@ def np_particles_update(tx, ty, tz, vx, vy, vz, dt_bits_: int, g=(0.0, -200.0, 0
     for t, v, gk in ((tx, vx, g[0]), (ty, vy, g[1]), (tz, vz, g[2])):
         v += np.float32(gk) * dt
         t += v * dt
+
+
+# ----------------------------------------------------------------------------- box_game
+def box_move(t, v, inp, dt_bits: int, accel=18.0, max_speed=3.0, friction=0.0018, half_width=None):
+    """move_cube_system (examples/box_game/box_game.rs:154-206), vectorised over entities.
+    t, v: float32 arrays (n, 3) (translation / Velocity), inp: uint8 array (n,) -- the input byte of the
+    entity's player.  Returns new (t, v).  Every numpy float32 op is one IEEE operation (no fusing);
+    FRICTION.powf(dt) goes through numpy's float32 power (libm powf)."""
+    f = np.float32
+    dt = np.array([dt_bits], dtype=np.uint32).view(np.float32)[0]
+    if half_width is None:
+        half_width = (f(5.0) - f(0.2)) * f(0.5)                      # (PLANE_SIZE - CUBE_SIZE) * 0.5
+    accel, max_speed, friction, half_width = f(accel), f(max_speed), f(friction), f(half_width)
+    t = np.array(t, dtype=np.float32, copy=True)
+    v = np.array(v, dtype=np.float32, copy=True)
+    up, down, left, right = [(inp & b) != 0 for b in (1, 2, 4, 8)]
+    adt = accel * dt
+    fp = np.power(friction, dt, dtype=np.float32)
+    vx, vy, vz = v[:, 0], v[:, 1], v[:, 2]
+    vz = np.where(up & ~down, vz - adt, vz)
+    vz = np.where(~up & down, vz + adt, vz)
+    vx = np.where(left & ~right, vx - adt, vx)
+    vx = np.where(~left & right, vx + adt, vx)
+    vz = np.where(~up & ~down, vz * fp, vz)
+    vx = np.where(~left & ~right, vx * fp, vx)
+    vy = vy * fp
+    len_sq = (vx * vx + vy * vy) + vz * vz
+    over = len_sq > max_speed * max_speed
+    with np.errstate(divide="ignore", invalid="ignore"):
+        l = np.sqrt(len_sq)
+        vx = np.where(over, max_speed * (vx / l), vx)
+        vy = np.where(over, max_speed * (vy / l), vy)
+        vz = np.where(over, max_speed * (vz / l), vz)
+    x = t[:, 0] + vx * dt
+    y = t[:, 1] + vy * dt
+    z = t[:, 2] + vz * dt
+    x = np.where(x < -half_width, -half_width, x); x = np.where(x > half_width, half_width, x)
+    z = np.where(z < -half_width, -half_width, z); z = np.where(z > half_width, half_width, z)
+    return (np.stack([x, y, z], axis=1).astype(np.float32), np.stack([vx, vy, vz], axis=1).astype(np.float32))

@@ -6,6 +6,7 @@
 // builds can be compared bit for bit.
 #include <atomic>
 #include <cassert>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -19,6 +20,7 @@ void* gor_world_create(uint64_t, uint32_t, int);
 void gor_world_destroy(void*);
 const char* gor_last_error(void*);
 int gor_register_component(void*, const char*, uint32_t, uint32_t, uint32_t*);
+int gor_register_component_ex(void*, const char*, uint32_t, uint32_t, uint32_t, uint32_t*);
 int gor_set_component_default(void*, uint32_t, const void*);
 int gor_checksum_component(void*, uint32_t, const uint32_t*, uint32_t);
 int gor_add_system(void*, const ggrs_system_desc*);
@@ -42,6 +44,7 @@ struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to 
     ~OracleBackend() { gor_world_destroy(w); }
     const char* last_error() { return gor_last_error(w); }
     int register_component(const char* n, uint32_t wb, uint32_t nw, uint32_t* id) { return gor_register_component(w, n, wb, nw, id); }
+    int register_component_ex(const char* n, uint32_t wb, uint32_t nw, uint32_t flags, uint32_t* id) { return gor_register_component_ex(w, n, wb, nw, flags, id); }
     int set_component_default(uint32_t c, const void* p) { return gor_set_component_default(w, c, p); }
     int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return gor_checksum_component(w, c, idx, n); }
     int add_system(const ggrs_system_desc* d) { return gor_add_system(w, d); }
@@ -114,6 +117,8 @@ template <> struct HipComponent<Health> { static constexpr const char* name = "H
 template <> struct HipComponent<Counter> { static constexpr const char* name = "Counter"; static constexpr uint32_t word_bytes = 4, n_words = 1; };
 template <> struct HipComponent<Transform> { static constexpr const char* name = "Transform"; static constexpr uint32_t word_bytes = 4, n_words = 10; };
 template <> struct HipComponent<Velocity> { static constexpr const char* name = "Velocity"; static constexpr uint32_t word_bytes = 4, n_words = 3; };
+struct Player {};
+template <> struct HipComponent<Player> { static constexpr const char* name = "Player"; static constexpr uint32_t word_bytes = 8, n_words = 1; };
 template <> struct HipComponent<Ttl> { static constexpr const char* name = "Ttl"; static constexpr uint32_t word_bytes = 8, n_words = 1; };
 }
 
@@ -355,6 +360,56 @@ static void host_ring_known_answers() {
     std::puts("ok host_ring_known_answers");
 }
 
+// examples/box_game/box_game_synctest.rs (`--num-players 2 --check-distance 7`, examples/README.md:64) with
+// box_game.rs's setup_system / move_cube_system / increase_frame_system; prints every checksum and the cubes
+struct FrameCount { uint32_t frame = 0; };                                           // box_game.rs:48-53
+static void ggrs_hash(const FrameCount& f, SeaHasher& h) { h.write_u32(f.frame); }
+static void box_game_synctest(size_t num_players, size_t check_distance, int updates) {
+    TestApp app(16);
+    auto sess = SessionBuilder<Config>().with_num_players(num_players).with_check_distance(check_distance).with_input_delay(2);
+    for (size_t i = 0; i < num_players; ++i) sess.add_player(PlayerType::Local, i);
+    app.add_plugins(GgrsPlugin<Config>{});
+    app.insert_resource(RollbackFrameRate{60});
+    int tick = 0;
+    app.add_systems(ReadInputs{}, [&](const LocalPlayers& p, LocalInputs<Config>& in) {   // read_local_inputs with a scripted keyboard
+        for (auto h : p.handles) in[h] = (uint8_t)((tick * 7 + (int)h * 3) % 16);
+    });
+    app.rollback_resource_with_copy<FrameCount>();
+    app.rollback_component_with_copy<Velocity>().rollback_component_with_clone<Transform>().plain_component<Player>();
+    app.checksum_resource_with_hash<FrameCount>();
+    app.add_systems(GgrsSchedule{}, systems::move_cube_system<Transform, Velocity, Player>());
+    app.add_systems(GgrsSchedule{}, TestApp::HostSystem([](TestApp& a, const PlayerInputs<Config>&) { a.resource<FrameCount>().frame += 1; }));
+    app.insert_resource(sess.start_synctest_session());
+    app.insert_resource(FrameCount{0});
+    app.add_observer([](const SyncTestMismatch& m) { std::fprintf(stderr, "desync detected at frame %d!\n", m.current_frame); std::exit(1); });
+    // setup_system (box_game.rs:89-131)
+    std::vector<float> col[10]; std::vector<float> vel[3]; std::vector<uint64_t> handle;
+    const float r = 5.0f / 4.0f;
+    for (size_t h = 0; h < num_players; ++h) {
+        const float rot = (float)h / (float)num_players * 2.0f * 3.14159265358979323846f;
+        const float t[10] = {r * std::cos(rot), 0.2f / 2.0f, r * std::sin(rot), 0, 0, 0, 1, 1, 1, 1};
+        for (int k = 0; k < 10; ++k) col[k].push_back(t[k]);
+        for (int k = 0; k < 3; ++k) vel[k].push_back(0.0f);
+        handle.push_back(h);
+    }
+    std::vector<const void*> cols;                                               // ascending component id: Velocity, Transform, Player
+    for (int k = 0; k < 3; ++k) cols.push_back(vel[k].data());
+    for (int k = 0; k < 10; ++k) cols.push_back(col[k].data());
+    cols.push_back(handle.data());
+    app.spawn(num_players, {"Transform", "Velocity", "Player"}, cols);
+    for (tick = 0; tick < updates; ++tick) {
+        app.update();
+        for (auto& c : app.last_checksums()) std::printf("box checksum %d %016llx%016llx\n", tick, (unsigned long long)c.hi, (unsigned long long)c.lo);
+    }
+    CHECK(app.resource<FrameCount>().frame == (uint32_t)app.rollback_frame_count());   // the resource rolled back and counted up again
+    { auto y = app.download<Transform, uint32_t>(1); float f; std::memcpy(&f, &y[0], 4); CHECK(f == 0.1f); }   // CUBE_SIZE / 2: nothing moves y
+    for (uint32_t k = 0; k < 3; ++k) {
+        auto x = app.download<Transform, uint32_t>(k); auto v = app.download<Velocity, uint32_t>(k);
+        for (size_t h = 0; h < num_players; ++h) std::printf("box cube %zu word %u t %08x v %08x\n", h, k, x[h], v[h]);
+    }
+    std::puts("ok box_game_synctest");
+}
+
 // examples/stress_tests/particles.rs:187-240 through the plugin API; prints every checksum
 static void particles(uint64_t n, int ticks, size_t cd, bool pipelined) {
     TestApp app(n + 100 * (uint64_t)ticks + 64);
@@ -416,6 +471,7 @@ int main(int argc, char** argv) {
     resource_removed_mid_session_rolls_back();
     resource_without_rollback_fires_mismatch();
     resource_checksum_part_is_folded();
+    box_game_synctest(2, 7, 40);
     particles(n, 24, 7, false);
     particles(n, 24, 7, true);
     return 0;

@@ -42,7 +42,7 @@ def _run(exe, n):
 EXPECTED = ["synctest_request_shape", "despawn_and_rollback_does_not_panic", "mismatch_fires_on_non_determinism",
             "confirmed_frame_pruning", "component_rollback_copy", "immutable_component_copy_strategy_rolls_back", "fixed_timestep_accumulator", "host_seahasher_known_answers",
             "host_ring_known_answers", "resource_inserted_mid_session_rolls_back", "resource_removed_mid_session_rolls_back",
-            "resource_without_rollback_fires_mismatch", "resource_checksum_part_is_folded", "particles",
+            "resource_without_rollback_fires_mismatch", "resource_checksum_part_is_folded", "box_game_synctest", "particles",
             "particles_pipelined"]
 
 
@@ -50,7 +50,8 @@ def test_cpp_host_on_oracle_backend():
     out = _run(_build("oracle"), 3000)
     for name in EXPECTED:
         assert f"ok {name}" in out
-    assert out.count("checksum ") == 2 * (8 + 16 * 7)      # cd = 7: frames 0..7 save once, then 7 saves per tick; sync + pipelined runs
+    assert out.count("\nchecksum ") == 2 * (8 + 16 * 7)      # cd = 7: frames 0..7 save once, then 7 saves per tick; sync + pipelined runs
+    assert out.count("box checksum ") == 8 + 32 * 7       # box_game: cd = 7, 40 updates
     lines = [l for l in out.splitlines() if l.startswith(("checksum", "final"))]
     assert lines[:len(lines) // 2] == lines[len(lines) // 2:], "pipelined run must reproduce the synchronous run"
 
