@@ -377,6 +377,7 @@ struct HipBackend {
     int set_frame_rate(uint64_t fps) { return ggrs_hip_set_frame_rate(w, fps); }
     int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return ggrs_hip_spawn(w, count, mask, cols, first); }
     int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
+    int set_confirmed(int has, int32_t f) { return ggrs_hip_set_confirmed(w, has, f); }
     int set_synctest_check_distance(int32_t cd) { return ggrs_hip_set_synctest_check_distance(w, cd); }
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) { return ggrs_hip_handle_requests(w, r, n, out); }
     int enqueue_requests(const ggrs_request* r, uint32_t n) { return ggrs_hip_enqueue_requests(w, r, n, nullptr); }
@@ -552,6 +553,14 @@ class App {
         }
     }
 
+    // ---- world.remove_resource::<Session<C>>(): the next update() takes the no-session branch
+    // (schedule_systems.rs:70-78)
+    App& remove_session() { flush(); session_ = std::monostate{}; return *this; }
+    // ---- Time<GgrsTime> (src/time.rs:63-87): fully derived from RollbackFrameCount and RollbackFrameRate,
+    // elapsed = Duration::from_nanos(frame * 1e9 / fps); a kernel system's dt for frame f is
+    // as_secs_f32(elapsed(f) - elapsed(f-1)) and is computed inside libggrs_hip.so (ggrs_request.dt_bits == 0)
+    std::chrono::nanoseconds ggrs_time_elapsed() { return std::chrono::nanoseconds((uint64_t)rollback_frame_count() * 1000000000ULL / fps_); }
+
     // ---- observers / resources
     App& add_observer(std::function<void(const SyncTestMismatch&)> f) { on_mismatch_ = std::move(f); return *this; }
     Frame rollback_frame_count() { return in_requests_ ? req_frame_ : be_.frame(); }                                        // RollbackFrameCount, mod.rs:70
@@ -579,6 +588,8 @@ class App {
             else {   // no session yet: reset time data and counters (schedule_systems.rs:70-78)
                 accumulator_ = 0; run_slow_ = false; confirmed_ = -1; max_prediction_window_ = 8;
                 check(be_.set_frame(0));
+                check(be_.set_confirmed(1, -1));           // world.insert_resource(ConfirmedFrameCount(-1))
+                check(be_.set_depth(8));                   // world.insert_resource(MaxPredictionWindow(8))
             }
         }
     }

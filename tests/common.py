@@ -133,3 +133,51 @@ def frame_spawn_fn(rate=100, seed=99):
         r = np.random.default_rng([seed, frame])
         return (r.uniform(-200, 200, rate).astype(np.float32), r.uniform(-200, 200, rate).astype(np.float32))
     return fn
+
+
+class P2PShapeDriver:
+    """Synthetic stand-in for ggrs's P2PSession::advance_frame on BASELINE config 4 (no sockets): every tick a
+    late remote input invalidates the last `r` predicted frames (r drawn per tick, 0..max_rollback; 120 ms RTT at
+    60 fps ~ 7-8 frames), so the request list is  [Load(F-r), Adv, (Save, Adv) x (r-1)]  +  [Save(F), Adv]
+    (non-sparse saving; shape restated from ggrs) and ConfirmedFrameCount trails by max_rollback
+    (schedule_systems.rs:202 `s.confirmed_frame()`).  inputs(frame) must be a pure function of the frame."""
+
+    def __init__(self, world, max_rollback=8, seed=4, inputs=lambda frame: (0,), spawn_fn=None):
+        self.world, self.max_rollback = world, max_rollback
+        self.rng = np.random.default_rng(seed)
+        self.inputs, self.spawn_fn = inputs, spawn_fn
+        self.frame = world.frame
+        self.lib_rule = hasattr(world, "_lib") and world._prefix == "ggrs_hip_"
+        world.set_depth(max_rollback)
+        if self.lib_rule:
+            world.set_synctest_check_distance(-1)
+        self.all_checksums = []
+        self.depths = []
+
+    def _adv(self, frame):
+        a = bg.AdvanceFrame(tuple(self.inputs(frame)))
+        if self.spawn_fn is not None and any(i & INPUT_SPAWN for i in a.inputs):
+            a.spawn_vx, a.spawn_vy = self.spawn_fn(frame)
+        return a
+
+    def tick(self):
+        F = self.frame
+        r = int(self.rng.integers(0, self.max_rollback + 1))
+        r = min(r, F, self.max_rollback - 1 if self.max_rollback > 1 else 0)   # only frames still in the ring
+        reqs = []
+        if r > 0:
+            reqs.append(bg.LoadGameState(F - r))
+            for i in range(r):
+                if i > 0:
+                    reqs.append(bg.SaveGameState(F - r + i))
+                reqs.append(self._adv(F - r + i))
+        reqs += [bg.SaveGameState(F), self._adv(F)]
+        c = F - self.max_rollback
+        if c >= 0:
+            self.world.set_confirmed(c)
+        cs = self.world.handle_requests(reqs)
+        saves = [q for q in reqs if isinstance(q, bg.SaveGameState)]
+        self.all_checksums += [(s.frame, x) for s, x in zip(saves, cs)]
+        self.depths.append(r)
+        self.frame = F + 1
+        return cs

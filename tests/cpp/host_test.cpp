@@ -51,6 +51,7 @@ struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to 
     int set_frame_rate(uint64_t fps) { gor_set_frame_rate(w, fps); return 0; }
     int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return gor_spawn(w, count, mask, cols, first); }
     int set_depth(uint32_t d) { gor_set_depth(w, d); return 0; }
+    int set_confirmed(int has, int32_t f) { gor_set_confirmed(w, has, f); return 0; }
     int set_synctest_check_distance(int32_t c) { cd = c; return 0; }
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) {
         uint32_t ns = 0;
@@ -218,6 +219,35 @@ static void immutable_component_copy_strategy_rolls_back() {
     auto v = app.download<Counter, uint32_t>(0);
     CHECK(v.size() == 1 && (Frame)v[0] == app.rollback_frame_count());
     std::puts("ok immutable_component_copy_strategy_rolls_back");
+}
+
+// tests/time.rs:18-49: a session is stopped after 30 frames and a new one started at frame 0
+static void ggrs_time_survives_session_restart() {
+    TestApp app(16);
+    base_synctest_app(app, 2);
+    app.rollback_component_with_copy<Counter>().checksum_component_with_hash<Counter>();
+    app.add_systems(GgrsSchedule{}, systems::add_u32<Counter>(1));
+    app.add_observer([](const SyncTestMismatch&) { CHECK(!"SyncTestMismatch after a session restart"); });
+    app.spawn(1, {"Counter"});
+    for (int i = 0; i < 30; ++i) app.update();
+    CHECK(app.ggrs_time_elapsed().count() > 0 && app.rollback_frame_count() == 30);
+    app.remove_session();
+    app.update();                                           // no-session branch: RollbackFrameCount back to 0
+    CHECK(app.rollback_frame_count() == 0);
+    app.insert_resource(synctest_session(2));
+    app.update();
+    const Frame frame = app.rollback_frame_count();
+    CHECK(frame == 1);
+    CHECK((uint64_t)app.ggrs_time_elapsed().count() == (uint64_t)frame * 1000000000ULL / 60);
+    app.update();
+    // the no-session branch re-inserted ConfirmedFrameCount(-1) (schedule_systems.rs:75): the stale confirmed
+    // frame of the first session must not prune the new session's first snapshots
+    CHECK(app.backend().has_snapshot(0) && app.backend().has_snapshot(1));
+    for (int i = 0; i < 9; ++i) app.update();              // the stale ring of the first session must not confuse the new one
+    CHECK(app.rollback_frame_count() == 11);
+    auto v = app.download<Counter, uint32_t>(0);
+    CHECK(v[0] == 30 + 11);                                 // the world itself is not reset by a session restart
+    std::puts("ok ggrs_time_survives_session_restart");
 }
 
 // run_ggrs_schedules accumulator (src/schedule_systems.rs:19-83) + tests/time.rs:18-49
@@ -465,6 +495,7 @@ int main(int argc, char** argv) {
     component_rollback_copy();
     immutable_component_copy_strategy_rolls_back();
     fixed_timestep_accumulator();
+    ggrs_time_survives_session_restart();
     host_seahasher_known_answers();
     host_ring_known_answers();
     resource_inserted_mid_session_rolls_back();

@@ -40,7 +40,7 @@ def _run(exe, n):
 
 
 EXPECTED = ["synctest_request_shape", "despawn_and_rollback_does_not_panic", "mismatch_fires_on_non_determinism",
-            "confirmed_frame_pruning", "component_rollback_copy", "immutable_component_copy_strategy_rolls_back", "fixed_timestep_accumulator", "host_seahasher_known_answers",
+            "confirmed_frame_pruning", "component_rollback_copy", "immutable_component_copy_strategy_rolls_back", "fixed_timestep_accumulator", "ggrs_time_survives_session_restart", "host_seahasher_known_answers",
             "host_ring_known_answers", "resource_inserted_mid_session_rolls_back", "resource_removed_mid_session_rolls_back",
             "resource_without_rollback_fires_mismatch", "resource_checksum_part_is_folded", "box_game_synctest", "particles",
             "particles_pipelined"]

@@ -112,20 +112,23 @@ def _run(world_size, **kw):
     return res
 
 
-def _serial_reference(n, D, n_branches, steps):
+def _serial_reference(n, D, n_branches, steps, branch_input=None, confirmed_input=None, ttl_init=25, rate=50, warm=3):
     """The same fan-out computed by ONE process walking every branch (no collectives)."""
+    import common as cm
+    branch_input = branch_input or (lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0)
+    confirmed_input = confirmed_input or (lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0)
     import common as cm
     from oracle.binding import OracleWorld
     import bevy_ggrs_amd as bg
-    cap = n + 100 * (steps + D + 2) * 2
+    cap = n + 2 * rate * (steps + D + 2) * 2
     w = OracleWorld(cap, D + 1)
-    ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
+    ids = cm.build_particles(w, with_spawn=True, ttl_init=ttl_init)
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     cm.spawn_particles(w, ids, n, vel, ttl)
-    for _ in range(3):
+    for _ in range(warm):
         w.advance((0,))
     w.set_depth(D + 1)
-    fn = cm.frame_spawn_fn(50)
+    fn = cm.frame_spawn_fn(rate)
 
     def adv(frame, inp):
         a = bg.AdvanceFrame((inp,))
@@ -141,9 +144,9 @@ def _serial_reference(n, D, n_branches, steps):
         for b in range(n_branches):
             reqs = [bg.LoadGameState(C)]
             for i in range(D):
-                reqs += [adv(C + i, cm.INPUT_SPAWN if b % 2 == 0 else 0), bg.SaveGameState(C + i + 1)]
+                reqs += [adv(C + i, branch_input(b, C + i)), bg.SaveGameState(C + i + 1)]
             per_branch[b] = w.handle_requests(reqs)
-        cs = w.handle_requests([bg.LoadGameState(C), adv(C, cm.INPUT_SPAWN if C % 2 == 1 else 0), bg.SaveGameState(C + 1)])
+        cs = w.handle_requests([bg.LoadGameState(C), adv(C, confirmed_input(C)), bg.SaveGameState(C + 1)])
         C += 1
         w.set_confirmed(C)
         out.append({"confirmed_frame": C, "confirmed_checksum": cs[0], "branch_checksums": per_branch})

@@ -211,3 +211,17 @@ def test_async_enqueue_collect_matches_sync():
         out.append((cs, cm.snapshot_state(w, ids)))
     assert out[0][0] == out[1][0]
     cm.assert_states_equal(out[0][1], out[1][1], "async")
+
+
+@pytest.mark.parametrize("n,ticks,flags", [(100_000, 40, 0), (100_000, 16, bg.GGRS_WORLD_NO_GROUPS), (3000, 80, 0)])
+def test_p2p_shaped_rollbacks_100k(n, ticks, flags):
+    """BASELINE config 4: 2-player p2p session shape, 100k entities, rollbacks of 0..7 frames per tick (120 ms RTT),
+    confirmed frame trailing by 8; spawns and Ttl despawns inside the rolled-back window."""
+    from test_oracle_selfcheck import _p2p_run
+    g, o = _pair(n + 40 * (ticks + 10) + 64, 8, flags)
+    a, sa = _p2p_run(g, n, ticks)
+    b, sb = _p2p_run(o, n, ticks)
+    assert a.depths == b.depths and len(a.all_checksums) == len(b.all_checksums) > ticks
+    for (fa, ca), (fb, cb) in zip(a.all_checksums, b.all_checksums):
+        assert fa == fb and ca == cb, f"frame {fa}: gpu {ca:#x} oracle {cb:#x}"
+    cm.assert_states_equal(sa, sb, "p2p shape")

@@ -58,5 +58,26 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
         assert w2.len == w.len and w2.frame == w.frame
         cm.assert_states_equal(cm.snapshot_state(w2, ids2), cm.snapshot_state(w, ids), "adopted")
         assert w2.save() == w.save()
+
+        # ---- BASELINE config 5 on the one GPU of this box: 256 predicted-input branches (branch id = the input
+        # byte repeated every frame), 100k entities, 8 frames each, all on rank 0; inputs with
+        # INPUT_SPAWN set spawn 100 particles per frame so the branches really diverge
+        from bevy_ggrs_amd.fanout import default_branch_input
+        n, D, steps, bpr, rate = 100_000, 8, 2, 256, 100
+        cap = n + 2 * rate * (steps + D + 2) * 2
+        w5, arena5 = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0))
+        ids5 = cm.build_particles(w5, with_spawn=True, ttl_init=300)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w5, ids5, n, vel, ttl)
+        fan5 = SpeculativeFanout(w5, dist, D, HipStateExchange(w5, arena5), branches_per_rank=bpr,
+                                 confirmed_input=lambda f: 0x13, spawn_fn=cm.frame_spawn_fn(rate))
+        out5 = [fan5.step() for _ in range(steps)]
+        ref5, state5 = _serial_reference(n, D, bpr, steps, branch_input=default_branch_input,
+                                         confirmed_input=lambda f: 0x13, ttl_init=300, rate=rate, warm=0)
+        for got, want in zip(out5, ref5):
+            assert got["confirmed_checksum"] == want["confirmed_checksum"]
+            assert got["branch_checksums"] == want["branch_checksums"]
+            assert len({tuple(v) for v in got["branch_checksums"].values()}) == 2      # spawning vs non-spawning inputs
+        cm.assert_states_equal(cm.snapshot_state(w5, ids5), state5, "config 5")
     finally:
         dist.destroy_process_group()

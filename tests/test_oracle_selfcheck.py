@@ -147,3 +147,26 @@ def test_load_missing_frame_is_an_error():
     with pytest.raises(bg.GgrsHipError) as e:
         w.load(99)
     assert e.value.code == bg.GGRS_E_NO_SNAPSHOT
+
+
+def _p2p_run(world, n, ticks, rate=40):
+    ids = cm.build_particles(world, with_spawn=True, ttl_init=30)
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(world, ids, n, vel, ttl)
+    drv = cm.P2PShapeDriver(world, 8, inputs=lambda f: (cm.INPUT_SPAWN if f % 5 == 2 else 0, 0), spawn_fn=cm.frame_spawn_fn(rate))
+    for _ in range(ticks):
+        drv.tick()
+    return drv, cm.snapshot_state(world, ids)
+
+
+def test_p2p_shaped_rollbacks_are_deterministic_and_shapes_agree():
+    """BASELINE config 4's request shape (variable-depth rollbacks, trailing confirmed frame) on the oracle: a
+    frame's checksum never changes when it is resimulated, and both storage shapes agree."""
+    a, sa = _p2p_run(OracleWorld(4000, 8, FLAT), 600, 60)
+    b, sb = _p2p_run(OracleWorld(4000, 8, REFSHAPED), 600, 60)
+    assert a.all_checksums == b.all_checksums and a.depths == b.depths
+    assert max(a.depths) == 7 and min(a.depths) == 0
+    seen = {}
+    for f, c in a.all_checksums:
+        assert seen.setdefault(f, c) == c, f"frame {f} changed under resimulation"
+    cm.assert_states_equal(sa, sb, "p2p shape")
