@@ -21,9 +21,11 @@ flight (a shim collects right before the next advance_frame()); `--sync` blocks 
   cpu_baseline = the oracle's REFERENCE-SHAPED variant (kind "port"), 1 thread, bounded sample.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): speculative fan-out -- rank 0's
-confirmed snapshot is broadcast ONCE over RCCL/xGMI, then each rank re-simulates its own
-predicted-input branch for D frames and advances its replica of the confirmed frame; one
-all-gather of checksums per step.  Weak scaling (per-GPU work fixed).
+confirmed snapshot is broadcast ONCE over RCCL/xGMI; per step every rank runs ONE request list of the
+same shape as the N = 1 tick (1 load + D saves + D+1 advances: the confirmed input for frame C, then its
+own predicted-input branch for the following frames), one step in flight, and ONE all-gather of the
+checksums per step on a side stream (bevy_ggrs_amd/fanout.py).  Weak scaling (per-GPU work fixed).
+`--fanout` forces this code path at world size 1 (validation on a 1-GPU box).
 """
 from __future__ import annotations
 
@@ -127,6 +129,7 @@ def main():
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
+    ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (torch arena, RCCL broadcast + all-gather) even at world size 1")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
 
@@ -140,11 +143,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world_size > 1:
+    distributed = world_size > 1 or args.fanout
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -153,7 +158,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
 
-    if world_size == 1:
+    if not distributed:
         w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum)
         warm_ring(bg, w, D)
         run, _keep = tick_requests(bg, w, D)
@@ -204,11 +209,14 @@ def main():
                                 branches_per_rank=1)
         fan.sync_confirmed(0)
         for _ in range(W):
-            fan.step()
+            fan.step_pipelined(want_result=False)
+        fan.drain(want_result=False)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
-            fan.step()
+            fan.step_pipelined(want_result=False)            # enqueue step k+1, collect + all-gather step k
+        fan.drain(want_result=False)                                          # every one of the K steps is collected inside the timed region
+        w.synchronize()
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         secs = time.perf_counter() - t0
         t = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{dev}")
@@ -220,7 +228,7 @@ def main():
         total_entities = int(cnt.item())
         w.profile_enable(True)
         for _ in range(min(K, 20)):
-            fan.step()
+            fan.step(want_result=False)
         prof = w.profile_read()
         w.profile_enable(False)
 
@@ -241,7 +249,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            same = (tj.get("entities") == n and tj.get("depth") == D and world_size == 1 and not args.no_checksum)
+            same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum)
             if same:
                 traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
         except Exception:
@@ -249,11 +257,9 @@ def main():
 
     if grouped:
         # one k_tick launch per step (N = 1): read the snapshot once, write D snapshots, write live once
-        launches_per_step = tick_n / max(min(K, 50 if world_size == 1 else 20), 1)
-        if world_size == 1:
-            bytes_per_launch = BYTES_PER_ENTITY * (1 + D + 1) * live          # 600 B/entity at D = 8
-        else:   # fan-out step = [Load, (Adv, Save) x D] + [Load, Adv, Save]: two launches
-            bytes_per_launch = BYTES_PER_ENTITY * ((1 + D + 1) + (1 + 1 + 1)) * live / 2
+        launches_per_step = tick_n / max(min(K, 20 if distributed else 50), 1)
+        # N = 1 tick and fan-out step have the same shape: read one snapshot, write D, write live once
+        bytes_per_launch = BYTES_PER_ENTITY * (1 + D + 1) * live              # 600 B/entity at D = 8
         avg_s = per(tick_ms, tick_n)
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
         roof = {"bound": "hbm", "kernel": "k_tick (fused request group: LoadWorld + D x SaveWorld + (D+1) x AdvanceWorld in one pass)",
@@ -288,12 +294,12 @@ def main():
         "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if world_size == 1 else f"speculative fan-out, 1 branch per rank x {world_size} ranks",
+                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (RCCL broadcast of the confirmed snapshot once, one checksum all-gather per step)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if (args.sync or world_size > 1) else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
+                   "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }
-    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(n, D, args.cpu_ticks)
     elif rank == 0:
         line["cpu_baseline"] = None

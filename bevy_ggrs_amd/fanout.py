@@ -9,14 +9,21 @@ per GPU (torch.distributed, backend "nccl" == RCCL over xGMI):
                      presence masks + every registered word column; one contiguous buffer,
                      include/ggrs_hip.h `ggrs_hip_live_state_ptr`) -- ONE RCCL broadcast.  xGMI is
                      point-to-point, so this costs ~state_bytes / per-link bandwidth; it is done at
-                     start-up and after a detected desync, NOT every step:
-  step()             every rank re-simulates its own branches for D frames from its replica of
-                     the confirmed snapshot [Load(C), (Advance(b_i), Save) x D per branch], then
-                     applies the *confirmed* input to its replica [Load(C), Advance(c), Save(C+1)]
-                     -- rollback netcode's determinism keeps the replicas bit-identical, so moving
-                     the 1-byte input replaces re-broadcasting 60 B/entity -- and ONE all-gather
-                     carries every branch's per-frame Checksum(u128) plus the replica's confirmed
-                     checksum, which doubles as cross-rank desync detection.
+                     start-up and after a detected desync, NOT every step.
+  step()             the true input of the confirmed frame C has arrived.  Every rank, for each of
+                     its branches b, runs ONE request list of the same shape as a rollback tick
+                       [Load(C), Advance(confirmed input), Save(C+1),
+                        (Advance(predicted input of branch b), Save(C+1+i)) x (D-1), Advance(predicted)]
+                     = 1 LoadWorld + D SaveWorld + (D+1) AdvanceWorld: ONE fused launch per branch.
+                     Frame C+1 is the new confirmed frame -- rollback netcode's determinism keeps it
+                     bit-identical on every rank, so moving the 1-byte input replaces re-broadcasting
+                     60 B/entity -- and frames C+2.. are the branch's speculative future.  ONE
+                     all-gather carries every branch's D Checksum(u128)s; the C+1 entries double as
+                     cross-rank desync detection (GgrsEvent::DesyncDetected analogue).
+  step_pipelined()   the same, with one step in flight: step k+1 is enqueued on the device
+                     (ggrs_hip_enqueue_requests) before step k's checksums are collected and
+                     all-gathered on a side stream, so the collective and the host work overlap
+                     the next step's kernel.
 
 No data-path collective touches entity columns inside step(); per-GPU work is fixed as the
 world size grows (weak scaling).  `exchange` abstracts where the packed state lives so the same
@@ -59,11 +66,28 @@ class HipStateExchange:
         w.adopt_live_state()
 
     def all_gather_u64(self, dist, values: np.ndarray) -> np.ndarray:
+        """Checksums come from host memory: the H2D copy, the RCCL all-gather and the D2H copy run on a side
+        stream, so they neither wait for nor delay the kernels already enqueued on the world's stream.
+        Staging buffers (pinned host, device) are allocated once per message size."""
         import torch
-        t = torch.from_numpy(values.view(np.int64)).to(self.arena.device)
-        out = torch.empty((dist.get_world_size(), t.numel()), dtype=torch.int64, device=self.arena.device)
-        dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().view(np.uint64)
+        n, size = int(values.size), dist.get_world_size()
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self.arena.device)
+            self._bufs = {}
+        b = self._bufs.get(n)
+        if b is None:
+            h_in = torch.empty(n, dtype=torch.int64).pin_memory()
+            h_out = torch.empty((size, n), dtype=torch.int64).pin_memory()
+            b = self._bufs[n] = {"h_in": h_in, "h_in_np": h_in.numpy(), "h_out": h_out, "h_out_np": h_out.numpy(),
+                                 "d_in": torch.empty(n, dtype=torch.int64, device=self.arena.device),
+                                 "d_out": torch.empty((size, n), dtype=torch.int64, device=self.arena.device)}
+        b["h_in_np"][:] = values.view(np.int64)
+        with torch.cuda.stream(self._comm):
+            b["d_in"].copy_(b["h_in"], non_blocking=True)
+            dist.all_gather_into_tensor(b["d_out"], b["d_in"])
+            b["h_out"].copy_(b["d_out"], non_blocking=True)
+        self._comm.synchronize()
+        return b["h_out_np"].view(np.uint64).copy()
 
 
 def make_torch_world(bg, capacity: int, max_depth: int, n_components: int, bytes_per_slot: int,
@@ -98,7 +122,10 @@ class SpeculativeFanout:
         self.spawn_fn, self.spawn_mask = spawn_fn, spawn_mask
         self.num_players = num_players
         self.synced = False
-        self.last: dict = {}
+        self._last_raw = None
+        self._tmpl = None
+        self.confirmed = world.frame
+        self._inflight: List[int] = []
         world.set_depth(depth + 1)
 
     # ------------------------------------------------------------------ helpers
@@ -114,50 +141,131 @@ class SpeculativeFanout:
 
     def sync_confirmed(self, src: int = 0):
         """Broadcast `src`'s live world as the confirmed frame C and snapshot it on every rank."""
+        self.drain()
         self.x.broadcast(self.dist, src)
         self.w.set_confirmed(self.w.frame)
         cs = self.w.handle_requests([SaveGameState(self.w.frame)])[0]
+        self.confirmed = self.w.frame
         self.synced = True
         return cs
 
     # ------------------------------------------------------------------ one confirmed frame
-    def step(self) -> dict:
-        if not self.synced:
-            self.sync_confirmed(0)
-        w, D = self.w, self.D
-        C = w.frame if not self.last else self.last["confirmed_frame"]
+    def _requests(self, C: int) -> list:
+        D = self.D
+        c_in = self.confirmed_input(C)
         reqs: list = []
         for b in self.branch_ids():
-            reqs.append(LoadGameState(C))
-            for i in range(D):
-                reqs.append(self._advance(C + i, self.branch_input(b, C + i)))
-                reqs.append(SaveGameState(C + i + 1))
-        c_in = self.confirmed_input(C)
-        last_b = self.branch_ids()[-1]
-        adopted = self.bpr > 0 and D > 0 and self.branch_input(last_b, C) == c_in
-        n_spec = self.bpr * D
-        if adopted:
-            # the last branch's frame C+1 was simulated with the true input: adopt its snapshot
-            reqs.append(LoadGameState(C + 1))
-        else:
             reqs += [LoadGameState(C), self._advance(C, c_in), SaveGameState(C + 1)]
-        cs = w.handle_requests(reqs)
-        confirmed_cs = cs[(self.bpr - 1) * D] if adopted else cs[n_spec]
-        # ---- ONE all-gather: [bpr x D speculative checksums | confirmed checksum], u128 as 2 x u64
-        mine = np.zeros((n_spec + 1, 2), dtype=np.uint64)
-        for k in range(n_spec):
-            mine[k] = (cs[k] & 0xFFFFFFFFFFFFFFFF, cs[k] >> 64)
-        mine[n_spec] = (confirmed_cs & 0xFFFFFFFFFFFFFFFF, confirmed_cs >> 64)
-        allv = self.x.all_gather_u64(self.dist, mine.reshape(-1)).reshape(self.size, n_spec + 1, 2)
-        to_int = lambda p: int(p[0]) | (int(p[1]) << 64)
-        confirmed_all = [to_int(allv[r, n_spec]) for r in range(self.size)]
-        if len(set(confirmed_all)) != 1:
+            for i in range(1, D):
+                reqs += [self._advance(C + i, self.branch_input(b, C + i)), SaveGameState(C + 1 + i)]
+            reqs.append(self._advance(C + D, self.branch_input(b, C + D)))      # the newest predicted frame stays live-only
+        return reqs
+
+    def _finish(self, C: int, mine: np.ndarray, want_result: bool = True) -> Optional[dict]:
+        """mine: this rank's bpr x D checksums as a (bpr*D, 2) u64 array {lo, hi}."""
+        D, n = self.D, self.bpr * self.D
+        # ---- ONE all-gather: bpr x D checksums, u128 as 2 x u64
+        allv = self.x.all_gather_u64(self.dist, np.ascontiguousarray(mine).reshape(-1)).reshape(self.size, max(n, 1), 2)
+        conf = allv[:, 0:n:D, :].reshape(-1, 2)              # the C+1 entry of every branch of every rank
+        if (conf != conf[0]).any():
             self.synced = False                              # caller may sync_confirmed() again
-            raise DesyncDetected(C + 1, confirmed_all)
-        w.set_confirmed(C + 1)                               # discard_old_snapshots bound
-        self.last = {
-            "confirmed_frame": C + 1, "confirmed_checksum": confirmed_all[0], "adopted": adopted,
-            "branch_checksums": {r * self.bpr + j: [to_int(allv[r, j * D + i]) for i in range(D)]
-                                 for r in range(self.size) for j in range(self.bpr)},
-        }
-        return self.last
+            raise DesyncDetected(C + 1, [int(p[0]) | (int(p[1]) << 64) for p in conf])
+        self._last_raw = (C, allv)
+        return self.last if want_result else None
+
+    @property
+    def last(self) -> dict:
+        if self._last_raw is None:
+            return {}
+        C, allv = self._last_raw
+        D = self.D
+        to_int = lambda p: int(p[0]) | (int(p[1]) << 64)
+        return {"confirmed_frame": C + 1, "confirmed_checksum": to_int(allv[0, 0]),
+                "branch_checksums": {r * self.bpr + j: [to_int(allv[r, j * D + i]) for i in range(D)]
+                                     for r in range(self.size) for j in range(self.bpr)}}
+
+    @staticmethod
+    def _as_u64_pairs(cs: Sequence[int]) -> np.ndarray:
+        out = np.zeros((max(len(cs), 1), 2), dtype=np.uint64)
+        for k, c in enumerate(cs):
+            out[k] = (c & 0xFFFFFFFFFFFFFFFF, c >> 64)
+        return out
+
+    def step(self, want_result: bool = True) -> Optional[dict]:
+        """One confirmed frame, synchronously."""
+        if not self.synced:
+            self.sync_confirmed(0)
+        self.drain()
+        C = self.confirmed
+        self.w.set_confirmed(C)                              # discard_old_snapshots bound
+        cs = self.w.handle_requests(self._requests(C))
+        self.confirmed = C + 1
+        return self._finish(C, self._as_u64_pairs(cs), want_result)
+
+    # ---- pre-marshalled request list for the pipelined path: with no spawn payloads a step's list only
+    # differs from the previous one in its frame numbers and input bytes, which are patched in place
+    def _template(self):
+        import ctypes as C_
+        reqs = self._requests(0)
+        arr, keep, n_save = self.w.build_requests(reqs)
+        loads = [i for i, r in enumerate(reqs) if isinstance(r, LoadGameState)]
+        saves = [(i, r.frame) for i, r in enumerate(reqs) if isinstance(r, SaveGameState)]
+        advs = [i for i, r in enumerate(reqs) if isinstance(r, AdvanceFrame)]
+        out = (C_.c_uint64 * (2 * max(n_save, 1)))()
+        return {"arr": arr, "keep": keep, "n": len(reqs), "n_save": n_save, "loads": loads, "saves": saves, "advs": advs,
+                "out": out, "out_np": np.frombuffer(out, dtype=np.uint64).reshape(-1, 2)}
+
+    def _patch(self, t, C: int):
+        arr, D = t["arr"], self.D
+        for i in t["loads"]:
+            arr[i].frame = C
+        for i, rel in t["saves"]:
+            arr[i].frame = C + rel
+        per_branch = D + 1
+        c_in = self.confirmed_input(C)
+        for k, i in enumerate(t["advs"]):
+            b, j = self.branch_ids()[k // per_branch], k % per_branch
+            inp = c_in if j == 0 else self.branch_input(b, C + j)
+            q = arr[i]
+            for p in range(q.n_inputs):
+                q.inputs[p] = inp
+
+    def step_pipelined(self, want_result: bool = True) -> Optional[dict]:
+        """Enqueue the step of confirmed frame C on the device, THEN collect and all-gather the previous
+        step (one step in flight).  Returns the previous step's result (None on the first call)."""
+        if not self.synced:
+            self.sync_confirmed(0)
+        if self.bpr * self.D > 256 or not hasattr(self.w, "enqueue_requests_raw"):
+            return self.step(want_result)
+        C = self.confirmed
+        self.w.set_confirmed(C)
+        if self.spawn_fn is None:
+            if self._tmpl is None:
+                self._tmpl = self._template()
+            self._patch(self._tmpl, C)
+            self.w.enqueue_requests_raw(self._tmpl["arr"], self._tmpl["n"])
+        else:
+            self.w.enqueue_requests(self._requests(C))
+        self._inflight.append(C)
+        self.confirmed = C + 1
+        return self._collect_one(want_result) if len(self._inflight) > 1 else None
+
+    def _collect_one(self, want_result: bool = True) -> Optional[dict]:
+        C = self._inflight.pop(0)
+        n = self.bpr * self.D
+        if self._tmpl is not None:
+            self.w.collect_checksums_raw(self._tmpl["out"], n)
+            return self._finish(C, self._tmpl["out_np"][:max(n, 1)].copy(), want_result)
+        return self._finish(C, self._as_u64_pairs(self.w.collect_checksums(n)), want_result)
+
+    def drain(self, want_result: bool = True) -> Optional[dict]:
+        out = None
+        while self._inflight:
+            out = self._collect_one(want_result)
+        return out
+
+    def settle(self) -> int:
+        """Bring the live world back to the confirmed frame (drops the speculative tail)."""
+        self.drain()
+        self.w.handle_requests([LoadGameState(self.confirmed)])
+        return self.confirmed

@@ -85,14 +85,18 @@ def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
         err = None
         for s in range(steps):
             if corrupt and s == corrupt and rank == 1:
-                # replica drifts: a live particle's velocity changes and the confirmed snapshot is re-saved
+                # replica drifts: back on the confirmed frame a live particle's velocity changes and the confirmed
+                # snapshot is re-saved
+                fan.settle()
                 w.upload_word(ids[1], 0, 250, np.array([0x3f800000], dtype=np.uint32))
-                w.handle_requests([bg_SaveGameState(w.frame)])
+                w.handle_requests([bg_SaveGameState(fan.confirmed)])
             try:
                 out.append(fan.step())
             except DesyncDetected as e:
                 err = ("desync", e.frame, len(set(e.checksums)))
                 break
+        if err is None:
+            fan.settle()                           # back to the confirmed frame: identical on every rank
         q.put((rank, out, err, cm.snapshot_state(w, ids) if err is None else None))
     finally:
         dist.destroy_process_group()
@@ -141,15 +145,18 @@ def _serial_reference(n, D, n_branches, steps, branch_input=None, confirmed_inpu
     out = []
     for _ in range(steps):
         per_branch = {}
-        for b in range(n_branches):
-            reqs = [bg.LoadGameState(C)]
-            for i in range(D):
-                reqs += [adv(C + i, branch_input(b, C + i)), bg.SaveGameState(C + i + 1)]
-            per_branch[b] = w.handle_requests(reqs)
-        cs = w.handle_requests([bg.LoadGameState(C), adv(C, confirmed_input(C)), bg.SaveGameState(C + 1)])
-        C += 1
         w.set_confirmed(C)
-        out.append({"confirmed_frame": C, "confirmed_checksum": cs[0], "branch_checksums": per_branch})
+        for b in range(n_branches):
+            # the confirmed input of frame C, then the branch's predicted inputs (fanout.py step())
+            reqs = [bg.LoadGameState(C), adv(C, confirmed_input(C)), bg.SaveGameState(C + 1)]
+            for i in range(1, D):
+                reqs += [adv(C + i, branch_input(b, C + i)), bg.SaveGameState(C + 1 + i)]
+            reqs.append(adv(C + D, branch_input(b, C + D)))
+            per_branch[b] = w.handle_requests(reqs)
+        assert len({v[0] for v in per_branch.values()}) == 1
+        C += 1
+        out.append({"confirmed_frame": C, "confirmed_checksum": per_branch[0][0], "branch_checksums": per_branch})
+    w.handle_requests([bg.LoadGameState(C)])
     return out, cm.snapshot_state(w, ids)
 
 
@@ -167,13 +174,12 @@ def test_fanout_two_ranks_matches_serial_walk(bpr):
             assert got["confirmed_checksum"] == want["confirmed_checksum"]
             assert got["branch_checksums"] == want["branch_checksums"]      # every rank sees every branch
         cm.assert_states_equal(state, ref_state, f"rank {rank}")
-    # branches with different inputs really diverge, same inputs agree
+    # every branch agrees on the confirmed frame; branches with different predicted inputs diverge after it,
+    # branches with the same inputs agree
     last = res[0][1][-1]["branch_checksums"]
-    assert last[0] != last[1]
+    assert last[0][0] == last[1][0] and last[0][1:] != last[1][1:]
     if bpr == 3:
         assert last[0] == last[2] == last[4] and last[1] == last[3] == last[5]
-    # adoption happens on the rank whose last branch predicted the confirmed input
-    assert any(o["adopted"] for _, out, _, _ in res for o in out)
 
 
 def test_fanout_detects_replica_desync():

@@ -36,8 +36,15 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
                                 branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
                                 confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
                                 spawn_fn=cm.frame_spawn_fn(50))
-        out = [fan.step() for _ in range(steps)]
+        # first half synchronously, second half with one step in flight (enqueue k+1, then collect + all-gather k)
+        out = [fan.step() for _ in range(steps // 2)]
+        for _ in range(steps - steps // 2):
+            r = fan.step_pipelined()
+            if r is not None: out.append(r)
+        out.append(fan.drain())
+        fan.settle()
         ref, ref_state = _serial_reference(n, D, bpr, steps)
+        assert len(out) == len(ref) == steps
         for got, want in zip(out, ref):
             assert got["confirmed_frame"] == want["confirmed_frame"]
             assert got["confirmed_checksum"] == want["confirmed_checksum"]
@@ -59,6 +66,25 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
         cm.assert_states_equal(cm.snapshot_state(w2, ids2), cm.snapshot_state(w, ids), "adopted")
         assert w2.save() == w.save()
 
+        # ---- the pre-marshalled pipelined path (no spawn payloads: frames and input bytes patched in place)
+        # must reproduce the synchronous path
+        res = []
+        for mode in ("sync", "pipelined"):
+            wp, arenap = make_torch_world(bg, 5000, D + 2, 3, 60, torch.device("cuda", 0))
+            idsp = cm.build_particles(wp)
+            vel, ttl = cm.synthetic_particles(5000, ttl="despawn")
+            cm.spawn_particles(wp, idsp, 5000, vel, ttl)
+            fp = SpeculativeFanout(wp, dist, D, HipStateExchange(wp, arenap), branches_per_rank=3,
+                                   branch_input=lambda b, f: (b + f) & 0xF, confirmed_input=lambda f: f & 3)
+            if mode == "sync":
+                outp = [fp.step() for _ in range(7)]
+            else:
+                outp = [r for r in (fp.step_pipelined() for _ in range(7)) if r is not None] + [fp.drain()]
+            fp.settle()
+            res.append((outp, cm.snapshot_state(wp, idsp)))
+        assert len(res[0][0]) == len(res[1][0]) == 7 and res[0][0] == res[1][0]
+        cm.assert_states_equal(res[0][1], res[1][1], "pipelined fan-out")
+
         # ---- BASELINE config 5 on the one GPU of this box: 256 predicted-input branches (branch id = the input
         # byte repeated every frame), 100k entities, 8 frames each, all on rank 0; inputs with
         # INPUT_SPAWN set spawn 100 particles per frame so the branches really diverge
@@ -72,12 +98,14 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
         fan5 = SpeculativeFanout(w5, dist, D, HipStateExchange(w5, arena5), branches_per_rank=bpr,
                                  confirmed_input=lambda f: 0x13, spawn_fn=cm.frame_spawn_fn(rate))
         out5 = [fan5.step() for _ in range(steps)]
+        fan5.settle()
         ref5, state5 = _serial_reference(n, D, bpr, steps, branch_input=default_branch_input,
                                          confirmed_input=lambda f: 0x13, ttl_init=300, rate=rate, warm=0)
         for got, want in zip(out5, ref5):
             assert got["confirmed_checksum"] == want["confirmed_checksum"]
             assert got["branch_checksums"] == want["branch_checksums"]
-            assert len({tuple(v) for v in got["branch_checksums"].values()}) == 2      # spawning vs non-spawning inputs
+            assert len({v[0] for v in got["branch_checksums"].values()}) == 1          # one confirmed frame
+            assert len({tuple(v) for v in got["branch_checksums"].values()}) == 2      # spawning vs non-spawning predictions
         cm.assert_states_equal(cm.snapshot_state(w5, ids5), state5, "config 5")
     finally:
         dist.destroy_process_group()
