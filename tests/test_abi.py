@@ -51,3 +51,24 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("the CPU oracle", "").replace("CPU\n oracle", "") or f == "world.py", (dp, f)
+
+
+def test_rust_ffi_declares_every_header_symbol():
+    """rust/bevy_ggrs_hip/src/ffi.rs (un-built source: no Rust toolchain in this image) must stay in lock-step with
+    include/ggrs_hip.h: same entry points, same number of arguments, same ABI version and request/system constants."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ggrs_hip.h")).read()
+    rs = open(os.path.join(root, "rust", "bevy_ggrs_hip", "src", "ffi.rs")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(ggrs_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr_nc)}
+    rs_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (ggrs_hip_[a-z0-9_]+)\(([^)]*)\)", rs)}
+    assert set(c_fns) == set(rs_fns), set(c_fns) ^ set(rs_fns)
+    def argc(a):
+        a = a.strip()
+        return 0 if a in ("", "void") else a.count(",") + 1
+    for name in c_fns:
+        assert argc(c_fns[name]) == argc(rs_fns[name]), name
+    for const in re.findall(r"#define (GGRS_(?:E|REQ|SYS|WORLD|COMP|DESPAWN)_[A-Z0-9_]+|GGRS_OK|GGRS_HIP_ABI_VERSION)\s+(-?\d+)u?", hdr):
+        m = re.search(r"pub const %s: \w+ = (-?\d+);" % const[0], rs)
+        assert m and int(m.group(1)) == int(const[1]), const
