@@ -83,7 +83,7 @@ SIGNATURES = {
     "ggrs_hip_download_word": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _P]),
     "ggrs_hip_download_alive": (C.c_int, [_P, _P, C.c_uint64]),
     "ggrs_hip_download_present": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64]),
-    "ggrs_hip_column_device_ptr": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "ggrs_hip_column_device_ptr": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ggrs_hip_len": (C.c_uint64, [_P]),
     "ggrs_hip_active_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ggrs_hip_frame": (C.c_int32, [_P]),

@@ -57,6 +57,7 @@ struct ggrs_world {
     uint32_t max_depth = 0, flags = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false;
+    uint8_t* arena_alloc = nullptr;      // what hipMalloc returned (arena may be aligned / skewed inside it)
 
     std::vector<Comp> comps;
     std::vector<ggrs_system_desc> systems;
@@ -72,8 +73,9 @@ struct ggrs_world {
     bool marks_possible = false;         // a RollbackDespawned marker may exist in the live world
     int32_t dc_local = 0;                // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
     uint64_t state_bytes = 0, off_alive = 0;
-    std::vector<uint64_t> off_present, col_off;
-    std::vector<uint32_t> col_wb;
+    std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0
+    std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
+    uint32_t ts = 0;                               // tile stride of the rollback word columns: bytes of all their words x 1024 slots
     CopyPlan plan{};
 
     // ---- device buffers
@@ -100,6 +102,9 @@ struct ggrs_world {
     TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
     uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
     int tick_vec = 0;                    // 0: pick per launch by size; 1 / 4: forced (GGRS_TICK_VEC, A/B knob)
+    uint64_t block_pad = 0, col_pad = 0; // extra bytes between ring blocks / columns (GGRS_BLOCK_PAD / GGRS_COL_PAD, A/B knobs; library-owned arenas only)
+    uint32_t tick_lds = 0;               // dynamic LDS bytes per k_tick workgroup: occupancy throttle (GGRS_TICK_LDS, A/B knob)
+    int tick_rest_loop = 1;              // rest rows stored with each Save (default) instead of the up-front fan-out (GGRS_TICK_REST=0)
 
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
@@ -164,15 +169,39 @@ void build_layout(ggrs_world* w) {
     for (auto& c : w->comps) { c.col_base = ncols; ncols += c.n_words; w->has_nr |= c.no_rollback; }
     w->col_off.assign(ncols, 0); w->col_wb.assign(ncols, 4);
     for (size_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback) { w->off_present[c] = off; off += mask_bytes; }
-    for (auto& c : w->comps) {
-        for (uint32_t k = 0; k < c.n_words; ++k) {
-            w->col_wb[c.col_base + k] = c.word_bytes;
-            if (c.no_rollback) continue;
-            w->col_off[c.col_base + k] = off;
-            off += align_up(w->cap_pad * c.word_bytes, ALIGN);
+    // rollback word columns, TILE-MAJOR: tile t of every column is contiguous (ts bytes per tile).  Inside a
+    // tile the words that GgrsSchedule systems read or write come first, so a per-request AdvanceWorld kernel
+    // streams one contiguous span per tile (particles: 32 of the 60 KiB) instead of 4 KiB pieces.
+    w->col_ts.assign(ncols, 0);
+    std::vector<uint8_t> hot(ncols, 0);
+    for (auto& sd : w->systems) {
+        auto mark = [&](uint32_t comp, uint32_t word, uint32_t span) {
+            if (comp >= w->comps.size()) return;
+            for (uint32_t k = 0; k < span && word + k < w->comps[comp].n_words; ++k) hot[w->comps[comp].col_base + word + k] = 1;
+        };
+        switch (sd.kind) {
+        case GGRS_SYS_PARTICLES_UPDATE: mark(sd.comp[0], sd.word[0], 3); mark(sd.comp[1], sd.word[1], 3); break;
+        case GGRS_SYS_TTL_DESPAWN: case GGRS_SYS_ADD_U32: case GGRS_SYS_SAT_SUB_DESPAWN: mark(sd.comp[0], sd.word[0], 1); break;
+        case GGRS_SYS_BOX_MOVE: mark(sd.comp[0], sd.word[0], 3); mark(sd.comp[1], sd.word[1], 3); mark(sd.comp[2], sd.word[2], 1); break;
+        default: break;
         }
     }
-    w->state_bytes = align_up(off, 4096);
+    uint64_t tcol = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (auto& c : w->comps) {
+            for (uint32_t k = 0; k < c.n_words; ++k) {
+                w->col_wb[c.col_base + k] = c.word_bytes;
+                if (c.no_rollback || (hot[c.col_base + k] != 0) != (pass == 0)) continue;
+                w->col_off[c.col_base + k] = tcol;           // offset inside a tile for now
+                tcol += (uint64_t)TILE * c.word_bytes;
+            }
+        }
+    w->ts = (uint32_t)tcol;
+    const uint64_t cols_base = align_up(off, 4096);
+    for (auto& c : w->comps) if (!c.no_rollback)
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] += cols_base; w->col_ts[c.col_base + k] = w->ts; }
+    off = cols_base + (w->cap_pad / TILE) * (uint64_t)w->ts + w->col_pad;
+    w->state_bytes = align_up(off, 4096) + w->block_pad;
     // ---- live-only side region, placed right behind the ring blocks
     w->side_off = (uint64_t)(w->max_depth + 1) * w->state_bytes;
     uint64_t so = w->side_off;
@@ -181,7 +210,8 @@ void build_layout(ggrs_world* w) {
     for (size_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].no_rollback) { w->off_present[c] = so; so += mask_bytes; }
     for (auto& c : w->comps) {
         if (!c.no_rollback) continue;
-        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
+        // live-only columns are plain arrays: the same addressing formula with tile stride = 1024 words
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; w->col_ts[c.col_base + k] = TILE * c.word_bytes; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
     }
     w->side_bytes = align_up(so - w->side_off, 4096);
 
@@ -197,7 +227,7 @@ void build_layout(ggrs_world* w) {
         for (uint32_t k = 0; k < cc.n_words; ++k)
             for (uint32_t r = 0; r < cc.word_bytes / 4; ++r) {
                 RowDesc& rd = p.row[nr++];
-                rd.col_off = w->col_off[cc.col_base + k]; rd.roff = r * 4096; rd.tile_stride = TILE * cc.word_bytes; rd.word_bytes = cc.word_bytes; rd.pad = 0;
+                rd.col_off = w->col_off[cc.col_base + k]; rd.roff = r * 4096; rd.tile_stride = w->ts; rd.word_bytes = cc.word_bytes; rd.pad = 0;
             }
     }
     p.n_rows = nr;
@@ -252,8 +282,9 @@ int seal(ggrs_world* w) {
         w->cks_args.unit_base[k] = (uint32_t)units.size();
         for (uint32_t wi : cc.cks_words) {
             const uint64_t co = w->col_off[cc.col_base + wi];
-            if (cc.word_bytes == 4) units.push_back({co, 4, 0});
-            else { units.push_back({co, 8, 0}); units.push_back({co + 4, 8, 0}); }
+            const uint32_t cts = w->col_ts[cc.col_base + wi];
+            if (cc.word_bytes == 4) units.push_back({co, 4, cts});
+            else { units.push_back({co, 8, cts}); units.push_back({co + 4, 8, cts}); }
         }
         w->cks_args.n_units[k] = (uint32_t)units.size() - w->cks_args.unit_base[k];
         if (w->cks_args.n_units[k] > (uint32_t)MAX_UNITS) return w->fail(GGRS_E_INVALID, "checksum spec too long");
@@ -292,6 +323,7 @@ int seal(ggrs_world* w) {
             a.g[k] = w->f_g[k];
         }
         a.off_ttl = w->col_off[L.col_base + w->f_lw];
+        a.ts = w->ts;
         for (uint32_t c = 0; c < w->comps.size(); ++c)
             if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
         for (uint32_t c = 0; c < w->comps.size(); ++c) {
@@ -302,7 +334,7 @@ int seal(ggrs_world* w) {
                 bool owned = (co == a.off_ttl);
                 for (int j = 0; j < 3; ++j) owned |= (co == a.off_t[j]) || (co == a.off_v[j]);
                 if (owned) continue;
-                for (uint32_t r = 0; r < cc.word_bytes / 4; ++r) a.rest[a.n_rest_rows++] = RowLite{co, r * 4096, TILE * cc.word_bytes};
+                for (uint32_t r = 0; r < cc.word_bytes / 4; ++r) a.rest[a.n_rest_rows++] = RowLite{co, r * 4096, w->ts, cc.word_bytes, 0};
             }
         }
         w->tick_ok = true;
@@ -323,8 +355,17 @@ int seal(ggrs_world* w) {
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
-        HIPCHK(w, hipMalloc((void**)&w->arena, need));
+        // A/B knobs: GGRS_ARENA_ALIGN (power of two) aligns the first block inside an over-allocation,
+        // GGRS_ARENA_SKEW then shifts it; GGRS_DEBUG_ARENA prints the placement
+        uint64_t al = 0, skew = 0;
+        if (const char* v = getenv("GGRS_ARENA_ALIGN")) al = (uint64_t)atoll(v);
+        if (const char* v = getenv("GGRS_ARENA_SKEW")) skew = align_up((uint64_t)atoll(v), ALIGN);
+        HIPCHK(w, hipMalloc((void**)&w->arena_alloc, need + al + skew));
+        w->arena = w->arena_alloc;
+        if (al) w->arena = (uint8_t*)align_up((uint64_t)w->arena_alloc, al);
+        w->arena += skew;
         w->arena_bytes = need; w->own_arena = true;
+        if (getenv("GGRS_DEBUG_ARENA")) fprintf(stderr, "[ggrs arena] alloc=%p base=%p need=%llu state_bytes=%llu (0x%llx)\n", (void*)w->arena_alloc, (void*)w->arena, (unsigned long long)need, (unsigned long long)w->state_bytes, (unsigned long long)w->state_bytes);
     }
     uint8_t* p = w->arena;
     w->live.ptr = p; p += w->state_bytes;
@@ -522,12 +563,37 @@ int set_masks_for_range(ggrs_world* w, uint64_t first, uint64_t count, uint64_t 
     return GGRS_OK;
 }
 
+// Host <-> device copy of `count` words of one column starting at slot `first` (tile-major columns: a head
+// piece, the full tiles as one pitched 2D copy, a tail piece; plain arrays: one copy).
+int copy_column(ggrs_world* w, uint32_t col, uint64_t first, uint64_t count, void* host, bool to_device) {
+    if (count == 0) return GGRS_OK;
+    const uint32_t wb = w->col_wb[col], ts = w->col_ts[col];
+    uint8_t* h = (uint8_t*)host;
+    auto dev = [&](uint64_t slot) { return w->live.ptr + col_at(w->col_off[col], ts, wb, slot); };
+    auto piece = [&](uint64_t slot, uint64_t n) -> hipError_t {
+        return to_device ? hipMemcpyAsync(dev(slot), h + (slot - first) * wb, n * wb, hipMemcpyHostToDevice, w->stream)
+                         : hipMemcpyAsync(h + (slot - first) * wb, dev(slot), n * wb, hipMemcpyDeviceToHost, w->stream);
+    };
+    if (ts == TILE * wb) { HIPCHK(w, piece(first, count)); return GGRS_OK; }
+    uint64_t s0 = first, end = first + count;
+    if (s0 % TILE) { const uint64_t n = std::min<uint64_t>(end - s0, TILE - s0 % TILE); HIPCHK(w, piece(s0, n)); s0 += n; }
+    const uint64_t full = (end - s0) / TILE;
+    if (full) {
+        const size_t width = (size_t)TILE * wb;
+        if (to_device) HIPCHK(w, hipMemcpy2DAsync(dev(s0), ts, h + (s0 - first) * wb, width, width, full, hipMemcpyHostToDevice, w->stream));
+        else HIPCHK(w, hipMemcpy2DAsync(h + (s0 - first) * wb, width, dev(s0), ts, width, full, hipMemcpyDeviceToHost, w->stream));
+        s0 += full * TILE;
+    }
+    if (s0 < end) HIPCHK(w, piece(s0, end - s0));
+    return GGRS_OK;
+}
+
 int fill_defaults(ggrs_world* w, uint32_t c, uint64_t first, uint64_t count) {
     const Comp& cc = w->comps[c];
     for (uint32_t k = 0; k < cc.n_words; ++k) {
         uint64_t v = 0; memcpy(&v, &cc.defaults[(size_t)k * cc.word_bytes], cc.word_bytes);
         hipLaunchKernelGGL(k_fill_col, dim3((uint32_t)((count + TPB - 1) / TPB)), dim3(TPB), 0, w->stream,
-                           w->live.ptr, w->col_off[cc.col_base + k], cc.word_bytes, first, count, v);
+                           w->live.ptr, w->col_off[cc.col_base + k], w->col_ts[cc.col_base + k], cc.word_bytes, first, count, v);
     }
     HIPCHK(w, hipGetLastError());
     return GGRS_OK;
@@ -583,6 +649,7 @@ int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, u
             memcpy(&a.t_default[k], &T.defaults[(size_t)(w->fused_ok ? w->f_tw + k : k) * 4], 4);
         }
         a.off_ttl = w->col_off[L.col_base + 0];
+        a.ts = w->ts;
         a.vx = dvx; a.vy = dvy; a.first = first; a.count = spawn_count; a.ttl = (uint64_t)s.iparam[0];
         const uint32_t gs = (uint32_t)((spawn_count + TPB - 1) / TPB);
         const bool keep = w->pending_valid && (w->pending_parts + gs <= w->part_stride);
@@ -628,7 +695,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
 
     auto step_args = [&](const ggrs_system_desc* upd, const ggrs_system_desc* ttl) {
         StepArgs a; memset(&a, 0, sizeof a);
-        a.state = w->live.ptr; a.off_alive = w->off_alive; a.dt_bits = dt_bits;
+        a.state = w->live.ptr; a.off_alive = w->off_alive; a.dt_bits = dt_bits; a.ts = w->ts;
         if (upd) {
             const Comp& T = w->comps[upd->comp[0]]; const Comp& V = w->comps[upd->comp[1]];
             a.off_pT = w->off_present[upd->comp[0]]; a.off_pV = w->off_present[upd->comp[1]];
@@ -681,7 +748,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                 case GGRS_SYS_ADD_U32: {
                     const Comp& C = w->comps[s.comp[0]];
                     hipLaunchKernelGGL(k_add_u32, dim3((uint32_t)((w->len + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, w->live.ptr,
-                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], w->len);
+                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], w->col_ts[C.col_base + s.word[0]], (uint32_t)s.iparam[0], w->len);
                 } break;
                 case GGRS_SYS_SAT_SUB_DESPAWN: {
                     const Comp& C = w->comps[s.comp[0]];
@@ -690,7 +757,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                     const int defer = (s.iparam[1] == GGRS_DESPAWN_ROLLBACK && w->confirmed < w->frame) ? 1 : 0;
                     if (defer) w->marks_possible = true;
                     hipLaunchKernelGGL(k_sat_sub_despawn, dim3((uint32_t)((lp + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, w->live.ptr,
-                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp,
+                                       w->off_alive, w->off_present[s.comp[0]], w->col_off[C.col_base + s.word[0]], w->col_ts[C.col_base + s.word[0]], (uint32_t)s.iparam[0], lp,
                                        defer, w->frame, w->marks);
                 } break;
                 case GGRS_SYS_BOX_MOVE: {
@@ -700,6 +767,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                     a.off_pT = w->off_present[s.comp[0]]; a.off_pV = w->off_present[s.comp[1]]; a.off_pP = w->off_present[s.comp[2]];
                     for (int k = 0; k < 3; ++k) { a.off_t[k] = w->col_off[T.col_base + s.word[0] + k]; a.off_v[k] = w->col_off[V.col_base + s.word[1] + k]; }
                     a.off_handle = w->col_off[P.col_base + s.word[2]];
+                    a.ts_t = w->col_ts[T.col_base + s.word[0]]; a.ts_v = w->col_ts[V.col_base + s.word[1]]; a.ts_handle = w->col_ts[P.col_base + s.word[2]];
                     a.len = w->len; a.dt_bits = dt_bits;
                     // FRICTION.powf(dt) (box_game.rs:189-195): Rust lowers f32::powf to the platform libm's powf
                     float dtf; memcpy(&dtf, &dt_bits, 4);
@@ -753,12 +821,19 @@ void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
     else hipLaunchKernelGGL((k_tick1<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
 }
 
+constexpr int TICK_RESTL = 8;          // rest rows the register-resident variant of k_tick can carry
 template <bool NT>
 void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
-    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick<true, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksT) hipLaunchKernelGGL((k_tick<true, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksV) hipLaunchKernelGGL((k_tick<false, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else hipLaunchKernelGGL((k_tick<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+    const uint32_t lds = w->tick_lds;
+    const bool rl = w->tick_rest_loop && a.n_rest_rows <= (uint32_t)TICK_RESTL && a.n_rest_rows > 0 && a.n_saves > 0;
+#define GGRS_LAUNCH_TICK(T_, V_) do { \
+        if (rl) hipLaunchKernelGGL((k_tick<T_, V_, NT, TICK_RESTL>), dim3(g), dim3(TPB), lds, w->stream, a); \
+        else hipLaunchKernelGGL((k_tick<T_, V_, NT, 0>), dim3(g), dim3(TPB), lds, w->stream, a); } while (0)
+    if (w->f_cksT && w->f_cksV) GGRS_LAUNCH_TICK(true, true);
+    else if (w->f_cksT) GGRS_LAUNCH_TICK(true, false);
+    else if (w->f_cksV) GGRS_LAUNCH_TICK(false, true);
+    else GGRS_LAUNCH_TICK(false, false);
+#undef GGRS_LAUNCH_TICK
 }
 
 // res_base: first slot of the pinned result ring this list writes to.  wait == false only enqueues
@@ -882,6 +957,12 @@ int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
     w->depth = w->max_depth;
     w->nt_copy = (d->flags & GGRS_WORLD_NT_COPY) != 0;
     if (const char* v = getenv("GGRS_TICK_VEC")) { const int x = atoi(v); if (x == 1 || x == 4) w->tick_vec = x; }
+    if (const char* v = getenv("GGRS_TICK_LDS")) { const int x = atoi(v); if (x >= 0 && x <= 160 * 1024) w->tick_lds = (uint32_t)x; }
+    if (const char* v = getenv("GGRS_TICK_REST")) w->tick_rest_loop = atoi(v) != 0;
+    if (!d->arena) {
+        if (const char* v = getenv("GGRS_BLOCK_PAD")) w->block_pad = align_up((uint64_t)atoll(v), ALIGN);
+        if (const char* v = getenv("GGRS_COL_PAD")) w->col_pad = align_up((uint64_t)atoll(v), ALIGN);
+    }
     if (d->stream) w->stream = (hipStream_t)d->stream;
     else {
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return GGRS_E_HIP; }
@@ -900,7 +981,8 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t cap_pad = align_up(capacity, TILE);
     const uint64_t mask = align_up(cap_pad / 8, ALIGN);
     // each 4-byte word column is 256-B aligned; bytes_per_slot/4 bounds the column count
-    const uint64_t state = align_up(ALIGN + (1 + (uint64_t)n_components) * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
+    // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 1024 per tile)
+    const uint64_t state = align_up(align_up(ALIGN + (1 + (uint64_t)n_components) * mask, 4096) + cap_pad * bytes_per_slot, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
                            align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
@@ -915,7 +997,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
-    if (w->own_arena && w->arena) (void)hipFree(w->arena);
+    if (w->own_arena && w->arena_alloc) (void)hipFree(w->arena_alloc);
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
@@ -993,7 +1075,7 @@ int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void
         if (any_null) { rc = fill_defaults(w, c, first, count); if (rc) return rc; }
         for (uint32_t k = 0; k < cc.n_words; ++k) {
             const void* src = cols ? cols[ci + k] : nullptr;
-            if (src) HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + k] + first * cc.word_bytes, src, (size_t)count * cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+            if (src) { rc = copy_column(w, cc.col_base + k, first, count, const_cast<void*>(src), true); if (rc) return rc; }
         }
         ci += cc.n_words;
     }
@@ -1033,7 +1115,7 @@ int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const vo
     if (c >= w->comps.size() || slot >= w->len || !words) return w->fail(GGRS_E_INVALID, "bad insert_component arguments");
     const Comp& cc = w->comps[c];
     for (uint32_t k = 0; k < cc.n_words; ++k)
-        HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + k] + slot * cc.word_bytes, (const uint8_t*)words + (size_t)k * cc.word_bytes, cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+        { rc = copy_column(w, cc.col_base + k, slot, 1, const_cast<uint8_t*>((const uint8_t*)words + (size_t)k * cc.word_bytes), true); if (rc) return rc; }
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 1);
     HIPCHK(w, hipGetLastError());
     w->pending_valid = false;
@@ -1054,7 +1136,7 @@ int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t firs
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
     const Comp& cc = w->comps[c];
-    HIPCHK(w, hipMemcpyAsync(w->live.ptr + w->col_off[cc.col_base + word] + first * cc.word_bytes, src, (size_t)count * cc.word_bytes, hipMemcpyHostToDevice, w->stream));
+    rc = copy_column(w, cc.col_base + word, first, count, const_cast<void*>(src), true); if (rc) return rc;
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->pending_valid = false;
     return GGRS_OK;
@@ -1064,7 +1146,7 @@ int ggrs_hip_download_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t fi
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !dst) return w->fail(GGRS_E_INVALID, "bad download_word arguments");
     const Comp& cc = w->comps[c];
-    HIPCHK(w, hipMemcpyAsync(dst, w->live.ptr + w->col_off[cc.col_base + word] + first * cc.word_bytes, (size_t)count * cc.word_bytes, hipMemcpyDeviceToHost, w->stream));
+    rc = copy_column(w, cc.col_base + word, first, count, dst, false); if (rc) return rc;
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return GGRS_OK;
 }
@@ -1109,11 +1191,12 @@ int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t c
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return GGRS_OK;
 }
-int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p) {
+int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p, uint64_t* tile_stride) {
     if (!w || !p) return GGRS_E_INVALID;
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words) return w->fail(GGRS_E_INVALID, "bad column");
     *p = w->live.ptr + w->col_off[w->comps[c].col_base + word];
+    if (tile_stride) *tile_stride = w->col_ts[w->comps[c].col_base + word];
     return GGRS_OK;
 }
 uint64_t ggrs_hip_len(ggrs_world* w) { return w ? w->len : 0; }

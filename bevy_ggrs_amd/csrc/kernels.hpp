@@ -5,6 +5,11 @@
 //   * one workgroup (256 threads = 4 waves) owns one TILE of 1024 consecutive slots in EVERY
 //     kernel, and tile t is always blockIdx t.  Workgroup b lands on XCD b % 8, so the same
 //     XCD (and its private 4 MiB L2) touches the same slots in load -> advance -> save chains;
+//   * word columns are stored TILE-MAJOR inside a state block: the 1024 slots of tile t of every
+//     registered word sit next to each other (tile_stride = bytes of all words of 1024 slots, 60 KiB
+//     for the particles world), so one workgroup's whole traffic to a block is one contiguous span;
+//     word w of slot e lives at  col_off[w] + (e >> 10) * tile_stride + (e & 1023) * word_bytes.
+//     Live-only side columns keep the same formula with tile_stride = 1024 * word_bytes (a plain array);
 //   * every column access is 16 B per lane (dwordx4), 1 KiB per wave instruction, all loads
 //     of a tile issued before the first store;
 //   * Rollback-entity liveness is a 1 bit/slot mask; despawn masks are built with wave64
@@ -76,6 +81,11 @@ struct SeaStream {
     }
 };
 
+// byte offset (inside a state block) of word-column element `e`: see the layout note at the top
+__host__ __device__ __forceinline__ uint64_t col_at(uint64_t col_off, uint32_t tile_stride, uint32_t word_bytes, uint64_t e) {
+    return col_off + (e >> 10) * (uint64_t)tile_stride + (e & 1023u) * (uint64_t)word_bytes;
+}
+
 // ------------------------------------------------------------------ kernel argument blocks
 struct RowDesc {          // one 4 KiB-per-tile copy row of the packed state block
     uint64_t col_off;     // byte offset of the column inside the state block
@@ -103,9 +113,10 @@ struct StepArgs {         // fused GgrsSchedule step of the particles workload
     uint64_t off_t[3], off_v[3], off_ttl;
     uint32_t dt_bits; float g[3];
     uint64_t* part_T; uint64_t* part_V; uint64_t* part_cnt;
+    uint32_t ts; uint32_t pad;            // tile stride of the rollback word columns
 };
 
-struct UnitDesc { uint64_t off; uint32_t stride; uint32_t pad; };
+struct UnitDesc { uint64_t off; uint32_t stride; uint32_t ts; };   // u32 unit e at off + (e>>10)*ts + (e&1023)*stride
 struct CksArgs {          // generic component checksum
     const uint8_t* state;
     uint64_t off_alive;
@@ -230,7 +241,8 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
         for (uint32_t r = 0; r < n_rows; ++r) {
             const RowDesc rd = plan.row[r];
             const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
-            if (pos < len * rd.word_bytes)
+            const uint64_t slot0 = (uint64_t)t * TILE + (rd.roff + tid * 16u) / rd.word_bytes;   // first slot of this lane's 16 bytes
+            if (slot0 < len)
                 *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
         }
     }
@@ -266,6 +278,8 @@ template <bool UPD, bool TTL, bool CKS_T, bool CKS_V>
 __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;     // first of this lane's 4 slots
+    const uint64_t tb4 = (uint64_t)t * a.ts + (uint64_t)tid * 16;    // its 16 bytes inside a 4-byte column's tile row
+    const uint64_t tb8 = (uint64_t)t * a.ts + (uint64_t)tid * 32;    // its 32 bytes inside an 8-byte column's tile rows
     const uint64_t w0 = (uint64_t)t * 16 + wave * 4;                 // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
     const uint64_t wi = w0 + (lane >> 4);
@@ -281,15 +295,15 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     ulonglong2 tl[2];
     if (NEED_T) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.state + a.off_t[k] + e0 * 4);
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.state + a.off_t[k] + tb4);
     }
     if (NEED_V) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.state + a.off_v[k] + e0 * 4);
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.state + a.off_v[k] + tb4);
     }
     if (TTL) {
-        tl[0] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8);
-        tl[1] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16);
+        tl[0] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + tb8);
+        tl[1] = *reinterpret_cast<const ulonglong2*>(a.state + a.off_ttl + tb8 + 16);
     }
 
     const uint32_t n_alive = (uint32_t)(alive_w >> sh) & 0xFu;
@@ -318,8 +332,8 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
         if (__ballot(m_upd != 0) != 0) {                      // wave-uniform
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                *reinterpret_cast<float4*>(a.state + a.off_t[k] + e0 * 4) = tx[k];
-                *reinterpret_cast<float4*>(a.state + a.off_v[k] + e0 * 4) = vv[k];
+                *reinterpret_cast<float4*>(a.state + a.off_t[k] + tb4) = tx[k];
+                *reinterpret_cast<float4*>(a.state + a.off_v[k] + tb4) = vv[k];
             }
         }
     }
@@ -336,8 +350,8 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
             kill |= (on && nq == 0) ? (1u << j) : 0u;
         }
         if (__ballot(m_ttl != 0) != 0) {
-            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8) = tl[0];
-            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + e0 * 8 + 16) = tl[1];
+            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + tb8) = tl[0];
+            *reinterpret_cast<ulonglong2*>(a.state + a.off_ttl + tb8 + 16) = tl[1];
         }
     }
     const uint32_t n_new = n_alive & ~kill;
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
 // safe because every location is read by the lane that later writes it, and all reads of a
 // location precede its first write (pointers are deliberately not __restrict__).
 constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
-struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; };
+struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; uint32_t word_bytes; uint32_t pad; };
 struct TickArgs {
     const uint8_t* src;                    // ring slot (group starts with LoadGameState) or live
     uint8_t* live;
@@ -428,7 +442,7 @@ struct TickArgs {
     uint64_t len;
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
-    uint32_t n_rest_rows, n_rest_masks, part_stride, pad;
+    uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
     uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE
     uint64_t rest_mask_off[MAX_MASKS];     // presence masks of components the schedule does not touch
     RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
@@ -438,6 +452,7 @@ struct TickArgs {
 // saddr form of global_load/global_store (no 64-bit VALU address arithmetic per access).  The value
 // comes back as an explicit global (address space 1) pointer: laundering a generic pointer through
 // inline asm would otherwise make the compiler fall back to flat_* instructions.
+static_assert(sizeof(TickArgs) <= 4096, "kernel argument segment limit");
 #define GGRS_GLOBAL __attribute__((address_space(1)))
 typedef GGRS_GLOBAL uint8_t g_u8;
 __device__ __forceinline__ g_u8* sgpr_base(const uint8_t* p) {
@@ -446,12 +461,20 @@ __device__ __forceinline__ g_u8* sgpr_base(const uint8_t* p) {
     return (g_u8*)x;
 }
 
+// 16-byte store to `base + lo` (base wave-uniform, lo a 32-bit lane offset).  The non-temporal form is written
+// as inline asm: __builtin_nontemporal_store on the same expression makes hipcc fall back to a 64-bit VGPR
+// address that it recomputes into ONE register pair before every store, which serialises the whole store
+// burst behind VALU address arithmetic (measured: NT 6 % slower than plain stores; saddr-form NT is faster).
 template <bool NT, class V>
-__device__ __forceinline__ void st16(g_u8* p, const V& v) {
+__device__ __forceinline__ void st16(g_u8* base, uint32_t lo, const V& v) {
     static_assert(sizeof(V) == 16, "16-byte register tuple");
     const u32x4 x = reinterpret_cast<const u32x4&>(v);
-    if (NT) __builtin_nontemporal_store(x, (GGRS_GLOBAL u32x4*)p);
-    else *(GGRS_GLOBAL u32x4*)p = x;
+    if (NT) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(lo), "v"(x), "s"(b) : "memory");
+    } else {
+        *(GGRS_GLOBAL u32x4*)(base + lo) = x;
+    }
 }
 __device__ __forceinline__ void st8(g_u8* p, uint64_t v) { *(GGRS_GLOBAL uint64_t*)p = v; }
 
@@ -475,23 +498,29 @@ __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_
         if (!dst) continue;
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            st16<NT>(sgpr_base(dst + pos[j]) + lo, v[j]);
+            st16<NT>(sgpr_base(dst + pos[j]), lo, v[j]);
         }
     }
     if (!a.src_is_live) {
 #pragma unroll
-        for (int j = 0; j < B; ++j) st16<false>(sgpr_base(a.live + pos[j]) + lo, v[j]);
+        for (int j = 0; j < B; ++j) st16<false>(sgpr_base(a.live + pos[j]), lo, v[j]);
     }
 }
 
-template <bool CKS_T, bool CKS_V, bool NT>
+// RESTL > 0: the (up to RESTL) word rows the schedule never touches stay in registers too and every Save stores
+// its snapshot's full tile (schedule-owned rows + rest rows) together, instead of the up-front fan-out: fewer
+// workgroups resident (4 * RESTL more VGPRs), each snapshot's tile written as one burst.  Measured 128-129 us vs
+// 126-136 us (the plain variant is bimodal with the arena's placement, profiles/README.md); default when the
+// world has at most RESTL such rows, GGRS_TICK_REST=0 selects the fan-out variant.
+template <bool CKS_T, bool CKS_V, bool NT, int RESTL = 0>
 __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool in_len = (uint64_t)t * TILE < a.len;               // workgroup-uniform
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
-    // 32-bit per-lane byte offsets (capacity is capped at 2^28 slots): every access below is
-    // "uniform 64-bit base + 32-bit lane offset", i.e. the saddr form of global_load/store
-    const uint32_t o4 = (uint32_t)e0 * 4u, o8 = (uint32_t)e0 * 8u;
+    // every access below is "uniform 64-bit base (block + column row + tile offset) + 32-bit lane
+    // offset", i.e. the saddr form of global_load/store
+    const uint64_t toff = (uint64_t)t * a.ts;                     // this tile inside a block (tile-major columns)
+    const uint32_t o4 = tid * 16u, o8 = tid * 32u;                // lane offsets inside a 4- / 8-byte column's tile rows
     const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
     const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;                 // byte offset of this lane's mask word
@@ -505,11 +534,11 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
     ulonglong2 tl[2];
     if (in_len) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + o4);
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + toff + o4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + o4);
-        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + o8);
-        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + 16 + o8);
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + toff + o4);
+        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + toff + o8);
+        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + toff + 16 + o8);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
@@ -525,7 +554,19 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
             if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
         if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
     }
-    if (in_len && (a.n_saves || !a.src_is_live)) {
+    u32x4 restv[RESTL > 0 ? RESTL : 1];
+    uint64_t restpos[RESTL > 0 ? RESTL : 1];
+    if (RESTL > 0) {
+#pragma unroll
+        for (int j = 0; j < RESTL; ++j) {
+            restv[j] = u32x4{0, 0, 0, 0}; restpos[j] = 0;
+            if ((uint32_t)j < a.n_rest_rows) {                   // wave-uniform
+                const RowLite rd = a.rest[j];
+                restpos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff;
+                if (in_len) restv[j] = *reinterpret_cast<const u32x4*>(a.src + restpos[j] + tid * 16u);
+            }
+        }
+    } else if (in_len && (a.n_saves || !a.src_is_live)) {
         // batches of up to 8 rows: while this phase runs only the schedule-owned state is live in
         // registers (the hash temporaries come later), so 32 more VGPRs are free.  The particles world
         // has 7 such rows: ONE batch, one wait shared with the state loads above, then stores only.
@@ -610,11 +651,15 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
                 if (in_len) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        st16<NT>(sgpr_base(dst + a.off_t[k]) + o4, tx[k]);
-                        st16<NT>(sgpr_base(dst + a.off_v[k]) + o4, vv[k]);
+                        st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, tx[k]);
+                        st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, vv[k]);
                     }
-                    st16<NT>(sgpr_base(dst + a.off_ttl) + o8, tl[0]);
-                    st16<NT>(sgpr_base(dst + a.off_ttl + 16) + o8, tl[1]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl + toff), o8, tl[0]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl + toff + 16), o8, tl[1]);
+                    if (RESTL > 0) {
+#pragma unroll
+                        for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<NT>(sgpr_base(dst + restpos[j]), tid * 16u, restv[j]);
+                    }
                 }
                 uint64_t mine = 0;
 #pragma unroll
@@ -675,11 +720,15 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
         if (in_len) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                st16<false>(sgpr_base(a.live + a.off_t[k]) + o4, tx[k]);
-                st16<false>(sgpr_base(a.live + a.off_v[k]) + o4, vv[k]);
+                st16<false>(sgpr_base(a.live + a.off_t[k] + toff), o4, tx[k]);
+                st16<false>(sgpr_base(a.live + a.off_v[k] + toff), o4, vv[k]);
             }
-            st16<false>(sgpr_base(a.live + a.off_ttl) + o8, tl[0]);
-            st16<false>(sgpr_base(a.live + a.off_ttl + 16) + o8, tl[1]);
+            st16<false>(sgpr_base(a.live + a.off_ttl + toff), o8, tl[0]);
+            st16<false>(sgpr_base(a.live + a.off_ttl + toff + 16), o8, tl[1]);
+            if (RESTL > 0 && !a.src_is_live) {
+#pragma unroll
+                for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<false>(sgpr_base(a.live + restpos[j]), tid * 16u, restv[j]);
+            }
         }
         const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
                        b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
@@ -713,7 +762,9 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool in_len = (uint64_t)t * TILE1 < a.len;              // workgroup-uniform
     const uint32_t e = t * TILE1 + tid;                           // this lane's slot
-    const uint32_t o4 = e * 4u, o8 = e * 8u;
+    const uint64_t toff = (uint64_t)(t >> 2) * a.ts;              // its 1024-slot tile inside a block (tile-major columns)
+    const uint32_t ti = (t & 3u) * TILE1 + tid;                   // its index inside that tile
+    const uint32_t o4 = ti * 4u, o8 = ti * 8u;
     const uint32_t wi8 = (t * 4u + wave) * 8u;                    // this wave's mask word
 
     const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
@@ -724,10 +775,10 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     uint64_t ttl = 0;
     if (in_len) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float*>(a.src + a.off_t[k] + o4);
+        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float*>(a.src + a.off_t[k] + toff + o4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float*>(a.src + a.off_v[k] + o4);
-        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + o8);
+        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float*>(a.src + a.off_v[k] + toff + o4);
+        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + toff + o8);
     }
 
     // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
@@ -740,8 +791,8 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
     }
     if (in_len && (a.n_saves || !a.src_is_live)) {
-        // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0 and
-        // word_bytes = tile_stride / 1024.  Up to 8 columns per batch, one wait per batch.
+        // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0.
+        // Up to 8 columns per batch, one wait per batch.
         const uint32_t n_rows = a.n_rest_rows;
         uint32_t r = 0;
         while (r < n_rows) {
@@ -754,9 +805,9 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 while (r < n_rows && a.rest[r].roff != 0) ++r;
                 if (r < n_rows) {
                     const RowLite rd = a.rest[r]; ++r;
-                    wb[j] = rd.tile_stride >> 10; off[j] = rd.col_off; nb = j + 1;
-                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + o8);
-                    else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + o4);
+                    wb[j] = rd.word_bytes; off[j] = rd.col_off; nb = j + 1;
+                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + toff + o8);
+                    else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + toff + o4);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): land the loads once
@@ -766,8 +817,8 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nb) {
-                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + o8) = v[j];
-                        else *reinterpret_cast<uint32_t*>(dst + off[j] + o4) = (uint32_t)v[j];
+                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + toff + o8) = v[j];
+                        else *reinterpret_cast<uint32_t*>(dst + off[j] + toff + o4) = (uint32_t)v[j];
                     }
                 }
             }
@@ -790,10 +841,10 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 if (in_len) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        *reinterpret_cast<float*>(dst + a.off_t[k] + o4) = tx[k];
-                        *reinterpret_cast<float*>(dst + a.off_v[k] + o4) = vv[k];
+                        *reinterpret_cast<float*>(dst + a.off_t[k] + toff + o4) = tx[k];
+                        *reinterpret_cast<float*>(dst + a.off_v[k] + toff + o4) = vv[k];
                     }
-                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + o8) = ttl;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + toff + o8) = ttl;
                 }
                 if (lane == 0) {
                     *reinterpret_cast<uint64_t*>(dst + a.off_alive + wi8) = alive_now;
@@ -844,10 +895,10 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         if (in_len) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                *reinterpret_cast<float*>(a.live + a.off_t[k] + o4) = tx[k];
-                *reinterpret_cast<float*>(a.live + a.off_v[k] + o4) = vv[k];
+                *reinterpret_cast<float*>(a.live + a.off_t[k] + toff + o4) = tx[k];
+                *reinterpret_cast<float*>(a.live + a.off_v[k] + toff + o4) = vv[k];
             }
-            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + o8) = ttl;
+            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + toff + o8) = ttl;
         }
         const uint64_t alive_now = __ballot(alive);
         if (lane == 0) {
@@ -931,7 +982,7 @@ __global__ __launch_bounds__(TPB) void k_checksum(CksArgs a, const UnitDesc* __r
 #pragma unroll 1
             for (uint32_t u = 0; u < n; ++u) {
                 const UnitDesc ud = units[ub + u];
-                s.unit(*reinterpret_cast<const uint32_t*>(a.state + ud.off + e * ud.stride));
+                s.unit(*reinterpret_cast<const uint32_t*>(a.state + col_at(ud.off, ud.ts, ud.stride, e)));
             }
             h ^= sea_pair(e, s.finish());
         }
@@ -950,13 +1001,13 @@ __global__ __launch_bounds__(TPB) void k_checksum(CksArgs a, const UnitDesc* __r
 // ------------------------------------------------------------------ generic systems
 // benches/bench.rs:30-46 (increment_foos ...), tests/component_rollback.rs:24-28
 __global__ __launch_bounds__(TPB) void k_add_u32(uint8_t* state, uint64_t off_alive, uint64_t off_present,
-                                                 uint64_t off_col, uint32_t delta, uint64_t len) {
+                                                 uint64_t off_col, uint32_t ts, uint32_t delta, uint64_t len) {
     const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= len) return;
     const uint64_t m = *reinterpret_cast<const uint64_t*>(state + off_alive + (e >> 6) * 8) &
                        *reinterpret_cast<const uint64_t*>(state + off_present + (e >> 6) * 8);
     if ((m >> (e & 63)) & 1ULL) {
-        uint32_t* p = reinterpret_cast<uint32_t*>(state + off_col + e * 4);
+        uint32_t* p = reinterpret_cast<uint32_t*>(state + col_at(off_col, ts, 4, e));
         *p = *p + delta;
     }
 }
@@ -966,7 +1017,7 @@ __global__ __launch_bounds__(TPB) void k_add_u32(uint8_t* state, uint64_t off_al
 // disabled -- RollbackDespawned(frame) -- instead of freed.
 struct DespawnMarks { uint64_t off_disabled, off_dframe; };   // live-only side state (outside every snapshot)
 __global__ __launch_bounds__(TPB) void k_sat_sub_despawn(uint8_t* state, uint64_t off_alive, uint64_t off_present,
-                                                         uint64_t off_col, uint32_t amount, uint64_t len_pad64,
+                                                         uint64_t off_col, uint32_t ts, uint32_t amount, uint64_t len_pad64,
                                                          int defer, int32_t frame, DespawnMarks dm) {
     const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= len_pad64) return;                       // whole waves only (len padded to 64)
@@ -975,7 +1026,7 @@ __global__ __launch_bounds__(TPB) void k_sat_sub_despawn(uint8_t* state, uint64_
     bool alive = (aw >> (e & 63)) & 1ULL;
     bool killed = false;
     if (alive && ((pw >> (e & 63)) & 1ULL)) {
-        uint32_t* p = reinterpret_cast<uint32_t*>(state + off_col + e * 4);
+        uint32_t* p = reinterpret_cast<uint32_t*>(state + col_at(off_col, ts, 4, e));
         const uint32_t v = *p >= amount ? *p - amount : 0u;
         *p = v;
         if (v == 0) { alive = false; killed = true; }
@@ -1000,6 +1051,7 @@ struct BoxMoveArgs {
     uint8_t* state;
     uint64_t off_alive, off_pT, off_pV, off_pP;
     uint64_t off_t[3], off_v[3], off_handle;
+    uint32_t ts_t, ts_v, ts_handle, pad0;   // tile strides of the three components' columns
     uint64_t len;
     uint32_t dt_bits, friction_pow_bits;
     float accel, max_speed, half_width;
@@ -1016,16 +1068,16 @@ __global__ __launch_bounds__(TPB) void k_box_move(BoxMoveArgs a) {
                        *reinterpret_cast<const uint64_t*>(a.state + a.off_pV + wi8) &
                        *reinterpret_cast<const uint64_t*>(a.state + a.off_pP + wi8);
     if (!((m >> b) & 1ULL)) return;
-    const uint64_t handle = *reinterpret_cast<const uint64_t*>(a.state + a.off_handle + e * 8);
+    const uint64_t handle = *reinterpret_cast<const uint64_t*>(a.state + col_at(a.off_handle, a.ts_handle, 8, e));
     if (handle >= a.n_inputs) return;                  // inputs[p.handle] would panic in the reference
     const uint8_t in = a.inputs[handle];
     const float dt = __uint_as_float(a.dt_bits), fp = __uint_as_float(a.friction_pow_bits);
-    float* px = reinterpret_cast<float*>(a.state + a.off_t[0] + e * 4);
-    float* pz = reinterpret_cast<float*>(a.state + a.off_t[2] + e * 4);
-    float* py = reinterpret_cast<float*>(a.state + a.off_t[1] + e * 4);
-    float* pvx = reinterpret_cast<float*>(a.state + a.off_v[0] + e * 4);
-    float* pvy = reinterpret_cast<float*>(a.state + a.off_v[1] + e * 4);
-    float* pvz = reinterpret_cast<float*>(a.state + a.off_v[2] + e * 4);
+    float* px = reinterpret_cast<float*>(a.state + col_at(a.off_t[0], a.ts_t, 4, e));
+    float* pz = reinterpret_cast<float*>(a.state + col_at(a.off_t[2], a.ts_t, 4, e));
+    float* py = reinterpret_cast<float*>(a.state + col_at(a.off_t[1], a.ts_t, 4, e));
+    float* pvx = reinterpret_cast<float*>(a.state + col_at(a.off_v[0], a.ts_v, 4, e));
+    float* pvy = reinterpret_cast<float*>(a.state + col_at(a.off_v[1], a.ts_v, 4, e));
+    float* pvz = reinterpret_cast<float*>(a.state + col_at(a.off_v[2], a.ts_v, 4, e));
     float vx = *pvx, vy = *pvy, vz = *pvz;
     const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT;
     const float adt = __fmul_rn(a.accel, dt);
@@ -1145,12 +1197,12 @@ __global__ void k_edit_mask_bit(uint8_t* state, uint64_t mask_off, uint64_t slot
     if (value) *p |= 1ULL << (slot & 63); else *p &= ~(1ULL << (slot & 63));
 }
 // Fill one column over [first, first+count) with a constant word (component defaults).
-__global__ __launch_bounds__(TPB) void k_fill_col(uint8_t* state, uint64_t col_off, uint32_t word_bytes,
+__global__ __launch_bounds__(TPB) void k_fill_col(uint8_t* state, uint64_t col_off, uint32_t ts, uint32_t word_bytes,
                                                   uint64_t first, uint64_t count, uint64_t value) {
     const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= count) return;
-    if (word_bytes == 4) *reinterpret_cast<uint32_t*>(state + col_off + (first + i) * 4) = (uint32_t)value;
-    else *reinterpret_cast<uint64_t*>(state + col_off + (first + i) * 8) = value;
+    if (word_bytes == 4) *reinterpret_cast<uint32_t*>(state + col_at(col_off, ts, 4, first + i)) = (uint32_t)value;
+    else *reinterpret_cast<uint64_t*>(state + col_at(col_off, ts, 8, first + i)) = value;
 }
 // spawn_particles (particles.rs:258-270) payload: Velocity(vx, vy, 0.0), Ttl(ttl); Transform gets
 // its default through k_fill_col.  Also emits checksum partials for the new rows so a fused
@@ -1158,6 +1210,7 @@ __global__ __launch_bounds__(TPB) void k_fill_col(uint8_t* state, uint64_t col_o
 struct SpawnArgs {
     uint8_t* state;
     uint64_t off_t[3], off_v[3], off_ttl;
+    uint32_t ts;                          // tile stride of the rollback word columns
     uint32_t t_default[3];
     const float* vx; const float* vy;
     uint64_t first, count, ttl;
@@ -1172,10 +1225,10 @@ __global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
     if (i < a.count) {
         const uint64_t e = a.first + i;
         const float vx = a.vx[i], vy = a.vy[i];
-        *reinterpret_cast<float*>(a.state + a.off_v[0] + e * 4) = vx;
-        *reinterpret_cast<float*>(a.state + a.off_v[1] + e * 4) = vy;
-        *reinterpret_cast<float*>(a.state + a.off_v[2] + e * 4) = 0.0f;
-        *reinterpret_cast<uint64_t*>(a.state + a.off_ttl + e * 8) = a.ttl;
+        *reinterpret_cast<float*>(a.state + col_at(a.off_v[0], a.ts, 4, e)) = vx;
+        *reinterpret_cast<float*>(a.state + col_at(a.off_v[1], a.ts, 4, e)) = vy;
+        *reinterpret_cast<float*>(a.state + col_at(a.off_v[2], a.ts, 4, e)) = 0.0f;
+        *reinterpret_cast<uint64_t*>(a.state + col_at(a.off_ttl, a.ts, 8, e)) = a.ttl;
         if (a.cks_T) hT = sea_pair(e, sea_inner3(a.t_default[0], a.t_default[1], a.t_default[2]));
         if (a.cks_V) hV = sea_pair(e, sea_inner3(__float_as_uint(vx), __float_as_uint(vy), 0u));
         cnt = 1;

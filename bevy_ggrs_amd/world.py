@@ -313,10 +313,13 @@ class World(WorldBase):
     def adopt_live_state(self):
         self._check(self._lib.ggrs_hip_adopt_live_state(self._p))
 
-    def column_device_ptr(self, comp: int, word: int) -> int:
+    def column_device_ptr(self, comp: int, word: int):
+        """(device address of element 0, tile stride in bytes): element e of the column lives at
+        ptr + (e // 1024) * tile_stride + (e % 1024) * word_bytes (tile-major word columns)."""
         p = C.c_void_p()
-        self._check(self._lib.ggrs_hip_column_device_ptr(self._p, comp, word, C.byref(p)))
-        return p.value
+        ts = C.c_uint64(0)
+        self._check(self._lib.ggrs_hip_column_device_ptr(self._p, comp, word, C.byref(p), C.byref(ts)))
+        return p.value, ts.value
 
     def profile_enable(self, on: bool = True):
         self._check(self._lib.ggrs_hip_profile_enable(self._p, 1 if on else 0))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 3
+#define GGRS_HIP_ABI_VERSION 4
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -176,8 +176,12 @@ int ggrs_hip_download_word(ggrs_world* w, uint32_t comp_id, uint32_t word, uint6
                            uint64_t count, void* host_dst);
 int ggrs_hip_download_alive(ggrs_world* w, uint64_t* host_dst, uint64_t n_words64);
 int ggrs_hip_download_present(ggrs_world* w, uint32_t comp_id, uint64_t* host_dst, uint64_t n_words64);
-/* device address of a live column (for zero-copy interop, e.g. RCCL through torch tensors) */
-int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr);
+/* device address of a live column (for zero-copy interop).  Word columns are stored tile-major: element e
+ * of the column lives at dev_ptr + (e / 1024) * tile_stride + (e % 1024) * word_bytes; *tile_stride (may be
+ * NULL) is 1024 * word_bytes for a plain array (non-rollback components) and the bytes of all rollback words
+ * of 1024 slots otherwise. */
+int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr,
+                               uint64_t* tile_stride);
 
 uint64_t ggrs_hip_len(ggrs_world* w);            /* RollbackOrdered::len (rollback.rs:91-93)   */
 int      ggrs_hip_active_count(ggrs_world* w, uint64_t* out);   /* live Rollback entities    */

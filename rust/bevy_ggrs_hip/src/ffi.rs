@@ -1,9 +1,9 @@
-//! Raw bindings to `include/ggrs_hip.h` (ABI version 3) -- what `bindgen` emits, by hand.
+//! Raw bindings to `include/ggrs_hip.h` (ABI version 4) -- what `bindgen` emits, by hand.
 //! UN-BUILT SOURCE: kept in lock-step with the header by tests/test_abi.py.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 3;
+pub const GGRS_HIP_ABI_VERSION: c_int = 4;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -110,7 +110,7 @@ unsafe extern "C" {
     pub fn ggrs_hip_download_word(w: *mut ggrs_world, comp_id: u32, word: u32, first: u64, count: u64, host_dst: *mut c_void) -> c_int;
     pub fn ggrs_hip_download_alive(w: *mut ggrs_world, host_dst: *mut u64, n_words64: u64) -> c_int;
     pub fn ggrs_hip_download_present(w: *mut ggrs_world, comp_id: u32, host_dst: *mut u64, n_words64: u64) -> c_int;
-    pub fn ggrs_hip_column_device_ptr(w: *mut ggrs_world, comp_id: u32, word: u32, dev_ptr: *mut *mut c_void) -> c_int;
+    pub fn ggrs_hip_column_device_ptr(w: *mut ggrs_world, comp_id: u32, word: u32, dev_ptr: *mut *mut c_void, tile_stride: *mut u64) -> c_int;
     pub fn ggrs_hip_len(w: *mut ggrs_world) -> u64;
     pub fn ggrs_hip_active_count(w: *mut ggrs_world, out: *mut u64) -> c_int;
     // ---- frame counters and the snapshot ring

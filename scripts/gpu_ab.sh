@@ -1,0 +1,23 @@
+#!/bin/bash
+# A/B of k_tick launch knobs (env): GGRS_TICK_LDS (occupancy throttle), GGRS_TICK_REST (rest rows stored per Save).
+TAG=${1:-ab}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -v 'RCCL\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -6 | tee $OUT/pytest.log
+run() {
+  label="$1"; shift
+  env "$@" timeout 200 python bench.py --no-cpu-baseline --steps 300 $BENCH_EXTRA 2>>$OUT/err.log | tee -a $OUT/lines.jsonl | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); r=d['roofline']
+    print('[$label]', 'G ef/s=%.2f ms/step=%.4f kernel_us=%.1f frac=%.3f' % (d['value']/1e9, d['ms_per_step'], r['avg_launch_us'], r['frac']))"
+}
+run "default (rest rows per save)" A=1
+run "default #2" A=1
+run "GGRS_TICK_REST=0 (up-front fan-out)" GGRS_TICK_REST=0
+BENCH_EXTRA="--entities 4000000" run "4M" A=1
+BENCH_EXTRA="--entities 100000" run "100k" A=1
+BENCH_EXTRA="--sync" run "sync" A=1
+BENCH_EXTRA="--fanout" run "fanout path, world size 1" A=1
+tail -3 $OUT/err.log
