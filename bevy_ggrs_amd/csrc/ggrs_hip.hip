@@ -1303,14 +1303,15 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     if (w->tick_ok) {
         rc = run_request_groups(w, reqs, n, nullptr, b.first, false, nullptr);
         if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
-    } else {                                   // worlds without request-group kernels: run now, hand back later
-        b.host.assign(2 * (size_t)n_save + 2, 0);
+    } else {
+        // worlds without request-group kernels: one launch per request, enqueued like the groups are; every
+        // Save's fold writes straight into its slot of the pinned result ring, nothing is waited for here
         uint32_t ns = 0;
         for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
             const ggrs_request& r = reqs[i];
             apply_synctest_confirmed(w);
             switch (r.kind) {
-            case GGRS_REQ_SAVE: rc = do_save(w, 0); if (!rc) rc = read_back(w, 1, &b.host[2 * (size_t)ns]); ++ns; break;
+            case GGRS_REQ_SAVE: rc = do_save(w, b.first + ns); ++ns; break;
             case GGRS_REQ_LOAD: rc = do_load(w, r.frame); break;
             case GGRS_REQ_ADVANCE: rc = do_advance(w, r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy); break;
             default: rc = w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);

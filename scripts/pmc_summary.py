@@ -53,6 +53,7 @@ def main():
                 roof["k_copy_state_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
     if roof:
         roof["source"] = os.path.join(dst, "pmc_summary.json")
+        roof["entities"] = 1000000; roof["depth"] = 8       # the workload scripts/gpu_round.sh profiles (bench.py defaults)
         json.dump(roof, open(os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

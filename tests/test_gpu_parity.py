@@ -160,14 +160,16 @@ def test_full_size_properties_1m():
     assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
-def test_async_enqueue_collect_matches_sync():
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_NO_GROUPS, bg.GGRS_WORLD_UNFUSED])
+def test_async_enqueue_collect_matches_sync(flags):
     """ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums: same checksums and state as the
-    synchronous call, batches collected oldest-first, sync calls refused while batches are pending."""
+    synchronous call, batches collected oldest-first, sync calls refused while batches are pending
+    (request-group worlds and one-launch-per-request worlds alike)."""
     n = 3000
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     out = []
     for mode in ("sync", "async"):
-        w = bg.World(n + 2000, max_depth=9)
+        w = bg.World(n + 2000, max_depth=9, flags=flags)
         ids = cm.build_particles(w, with_spawn=True, ttl_init=30)
         cm.spawn_particles(w, ids, n, vel, ttl)
         w.set_depth(9)
