@@ -99,20 +99,38 @@ def warm_ring(bg, w, depth):
 
 
 def cpu_baseline(n, depth, budget_ticks):
-    from oracle.binding import REFSHAPED, OracleWorld, lib
+    """The CPU path timed beside the GPU line: the oracle's REFERENCE-SHAPED variant (per-save hash-map
+    rebuild, per-entity lookups: the reference's cost structure) on ONE thread -- SaveWorld/LoadWorld are
+    sequential `for` loops in the reference and AdvanceWorld runs single-threaded (src/lib.rs:236-240).  Also
+    reported: the oracle's FLAT variant (SoA + memcpy ring, the best a CPU port could do) on many host cores."""
+    from oracle.binding import FLAT, REFSHAPED, OracleWorld, lib
     import common as cm
-    w = OracleWorld(n, depth + 1, REFSHAPED)
-    ids = cm.build_particles(w)
-    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
-    cm.spawn_particles(w, ids, n, vel, ttl)
-    w.set_depth(depth + 1)
+
+    def world(mode):
+        w = OracleWorld(n, depth + 1, mode)
+        ids = cm.build_particles(w)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(depth + 1)
+        return w
+    w = world(REFSHAPED)
     lib.gor_set_num_threads(1)
     secs = w.bench_synctest(depth, depth + 1, budget_ticks)
+    del w
+    cores = os.cpu_count() or 1
+    flat_threads = max(1, min(64, cores))
+    wf = world(FLAT)
+    lib.gor_set_num_threads(flat_threads)
+    flat_ticks = 8 * budget_ticks
+    fsecs = wf.bench_synctest(depth, depth + 1, flat_ticks)
+    lib.gor_set_num_threads(1)
     return {"value": n * (depth + 1) * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
             "kind": "port",
             "sample": f"{budget_ticks} steady-state SyncTest ticks (depth {depth}) of the same {n}-entity x 3-component "
                       f"world on the oracle's reference-shaped storage (per-save HashMap rebuild), {secs:.1f} s",
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": cores,
+            "flat_soa_port": {"value": n * (depth + 1) * flat_ticks / fsecs, "unit": "entity-frames/s", "cores": flat_threads,
+                              "sample": f"{flat_ticks} ticks of the oracle's flat SoA + memcpy-ring variant (OpenMP), {fsecs:.1f} s"}}
 
 
 def main():

@@ -64,7 +64,7 @@ typedef struct {
 } ggrs_world_desc;
 
 #define GGRS_WORLD_DEFAULT      0u
-#define GGRS_WORLD_NO_GRAPH     1u   /* never capture request batches into hipGraphs           */
+#define GGRS_WORLD_NO_GRAPH     1u   /* reserved, no effect: request-group fusion made a tick 2 launches */
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */

@@ -87,6 +87,23 @@ def main():
                       "folds": {k: f"{fold(v):016x}" for k, v in st.items() if isinstance(v, np.ndarray) and k.startswith("c")}},
         }
     out["particles_synctest"] = cases
+    # ---- further scenarios (SURVEY 8f rows + BASELINE configs 1 and 4): both oracle shapes must agree before freezing
+    import golden_util as gu
+    scen = {
+        "box_game_synctest": {"2p_cd7": {"n": 2, "players": 2, "check_distance": 7, "ticks": 40},
+                              "300cubes_4p_cd3": {"n": 300, "players": 4, "check_distance": 3, "ticks": 25}},
+        "despawn_rollback_synctest": {"n200_cd3": {"n": 200, "ticks": 16, "check_distance": 3},
+                                      "n5000_cd2": {"n": 5000, "ticks": 14, "check_distance": 2}},
+        "p2p_shape": {"n600": {"n": 600, "ticks": 60}, "n3000": {"n": 3000, "ticks": 80}},
+    }
+    out["scenarios"] = {}
+    for kind, cases_ in scen.items():
+        out["scenarios"][kind] = {}
+        for name, args in cases_.items():
+            a = gu.SCENARIOS[kind](lambda cap, depth: OracleWorld(cap, depth, FLAT), args)
+            b = gu.SCENARIOS[kind](lambda cap, depth: OracleWorld(cap, depth, REFSHAPED), args)
+            assert a == b, (kind, name, "flat and reference-shaped oracle disagree")
+            out["scenarios"][kind][name] = {"args": args, "expect": a}
     with open(os.path.join(HERE, "hot_path_vectors.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "hot_path_vectors.json"))

@@ -36,3 +36,40 @@ def replay_particles_case(make_world, case):
     assert (int(st["len"]), int(st["frame"]), int(st["alive"].sum())) == (fin["len"], fin["frame"], fin["active"])
     for k, want in fin["folds"].items():
         assert f"{fold(st[k]):016x}" == want, k
+
+
+def _state_folds(st):
+    return {k: f"{fold(np.asarray(v).astype(np.uint64)):016x}" for k, v in sorted(st.items())
+            if isinstance(v, np.ndarray)}
+
+
+# ---- scenario runners shared by the generator (oracle) and the replays (oracle on CPU, HIP on GPU)
+def run_box_game(make_world, a):
+    from test_box_game import synctest_box_game
+    cs, trace = synctest_box_game(make_world(a["n"] + 8, 8), a["players"], a["check_distance"], a["ticks"], a["n"])
+    t, v = trace[-1]
+    return {"n_checksums": len(cs), "checksums_head": [[int(f), f"{c:032x}"] for f, c in cs[:12]],
+            "translation_fold": f"{fold(t.reshape(-1)):016x}", "velocity_fold": f"{fold(v.reshape(-1)):016x}",
+            "cube0": [f"{int(x):08x}" for x in list(t[0]) + list(v[0])]}
+
+
+def run_despawn_rollback(make_world, a):
+    from test_despawn_rollback import synctest_run
+    cs, trace = synctest_run(make_world(a["n"] + 56, 8), a["n"], a["ticks"], a["check_distance"])
+    mid, last = trace[a["ticks"] // 3], trace[-1]
+    return {"checksums": [[int(f), f"{c:032x}"] for f, c in cs], "mid": _state_folds(mid), "last": _state_folds(last)}
+
+
+def run_p2p_shape(make_world, a):
+    from test_oracle_selfcheck import _p2p_run
+    drv, st = _p2p_run(make_world(a["n"] + 40 * (a["ticks"] + 10) + 64, 8), a["n"], a["ticks"])
+    return {"depths": [int(d) for d in drv.depths], "checksums": [[int(f), f"{c:032x}"] for f, c in drv.all_checksums],
+            "final": _state_folds(st), "len": int(st["len"]), "frame": int(st["frame"])}
+
+
+SCENARIOS = {"box_game_synctest": run_box_game, "despawn_rollback_synctest": run_despawn_rollback, "p2p_shape": run_p2p_shape}
+
+
+def replay_scenario(make_world, kind, case):
+    got = SCENARIOS[kind](make_world, case["args"])
+    assert got == case["expect"], {k: (got[k], case["expect"][k]) for k in got if got[k] != case["expect"][k]}
