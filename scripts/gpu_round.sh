@@ -24,6 +24,7 @@ BENCH="python bench.py --steps 50 --warmup 8 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- $BENCH > $OUT/prof_stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/prof_fetch -o fetch -- $BENCH > $OUT/prof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/prof_write -o write -- $BENCH > $OUT/prof_write.log 2>&1
+python scripts/kernel_trace_steady.py $OUT/prof_stats $OUT/kernel_trace_steady.json > /dev/null 2>&1
 # keep only csv summaries (sqlite dbs can be large)
 find $OUT -name '*.db' -size +20M -delete
 ls -laR $OUT | head -80
