@@ -102,6 +102,13 @@ struct ggrs_world {
     TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
     uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
     int tick_vec = 0;                    // 0: pick per launch by size; 1 / 4: forced (GGRS_TICK_VEC, A/B knob)
+    // generic fused request groups (k_tick_gen): any mix of the supported kernel systems, state staged in LDS
+    bool gen_ok = false;
+    GenArgs gen_proto{};                 // layout part of the kernel arguments, filled at seal
+    uint32_t gen_sub_max = 0;            // largest slots-per-workgroup whose LDS image fits 64 KiB
+    GenWord* d_gen_words = nullptr; GenUnit* d_gen_units = nullptr;
+    uint64_t* d_gen_parts = nullptr;     // [MAX_TICK_SAVES][n_cks + 1][tick_part_stride]
+    int gen_box_sys = -1;                // index of a BOX_MOVE system (its FRICTION.powf(dt) is evaluated per step on the host)
     uint64_t block_pad = 0, col_pad = 0; // extra bytes between ring blocks / columns (GGRS_BLOCK_PAD / GGRS_COL_PAD, A/B knobs; library-owned arenas only)
     uint32_t tick_lds = 0;               // dynamic LDS bytes per k_tick workgroup: occupancy throttle (GGRS_TICK_LDS, A/B knob)
     int tick_rest_loop = 1;              // rest rows stored with each Save (default) instead of the up-front fan-out (GGRS_TICK_REST=0)
@@ -340,6 +347,91 @@ int seal(ggrs_world* w) {
         w->tick_ok = true;
     }
 
+
+    // ---- generic fused request groups (k_tick_gen): every world whose systems it implements and whose words fit in LDS
+    w->gen_ok = false; w->gen_box_sys = -1;
+    std::vector<GenWord> gwords; std::vector<GenUnit> gunits;
+    if (!w->tick_ok && !(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && w->systems.size() <= (size_t)GEN_MAX_SYS &&
+        w->cks_comp.size() <= (size_t)GEN_MAX_CKS) {
+        GenArgs& a = w->gen_proto;
+        memset(&a, 0, sizeof a);
+        const uint32_t bps = w->ts / TILE;                                   // bytes per slot of all rollback words
+        uint32_t sub = 0;
+        for (uint32_t cand : {1024u, 512u, 256u}) if ((uint64_t)bps * cand + (uint64_t)w->plan.n_masks * (cand / 8) <= 65536) { sub = cand; break; }
+        bool ok = sub != 0;
+        const uint64_t cols_base = w->plan.n_rows ? w->plan.row[0].col_off : 0;   // every rollback column: cols_base + tcol
+        uint64_t min_off = ~0ULL;
+        for (uint32_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback)
+            for (uint32_t k = 0; k < w->comps[c].n_words; ++k) min_off = std::min(min_off, w->col_off[w->comps[c].col_base + k]);
+        a.cols_base = min_off == ~0ULL ? cols_base : min_off;
+        auto pso_of = [&](uint32_t col) { return (uint32_t)((w->col_off[col] - a.cols_base) / TILE); };
+        auto mask_index = [&](uint32_t comp) -> uint32_t {                    // index into plan.mask_off (0 = liveness)
+            for (uint32_t m = 1; m < w->plan.n_masks; ++m) if (w->plan.mask_off[m] == w->off_present[comp]) return m;
+            return ~0u;
+        };
+        for (uint32_t c = 0; c < w->comps.size(); ++c) {
+            const Comp& cc = w->comps[c];
+            if (cc.no_rollback) continue;
+            for (uint32_t k = 0; k < cc.n_words; ++k) gwords.push_back({(uint32_t)(w->col_off[cc.col_base + k] - a.cols_base), cc.word_bytes, pso_of(cc.col_base + k), 0});
+        }
+        a.ts = w->ts; a.n_words = (uint32_t)gwords.size(); a.n_masks = w->plan.n_masks;
+        for (uint32_t m = 0; m < w->plan.n_masks; ++m) a.mask_off[m] = w->plan.mask_off[m];
+        // checksum specs
+        a.n_cks = (uint32_t)w->cks_comp.size();
+        for (uint32_t k = 0; k < a.n_cks && ok; ++k) {
+            const Comp& cc = w->comps[w->cks_comp[k]];
+            if (cc.no_rollback) { ok = false; break; }
+            a.cks_pmask[k] = mask_index(w->cks_comp[k]);
+            a.cks_unit_base[k] = (uint32_t)gunits.size();
+            for (uint32_t wi : cc.cks_words) {
+                const uint32_t pso = pso_of(cc.col_base + wi);
+                gunits.push_back({pso, 0, cc.word_bytes, 0});
+                if (cc.word_bytes == 8) gunits.push_back({pso, 4, 8, 0});
+            }
+            a.cks_n_units[k] = (uint32_t)gunits.size() - a.cks_unit_base[k];
+        }
+        // systems
+        a.n_sys = 0;
+        for (size_t i = 0; i < w->systems.size() && ok; ++i) {
+            const ggrs_system_desc& d = w->systems[i];
+            if (d.kind == GGRS_SYS_PARTICLES_SPAWN) continue;                 // a firing spawn system ends the group (Commands flush)
+            GenSys& y = a.sys[a.n_sys];
+            memset(&y, 0, sizeof y);
+            y.kind = d.kind; y.iparam[0] = d.iparam[0]; y.iparam[1] = d.iparam[1];
+            for (int k = 0; k < 4; ++k) y.fparam[k] = d.fparam[k];
+            y.pmask[0] = y.pmask[1] = y.pmask[2] = ~0u;
+            auto rb = [&](uint32_t comp) { return comp < w->comps.size() && !w->comps[comp].no_rollback; };
+            switch (d.kind) {
+            case GGRS_SYS_PARTICLES_UPDATE: case GGRS_SYS_BOX_MOVE:
+                if (!rb(d.comp[0]) || !rb(d.comp[1])) { ok = false; break; }
+                for (uint32_t k = 0; k < 3; ++k) {
+                    y.pso[k] = pso_of(w->comps[d.comp[0]].col_base + d.word[0] + k);
+                    y.pso[3 + k] = pso_of(w->comps[d.comp[1]].col_base + d.word[1] + k);
+                }
+                y.pmask[0] = mask_index(d.comp[0]); y.pmask[1] = mask_index(d.comp[1]);
+                if (d.kind == GGRS_SYS_BOX_MOVE) {
+                    const uint32_t hc = w->comps[d.comp[2]].col_base + d.word[2];
+                    if (rb(d.comp[2])) { y.pmask[2] = mask_index(d.comp[2]); y.pso_h = pso_of(hc); }
+                    else { y.side_off = w->col_off[hc]; y.side_ts = w->col_ts[hc]; y.side_pmask_off = w->off_present[d.comp[2]]; }
+                    w->gen_box_sys = (int)i;
+                }
+                break;
+            case GGRS_SYS_TTL_DESPAWN: case GGRS_SYS_ADD_U32:
+                if (!rb(d.comp[0])) { ok = false; break; }
+                y.pso[0] = pso_of(w->comps[d.comp[0]].col_base + d.word[0]); y.pmask[0] = mask_index(d.comp[0]);
+                break;
+            case GGRS_SYS_SAT_SUB_DESPAWN:
+                // despawn_rollback() marks are live-only state that DespawnConfirmed reads between frames: per-request path
+                if (!rb(d.comp[0]) || d.iparam[1] == GGRS_DESPAWN_ROLLBACK) { ok = false; break; }
+                y.pso[0] = pso_of(w->comps[d.comp[0]].col_base + d.word[0]); y.pmask[0] = mask_index(d.comp[0]);
+                break;
+            default: ok = false;
+            }
+            ++a.n_sys;
+        }
+        if (ok) { w->gen_ok = true; w->gen_sub_max = sub; }
+    }
+
     // ---- arena carve
     const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
     w->tick_part_stride = 4 * (uint32_t)(w->cap_pad / TILE1);     // one partial per wave of the finest tiling
@@ -396,6 +488,15 @@ int seal(ggrs_world* w) {
         HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
+    if (w->gen_ok) {
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_words, (gwords.size() + 1) * sizeof(GenWord)));
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_units, (gunits.size() + 1) * sizeof(GenUnit)));
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, (size_t)MAX_TICK_SAVES * (w->gen_proto.n_cks + 1) * w->tick_part_stride * 8));
+        if (!gwords.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_words, gwords.data(), gwords.size() * sizeof(GenWord), hipMemcpyHostToDevice, w->stream));
+        if (!gunits.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_units, gunits.data(), gunits.size() * sizeof(GenUnit), hipMemcpyHostToDevice, w->stream));
+        w->gen_proto.words = w->d_gen_words; w->gen_proto.units = w->d_gen_units;
+        w->gen_proto.parts = w->d_gen_parts; w->gen_proto.part_stride = w->tick_part_stride;
+    }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;
     return GGRS_OK;
@@ -937,6 +1038,109 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
     return read_back(w, ns, checksums_out);
 }
 
+// The same grouping for worlds served by the generic LDS-staged kernel (k_tick_gen + k_gen_finalize).
+constexpr uint64_t GEN_SMALL_SLOTS = 512 * 1024;       // below this, 256 slots per workgroup fill the chip better
+int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
+                           uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
+    uint32_t i = 0, ns = 0;
+    int rc = GGRS_OK;
+    while (i < n) {
+        GenArgs a = w->gen_proto;
+        Block* src = &w->live;
+        uint64_t cover = w->live.dirty_len;
+        a.src_is_live = 1;
+        Block* dsts[MAX_TICK_SAVES];
+        const ggrs_request* spawn_req = nullptr;
+        if (reqs[i].kind == GGRS_REQ_LOAD) {                                   // schedule_systems.rs:238-250
+            apply_synctest_confirmed(w);
+            w->frame = reqs[i].frame;
+            if (!ring_rollback(w, reqs[i].frame))
+                return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
+            src = &w->slots[w->ring_slot.front()];
+            rc = launch_load_reconcile(w, *src); if (rc) return rc;
+            w->len = src->len;
+            cover = std::max(cover, src->dirty_len);
+            a.src_is_live = 0;
+            ++i;
+        }
+        while (i < n && a.n_ops < (uint32_t)MAX_TICK_OPS) {
+            const ggrs_request& r = reqs[i];
+            if (r.kind == GGRS_REQ_LOAD) break;
+            if (r.kind == GGRS_REQ_SAVE) {
+                if (a.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + a.n_saves == w->max_results)) break;
+                apply_synctest_confirmed(w);
+                if (w->has_confirmed) ring_confirm(w, w->confirmed);
+                int sl = -1;
+                rc = ring_push(w, w->frame, &sl); if (rc) return rc;
+                Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
+                dsts[a.n_saves] = d;
+                a.save_dst[a.n_saves] = d ? d->ptr : nullptr;
+                a.save_frame[a.n_saves] = w->frame;
+                if (d) { cover = std::max(cover, d->dirty_len); d->len = w->len; }
+                ++a.n_ops; ++a.n_saves;
+            } else if (r.kind == GGRS_REQ_ADVANCE) {
+                if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
+                if (r.n_inputs > 16) return w->fail(GGRS_E_INVALID, "more than 16 player inputs");
+                apply_synctest_confirmed(w);
+                w->frame += 1;
+                rc = step_despawn_confirmed(w); if (rc) return rc;
+                const uint32_t dtb = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+                a.dt_bits[a.n_steps] = dtb;
+                if (w->gen_box_sys >= 0) {                                     // FRICTION.powf(dt), platform libm (box_game.rs:189-195)
+                    float dtf; memcpy(&dtf, &dtb, 4);
+                    const float fp = powf(w->systems[w->gen_box_sys].fparam[2], dtf);
+                    memcpy(&a.aux_bits[a.n_steps], &fp, 4);
+                }
+                a.n_inputs[a.n_steps] = (uint8_t)r.n_inputs;
+                for (uint32_t k = 0; k < r.n_inputs; ++k) a.inputs[a.n_steps][k] = r.inputs[k];
+                ++a.n_steps;
+                a.op_bits |= 1ULL << a.n_ops; ++a.n_ops;
+                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }
+            } else {
+                return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+            }
+            ++i;
+        }
+        cover = std::max(cover, w->len);
+        uint32_t sub = w->gen_sub_max;
+        if (cover <= GEN_SMALL_SLOTS) sub = std::min<uint32_t>(sub, 256);
+        const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + sub - 1) / sub));
+        a.sub = sub; a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
+        const uint32_t lds = (a.ts / TILE) * sub + a.n_masks * (sub / 8);
+        if (a.n_ops || !a.src_is_live) {
+            ProfScope ps(w, GGRS_KERNEL_TICK);
+            hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(TPB), lds, w->stream, a);
+        }
+        HIPCHK(w, hipGetLastError());
+        const uint64_t new_dirty = std::max(src->dirty_len, w->len);
+        for (uint32_t k = 0; k < a.n_saves; ++k) if (dsts[k]) dsts[k]->dirty_len = new_dirty;
+        w->live.dirty_len = new_dirty;
+        w->pending_valid = false;
+        if (a.n_saves) {
+            GenFinArgs f; memset(&f, 0, sizeof f);
+            f.parts = a.parts; f.part_stride = a.part_stride; f.n_parts = 4 * g; f.n_cks = a.n_cks; f.total_len = w->len;
+            f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+            {
+                ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+                hipLaunchKernelGGL(k_gen_finalize, dim3(a.n_saves), dim3(FIN_TPB), 0, w->stream, f);
+            }
+            HIPCHK(w, hipGetLastError());
+            ns += a.n_saves;
+        }
+        if (spawn_req) {
+            rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
+            if (rc) return rc;
+        }
+        if (wait && ns == w->max_results) {
+            rc = read_back(w, ns, checksums_out); if (rc) return rc;
+            checksums_out += 2 * (uint64_t)ns; ns = 0;
+        }
+    }
+    if (n_saves_out) *n_saves_out = ns;
+    if (!wait) return GGRS_OK;
+    return read_back(w, ns, checksums_out);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -995,6 +1199,9 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
+    if (w->d_gen_words) (void)hipFree(w->d_gen_words);
+    if (w->d_gen_units) (void)hipFree(w->d_gen_units);
+    if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->own_arena && w->arena_alloc) (void)hipFree(w->arena_alloc);
@@ -1261,8 +1468,8 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
     int rc = seal(w); if (rc) return rc;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "handle_requests while %zu enqueued batches are uncollected", w->pending.size());
-    if (w->tick_ok) {
-        rc = run_request_groups(w, reqs, n, checksums_out);
+    if (w->tick_ok || w->gen_ok) {
+        rc = w->tick_ok ? run_request_groups(w, reqs, n, checksums_out) : run_request_groups_gen(w, reqs, n, checksums_out);
         if (rc && w->stream) (void)hipStreamSynchronize(w->stream);
         return rc;
     }
@@ -1300,8 +1507,8 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     ggrs_world::PendingBatch b;
     b.first = (w->res_head + n_save > w->max_results) ? 0u : w->res_head;
     b.count = n_save;
-    if (w->tick_ok) {
-        rc = run_request_groups(w, reqs, n, nullptr, b.first, false, nullptr);
+    if (w->tick_ok || w->gen_ok) {
+        rc = w->tick_ok ? run_request_groups(w, reqs, n, nullptr, b.first, false, nullptr) : run_request_groups_gen(w, reqs, n, nullptr, b.first, false, nullptr);
         if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
     } else {
         // worlds without request-group kernels: one launch per request, enqueued like the groups are; every

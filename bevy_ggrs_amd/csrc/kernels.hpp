@@ -1059,6 +1059,34 @@ struct BoxMoveArgs {
     uint8_t inputs[16];
 };
 constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3;   // box_game.rs:13-16
+__device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in,
+                                              float dt, float fp, float accel, float max_speed, float half_width) {
+    const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT;
+    const float adt = __fmul_rn(accel, dt);
+    if (up && !down) vz = __fsub_rn(vz, adt);
+    if (!up && down) vz = __fadd_rn(vz, adt);
+    if (left && !right) vx = __fsub_rn(vx, adt);
+    if (!left && right) vx = __fadd_rn(vx, adt);
+    if (!up && !down) vz = __fmul_rn(vz, fp);
+    if (!left && !right) vx = __fmul_rn(vx, fp);
+    vy = __fmul_rn(vy, fp);
+    const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
+    if (len_sq > __fmul_rn(max_speed, max_speed)) {
+        // NOT __fsqrt_rn: clang's HIP header maps it to __ocml_native_sqrt_f32 (approximate) unless
+        // OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf is the correctly rounded one (Makefile pins
+        // -fhip-fp32-correctly-rounded-divide-sqrt, the default)
+        const float l = sqrtf(len_sq);
+        vx = __fmul_rn(max_speed, vx / l);
+        vy = __fmul_rn(max_speed, vy / l);
+        vz = __fmul_rn(max_speed, vz / l);
+    }
+    x = __fadd_rn(x, __fmul_rn(vx, dt)); y = __fadd_rn(y, __fmul_rn(vy, dt)); z = __fadd_rn(z, __fmul_rn(vz, dt));
+    const float lo = -half_width, hi = half_width;
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    if (z < lo) z = lo;
+    if (z > hi) z = hi;
+}
 __global__ __launch_bounds__(TPB) void k_box_move(BoxMoveArgs a) {
     const uint64_t e = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= a.len) return;
@@ -1078,32 +1106,8 @@ __global__ __launch_bounds__(TPB) void k_box_move(BoxMoveArgs a) {
     float* pvx = reinterpret_cast<float*>(a.state + col_at(a.off_v[0], a.ts_v, 4, e));
     float* pvy = reinterpret_cast<float*>(a.state + col_at(a.off_v[1], a.ts_v, 4, e));
     float* pvz = reinterpret_cast<float*>(a.state + col_at(a.off_v[2], a.ts_v, 4, e));
-    float vx = *pvx, vy = *pvy, vz = *pvz;
-    const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT;
-    const float adt = __fmul_rn(a.accel, dt);
-    if (up && !down) vz = __fsub_rn(vz, adt);
-    if (!up && down) vz = __fadd_rn(vz, adt);
-    if (left && !right) vx = __fsub_rn(vx, adt);
-    if (!left && right) vx = __fadd_rn(vx, adt);
-    if (!up && !down) vz = __fmul_rn(vz, fp);
-    if (!left && !right) vx = __fmul_rn(vx, fp);
-    vy = __fmul_rn(vy, fp);
-    const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
-    if (len_sq > __fmul_rn(a.max_speed, a.max_speed)) {
-        // NOT __fsqrt_rn: clang's HIP header maps it to __ocml_native_sqrt_f32 (approximate) unless
-        // OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf is the correctly rounded one (Makefile pins
-        // -fhip-fp32-correctly-rounded-divide-sqrt, the default)
-        const float l = sqrtf(len_sq);
-        vx = __fmul_rn(a.max_speed, vx / l);
-        vy = __fmul_rn(a.max_speed, vy / l);
-        vz = __fmul_rn(a.max_speed, vz / l);
-    }
-    float x = __fadd_rn(*px, __fmul_rn(vx, dt)), y = __fadd_rn(*py, __fmul_rn(vy, dt)), z = __fadd_rn(*pz, __fmul_rn(vz, dt));
-    const float lo = -a.half_width, hi = a.half_width;
-    if (x < lo) x = lo;
-    if (x > hi) x = hi;
-    if (z < lo) z = lo;
-    if (z > hi) z = hi;
+    float vx = *pvx, vy = *pvy, vz = *pvz, x = *px, y = *py, z = *pz;
+    box_move_math(x, y, z, vx, vy, vz, in, dt, fp, a.accel, a.max_speed, a.half_width);
     *pvx = vx; *pvy = vy; *pvz = vz;
     *px = x; *py = y; *pz = z;
 }
@@ -1244,6 +1248,231 @@ __global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
         a.part_V[blockIdx.x] = sV[0] ^ sV[1] ^ sV[2] ^ sV[3];
         a.part_cnt[blockIdx.x] = (uint64_t)sC[0] + sC[1] + sC[2] + sC[3];
     }
+}
+
+// ------------------------------------------------------------------ k_tick_gen (generic fused request group)
+// The same request-group fusion as k_tick for ANY mix of the kernel-backed systems (box_game, add_u32, the Health
+// scenario of tests/synctest.rs, particles with extra checksum specs ...): a workgroup stages the `sub` slots it
+// owns -- every registered word and every mask -- in LDS (tile-major columns make that `n_words` contiguous global
+// spans), replays the ops of the group on the LDS image (Save = LDS -> ring slot + generic checksum partials,
+// Advance = each registered system in order over the LDS columns) and writes the live block once at the end.
+// One launch per group instead of one per request: an 18-request tick of a small world is 2 launches.
+// Not covered (such worlds keep the one-launch-per-request path): despawn_rollback systems (their marks are
+// live-only global state that DespawnConfirmed reads between frames) and worlds whose words do not fit 64 KiB of LDS
+// at 256 slots per workgroup.
+constexpr int GEN_MAX_SYS = 16, GEN_MAX_CKS = 16;
+// LDS image of a workgroup: the registered word columns in tile order, each `sub` slots long -- a word whose
+// preceding words take `pso` bytes per slot starts at byte pso * sub -- then the masks ([n_masks][sub / 64] u64).
+struct GenWord { uint32_t tcol, wb, pso, pad; };      // offset inside a tile, word bytes, bytes per slot before it
+struct GenUnit { uint32_t pso, add, stride, pad; };   // u32 checksum unit of slot i: pso * sub + add + i * stride
+struct GenSys {
+    uint32_t kind;
+    uint32_t pso[6];          // per-slot byte offsets (GenWord::pso) of the words the system touches (t.x t.y t.z v.x v.y v.z | word)
+    uint32_t pmask[3];        // mask index of each component's presence mask; ~0u: live-only component
+    uint32_t pso_h, side_ts;  // BOX_MOVE: Player.handle in LDS (rollback component) or in the live block (live-only)
+    uint32_t pad;
+    uint64_t side_off;        // live-only column the system reads from the live block (BOX_MOVE: Player.handle)
+    uint64_t side_pmask_off;  // and its presence mask
+    int64_t iparam[2];
+    float fparam[4];
+};
+struct GenArgs {
+    const uint8_t* src; uint8_t* live;
+    uint8_t* save_dst[MAX_TICK_SAVES]; int32_t save_frame[MAX_TICK_SAVES];
+    uint32_t dt_bits[MAX_TICK_STEPS]; uint32_t aux_bits[MAX_TICK_STEPS];      // aux: FRICTION.powf(dt) of BOX_MOVE (host libm)
+    uint8_t inputs[MAX_TICK_STEPS][16]; uint8_t n_inputs[MAX_TICK_STEPS];
+    uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
+    uint64_t len, cols_base;
+    uint32_t ts, sub, n_words, n_masks, pad0, n_sys, n_cks, part_stride;
+    uint64_t mask_off[MAX_MASKS];
+    const GenWord* words; const GenUnit* units;
+    uint32_t cks_pmask[GEN_MAX_CKS], cks_unit_base[GEN_MAX_CKS], cks_n_units[GEN_MAX_CKS];   // pmask: mask index
+    uint64_t* parts;                                   // [n_saves][n_cks + 1][part_stride], one entry per wave; last = live count
+    GenSys sys[GEN_MAX_SYS];
+};
+static_assert(sizeof(GenArgs) <= 4096, "kernel argument segment limit");
+
+__global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sub = a.sub, mw = sub >> 6;                        // slots / mask words per workgroup
+    const uint64_t s0 = (uint64_t)blockIdx.x * sub;                   // first slot of this workgroup
+    const uint64_t tbase = a.cols_base + (s0 >> 10) * a.ts;           // its tile inside a block
+    const uint32_t in_tile = (uint32_t)(s0 & 1023u);
+    const bool in_len = s0 < a.len;                                   // workgroup-uniform
+    uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + (size_t)(a.ts >> 10) * sub);   // [n_masks][mw] behind the words; mask 0 = liveness
+
+    auto copy_words = [&](uint8_t* block, bool to_block) {            // LDS image <-> one state block
+        for (uint32_t w = 0; w < a.n_words; ++w) {
+            const GenWord gw = a.words[w];
+            uint8_t* g = block + tbase + gw.tcol + (uint64_t)in_tile * gw.wb;
+            const uint32_t bytes = sub * gw.wb;
+            for (uint32_t o = tid * 16u; o < bytes; o += TPB * 16u) {
+                if (to_block) *reinterpret_cast<u32x4*>(g + o) = *reinterpret_cast<const u32x4*>(lds + gw.pso * sub + o);
+                else *reinterpret_cast<u32x4*>(lds + gw.pso * sub + o) = *reinterpret_cast<const u32x4*>(g + o);
+            }
+        }
+    };
+    auto copy_masks = [&](uint8_t* block, bool to_block) {
+        for (uint32_t m = tid; m < a.n_masks * mw; m += TPB) {
+            uint64_t* g = reinterpret_cast<uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8);
+            if (to_block) *g = lmask[m]; else lmask[m] = *g;
+        }
+    };
+    // ---- stage the workgroup's slots
+    copy_masks(const_cast<uint8_t*>(a.src), false);
+    if (in_len) copy_words(const_cast<uint8_t*>(a.src), false);
+    __syncthreads();
+
+    uint32_t si = 0, sj = 0;
+    for (uint32_t op = 0; op < a.n_ops; ++op) {
+        if (!((a.op_bits >> op) & 1ULL)) {
+            // ---------------- SaveWorld: snapshot + per-entity half of every component checksum
+            uint8_t* dst = a.save_dst[si];
+            if (dst) {
+                if (in_len) copy_words(dst, true);
+                copy_masks(dst, true);
+                if (blockIdx.x == 0 && tid == 0) {
+                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = h;
+                }
+            }
+            uint64_t* prow = a.parts + (uint64_t)si * (a.n_cks + 1) * a.part_stride + (uint64_t)blockIdx.x * 4 + wave;
+            for (uint32_t k = 0; k < a.n_cks; ++k) {
+                const uint64_t* pm = lmask + a.cks_pmask[k] * mw;
+                uint64_t h = 0;
+                for (uint32_t i = tid; i < sub; i += TPB) {
+                    if (((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL) {
+                        SeaStream st;
+                        for (uint32_t u = 0; u < a.cks_n_units[k]; ++u) {
+                            const GenUnit gu = a.units[a.cks_unit_base[k] + u];
+                            st.unit(*reinterpret_cast<const uint32_t*>(lds + gu.pso * sub + gu.add + i * gu.stride));
+                        }
+                        h ^= sea_pair(s0 + i, st.finish());              // order == slot
+                    }
+                }
+                h = wave_xor(h);
+                if (lane == 0) prow[(uint64_t)k * a.part_stride] = h;
+            }
+            uint32_t cnt = 0;
+            for (uint32_t wi = wave; wi < mw; wi += 4) cnt += (uint32_t)__popcll(lmask[wi]);
+            if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;
+            ++si;
+            __syncthreads();          // the copy above reads LDS bytes that OTHER waves' lanes own in the next Advance
+        } else {
+            // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
+            const float dt = __uint_as_float(a.dt_bits[sj]);
+            for (uint32_t s = 0; s < a.n_sys; ++s) {
+                const GenSys& y = a.sys[s];
+                const uint64_t* p0 = y.pmask[0] != ~0u ? lmask + y.pmask[0] * mw : lmask;
+                const uint64_t* p1 = y.pmask[1] != ~0u ? lmask + y.pmask[1] * mw : lmask;
+                for (uint32_t i = tid; i < sub; i += TPB) {               // a wave's 64 lanes == one mask word
+                    const uint32_t wi = i >> 6;
+                    const uint64_t alive_w = lmask[wi];
+                    bool kill = false;
+                    switch (y.kind) {
+                    case 1u: {   // GGRS_SYS_PARTICLES_UPDATE (particles.rs:272-280)
+                        if (((alive_w & p0[wi] & p1[wi]) >> (i & 63u)) & 1ULL) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                float* x = reinterpret_cast<float*>(lds + y.pso[k] * sub + i * 4u);
+                                float* v = reinterpret_cast<float*>(lds + y.pso[3 + k] * sub + i * 4u);
+                                const float nv = __fadd_rn(*v, __fmul_rn(y.fparam[k], dt));
+                                *v = nv; *x = __fadd_rn(*x, __fmul_rn(nv, dt));
+                            }
+                        }
+                    } break;
+                    case 2u: {   // GGRS_SYS_TTL_DESPAWN (particles.rs:282-289)
+                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
+                            uint64_t* q = reinterpret_cast<uint64_t*>(lds + y.pso[0] * sub + i * 8u);
+                            const uint64_t nq = *q - 1; *q = nq; kill = nq == 0;
+                        }
+                    } break;
+                    case 4u: {   // GGRS_SYS_ADD_U32 (benches/bench.rs:30-46)
+                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
+                            uint32_t* q = reinterpret_cast<uint32_t*>(lds + y.pso[0] * sub + i * 4u);
+                            *q = *q + (uint32_t)y.iparam[0];
+                        }
+                    } break;
+                    case 5u: {   // GGRS_SYS_SAT_SUB_DESPAWN, immediate despawn (tests/synctest.rs:37-44)
+                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
+                            uint32_t* q = reinterpret_cast<uint32_t*>(lds + y.pso[0] * sub + i * 4u);
+                            const uint32_t amount = (uint32_t)y.iparam[0];
+                            const uint32_t v = *q >= amount ? *q - amount : 0u;
+                            *q = v; kill = v == 0;
+                        }
+                    } break;
+                    case 6u: {   // GGRS_SYS_BOX_MOVE (box_game.rs:154-206), arithmetic shared with k_box_move
+                        const uint64_t e = s0 + i;
+                        uint64_t m = alive_w & p0[wi] & p1[wi];
+                        const bool h_lds = y.pmask[2] != ~0u;                // Player registered for rollback: staged in LDS
+                        if (h_lds) m &= lmask[y.pmask[2] * mw + wi];
+                        else m &= *reinterpret_cast<const uint64_t*>(a.live + y.side_pmask_off + (e >> 6) * 8);
+                        if ((m >> (i & 63u)) & 1ULL) {
+                            const uint64_t handle = h_lds ? *reinterpret_cast<const uint64_t*>(lds + y.pso_h * sub + i * 8u)
+                                                          : *reinterpret_cast<const uint64_t*>(a.live + col_at(y.side_off, y.side_ts, 8, e));
+                            if (handle < a.n_inputs[sj]) {
+                                float* px = reinterpret_cast<float*>(lds + y.pso[0] * sub + i * 4u);
+                                float* py = reinterpret_cast<float*>(lds + y.pso[1] * sub + i * 4u);
+                                float* pz = reinterpret_cast<float*>(lds + y.pso[2] * sub + i * 4u);
+                                float* pvx = reinterpret_cast<float*>(lds + y.pso[3] * sub + i * 4u);
+                                float* pvy = reinterpret_cast<float*>(lds + y.pso[4] * sub + i * 4u);
+                                float* pvz = reinterpret_cast<float*>(lds + y.pso[5] * sub + i * 4u);
+                                float x = *px, yy = *py, z = *pz, vx = *pvx, vy = *pvy, vz = *pvz;
+                                box_move_math(x, yy, z, vx, vy, vz, a.inputs[sj][handle], dt, __uint_as_float(a.aux_bits[sj]),
+                                              y.fparam[0], y.fparam[1], y.fparam[3]);
+                                *px = x; *py = yy; *pz = z; *pvx = vx; *pvy = vy; *pvz = vz;
+                            }
+                        }
+                    } break;
+                    default: break;
+                    }
+                    const uint64_t kills = __ballot(kill);
+                    if (kills && lane == 0) lmask[wi] = alive_w & ~kills;
+                }
+                __syncthreads();
+            }
+            ++sj;
+        }
+    }
+    __syncthreads();
+    // ---- the live block, written once
+    if (!a.src_is_live || a.n_steps) {
+        if (in_len) copy_words(a.live, true);
+        copy_masks(a.live, true);
+    }
+}
+
+// Fold of k_tick_gen's per-wave partials: one 1024-thread workgroup per Save; any number of checksummed components.
+struct GenFinArgs {
+    const uint64_t* parts; uint32_t part_stride, n_parts, n_cks, pad;
+    uint64_t total_len;
+    uint64_t* out;
+};
+__global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
+    const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint64_t s[FIN_TPB / 64];
+    __shared__ uint64_t total_s;
+    if (tid == 0) total_s = 0;
+    __syncthreads();
+    for (uint32_t c = 0; c <= f.n_cks; ++c) {
+        const uint64_t* p = f.parts + ((uint64_t)k * (f.n_cks + 1) + c) * f.part_stride;
+        const bool is_cnt = c == f.n_cks;
+        uint64_t x = 0, sum = 0;
+        for (uint32_t i = tid; i < f.n_parts; i += FIN_TPB) { const uint64_t v = p[i]; x ^= v; sum += v; }
+        x = wave_xor(x);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) s[wave] = is_cnt ? sum : x;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t acc = 0;
+            for (int w2 = 0; w2 < FIN_TPB / 64; ++w2) acc = is_cnt ? acc + s[w2] : acc ^ s[w2];
+            total_s ^= is_cnt ? sea_pair(acc, f.total_len) : sea_one(acc);      // entity_checksum.rs:29-52 / component_checksum.rs:92-95
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { f.out[2 * (uint64_t)k] = total_s; f.out[2 * (uint64_t)k + 1] = 0; }
 }
 
 }  // namespace ggrs

@@ -1,0 +1,113 @@
+"""Request-group fusion for worlds OTHER than the stress_test schedule: k_tick_gen stages a workgroup's slots in LDS
+and replays [Load?](Save | Advance)* there for any mix of the kernel-backed systems.  Every scenario runs on the
+generic fused path (flags 0), on the one-launch-per-request path (GGRS_WORLD_NO_GROUPS) and on the oracle; all three
+must agree bit for bit, and the fused worlds must really have used the group kernel."""
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+from oracle.binding import OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+
+def _worlds(cap, depth=8):
+    return [("gen", bg.World(cap, max_depth=depth)), ("per-request", bg.World(cap, max_depth=depth, flags=bg.GGRS_WORLD_NO_GROUPS)),
+            ("oracle", OracleWorld(cap, depth))]
+
+
+def _group_launches(w):
+    ms = w.profile_read()
+    return ms["tick"][1]
+
+
+def _check(results):
+    (n0, c0, s0), rest = results[0], results[1:]
+    for name, cs, st in rest:
+        assert cs == c0, f"checksums of {name} differ from {n0}"
+        cm.assert_states_equal(st, s0, f"{name} vs {n0}")
+
+
+@pytest.mark.parametrize("n,cd,ticks", [(1, 2, 10), (300, 3, 16), (5000, 7, 20), (70_000, 4, 12)])
+def test_particles_with_extra_checksum_specs(n, cd, ticks):
+    """particles + spawn, but Ttl (u64) and a non-prefix word subset of Transform are checksummed too: the register
+    kernel k_tick does not cover those specs, the generic kernel does."""
+    res = []
+    for name, w in _worlds(n + 60 * ticks + 64):
+        T = w.register_component("Transform", 4, 10); V = w.register_component("Velocity", 4, 3); L = w.register_component("Ttl", 8, 1)
+        w.set_component_default(T, cm.TRANSFORM_DEFAULT)
+        w.checksum_component(V, [0, 1, 2]); w.checksum_component(L, [0]); w.checksum_component(T, [2, 0, 9, 6])
+        w.add_system(bg.SYS_PARTICLES_UPDATE, comp=(T, V), word=(0, 0), fparam=(0.0, -200.0, 0.0))
+        w.add_system(bg.SYS_TTL_DESPAWN, comp=(L,), word=(0,))
+        w.add_system(bg.SYS_PARTICLES_SPAWN, comp=(T, V, L), iparam=(30, cm.INPUT_SPAWN))
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, (T, V, L), n, vel, ttl)
+        if name != "oracle": w.profile_enable(True)
+        drv = cm.SyncTestDriver(w, cd)
+        fn = cm.frame_spawn_fn(60)
+        for t in range(ticks):
+            drv.tick((cm.INPUT_SPAWN if t % 3 == 1 else 0,), spawn_fn=fn)
+        if name == "gen": assert _group_launches(w) > 0
+        if name == "per-request": assert _group_launches(w) == 0
+        res.append((name, drv.all_checksums, cm.snapshot_state(w, (T, V, L))))
+    _check(res)
+
+
+@pytest.mark.parametrize("n,cd", [(200, 3), (5000, 2), (70_000, 7)])
+def test_health_world_immediate_despawn(n, cd):
+    """tests/synctest.rs:26-75: Health, decrease_health with commands.entity(e).despawn() at zero."""
+    res = []
+    for name, w in _worlds(n + 8):
+        H = w.register_component("Health", 4, 1)
+        w.checksum_component(H, [0])
+        w.add_system(bg.SYS_SAT_SUB_DESPAWN, comp=(H,), word=(0,), iparam=(1, bg.DESPAWN_IMMEDIATE))
+        w.spawn(n, {H: [(1 + (np.arange(n) % 9)).astype(np.uint32)]})
+        if name != "oracle": w.profile_enable(True)
+        drv = cm.SyncTestDriver(w, cd)
+        for _ in range(16):
+            drv.tick((0,))
+        if name == "gen": assert _group_launches(w) > 0
+        st = cm.snapshot_state(w, (H,))
+        assert not st["alive"].any()                       # everybody died by frame 9
+        res.append((name, drv.all_checksums, st))
+    _check(res)
+
+
+def test_disjoint_components_in_request_lists():
+    """benches/bench.rs:68-95 foo_bar_baz (three add_u32 systems over disjoint entity sets) driven by request lists;
+    8-byte and 4-byte words side by side, one component never touched by any system."""
+    res = []
+    for name, w in _worlds(4000):
+        foo = w.register_component("Foo", 4, 1); bar = w.register_component("Bar", 4, 2); baz = w.register_component("Baz", 4, 1)
+        big = w.register_component("Big", 8, 2)
+        for c in (foo, bar, baz): w.checksum_component(c, list(range(1 if c != bar else 2)))
+        w.checksum_component(big, [1])
+        w.add_system(bg.SYS_ADD_U32, comp=(foo,), word=(0,), iparam=(1,))
+        w.add_system(bg.SYS_ADD_U32, comp=(bar,), word=(1,), iparam=(-1 & 0xFFFFFFFF,))
+        w.add_system(bg.SYS_ADD_U32, comp=(baz,), word=(0,), iparam=(3,))
+        v = np.arange(1000, dtype=np.uint32)
+        w.spawn(1000, {foo: [v], big: [v.astype(np.uint64) << np.uint64(33), v.astype(np.uint64) * np.uint64(7)]})
+        w.spawn(1000, {bar: [v, v + 5]})
+        w.spawn(1500, {baz: [np.arange(1500, dtype=np.uint32)], foo: [np.arange(1500, dtype=np.uint32) * 2]})
+        if name != "oracle": w.profile_enable(True)
+        drv = cm.SyncTestDriver(w, 5)
+        for _ in range(18):
+            drv.tick((0,))
+        if name == "gen": assert _group_launches(w) > 0
+        res.append((name, drv.all_checksums, cm.snapshot_state(w, (foo, bar, baz, big))))
+    _check(res)
+
+
+def test_box_game_uses_the_group_kernel():
+    from test_box_game import build_box, input_script
+    res = []
+    for name, w in _worlds(600):
+        ids, *_ = build_box(w, 500, 4, spread=True)
+        if name != "oracle": w.profile_enable(True)
+        drv = cm.SyncTestDriver(w, 6, num_players=4, input_delay=2)
+        for t in range(24):
+            drv.tick(input_script(t, 4))
+        if name == "gen": assert _group_launches(w) > 0
+        res.append((name, drv.all_checksums, cm.snapshot_state(w, ids[:2])))
+    _check(res)

@@ -227,3 +227,42 @@ def test_p2p_shaped_rollbacks_100k(n, ticks, flags):
     for (fa, ca), (fb, cb) in zip(a.all_checksums, b.all_checksums):
         assert fa == fb and ca == cb, f"frame {fa}: gpu {ca:#x} oracle {cb:#x}"
     cm.assert_states_equal(sa, sb, "p2p shape")
+
+
+def test_column_transfers_across_tile_boundaries():
+    """Word columns are tile-major on the device (1024-slot tiles): uploads, downloads and
+    spawns of arbitrary [first, first + count) ranges are a head piece + a pitched 2-D copy + a tail piece.  Every
+    range must round-trip and leave its neighbours alone -- 4- and 8-byte words, rollback and live-only columns."""
+    cap = 5000
+    w = bg.World(cap, max_depth=4)
+    A = w.register_component("A", 4, 3)
+    B = w.register_component("B", 8, 2)
+    N = w.register_component("N", 4, 1, rollback=False)
+    w.spawn(cap, {A: None, B: None, N: None})
+    rng = np.random.default_rng(3)
+    shadow = {(A, k): np.zeros(cap, np.uint32) for k in range(3)}
+    shadow.update({(B, k): np.zeros(cap, np.uint64) for k in range(2)})
+    shadow[(N, 0)] = np.zeros(cap, np.uint32)
+    ranges = [(0, 1), (1023, 2), (1000, 3000), (1024, 1024), (1, 4998), (2047, 1), (2048, 2952), (4999, 1), (0, 5000), (3071, 1026)]
+    for i, (first, count) in enumerate(ranges):
+        for (c, k), sh in shadow.items():
+            data = rng.integers(0, 2 ** 32 - 1, count).astype(sh.dtype) + (np.uint64(i) << np.uint64(40) if sh.dtype == np.uint64 else 0)
+            data = data.astype(sh.dtype)
+            w.upload_word(c, k, first, data)
+            sh[first:first + count] = data
+        for (c, k), sh in shadow.items():
+            assert np.array_equal(w.download_word(c, k, 0, cap), sh), (c, k, first, count)
+            f2, n2 = ranges[(i + 3) % len(ranges)]
+            assert np.array_equal(w.download_word(c, k, f2, n2), sh[f2:f2 + n2]), (c, k, f2, n2)
+    # a snapshot round trip keeps the rollback columns, and insert_component lands on the right slot of the right tile
+    w.save()
+    w.insert_component(A, 2049, np.array([7, 8, 9], np.uint32))
+    assert [int(w.download_word(A, k, 2049, 1)[0]) for k in range(3)] == [7, 8, 9]
+    assert int(w.download_word(A, 0, 2048, 1)[0]) == int(shadow[(A, 0)][2048]) and int(w.download_word(A, 0, 2050, 1)[0]) == int(shadow[(A, 0)][2050])
+    w.load(0)
+    for (c, k), sh in shadow.items():
+        assert np.array_equal(w.download_word(c, k, 0, cap), sh), ("after load", c, k)
+    ptr, ts = w.column_device_ptr(A, 0)
+    assert ptr and ts == 1024 * (3 * 4 + 2 * 8)                   # tile stride = bytes of all rollback words of 1024 slots
+    ptr_n, ts_n = w.column_device_ptr(N, 0)
+    assert ptr_n and ts_n == 1024 * 4                             # live-only column: a plain array
