@@ -316,7 +316,8 @@ int seal(ggrs_world* w) {
 
     // ---- fused request groups
     w->tick_ok = false;
-    if (w->fused_ok && !(w->flags & GGRS_WORLD_NO_GROUPS) && w->f_T != w->f_V && w->f_T != w->f_L && w->f_V != w->f_L &&
+    const bool force_generic = getenv("GGRS_TICK_GENERIC") && atoi(getenv("GGRS_TICK_GENERIC")) != 0;   // A/B knob: k_tick_gen for every world
+    if (w->fused_ok && !force_generic && !(w->flags & GGRS_WORLD_NO_GROUPS) && w->f_T != w->f_V && w->f_T != w->f_L && w->f_V != w->f_L &&
         (w->fused_cks || w->cks_comp.empty())) {
         for (auto& sd : w->systems) if (sd.kind == GGRS_SYS_TTL_DESPAWN) w->f_lw = sd.word[0];
         TickArgs& a = w->tick_proto;
@@ -356,9 +357,7 @@ int seal(ggrs_world* w) {
         GenArgs& a = w->gen_proto;
         memset(&a, 0, sizeof a);
         const uint32_t bps = w->ts / TILE;                                   // bytes per slot of all rollback words
-        uint32_t sub = 0;
-        for (uint32_t cand : {1024u, 512u, 256u}) if ((uint64_t)bps * cand + (uint64_t)w->plan.n_masks * (cand / 8) <= 65536) { sub = cand; break; }
-        bool ok = sub != 0;
+        bool ok = true;
         const uint64_t cols_base = w->plan.n_rows ? w->plan.row[0].col_off : 0;   // every rollback column: cols_base + tcol
         uint64_t min_off = ~0ULL;
         for (uint32_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback)
@@ -429,7 +428,11 @@ int seal(ggrs_world* w) {
             }
             ++a.n_sys;
         }
-        if (ok) { w->gen_ok = true; w->gen_sub_max = sub; }
+        // largest slots-per-workgroup whose LDS image (words + masks + staged tables) fits 64 KiB
+        uint32_t sub = 0;
+        const uint64_t tables = (uint64_t)(bps / 4 + 4) * 4 + gunits.size() * sizeof(GenUnit);
+        for (uint32_t cand : {1024u, 512u, 256u}) if ((uint64_t)bps * cand + (uint64_t)w->plan.n_masks * (cand / 8) + tables <= 65536) { sub = cand; break; }
+        if (ok && sub) { w->gen_ok = true; w->gen_sub_max = sub; }
     }
 
     // ---- arena carve
@@ -494,7 +497,7 @@ int seal(ggrs_world* w) {
         HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, (size_t)MAX_TICK_SAVES * (w->gen_proto.n_cks + 1) * w->tick_part_stride * 8));
         if (!gwords.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_words, gwords.data(), gwords.size() * sizeof(GenWord), hipMemcpyHostToDevice, w->stream));
         if (!gunits.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_units, gunits.data(), gunits.size() * sizeof(GenUnit), hipMemcpyHostToDevice, w->stream));
-        w->gen_proto.words = w->d_gen_words; w->gen_proto.units = w->d_gen_units;
+        w->gen_proto.words = w->d_gen_words; w->gen_proto.units = w->d_gen_units; w->gen_proto.n_units = (uint32_t)gunits.size();
         w->gen_proto.parts = w->d_gen_parts; w->gen_proto.part_stride = w->tick_part_stride;
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -1106,7 +1109,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         if (cover <= GEN_SMALL_SLOTS) sub = std::min<uint32_t>(sub, 256);
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + sub - 1) / sub));
         a.sub = sub; a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
-        const uint32_t lds = (a.ts / TILE) * sub + a.n_masks * (sub / 8);
+        // word image + masks + the staged row-offset and checksum-unit tables
+        const uint32_t n_rows = a.ts >> 12;
+        const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit);
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
             hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(TPB), lds, w->stream, a);

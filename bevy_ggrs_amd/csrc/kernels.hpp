@@ -1283,7 +1283,7 @@ struct GenArgs {
     uint8_t inputs[MAX_TICK_STEPS][16]; uint8_t n_inputs[MAX_TICK_STEPS];
     uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len, cols_base;
-    uint32_t ts, sub, n_words, n_masks, pad0, n_sys, n_cks, part_stride;
+    uint32_t ts, sub, n_words, n_masks, n_units, n_sys, n_cks, part_stride;
     uint64_t mask_off[MAX_MASKS];
     const GenWord* words; const GenUnit* units;
     uint32_t cks_pmask[GEN_MAX_CKS], cks_unit_base[GEN_MAX_CKS], cks_n_units[GEN_MAX_CKS];   // pmask: mask index
@@ -1291,6 +1291,15 @@ struct GenArgs {
     GenSys sys[GEN_MAX_SYS];
 };
 static_assert(sizeof(GenArgs) <= 4096, "kernel argument segment limit");
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
+// snapshot store still in flight (1-2 us per Save); nobody in the workgroup reads those stores back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // vmcnt(63) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1300,16 +1309,42 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     const uint64_t tbase = a.cols_base + (s0 >> 10) * a.ts;           // its tile inside a block
     const uint32_t in_tile = (uint32_t)(s0 & 1023u);
     const bool in_len = s0 < a.len;                                   // workgroup-uniform
-    uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + (size_t)(a.ts >> 10) * sub);   // [n_masks][mw] behind the words; mask 0 = liveness
+    const uint32_t n_rows = a.ts >> 12;                               // 4-byte row units per slot (8-byte words = 2)
+    const uint32_t img = n_rows * sub * 4u;                           // bytes of the word image
+    uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + img);         // [n_masks][mw] behind the words; mask 0 = liveness
+    // small tables staged once: global offset of every row unit of this workgroup, the checksum units
+    uint32_t* grow = reinterpret_cast<uint32_t*>(lds + img + a.n_masks * mw * 8u);   // [n_rows] byte offset inside the tile
+    GenUnit* lunits = reinterpret_cast<GenUnit*>(grow + ((n_rows + 3u) & ~3u));      // [n_units]
+    for (uint32_t w = tid; w < a.n_words; w += TPB) {
+        const GenWord gw = a.words[w];
+        const uint32_t r0 = gw.pso >> 2;
+        grow[r0] = gw.tcol + in_tile * gw.wb;
+        if (gw.wb == 8) grow[r0 + 1] = gw.tcol + in_tile * 8u + sub * 4u;      // second half of the contiguous sub x 8 bytes
+    }
+    for (uint32_t u = tid; u < a.n_units; u += TPB) lunits[u] = a.units[u];
+    __syncthreads();
 
-    auto copy_words = [&](uint8_t* block, bool to_block) {            // LDS image <-> one state block
-        for (uint32_t w = 0; w < a.n_words; ++w) {
-            const GenWord gw = a.words[w];
-            uint8_t* g = block + tbase + gw.tcol + (uint64_t)in_tile * gw.wb;
-            const uint32_t bytes = sub * gw.wb;
-            for (uint32_t o = tid * 16u; o < bytes; o += TPB * 16u) {
-                if (to_block) *reinterpret_cast<u32x4*>(g + o) = *reinterpret_cast<const u32x4*>(lds + gw.pso * sub + o);
-                else *reinterpret_cast<u32x4*>(lds + gw.pso * sub + o) = *reinterpret_cast<const u32x4*>(g + o);
+    // LDS image <-> one state block: 16-byte chunks, chunk c lives at LDS byte c * 16, 4 chunks in flight per lane
+    const uint32_t n_chunks = img >> 4, chunks_per_row = sub >> 2;
+    auto copy_words = [&](uint8_t* block, bool to_block) {
+        uint8_t* gb = block + tbase;
+        for (uint32_t c0 = tid; c0 < n_chunks; c0 += 4 * TPB) {
+            u32x4 v[4]; uint32_t goff[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = c0 + j * TPB;
+                if (c < n_chunks) {
+                    goff[j] = grow[c / chunks_per_row] + (c % chunks_per_row) * 16u;
+                    v[j] = to_block ? *reinterpret_cast<const u32x4*>(lds + c * 16u) : *reinterpret_cast<const u32x4*>(gb + goff[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = c0 + j * TPB;
+                if (c < n_chunks) {
+                    if (to_block) *reinterpret_cast<u32x4*>(gb + goff[j]) = v[j];
+                    else *reinterpret_cast<u32x4*>(lds + c * 16u) = v[j];
+                }
             }
         }
     };
@@ -1328,15 +1363,7 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     for (uint32_t op = 0; op < a.n_ops; ++op) {
         if (!((a.op_bits >> op) & 1ULL)) {
             // ---------------- SaveWorld: snapshot + per-entity half of every component checksum
-            uint8_t* dst = a.save_dst[si];
-            if (dst) {
-                if (in_len) copy_words(dst, true);
-                copy_masks(dst, true);
-                if (blockIdx.x == 0 && tid == 0) {
-                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = h;
-                }
-            }
+            // (every lane hashes the slots it also steps in Advance ops: no barrier needed before this part)
             uint64_t* prow = a.parts + (uint64_t)si * (a.n_cks + 1) * a.part_stride + (uint64_t)blockIdx.x * 4 + wave;
             for (uint32_t k = 0; k < a.n_cks; ++k) {
                 const uint64_t* pm = lmask + a.cks_pmask[k] * mw;
@@ -1345,7 +1372,7 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
                     if (((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL) {
                         SeaStream st;
                         for (uint32_t u = 0; u < a.cks_n_units[k]; ++u) {
-                            const GenUnit gu = a.units[a.cks_unit_base[k] + u];
+                            const GenUnit gu = lunits[a.cks_unit_base[k] + u];
                             st.unit(*reinterpret_cast<const uint32_t*>(lds + gu.pso * sub + gu.add + i * gu.stride));
                         }
                         h ^= sea_pair(s0 + i, st.finish());              // order == slot
@@ -1357,8 +1384,19 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
             uint32_t cnt = 0;
             for (uint32_t wi = wave; wi < mw; wi += 4) cnt += (uint32_t)__popcll(lmask[wi]);
             if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;
+            // the snapshot copy moves 16-byte chunks whatever lane owns their slots: barriers on both sides
+            lds_barrier();
+            uint8_t* dst = a.save_dst[si];
+            if (dst) {
+                if (in_len) copy_words(dst, true);
+                copy_masks(dst, true);
+                if (blockIdx.x == 0 && tid == 0) {
+                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = h;
+                }
+            }
+            lds_barrier();
             ++si;
-            __syncthreads();          // the copy above reads LDS bytes that OTHER waves' lanes own in the next Advance
         } else {
             // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
             const float dt = __uint_as_float(a.dt_bits[sj]);
@@ -1428,14 +1466,13 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
                     default: break;
                     }
                     const uint64_t kills = __ballot(kill);
-                    if (kills && lane == 0) lmask[wi] = alive_w & ~kills;
+                    if (kills && lane == 0) lmask[wi] = alive_w & ~kills;   // word wi is only ever read by this wave: no barrier
                 }
-                __syncthreads();
             }
             ++sj;
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- the live block, written once
     if (!a.src_is_live || a.n_steps) {
         if (in_len) copy_words(a.live, true);
