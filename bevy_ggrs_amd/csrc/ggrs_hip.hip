@@ -332,6 +332,7 @@ int seal(ggrs_world* w) {
         }
         a.off_ttl = w->col_off[L.col_base + w->f_lw];
         a.ts = w->ts;
+        a.nt_load = (getenv("GGRS_TICK_NTLOAD") && atoi(getenv("GGRS_TICK_NTLOAD"))) ? 1u : 0u;
         for (uint32_t c = 0; c < w->comps.size(); ++c)
             if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
         for (uint32_t c = 0; c < w->comps.size(); ++c) {

@@ -440,6 +440,7 @@ struct TickArgs {
     uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
     uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len;
+    uint32_t nt_load, pad1;
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
@@ -532,13 +533,17 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
     const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
     float4 tx[3], vv[3];
     ulonglong2 tl[2];
+    // the source block is read exactly once: a.nt_load (A/B knob GGRS_TICK_NTLOAD) marks the loads non-temporal
+    auto ld16 = [&](const uint8_t* p) -> u32x4 {
+        return a.nt_load ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+    };
     if (in_len) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float4*>(a.src + a.off_t[k] + toff + o4);
+        for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float4*>(a.src + a.off_v[k] + toff + o4);
-        tl[0] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + toff + o8);
-        tl[1] = *reinterpret_cast<const ulonglong2*>(a.src + a.off_ttl + toff + 16 + o8);
+        for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
+        { const u32x4 x = ld16(a.src + a.off_ttl + toff + o8); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
+        { const u32x4 x = ld16(a.src + a.off_ttl + toff + 16 + o8); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
             if ((uint32_t)j < a.n_rest_rows) {                   // wave-uniform
                 const RowLite rd = a.rest[j];
                 restpos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff;
-                if (in_len) restv[j] = *reinterpret_cast<const u32x4*>(a.src + restpos[j] + tid * 16u);
+                if (in_len) restv[j] = ld16(a.src + restpos[j] + tid * 16u);
             }
         }
     } else if (in_len && (a.n_saves || !a.src_is_live)) {
