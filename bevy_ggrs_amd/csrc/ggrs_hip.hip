@@ -908,7 +908,9 @@ void apply_synctest_confirmed(ggrs_world* w) {
 }
 
 // ---- fused request groups: [Load?] (Save | Advance)* as ONE k_tick launch + one finalize ----
-constexpr uint64_t TICK_VEC1_MAX_SLOTS = 512 * 1024;   // measured crossover, see DESIGN.md section 6
+// measured crossovers (profiles/README.md, run wpb1): the 1-slot-per-lane kernel has the shortest per-wave dependency
+// chain and wins while the chip is under-filled; single-wave workgroups of the 4-slots-per-lane kernel win in between
+constexpr uint64_t TICK_VEC1_MAX_SLOTS = 400 * 1024, TICK_WAVE_WG_MAX_SLOTS = 800 * 1024;
 bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
     if (r.spawn_count == 0) return false;
     for (auto& s : w->systems) {
@@ -927,13 +929,14 @@ void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
 }
 
 constexpr int TICK_RESTL = 8;          // rest rows the register-resident variant of k_tick can carry
-template <bool NT>
+// wpb: waves per workgroup (4: one 1024-slot tile per workgroup, g = tiles; 1: one 256-slot quarter per workgroup)
+template <bool NT, int WPB>
 void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
     const uint32_t lds = w->tick_lds;
     const bool rl = w->tick_rest_loop && a.n_rest_rows <= (uint32_t)TICK_RESTL && a.n_rest_rows > 0 && a.n_saves > 0;
 #define GGRS_LAUNCH_TICK(T_, V_) do { \
-        if (rl) hipLaunchKernelGGL((k_tick<T_, V_, NT, TICK_RESTL>), dim3(g), dim3(TPB), lds, w->stream, a); \
-        else hipLaunchKernelGGL((k_tick<T_, V_, NT, 0>), dim3(g), dim3(TPB), lds, w->stream, a); } while (0)
+        if (rl) hipLaunchKernelGGL((k_tick<T_, V_, NT, TICK_RESTL, WPB>), dim3(g), dim3(WPB * 64), lds, w->stream, a); \
+        else hipLaunchKernelGGL((k_tick<T_, V_, NT, 0, WPB>), dim3(g), dim3(WPB * 64), lds, w->stream, a); } while (0)
     if (w->f_cksT && w->f_cksV) GGRS_LAUNCH_TICK(true, true);
     else if (w->f_cksT) GGRS_LAUNCH_TICK(true, false);
     else if (w->f_cksV) GGRS_LAUNCH_TICK(false, true);
@@ -1000,16 +1003,19 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         }
         // ---- one pass over the tiles
         cover = std::max(cover, w->len);
-        // tile width: 1 slot/lane (256-slot tiles) for worlds that would not fill the chip with
-        // 1024-slot tiles, 4 slots/lane (16-byte accesses) for big ones
-        const int vec = w->tick_vec ? w->tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : 4);
-        const uint32_t g = vec == 1 ? std::max(1u, (uint32_t)((cover + TILE1 - 1) / TILE1)) : std::max(1u, tiles_for(cover));
+        // kernel shape by world size: k_tick1 (1 slot per lane, 256-slot workgroups) for small worlds, k_tick with
+        // single-wave workgroups (256 slots, 16 B per lane) in between, k_tick with one 1024-slot tile per 4-wave
+        // workgroup for big ones; GGRS_TICK_VEC = 1 / 41 / 4 forces one (A/B)
+        const int vec = w->tick_vec ? w->tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : (cover <= TICK_WAVE_WG_MAX_SLOTS ? 41 : 4));
+        const uint32_t n_waves = std::max(1u, (uint32_t)((cover + TILE1 - 1) / TILE1));      // 256-slot quarters
+        const uint32_t g = vec == 4 ? std::max(1u, tiles_for(cover)) : n_waves;
         a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
             if (vec == 1) { if (w->nt_copy) launch_tick1<true>(w, a, g); else launch_tick1<false>(w, a, g); }
-            else { if (w->nt_copy) launch_tick<true>(w, a, g); else launch_tick<false>(w, a, g); }
+            else if (vec == 41) { if (w->nt_copy) launch_tick<true, 1>(w, a, g); else launch_tick<false, 1>(w, a, g); }
+            else { if (w->nt_copy) launch_tick<true, 4>(w, a, g); else launch_tick<false, 4>(w, a, g); }
         }
         HIPCHK(w, hipGetLastError());
         const uint64_t new_dirty = std::max(src->dirty_len, w->len);
@@ -1018,7 +1024,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         w->pending_valid = false;
         if (a.n_saves) {
             TickFinArgs f; memset(&f, 0, sizeof f);
-            f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = 4 * g;
+            f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = vec == 4 ? 4 * g : (vec == 41 ? g : 4 * g);
             f.cks_T = w->f_cksT; f.cks_V = w->f_cksV; f.total_len = w->len;
             f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
             {
@@ -1166,7 +1172,7 @@ int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
     w->max_depth = d->max_depth ? d->max_depth : 8; w->flags = d->flags;
     w->depth = w->max_depth;
     w->nt_copy = (d->flags & GGRS_WORLD_NT_COPY) != 0;
-    if (const char* v = getenv("GGRS_TICK_VEC")) { const int x = atoi(v); if (x == 1 || x == 4) w->tick_vec = x; }
+    if (const char* v = getenv("GGRS_TICK_VEC")) { const int x = atoi(v); if (x == 1 || x == 4 || x == 41) w->tick_vec = x; }
     if (const char* v = getenv("GGRS_TICK_LDS")) { const int x = atoi(v); if (x >= 0 && x <= 160 * 1024) w->tick_lds = (uint32_t)x; }
     if (const char* v = getenv("GGRS_TICK_REST")) w->tick_rest_loop = atoi(v) != 0;
     if (!d->arena) {

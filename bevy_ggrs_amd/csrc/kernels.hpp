@@ -513,10 +513,18 @@ __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_
 // workgroups resident (4 * RESTL more VGPRs), each snapshot's tile written as one burst.  Measured 128-129 us vs
 // 126-136 us (the plain variant is bimodal with the arena's placement, profiles/README.md); default when the
 // world has at most RESTL such rows, GGRS_TICK_REST=0 selects the fan-out variant.
-template <bool CKS_T, bool CKS_V, bool NT, int RESTL = 0>
-__global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
-    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const bool in_len = (uint64_t)t * TILE < a.len;               // workgroup-uniform
+// WPB = waves per workgroup.  Every wave owns one 256-slot quarter of a tile and shares nothing with the other
+// waves (no LDS, no barrier), so the same code runs as 4-wave workgroups (one tile each) for big worlds and as
+// single-wave workgroups for small ones: four times as many workgroups to spread over the 256 CUs, still 16 bytes
+// per lane per access.
+template <bool CKS_T, bool CKS_V, bool NT, int RESTL = 0, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // readfirstlane: the wave index is uniform, and the compiler must know it (uniform bases live in SGPRs)
+    const uint32_t gw = blockIdx.x * WPB + (WPB == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));   // global wave id == 256-slot quarter tile
+    const uint32_t t = gw >> 2, wave = gw & 3u;                   // its tile, and which quarter of it
+    const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
+    const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
     // every access below is "uniform 64-bit base (block + column row + tile offset) + 32-bit lane
     // offset", i.e. the saddr form of global_load/store
@@ -551,9 +559,9 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
     }
 
     // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
-    if (tid < 16u * a.n_rest_masks) {
-        const uint32_t m = tid >> 4, mw = tid & 15u;
-        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)t * 16 + mw) * 8;
+    if (lane < 4u * a.n_rest_masks) {                             // this wave's 4 words of every such mask
+        const uint32_t m = lane >> 2, mw = lane & 3u;
+        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
         const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
         for (uint32_t k = 0; k < a.n_saves; ++k)
             if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
         if (lane == 0) {
             // plain per-wave partial stores: agent-scope atomics (tried: 64 accumulator copies + last-block
             // fold) cost ~1 ns EACH chip-wide on gfx950 -- 94k of them added 90 us to a 134 us kernel
-            uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
+            uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + gw;
             p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = cnt;
         }
     };
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(TPB) void k_tick(TickArgs a) {
                     st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
                     st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
                 }
-                if (t == 0 && tid == 0) {
+                if (gw == 0 && lane == 0) {
                     Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
                     h.checksum[0] = 0; h.checksum[1] = 0;
                     *reinterpret_cast<Header*>(dst) = h;
