@@ -23,8 +23,8 @@ flight (a shim collects right before the next advance_frame()); `--sync` blocks 
 N > 1 (one process per GPU, launched by torch.distributed.run): speculative fan-out -- rank 0's
 confirmed snapshot is broadcast ONCE over RCCL/xGMI; per step every rank runs ONE request list of the
 same shape as the N = 1 tick (1 load + D saves + D+1 advances: the confirmed input for frame C, then its
-own predicted-input branch for the following frames), one step in flight, and ONE all-gather of the
-checksums per step on a side stream (bevy_ggrs_amd/fanout.py).  Weak scaling (per-GPU work fixed).
+own predicted-input branch for the following frames), two steps in flight, and ONE all-gather of the checksums
+per desync-detection interval (10 steps, the reference stress_test's default) on a side stream (bevy_ggrs_amd/fanout.py).  Weak scaling (per-GPU work fixed).
 `--fanout` forces this code path at world size 1 (validation on a 1-GPU box).
 """
 from __future__ import annotations
@@ -224,7 +224,8 @@ def main():
         else:
             w.spawn(0, {})                                   # seals the world (layout fixed)
         fan = SpeculativeFanout(w, dist, depth=D, exchange=HipStateExchange(w, arena),
-                                branches_per_rank=1)
+                                branches_per_rank=1, max_inflight=2,
+                                desync_detection_interval=10)   # the reference stress_test's default (particles.rs:49, README.md:84)
         fan.sync_confirmed(0)
         for _ in range(W):
             fan.step_pipelined(want_result=False)
@@ -312,7 +313,7 @@ def main():
         "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (RCCL broadcast of the confirmed snapshot once, one checksum all-gather per step)",
+                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (RCCL broadcast of the confirmed snapshot once; one checksum all-gather per 10 steps = the reference's --desync-detection-interval default)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,

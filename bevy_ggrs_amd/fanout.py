@@ -65,29 +65,42 @@ class HipStateExchange:
         torch.cuda.current_stream().synchronize()
         w.adopt_live_state()
 
-    def all_gather_u64(self, dist, values: np.ndarray) -> np.ndarray:
-        """Checksums come from host memory: the H2D copy, the RCCL all-gather and the D2H copy run on a side
-        stream, so they neither wait for nor delay the kernels already enqueued on the world's stream.
-        Staging buffers (pinned host, device) are allocated once per message size."""
+    def all_gather_u64_start(self, dist, values: np.ndarray):
+        """Checksums come from host memory: the H2D copy, the RCCL all-gather and the D2H copy are queued on a side
+        stream, so they neither wait for nor delay the kernels already enqueued on the world's stream, and the host
+        does not wait for them here.  Staging buffers (pinned host, device) rotate over 4 sets per message size."""
         import torch
         n, size = int(values.size), dist.get_world_size()
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self.arena.device)
-            self._bufs = {}
-        b = self._bufs.get(n)
-        if b is None:
+            self._bufs, self._turn = {}, 0
+        ring = self._bufs.setdefault(n, [])
+        if len(ring) < 4:
             h_in = torch.empty(n, dtype=torch.int64).pin_memory()
             h_out = torch.empty((size, n), dtype=torch.int64).pin_memory()
-            b = self._bufs[n] = {"h_in": h_in, "h_in_np": h_in.numpy(), "h_out": h_out, "h_out_np": h_out.numpy(),
-                                 "d_in": torch.empty(n, dtype=torch.int64, device=self.arena.device),
-                                 "d_out": torch.empty((size, n), dtype=torch.int64, device=self.arena.device)}
+            ring.append({"h_in": h_in, "h_in_np": h_in.numpy(), "h_out": h_out, "h_out_np": h_out.numpy(),
+                         "d_in": torch.empty(n, dtype=torch.int64, device=self.arena.device),
+                         "d_out": torch.empty((size, n), dtype=torch.int64, device=self.arena.device),
+                         "done": torch.cuda.Event()})
+            b = ring[-1]
+        else:
+            b = ring[self._turn % 4]
+            b["done"].synchronize()                          # its previous use (4 gathers ago) is long over
+        self._turn += 1
         b["h_in_np"][:] = values.view(np.int64)
         with torch.cuda.stream(self._comm):
             b["d_in"].copy_(b["h_in"], non_blocking=True)
             dist.all_gather_into_tensor(b["d_out"], b["d_in"])
             b["h_out"].copy_(b["d_out"], non_blocking=True)
-        self._comm.synchronize()
-        return b["h_out_np"].view(np.uint64).copy()
+            b["done"].record(self._comm)
+        return b
+
+    def all_gather_u64_finish(self, token) -> np.ndarray:
+        token["done"].synchronize()
+        return token["h_out_np"].view(np.uint64).copy()
+
+    def all_gather_u64(self, dist, values: np.ndarray) -> np.ndarray:
+        return self.all_gather_u64_finish(self.all_gather_u64_start(dist, values))
 
 
 def make_torch_world(bg, capacity: int, max_depth: int, n_components: int, bytes_per_slot: int,
@@ -114,8 +127,11 @@ class SpeculativeFanout:
                  branch_input: Callable[[int, int], int] = default_branch_input,
                  confirmed_input: Callable[[int], int] = lambda frame: 0,
                  spawn_fn: Optional[Callable[[int], tuple]] = None, spawn_mask: int = 1 << 4,
-                 num_players: int = 1):
+                 num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1):
         self.w, self.dist, self.D, self.x = world, dist, depth, exchange
+        self.interval = max(1, desync_detection_interval)    # steps whose checksums share one all-gather (pipelined path)
+        self._acc: list = []
+        self.max_inflight = max_inflight                     # steps enqueued on the device before the oldest is collected
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.bpr = branches_per_rank
         self.branch_input, self.confirmed_input = branch_input, confirmed_input
@@ -126,6 +142,8 @@ class SpeculativeFanout:
         self._tmpl = None
         self.confirmed = world.frame
         self._inflight: List[int] = []
+        self._gathers: list = []
+        self.results: list = []                              # every result the pipelined path completes, in step order
         world.set_depth(depth + 1)
 
     # ------------------------------------------------------------------ helpers
@@ -161,17 +179,49 @@ class SpeculativeFanout:
             reqs.append(self._advance(C + D, self.branch_input(b, C + D)))      # the newest predicted frame stays live-only
         return reqs
 
-    def _finish(self, C: int, mine: np.ndarray, want_result: bool = True) -> Optional[dict]:
-        """mine: this rank's bpr x D checksums as a (bpr*D, 2) u64 array {lo, hi}."""
+    def _check(self, C: int, allv: np.ndarray, want_result: bool = True) -> Optional[dict]:
         D, n = self.D, self.bpr * self.D
-        # ---- ONE all-gather: bpr x D checksums, u128 as 2 x u64
-        allv = self.x.all_gather_u64(self.dist, np.ascontiguousarray(mine).reshape(-1)).reshape(self.size, max(n, 1), 2)
+        allv = allv.reshape(self.size, max(n, 1), 2)
         conf = allv[:, 0:n:D, :].reshape(-1, 2)              # the C+1 entry of every branch of every rank
         if (conf != conf[0]).any():
             self.synced = False                              # caller may sync_confirmed() again
             raise DesyncDetected(C + 1, [int(p[0]) | (int(p[1]) << 64) for p in conf])
         self._last_raw = (C, allv)
         return self.last if want_result else None
+
+    def _finish(self, C: int, mine: np.ndarray, want_result: bool = True, defer: bool = False) -> Optional[dict]:
+        """mine: this rank's bpr x D checksums as a (bpr*D, 2) u64 array {lo, hi}; u128 as 2 x u64.
+        Synchronous path: ONE all-gather per step.  Pipelined path (defer): the checksums of
+        `desync_detection_interval` consecutive steps travel in ONE all-gather (the reference's stress_test exchanges
+        checksums every `--desync-detection-interval` frames, default 10: examples/stress_tests/particles.rs:49,135-137),
+        and the host never waits for a collective it has just launched: it completes the one started before."""
+        if not defer:
+            return self._check(C, self.x.all_gather_u64(self.dist, np.ascontiguousarray(mine).reshape(-1)), want_result)
+        self._acc.append((C, np.ascontiguousarray(mine)))
+        if len(self._acc) < self.interval:
+            return None
+        return self._launch_gather(want_result)
+
+    def _launch_gather(self, want_result: bool) -> Optional[dict]:
+        steps = [c for c, _ in self._acc]
+        flat = np.concatenate([m.reshape(-1) for _, m in self._acc])
+        self._acc = []
+        if hasattr(self.x, "all_gather_u64_start"):
+            self._gathers.append((steps, self.x.all_gather_u64_start(self.dist, flat)))
+            if len(self._gathers) <= 1:
+                return None
+            return self._complete(*self._gathers.pop(0), want_result)
+        return self._complete(steps, None, want_result, data=self.x.all_gather_u64(self.dist, flat))
+
+    def _complete(self, steps, token, want_result: bool, data=None) -> Optional[dict]:
+        allv = data if data is not None else self.x.all_gather_u64_finish(token)
+        allv = allv.reshape(self.size, len(steps), -1)
+        out = None
+        for k, C in enumerate(steps):
+            out = self._check(C, np.ascontiguousarray(allv[:, k, :]), want_result)
+            if out is not None:
+                self.results.append(out)
+        return out
 
     @property
     def last(self) -> dict:
@@ -223,16 +273,19 @@ class SpeculativeFanout:
             arr[i].frame = C + rel
         per_branch = D + 1
         c_in = self.confirmed_input(C)
+        ids = self.branch_ids()
+        inputs = [c_in if k % per_branch == 0 else self.branch_input(ids[k // per_branch], C + k % per_branch) for k in range(len(t["advs"]))]
+        if inputs == t.get("inputs"):                        # the usual case: predictions repeat, nothing to rewrite
+            return
+        t["inputs"] = inputs
         for k, i in enumerate(t["advs"]):
-            b, j = self.branch_ids()[k // per_branch], k % per_branch
-            inp = c_in if j == 0 else self.branch_input(b, C + j)
             q = arr[i]
             for p in range(q.n_inputs):
-                q.inputs[p] = inp
+                q.inputs[p] = inputs[k]
 
     def step_pipelined(self, want_result: bool = True) -> Optional[dict]:
-        """Enqueue the step of confirmed frame C on the device, THEN collect and all-gather the previous
-        step (one step in flight).  Returns the previous step's result (None on the first call)."""
+        """Enqueue the step of confirmed frame C on the device, THEN collect and all-gather the oldest step once more
+        than `max_inflight` are queued.  Returns that step's result (None while the pipeline fills)."""
         if not self.synced:
             self.sync_confirmed(0)
         if self.bpr * self.D > 256 or not hasattr(self.w, "enqueue_requests_raw"):
@@ -248,20 +301,29 @@ class SpeculativeFanout:
             self.w.enqueue_requests(self._requests(C))
         self._inflight.append(C)
         self.confirmed = C + 1
-        return self._collect_one(want_result) if len(self._inflight) > 1 else None
+        return self._collect_one(want_result) if len(self._inflight) > self.max_inflight else None
 
     def _collect_one(self, want_result: bool = True) -> Optional[dict]:
         C = self._inflight.pop(0)
         n = self.bpr * self.D
         if self._tmpl is not None:
             self.w.collect_checksums_raw(self._tmpl["out"], n)
-            return self._finish(C, self._tmpl["out_np"][:max(n, 1)].copy(), want_result)
-        return self._finish(C, self._as_u64_pairs(self.w.collect_checksums(n)), want_result)
+            return self._finish(C, self._tmpl["out_np"][:max(n, 1)].copy(), want_result, defer=True)
+        return self._finish(C, self._as_u64_pairs(self.w.collect_checksums(n)), want_result, defer=True)
 
     def drain(self, want_result: bool = True) -> Optional[dict]:
+        """Collect every step still on the device and complete every collective still in flight; returns the newest
+        result.  (Results of the pipelined path arrive in order, possibly more than one per call: see `results`.)"""
         out = None
         while self._inflight:
-            out = self._collect_one(want_result)
+            r = self._collect_one(want_result)
+            if r is not None: out = r
+        if self._acc:                                        # a partly filled interval
+            r = self._launch_gather(want_result)
+            if r is not None: out = r
+        while self._gathers:
+            r = self._complete(*self._gathers.pop(0), want_result)
+            if r is not None: out = r
         return out
 
     def settle(self) -> int:

@@ -38,10 +38,11 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
                                 spawn_fn=cm.frame_spawn_fn(50))
         # first half synchronously, second half with one step in flight (enqueue k+1, then collect + all-gather k)
         out = [fan.step() for _ in range(steps // 2)]
+        fan.results.clear()
         for _ in range(steps - steps // 2):
-            r = fan.step_pipelined()
-            if r is not None: out.append(r)
-        out.append(fan.drain())
+            fan.step_pipelined()
+        fan.drain()
+        out += fan.results                                  # every step the pipelined path completed, in order
         fan.settle()
         ref, ref_state = _serial_reference(n, D, bpr, steps)
         assert len(out) == len(ref) == steps
@@ -69,7 +70,7 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
         # ---- the pre-marshalled pipelined path (no spawn payloads: frames and input bytes patched in place)
         # must reproduce the synchronous path
         res = []
-        for mode in ("sync", "pipelined"):
+        for mode in ("sync", "pipelined", "pipelined3"):
             wp, arenap = make_torch_world(bg, 5000, D + 2, 3, 60, torch.device("cuda", 0))
             idsp = cm.build_particles(wp)
             vel, ttl = cm.synthetic_particles(5000, ttl="despawn")
@@ -79,11 +80,15 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
             if mode == "sync":
                 outp = [fp.step() for _ in range(7)]
             else:
-                outp = [r for r in (fp.step_pipelined() for _ in range(7)) if r is not None] + [fp.drain()]
+                fp.interval = 3 if mode == "pipelined3" else 1   # checksums of 3 steps per all-gather
+                for _ in range(7): fp.step_pipelined()
+                fp.drain()
+                outp = list(fp.results)
             fp.settle()
             res.append((outp, cm.snapshot_state(wp, idsp)))
-        assert len(res[0][0]) == len(res[1][0]) == 7 and res[0][0] == res[1][0]
-        cm.assert_states_equal(res[0][1], res[1][1], "pipelined fan-out")
+        for r in res[1:]:
+            assert len(res[0][0]) == len(r[0]) == 7 and res[0][0] == r[0]
+            cm.assert_states_equal(res[0][1], r[1], "pipelined fan-out")
 
         # ---- BASELINE config 5 on the one GPU of this box: 256 predicted-input branches (branch id = the input
         # byte repeated every frame), 100k entities, 8 frames each, all on rank 0; inputs with
