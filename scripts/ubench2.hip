@@ -136,6 +136,28 @@ __global__ __launch_bounds__(256) void fan_rot(u32x4* ring, u32x4* live, size_t 
     for (int j = 0; j < ROWS; ++j) st<false>(l + j * 256, v[j]);
 }
 
+// same rotation, but the block the NEXT launch will read (src + 1) is stored LAST instead of first: is a block
+// that was just written still cache-resident (L2 / Infinity Cache) when the next launch reads it?
+template <bool NT>
+__global__ __launch_bounds__(256) void fan_rot_last(u32x4* ring, u32x4* live, size_t bs, int src_slot, int tiles) {
+    const int t = blockIdx.x;
+    u32x4 v[ROWS];
+    const u32x4* s = ring + (size_t)src_slot * bs + (size_t)t * TILE_V + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) v[j] = s[j * 256];
+    for (int k = 2; k <= 9; ++k) {
+        const int d = (src_slot + (k == 9 ? 1 : k)) % 9;
+        u32x4* p = ring + (size_t)d * bs + (size_t)t * TILE_V + threadIdx.x;
+        if (k == 9) {      // the next source: after the live block
+            u32x4* l = live + (size_t)t * TILE_V + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) st<false>(l + j * 256, v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { v[j].x += d; st<NT>(p + j * 256, v[j]); }
+    }
+}
+
 int main(int argc, char** argv) {
     const int tiles = 977;
     const size_t bs = (size_t)tiles * TILE_V;            // u32x4 per block
@@ -175,6 +197,9 @@ int main(int argc, char** argv) {
     timeit("fan ROTATING src (engine-like), default stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
     timeit("fan ROTATING src (engine-like), nt stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot<true>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
     timeit("fan ROTATING src (engine-like), default stores again", F, [&](int i) { hipLaunchKernelGGL(fan_rot<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
+    timeit("fan ROTATING, next source stored LAST, default stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_last<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
+    timeit("fan ROTATING, next source stored LAST, nt stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_last<true>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
+    timeit("fan ROTATING src (engine-like), default stores #3", F, [&](int i) { hipLaunchKernelGGL(fan_rot<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
     timeit("fan slot-major", F, [&](int) { hipLaunchKernelGGL((fan<false, 0, false>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
     timeit("fan slot-major nt", F, [&](int) { hipLaunchKernelGGL((fan<true, 0, false>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
     timeit("fan slot-major row-order", F, [&](int) { hipLaunchKernelGGL((fan<false, 0, true>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
