@@ -920,6 +920,59 @@ bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
     return false;
 }
 
+
+// ---- bookkeeping shared by the two request-group runners (k_tick and k_tick_gen): everything the host does in
+// request order while a group is assembled -- frame counters, ring push / confirm / rollback, dirty extents
+struct GroupState {
+    Block* src; uint64_t cover; uint32_t src_is_live;
+    Block* dsts[MAX_TICK_SAVES];
+};
+// LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
+int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState& g) {
+    g.src = &w->live; g.cover = w->live.dirty_len; g.src_is_live = 1;
+    if (reqs[i].kind != GGRS_REQ_LOAD) return GGRS_OK;
+    apply_synctest_confirmed(w);
+    w->frame = reqs[i].frame;
+    if (!ring_rollback(w, reqs[i].frame))
+        return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
+    g.src = &w->slots[w->ring_slot.front()];
+    int rc = launch_load_reconcile(w, *g.src); if (rc) return rc;        // EntityResurrect: before the group rewrites live liveness
+    w->len = g.src->len;
+    g.cover = std::max(g.cover, g.src->dirty_len);
+    g.src_is_live = 0;
+    ++i;
+    return GGRS_OK;
+}
+// SaveGameState inside a group: discard_old_snapshots + GgrsSnapshots::push (mod.rs:147-202); the copy itself is an op of the kernel
+int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int32_t* save_frame) {
+    apply_synctest_confirmed(w);
+    if (w->has_confirmed) ring_confirm(w, w->confirmed);
+    int sl = -1;
+    int rc = ring_push(w, w->frame, &sl); if (rc) return rc;
+    Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
+    g.dsts[k] = d;
+    save_dst[k] = d ? d->ptr : nullptr;
+    save_frame[k] = w->frame;
+    if (d) { g.cover = std::max(g.cover, d->dirty_len); d->len = w->len; }
+    return GGRS_OK;
+}
+// AdvanceFrame inside a group: RollbackFrameCount += 1 (schedule_systems.rs:254-259), DespawnConfirmed, Time<GgrsTime>.
+// DespawnConfirmed only touches the live-only marker mask, which no op inside a group reads or writes: queueing it
+// ahead of the group's launch keeps request order.
+int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out) {
+    apply_synctest_confirmed(w);
+    w->frame += 1;
+    int rc = step_despawn_confirmed(w); if (rc) return rc;
+    *dt_bits_out = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+    return GGRS_OK;
+}
+void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves) {
+    const uint64_t new_dirty = std::max(g.src->dirty_len, w->len);
+    for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) g.dsts[k]->dirty_len = new_dirty;
+    w->live.dirty_len = new_dirty;
+    w->pending_valid = false;
+}
+
 template <bool NT>
 void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
     if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
@@ -952,48 +1005,22 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
     int rc = GGRS_OK;
     while (i < n) {
         TickArgs a = w->tick_proto;
-        Block* src = &w->live;
-        uint64_t cover = w->live.dirty_len;
-        a.src_is_live = 1;
-        Block* dsts[MAX_TICK_SAVES];
+        GroupState gs;
         const ggrs_request* spawn_req = nullptr;
-        // ---- LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
-        if (reqs[i].kind == GGRS_REQ_LOAD) {
-            apply_synctest_confirmed(w);
-            w->frame = reqs[i].frame;
-            if (!ring_rollback(w, reqs[i].frame))
-                return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
-            src = &w->slots[w->ring_slot.front()];
-            rc = launch_load_reconcile(w, *src); if (rc) return rc;          // EntityResurrect: before k_tick rewrites live liveness
-            w->len = src->len;
-            cover = std::max(cover, src->dirty_len);
-            a.src_is_live = 0;
-            ++i;
-        }
+        rc = group_open(w, reqs, i, gs); if (rc) return rc;
+        a.src_is_live = gs.src_is_live;
         // ---- gather the ops that follow, doing the host-side bookkeeping in request order
         while (i < n && a.n_ops < (uint32_t)MAX_TICK_OPS) {
             const ggrs_request& r = reqs[i];
             if (r.kind == GGRS_REQ_LOAD) break;
             if (r.kind == GGRS_REQ_SAVE) {
                 if (a.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + a.n_saves == w->max_results)) break;
-                apply_synctest_confirmed(w);
-                if (w->has_confirmed) ring_confirm(w, w->confirmed);        // discard_old_snapshots
-                int sl = -1;
-                rc = ring_push(w, w->frame, &sl); if (rc) return rc;        // GgrsSnapshots::push
-                Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
-                dsts[a.n_saves] = d;
-                a.save_dst[a.n_saves] = d ? d->ptr : nullptr;
-                a.save_frame[a.n_saves] = w->frame;
-                if (d) { cover = std::max(cover, d->dirty_len); d->len = w->len; }
+                rc = group_save(w, gs, a.n_saves, a.save_dst, a.save_frame); if (rc) return rc;
                 ++a.n_ops; ++a.n_saves;                                     // op bit stays 0: Save
             } else if (r.kind == GGRS_REQ_ADVANCE) {
                 if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
-                apply_synctest_confirmed(w);
-                w->frame += 1;                                              // schedule_systems.rs:254-259
-                // DespawnConfirmed only touches the live-only marker mask, which k_tick never reads and
-                // no op inside a group writes: queueing it ahead of the group's launch keeps request order
-                rc = step_despawn_confirmed(w); if (rc) return rc;
-                a.dt_bits[a.n_steps++] = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+                rc = group_step(w, r, &a.dt_bits[a.n_steps]); if (rc) return rc;
+                ++a.n_steps;
                 a.op_bits |= 1ULL << a.n_ops; ++a.n_ops;                     // op bit 1: Advance
                 if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }   // Commands flush ends the group
             } else {
@@ -1002,14 +1029,14 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             ++i;
         }
         // ---- one pass over the tiles
-        cover = std::max(cover, w->len);
+        const uint64_t cover = std::max(gs.cover, w->len);
         // kernel shape by world size: k_tick1 (1 slot per lane, 256-slot workgroups) for small worlds, k_tick with
         // single-wave workgroups (256 slots, 16 B per lane) in between, k_tick with one 1024-slot tile per 4-wave
         // workgroup for big ones; GGRS_TICK_VEC = 1 / 41 / 4 forces one (A/B)
         const int vec = w->tick_vec ? w->tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : (cover <= TICK_WAVE_WG_MAX_SLOTS ? 41 : 4));
         const uint32_t n_waves = std::max(1u, (uint32_t)((cover + TILE1 - 1) / TILE1));      // 256-slot quarters
         const uint32_t g = vec == 4 ? std::max(1u, tiles_for(cover)) : n_waves;
-        a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
+        a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
@@ -1018,10 +1045,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             else { if (w->nt_copy) launch_tick<true, 4>(w, a, g); else launch_tick<false, 4>(w, a, g); }
         }
         HIPCHK(w, hipGetLastError());
-        const uint64_t new_dirty = std::max(src->dirty_len, w->len);
-        for (uint32_t k = 0; k < a.n_saves; ++k) if (dsts[k]) dsts[k]->dirty_len = new_dirty;
-        w->live.dirty_len = new_dirty;
-        w->pending_valid = false;
+        group_close(w, gs, a.n_saves);
         if (a.n_saves) {
             TickFinArgs f; memset(&f, 0, sizeof f);
             f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = vec == 4 ? 4 * g : (vec == 41 ? g : 4 * g);
@@ -1056,45 +1080,22 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     int rc = GGRS_OK;
     while (i < n) {
         GenArgs a = w->gen_proto;
-        Block* src = &w->live;
-        uint64_t cover = w->live.dirty_len;
-        a.src_is_live = 1;
-        Block* dsts[MAX_TICK_SAVES];
+        GroupState gs;
         const ggrs_request* spawn_req = nullptr;
-        if (reqs[i].kind == GGRS_REQ_LOAD) {                                   // schedule_systems.rs:238-250
-            apply_synctest_confirmed(w);
-            w->frame = reqs[i].frame;
-            if (!ring_rollback(w, reqs[i].frame))
-                return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
-            src = &w->slots[w->ring_slot.front()];
-            rc = launch_load_reconcile(w, *src); if (rc) return rc;
-            w->len = src->len;
-            cover = std::max(cover, src->dirty_len);
-            a.src_is_live = 0;
-            ++i;
-        }
+        rc = group_open(w, reqs, i, gs); if (rc) return rc;
+        a.src_is_live = gs.src_is_live;
         while (i < n && a.n_ops < (uint32_t)MAX_TICK_OPS) {
             const ggrs_request& r = reqs[i];
             if (r.kind == GGRS_REQ_LOAD) break;
             if (r.kind == GGRS_REQ_SAVE) {
                 if (a.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + a.n_saves == w->max_results)) break;
-                apply_synctest_confirmed(w);
-                if (w->has_confirmed) ring_confirm(w, w->confirmed);
-                int sl = -1;
-                rc = ring_push(w, w->frame, &sl); if (rc) return rc;
-                Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
-                dsts[a.n_saves] = d;
-                a.save_dst[a.n_saves] = d ? d->ptr : nullptr;
-                a.save_frame[a.n_saves] = w->frame;
-                if (d) { cover = std::max(cover, d->dirty_len); d->len = w->len; }
+                rc = group_save(w, gs, a.n_saves, a.save_dst, a.save_frame); if (rc) return rc;
                 ++a.n_ops; ++a.n_saves;
             } else if (r.kind == GGRS_REQ_ADVANCE) {
                 if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
                 if (r.n_inputs > 16) return w->fail(GGRS_E_INVALID, "more than 16 player inputs");
-                apply_synctest_confirmed(w);
-                w->frame += 1;
-                rc = step_despawn_confirmed(w); if (rc) return rc;
-                const uint32_t dtb = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+                uint32_t dtb = 0;
+                rc = group_step(w, r, &dtb); if (rc) return rc;
                 a.dt_bits[a.n_steps] = dtb;
                 if (w->gen_box_sys >= 0) {                                     // FRICTION.powf(dt), platform libm (box_game.rs:189-195)
                     float dtf; memcpy(&dtf, &dtb, 4);
@@ -1111,11 +1112,11 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             ++i;
         }
-        cover = std::max(cover, w->len);
+        const uint64_t cover = std::max(gs.cover, w->len);
         uint32_t sub = w->gen_sub_max;
         if (cover <= GEN_SMALL_SLOTS) sub = std::min<uint32_t>(sub, 256);
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + sub - 1) / sub));
-        a.sub = sub; a.src = src->ptr; a.live = w->live.ptr; a.len = w->len;
+        a.sub = sub; a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         // word image + masks + the staged row-offset and checksum-unit tables
         const uint32_t n_rows = a.ts >> 12;
         const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit);
@@ -1124,10 +1125,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(TPB), lds, w->stream, a);
         }
         HIPCHK(w, hipGetLastError());
-        const uint64_t new_dirty = std::max(src->dirty_len, w->len);
-        for (uint32_t k = 0; k < a.n_saves; ++k) if (dsts[k]) dsts[k]->dirty_len = new_dirty;
-        w->live.dirty_len = new_dirty;
-        w->pending_valid = false;
+        group_close(w, gs, a.n_saves);
         if (a.n_saves) {
             GenFinArgs f; memset(&f, 0, sizeof f);
             f.parts = a.parts; f.part_stride = a.part_stride; f.n_parts = 4 * g; f.n_cks = a.n_cks; f.total_len = w->len;
