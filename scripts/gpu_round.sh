@@ -19,6 +19,7 @@ timeout 300 python bench.py --entities 4000000 --no-cpu-baseline > $OUT/bench_4m
 timeout 300 python bench.py --sync --no-cpu-baseline > $OUT/bench_sync.json 2>> $OUT/bench.err
 timeout 300 python bench.py --no-groups --sync --no-cpu-baseline > $OUT/bench_nogroups_sync.json 2>> $OUT/bench.err
 timeout 300 python bench.py --fanout --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_fanout_ws1.json
+[ -x scripts/ubench2 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench2.hip -o scripts/ubench2 > /dev/null 2>&1
 timeout 120 ./scripts/ubench2 > $OUT/ubench2.txt 2>&1
 BENCH="python bench.py --steps 50 --warmup 8 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- $BENCH > $OUT/prof_stats.log 2>&1
