@@ -10,6 +10,7 @@
 // There is NO CPU fallback: without a HIP device world creation fails with GGRS_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 
 #include <cstdarg>
@@ -921,6 +922,49 @@ bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
 }
 
 
+// ---- tracing (the reference: tracing spans "HandleRequests" / "SaveWorld" / "LoadWorld" / "AdvanceWorld" and a
+// debug! line per request, schedule_systems.rs:171,224-267).  GGRS_HIP_TRACE=1 prints one line per request to stderr;
+// GGRS_HIP_ROCTX=1 opens roctx ranges with the same names (the roctx library is dlopen'ed: no link-time dependency), so a
+// `rocprofv3 --marker-trace` timeline shows which requests every fused launch carries.
+struct Tracer {
+    bool log = false;
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Tracer() {
+        if (const char* v = getenv("GGRS_HIP_TRACE")) log = atoi(v) != 0;
+        if (const char* v = getenv("GGRS_HIP_ROCTX")) if (atoi(v)) {
+            void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);    // what rocprofv3 --marker-trace intercepts
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (!push || !pop) { push = nullptr; pop = nullptr; }
+            }
+        }
+    }
+    bool on() const { return log || push; }
+    void begin(const char* name) const { if (push) push(name); }
+    void end() const { if (pop) pop(); }
+};
+const Tracer& tracer() { static Tracer t; return t; }
+struct TraceRange {
+    bool active;
+    explicit TraceRange(const char* name) : active(tracer().push != nullptr) { if (active) tracer().begin(name); }
+    ~TraceRange() { if (active) tracer().end(); }
+};
+void trace_request(const ggrs_world* w, const ggrs_request& r) {
+    const Tracer& t = tracer();
+    if (!t.on()) return;
+    char buf[96];
+    switch (r.kind) {
+    case GGRS_REQ_SAVE: snprintf(buf, sizeof buf, "SaveWorld: saving snapshot for frame %d", r.frame); break;
+    case GGRS_REQ_LOAD: snprintf(buf, sizeof buf, "LoadWorld: restoring snapshot for frame %d", r.frame); break;
+    case GGRS_REQ_ADVANCE: snprintf(buf, sizeof buf, "AdvanceWorld: advancing to frame: %d", w->frame + 1); break;
+    default: snprintf(buf, sizeof buf, "unknown request %u", r.kind);
+    }
+    if (t.log) fprintf(stderr, "[ggrs_hip] %s\n", buf);
+    if (t.push) { t.begin(buf); t.end(); }            // a zero-length marker inside the enclosing HandleRequests range
+}
+
 // ---- bookkeeping shared by the two request-group runners (k_tick and k_tick_gen): everything the host does in
 // request order while a group is assembled -- frame counters, ring push / confirm / rollback, dirty extents
 struct GroupState {
@@ -931,6 +975,7 @@ struct GroupState {
 int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState& g) {
     g.src = &w->live; g.cover = w->live.dirty_len; g.src_is_live = 1;
     if (reqs[i].kind != GGRS_REQ_LOAD) return GGRS_OK;
+    trace_request(w, reqs[i]);
     apply_synctest_confirmed(w);
     w->frame = reqs[i].frame;
     if (!ring_rollback(w, reqs[i].frame))
@@ -945,6 +990,7 @@ int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState&
 }
 // SaveGameState inside a group: discard_old_snapshots + GgrsSnapshots::push (mod.rs:147-202); the copy itself is an op of the kernel
 int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int32_t* save_frame) {
+    if (tracer().on()) { ggrs_request r{}; r.kind = GGRS_REQ_SAVE; r.frame = w->frame; trace_request(w, r); }
     apply_synctest_confirmed(w);
     if (w->has_confirmed) ring_confirm(w, w->confirmed);
     int sl = -1;
@@ -960,6 +1006,7 @@ int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int
 // DespawnConfirmed only touches the live-only marker mask, which no op inside a group reads or writes: queueing it
 // ahead of the group's launch keeps request order.
 int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out) {
+    trace_request(w, r);
     apply_synctest_confirmed(w);
     w->frame += 1;
     int rc = step_despawn_confirmed(w); if (rc) return rc;
@@ -1476,6 +1523,7 @@ int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uin
 
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
+    TraceRange tr("HandleRequests");
     int rc = seal(w); if (rc) return rc;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "handle_requests while %zu enqueued batches are uncollected", w->pending.size());
     if (w->tick_ok || w->gen_ok) {
@@ -1486,6 +1534,7 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
     uint32_t ns = 0;
     for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
         const ggrs_request& r = reqs[i];
+        trace_request(w, r);
         apply_synctest_confirmed(w);
         switch (r.kind) {
         case GGRS_REQ_SAVE:
@@ -1509,6 +1558,7 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
 // the host's frame instead of blocking it.
 int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
+    TraceRange tr("HandleRequests");
     int rc = seal(w); if (rc) return rc;
     uint32_t n_save = 0;
     for (uint32_t i = 0; i < n; ++i) n_save += reqs[i].kind == GGRS_REQ_SAVE;
@@ -1526,6 +1576,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
         uint32_t ns = 0;
         for (uint32_t i = 0; i < n && rc == GGRS_OK; ++i) {
             const ggrs_request& r = reqs[i];
+            trace_request(w, r);
             apply_synctest_confirmed(w);
             switch (r.kind) {
             case GGRS_REQ_SAVE: rc = do_save(w, b.first + ns); ++ns; break;
