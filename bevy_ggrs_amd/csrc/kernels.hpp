@@ -773,6 +773,16 @@ constexpr int TILE1 = 256;
 template <bool CKS_T, bool CKS_V, bool NT>
 __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // Small worlds are latency-bound, and every dynamically indexed kernel argument (save_dst[si], dt_bits[sj], rest[r]
+    // ...) is a dependent scalar load that misses the scalar cache on its first touch.  One vector load per lane
+    // stages the whole argument block in LDS; the op loop then reads it with ds_read (an order of magnitude closer).
+    __shared__ __attribute__((aligned(16))) TickArgs sa;
+    static_assert(sizeof(TickArgs) % 16 == 0 && sizeof(TickArgs) <= TPB * 16, "one 16-byte piece per lane");
+    if (tid < sizeof(TickArgs) / 16) reinterpret_cast<u32x4*>(&sa)[tid] = reinterpret_cast<const u32x4*>(&a)[tid];
+    __syncthreads();
+    auto uni64 = [](uint64_t v) -> uint64_t {                      // a uniform value read through LDS, back into SGPRs
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
     const bool in_len = (uint64_t)t * TILE1 < a.len;              // workgroup-uniform
     const uint32_t e = t * TILE1 + tid;                           // this lane's slot
     const uint64_t toff = (uint64_t)(t >> 2) * a.ts;              // its 1024-slot tile inside a block (tile-major columns)
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
     if (tid < 4u * a.n_rest_masks) {
         const uint32_t m = tid >> 2, mw = tid & 3u;
-        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)t * 4 + mw) * 8;
+        const uint64_t o = sa.rest_mask_off[m] + ((uint64_t)t * 4 + mw) * 8;
         const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
         for (uint32_t k = 0; k < a.n_saves; ++k)
             if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
@@ -815,9 +825,9 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
             for (int j = 0; j < 8; ++j) { v[j] = 0; off[j] = 0; wb[j] = 0; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                while (r < n_rows && a.rest[r].roff != 0) ++r;
+                while (r < n_rows && sa.rest[r].roff != 0) ++r;
                 if (r < n_rows) {
-                    const RowLite rd = a.rest[r]; ++r;
+                    const RowLite rd = sa.rest[r]; ++r;
                     wb[j] = rd.word_bytes; off[j] = rd.col_off; nb = j + 1;
                     if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + toff + o8);
                     else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + toff + o4);
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     for (uint32_t i = 0; i < a.n_ops; ++i) {
         if (!((a.op_bits >> i) & 1ULL)) {
             // ---------------- SaveWorld
-            uint8_t* dst = a.save_dst[si];
+            uint8_t* dst = reinterpret_cast<uint8_t*>(uni64(reinterpret_cast<uint64_t>(sa.save_dst[si])));
             const uint64_t alive_now = __ballot(alive);           // == this wave's liveness word
             if (dst) {
                 if (in_len) {
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                     *reinterpret_cast<uint64_t*>(dst + a.off_pL + wi8) = pL_w;
                 }
                 if (t == 0 && tid == 0) {
-                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
+                    Header h; h.len = a.len; h.frame = sa.save_frame[si]; h.pad0 = 0; h.active = 0;
                     h.checksum[0] = 0; h.checksum[1] = 0;
                     *reinterpret_cast<Header*>(dst) = h;
                 }
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
             ++si;
         } else {
             // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
-            const float dt = __uint_as_float(a.dt_bits[sj]);
+            const float dt = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sa.dt_bits[sj]));
             ++sj;
             const bool upd = alive && has_T && has_V, tt = alive && has_L;
 #pragma unroll

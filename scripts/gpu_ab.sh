@@ -4,9 +4,7 @@ TAG=${1:-ab}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -v 'RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -4 | tee $OUT/pytest.log
-GGRS_TICK_VEC=41 timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v 'RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -3
-GGRS_TICK_VEC=4 timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v 'RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -3
+GGRS_TICK_VEC=1 timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v 'RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -3
 run() {
   label="$1"; shift
   env "$@" timeout 200 python bench.py --no-cpu-baseline --steps 300 $BENCH_EXTRA 2>>$OUT/err.log | tee -a $OUT/lines.jsonl | python -c "
@@ -15,9 +13,9 @@ for l in sys.stdin:
     d=json.loads(l); r=d['roofline']
     print('[$label]', 'G ef/s=%.2f ms/step=%.4f kernel_us=%.1f frac=%.3f' % (d['value']/1e9, d['ms_per_step'], r['avg_launch_us'], r['frac']))"
 }
-for n in 10000 100000 300000 600000 1000000; do
-BENCH_EXTRA="--entities $n" run "$n k_tick1 (vec 1)" GGRS_TICK_VEC=1
-BENCH_EXTRA="--entities $n" run "$n k_tick 1-wave WGs (vec 41)" GGRS_TICK_VEC=41
-BENCH_EXTRA="--entities $n" run "$n k_tick 4-wave WGs (vec 4)" GGRS_TICK_VEC=4
-done
+BENCH_EXTRA="--entities 10000" run "10k k_tick1" A=1
+BENCH_EXTRA="--entities 100000" run "100k k_tick1" A=1
+BENCH_EXTRA="--entities 300000" run "300k k_tick1" A=1
+BENCH_EXTRA="--entities 10000" run "10k k_tick1 #2" A=1
+BENCH_EXTRA="--entities 100000" run "100k k_tick1 #2" A=1
 tail -3 $OUT/err.log
