@@ -227,6 +227,8 @@ def test_p2p_shaped_rollbacks_100k(n, ticks, flags):
     for (fa, ca), (fb, cb) in zip(a.all_checksums, b.all_checksums):
         assert fa == fb and ca == cb, f"frame {fa}: gpu {ca:#x} oracle {cb:#x}"
     cm.assert_states_equal(sa, sb, "p2p shape")
+    assert not a.world.has_snapshot(0) and a.world.has_snapshot(a.frame - 1) and a.world.snapshot_count() <= 8
+    assert a.world.snapshot_count() == b.world.snapshot_count()
 
 
 def test_column_transfers_across_tile_boundaries():

@@ -170,3 +170,7 @@ def test_p2p_shaped_rollbacks_are_deterministic_and_shapes_agree():
     for f, c in a.all_checksums:
         assert seen.setdefault(f, c) == c, f"frame {f} changed under resimulation"
     cm.assert_states_equal(sa, sb, "p2p shape")
+    # tests/p2p.rs:262-321 (p2p_confirmed_frame_advances_and_prunes_snapshots): once ConfirmedFrameCount advances,
+    # snapshots older than it are pruned -- frame 0 is gone, at most max_prediction snapshots remain
+    for d in (a, b):
+        assert not d.world.has_snapshot(0) and d.world.has_snapshot(d.frame - 1) and d.world.snapshot_count() <= 8
