@@ -422,8 +422,8 @@ int seal(ggrs_world* w) {
                 y.pso[0] = pso_of(w->comps[d.comp[0]].col_base + d.word[0]); y.pmask[0] = mask_index(d.comp[0]);
                 break;
             case GGRS_SYS_SAT_SUB_DESPAWN:
-                // despawn_rollback() marks are live-only state that DespawnConfirmed reads between frames: per-request path
-                if (!rb(d.comp[0]) || d.iparam[1] == GGRS_DESPAWN_ROLLBACK) { ok = false; break; }
+                if (!rb(d.comp[0])) { ok = false; break; }
+                if (d.iparam[1] == GGRS_DESPAWN_ROLLBACK) { a.marks = 1; a.dm = w->marks; }    // markers staged in LDS too
                 y.pso[0] = pso_of(w->comps[d.comp[0]].col_base + d.word[0]); y.pmask[0] = mask_index(d.comp[0]);
                 break;
             default: ok = false;
@@ -433,7 +433,9 @@ int seal(ggrs_world* w) {
         // largest slots-per-workgroup whose LDS image (words + masks + staged tables) fits 64 KiB
         uint32_t sub = 0;
         const uint64_t tables = (uint64_t)(bps / 4 + 4) * 4 + gunits.size() * sizeof(GenUnit);
-        for (uint32_t cand : {1024u, 512u, 256u}) if ((uint64_t)bps * cand + (uint64_t)w->plan.n_masks * (cand / 8) + tables <= 65536) { sub = cand; break; }
+        const uint64_t per_slot = (uint64_t)bps + (a.marks ? 4 : 0);                     // + the despawned-frame column
+        const uint64_t n_masks_lds = (uint64_t)w->plan.n_masks + (a.marks ? 1 : 0);      // + the disabled mask
+        for (uint32_t cand : {1024u, 512u, 256u}) if (per_slot * cand + n_masks_lds * (cand / 8) + tables <= 65536) { sub = cand; break; }
         if (ok && sub) { w->gen_ok = true; w->gen_sub_max = sub; }
     }
 
@@ -1005,11 +1007,21 @@ int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int
 // AdvanceFrame inside a group: RollbackFrameCount += 1 (schedule_systems.rs:254-259), DespawnConfirmed, Time<GgrsTime>.
 // DespawnConfirmed only touches the live-only marker mask, which no op inside a group reads or writes: queueing it
 // ahead of the group's launch keeps request order.
-int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out) {
+// marks_flags != nullptr: the group kernel keeps the RollbackDespawned markers itself (k_tick_gen with a.marks);
+// it receives bit 0 = DespawnConfirmed is due before this step (its Local<ConfirmedFrameCount> changed, despawn.rs:92-99),
+// bit 1 = the step's frame is unconfirmed, i.e. despawn_rollback() defers (despawn.rs:129-137).
+int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out, uint8_t* marks_flags = nullptr) {
     trace_request(w, r);
     apply_synctest_confirmed(w);
     w->frame += 1;
-    int rc = step_despawn_confirmed(w); if (rc) return rc;
+    if (marks_flags) {
+        uint8_t f = 0;
+        if (w->confirmed != w->dc_local) { w->dc_local = w->confirmed; f |= 1; }
+        if (w->confirmed < w->frame) { f |= 2; w->marks_possible = true; }
+        *marks_flags = f;
+    } else {
+        int rc = step_despawn_confirmed(w); if (rc) return rc;
+    }
     *dt_bits_out = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
     return GGRS_OK;
 }
@@ -1142,8 +1154,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 if (a.n_steps == (uint32_t)MAX_TICK_STEPS) break;
                 if (r.n_inputs > 16) return w->fail(GGRS_E_INVALID, "more than 16 player inputs");
                 uint32_t dtb = 0;
-                rc = group_step(w, r, &dtb); if (rc) return rc;
+                rc = group_step(w, r, &dtb, a.marks ? &a.step_flags[a.n_steps] : nullptr); if (rc) return rc;
                 a.dt_bits[a.n_steps] = dtb;
+                a.step_frame[a.n_steps] = w->frame; a.step_confirmed[a.n_steps] = w->confirmed;
                 if (w->gen_box_sys >= 0) {                                     // FRICTION.powf(dt), platform libm (box_game.rs:189-195)
                     float dtf; memcpy(&dtf, &dtb, 4);
                     const float fp = powf(w->systems[w->gen_box_sys].fparam[2], dtf);
@@ -1166,7 +1179,8 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         a.sub = sub; a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         // word image + masks + the staged row-offset and checksum-unit tables
         const uint32_t n_rows = a.ts >> 12;
-        const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit);
+        const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit) +
+                             (a.marks ? sub / 8 + sub * 4 : 0);
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
             hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(TPB), lds, w->stream, a);

@@ -1280,9 +1280,9 @@ __global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
 // spans), replays the ops of the group on the LDS image (Save = LDS -> ring slot + generic checksum partials,
 // Advance = each registered system in order over the LDS columns) and writes the live block once at the end.
 // One launch per group instead of one per request: an 18-request tick of a small world is 2 launches.
-// Not covered (such worlds keep the one-launch-per-request path): despawn_rollback systems (their marks are
-// live-only global state that DespawnConfirmed reads between frames) and worlds whose words do not fit 64 KiB of LDS
-// at 256 slots per workgroup.
+// despawn_rollback systems are covered too: the live-only RollbackDespawned markers of the slots are staged in LDS and
+// DespawnConfirmed runs in-kernel before each step.  Not covered (one launch per request): worlds whose words do not
+// fit 64 KiB of LDS at 256 slots per workgroup.
 constexpr int GEN_MAX_SYS = 16, GEN_MAX_CKS = 16;
 // LDS image of a workgroup: the registered word columns in tile order, each `sub` slots long -- a word whose
 // preceding words take `pso` bytes per slot starts at byte pso * sub -- then the masks ([n_masks][sub / 64] u64).
@@ -1304,6 +1304,10 @@ struct GenArgs {
     uint8_t* save_dst[MAX_TICK_SAVES]; int32_t save_frame[MAX_TICK_SAVES];
     uint32_t dt_bits[MAX_TICK_STEPS]; uint32_t aux_bits[MAX_TICK_STEPS];      // aux: FRICTION.powf(dt) of BOX_MOVE (host libm)
     uint8_t inputs[MAX_TICK_STEPS][16]; uint8_t n_inputs[MAX_TICK_STEPS];
+    // RollbackDespawned markers (snapshot/despawn.rs), staged only for worlds with a despawn_rollback system:
+    int32_t step_frame[MAX_TICK_STEPS], step_confirmed[MAX_TICK_STEPS];
+    uint8_t step_flags[MAX_TICK_STEPS];            // bit 0: DespawnConfirmed runs before this step; bit 1: its frame is unconfirmed (despawns are deferred)
+    uint32_t marks, pad_m; DespawnMarks dm;
     uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len, cols_base;
     uint32_t ts, sub, n_words, n_masks, n_units, n_sys, n_cks, part_stride;
@@ -1345,6 +1349,14 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
         if (gw.wb == 8) grow[r0 + 1] = gw.tcol + in_tile * 8u + sub * 4u;      // second half of the contiguous sub x 8 bytes
     }
     for (uint32_t u = tid; u < a.n_units; u += TPB) lunits[u] = a.units[u];
+    // live-only RollbackDespawned markers of these slots: disabled bits + the frame each was despawned on.  Not part of
+    // any snapshot; LoadWorld's resurrect pass (k_load_reconcile) has already run on the live copy (stream order).
+    uint64_t* ldis = reinterpret_cast<uint64_t*>(lunits + a.n_units);                 // [mw]
+    int32_t* ldf = reinterpret_cast<int32_t*>(ldis + mw);                             // [sub]
+    if (a.marks) {
+        for (uint32_t m = tid; m < mw; m += TPB) ldis[m] = *reinterpret_cast<const uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8);
+        for (uint32_t i = tid; i < sub; i += TPB) ldf[i] = *reinterpret_cast<const int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4);
+    }
     __syncthreads();
 
     // LDS image <-> one state block: 16-byte chunks, chunk c lives at LDS byte c * 16, 4 chunks in flight per lane
@@ -1423,6 +1435,17 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
         } else {
             // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
             const float dt = __uint_as_float(a.dt_bits[sj]);
+            const uint32_t sflags = a.step_flags[sj];
+            if (a.marks && (sflags & 1u)) {
+                // AdvanceWorldSystems::DespawnConfirmed (despawn.rs:89-112): marks <= ConfirmedFrameCount are freed for good
+                const int32_t confirmed = a.step_confirmed[sj];
+                for (uint32_t i = tid; i < sub; i += TPB) {
+                    const uint32_t wi = i >> 6;
+                    const uint64_t dw = ldis[wi];
+                    const uint64_t gone = __ballot(((dw >> (i & 63u)) & 1ULL) && ldf[i] <= confirmed);
+                    if (gone && lane == 0) ldis[wi] = dw & ~gone;
+                }
+            }
             for (uint32_t s = 0; s < a.n_sys; ++s) {
                 const GenSys& y = a.sys[s];
                 const uint64_t* p0 = y.pmask[0] != ~0u ? lmask + y.pmask[0] * mw : lmask;
@@ -1455,13 +1478,18 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
                             *q = *q + (uint32_t)y.iparam[0];
                         }
                     } break;
-                    case 5u: {   // GGRS_SYS_SAT_SUB_DESPAWN, immediate despawn (tests/synctest.rs:37-44)
+                    case 5u: {   // GGRS_SYS_SAT_SUB_DESPAWN (tests/synctest.rs:37-44): despawn() or despawn_rollback()
                         if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
                             uint32_t* q = reinterpret_cast<uint32_t*>(lds + y.pso[0] * sub + i * 4u);
                             const uint32_t amount = (uint32_t)y.iparam[0];
                             const uint32_t v = *q >= amount ? *q - amount : 0u;
                             *q = v; kill = v == 0;
                         }
+                        // despawn_rollback() on an unconfirmed frame (despawn.rs:129-137): disabled, marked with the frame
+                        const bool defer = a.marks && y.iparam[1] == 1 && (sflags & 2u);
+                        const uint64_t marked = __ballot(kill && defer);
+                        if (kill && defer) ldf[i] = a.step_frame[sj];
+                        if (marked && lane == 0) ldis[wi] |= marked;
                     } break;
                     case 6u: {   // GGRS_SYS_BOX_MOVE (box_game.rs:154-206), arithmetic shared with k_box_move
                         const uint64_t e = s0 + i;
@@ -1500,6 +1528,10 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     if (!a.src_is_live || a.n_steps) {
         if (in_len) copy_words(a.live, true);
         copy_masks(a.live, true);
+    }
+    if (a.marks && a.n_steps) {
+        for (uint32_t m = tid; m < mw; m += TPB) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8) = ldis[m];
+        for (uint32_t i = tid; i < sub; i += TPB) *reinterpret_cast<int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4) = ldf[i];
     }
 }
 

@@ -148,8 +148,9 @@ def test_oracle_synctest_despawn_rollback(mode):
 
 
 @pytest.mark.gpu
-def test_gpu_scripted_matches_oracle():
-    got, want = scripted(bg.World(512, max_depth=8)), scripted(OracleWorld(512, 8))
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_NO_GROUPS])     # generic fused groups (markers staged in LDS) / one launch per request
+def test_gpu_scripted_matches_oracle(flags):
+    got, want = scripted(bg.World(512, max_depth=8, flags=flags)), scripted(OracleWorld(512, 8))
     check_scripted(got)
     for (ka, sa), (kb, sb) in zip(got, want):
         assert ka == kb
@@ -157,10 +158,11 @@ def test_gpu_scripted_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,cd", [(200, 3), (5000, 2), (70_000, 4)])
-def test_gpu_synctest_despawn_rollback_matches_oracle(n, cd):
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_NO_GROUPS])
+@pytest.mark.parametrize("n,cd", [(200, 3), (5000, 2), (70_000, 4), (3000, 7)])
+def test_gpu_synctest_despawn_rollback_matches_oracle(n, cd, flags):
     cap = n + 100
-    cs_g, tr_g = synctest_run(bg.World(cap, max_depth=8), n, 14, cd)
+    cs_g, tr_g = synctest_run(bg.World(cap, max_depth=8, flags=flags), n, 14, cd)
     cs_o, tr_o = synctest_run(OracleWorld(cap, 8), n, 14, cd)
     assert cs_g == cs_o
     for t, (a, b) in enumerate(zip(tr_g, tr_o)):
@@ -255,3 +257,17 @@ def test_gpu_particles_world_with_markers():
     assert cs_g == cs_o
     for t, (a, b) in enumerate(zip(out_g, out_o)):
         cm.assert_states_equal(a, b, f"step {t}")
+
+
+@pytest.mark.gpu
+def test_gpu_despawn_rollback_world_runs_as_fused_groups():
+    """A world with a despawn_rollback() system is served by k_tick_gen (markers staged in LDS): its ticks are group
+    launches, not one launch per request."""
+    w = bg.World(400, max_depth=8)
+    build(w, 300)
+    w.profile_enable(True)
+    drv = cm.SyncTestDriver(w, 3)
+    for _ in range(10):
+        drv.tick((0,))
+    prof = w.profile_read()
+    assert prof["tick"][1] >= 10 and prof["advance"][1] == 0 and prof["save"][1] == 0
