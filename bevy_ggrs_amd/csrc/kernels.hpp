@@ -440,7 +440,7 @@ struct TickArgs {
     uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
     uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len;
-    uint32_t nt_load, pad1;
+    uint32_t nt_load, diag;                // diag: DIAGNOSTIC timing experiments only (GGRS_TICK_DIAG), results invalid when non-zero
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
@@ -631,10 +631,12 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
                     hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
                 }
             }
-            if (CKS_T) hT = wave_xor(hT);
-            if (CKS_V) hV = wave_xor(hV);
+            if (!(a.diag & 1u)) {                                    // (diag bit 0: timing experiment without the wave reduction)
+                if (CKS_T) hT = wave_xor(hT);
+                if (CKS_V) hV = wave_xor(hV);
+            }
         }
-        if (lane == 0) {
+        if (lane == 0 && !(a.diag & 4u)) {
             // plain per-wave partial stores: agent-scope atomics (tried: 64 accumulator copies + last-block
             // fold) cost ~1 ns EACH chip-wide on gfx950 -- 94k of them added 90 us to a 134 us kernel
             uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + gw;
@@ -675,14 +677,16 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
                     }
                 }
                 uint64_t mine = 0;
+                if (!(a.diag & 2u)) {                                // (diag bit 1: timing experiment without the mask rebuild)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
                                         (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
                     if (lane == (uint32_t)w) mine = nw;
                 }
+                }
                 if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
-                if ((lane & 15u) == 0) {
+                if ((lane & 15u) == 0 && !(a.diag & 2u)) {
                     st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
                     st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
                     st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);

@@ -4,7 +4,6 @@ TAG=${1:-ab}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-GGRS_TICK_VEC=1 timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v 'RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl' | tail -3
 run() {
   label="$1"; shift
   env "$@" timeout 200 python bench.py --no-cpu-baseline --steps 300 $BENCH_EXTRA 2>>$OUT/err.log | tee -a $OUT/lines.jsonl | python -c "
@@ -13,9 +12,13 @@ for l in sys.stdin:
     d=json.loads(l); r=d['roofline']
     print('[$label]', 'G ef/s=%.2f ms/step=%.4f kernel_us=%.1f frac=%.3f' % (d['value']/1e9, d['ms_per_step'], r['avg_launch_us'], r['frac']))"
 }
-BENCH_EXTRA="--entities 10000" run "10k k_tick1" A=1
-BENCH_EXTRA="--entities 100000" run "100k k_tick1" A=1
-BENCH_EXTRA="--entities 300000" run "300k k_tick1" A=1
-BENCH_EXTRA="--entities 10000" run "10k k_tick1 #2" A=1
-BENCH_EXTRA="--entities 100000" run "100k k_tick1 #2" A=1
+run "default" A=1
+run "diag 1: no wave reduction" GGRS_TICK_DIAG=1
+run "diag 2: no mask rebuild" GGRS_TICK_DIAG=2
+run "diag 4: no partial stores" GGRS_TICK_DIAG=4
+run "diag 7: all three" GGRS_TICK_DIAG=7
+BENCH_EXTRA="--nt" run "nt" A=1
+BENCH_EXTRA="--nt" run "nt diag 7" GGRS_TICK_DIAG=7
+BENCH_EXTRA="--nt" run "nt diag 1" GGRS_TICK_DIAG=1
+run "default #2" A=1
 tail -3 $OUT/err.log

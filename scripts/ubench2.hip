@@ -158,6 +158,38 @@ __global__ __launch_bounds__(256) void fan_rot_last(u32x4* ring, u32x4* live, si
     }
 }
 
+// the engine's rotation WITH the SeaHash work k_tick does per Save (40 diffuse = 80 u64 multiplies per lane): does the
+// ALU burst between store bursts change what non-temporal stores buy?
+__device__ __forceinline__ uint64_t diffuse(uint64_t x) {
+    x *= 0x6eed0e9da4d94a4fULL; x ^= (x >> 32) >> (x >> 60); x *= 0x6eed0e9da4d94a4fULL; return x;
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void fan_rot_hash(u32x4* ring, u32x4* live, size_t bs, int src_slot, int tiles, uint64_t* sink) {
+    const int t = blockIdx.x;
+    u32x4 v[ROWS];
+    const u32x4* s = ring + (size_t)src_slot * bs + (size_t)t * TILE_V + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) v[j] = s[j * 256];
+    uint64_t acc = 0;
+    for (int k = 1; k <= 8; ++k) {
+        const int d = (src_slot + k) % 9;
+        u32x4* p = ring + (size_t)d * bs + (size_t)t * TILE_V + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { v[j].x += d; st<NT>(p + j * 256, v[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                       // 8 rows x 4 lanes-words... 40 diffuses in chains of 5
+            uint64_t h = ((uint64_t)v[j].x << 32) | v[j].y;
+            h = diffuse(h ^ 0x16f11fe89b0d677cULL); h = diffuse(h ^ v[j].z); h = diffuse(h ^ 0xb480a793d8e6c86cULL);
+            h = diffuse(h ^ v[j].w); h = diffuse(h ^ (uint64_t)k);
+            acc ^= h;
+        }
+    }
+    u32x4* l = live + (size_t)t * TILE_V + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) st<false>(l + j * 256, v[j]);
+    if (acc == 0x1234567ULL) sink[0] = acc;
+}
+
 int main(int argc, char** argv) {
     const int tiles = 977;
     const size_t bs = (size_t)tiles * TILE_V;            // u32x4 per block
@@ -200,6 +232,11 @@ int main(int argc, char** argv) {
     timeit("fan ROTATING, next source stored LAST, default stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_last<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
     timeit("fan ROTATING, next source stored LAST, nt stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_last<true>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
     timeit("fan ROTATING src (engine-like), default stores #3", F, [&](int i) { hipLaunchKernelGGL(fan_rot<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles); });
+    uint64_t* sinkp; CK(hipMalloc(&sinkp, 64));
+    timeit("fan ROTATING + 40 diffuse per Save, default stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_hash<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles, sinkp); });
+    timeit("fan ROTATING + 40 diffuse per Save, nt stores", F, [&](int i) { hipLaunchKernelGGL(fan_rot_hash<true>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles, sinkp); });
+    timeit("fan ROTATING + 40 diffuse per Save, default stores #2", F, [&](int i) { hipLaunchKernelGGL(fan_rot_hash<false>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles, sinkp); });
+    timeit("fan ROTATING + 40 diffuse per Save, nt stores #2", F, [&](int i) { hipLaunchKernelGGL(fan_rot_hash<true>, tiles, 256, 0, 0, ring, live, bs, i % 9, tiles, sinkp); });
     timeit("fan slot-major", F, [&](int) { hipLaunchKernelGGL((fan<false, 0, false>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
     timeit("fan slot-major nt", F, [&](int) { hipLaunchKernelGGL((fan<true, 0, false>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
     timeit("fan slot-major row-order", F, [&](int) { hipLaunchKernelGGL((fan<false, 0, true>), tiles, 256, 0, 0, src0, ring, live, bs, D, tiles); });
