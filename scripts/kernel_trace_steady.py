@@ -23,14 +23,20 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            per.setdefault(name, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    for name, v in per.items():
+            per.setdefault(name, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for name, tv in per.items():
         if "ggrs::k_tick" not in name or "finalize" in name:
             continue
+        v = [d for _, d in sorted(tv)]
         big = [x for x in v if x > max(v) / 2]
+        # world creation times a few tick-shaped launches on every candidate arena (placement probe);
+        # the bench's own ticks are the LAST ones of the trace
+        last = big[-100:]
         out[name] = {"all_calls": {"n": len(v), "mean_us": statistics.mean(v) / 1e3},
                      "tick_shaped_launches": {"n": len(big), "mean_us": statistics.mean(big) / 1e3,
-                                              "min_us": min(big) / 1e3, "max_us": max(big) / 1e3}}
+                                              "min_us": min(big) / 1e3, "max_us": max(big) / 1e3},
+                     "last_100_tick_shaped_launches": {"n": len(last), "mean_us": statistics.mean(last) / 1e3,
+                                                       "min_us": min(last) / 1e3, "max_us": max(last) / 1e3}}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
