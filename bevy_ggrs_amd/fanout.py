@@ -103,18 +103,74 @@ class HipStateExchange:
         return self.all_gather_u64_finish(self.all_gather_u64_start(dist, values))
 
 
+class _DeviceSpan:
+    """A raw device allocation presented through __cuda_array_interface__ so torch can alias it without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
 def make_torch_world(bg, capacity: int, max_depth: int, n_components: int, bytes_per_slot: int,
-                     device, flags: int = 0):
-    """World whose device memory is ONE torch uint8 tensor (so collectives can address it)."""
+                     device, flags: int = 0, library_arena: bool = True):
+    """World whose live state block is addressable as ONE torch uint8 tensor (so collectives can read and write it).
+
+    library_arena (default): the library owns the arena -- so world creation can run its placement probe
+     -- and `late_tensor(world)` aliases the live block through __cuda_array_interface__ once the world
+    is sealed.  Otherwise (or when aliasing is not available) the arena is a torch tensor handed to the library."""
     import torch
     from . import _ffi
-    nbytes = int(_ffi.lib.ggrs_hip_arena_bytes(capacity, max_depth, n_components, bytes_per_slot))
-    arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream(device).cuda_stream
     dev_index = device.index if hasattr(device, "index") and device.index is not None else 0
+    if library_arena and _aliasing_works(device):
+        w = bg.World(capacity, max_depth=max_depth, device=dev_index, stream=stream, flags=flags)
+        return w, LateArena(w, device)
+    nbytes = int(_ffi.lib.ggrs_hip_arena_bytes(capacity, max_depth, n_components, bytes_per_slot))
+    arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
     w = bg.World(capacity, max_depth=max_depth, device=dev_index, stream=stream,
                  arena_ptr=arena.data_ptr(), arena_bytes=nbytes, flags=flags)
     return w, arena
+
+
+_ALIAS_OK = {}
+
+
+def _aliasing_works(device) -> bool:
+    """torch.as_tensor over __cuda_array_interface__ must alias (not copy) device memory on this build."""
+    key = str(device)
+    if key not in _ALIAS_OK:
+        try:
+            import torch
+            probe = torch.arange(64, dtype=torch.uint8, device=device)
+            alias = torch.as_tensor(_DeviceSpan(probe.data_ptr(), 64), device=device)
+            alias[3] = 200
+            torch.cuda.synchronize(device)
+            _ALIAS_OK[key] = bool(alias.data_ptr() == probe.data_ptr() and int(probe[3].item()) == 200)
+        except Exception:
+            _ALIAS_OK[key] = False
+    return _ALIAS_OK[key]
+
+
+class LateArena:
+    """Tensor view of a library-owned live state block, materialised on first use (the world must be sealed, i.e. its
+    components registered and at least one spawn issued, before the block's address and size exist)."""
+
+    def __init__(self, world, device):
+        self.world, self.device, self._t = world, device, None
+
+    def tensor(self):
+        if self._t is None:
+            import torch
+            nbytes = self.world.state_bytes()
+            ptr = self.world.live_state_ptr()
+            self._t = torch.as_tensor(_DeviceSpan(ptr, nbytes), device=self.device)
+            assert self._t.data_ptr() == ptr and self._t.numel() == nbytes and self._t.dtype == torch.uint8
+        return self._t
+
+    # the bits of the torch.Tensor surface HipStateExchange and the tests use
+    def data_ptr(self): return self.tensor().data_ptr()
+    def __getitem__(self, k): return self.tensor()[k]
+    @property
+    def device_(self): return self.device
 
 
 def default_branch_input(branch: int, frame: int) -> int:

@@ -54,7 +54,7 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
 
         # a second world adopts the first one's packed state block byte-for-byte (what a
         # receiving rank does after the broadcast)
-        w2, arena2 = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0))
+        w2, arena2 = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0), library_arena=False)   # the caller-provided arena path
         ids2 = cm.build_particles(w2, with_spawn=True, ttl_init=25)
         w2.spawn(0, {})
         nb = w.state_bytes()
