@@ -486,9 +486,30 @@ static void particles(uint64_t n, int ticks, size_t cd, bool pipelined) {
     std::puts(pipelined ? "ok particles_pipelined" : "ok particles");
 }
 
+
+// The two restatements of ggrs's SyncTestSession::advance_frame (this header and bevy_ggrs_amd/session.py) must
+// emit the same requests: printed here, compared by tests/test_cpp_host.py::test_synctest_sessions_agree
+static void print_request_traces() {
+    for (size_t cd : {0, 1, 3, 7}) for (size_t delay : {0, 2}) {
+        auto b = SessionBuilder<Config>().with_num_players(2).with_check_distance(cd).with_input_delay(delay);
+        auto s = b.start_synctest_session();
+        for (int t = 0; t < 14; ++t) {
+            for (PlayerHandle h = 0; h < 2; ++h) s.add_local_input(h, (uint8_t)((t * 5 + (int)h * 3) & 15));
+            std::printf("trace cd=%zu delay=%zu t=%d:", cd, delay, t);
+            for (auto& r : s.advance_frame()) {
+                if (r.kind == GgrsRequest<Config>::SaveGameState) { std::printf(" S%d", r.frame); r.cell->save(r.frame, nullptr, u128{(uint64_t)r.frame * 7 + 1, 0}); }
+                else if (r.kind == GgrsRequest<Config>::LoadGameState) std::printf(" L%d", r.frame);
+                else { std::printf(" A"); for (auto& in : r.inputs) std::printf("%s%d", &in == &r.inputs[0] ? "" : ",", (int)in.first); }
+            }
+            std::printf("\n");
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 5000;
     synctest_request_shape();
+    print_request_traces();
     despawn_and_rollback_does_not_panic();
     mismatch_fires_on_non_determinism();
     confirmed_frame_pruning();

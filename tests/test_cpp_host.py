@@ -67,3 +67,33 @@ def test_cpp_host_on_hip_matches_oracle_build(n):
     want = _run(_build("oracle"), n)
     got = _run(_build("hip"), n)
     assert got == want
+
+
+def test_synctest_sessions_agree():
+    """The C++ (include/bevy_ggrs_hip.hpp) and Python (bevy_ggrs_amd/session.py) restatements of ggrs's
+    SyncTestSession::advance_frame emit the same request lists -- kinds, frames and (delayed) inputs -- for check
+    distances 0/1/3/7 and input delays 0/2.  (ggrs itself is un-vendored: its request order is parity-unpinned by the
+    reference; two independent restatements that agree is what can be checked here.)"""
+    import bevy_ggrs_amd as bg
+    from bevy_ggrs_amd.session import SyncTestSession
+    out = _run(_build("oracle"), 500)
+    got = {}
+    for l in out.splitlines():
+        if l.startswith("trace "):
+            head, _, body = l.partition(":")
+            got[head] = body.split()
+    assert len(got) == 4 * 2 * 14
+    for cd in (0, 1, 3, 7):
+        for delay in (0, 2):
+            s = SyncTestSession(2, cd, 8, delay)
+            for t in range(14):
+                for h in range(2):
+                    s.add_local_input(h, (t * 5 + h * 3) & 15)
+                want = []
+                reqs = s.advance_frame()
+                for r in reqs:
+                    if isinstance(r, bg.SaveGameState): want.append(f"S{r.frame}")
+                    elif isinstance(r, bg.LoadGameState): want.append(f"L{r.frame}")
+                    else: want.append("A" + ",".join(str(int(i)) for i in r.inputs))
+                s.record_checksums([r.frame * 7 + 1 for r in reqs if isinstance(r, bg.SaveGameState)])
+                assert got[f"trace cd={cd} delay={delay} t={t}"] == want, (cd, delay, t)
