@@ -98,11 +98,16 @@ def warm_ring(bg, w, depth):
         w.handle_requests([bg.SaveGameState(w.frame), bg.AdvanceFrame((0,))])
 
 
-def cpu_baseline(n, depth, budget_ticks):
-    """The CPU path timed beside the GPU line: the oracle's REFERENCE-SHAPED variant (per-save hash-map
-    rebuild, per-entity lookups: the reference's cost structure) on ONE thread -- SaveWorld/LoadWorld are
-    sequential `for` loops in the reference and AdvanceWorld runs single-threaded (src/lib.rs:236-240).  Also
-    reported: the oracle's FLAT variant (SoA + memcpy ring, the best a CPU port could do) on many host cores."""
+def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks):
+    """The CPU path timed beside the GPU line, and the parity check of the same run.
+
+    * reference-shaped oracle (per-save hash-map rebuild, per-entity lookups: the reference's cost structure) on ONE
+      thread -- SaveWorld / LoadWorld are sequential `for` loops in the reference and AdvanceWorld runs single-threaded
+      (src/lib.rs:236-240) -- and on 3 threads, one per registered component (the reference's per-component save / load /
+      checksum systems may run on separate Bevy workers);
+    * the oracle's FLAT variant (SoA + memcpy ring, the best a CPU port could do) on the host's cores, REPLAYING the very
+      frames the timed GPU ticks covered: its Checksum(u128) of every SaveWorld must equal what the GPU returned for the
+      first `parity_ticks` timed ticks (gpu_cs[k] = the D checksums of timed tick k)."""
     from oracle.binding import FLAT, REFSHAPED, OracleWorld, lib
     import common as cm
 
@@ -113,24 +118,56 @@ def cpu_baseline(n, depth, budget_ticks):
         cm.spawn_particles(w, ids, n, vel, ttl)
         w.set_depth(depth + 1)
         return w
+    cores = os.cpu_count() or 1
+    ef = n * (depth + 1)                       # entity-frames per tick
     w = world(REFSHAPED)
     lib.gor_set_num_threads(1)
     secs = w.bench_synctest(depth, depth + 1, budget_ticks)
+    lib.gor_set_ref_component_threads(3)
+    lib.gor_set_num_threads(3)
+    secs3 = w.bench_synctest(depth, 0, budget_ticks)
+    lib.gor_set_ref_component_threads(1)
     del w
-    cores = os.cpu_count() or 1
+    # ---- flat port == parity replay: ring warm-up (D + 1 plain ticks) + the bench's warm-up ticks + P timed ticks
+    P = max(0, min(parity_ticks, len(gpu_cs)))
     flat_threads = max(1, min(64, cores))
     wf = world(FLAT)
     lib.gor_set_num_threads(flat_threads)
-    flat_ticks = 8 * budget_ticks
-    fsecs = wf.bench_synctest(depth, depth + 1, flat_ticks)
+    fsecs, ocs = wf.replay_synctest(depth, (depth + 1) + warmup + P, max(P, 1))
+    del wf
+    parity = {"checked_ticks": P, "checked_saves": P * depth, "equal": None}
+    if P:
+        want = ocs[len(ocs) - P * depth:]
+        got = [c for tick in gpu_cs[:P] for c in tick]
+        bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+        parity["equal"] = (len(got) == len(want) == P * depth) and not bad
+        parity["oracle"] = "oracle/ggrs_oracle.cpp FLAT variant, same seeded inputs, same request sequence"
+        if bad:
+            parity["first_mismatch"] = {"timed_tick": bad[0] // depth, "save": bad[0] % depth, "gpu": hex(got[bad[0]]), "oracle": hex(want[bad[0]])}
+    flat = {"value": ef * max(P, 1) / fsecs, "unit": "entity-frames/s", "cores": flat_threads,
+            "sample": f"{max(P, 1)} steady-state ticks of the oracle's flat SoA + memcpy-ring variant (OpenMP; the parity replay itself), {fsecs:.1f} s"}
+    if cores > flat_threads:
+        # more threads than memory channels can feed rarely helps a memcpy-bound port: measured, the better one is reported
+        wa = world(FLAT)
+        lib.gor_set_num_threads(cores)
+        ticks_all = max(4, P // 2)
+        asecs = wa.bench_synctest(depth, depth + 1, ticks_all)
+        del wa
+        flat["all_cores"] = {"value": ef * ticks_all / asecs, "cores": cores, "sample": f"{ticks_all} ticks, {asecs:.1f} s"}
+        if flat["all_cores"]["value"] > flat["value"]:
+            flat = {"value": flat["all_cores"]["value"], "unit": "entity-frames/s", "cores": cores, "sample": flat["all_cores"]["sample"],
+                    "at_64_threads": {"value": ef * max(P, 1) / fsecs, "cores": flat_threads}}
     lib.gor_set_num_threads(1)
-    return {"value": n * (depth + 1) * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
+    base = {"value": ef * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
             "kind": "port",
             "sample": f"{budget_ticks} steady-state SyncTest ticks (depth {depth}) of the same {n}-entity x 3-component "
                       f"world on the oracle's reference-shaped storage (per-save HashMap rebuild), {secs:.1f} s",
             "host_cores_available": cores,
-            "flat_soa_port": {"value": n * (depth + 1) * flat_ticks / fsecs, "unit": "entity-frames/s", "cores": flat_threads,
-                              "sample": f"{flat_ticks} ticks of the oracle's flat SoA + memcpy-ring variant (OpenMP), {fsecs:.1f} s"}}
+            "ref_shaped_3_threads": {"value": ef * budget_ticks / secs3, "unit": "entity-frames/s", "cores": 3,
+                                     "sample": f"the same {budget_ticks} ticks with one thread per registered component for the per-component "
+                                               f"checksum / save / load systems (AdvanceWorld and the entity systems stay sequential, src/lib.rs:236-240), {secs3:.1f} s"},
+            "flat_soa_port": flat}
+    return base, parity
 
 
 def main():
@@ -142,6 +179,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ticks", type=int, default=3)
+    ap.add_argument("--parity-ticks", type=int, default=24, help="timed ticks whose checksums the CPU oracle replays and compares (N = 1 only; 0 = off)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per reference system (no fusion at all)")
     ap.add_argument("--no-groups", action="store_true", help="one launch per request (no request-group fusion)")
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
@@ -183,10 +221,12 @@ def main():
         for _ in range(W):
             run(w.frame)
         torch.cuda.synchronize()
+        gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
+        take = lambda out: gpu_cs.append(bytes(out))  # one 16 x D byte copy per tick inside the timed region; parsed afterwards
         if args.sync:
             t0 = time.perf_counter()
             for _ in range(K):
-                run(w.frame)
+                take(run(w.frame))
             torch.cuda.synchronize()
             secs = time.perf_counter() - t0
         else:
@@ -198,12 +238,20 @@ def main():
             run.enqueue(w.frame)
             for _ in range(K - 1):
                 run.enqueue(w.frame)
-                run.collect()
-            run.collect()
+                take(run.collect())
+            take(run.collect())
             w.synchronize()
             torch.cuda.synchronize()
             secs = time.perf_counter() - t0
         live = w.active_count()
+        gpu_cs = [[int.from_bytes(b[16 * k:16 * k + 16], "little") for k in range(D)] for b in gpu_cs]
+        # SyncTest's own check over ALL timed ticks (ggrs SyncTestSession: a resimulated frame's checksum must equal the first
+        # one recorded for that frame, else MismatchedChecksum): timed tick k at frame F saved frames F-D+1 .. F
+        first_seen, resim_ok, f_end = {}, True, w.frame
+        for k, tick in enumerate(gpu_cs):
+            F = f_end - (len(gpu_cs) - k)
+            for j, c in enumerate(tick):
+                resim_ok &= first_seen.setdefault(F - D + 1 + j, c) == c
         # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
         w.profile_enable(True)
         for _ in range(min(K, 50)):
@@ -263,6 +311,7 @@ def main():
 
     # PMC-derived HBM bytes per launch: only valid for the exact workload the counters were collected on
     traffic = None
+    traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     grouped = tick_n > 0
     if os.path.exists(tpath):
@@ -271,6 +320,8 @@ def main():
             same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum)
             if same:
                 traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"{tj.get('source', 'profiles/roofline_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's box; NOT measured in this run)"
         except Exception:
             traffic = None
 
@@ -283,6 +334,10 @@ def main():
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
         roof = {"bound": "hbm", "kernel": "k_tick (fused request group: LoadWorld + D x SaveWorld + (D+1) x AdvanceWorld in one pass)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_source,
+                # the two accountings, named so they cannot be confused: `frac` == frac_compulsory_600B
+                "frac_compulsory_600B": achieved / HBM_PEAK_GBS,
+                "frac_per_request_1656B": (TICK_BYTES(D) * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_note": "compulsory traffic of the fused group: 60 B/entity snapshot read + 60 B x saves + 60 B live write "
                                           "(SURVEY 8d's 1656 B/entity-tick assumes one kernel per request; that per-request equivalent is reported below)",
@@ -294,7 +349,7 @@ def main():
         save_avg_s = per(save_ms, save_n)
         achieved = SAVE_BYTES * live / save_avg_s / 1e9 if save_n else 0.0
         roof = {"bound": "hbm", "kernel": "k_copy_state (SaveWorld)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": SAVE_BYTES * live,
                 "avg_launch_us": save_avg_s * 1e6, "launches_timed": save_n,
                 "other_kernels": {
@@ -318,8 +373,15 @@ def main():
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }
+    parity_failed = False
+    if rank == 0 and not distributed:
+        line["parity"] = {"synctest_resim_consistent_over_timed_ticks": bool(resim_ok), "timed_ticks": len(gpu_cs)}
+        parity_failed = not resim_ok
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(n, D, args.cpu_ticks)
+        base, par = cpu_baseline_and_parity(n, D, args.cpu_ticks, W, gpu_cs, 0 if args.no_checksum else args.parity_ticks)
+        line["cpu_baseline"] = base
+        line["parity"].update(par)
+        parity_failed |= par["equal"] is False
     elif rank == 0:
         line["cpu_baseline"] = None
     if dist is not None:
@@ -327,6 +389,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line))
+        if parity_failed:
+            print("bench.py: PARITY FAILURE -- GPU checksums differ from the CPU oracle's (see \"parity\")", file=sys.stderr)
+            sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -82,6 +82,8 @@ def _load():
                                   C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "gor_handle_requests": (C.c_int, [P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64)]),
         "gor_bench_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "gor_replay_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
+        "gor_set_ref_component_threads": (None, [C.c_int]),
         "gor_num_threads": (C.c_int, []),
         "gor_set_num_threads": (None, [C.c_int]),
     }
@@ -125,6 +127,14 @@ class OracleWorld(WorldBase):
 
     def bench_synctest(self, d: int, warm_ticks: int, ticks: int) -> float:
         return float(lib.gor_bench_synctest(self._p, d, warm_ticks, ticks))
+
+    def replay_synctest(self, d: int, ticks: int, timed_ticks: int):
+        """`ticks` SyncTest ticks from the current frame; returns (seconds of the last `timed_ticks`, [checksum per Save])."""
+        cap = (d + 1) * ticks + 8
+        buf = (C.c_uint64 * (2 * cap))()
+        n = C.c_uint64(0)
+        secs = float(lib.gor_replay_synctest(self._p, d, ticks, timed_ticks, buf, cap, C.byref(n)))
+        return secs, [int(buf[2 * k]) | (int(buf[2 * k + 1]) << 64) for k in range(n.value)]
 
 
 class OracleRing:

@@ -753,13 +753,24 @@ static int world_spawn(World& w, uint64_t count, uint64_t comp_mask, const void*
     return 0;
 }
 
+// REFSHAPED only: the reference's per-component systems (ComponentChecksumPlugin<C>::update, ComponentSnapshotPlugin<S>::
+// save / load) are separate Bevy systems that the multi-threaded executor MAY run on different worker threads
+// ("also report a 3-thread (one per component) figure").  > 1: one OpenMP thread per registered component.
+static int g_ref_comp_threads = 1;
+
 // ---------------- SaveWorld ----------------
 static void world_save(World& w, uint64_t out[2]) {
     w.seal();
     // SaveWorldSystems::Checksum (set.rs:104-107): component parts, entity part; then fold (checksum.rs:88-99)
     uint64_t total = 0;
-    for (uint32_t c = 0; c < w.comps.size(); ++c)
-        if (w.comps[c].checksummed) total ^= (w.mode == 1 ? component_checksum_ref(w, c) : component_checksum_flat(w, c));
+    if (w.mode == 1 && g_ref_comp_threads > 1) {
+        const int nc = (int)w.comps.size();
+#pragma omp parallel for num_threads(g_ref_comp_threads) schedule(static, 1) reduction(^ : total)
+        for (int c = 0; c < nc; ++c) if (w.comps[c].checksummed) total ^= component_checksum_ref(w, (uint32_t)c);
+    } else {
+        for (uint32_t c = 0; c < w.comps.size(); ++c)
+            if (w.comps[c].checksummed) total ^= (w.mode == 1 ? component_checksum_ref(w, c) : component_checksum_flat(w, c));
+    }
     total ^= entity_checksum(active_count_flat(w), w.len);
     out[0] = total; out[1] = 0;   // `as u128` of a u64: upper half always 0 (component_checksum.rs:95)
 
@@ -788,7 +799,9 @@ static void world_save(World& w, uint64_t out[2]) {
         s.len = w.len;
         uint64_t n_alive = active_count_flat(w);
         s.comp.resize(w.comps.size());
-        for (uint32_t c = 0; c < w.comps.size(); ++c) {           // ComponentSnapshotPlugin::save, component_snapshot.rs:66-84
+        const int nc_save = (int)w.comps.size();
+#pragma omp parallel for num_threads(g_ref_comp_threads) schedule(static, 1) if (g_ref_comp_threads > 1)
+        for (int c = 0; c < nc_save; ++c) {                       // ComponentSnapshotPlugin::save, component_snapshot.rs:66-84
             if (w.comps[c].no_rollback) continue;
             uint32_t st = w.stride(c);
             s.comp[c].init(n_alive, st);
@@ -860,7 +873,9 @@ static int world_load(World& w, int32_t frame) {
         // slots beyond the snapshot's len never existed then
         for (uint64_t i = s.len; i < w.len; ++i) setbit(w.alive, i, false);
         // ComponentSnapshotPlugin::load (component_snapshot.rs:95-123): per entity lookup
-        for (uint32_t c = 0; c < w.comps.size(); ++c) {
+        const int nc_load = (int)w.comps.size();
+#pragma omp parallel for num_threads(g_ref_comp_threads) schedule(static, 1) if (g_ref_comp_threads > 1)
+        for (int c = 0; c < nc_load; ++c) {
             if (w.comps[c].no_rollback) continue;
             uint32_t st = w.stride(c);
             for (uint64_t i = 0; i < s.len; ++i) {
@@ -1119,6 +1134,43 @@ double gor_bench_synctest(void* wp, uint32_t d, uint32_t warm_ticks, uint32_t ti
     auto t1 = std::chrono::steady_clock::now();
     return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// The same SyncTest ticks as gor_bench_synctest, but every SaveWorld's Checksum(u128) is handed back in request order
+// ({lo, hi} per Save): bench.py replays the frames its timed GPU ticks covered and compares (SURVEY 8d "parity check in
+// the same run").  Returns the seconds the LAST `timed_ticks` of the `ticks` took; *n_saves_out = checksums written.
+double gor_replay_synctest(void* wp, uint32_t d, uint32_t ticks, uint32_t timed_ticks, uint64_t* cs_out, uint64_t cs_cap, uint64_t* n_saves_out) {
+    World& w = *(World*)wp;
+    uint64_t n = 0;
+    auto save = [&]() {
+        uint64_t cs[2];
+        w.has_confirmed = (w.frame - (int32_t)d) >= 0; w.confirmed = w.frame - (int32_t)d;
+        world_save(w, cs);
+        if (cs_out && n < cs_cap) { cs_out[2 * n] = cs[0]; cs_out[2 * n + 1] = cs[1]; }
+        ++n;
+    };
+    auto tick = [&]() {
+        int32_t F = w.frame;
+        if (F > (int32_t)d) {
+            w.has_confirmed = (F - (int32_t)d) >= 0; w.confirmed = F - (int32_t)d;
+            world_load(w, F - (int32_t)d);
+            for (uint32_t i = 0; i < d; ++i) {
+                if (i > 0) save();
+                AdvanceArgs a{0, nullptr, 0, 0, nullptr, nullptr}; world_advance(w, a);
+            }
+        }
+        save();
+        AdvanceArgs a{0, nullptr, 0, 0, nullptr, nullptr}; world_advance(w, a);
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t t = 0; t < ticks; ++t) {
+        if (t + timed_ticks == ticks) t0 = std::chrono::steady_clock::now();
+        tick();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (n_saves_out) *n_saves_out = n;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+void gor_set_ref_component_threads(int n) { g_ref_comp_threads = n < 1 ? 1 : n; }
 
 int gor_num_threads() {
 #if defined(_OPENMP)

@@ -133,6 +133,36 @@ def test_errors_match_reference_panics():
         g.register_component("late", 4, 1)           # registration after seal
 
 
+@pytest.mark.parametrize("n,ticks", [(300_000, 12), (600_000, 12), (1_000_000, 12), (4_000_000, 11)])
+@pytest.mark.parametrize("ttl_mode", ["despawn"])
+def test_headline_depth8_matches_oracle(n, ticks, ttl_mode):
+    """BASELINE config 3 at its own size (and the sizes either side of every k_tick dispatch tier: k_tick1 <= 400 k slots,
+    single-wave k_tick <= 800 k, 4-wave k_tick above -- ggrs_hip.hip TICK_VEC1_MAX_SLOTS / TICK_WAVE_WG_MAX_SLOTS), DEFAULT
+    dispatch, SyncTest check distance 8 with max_prediction 9: every Save's Checksum(u128) == the oracle's
+    (component_checksum.rs:67-108, tests/synctest.rs:84-125) and the final live state is byte-equal."""
+    from oracle.binding import lib as olib
+    import os
+    olib.gor_set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    try:
+        vel, ttl = cm.synthetic_particles(n, ttl=ttl_mode)
+        res = []
+        for w in (bg.World(n, max_depth=9), OracleWorld(n, 9, FLAT)):
+            ids = cm.build_particles(w)
+            cm.spawn_particles(w, ids, n, vel, ttl)
+            drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+            for _ in range(ticks):
+                drv.tick((0,))
+            res.append((drv.all_checksums, cm.snapshot_state(w, ids)))
+            w.close()
+    finally:
+        olib.gor_set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+    a, b = res
+    assert len(a[0]) == len(b[0]) >= 8 * (ticks - 9)
+    for (fa, ca), (fb, cb) in zip(a[0], b[0]):
+        assert fa == fb and ca == cb, f"n={n} frame {fa}: gpu {ca:#x} oracle {cb:#x}"
+    cm.assert_states_equal(a[1], b[1], f"headline n={n}")
+
+
 def test_full_size_properties_1m():
     """BASELINE config 3 (1M x 3 components, depth 8): size-independent properties instead of
     the (slow) oracle: resimulation reproduces every first-recorded checksum (the SyncTest

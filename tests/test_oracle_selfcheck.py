@@ -174,3 +174,35 @@ def test_p2p_shaped_rollbacks_are_deterministic_and_shapes_agree():
     # snapshots older than it are pruned -- frame 0 is gone, at most max_prediction snapshots remain
     for d in (a, b):
         assert not d.world.has_snapshot(0) and d.world.has_snapshot(d.frame - 1) and d.world.snapshot_count() <= 8
+
+
+def test_replay_synctest_equals_the_driver_and_per_component_threads_change_nothing():
+    """bench.py's parity leg replays the timed ticks through gor_replay_synctest: it must produce exactly the checksums the
+    Python SyncTest driver gets request by request (same frames, same order), in both storage shapes, and the REFSHAPED
+    variant's one-thread-per-component mode (the 3-thread CPU figure of SURVEY 8d) must not change a bit."""
+    from oracle.binding import REFSHAPED, lib
+    n, d, ticks = 3000, 4, 14
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    ref = None
+    for mode, threads in ((FLAT, 1), (REFSHAPED, 1), (REFSHAPED, 3)):
+        w = OracleWorld(n, d + 1, mode)
+        ids = cm.build_particles(w)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(d + 1)
+        lib.gor_set_ref_component_threads(threads)
+        try:
+            _, cs = w.replay_synctest(d, ticks, 2)
+        finally:
+            lib.gor_set_ref_component_threads(1)
+        st = cm.snapshot_state(w, ids)
+        if ref is None:
+            w2 = OracleWorld(n, d + 1, FLAT)
+            ids2 = cm.build_particles(w2)
+            cm.spawn_particles(w2, ids2, n, vel, ttl)
+            drv = cm.SyncTestDriver(w2, d, max_prediction=d + 1)
+            for _ in range(ticks):
+                drv.tick((0,))
+            ref = ([c for _, c in drv.all_checksums], cm.snapshot_state(w2, ids2))
+            assert len(ref[0]) == (d + 1) + (ticks - d - 1) * d
+        assert cs == ref[0], (mode, threads)
+        cm.assert_states_equal(st, ref[1], f"replay mode={mode} threads={threads}")
