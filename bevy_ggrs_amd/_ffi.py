@@ -19,7 +19,6 @@ GGRS_E_HIP = -4
 GGRS_E_NO_DEVICE = -5
 
 GGRS_WORLD_DEFAULT = 0
-GGRS_WORLD_NO_GRAPH = 1
 GGRS_WORLD_UNFUSED = 2
 GGRS_WORLD_NT_COPY = 4
 GGRS_WORLD_NO_GROUPS = 8

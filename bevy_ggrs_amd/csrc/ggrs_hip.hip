@@ -30,6 +30,7 @@ using namespace ggrs;
 namespace {
 
 constexpr uint64_t ALIGN = 256;
+constexpr int TICK2_RESTL_MAX = 7;     // untouched rows k_tick2 keeps in registers: EXACTLY this many (the stress_test world, kernels.hpp)
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct Comp {
@@ -50,6 +51,47 @@ struct Block {                           // one packed state block in the arena
 
 struct EventPair { hipEvent_t a, b; uint32_t cls; };
 
+// Every environment variable the library reads, in ONE place, read ONCE per world at creation.  They are A/B and
+// debugging aids for measurements (INTEGRATION.md lists them); none of them changes a result.
+// (GGRS_HIP_TRACE / GGRS_HIP_ROCTX, the two tracing switches, are process-wide: see Tracer below.)
+struct Knobs {
+    bool tick_generic = false;     // GGRS_TICK_GENERIC=1   serve every world with the LDS-staged k_tick_gen
+    bool tick_ntload = false;      // GGRS_TICK_NTLOAD=1    non-temporal loads of the group's source block
+    int tick_vec = 0;              // GGRS_TICK_VEC=1|41|4  force a k_tick shape (0: by world size)
+    uint32_t tick_lds = 0;         // GGRS_TICK_LDS=bytes   dynamic LDS per k_tick workgroup (occupancy throttle)
+    bool tick_rest_loop = true;    // GGRS_TICK_REST=0      untouched rows fanned out up front instead of with each Save
+    int arena_probe = 0;           // GGRS_ARENA_PROBE=n    time n candidate arena placements per round at world creation (default off)
+    uint64_t arena_align = 0, arena_skew = 0;   // GGRS_ARENA_ALIGN / GGRS_ARENA_SKEW   placement of the first block inside the allocation
+    uint64_t block_pad = 0, col_pad = 0;        // GGRS_BLOCK_PAD / GGRS_COL_PAD        extra bytes between ring blocks / behind the columns
+    bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
+    bool arena_contig = false;     // GGRS_ARENA_CONTIG=1   hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous arena
+    bool tick2 = true;             // GGRS_TICK2=0          big worlds on the round-1 k_tick + k_tick_finalize pair instead of k_tick2
+    int tick2_wgs_per_cu = 2;      // GGRS_TICK2_WGS=n      persistent workgroups per CU of k_tick2 (0: one workgroup per tile, not persistent)
+    int tick2_nt = 1;              // GGRS_TICK2_NT=0|1     non-temporal snapshot stores in k_tick2
+    int tick2_ilv = 0;             // GGRS_TICK2_ILV=0|1    Save = store burst + hash (0) or stores spaced out between the hash multiplies (1)
+    static Knobs from_env() {
+        Knobs k;
+        auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
+        k.tick_generic = num("GGRS_TICK_GENERIC", 0) != 0;
+        k.tick_ntload = num("GGRS_TICK_NTLOAD", 0) != 0;
+        { const long long x = num("GGRS_TICK_VEC", 0); if (x == 1 || x == 4 || x == 41) k.tick_vec = (int)x; }
+        { const long long x = num("GGRS_TICK_LDS", 0); if (x >= 0 && x <= 160 * 1024) k.tick_lds = (uint32_t)x; }
+        k.tick_rest_loop = num("GGRS_TICK_REST", 1) != 0;
+        k.arena_probe = (int)std::max<long long>(0, num("GGRS_ARENA_PROBE", 0));
+        k.arena_align = (uint64_t)std::max<long long>(0, num("GGRS_ARENA_ALIGN", 0));
+        k.arena_skew = (uint64_t)std::max<long long>(0, num("GGRS_ARENA_SKEW", 0));
+        k.block_pad = (uint64_t)std::max<long long>(0, num("GGRS_BLOCK_PAD", 0));
+        k.col_pad = (uint64_t)std::max<long long>(0, num("GGRS_COL_PAD", 0));
+        k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
+        k.arena_contig = num("GGRS_ARENA_CONTIG", 0) != 0;
+        k.tick2 = num("GGRS_TICK2", 1) != 0;
+        k.tick2_wgs_per_cu = (int)std::min<long long>(8, std::max<long long>(0, num("GGRS_TICK2_WGS", 2)));
+        k.tick2_nt = num("GGRS_TICK2_NT", 1) != 0;
+        k.tick2_ilv = num("GGRS_TICK2_ILV", 0) != 0;
+        return k;
+    }
+};
+
 }  // namespace
 
 struct ggrs_world {
@@ -64,6 +106,8 @@ struct ggrs_world {
     std::vector<Comp> comps;
     std::vector<ggrs_system_desc> systems;
     bool sealed = false;
+    int seal_error = 0;                  // a failed seal latches: every later call reports it instead of re-carving the arena
+    Knobs knobs;
     std::string err;
 
     // ---- layout of a packed state block.  Offsets of non-rollback components and of the
@@ -103,7 +147,9 @@ struct ggrs_world {
     bool tick_ok = false; uint32_t f_lw = 0;
     TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
     uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
-    int tick_vec = 0;                    // 0: pick per launch by size; 1 / 4: forced (GGRS_TICK_VEC, A/B knob)
+    // k_tick2: persistent grid + in-kernel fold (big worlds)
+    bool tick2_ok = false; Tick2Args tick2_proto{};
+    uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
     // generic fused request groups (k_tick_gen): any mix of the supported kernel systems, state staged in LDS
     bool gen_ok = false;
     GenArgs gen_proto{};                 // layout part of the kernel arguments, filled at seal
@@ -111,9 +157,7 @@ struct ggrs_world {
     GenWord* d_gen_words = nullptr; GenUnit* d_gen_units = nullptr;
     uint64_t* d_gen_parts = nullptr;     // [MAX_TICK_SAVES][n_cks + 1][tick_part_stride]
     int gen_box_sys = -1;                // index of a BOX_MOVE system (its FRICTION.powf(dt) is evaluated per step on the host)
-    uint64_t block_pad = 0, col_pad = 0; // extra bytes between ring blocks / columns (GGRS_BLOCK_PAD / GGRS_COL_PAD, A/B knobs; library-owned arenas only)
-    uint32_t tick_lds = 0;               // dynamic LDS bytes per k_tick workgroup: occupancy throttle (GGRS_TICK_LDS, A/B knob)
-    int tick_rest_loop = 1;              // rest rows stored with each Save (default) instead of the up-front fan-out (GGRS_TICK_REST=0)
+    uint64_t block_pad = 0, col_pad = 0; // extra bytes between ring blocks / columns (Knobs; library-owned arenas only)
 
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
@@ -202,14 +246,14 @@ void build_layout(ggrs_world* w) {
                 w->col_wb[c.col_base + k] = c.word_bytes;
                 if (c.no_rollback || (hot[c.col_base + k] != 0) != (pass == 0)) continue;
                 w->col_off[c.col_base + k] = tcol;           // offset inside a tile for now
-                tcol += (uint64_t)TILE * c.word_bytes;
+                tcol += (uint64_t)LAYOUT_TILE * c.word_bytes;
             }
         }
     w->ts = (uint32_t)tcol;
     const uint64_t cols_base = align_up(off, 4096);
     for (auto& c : w->comps) if (!c.no_rollback)
         for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] += cols_base; w->col_ts[c.col_base + k] = w->ts; }
-    off = cols_base + (w->cap_pad / TILE) * (uint64_t)w->ts + w->col_pad;
+    off = cols_base + (w->cap_pad / LAYOUT_TILE) * (uint64_t)w->ts + w->col_pad;
     w->state_bytes = align_up(off, 4096) + w->block_pad;
     // ---- live-only side region, placed right behind the ring blocks
     w->side_off = (uint64_t)(w->max_depth + 1) * w->state_bytes;
@@ -220,7 +264,7 @@ void build_layout(ggrs_world* w) {
     for (auto& c : w->comps) {
         if (!c.no_rollback) continue;
         // live-only columns are plain arrays: the same addressing formula with tile stride = 1024 words
-        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; w->col_ts[c.col_base + k] = TILE * c.word_bytes; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; w->col_ts[c.col_base + k] = LAYOUT_TILE * c.word_bytes; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
     }
     w->side_bytes = align_up(so - w->side_off, 4096);
 
@@ -251,9 +295,41 @@ uint32_t total_rows(const ggrs_world* w) {
 // times k_tick on a candidate arena placement (defined next to the launchers)
 int probe_arena_placement(ggrs_world* w, uint8_t* base, uint64_t tick_parts_off, float* us_out);
 
+int seal_impl(ggrs_world* w);
+// Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
+// failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
+// reports the same error instead of carving a second arena over half-initialised bookkeeping.
 int seal(ggrs_world* w) {
     if (w->sealed) return GGRS_OK;
+    if (w->seal_error) return w->seal_error;
+    const int rc = seal_impl(w);
+    if (rc == GGRS_OK) return rc;
+    const std::string why = w->err;
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->d_gen_words) { (void)hipFree(w->d_gen_words); w->d_gen_words = nullptr; }
+    if (w->d_gen_units) { (void)hipFree(w->d_gen_units); w->d_gen_units = nullptr; }
+    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
+    if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
+    if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
+    if (w->own_arena && w->arena_alloc) { (void)hipFree(w->arena_alloc); w->arena_alloc = nullptr; w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
+    (void)hipGetLastError();
+    w->slots.clear(); w->free_slots.clear(); w->live = Block{};
+    w->sealed = false; w->seal_error = rc;
+    w->err = "world could not be sealed (permanent): " + why;
+    return rc;
+}
+int seal_impl(ggrs_world* w) {
     if (total_rows(w) > (uint32_t)MAX_ROWS) return w->fail(GGRS_E_INVALID, "too many registered words (%u rows > %d)", total_rows(w), MAX_ROWS);
+    // The particles kernels address their columns with the tile stride of the ROLLBACK columns; a live-only
+    // (GGRS_COMP_NO_ROLLBACK) column is a plain array with a different stride.  The flag is set after registration
+    // (register_component_ex), so the check lives here rather than in add_system.
+    for (auto& sd : w->systems) {
+        if (sd.kind != GGRS_SYS_PARTICLES_UPDATE && sd.kind != GGRS_SYS_TTL_DESPAWN && sd.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
+        const uint32_t nc = sd.kind == GGRS_SYS_PARTICLES_UPDATE ? 2u : (sd.kind == GGRS_SYS_TTL_DESPAWN ? 1u : 3u);
+        for (uint32_t k = 0; k < nc; ++k)
+            if (sd.comp[k] >= w->comps.size() || w->comps[sd.comp[k]].no_rollback)
+                return w->fail(GGRS_E_INVALID, "system %u runs over component %u, which is not registered for rollback (GGRS_COMP_NO_ROLLBACK): unsupported", sd.kind, sd.comp[k]);
+    }
     HIPCHK(w, hipSetDevice(w->device));
     build_layout(w);
 
@@ -321,7 +397,7 @@ int seal(ggrs_world* w) {
 
     // ---- fused request groups
     w->tick_ok = false;
-    const bool force_generic = getenv("GGRS_TICK_GENERIC") && atoi(getenv("GGRS_TICK_GENERIC")) != 0;   // A/B knob: k_tick_gen for every world
+    const bool force_generic = w->knobs.tick_generic;
     if (w->fused_ok && !force_generic && !(w->flags & GGRS_WORLD_NO_GROUPS) && w->f_T != w->f_V && w->f_T != w->f_L && w->f_V != w->f_L &&
         (w->fused_cks || w->cks_comp.empty())) {
         for (auto& sd : w->systems) if (sd.kind == GGRS_SYS_TTL_DESPAWN) w->f_lw = sd.word[0];
@@ -337,8 +413,7 @@ int seal(ggrs_world* w) {
         }
         a.off_ttl = w->col_off[L.col_base + w->f_lw];
         a.ts = w->ts;
-        a.nt_load = (getenv("GGRS_TICK_NTLOAD") && atoi(getenv("GGRS_TICK_NTLOAD"))) ? 1u : 0u;
-        a.diag = getenv("GGRS_TICK_DIAG") ? (uint32_t)atoi(getenv("GGRS_TICK_DIAG")) : 0u;
+        a.nt_load = w->knobs.tick_ntload ? 1u : 0u;
         for (uint32_t c = 0; c < w->comps.size(); ++c)
             if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) a.rest_mask_off[a.n_rest_masks++] = w->off_present[c];
         for (uint32_t c = 0; c < w->comps.size(); ++c) {
@@ -354,6 +429,25 @@ int seal(ggrs_world* w) {
         }
         w->tick_ok = true;
     }
+    // k_tick2 keeps the untouched rows in registers and addresses them as one contiguous run behind the schedule-owned rows
+    w->tick2_ok = false;
+    if (w->tick_ok && w->knobs.tick2 && w->tick_proto.n_rest_rows == (uint32_t)TICK2_RESTL_MAX) {
+        const TickArgs& t = w->tick_proto;
+        const uint64_t base = t.n_rest_rows ? t.rest[0].col_off + t.rest[0].roff : 0;
+        bool contig = true;
+        for (uint32_t j = 0; j < t.n_rest_rows; ++j) contig &= (t.rest[j].word_bytes == 4 && t.rest[j].col_off == base + (uint64_t)j * REST_ROW_STRIDE);
+        if (contig) {
+            Tick2Args& b = w->tick2_proto;
+            memset(&b, 0, sizeof b);
+            b.off_alive = t.off_alive; b.off_pT = t.off_pT; b.off_pV = t.off_pV; b.off_pL = t.off_pL;
+            for (int k = 0; k < 3; ++k) { b.off_t[k] = t.off_t[k]; b.off_v[k] = t.off_v[k]; b.g[k] = t.g[k]; }
+            b.off_ttl = t.off_ttl; b.rest_off = base; b.ts = t.ts;
+            b.n_rest_rows = t.n_rest_rows; b.n_rest_masks = t.n_rest_masks;
+            for (uint32_t m = 0; m < t.n_rest_masks; ++m) b.rest_mask_off[m] = t.rest_mask_off[m];
+            b.cks_T = w->f_cksT; b.cks_V = w->f_cksV;
+            w->tick2_ok = true;
+        }
+    }
 
 
     // ---- generic fused request groups (k_tick_gen): every world whose systems it implements and whose words fit in LDS
@@ -363,14 +457,14 @@ int seal(ggrs_world* w) {
         w->cks_comp.size() <= (size_t)GEN_MAX_CKS) {
         GenArgs& a = w->gen_proto;
         memset(&a, 0, sizeof a);
-        const uint32_t bps = w->ts / TILE;                                   // bytes per slot of all rollback words
+        const uint32_t bps = w->ts / LAYOUT_TILE;                            // bytes per slot of all rollback words
         bool ok = true;
         const uint64_t cols_base = w->plan.n_rows ? w->plan.row[0].col_off : 0;   // every rollback column: cols_base + tcol
         uint64_t min_off = ~0ULL;
         for (uint32_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback)
             for (uint32_t k = 0; k < w->comps[c].n_words; ++k) min_off = std::min(min_off, w->col_off[w->comps[c].col_base + k]);
         a.cols_base = min_off == ~0ULL ? cols_base : min_off;
-        auto pso_of = [&](uint32_t col) { return (uint32_t)((w->col_off[col] - a.cols_base) / TILE); };
+        auto pso_of = [&](uint32_t col) { return (uint32_t)((w->col_off[col] - a.cols_base) / LAYOUT_TILE); };
         auto mask_index = [&](uint32_t comp) -> uint32_t {                    // index into plan.mask_off (0 = liveness)
             for (uint32_t m = 1; m < w->plan.n_masks; ++m) if (w->plan.mask_off[m] == w->off_present[comp]) return m;
             return ~0u;
@@ -455,22 +549,21 @@ int seal(ggrs_world* w) {
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
-    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes;
+    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max(n_tiles, 1u) * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN;   // k_tick2 partial rows + its ticket
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
-        // A/B knobs: GGRS_ARENA_ALIGN (power of two) aligns the first block inside an over-allocation,
-        // GGRS_ARENA_SKEW then shifts it; GGRS_DEBUG_ARENA prints the placement
-        uint64_t al = 0, skew = 0;
-        if (const char* v = getenv("GGRS_ARENA_ALIGN")) al = (uint64_t)atoll(v);
-        if (const char* v = getenv("GGRS_ARENA_SKEW")) skew = align_up((uint64_t)atoll(v), ALIGN);
+        // A/B knobs: arena_align (power of two) aligns the first block inside an over-allocation, arena_skew then shifts it
+        const uint64_t al = w->knobs.arena_align, skew = align_up(w->knobs.arena_skew, ALIGN);
+        const bool dbg = w->knobs.debug_arena;
         // Placement probe.  The dominant kernel of a big world runs in one of two latency modes (~120 vs ~129 us at 1 M
         // entities) depending on where the arena lands in the physical address space -- nothing in the virtual address
         // predicts it (profiles/README.md, "mode_probe").  For HBM-sized worlds of the stress_test shape, allocate a few
         // candidate arenas, time k_tick on each (uninitialised memory: the traffic is what matters), keep the fastest,
-        // free the rest.  GGRS_ARENA_PROBE=<n> sets the candidates per round (0 / 1: off).
-        int n_cand = (w->tick_ok && need >= (256ull << 20) && w->max_depth >= 3) ? 6 : 1;    // candidates per round (up to 4 rounds)
-        if (const char* v = getenv("GGRS_ARENA_PROBE")) n_cand = std::max(1, atoi(v));
+        // free the rest.  OPT-IN (GGRS_ARENA_PROBE=<n> candidates per round): it costs world-creation latency and transient
+        // memory, which a library constructor must not spend unasked.
+        int n_cand = std::max(1, w->knobs.arena_probe);
         if (!(w->tick_ok && w->max_depth >= 3)) n_cand = 1;
         // transient memory: the kept best + the previous round's losers + the new batch <= 16 GiB
         if (n_cand > 1) n_cand = (int)std::min<uint64_t>((uint64_t)n_cand, std::max<uint64_t>(1, ((16ull << 30) / (need + al + skew) - 1) / 2));
@@ -485,7 +578,9 @@ int seal(ggrs_world* w) {
             std::vector<uint8_t*> batch;
             for (int k = 0; k < n_cand; ++k) {
                 uint8_t* pa = nullptr;
-                if (hipMalloc((void**)&pa, need + al + skew) != hipSuccess) { (void)hipGetLastError(); break; }
+                const hipError_t me = w->knobs.arena_contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous)
+                                                            : hipMalloc((void**)&pa, need + al + skew);
+                if (me != hipSuccess) { (void)hipGetLastError(); break; }
                 batch.push_back(pa);
             }
             for (auto q : losers) (void)hipFree(q);
@@ -498,7 +593,7 @@ int seal(ggrs_world* w) {
                 float us = 0;
                 prc = probe_arena_placement(w, place(batch[k]), tick_parts_off, &us);
                 times.push_back(us);
-                if (getenv("GGRS_DEBUG_ARENA")) fprintf(stderr, "[ggrs arena] round %d candidate %zu at %p: k_tick %.1f us\n", round, k, (void*)place(batch[k]), us);
+                if (dbg) fprintf(stderr, "[ggrs arena] round %d candidate %zu at %p: k_tick %.1f us\n", round, k, (void*)place(batch[k]), us);
             }
             if (prc) { for (auto q : batch) (void)hipFree(q); for (auto q : cand) (void)hipFree(q); return prc; }
             size_t bi = 0;
@@ -515,7 +610,7 @@ int seal(ggrs_world* w) {
         w->arena_alloc = cand[best];
         w->arena = place(w->arena_alloc);
         w->arena_bytes = need; w->own_arena = true;
-        if (getenv("GGRS_DEBUG_ARENA")) fprintf(stderr, "[ggrs arena] alloc=%p base=%p need=%llu state_bytes=%llu (0x%llx)\n", (void*)w->arena_alloc, (void*)w->arena, (unsigned long long)need, (unsigned long long)w->state_bytes, (unsigned long long)w->state_bytes);
+        if (dbg) fprintf(stderr, "[ggrs arena] alloc=%p base=%p need=%llu state_bytes=%llu (0x%llx)\n", (void*)w->arena_alloc, (void*)w->arena, (unsigned long long)need, (unsigned long long)w->state_bytes, (unsigned long long)w->state_bytes);
     }
     uint8_t* p = w->arena;
     w->live.ptr = p; p += w->state_bytes;
@@ -528,6 +623,8 @@ int seal(ggrs_world* w) {
     w->d_units = (UnitDesc*)p; p += units_bytes;
     w->d_maskoffs = (uint64_t*)p; p += ALIGN;
     w->d_stage = (float*)p; p += stage_bytes;
+    w->d_wg_parts = (uint64_t*)p; p += wg_parts_bytes - ALIGN;
+    w->d_ticket = (uint32_t*)p; p += ALIGN;
     w->cks_args.parts = w->d_parts;
     w->cks_args.part_cnt = w->d_parts + (uint64_t)w->cks_args.n_cks * w->part_stride;
     w->cks_args.part_stride = w->part_stride;
@@ -544,6 +641,7 @@ int seal(ggrs_world* w) {
         HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
         for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
         HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
+        HIPCHK(w, hipMemsetAsync(w->d_ticket, 0, ALIGN, w->stream));      // k_tick2's arrival counter: zero between launches
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
@@ -733,15 +831,15 @@ int copy_column(ggrs_world* w, uint32_t col, uint64_t first, uint64_t count, voi
         return to_device ? hipMemcpyAsync(dev(slot), h + (slot - first) * wb, n * wb, hipMemcpyHostToDevice, w->stream)
                          : hipMemcpyAsync(h + (slot - first) * wb, dev(slot), n * wb, hipMemcpyDeviceToHost, w->stream);
     };
-    if (ts == TILE * wb) { HIPCHK(w, piece(first, count)); return GGRS_OK; }
+    if (ts == LAYOUT_TILE * wb) { HIPCHK(w, piece(first, count)); return GGRS_OK; }
     uint64_t s0 = first, end = first + count;
-    if (s0 % TILE) { const uint64_t n = std::min<uint64_t>(end - s0, TILE - s0 % TILE); HIPCHK(w, piece(s0, n)); s0 += n; }
-    const uint64_t full = (end - s0) / TILE;
+    if (s0 % LAYOUT_TILE) { const uint64_t n = std::min<uint64_t>(end - s0, LAYOUT_TILE - s0 % LAYOUT_TILE); HIPCHK(w, piece(s0, n)); s0 += n; }
+    const uint64_t full = (end - s0) / LAYOUT_TILE;
     if (full) {
-        const size_t width = (size_t)TILE * wb;
+        const size_t width = (size_t)LAYOUT_TILE * wb;
         if (to_device) HIPCHK(w, hipMemcpy2DAsync(dev(s0), ts, h + (s0 - first) * wb, width, width, full, hipMemcpyHostToDevice, w->stream));
         else HIPCHK(w, hipMemcpy2DAsync(h + (s0 - first) * wb, width, dev(s0), ts, width, full, hipMemcpyDeviceToHost, w->stream));
-        s0 += full * TILE;
+        s0 += full * LAYOUT_TILE;
     }
     if (s0 < end) HIPCHK(w, piece(s0, end - s0));
     return GGRS_OK;
@@ -1092,11 +1190,12 @@ void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
 }
 
 constexpr int TICK_RESTL = 8;          // rest rows the register-resident variant of k_tick can carry
+constexpr int TICK2_RESTL = TICK2_RESTL_MAX;
 // wpb: waves per workgroup (4: one 1024-slot tile per workgroup, g = tiles; 1: one 256-slot quarter per workgroup)
 template <bool NT, int WPB>
 void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
-    const uint32_t lds = w->tick_lds;
-    const bool rl = w->tick_rest_loop && a.n_rest_rows <= (uint32_t)TICK_RESTL && a.n_rest_rows > 0 && a.n_saves > 0;
+    const uint32_t lds = w->knobs.tick_lds;
+    const bool rl = w->knobs.tick_rest_loop && a.n_rest_rows <= (uint32_t)TICK_RESTL && a.n_rest_rows > 0 && a.n_saves > 0;
 #define GGRS_LAUNCH_TICK(T_, V_) do { \
         if (rl) hipLaunchKernelGGL((k_tick<T_, V_, NT, TICK_RESTL, WPB>), dim3(g), dim3(WPB * 64), lds, w->stream, a); \
         else hipLaunchKernelGGL((k_tick<T_, V_, NT, 0, WPB>), dim3(g), dim3(WPB * 64), lds, w->stream, a); } while (0)
@@ -1105,6 +1204,15 @@ void launch_tick(ggrs_world* w, const TickArgs& a, uint32_t g) {
     else if (w->f_cksV) GGRS_LAUNCH_TICK(false, true);
     else GGRS_LAUNCH_TICK(false, false);
 #undef GGRS_LAUNCH_TICK
+}
+
+template <bool NT, int ILV>
+void launch_tick2(ggrs_world* w, const Tick2Args& a, uint32_t g) {
+    const uint32_t lds = w->knobs.tick_lds;
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick2<true, true, NT, TICK2_RESTL, ILV>), dim3(g), dim3(TPB), lds, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick2<true, false, NT, TICK2_RESTL, ILV>), dim3(g), dim3(TPB), lds, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick2<false, true, NT, TICK2_RESTL, ILV>), dim3(g), dim3(TPB), lds, w->stream, a);
+    else hipLaunchKernelGGL((k_tick2<false, false, NT, TICK2_RESTL, ILV>), dim3(g), dim3(TPB), lds, w->stream, a);
 }
 
 // One SyncTest-shaped group -- Load, (Advance, Save) x D, live write -- on a candidate arena, straight through the
@@ -1172,11 +1280,34 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         // kernel shape by world size: k_tick1 (1 slot per lane, 256-slot workgroups) for small worlds, k_tick with
         // single-wave workgroups (256 slots, 16 B per lane) in between, k_tick with one 1024-slot tile per 4-wave
         // workgroup for big ones; GGRS_TICK_VEC = 1 / 41 / 4 forces one (A/B)
-        const int vec = w->tick_vec ? w->tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : (cover <= TICK_WAVE_WG_MAX_SLOTS ? 41 : 4));
+        const int vec = w->knobs.tick_vec ? w->knobs.tick_vec : (cover <= TICK_VEC1_MAX_SLOTS ? 1 : (cover <= TICK_WAVE_WG_MAX_SLOTS ? 41 : 4));
         const uint32_t n_waves = std::max(1u, (uint32_t)((cover + TILE1 - 1) / TILE1));      // 256-slot quarters
         const uint32_t g = vec == 4 ? std::max(1u, tiles_for(cover)) : n_waves;
         a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
+        const bool use2 = vec == 4 && w->tick2_ok && !w->knobs.tick_vec;
+        if (use2) {
+            // persistent grid, in-kernel fold: ONE launch per group, the Checksum(u128)s land in the pinned result ring
+            Tick2Args b = w->tick2_proto;
+            b.src = a.src; b.live = a.live; b.len = a.len;
+            memcpy(b.save_dst, a.save_dst, sizeof b.save_dst); memcpy(b.save_frame, a.save_frame, sizeof b.save_frame);
+            memcpy(b.dt_bits, a.dt_bits, sizeof b.dt_bits);
+            b.op_bits = a.op_bits; b.n_ops = a.n_ops; b.n_saves = a.n_saves; b.n_steps = a.n_steps; b.src_is_live = a.src_is_live;
+            b.n_units = n_waves;
+            b.wg_parts = w->d_wg_parts; b.ticket = w->d_ticket;
+            b.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+            const uint32_t tiles = std::max(1u, tiles_for(cover));
+            const uint32_t g2 = w->knobs.tick2_wgs_per_cu > 0 ? std::min<uint32_t>(tiles, (uint32_t)(w->n_cu * w->knobs.tick2_wgs_per_cu)) : tiles;
+            if (b.n_ops || !b.src_is_live) {
+                ProfScope ps(w, GGRS_KERNEL_TICK);
+                const bool nt = w->nt_copy || w->knobs.tick2_nt;
+                if (w->knobs.tick2_ilv) { if (nt) launch_tick2<true, 1>(w, b, g2); else launch_tick2<false, 1>(w, b, g2); }
+                else { if (nt) launch_tick2<true, 0>(w, b, g2); else launch_tick2<false, 0>(w, b, g2); }
+            }
+            HIPCHK(w, hipGetLastError());
+            group_close(w, gs, a.n_saves);
+            ns += a.n_saves;
+        } else {
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
             if (vec == 1) { if (w->nt_copy) launch_tick1<true>(w, a, g); else launch_tick1<false>(w, a, g); }
@@ -1196,6 +1327,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             }
             HIPCHK(w, hipGetLastError());
             ns += a.n_saves;
+        }
         }
         if (spawn_req) {
             rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
@@ -1258,7 +1390,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + sub - 1) / sub));
         a.sub = sub; a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         // word image + masks + the staged row-offset and checksum-unit tables
-        const uint32_t n_rows = a.ts >> 12;
+        const uint32_t n_rows = a.ts >> (LT_SHIFT + 2);
         const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit) +
                              (a.marks ? sub / 8 + sub * 4 : 0);
         if (a.n_ops || !a.src_is_live) {
@@ -1292,6 +1424,32 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     return read_back(w, ns, checksums_out);
 }
 
+// Every entry point that touches the device runs with the world's device current on the calling thread and puts the
+// caller's device back on return (two worlds on different GPUs in one process; a host thread torch switched elsewhere).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const ggrs_world* w) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != w->device) switched = hipSetDevice(w->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+// Requests are validated BEFORE any host bookkeeping (frame counters, ring) is touched: a malformed list fails with
+// GGRS_E_INVALID and leaves the world exactly as it was.
+int validate_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const ggrs_request& r = reqs[i];
+        if (r.kind != GGRS_REQ_SAVE && r.kind != GGRS_REQ_LOAD && r.kind != GGRS_REQ_ADVANCE)
+            return w->fail(GGRS_E_INVALID, "request %u: unknown request kind %u", i, r.kind);
+        if (r.kind != GGRS_REQ_ADVANCE) continue;
+        if (r.n_inputs > GGRS_MAX_PLAYERS) return w->fail(GGRS_E_INVALID, "request %u: %u player inputs (at most %d)", i, r.n_inputs, GGRS_MAX_PLAYERS);
+        if (r.n_inputs && !r.inputs) return w->fail(GGRS_E_INVALID, "request %u: n_inputs = %u but inputs is NULL", i, r.n_inputs);
+        if (advance_spawns(w, r) && (!r.spawn_vx || !r.spawn_vy)) return w->fail(GGRS_E_INVALID, "request %u: a spawn of %llu fires but spawn_vx / spawn_vy is NULL", i, (unsigned long long)r.spawn_count);
+    }
+    return GGRS_OK;
+}
+inline bool range_ok(uint64_t first, uint64_t count, uint64_t capacity) { return first <= capacity && count <= capacity - first; }
+
 }  // namespace
 
 // =============================================================================================
@@ -1307,17 +1465,13 @@ int ggrs_hip_world_create_ex(const ggrs_world_desc* d, ggrs_world** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || d->device >= n) return GGRS_E_NO_DEVICE;
     if (hipSetDevice(d->device) != hipSuccess) return GGRS_E_NO_DEVICE;
     ggrs_world* w = new ggrs_world();
-    w->device = d->device; w->capacity = d->capacity; w->cap_pad = align_up(d->capacity, TILE);
+    w->device = d->device; w->capacity = d->capacity; w->cap_pad = align_up(d->capacity, LAYOUT_TILE);
     w->max_depth = d->max_depth ? d->max_depth : 8; w->flags = d->flags;
     w->depth = w->max_depth;
     w->nt_copy = (d->flags & GGRS_WORLD_NT_COPY) != 0;
-    if (const char* v = getenv("GGRS_TICK_VEC")) { const int x = atoi(v); if (x == 1 || x == 4 || x == 41) w->tick_vec = x; }
-    if (const char* v = getenv("GGRS_TICK_LDS")) { const int x = atoi(v); if (x >= 0 && x <= 160 * 1024) w->tick_lds = (uint32_t)x; }
-    if (const char* v = getenv("GGRS_TICK_REST")) w->tick_rest_loop = atoi(v) != 0;
-    if (!d->arena) {
-        if (const char* v = getenv("GGRS_BLOCK_PAD")) w->block_pad = align_up((uint64_t)atoll(v), ALIGN);
-        if (const char* v = getenv("GGRS_COL_PAD")) w->col_pad = align_up((uint64_t)atoll(v), ALIGN);
-    }
+    w->knobs = Knobs::from_env();
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) w->n_cu = v; }
+    if (!d->arena) { w->block_pad = align_up(w->knobs.block_pad, ALIGN); w->col_pad = align_up(w->knobs.col_pad, ALIGN); }
     if (d->stream) w->stream = (hipStream_t)d->stream;
     else {
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return GGRS_E_HIP; }
@@ -1333,7 +1487,7 @@ int ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggr
     return ggrs_hip_world_create_ex(&d, out);
 }
 uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_components, uint32_t bytes_per_slot) {
-    const uint64_t cap_pad = align_up(capacity, TILE);
+    const uint64_t cap_pad = align_up(capacity, LAYOUT_TILE);
     const uint64_t mask = align_up(cap_pad / 8, ALIGN);
     // each 4-byte word column is 256-B aligned; bytes_per_slot/4 bounds the column count
     // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 1024 per tile)
@@ -1341,7 +1495,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
                            align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
-    return (uint64_t)(max_depth + 1) * state + side + parts + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;
@@ -1419,8 +1573,9 @@ int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) r
 
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
-    if (w->len + count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)w->capacity);
+    if (!range_ok(w->len, count, w->capacity)) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)w->capacity);
     const uint64_t first = w->len;
     if (first_slot) *first_slot = first;
     if (count == 0) return GGRS_OK;
@@ -1446,6 +1601,7 @@ int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void
 }
 int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_alive, slot, 0);
@@ -1455,6 +1611,7 @@ int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
 }
 int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
     if (w->confirmed < w->frame) {                 // despawn.rs:129-137: insert RollbackDespawned(frame)
@@ -1469,6 +1626,7 @@ int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot) {
 }
 int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const void* words) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || slot >= w->len || !words) return w->fail(GGRS_E_INVALID, "bad insert_component arguments");
     const Comp& cc = w->comps[c];
@@ -1482,6 +1640,7 @@ int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const vo
 }
 int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || slot >= w->len) return w->fail(GGRS_E_INVALID, "bad remove_component arguments");
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 0);
@@ -1491,8 +1650,9 @@ int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
 }
 int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, const void* src) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
-    if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
+    if (c >= w->comps.size() || word >= w->comps[c].n_words || !range_ok(first, count, w->capacity) || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
     const Comp& cc = w->comps[c];
     rc = copy_column(w, cc.col_base + word, first, count, const_cast<void*>(src), true); if (rc) return rc;
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -1501,8 +1661,9 @@ int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t firs
 }
 int ggrs_hip_download_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, void* dst) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
-    if (c >= w->comps.size() || word >= w->comps[c].n_words || first + count > w->capacity || !dst) return w->fail(GGRS_E_INVALID, "bad download_word arguments");
+    if (c >= w->comps.size() || word >= w->comps[c].n_words || !range_ok(first, count, w->capacity) || !dst) return w->fail(GGRS_E_INVALID, "bad download_word arguments");
     const Comp& cc = w->comps[c];
     rc = copy_column(w, cc.col_base + word, first, count, dst, false); if (rc) return rc;
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -1518,11 +1679,13 @@ static int download_mask(ggrs_world* w, uint64_t off, uint64_t* dst, uint64_t n)
 }
 int ggrs_hip_download_alive(ggrs_world* w, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     return download_mask(w, w->off_alive, dst, n);
 }
 int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size()) return w->fail(GGRS_E_INVALID, "bad component");
     rc = download_mask(w, w->off_present[c], dst, n); if (rc) return rc;
@@ -1538,19 +1701,22 @@ int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t
 }
 int ggrs_hip_download_disabled(ggrs_world* w, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     return download_mask(w, w->marks.off_disabled, dst, n);
 }
 int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t count, int32_t* frames) {
     if (!w || !frames) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
-    if (first + count > w->capacity) return w->fail(GGRS_E_INVALID, "bad download_despawned_frames range");
+    if (!range_ok(first, count, w->capacity)) return w->fail(GGRS_E_INVALID, "bad download_despawned_frames range");
     if (count) HIPCHK(w, hipMemcpyAsync(frames, w->live.ptr + w->marks.off_dframe + first * 4, (size_t)count * 4, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return GGRS_OK;
 }
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p, uint64_t* tile_stride) {
     if (!w || !p) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words) return w->fail(GGRS_E_INVALID, "bad column");
     *p = w->live.ptr + w->col_off[w->comps[c].col_base + word];
@@ -1560,6 +1726,7 @@ int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** 
 uint64_t ggrs_hip_len(ggrs_world* w) { return w ? w->len : 0; }
 int ggrs_hip_active_count(ggrs_world* w, uint64_t* out) {
     if (!w || !out) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     const uint64_t n = (w->live.dirty_len + 63) / 64;
     std::vector<uint64_t> m(n ? n : 1, 0);
@@ -1589,6 +1756,7 @@ int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t cd) { if (!w) re
 int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
     if (!w) return GGRS_E_INVALID;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_SAVE; r.frame = w->frame; return run_request_groups(w, &r, 1, out); }
     rc = do_save(w, 0); if (rc) return rc;
@@ -1597,6 +1765,7 @@ int ggrs_hip_save(ggrs_world* w, uint64_t out[2]) {
 int ggrs_hip_load(ggrs_world* w, int32_t frame) {
     if (!w) return GGRS_E_INVALID;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (w->tick_ok) { ggrs_request r; memset(&r, 0, sizeof r); r.kind = GGRS_REQ_LOAD; r.frame = frame; return run_request_groups(w, &r, 1, nullptr); }
     return do_load(w, frame);
@@ -1605,21 +1774,23 @@ int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uin
                      uint64_t spawn_count, const float* vx, const float* vy) {
     if (!w) return GGRS_E_INVALID;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "synchronous request while %zu enqueued batches are uncollected", w->pending.size());
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
-    if (w->tick_ok) {
-        ggrs_request r; memset(&r, 0, sizeof r);
-        r.kind = GGRS_REQ_ADVANCE; r.dt_bits = dt_bits; r.inputs = inputs; r.n_inputs = n_inputs;
-        r.spawn_count = spawn_count; r.spawn_vx = vx; r.spawn_vy = vy;
-        return run_request_groups(w, &r, 1, nullptr);
-    }
+    ggrs_request r; memset(&r, 0, sizeof r);
+    r.kind = GGRS_REQ_ADVANCE; r.dt_bits = dt_bits; r.inputs = inputs; r.n_inputs = n_inputs;
+    r.spawn_count = spawn_count; r.spawn_vx = vx; r.spawn_vy = vy;
+    rc = validate_requests(w, &r, 1); if (rc) return rc;
+    if (w->tick_ok) return run_request_groups(w, &r, 1, nullptr);
     return do_advance(w, dt_bits, inputs, n_inputs, spawn_count, vx, vy);
 }
 
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
     TraceRange tr("HandleRequests");
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (!w->pending.empty()) return w->fail(GGRS_E_INVALID, "handle_requests while %zu enqueued batches are uncollected", w->pending.size());
+    rc = validate_requests(w, reqs, n); if (rc) return rc;
     if (w->tick_ok || w->gen_ok) {
         rc = w->tick_ok ? run_request_groups(w, reqs, n, checksums_out) : run_request_groups_gen(w, reqs, n, checksums_out);
         if (rc && w->stream) (void)hipStreamSynchronize(w->stream);
@@ -1653,7 +1824,9 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
 int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
     TraceRange tr("HandleRequests");
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
+    rc = validate_requests(w, reqs, n); if (rc) return rc;
     uint32_t n_save = 0;
     for (uint32_t i = 0; i < n; ++i) n_save += reqs[i].kind == GGRS_REQ_SAVE;
     if (n_save > w->max_results / 4 || w->pending_results + n_save > w->max_results / 2 || w->pending.size() >= 16)
@@ -1692,6 +1865,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
 int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t max_saves, uint32_t* n_saves_out) {
     if (!w) return GGRS_E_INVALID;
     if (w->pending.empty()) return w->fail(GGRS_E_INVALID, "no enqueued batch to collect");
+    DeviceGuard dg(w);
     ggrs_world::PendingBatch& b = w->pending.front();
     if (b.count > max_saves || (b.count && !checksums_out)) return w->fail(GGRS_E_INVALID, "oldest batch holds %u checksums, room for %u", b.count, max_saves);
     HIPCHK(w, hipEventSynchronize(b.ev));
@@ -1710,13 +1884,15 @@ uint32_t ggrs_hip_pending_batches(ggrs_world* w) { return w ? (uint32_t)w->pendi
 
 int ggrs_hip_synchronize(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return GGRS_OK;
 }
 
-uint64_t ggrs_hip_state_bytes(ggrs_world* w) { if (!w || seal(w)) return 0; return w->state_bytes; }
+uint64_t ggrs_hip_state_bytes(ggrs_world* w) { if (!w) return 0; DeviceGuard dg(w); if (seal(w)) return 0; return w->state_bytes; }
 int ggrs_hip_live_state_ptr(ggrs_world* w, void** p) {
     if (!w || !p) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     // keep the header current so an exported block is self-describing
     Header h = header_of(w);
@@ -1727,6 +1903,7 @@ int ggrs_hip_live_state_ptr(ggrs_world* w, void** p) {
 }
 int ggrs_hip_adopt_live_state(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     Header h;
     HIPCHK(w, hipMemcpyAsync(&h, w->live.ptr, sizeof h, hipMemcpyDeviceToHost, w->stream));
@@ -1747,6 +1924,7 @@ int ggrs_hip_profile_enable(ggrs_world* w, int on) {
 }
 int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out) {
     if (!w || !ms_out || !launches_out) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
     HIPCHK(w, hipStreamSynchronize(w->stream));
     for (auto& e : w->prof_events) {
         float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);

@@ -5,11 +5,15 @@
 //   * one workgroup (256 threads = 4 waves) owns one TILE of 1024 consecutive slots in EVERY
 //     kernel, and tile t is always blockIdx t.  Workgroup b lands on XCD b % 8, so the same
 //     XCD (and its private 4 MiB L2) touches the same slots in load -> advance -> save chains;
-//   * word columns are stored TILE-MAJOR inside a state block: the 1024 slots of tile t of every
-//     registered word sit next to each other (tile_stride = bytes of all words of 1024 slots, 60 KiB
-//     for the particles world), so one workgroup's whole traffic to a block is one contiguous span;
-//     word w of slot e lives at  col_off[w] + (e >> 10) * tile_stride + (e & 1023) * word_bytes.
-//     Live-only side columns keep the same formula with tile_stride = 1024 * word_bytes (a plain array);
+//   * word columns are stored TILE-MAJOR inside a state block, in LAYOUT TILES of 8192 slots (= 8 workgroup tiles): the
+//     8192 slots of layout tile T of every registered word sit next to each other (tile_stride = bytes of all words of
+//     8192 slots, 480 KiB for the particles world);
+//     word w of slot e lives at  col_off[w] + (e >> 13) * tile_stride + (e & 8191) * word_bytes.
+//     A workgroup's 1024-slot tile t is sub-tile t & 7 of layout tile t >> 3: its 4 KiB row of a 4-byte word starts at
+//     col_off[w] + (t >> 3) * tile_stride + (t & 7) * 4096, and CONSECUTIVE ROWS OF ONE WORKGROUP ARE 32 KiB APART --
+//     the period of the HBM channel interleave (128 channels x 256 B), so the rows a wave stores back to back land in
+//     the same DRAM pages (scripts/ubench3.hip, layout 2 / G = 8: 100.6 us vs 108.5 us for 1024-slot layout tiles).
+//     Live-only side columns keep the same formula with tile_stride = 8192 * word_bytes (a plain array);
 //   * every column access is 16 B per lane (dwordx4), 1 KiB per wave instruction, all loads
 //     of a tile issued before the first store;
 //   * Rollback-entity liveness is a 1 bit/slot mask; despawn masks are built with wave64
@@ -23,6 +27,8 @@
 namespace ggrs {
 
 constexpr int TILE = 1024;     // slots per workgroup
+constexpr int LT_SHIFT = 13;   // log2 of the slots of a LAYOUT tile (8 workgroup tiles)
+constexpr int LAYOUT_TILE = 1 << LT_SHIFT;
 constexpr int TPB = 256;       // threads per workgroup (4 waves of 64)
 constexpr int MAX_ROWS = 96;   // 4 KiB copy rows per tile (a 4-byte column = 1 row, 8-byte = 2)
 constexpr int MAX_MASKS = 17;  // alive + one presence mask per component
@@ -83,7 +89,11 @@ struct SeaStream {
 
 // byte offset (inside a state block) of word-column element `e`: see the layout note at the top
 __host__ __device__ __forceinline__ uint64_t col_at(uint64_t col_off, uint32_t tile_stride, uint32_t word_bytes, uint64_t e) {
-    return col_off + (e >> 10) * (uint64_t)tile_stride + (e & 1023u) * (uint64_t)word_bytes;
+    return col_off + (e >> LT_SHIFT) * (uint64_t)tile_stride + (e & (uint64_t)(LAYOUT_TILE - 1)) * (uint64_t)word_bytes;
+}
+// byte offset (relative to the column's col_off) of the first element of workgroup tile t (1024 slots)
+__host__ __device__ __forceinline__ uint64_t wtile_off(uint32_t t, uint32_t tile_stride, uint32_t word_bytes) {
+    return (uint64_t)(t >> (LT_SHIFT - 10)) * tile_stride + (uint64_t)(t & ((LAYOUT_TILE / TILE) - 1u)) * (uint32_t)(TILE * word_bytes);
 }
 
 // ------------------------------------------------------------------ kernel argument blocks
@@ -116,7 +126,7 @@ struct StepArgs {         // fused GgrsSchedule step of the particles workload
     uint32_t ts; uint32_t pad;            // tile stride of the rollback word columns
 };
 
-struct UnitDesc { uint64_t off; uint32_t stride; uint32_t ts; };   // u32 unit e at off + (e>>10)*ts + (e&1023)*stride
+struct UnitDesc { uint64_t off; uint32_t stride; uint32_t ts; };   // u32 unit e at col_at(off, ts, stride, e)
 struct CksArgs {          // generic component checksum
     const uint8_t* state;
     uint64_t off_alive;
@@ -208,7 +218,7 @@ __device__ __forceinline__ void copy_rows(const uint8_t* __restrict__ src, uint8
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         const RowDesc rd = plan.row[r0 + j];
-        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+        pos[j] = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff + (uint64_t)tid * 16;
     }
 #pragma unroll
     for (int j = 0; j < B; ++j) {
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
     } else {
         for (uint32_t r = 0; r < n_rows; ++r) {
             const RowDesc rd = plan.row[r];
-            const uint64_t pos = (uint64_t)t * rd.tile_stride + rd.roff + (uint64_t)tid * 16;
+            const uint64_t pos = wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff + (uint64_t)tid * 16;
             const uint64_t slot0 = (uint64_t)t * TILE + (rd.roff + tid * 16u) / rd.word_bytes;   // first slot of this lane's 16 bytes
             if (slot0 < len)
                 *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
@@ -278,8 +288,8 @@ template <bool UPD, bool TTL, bool CKS_T, bool CKS_V>
 __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;     // first of this lane's 4 slots
-    const uint64_t tb4 = (uint64_t)t * a.ts + (uint64_t)tid * 16;    // its 16 bytes inside a 4-byte column's tile row
-    const uint64_t tb8 = (uint64_t)t * a.ts + (uint64_t)tid * 32;    // its 32 bytes inside an 8-byte column's tile rows
+    const uint64_t tb4 = wtile_off(t, a.ts, 4) + (uint64_t)tid * 16;    // its 16 bytes inside a 4-byte column's tile row
+    const uint64_t tb8 = wtile_off(t, a.ts, 8) + (uint64_t)tid * 32;    // its 32 bytes inside an 8-byte column's tile rows
     const uint64_t w0 = (uint64_t)t * 16 + wave * 4;                 // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
     const uint64_t wi = w0 + (lane >> 4);
@@ -440,7 +450,7 @@ struct TickArgs {
     uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
     uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len;
-    uint32_t nt_load, diag;                // diag: DIAGNOSTIC timing experiments only (GGRS_TICK_DIAG), results invalid when non-zero
+    uint32_t nt_load, pad_nt;
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
@@ -487,7 +497,7 @@ __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         const RowLite rd = a.rest[r0 + j];
-        pos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff;
+        pos[j] = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff;
     }
 #pragma unroll
     for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const u32x4*>(a.src + pos[j] + lo);
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
     const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
     // every access below is "uniform 64-bit base (block + column row + tile offset) + 32-bit lane
     // offset", i.e. the saddr form of global_load/store
-    const uint64_t toff = (uint64_t)t * a.ts;                     // this tile inside a block (tile-major columns)
+    const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);   // this tile's rows of a 4- / 8-byte column inside a block
     const uint32_t o4 = tid * 16u, o8 = tid * 32u;                // lane offsets inside a 4- / 8-byte column's tile rows
     const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
     const uint32_t sh = (lane & 15u) * 4;
@@ -550,8 +560,8 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
         for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
-        { const u32x4 x = ld16(a.src + a.off_ttl + toff + o8); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
-        { const u32x4 x = ld16(a.src + a.off_ttl + toff + 16 + o8); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
+        { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
+        { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + 16 + o8); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
             restv[j] = u32x4{0, 0, 0, 0}; restpos[j] = 0;
             if ((uint32_t)j < a.n_rest_rows) {                   // wave-uniform
                 const RowLite rd = a.rest[j];
-                restpos[j] = rd.col_off + (uint64_t)t * rd.tile_stride + rd.roff;
+                restpos[j] = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff;
                 if (in_len) restv[j] = ld16(a.src + restpos[j] + tid * 16u);
             }
         }
@@ -631,12 +641,10 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
                     hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
                 }
             }
-            if (!(a.diag & 1u)) {                                    // (diag bit 0: timing experiment without the wave reduction)
-                if (CKS_T) hT = wave_xor(hT);
-                if (CKS_V) hV = wave_xor(hV);
-            }
+            if (CKS_T) hT = wave_xor(hT);
+            if (CKS_V) hV = wave_xor(hV);
         }
-        if (lane == 0 && !(a.diag & 4u)) {
+        if (lane == 0) {
             // plain per-wave partial stores: agent-scope atomics (tried: 64 accumulator copies + last-block
             // fold) cost ~1 ns EACH chip-wide on gfx950 -- 94k of them added 90 us to a 134 us kernel
             uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + gw;
@@ -669,24 +677,22 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
                         st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, tx[k]);
                         st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, vv[k]);
                     }
-                    st16<NT>(sgpr_base(dst + a.off_ttl + toff), o8, tl[0]);
-                    st16<NT>(sgpr_base(dst + a.off_ttl + toff + 16), o8, tl[1]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8, tl[0]);
+                    st16<NT>(sgpr_base(dst + a.off_ttl + toff8 + 16), o8, tl[1]);
                     if (RESTL > 0) {
 #pragma unroll
                         for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<NT>(sgpr_base(dst + restpos[j]), tid * 16u, restv[j]);
                     }
                 }
                 uint64_t mine = 0;
-                if (!(a.diag & 2u)) {                                // (diag bit 1: timing experiment without the mask rebuild)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
                                         (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
                     if (lane == (uint32_t)w) mine = nw;
                 }
-                }
                 if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
-                if ((lane & 15u) == 0 && !(a.diag & 2u)) {
+                if ((lane & 15u) == 0) {
                     st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
                     st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
                     st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
@@ -740,8 +746,8 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
                 st16<false>(sgpr_base(a.live + a.off_t[k] + toff), o4, tx[k]);
                 st16<false>(sgpr_base(a.live + a.off_v[k] + toff), o4, vv[k]);
             }
-            st16<false>(sgpr_base(a.live + a.off_ttl + toff), o8, tl[0]);
-            st16<false>(sgpr_base(a.live + a.off_ttl + toff + 16), o8, tl[1]);
+            st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8, tl[0]);
+            st16<false>(sgpr_base(a.live + a.off_ttl + toff8 + 16), o8, tl[1]);
             if (RESTL > 0 && !a.src_is_live) {
 #pragma unroll
                 for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<false>(sgpr_base(a.live + restpos[j]), tid * 16u, restv[j]);
@@ -764,6 +770,376 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
         }
     }
 
+}
+
+// ------------------------------------------------------------------ k_tick2 (persistent fused request group, round 2)
+// The same request-group fusion as k_tick, restructured after the round-2 store-path study (scripts/ubench3.hip,
+// profiles/r02a): on MI355X the HBM write path runs closest to its ceiling when FEW waves stream stores continuously
+// (a linear fill from 256 workgroups reaches 6.2-6.4 TB/s, the same fill from 1024 workgroups 4.7-5.4 TB/s), and
+// k_tick's Save was a burst of 15 stores followed by a block of ~660 VALU instructions (80 u64 multiplies), so store
+// issue and hashing only overlapped across waves.  Here:
+//   * PERSISTENT grid: `gridDim.x` = CUs x workgroups-per-CU (host-chosen, <= the tiles); a wave walks over 256-slot
+//     units u = wave id, += waves of the grid.  No second "wave" of workgroups starting its loads while the rest of
+//     the chip is storing, a bounded number of store streams in flight;
+//   * inside a Save the eight independent SeaHash chains (4 slots x {Transform, Velocity}) are INTERLEAVED with the
+//     tile's 15 row stores -- two stores, one chain, pinned with sched_barrier -- so the store queue drains while the
+//     VALU multiplies instead of after it;
+//   * snapshot stores may be non-temporal (`nt`): with the order of stores now reaching DRAM in a dense sweep that is a
+//     gain (ubench3: 100-105 us vs 113-115 us for the same traffic);
+//   * NO finalize launch: a wave folds its partials into LDS, the workgroup publishes one 48-value row with
+//     write-through (sc0 sc1) stores, takes ONE agent-scope ticket, and the last workgroup to arrive folds the rows
+//     (component_checksum.rs:92-95, entity_checksum.rs:29-52, checksum.rs:88-99) and writes every Save's Checksum
+//     straight to pinned host memory.  256-768 tickets per launch, not one atomic per partial.
+// Register-resident rows: the 8 schedule-owned rows (translation, velocity, ttl) + up to RESTL untouched rows, which
+// the layout keeps back to back behind them (4-byte words only: rest row j of tile t at rest_off + wtile_off(t) + j * 32 KiB).
+constexpr uint32_t REST_ROW_STRIDE = LAYOUT_TILE * 4u;     // k_tick2: the untouched words are 4-byte words laid out back to back
+struct Tick2Args {
+    const uint8_t* src; uint8_t* live;
+    uint8_t* save_dst[MAX_TICK_SAVES];     // nullptr: ring depth 0, checksum only
+    int32_t save_frame[MAX_TICK_SAVES];
+    uint32_t dt_bits[MAX_TICK_STEPS];
+    uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
+    uint32_t n_ops, n_saves, n_steps, src_is_live;
+    uint64_t len;                          // slots of the source state == RollbackOrdered::len at every Save (a spawn ends the group)
+    uint32_t n_units, ts;                  // 256-slot units to walk (covers every dirty mask word); tile stride
+    uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl, rest_off;
+    float g[3];
+    uint32_t n_rest_rows, n_rest_masks, cks_T, cks_V, pad0;
+    uint64_t rest_mask_off[MAX_MASKS];
+    uint64_t* wg_parts;                    // [gridDim.x][n_saves * 3]: XOR T, XOR V, live count per Save
+    uint32_t* ticket;                      // arrival counter, zero between launches
+    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
+};
+static_assert(sizeof(Tick2Args) <= 1024, "keep the kernel argument block small: it is re-sent every tick");
+
+// Cross-workgroup hand-off of the partial rows: relaxed agent-scope 8-byte atomics on both sides (lowered to
+// `global_store / global_load ... sc1`: write-through stores, L1-bypassing loads -- MI355X_MICROARCH.md, "Valid forms"),
+// an explicit vmcnt(0) between a workgroup's row and its ticket, one agent-scope acquire in the workgroup that folds.
+__device__ __forceinline__ void st8_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte store whose cache policy the instruction scheduler can see (a compiler-generated store, unlike st16<true>'s
+// inline asm): used by the ILV variant, where sched_group_barrier spaces the stores out between the hash multiplies.
+__device__ __forceinline__ g_u8* sgpr_base_nv(const uint8_t* p) {      // sgpr_base without `volatile`: the statement may move
+    uint64_t x = reinterpret_cast<uint64_t>(p);
+    asm("" : "+s"(x));
+    return (g_u8*)x;
+}
+template <bool NT>
+__device__ __forceinline__ void st16v(g_u8* base, uint32_t lo, const u32x4& v) {
+    if (NT) __builtin_nontemporal_store(v, (GGRS_GLOBAL u32x4*)(base + lo));
+    else *(GGRS_GLOBAL u32x4*)(base + lo) = v;
+}
+
+// RESTL: EXACT number of untouched rows (the stress_test world: 7) -- a Save's body is then one straight-line block.
+// ILV 0: a Save = one burst of row stores + the eight hash chains scheduled by the compiler, odd waves hashing first;
+// ILV 1: the same instructions with one store placed after every ~1/15th of the hash VALU work (sched_group_barrier).
+template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int ILV>
+__global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
+    __shared__ uint64_t acc[MAX_TICK_SAVES * 3];      // this workgroup's partials: [save][T, V, count]
+    __shared__ uint32_t s_last;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint32_t sh = (lane & 15u) * 4;
+    const uint32_t n_waves = gridDim.x * 4u;
+    for (uint32_t gw = blockIdx.x * 4u + wave_in_wg; gw < a.n_units; gw += n_waves) {       // gw: 256-slot unit
+        const uint32_t t = gw >> 2, wave = gw & 3u;                   // its tile, and which quarter of it
+        const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
+        const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
+        const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
+        const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);   // this tile's rows of a 4- / 8-byte column inside a block
+        const uint32_t o4 = tid * 16u;                                // lane offset inside a 4-byte column's tile row
+        // The 8-byte Ttl column: TWO fully contiguous 1 KiB accesses per wave (lane l moves bytes [16 l, 16 l + 16) of each
+        // half of the wave's 2 KiB), not two 16-byte pieces at a 32-byte lane stride -- a streaming (nt) store of half-filled
+        // lines leaves the L2 before its other half arrives.  So lane l owns the Ttl of unit slots {2l, 2l+1, 128+2l, 129+2l}
+        // ("L slots") while it owns translation / velocity of unit slots {4l .. 4l+3}; liveness crosses over by ballot.
+        const uint32_t o8a = wave * 2048u + lane * 16u, o8b = o8a + 1024u;
+        const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
+        const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;                 // byte offset of this lane's mask word
+
+        // ---- every load of the unit, back to back
+        const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
+        const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
+        const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
+        const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
+        float4 tx[3], vv[3];
+        ulonglong2 tl[2];
+        u32x4 restv[RESTL > 0 ? RESTL : 1];
+        auto ld16 = [&](const uint8_t* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
+        if (in_len) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
+            { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8a); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
+            { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8b); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
+#pragma unroll
+            for (int j = 0; j < RESTL; ++j) restv[j] = ld16(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
+            tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
+#pragma unroll
+            for (int j = 0; j < RESTL; ++j) restv[j] = u32x4{0, 0, 0, 0};
+        }
+        // presence masks of components the schedule never touches: read once, fanned out to every snapshot (+ live on load)
+        if (lane < 4u * a.n_rest_masks) {
+            const uint32_t m = lane >> 2, mw = lane & 3u;
+            const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
+            const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
+            for (uint32_t k = 0; k < a.n_saves; ++k)
+                if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
+            if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+        }
+
+        uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
+        const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu;
+        // liveness / Ttl presence of this lane's four L slots: words l >> 5 and 2 + (l >> 5) of the wave's four mask words
+        // (lanes 0, 16, 32, 48 hold them), bit pair 2 (l & 31)
+        auto word_of = [&](uint64_t v, int k) -> uint64_t {
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * k);
+        };
+        const uint32_t shL = 2u * (lane & 31u);
+        auto l_bits = [&](uint64_t v) -> uint32_t {
+            const uint64_t lo = lane < 32 ? word_of(v, 0) : word_of(v, 1), hi = lane < 32 ? word_of(v, 2) : word_of(v, 3);
+            return ((uint32_t)(lo >> shL) & 3u) | (((uint32_t)(hi >> shL) & 3u) << 2);
+        };
+        uint32_t aliveL = l_bits(alive_w);
+        const uint32_t presL = l_bits(pL_w);
+
+        // diffuse(K0 ^ order), order == slot (RollbackOrdered::order): shared by both components and all Saves
+        uint64_t ordB[4];
+        if (CKS_T || CKS_V) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
+        }
+        // one SeaHash chain: component_checksum.rs:81-90 for slot j of this lane (5 diffuses; the 8 chains of a Save are independent)
+        auto chainT = [&](int j) -> uint64_t {
+            const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                                __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                                __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+            return (((alive4 & n_T) >> j) & 1u) ? h : 0ULL;
+        };
+        auto chainV = [&](int j) -> uint64_t {
+            const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                                __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                                __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+            return (((alive4 & n_V) >> j) & 1u) ? h : 0ULL;
+        };
+        const bool hash_first = (wave & 1u) != 0;                     // wave-uniform (see k_tick)
+
+        // every load issued above has to land before the first op anyway; saying so explicitly keeps the op loop free of
+        // conservative vmcnt waits (gfx9 counts stores in vmcnt too: such a wait would drain the snapshot stores in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0) expcnt(7) lgkmcnt(15)
+
+        uint32_t si = 0, sj = 0;
+        for (uint32_t i = 0; i < a.n_ops; ++i) {
+            if (!((a.op_bits >> i) & 1ULL)) {
+                // ---------------- SaveWorld: snapshot (component_snapshot.rs:66-84, entity.rs:39-51) + per-entity checksum half
+                uint8_t* dst = a.save_dst[si];
+                const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
+                               b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
+                const uint32_t cnt = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                uint64_t hT = 0, hV = 0;
+                auto hash_all = [&]() {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (CKS_T) hT ^= chainT(j); if (CKS_V) hV ^= chainV(j); }
+                };
+                if (dst && in_len) {
+                    if (ILV == 0) {
+                        if (hash_first) hash_all();
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, tx[k]);
+                            st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, vv[k]);
+                        }
+                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, tl[0]);
+                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, tl[1]);
+#pragma unroll
+                        for (int j = 0; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        if (!hash_first) hash_all();
+                    } else {
+                        // four pieces: ~4 row stores, then the two chains of one slot (T_j, V_j: enough independent multiplies
+                        // to keep the VALU issue-bound), pinned in this order
+                        st16<NT>(sgpr_base(dst + a.off_t[0] + toff), o4, tx[0]); st16<NT>(sgpr_base(dst + a.off_t[1] + toff), o4, tx[1]);
+                        st16<NT>(sgpr_base(dst + a.off_t[2] + toff), o4, tx[2]); st16<NT>(sgpr_base(dst + a.off_v[0] + toff), o4, vv[0]);
+                        if (CKS_T) hT ^= chainT(0);
+                        if (CKS_V) hV ^= chainV(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        st16<NT>(sgpr_base(dst + a.off_v[1] + toff), o4, vv[1]); st16<NT>(sgpr_base(dst + a.off_v[2] + toff), o4, vv[2]);
+                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, tl[0]); st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, tl[1]);
+                        if (CKS_T) hT ^= chainT(1);
+                        if (CKS_V) hV ^= chainV(1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < (RESTL + 1) / 2; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        if (CKS_T) hT ^= chainT(2);
+                        if (CKS_V) hV ^= chainV(2);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = (RESTL + 1) / 2; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        if (CKS_T) hT ^= chainT(3);
+                        if (CKS_V) hV ^= chainV(3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    hash_all();
+                }
+                if (dst) {
+                    uint64_t mine = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                            (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+                        if (lane == (uint32_t)w) mine = nw;
+                    }
+                    if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
+                    if ((lane & 15u) == 0) {
+                        st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
+                        st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
+                        st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
+                    }
+                    if (gw == 0 && lane == 0) {
+                        Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
+                        h.checksum[0] = 0; h.checksum[1] = 0;
+                        *reinterpret_cast<Header*>(dst) = h;
+                    }
+                }
+                // this wave's partials of the Save -> the workgroup's LDS accumulators (fire-and-forget LDS atomics)
+                if (CKS_T) hT = wave_xor(hT);
+                if (CKS_V) hV = wave_xor(hV);
+                if (lane == 0) {
+                    if (CKS_T) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 0]), (unsigned long long)hT);
+                    if (CKS_V) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 1]), (unsigned long long)hV);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 2]), (unsigned long long)cnt);
+                }
+                ++si;
+            } else {
+                // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
+                const float dt = __uint_as_float(a.dt_bits[sj]);
+                ++sj;
+                const uint32_t m_upd = alive4 & n_T & n_V;     // Query<(&mut Transform, &mut Velocity)>
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float gd = __fmul_rn(a.g[k], dt);    // gravity * time_step
+                    float* x = reinterpret_cast<float*>(&tx[k]);
+                    float* v = reinterpret_cast<float*>(&vv[k]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = (m_upd >> j) & 1u;
+                        const float nv = __fadd_rn(v[j], gd);                     // **velocity += ...
+                        const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));      // translation += **velocity * time_step
+                        v[j] = on ? nv : v[j];
+                        x[j] = on ? nx : x[j];
+                    }
+                }
+                const uint32_t m_ttl = aliveL & presL;         // Query<(Entity, &mut Ttl)>, over this lane's L slots
+                uint32_t killL = 0;
+                uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = (m_ttl >> j) & 1u;
+                    const uint64_t nq = q[j] - 1;              // usize, wrapping
+                    q[j] = on ? nq : q[j];
+                    killL |= (on && nq == 0) ? (1u << j) : 0u;
+                }
+                aliveL &= ~killL;                              // despawn is deferred to the end of the frame
+                // the kills, seen from the lanes that own the same slots' translation / velocity: unit slot 4m + i lives in
+                // L lane (2m + (i >> 1)) & 63, L index (i & 1) for m < 32 and 2 + (i & 1) for m >= 32
+                const uint64_t k0 = __ballot((killL >> 0) & 1u), k1 = __ballot((killL >> 1) & 1u),
+                               k2 = __ballot((killL >> 2) & 1u), k3 = __ballot((killL >> 3) & 1u);
+                if ((k0 | k1 | k2 | k3) != 0) {                // wave-uniform
+                    const uint64_t ka = lane < 32 ? k0 : k2, kb = lane < 32 ? k1 : k3;
+                    const uint32_t pa = (uint32_t)(ka >> shL) & 3u, pb = (uint32_t)(kb >> shL) & 3u;
+                    const uint32_t kill4 = (pa & 1u) | ((pb & 1u) << 1) | ((pa >> 1) << 2) | ((pb >> 1) << 3);
+                    alive4 &= ~kill4;
+                }
+            }
+        }
+
+        // ---- the live block, written once
+        if (!a.src_is_live || a.n_steps) {
+            if (in_len) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    st16<false>(sgpr_base(a.live + a.off_t[k] + toff), o4, tx[k]);
+                    st16<false>(sgpr_base(a.live + a.off_v[k] + toff), o4, vv[k]);
+                }
+                st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8a, tl[0]);
+                st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8b, tl[1]);
+                if (!a.src_is_live) {
+#pragma unroll
+                    for (int j = 0; j < RESTL; ++j) st16<false>(sgpr_base(a.live + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                }
+            }
+            const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
+                           b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
+            uint64_t mine = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                    (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+                if (lane == (uint32_t)w) mine = nw;
+            }
+            if (lane < 4) st8(sgpr_base(a.live + a.off_alive) + (w0 + lane) * 8u, mine);
+            if (!a.src_is_live && (lane & 15u) == 0) {
+                st8(sgpr_base(a.live + a.off_pT) + wi8, pT_w);
+                st8(sgpr_base(a.live + a.off_pV) + wi8, pV_w);
+                st8(sgpr_base(a.live + a.off_pL) + wi8, pL_w);
+            }
+        }
+    }
+
+    // ---- fold: one write-through row per workgroup, one ticket, the last workgroup finishes every Save's checksum
+    if (a.n_saves == 0) return;
+    __syncthreads();                                              // LDS atomics of all four waves have landed
+    const uint32_t n_vals = a.n_saves * 3u;                       // <= 48
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < n_vals) st8_agent(a.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is in memory before the ticket is taken
+        if (threadIdx.x == 0) {
+            const uint32_t ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;                                          // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  16 loads in flight per lane and trip.
+        const uint32_t n_flat = gridDim.x * n_vals;
+        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += 16u * TPB) {
+            uint64_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * TPB;
+                v[u] = i < n_flat ? ld8_agent(a.wg_parts + i) : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * TPB;
+                if (i >= n_flat) continue;
+                const uint32_t c = i % n_vals;
+                if ((c % 3u) == 2u) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.n_saves) {
+        const uint32_t k = threadIdx.x;
+        uint64_t total = 0;
+        if (a.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
+        if (a.cks_V) total ^= sea_one(acc[k * 3 + 1]);
+        total ^= sea_pair(acc[k * 3 + 2], a.len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        a.out[2 * (uint64_t)k] = total; a.out[2 * (uint64_t)k + 1] = 0;
+    }
+    if (threadIdx.x == 0) *a.ticket = 0;                          // ready for the next launch on this stream
 }
 
 // ------------------------------------------------------------------ k_tick1 (one slot per lane)
@@ -789,7 +1165,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     };
     const bool in_len = (uint64_t)t * TILE1 < a.len;              // workgroup-uniform
     const uint32_t e = t * TILE1 + tid;                           // this lane's slot
-    const uint64_t toff = (uint64_t)(t >> 2) * a.ts;              // its 1024-slot tile inside a block (tile-major columns)
+    const uint64_t toff = wtile_off(t >> 2, a.ts, 4), toff8 = wtile_off(t >> 2, a.ts, 8);   // its 1024-slot tile's rows of a 4- / 8-byte column
     const uint32_t ti = (t & 3u) * TILE1 + tid;                   // its index inside that tile
     const uint32_t o4 = ti * 4u, o8 = ti * 8u;
     const uint32_t wi8 = (t * 4u + wave) * 8u;                    // this wave's mask word
@@ -805,7 +1181,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float*>(a.src + a.off_t[k] + toff + o4);
 #pragma unroll
         for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float*>(a.src + a.off_v[k] + toff + o4);
-        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + toff + o8);
+        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + toff8 + o8);
     }
 
     // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
@@ -833,7 +1209,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 if (r < n_rows) {
                     const RowLite rd = sa.rest[r]; ++r;
                     wb[j] = rd.word_bytes; off[j] = rd.col_off; nb = j + 1;
-                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + toff + o8);
+                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + toff8 + o8);
                     else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + toff + o4);
                 }
             }
@@ -844,7 +1220,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nb) {
-                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + toff + o8) = v[j];
+                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + toff8 + o8) = v[j];
                         else *reinterpret_cast<uint32_t*>(dst + off[j] + toff + o4) = (uint32_t)v[j];
                     }
                 }
@@ -871,7 +1247,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                         *reinterpret_cast<float*>(dst + a.off_t[k] + toff + o4) = tx[k];
                         *reinterpret_cast<float*>(dst + a.off_v[k] + toff + o4) = vv[k];
                     }
-                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + toff + o8) = ttl;
+                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + toff8 + o8) = ttl;
                 }
                 if (lane == 0) {
                     *reinterpret_cast<uint64_t*>(dst + a.off_alive + wi8) = alive_now;
@@ -925,7 +1301,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 *reinterpret_cast<float*>(a.live + a.off_t[k] + toff + o4) = tx[k];
                 *reinterpret_cast<float*>(a.live + a.off_v[k] + toff + o4) = vv[k];
             }
-            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + toff + o8) = ttl;
+            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + toff8 + o8) = ttl;
         }
         const uint64_t alive_now = __ballot(alive);
         if (lane == 0) {
@@ -1337,10 +1713,10 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t sub = a.sub, mw = sub >> 6;                        // slots / mask words per workgroup
     const uint64_t s0 = (uint64_t)blockIdx.x * sub;                   // first slot of this workgroup
-    const uint64_t tbase = a.cols_base + (s0 >> 10) * a.ts;           // its tile inside a block
-    const uint32_t in_tile = (uint32_t)(s0 & 1023u);
+    const uint64_t tbase = a.cols_base + (s0 >> LT_SHIFT) * a.ts;     // its layout tile inside a block
+    const uint32_t in_tile = (uint32_t)(s0 & (uint64_t)(LAYOUT_TILE - 1));
     const bool in_len = s0 < a.len;                                   // workgroup-uniform
-    const uint32_t n_rows = a.ts >> 12;                               // 4-byte row units per slot (8-byte words = 2)
+    const uint32_t n_rows = a.ts >> (LT_SHIFT + 2);                   // 4-byte row units per slot (8-byte words = 2)
     const uint32_t img = n_rows * sub * 4u;                           // bytes of the word image
     uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + img);         // [n_masks][mw] behind the words; mask 0 = liveness
     // small tables staged once: global offset of every row unit of this workgroup, the checksum units

@@ -315,7 +315,7 @@ class World(WorldBase):
 
     def column_device_ptr(self, comp: int, word: int):
         """(device address of element 0, tile stride in bytes): element e of the column lives at
-        ptr + (e // 1024) * tile_stride + (e % 1024) * word_bytes (tile-major word columns)."""
+        ptr + (e // 8192) * tile_stride + (e % 8192) * word_bytes (tile-major word columns, 8192-slot layout tiles)."""
         p = C.c_void_p()
         ts = C.c_uint64(0)
         self._check(self._lib.ggrs_hip_column_device_ptr(self._p, comp, word, C.byref(p), C.byref(ts)))

@@ -64,7 +64,6 @@ typedef struct {
 } ggrs_world_desc;
 
 #define GGRS_WORLD_DEFAULT      0u
-#define GGRS_WORLD_NO_GRAPH     1u   /* reserved, no effect: request-group fusion made a tick 2 launches */
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
@@ -177,9 +176,9 @@ int ggrs_hip_download_word(ggrs_world* w, uint32_t comp_id, uint32_t word, uint6
 int ggrs_hip_download_alive(ggrs_world* w, uint64_t* host_dst, uint64_t n_words64);
 int ggrs_hip_download_present(ggrs_world* w, uint32_t comp_id, uint64_t* host_dst, uint64_t n_words64);
 /* device address of a live column (for zero-copy interop).  Word columns are stored tile-major: element e
- * of the column lives at dev_ptr + (e / 1024) * tile_stride + (e % 1024) * word_bytes; *tile_stride (may be
- * NULL) is 1024 * word_bytes for a plain array (non-rollback components) and the bytes of all rollback words
- * of 1024 slots otherwise. */
+ * of the column lives at dev_ptr + (e / 8192) * tile_stride + (e % 8192) * word_bytes; *tile_stride (may be
+ * NULL) is 8192 * word_bytes for a plain array (non-rollback components) and the bytes of all rollback words
+ * of 8192 slots otherwise (8192-slot layout tiles). */
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr,
                                uint64_t* tile_stride);
 

@@ -13,7 +13,6 @@ pub const GGRS_E_HIP: c_int = -4;
 pub const GGRS_E_NO_DEVICE: c_int = -5;
 
 pub const GGRS_WORLD_DEFAULT: u32 = 0;
-pub const GGRS_WORLD_NO_GRAPH: u32 = 1;
 pub const GGRS_WORLD_UNFUSED: u32 = 2;
 pub const GGRS_WORLD_NT_COPY: u32 = 4;
 pub const GGRS_WORLD_NO_GROUPS: u32 = 8;

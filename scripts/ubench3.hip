@@ -109,6 +109,52 @@ __global__ __launch_bounds__(256, MINW) void fan(Fan a) {
     }
 }
 
+// Wave specialisation: a 512-thread workgroup, waves 0-3 "compute" (hash stand-in: 8 independent chains of alu/8
+// dependent u64 multiplies per Save, then the 8 schedule-owned rows of the tile go to LDS), waves 4-7 "store" (7
+// untouched rows stay in their registers; per Save: 8 rows from LDS + 7 from registers -> the ring slot).  One
+// s_barrier per Save, double-buffered LDS: the compute waves never wait for a global store to be accepted.
+template <int K>
+__global__ __launch_bounds__(512) void fan_spec(Fan a) {
+    __shared__ u32x4 buf[2][8][256];                 // 2 x 32 KiB
+    const uint32_t tid = threadIdx.x & 255u;
+    const bool store_role = threadIdx.x >= 256;
+    for (int t = blockIdx.x; t < a.tiles; t += gridDim.x) {
+        u32x4 v[8]; u32x4 r[7];
+        const u32x4* s = a.ring + (size_t)a.src_slot * a.bs_v + tid;
+        if (!store_role) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s[row_off(a, t, j)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) r[j] = s[row_off(a, t, 8 + j)];
+        }
+        uint64_t h[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) h[c] = c + 1;
+        for (int k = 1; k <= 9; ++k) {               // 8 snapshots + the live block
+            if (!store_role) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j].x += k; buf[k & 1][j][tid] = v[j]; }
+            }
+            __syncthreads();
+            if (store_role) {
+                const bool live = k == 9;
+                u32x4* p = (live ? a.live : a.ring + (size_t)((a.src_slot + k) % 9) * a.bs_v) + tid;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const u32x4 x = buf[k & 1][j][tid]; if (live) st<PLAIN>(p + row_off(a, t, j), x); else st<K>(p + row_off(a, t, j), x); }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) { if (live) st<PLAIN>(p + row_off(a, t, 8 + j), r[j]); else st<K>(p + row_off(a, t, 8 + j), r[j]); }
+            } else if (k < 9 && a.alu) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) h[c] = churn(h[c] + v[c].y, a.alu / 8);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c].z ^= (uint32_t)h[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct Dev { u32x4* ring; u32x4* live; size_t bs_v; int tiles; };
 
 template <class F> float time_us(int iters, F f) {
@@ -163,13 +209,25 @@ template <int K, int KL, int MINW> void run_fan(const Dev& d, int layout, int G,
     printf("%-100s %8.1f us  %6.2f TB/s\n", name, us, mb / us);
 }
 
+template <int K> void run_fan_spec(const Dev& d, int layout, int G, int grid, int alu) {
+    char name[160];
+    snprintf(name, sizeof name, "fan_spec %-6s layout=%d G=%-4d grid=%-5d alu=%-3d (512-thread WGs: 4 compute + 4 store waves)", kname(K), layout, G, grid, alu);
+    if (!want(name)) return;
+    Fan a; a.ring = d.ring; a.live = d.live; a.bs_v = d.bs_v; a.tiles = d.tiles; a.layout = layout; a.G = G; a.alu = alu; a.stagger = 0; a.rest_first = 0;
+    float us = time_us(18, [&](int i) { Fan b = a; b.src_slot = i % 9; hipLaunchKernelGGL((fan_spec<K>), dim3(grid), dim3(512), 0, 0, b); });
+    const double mb = (double)d.tiles * TILE_V * 16.0 * 10 / 1e6;
+    printf("%-100s %8.1f us  %6.2f TB/s\n", name, us, mb / us);
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) g_filter = argv[1];
     const int tiles = 977;
     // the engine's block stride for 1 M entities: header + 4 masks (4 KiB aligned) + 977 tiles x 60 KiB
     const size_t bs = 503808 + (size_t)tiles * 61440;
     Dev d; d.tiles = tiles; d.bs_v = bs / 16;
-    CK(hipMalloc((void**)&d.ring, bs * 10 + (1 << 20)));
+    if (getenv("UB_CONTIG") && atoi(getenv("UB_CONTIG"))) CK(hipExtMallocWithFlags((void**)&d.ring, bs * 10 + (64 << 20), hipDeviceMallocContiguous));
+    else CK(hipMalloc((void**)&d.ring, bs * 10 + (64 << 20)));   // slack: layout 2 rounds the tile count up to a multiple of G
+    printf("ring at %p (%s)\n", (void*)d.ring, getenv("UB_CONTIG") ? "contiguous" : "hipMalloc");
     d.live = d.ring + 9 * d.bs_v;
     CK(hipMemset(d.ring, 1, bs * 10));
     // reference points: hipMemset / hipMemcpy of one block
@@ -194,7 +252,7 @@ int main(int argc, char** argv) {
         run_fan<NTSC1, PLAIN, 1>(d, layout, 0, T, 0, 0, 0);
         run_fan<NT, NT, 1>(d, layout, 0, T, 0, 0, 0);
     }
-    for (int G : {8, 32, 128, 256}) {
+    for (int G : {2, 4, 8, 16, 32, 128, 256}) {
         run_fan<PLAIN, PLAIN, 1>(d, 2, G, T, 0, 0, 0);
         run_fan<NT, PLAIN, 1>(d, 2, G, T, 0, 0, 0);
     }
@@ -216,6 +274,16 @@ int main(int argc, char** argv) {
             run_fan<NT, PLAIN, 1>(d, 0, 0, T, alu, stagger, 52 * 1024);
             run_fan<NT, PLAIN, 1>(d, 0, 0, T, alu, stagger, 38 * 1024);
         }
+    }
+    // wave specialisation vs the uniform kernel at the same ALU load, on the engine's layout (2, G = 8)
+    for (int alu : {0, 80, 160}) {
+        for (int grid : {256, 512, 977}) {
+            run_fan_spec<NT>(d, 2, 8, grid, alu);
+            run_fan_spec<PLAIN>(d, 2, 8, grid, alu);
+        }
+        run_fan<NT, PLAIN, 1>(d, 2, 8, T, alu, 1, 52 * 1024);
+        run_fan<NT, PLAIN, 1>(d, 2, 8, T, alu, 1, 0);
+        run_fan<NT, PLAIN, 1>(d, 2, 8, 768, alu, 1, 0);
     }
     CK(hipFree(d.ring));
     return 0;

@@ -262,10 +262,10 @@ def test_p2p_shaped_rollbacks_100k(n, ticks, flags):
 
 
 def test_column_transfers_across_tile_boundaries():
-    """Word columns are tile-major on the device (1024-slot tiles): uploads, downloads and
+    """Word columns are tile-major on the device (8192-slot layout tiles): uploads, downloads and
     spawns of arbitrary [first, first + count) ranges are a head piece + a pitched 2-D copy + a tail piece.  Every
     range must round-trip and leave its neighbours alone -- 4- and 8-byte words, rollback and live-only columns."""
-    cap = 5000
+    cap = 20000
     w = bg.World(cap, max_depth=4)
     A = w.register_component("A", 4, 3)
     B = w.register_component("B", 8, 2)
@@ -275,7 +275,8 @@ def test_column_transfers_across_tile_boundaries():
     shadow = {(A, k): np.zeros(cap, np.uint32) for k in range(3)}
     shadow.update({(B, k): np.zeros(cap, np.uint64) for k in range(2)})
     shadow[(N, 0)] = np.zeros(cap, np.uint32)
-    ranges = [(0, 1), (1023, 2), (1000, 3000), (1024, 1024), (1, 4998), (2047, 1), (2048, 2952), (4999, 1), (0, 5000), (3071, 1026)]
+    ranges = [(0, 1), (1023, 2), (1000, 3000), (1024, 1024), (1, 4998), (2047, 1), (2048, 2952), (4999, 1), (0, 5000), (3071, 1026),
+              (8191, 2), (8192, 8192), (8000, 400), (1, 19999), (16383, 3617), (0, 20000), (16384, 1), (8190, 8196)]
     for i, (first, count) in enumerate(ranges):
         for (c, k), sh in shadow.items():
             data = rng.integers(0, 2 ** 32 - 1, count).astype(sh.dtype) + (np.uint64(i) << np.uint64(40) if sh.dtype == np.uint64 else 0)
@@ -295,6 +296,62 @@ def test_column_transfers_across_tile_boundaries():
     for (c, k), sh in shadow.items():
         assert np.array_equal(w.download_word(c, k, 0, cap), sh), ("after load", c, k)
     ptr, ts = w.column_device_ptr(A, 0)
-    assert ptr and ts == 1024 * (3 * 4 + 2 * 8)                   # tile stride = bytes of all rollback words of 1024 slots
+    assert ptr and ts == 8192 * (3 * 4 + 2 * 8)                   # tile stride = bytes of all rollback words of 8192 slots
     ptr_n, ts_n = w.column_device_ptr(N, 0)
-    assert ptr_n and ts_n == 1024 * 4                             # live-only column: a plain array
+    assert ptr_n and ts_n == 8192 * 4                             # live-only column: a plain array
+
+
+def test_malformed_requests_fail_before_any_bookkeeping():
+    """NULL pointers with non-zero counts, > GGRS_MAX_PLAYERS inputs and unknown kinds return GGRS_E_INVALID
+    (the reference would panic / not compile) and leave frame counter, ring and state untouched."""
+    import ctypes as C
+    from bevy_ggrs_amd import _ffi
+    n = 2000
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    w = bg.World(n + 500, max_depth=4)
+    ids = cm.build_particles(w, with_spawn=True)
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    w.handle_requests([bg.SaveGameState(0), bg.AdvanceFrame((0,))])
+    before = (w.frame, w.snapshot_count(), cm.snapshot_state(w, ids))
+    out = (C.c_uint64 * 8)()
+
+    def bad(mut):
+        arr = (_ffi.Request * 3)()
+        arr[0].kind, arr[0].frame = _ffi.REQ_SAVE, w.frame
+        arr[1].kind = _ffi.REQ_ADVANCE
+        arr[2].kind, arr[2].frame = _ffi.REQ_SAVE, w.frame + 1
+        keep = mut(arr)
+        for fn in ("handle_requests", "enqueue_requests"):
+            rc = getattr(_ffi.lib, "ggrs_hip_" + fn)(w._p, arr, 3, out if fn == "handle_requests" else None)
+            assert rc == bg.GGRS_E_INVALID, (fn, rc)
+        assert w.pending_batches() == 0
+        return keep
+
+    def null_inputs(arr): arr[1].n_inputs = 2
+    def too_many(arr):
+        ia = (C.c_uint8 * 17)(); arr[1].inputs = C.cast(ia, C.POINTER(C.c_uint8)); arr[1].n_inputs = 17; return ia
+    def unknown_kind(arr): arr[2].kind = 9
+    def null_spawn(arr):
+        ia = (C.c_uint8 * 1)(cm.INPUT_SPAWN); arr[1].inputs = C.cast(ia, C.POINTER(C.c_uint8)); arr[1].n_inputs = 1; arr[1].spawn_count = 10; return ia
+    for m in (null_inputs, too_many, unknown_kind, null_spawn):
+        bad(m)
+    assert (w.frame, w.snapshot_count()) == before[:2]
+    cm.assert_states_equal(cm.snapshot_state(w, ids), before[2], "after rejected requests")
+    # overflow-safe ranges
+    with pytest.raises(bg.GgrsHipError):
+        w._check(_ffi.lib.ggrs_hip_download_word(w._p, ids[0], 0, 2 ** 64 - 4, 8, C.cast(out, C.c_void_p)))
+    # the world still works
+    assert len(w.handle_requests([bg.SaveGameState(w.frame), bg.AdvanceFrame((0,))])) == 1
+
+
+def test_particles_systems_over_live_only_components_are_rejected():
+    """PARTICLES_* / TTL_DESPAWN kernels address columns with the rollback tile stride; a
+    GGRS_COMP_NO_ROLLBACK component under them is refused when the world is sealed, and the failure is permanent."""
+    w = bg.World(4096, max_depth=4)
+    T = w.register_component("Transform", 4, 10)
+    V = w.register_component("Velocity", 4, 3, rollback=False)
+    w.add_system(bg.SYS_PARTICLES_UPDATE, comp=(T, V), word=(0, 0), fparam=(0.0, -200.0, 0.0))
+    for _ in range(2):
+        with pytest.raises(bg.GgrsHipError) as e:
+            w.spawn(10, {T: None, V: None})
+        assert e.value.code == bg.GGRS_E_INVALID and "not registered for rollback" in str(e.value)
