@@ -146,17 +146,9 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks
             parity["first_mismatch"] = {"timed_tick": bad[0] // depth, "save": bad[0] % depth, "gpu": hex(got[bad[0]]), "oracle": hex(want[bad[0]])}
     flat = {"value": ef * max(P, 1) / fsecs, "unit": "entity-frames/s", "cores": flat_threads,
             "sample": f"{max(P, 1)} steady-state ticks of the oracle's flat SoA + memcpy-ring variant (OpenMP; the parity replay itself), {fsecs:.1f} s"}
-    if cores > flat_threads:
-        # more threads than memory channels can feed rarely helps a memcpy-bound port: measured, the better one is reported
-        wa = world(FLAT)
-        lib.gor_set_num_threads(cores)
-        ticks_all = max(4, P // 2)
-        asecs = wa.bench_synctest(depth, depth + 1, ticks_all)
-        del wa
-        flat["all_cores"] = {"value": ef * ticks_all / asecs, "cores": cores, "sample": f"{ticks_all} ticks, {asecs:.1f} s"}
-        if flat["all_cores"]["value"] > flat["value"]:
-            flat = {"value": flat["all_cores"]["value"], "unit": "entity-frames/s", "cores": cores, "sample": flat["all_cores"]["sample"],
-                    "at_64_threads": {"value": ef * max(P, 1) / fsecs, "cores": flat_threads}}
+    # 64 threads, not all cores: a 256-thread OpenMP team over this memcpy-bound port measured 2.1 M entity-frames/s against
+    # 48.7 M at 64 threads on the 256-core gpurun host (profiles/r02a/bench.json) -- more threads than memory channels hurt
+    flat["threads_note"] = f"{flat_threads} of {cores} host cores: measured faster than a {cores}-thread team (profiles/r02a)"
     lib.gor_set_num_threads(1)
     base = {"value": ef * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
             "kind": "port",
@@ -332,7 +324,8 @@ def main():
         bytes_per_launch = BYTES_PER_ENTITY * (1 + D + 1) * live              # 600 B/entity at D = 8
         avg_s = per(tick_ms, tick_n)
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
-        roof = {"bound": "hbm", "kernel": "k_tick (fused request group: LoadWorld + D x SaveWorld + (D+1) x AdvanceWorld in one pass)",
+        roof = {"bound": "hbm", "kernel": ("k_tick3" if fin_n == 0 else "k_tick") + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
+                                          + (", checksum fold in-kernel)" if fin_n == 0 else "; + k_tick_finalize)"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
                 # the two accountings, named so they cannot be confused: `frac` == frac_compulsory_600B
@@ -342,7 +335,7 @@ def main():
                 "algorithmic_bytes_note": "compulsory traffic of the fused group: 60 B/entity snapshot read + 60 B x saves + 60 B live write "
                                           "(SURVEY 8d's 1656 B/entity-tick assumes one kernel per request; that per-request equivalent is reported below)",
                 "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
-                "other_kernels": {"k_tick_finalize": {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}},
+                "other_kernels": ({"k_tick_finalize": {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
                 "per_request_equiv_GBps": TICK_BYTES(D) * live * K / secs / 1e9,
                 "per_request_equiv_frac": TICK_BYTES(D) * live * K / secs / 1e9 / HBM_PEAK_GBS}
     else:

@@ -64,11 +64,16 @@ struct Knobs {
     uint64_t arena_align = 0, arena_skew = 0;   // GGRS_ARENA_ALIGN / GGRS_ARENA_SKEW   placement of the first block inside the allocation
     uint64_t block_pad = 0, col_pad = 0;        // GGRS_BLOCK_PAD / GGRS_COL_PAD        extra bytes between ring blocks / behind the columns
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
-    bool arena_contig = false;     // GGRS_ARENA_CONTIG=1   hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous arena
+    int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena (hipExtMallocWithFlags + hipDeviceMallocContiguous);
+                                   //                       default (-1): contiguous for arenas up to 1.5 GiB, where it measured faster at every
+                                   //                       size tried (profiles/r02*: 23.2 vs 23.6 us at 10 k entities, 27.4 vs 29.5 at 100 k,
+                                   //                       111.8 vs 114.5 at 1 M, equal at 2 M) -- and slower beyond (594 vs 480 us at 4 M)
     bool tick2 = true;             // GGRS_TICK2=0          big worlds on the round-1 k_tick + k_tick_finalize pair instead of k_tick2
     int tick2_wgs_per_cu = 2;      // GGRS_TICK2_WGS=n      persistent workgroups per CU of k_tick2 (0: one workgroup per tile, not persistent)
     int tick2_nt = 1;              // GGRS_TICK2_NT=0|1     non-temporal snapshot stores in k_tick2
     int tick2_ilv = 0;             // GGRS_TICK2_ILV=0|1    Save = store burst + hash (0) or stores spaced out between the hash multiplies (1)
+    uint64_t tick2_min_slots = 500 * 1024;   // GGRS_TICK2_MIN_SLOTS  worlds covering more slots than this run on k_tick3 / k_tick2
+    int tick3 = 2;                 // GGRS_TICK3=0|1|2      wave-specialised k_tick3 (1: workgroup barrier per hand-off, 2: per-pair LDS flags); 0: k_tick2
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
@@ -83,11 +88,13 @@ struct Knobs {
         k.block_pad = (uint64_t)std::max<long long>(0, num("GGRS_BLOCK_PAD", 0));
         k.col_pad = (uint64_t)std::max<long long>(0, num("GGRS_COL_PAD", 0));
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
-        k.arena_contig = num("GGRS_ARENA_CONTIG", 0) != 0;
+        k.arena_contig = (int)std::min<long long>(1, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.tick2 = num("GGRS_TICK2", 1) != 0;
         k.tick2_wgs_per_cu = (int)std::min<long long>(8, std::max<long long>(0, num("GGRS_TICK2_WGS", 2)));
         k.tick2_nt = num("GGRS_TICK2_NT", 1) != 0;
         k.tick2_ilv = num("GGRS_TICK2_ILV", 0) != 0;
+        k.tick3 = (int)std::min<long long>(2, std::max<long long>(0, num("GGRS_TICK3", 2)));
+        k.tick2_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_TICK2_MIN_SLOTS", 500 * 1024));
         return k;
     }
 };
@@ -578,9 +585,11 @@ int seal_impl(ggrs_world* w) {
             std::vector<uint8_t*> batch;
             for (int k = 0; k < n_cand; ++k) {
                 uint8_t* pa = nullptr;
-                const hipError_t me = w->knobs.arena_contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous)
-                                                            : hipMalloc((void**)&pa, need + al + skew);
+                const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0 : (need + al + skew) <= (1536ull << 20);
+                hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous) : hipErrorUnknown;
+                if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need + al + skew); }   // no contiguous range free: plain pages
                 if (me != hipSuccess) { (void)hipGetLastError(); break; }
+                if (dbg) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes\n", contig ? "contiguous" : "paged", (unsigned long long)(need + al + skew));
                 batch.push_back(pa);
             }
             for (auto q : losers) (void)hipFree(q);
@@ -1215,6 +1224,14 @@ void launch_tick2(ggrs_world* w, const Tick2Args& a, uint32_t g) {
     else hipLaunchKernelGGL((k_tick2<false, false, NT, TICK2_RESTL, ILV>), dim3(g), dim3(TPB), lds, w->stream, a);
 }
 
+template <bool NT, int PS>
+void launch_tick3(ggrs_world* w, const Tick2Args& a, uint32_t g) {
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick3<false, false, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
+}
+
 // One SyncTest-shaped group -- Load, (Advance, Save) x D, live write -- on a candidate arena, straight through the
 // launcher, with the world's real layout and checksum configuration; average of 3 launches after a warm-up.
 int probe_arena_placement(ggrs_world* w, uint8_t* base, uint64_t tick_parts_off, float* us_out) {
@@ -1285,7 +1302,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         const uint32_t g = vec == 4 ? std::max(1u, tiles_for(cover)) : n_waves;
         a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
-        const bool use2 = vec == 4 && w->tick2_ok && !w->knobs.tick_vec;
+        const bool use2 = w->tick2_ok && !w->knobs.tick_vec && cover > w->knobs.tick2_min_slots;
         if (use2) {
             // persistent grid, in-kernel fold: ONE launch per group, the Checksum(u128)s land in the pinned result ring
             Tick2Args b = w->tick2_proto;
@@ -1301,7 +1318,9 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             if (b.n_ops || !b.src_is_live) {
                 ProfScope ps(w, GGRS_KERNEL_TICK);
                 const bool nt = w->nt_copy || w->knobs.tick2_nt;
-                if (w->knobs.tick2_ilv) { if (nt) launch_tick2<true, 1>(w, b, g2); else launch_tick2<false, 1>(w, b, g2); }
+                if (w->knobs.tick3 == 2) { if (nt) launch_tick3<true, 1>(w, b, g2); else launch_tick3<false, 1>(w, b, g2); }
+                else if (w->knobs.tick3) { if (nt) launch_tick3<true, 0>(w, b, g2); else launch_tick3<false, 0>(w, b, g2); }
+                else if (w->knobs.tick2_ilv) { if (nt) launch_tick2<true, 1>(w, b, g2); else launch_tick2<false, 1>(w, b, g2); }
                 else { if (nt) launch_tick2<true, 0>(w, b, g2); else launch_tick2<false, 0>(w, b, g2); }
             }
             HIPCHK(w, hipGetLastError());

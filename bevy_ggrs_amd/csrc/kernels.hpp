@@ -772,6 +772,16 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
 
 }
 
+// GGRS_LDS_BARRIER_DEFINED
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
+// snapshot store still in flight (1-2 us per Save); nobody in the workgroup reads those stores back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // vmcnt(63) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------ k_tick2 (persistent fused request group, round 2)
 // The same request-group fusion as k_tick, restructured after the round-2 store-path study (scripts/ubench3.hip,
 // profiles/r02a): on MI355X the HBM write path runs closest to its ceiling when FEW waves stream stores continuously
@@ -820,6 +830,60 @@ __device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_
 
 // 16-byte store whose cache policy the instruction scheduler can see (a compiler-generated store, unlike st16<true>'s
 // inline asm): used by the ILV variant, where sched_group_barrier spaces the stores out between the hash multiplies.
+// The checksum fold shared by k_tick2 / k_tick3: one row of partials per workgroup (relaxed agent-scope stores), one
+// agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
+// entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
+template <int NTHREADS>
+__device__ __forceinline__ void tick_fold(const Tick2Args& a, uint64_t* acc, uint32_t* s_last) {
+    if (a.n_saves == 0) return;
+    __syncthreads();                                              // the LDS atomics of every wave have landed
+    const uint32_t n_vals = a.n_saves * 3u;                       // <= 48
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < n_vals) st8_agent(a.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is in memory before the ticket is taken
+        if (threadIdx.x == 0) {
+            const uint32_t ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!*s_last) return;                                         // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  24 loads in flight per lane and trip.
+        const uint32_t n_flat = gridDim.x * n_vals;
+        constexpr int INFL = 24;
+        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += (uint32_t)INFL * NTHREADS) {
+            uint64_t v[INFL];
+#pragma unroll
+            for (int u = 0; u < INFL; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
+                v[u] = i < n_flat ? ld8_agent(a.wg_parts + i) : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < INFL; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
+                if (i >= n_flat) continue;
+                const uint32_t c = i % n_vals;
+                if ((c % 3u) == 2u) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.n_saves) {
+        const uint32_t k = threadIdx.x;
+        uint64_t total = 0;
+        if (a.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
+        if (a.cks_V) total ^= sea_one(acc[k * 3 + 1]);
+        total ^= sea_pair(acc[k * 3 + 2], a.len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        a.out[2 * (uint64_t)k] = total; a.out[2 * (uint64_t)k + 1] = 0;
+    }
+    if (threadIdx.x == 0) *a.ticket = 0;                          // ready for the next launch on this stream
+}
+
 __device__ __forceinline__ g_u8* sgpr_base_nv(const uint8_t* p) {      // sgpr_base without `volatile`: the statement may move
     uint64_t x = reinterpret_cast<uint64_t>(p);
     asm("" : "+s"(x));
@@ -1093,53 +1157,270 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
         }
     }
 
-    // ---- fold: one write-through row per workgroup, one ticket, the last workgroup finishes every Save's checksum
-    if (a.n_saves == 0) return;
-    __syncthreads();                                              // LDS atomics of all four waves have landed
-    const uint32_t n_vals = a.n_saves * 3u;                       // <= 48
-    if (threadIdx.x < 64) {
-        if (threadIdx.x < n_vals) st8_agent(a.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is in memory before the ticket is taken
-        if (threadIdx.x == 0) {
-            const uint32_t ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;                                          // workgroup-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    tick_fold<TPB>(a, acc, &s_last);
+}
+
+// ------------------------------------------------------------------ k_tick3 (wave-specialised fused request group)
+// k_tick2's remaining cost over the memory system's floor for this traffic (scripts/ubench3.hip: ~95-99 us of stores
+// with no ALU at all vs 112-118 us) is ISSUE COUPLING: a wave that is blocked issuing a store (the TA queue is full
+// 55 % of the time, SQ_WAIT_INST_ANY) cannot hash, and a wave that hashes does not feed the store queue.  So the two
+// jobs get their own waves.  A 512-thread workgroup owns one 1024-slot tile:
+//   * waves 0-3, COMPUTE: keep the 8 schedule-owned rows of their 256-slot quarter in registers, replay the ops, hash;
+//     at every Save they drop the 8 rows (+ the 4 rebuilt liveness words) into LDS and go on hashing / stepping;
+//   * waves 4-7, STORE: keep the 7 untouched rows of the same quarter in registers; per Save they pick the 8 rows up
+//     from LDS and stream all 15 rows (nt) + the mask words to the ring slot, blocking on the store queue as long as
+//     it takes -- nobody is waiting for them but the next barrier.
+// One LDS-only barrier per Save, LDS double-buffered (2 x 32 KiB): compute runs at most one Save ahead.  Two
+// workgroups per CU (64.5 KiB LDS, <= 128 VGPRs): while one workgroup's store waves wait at a barrier the other's keep
+// the queue fed.  ubench3 `fan_spec` (same structure, hash stand-in): 98.7-102.5 us vs 108.9-110.4 us for the uniform
+// kernel at the engine's occupancy.  Checksum fold: tick_fold (as k_tick2).
+// PAIRSYNC 0: one workgroup-wide LDS barrier per hand-off.  PAIRSYNC 1: every compute / store pair has its own two-slot
+// ring guarded by LDS flags -- no coupling between the four pairs of a workgroup, and a store wave frees its slot as
+// soon as the rows are in its registers, i.e. BEFORE it starts issuing the (blocking) global stores.
+template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int PAIRSYNC>
+__global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
+    __shared__ __attribute__((aligned(16))) u32x4 rowbuf[2][4][8][64];   // [parity][quarter][row][lane]: 64 KiB
+    __shared__ uint64_t maskbuf[2][4][4];                                  // the quarter's 4 liveness words per Save
+    __shared__ uint32_t full[4][2];                                        // PAIRSYNC: slot state of pair q (0 free, 1 filled)
+    __shared__ uint64_t acc[MAX_TICK_SAVES * 3];
+    __shared__ uint32_t s_last;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool store_role = wave8 >= 4u;                              // wave-uniform
+    const uint32_t wave = wave8 & 3u;                                 // the quarter both waves of a pair serve
     if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
+    if (threadIdx.x < 8) full[threadIdx.x >> 1][threadIdx.x & 1u] = 0;
     __syncthreads();
-    {
-        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  16 loads in flight per lane and trip.
-        const uint32_t n_flat = gridDim.x * n_vals;
-        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += 16u * TPB) {
-            uint64_t v[16];
+    // LDS-only flag traffic of a pair (LDS operations of one wave execute in issue order; the waits are lgkmcnt-only so
+    // that a store wave's global stores stay in flight)
+    auto flag_wait = [&](uint32_t q, uint32_t p, uint32_t want) {
+        for (;;) {
+            const uint32_t v = __hip_atomic_load(&full[q][p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v == want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto flag_set = [&](uint32_t q, uint32_t p, uint32_t v) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): this wave's LDS reads / writes of the slot are done
+        __hip_atomic_store(&full[q][p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    const uint32_t sh = (lane & 15u) * 4;
+    const uint32_t n_tiles = (a.n_units + 3u) >> 2;
+    uint32_t par = 0;                                                 // LDS buffer parity, advances with every hand-off
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t gw = t * 4u + wave;                            // 256-slot unit
+        const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
+        const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
+        const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;
+        const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);
+        const uint32_t o4 = tid * 16u;
+        const uint32_t o8a = wave * 2048u + lane * 16u, o8b = o8a + 1024u;   // contiguous Ttl halves (see k_tick2)
+        const uint32_t w0 = t * 16u + wave * 4u;
+        const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;
+
+        // both roles need the presence words (the store waves write them into every snapshot)
+        const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
+        const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
+        const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
+
+        if (store_role) {
+            // ================================================= STORE waves
+            u32x4 restv[RESTL > 0 ? RESTL : 1];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * TPB;
-                v[u] = i < n_flat ? ld8_agent(a.wg_parts + i) : 0ULL;
+            for (int j = 0; j < RESTL; ++j) {
+                restv[j] = u32x4{0, 0, 0, 0};
+                if (in_len) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
             }
+            if (lane < 4u * a.n_rest_masks) {                         // untouched presence masks: fan out (+ live on load)
+                const uint32_t m = lane >> 2, mw = lane & 3u;
+                const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
+                const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
+                for (uint32_t k = 0; k < a.n_saves; ++k)
+                    if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
+                if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // the loads have landed: the op loop stays free of vmcnt waits
+            auto put = [&](uint8_t* dst, bool snapshot, bool with_rest, bool with_presence, int32_t frame) {
+                // rows of this quarter: 8 from LDS, RESTL from registers
+                if (PAIRSYNC) flag_wait(wave, par, 1u);
+                u32x4 h[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * TPB;
-                if (i >= n_flat) continue;
-                const uint32_t c = i % n_vals;
-                if ((c % 3u) == 2u) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
-                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+                for (int r = 0; r < 8; ++r) h[r] = rowbuf[par][wave][r][lane];
+                const uint64_t mw = lane < 4 ? maskbuf[par][wave][lane] : 0ULL;
+                if (PAIRSYNC) flag_set(wave, par, 0u);                 // rows are in registers: the compute wave may refill the slot
+                if (in_len) {
+                    if (snapshot) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
+                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
+                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
+#pragma unroll
+                        for (int j = 0; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { st16<false>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<false>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
+                        st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
+                        st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
+                        if (with_rest) {
+#pragma unroll
+                            for (int j = 0; j < RESTL; ++j) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        }
+                    }
+                }
+                if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mw);
+                if (with_presence && (lane & 15u) == 0) {
+                    st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
+                    st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
+                    st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
+                }
+                if (snapshot && gw == 0 && lane == 0) {
+                    Header hd; hd.len = a.len; hd.frame = frame; hd.pad0 = 0; hd.active = 0; hd.checksum[0] = 0; hd.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = hd;
+                }
+            };
+            uint32_t si = 0;
+            for (uint32_t i = 0; i < a.n_ops; ++i) {
+                if ((a.op_bits >> i) & 1ULL) continue;                // Advance: nothing to store
+                uint8_t* dst = a.save_dst[si];
+                if (dst) { if (!PAIRSYNC) lds_barrier(); put(dst, true, true, true, a.save_frame[si]); par ^= 1u; }
+                ++si;
             }
+            if (!a.src_is_live || a.n_steps) { if (!PAIRSYNC) lds_barrier(); put(a.live, false, !a.src_is_live, !a.src_is_live, 0); par ^= 1u; }
+        } else {
+            // ================================================= COMPUTE waves
+            const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
+            float4 tx[3], vv[3];
+            ulonglong2 tl[2];
+            auto ld16 = [&](const uint8_t* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
+            if (in_len) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
+                { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8a); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
+                { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8b); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
+                tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
+            }
+            uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
+            const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu;
+            auto word_of = [&](uint64_t v, int k) -> uint64_t {
+                return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * k);
+            };
+            const uint32_t shL = 2u * (lane & 31u);
+            auto l_bits = [&](uint64_t v) -> uint32_t {
+                const uint64_t lo = lane < 32 ? word_of(v, 0) : word_of(v, 1), hi = lane < 32 ? word_of(v, 2) : word_of(v, 3);
+                return ((uint32_t)(lo >> shL) & 3u) | (((uint32_t)(hi >> shL) & 3u) << 2);
+            };
+            uint32_t aliveL = l_bits(alive_w);
+            const uint32_t presL = l_bits(pL_w);
+            uint64_t ordB[4];
+            if (CKS_T || CKS_V) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
+            }
+            auto chainT = [&](int j) -> uint64_t {
+                const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
+                                                                    __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
+                                                                    __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
+                return (((alive4 & n_T) >> j) & 1u) ? h : 0ULL;
+            };
+            auto chainV = [&](int j) -> uint64_t {
+                const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
+                                                                    __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
+                                                                    __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
+                return (((alive4 & n_V) >> j) & 1u) ? h : 0ULL;
+            };
+            // the quarter's rows + rebuilt liveness words -> LDS[par]; the barrier hands them to the paired store wave
+            auto hand_off = [&]() {
+                if (PAIRSYNC) flag_wait(wave, par, 0u);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { rowbuf[par][wave][k][lane] = reinterpret_cast<const u32x4&>(tx[k]); rowbuf[par][wave][3 + k][lane] = reinterpret_cast<const u32x4&>(vv[k]); }
+                rowbuf[par][wave][6][lane] = reinterpret_cast<const u32x4&>(tl[0]);
+                rowbuf[par][wave][7][lane] = reinterpret_cast<const u32x4&>(tl[1]);
+                const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
+                               b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
+                uint64_t mine = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
+                                        (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
+                    if (lane == (uint32_t)w) mine = nw;
+                }
+                if (lane < 4) maskbuf[par][wave][lane] = mine;
+                if (PAIRSYNC) flag_set(wave, par, 1u); else lds_barrier();
+                par ^= 1u;
+                return (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            };
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+
+            uint32_t si = 0, sj = 0;
+            for (uint32_t i = 0; i < a.n_ops; ++i) {
+                if (!((a.op_bits >> i) & 1ULL)) {
+                    // ---------------- SaveWorld: hand the rows to the store wave, then hash them
+                    uint32_t cnt;
+                    if (a.save_dst[si]) cnt = hand_off();
+                    else cnt = (uint32_t)(__popcll(__ballot((alive4 >> 0) & 1u)) + __popcll(__ballot((alive4 >> 1) & 1u)) +
+                                          __popcll(__ballot((alive4 >> 2) & 1u)) + __popcll(__ballot((alive4 >> 3) & 1u)));
+                    uint64_t hT = 0, hV = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (CKS_T) hT ^= chainT(j); if (CKS_V) hV ^= chainV(j); }
+                    if (CKS_T) hT = wave_xor(hT);
+                    if (CKS_V) hV = wave_xor(hV);
+                    if (lane == 0) {
+                        if (CKS_T) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 0]), (unsigned long long)hT);
+                        if (CKS_V) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 1]), (unsigned long long)hV);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 2]), (unsigned long long)cnt);
+                    }
+                    ++si;
+                } else {
+                    // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
+                    const float dt = __uint_as_float(a.dt_bits[sj]);
+                    ++sj;
+                    const uint32_t m_upd = alive4 & n_T & n_V;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float gd = __fmul_rn(a.g[k], dt);
+                        float* x = reinterpret_cast<float*>(&tx[k]);
+                        float* v = reinterpret_cast<float*>(&vv[k]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool on = (m_upd >> j) & 1u;
+                            const float nv = __fadd_rn(v[j], gd);
+                            const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));
+                            v[j] = on ? nv : v[j];
+                            x[j] = on ? nx : x[j];
+                        }
+                    }
+                    const uint32_t m_ttl = aliveL & presL;
+                    uint32_t killL = 0;
+                    uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = (m_ttl >> j) & 1u;
+                        const uint64_t nq = q[j] - 1;
+                        q[j] = on ? nq : q[j];
+                        killL |= (on && nq == 0) ? (1u << j) : 0u;
+                    }
+                    aliveL &= ~killL;
+                    const uint64_t k0 = __ballot((killL >> 0) & 1u), k1 = __ballot((killL >> 1) & 1u),
+                                   k2 = __ballot((killL >> 2) & 1u), k3 = __ballot((killL >> 3) & 1u);
+                    if ((k0 | k1 | k2 | k3) != 0) {
+                        const uint64_t ka = lane < 32 ? k0 : k2, kb = lane < 32 ? k1 : k3;
+                        const uint32_t pa = (uint32_t)(ka >> shL) & 3u, pb = (uint32_t)(kb >> shL) & 3u;
+                        alive4 &= ~((pa & 1u) | ((pb & 1u) << 1) | ((pa >> 1) << 2) | ((pb >> 1) << 3));
+                    }
+                }
+            }
+            if (!a.src_is_live || a.n_steps) (void)hand_off();        // the live block, written once (by the store wave)
         }
     }
-    __syncthreads();
-    if (threadIdx.x < a.n_saves) {
-        const uint32_t k = threadIdx.x;
-        uint64_t total = 0;
-        if (a.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
-        if (a.cks_V) total ^= sea_one(acc[k * 3 + 1]);
-        total ^= sea_pair(acc[k * 3 + 2], a.len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
-        a.out[2 * (uint64_t)k] = total; a.out[2 * (uint64_t)k + 1] = 0;
-    }
-    if (threadIdx.x == 0) *a.ticket = 0;                          // ready for the next launch on this stream
+    tick_fold<512>(a, acc, &s_last);
 }
 
 // ------------------------------------------------------------------ k_tick1 (one slot per lane)
@@ -1699,14 +1980,6 @@ struct GenArgs {
 };
 static_assert(sizeof(GenArgs) <= 4096, "kernel argument segment limit");
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
-// snapshot store still in flight (1-2 us per Save); nobody in the workgroup reads those stores back.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // vmcnt(63) expcnt(7) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

@@ -47,8 +47,9 @@ def main():
     roof = {}
     for k, d in out.items():
         if isinstance(d, dict) and "hbm_bytes_per_launch_corrected" in d:
-            if "k_tick<" in k or k.endswith("k_tick"):
+            if ("k_tick3<" in k or "k_tick2<" in k or "k_tick<" in k or k.endswith("k_tick")) and d.get("dispatches_FETCH_SIZE", 0) >= 20:
                 roof["k_tick_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+                roof["kernel"] = k
             if "k_copy_state" in k:
                 roof["k_copy_state_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
     if roof:

@@ -148,13 +148,20 @@ __global__ __launch_bounds__(512) void fan_spec(Fan a) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) h[c] = churn(h[c] + v[c].y, a.alu / 8);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c].z ^= (uint32_t)h[c];
+                for (int c = 0; c < 8; ++c) { v[c].z ^= (uint32_t)h[c]; if (a.rest_first) { v[c].x ^= (uint32_t)(h[c] >> 7); v[c].y ^= (uint32_t)(h[c] >> 13); v[c].w ^= (uint32_t)(h[c] >> 32); } }
             }
         }
         __syncthreads();
     }
 }
 
+__global__ void init_random(u32x4* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = i * 0x9E3779B97F4A7C15ULL + 12345; x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 29;
+        uint64_t y = x * 0x94D049BB133111EBULL; y ^= y >> 32;
+        p[i] = u32x4{(uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32)};
+    }
+}
 struct Dev { u32x4* ring; u32x4* live; size_t bs_v; int tiles; };
 
 template <class F> float time_us(int iters, F f) {
@@ -209,11 +216,11 @@ template <int K, int KL, int MINW> void run_fan(const Dev& d, int layout, int G,
     printf("%-100s %8.1f us  %6.2f TB/s\n", name, us, mb / us);
 }
 
-template <int K> void run_fan_spec(const Dev& d, int layout, int G, int grid, int alu) {
+template <int K> void run_fan_spec(const Dev& d, int layout, int G, int grid, int alu, int scramble = 0) {
     char name[160];
-    snprintf(name, sizeof name, "fan_spec %-6s layout=%d G=%-4d grid=%-5d alu=%-3d (512-thread WGs: 4 compute + 4 store waves)", kname(K), layout, G, grid, alu);
+    snprintf(name, sizeof name, "fan_spec %-6s layout=%d G=%-4d grid=%-5d alu=%-3d scramble=%d (4 compute + 4 store waves)", kname(K), layout, G, grid, alu, scramble);
     if (!want(name)) return;
-    Fan a; a.ring = d.ring; a.live = d.live; a.bs_v = d.bs_v; a.tiles = d.tiles; a.layout = layout; a.G = G; a.alu = alu; a.stagger = 0; a.rest_first = 0;
+    Fan a; a.ring = d.ring; a.live = d.live; a.bs_v = d.bs_v; a.tiles = d.tiles; a.layout = layout; a.G = G; a.alu = alu; a.stagger = 0; a.rest_first = scramble;
     float us = time_us(18, [&](int i) { Fan b = a; b.src_slot = i % 9; hipLaunchKernelGGL((fan_spec<K>), dim3(grid), dim3(512), 0, 0, b); });
     const double mb = (double)d.tiles * TILE_V * 16.0 * 10 / 1e6;
     printf("%-100s %8.1f us  %6.2f TB/s\n", name, us, mb / us);
@@ -230,6 +237,7 @@ int main(int argc, char** argv) {
     printf("ring at %p (%s)\n", (void*)d.ring, getenv("UB_CONTIG") ? "contiguous" : "hipMalloc");
     d.live = d.ring + 9 * d.bs_v;
     CK(hipMemset(d.ring, 1, bs * 10));
+    if (getenv("UB_RANDOM") && atoi(getenv("UB_RANDOM"))) { hipLaunchKernelGGL(init_random, dim3(4096), dim3(256), 0, 0, d.ring, (bs * 10) / 16); CK(hipDeviceSynchronize()); printf("ring initialised with random data\n"); }
     // reference points: hipMemset / hipMemcpy of one block
     {
         float us = time_us(10, [&](int) { CK(hipMemsetAsync(d.ring, 0, bs, 0)); });
@@ -279,6 +287,7 @@ int main(int argc, char** argv) {
     for (int alu : {0, 80, 160}) {
         for (int grid : {256, 512, 977}) {
             run_fan_spec<NT>(d, 2, 8, grid, alu);
+            run_fan_spec<NT>(d, 2, 8, grid, alu, 1);
             run_fan_spec<PLAIN>(d, 2, 8, grid, alu);
         }
         run_fan<NT, PLAIN, 1>(d, 2, 8, T, alu, 1, 52 * 1024);
