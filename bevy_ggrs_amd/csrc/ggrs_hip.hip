@@ -451,7 +451,7 @@ int seal_impl(ggrs_world* w) {
             b.off_ttl = t.off_ttl; b.rest_off = base; b.ts = t.ts;
             b.n_rest_rows = t.n_rest_rows; b.n_rest_masks = t.n_rest_masks;
             for (uint32_t m = 0; m < t.n_rest_masks; ++m) b.rest_mask_off[m] = t.rest_mask_off[m];
-            b.cks_T = w->f_cksT; b.cks_V = w->f_cksV;
+            b.fold.cks_T = w->f_cksT; b.fold.cks_V = w->f_cksV;
             w->tick2_ok = true;
         }
     }
@@ -556,7 +556,7 @@ int seal_impl(ggrs_world* w) {
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
-    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max(n_tiles, 1u) * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN;   // k_tick2 partial rows + its ticket
+    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max(n_tiles, 1u) * 4 * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN;   // one partial row per workgroup of the finest grid (256-slot k_tick1 workgroups) + the ticket
     const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
@@ -1311,8 +1311,8 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             memcpy(b.dt_bits, a.dt_bits, sizeof b.dt_bits);
             b.op_bits = a.op_bits; b.n_ops = a.n_ops; b.n_saves = a.n_saves; b.n_steps = a.n_steps; b.src_is_live = a.src_is_live;
             b.n_units = n_waves;
-            b.wg_parts = w->d_wg_parts; b.ticket = w->d_ticket;
-            b.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+            b.fold.wg_parts = w->d_wg_parts; b.fold.ticket = w->d_ticket;
+            b.fold.out = w->d_results + 2 * (uint64_t)(res_base + ns);
             const uint32_t tiles = std::max(1u, tiles_for(cover));
             const uint32_t g2 = w->knobs.tick2_wgs_per_cu > 0 ? std::min<uint32_t>(tiles, (uint32_t)(w->n_cu * w->knobs.tick2_wgs_per_cu)) : tiles;
             if (b.n_ops || !b.src_is_live) {
@@ -1514,7 +1514,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
                            align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
-    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * 4 * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;

@@ -440,6 +440,14 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
 // safe because every location is read by the lane that later writes it, and all reads of a
 // location precede its first write (pointers are deliberately not __restrict__).
 constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
+// In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
+// the last workgroup to arrive writes every Save's Checksum(u128).
+struct FoldArgs {
+    uint64_t* wg_parts;                    // [gridDim.x][n_saves * 3]: XOR T, XOR V, live count per Save
+    uint32_t* ticket;                      // arrival counter, zero between launches
+    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
+    uint32_t cks_T, cks_V;
+};
 struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; uint32_t word_bytes; uint32_t pad; };
 struct TickArgs {
     const uint8_t* src;                    // ring slot (group starts with LoadGameState) or live
@@ -454,7 +462,7 @@ struct TickArgs {
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
-    uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE
+    uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE (folded by k_tick_finalize)
     uint64_t rest_mask_off[MAX_MASKS];     // presence masks of components the schedule does not touch
     RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
 };
@@ -814,11 +822,9 @@ struct Tick2Args {
     uint32_t n_units, ts;                  // 256-slot units to walk (covers every dirty mask word); tile stride
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl, rest_off;
     float g[3];
-    uint32_t n_rest_rows, n_rest_masks, cks_T, cks_V, pad0;
+    uint32_t n_rest_rows, n_rest_masks;
     uint64_t rest_mask_off[MAX_MASKS];
-    uint64_t* wg_parts;                    // [gridDim.x][n_saves * 3]: XOR T, XOR V, live count per Save
-    uint32_t* ticket;                      // arrival counter, zero between launches
-    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
+    FoldArgs fold;
 };
 static_assert(sizeof(Tick2Args) <= 1024, "keep the kernel argument block small: it is re-sent every tick");
 
@@ -834,15 +840,15 @@ __device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_
 // agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
 // entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
 template <int NTHREADS>
-__device__ __forceinline__ void tick_fold(const Tick2Args& a, uint64_t* acc, uint32_t* s_last) {
-    if (a.n_saves == 0) return;
+__device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
+    if (n_saves == 0) return;
     __syncthreads();                                              // the LDS atomics of every wave have landed
-    const uint32_t n_vals = a.n_saves * 3u;                       // <= 48
+    const uint32_t n_vals = n_saves * 3u;                       // <= 48
     if (threadIdx.x < 64) {
-        if (threadIdx.x < n_vals) st8_agent(a.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
+        if (threadIdx.x < n_vals) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is in memory before the ticket is taken
         if (threadIdx.x == 0) {
-            const uint32_t ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
         }
     }
@@ -860,7 +866,7 @@ __device__ __forceinline__ void tick_fold(const Tick2Args& a, uint64_t* acc, uin
 #pragma unroll
             for (int u = 0; u < INFL; ++u) {
                 const uint32_t i = i0 + (uint32_t)u * NTHREADS;
-                v[u] = i < n_flat ? ld8_agent(a.wg_parts + i) : 0ULL;
+                v[u] = i < n_flat ? ld8_agent(f.wg_parts + i) : 0ULL;
             }
 #pragma unroll
             for (int u = 0; u < INFL; ++u) {
@@ -873,15 +879,15 @@ __device__ __forceinline__ void tick_fold(const Tick2Args& a, uint64_t* acc, uin
         }
     }
     __syncthreads();
-    if (threadIdx.x < a.n_saves) {
+    if (threadIdx.x < n_saves) {
         const uint32_t k = threadIdx.x;
         uint64_t total = 0;
-        if (a.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
-        if (a.cks_V) total ^= sea_one(acc[k * 3 + 1]);
-        total ^= sea_pair(acc[k * 3 + 2], a.len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
-        a.out[2 * (uint64_t)k] = total; a.out[2 * (uint64_t)k + 1] = 0;
+        if (f.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
+        if (f.cks_V) total ^= sea_one(acc[k * 3 + 1]);
+        total ^= sea_pair(acc[k * 3 + 2], total_len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
     }
-    if (threadIdx.x == 0) *a.ticket = 0;                          // ready for the next launch on this stream
+    if (threadIdx.x == 0) *f.ticket = 0;                          // ready for the next launch on this stream
 }
 
 __device__ __forceinline__ g_u8* sgpr_base_nv(const uint8_t* p) {      // sgpr_base without `volatile`: the statement may move
@@ -1157,7 +1163,7 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
         }
     }
 
-    tick_fold<TPB>(a, acc, &s_last);
+    tick_fold<TPB>(a.fold, a.n_saves, a.len, acc, &s_last);
 }
 
 // ------------------------------------------------------------------ k_tick3 (wave-specialised fused request group)
@@ -1420,7 +1426,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
             if (!a.src_is_live || a.n_steps) (void)hand_off();        // the live block, written once (by the store wave)
         }
     }
-    tick_fold<512>(a, acc, &s_last);
+    tick_fold<512>(a.fold, a.n_saves, a.len, acc, &s_last);
 }
 
 // ------------------------------------------------------------------ k_tick1 (one slot per lane)
@@ -1552,6 +1558,8 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 hV = wave_xor((alive && has_V) ? h : 0ULL);
             }
             if (lane == 0) {
+                // per-wave partials, folded by k_tick_finalize: an in-kernel fold (tick_fold) LOSES at these sizes -- there is no
+                // long store drain to hide its ticket + acquire + gather behind (10 k: 25.5 vs 23.5 us, 300 k: 59 vs 47 us per tick)
                 uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
                 p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = (uint64_t)__popcll(alive_now);
             }
