@@ -72,3 +72,39 @@ def test_rust_ffi_declares_every_header_symbol():
     for const in re.findall(r"#define (GGRS_(?:E|REQ|SYS|WORLD|COMP|DESPAWN)_[A-Z0-9_]+|GGRS_OK|GGRS_HIP_ABI_VERSION)\s+(-?\d+)u?", hdr):
         m = re.search(r"pub const %s: \w+ = (-?\d+);" % const[0], rs)
         assert m and int(m.group(1)) == int(const[1]), const
+
+
+def test_rust_shim_uses_only_declared_symbols_and_owns_the_session_driver():
+    """rust/bevy_ggrs_hip/src/lib.rs (un-built source) must (a) use only `ffi::` items that ffi.rs declares and the
+    header exports, (b) install its OWN session-driving system -- the stock bevy_ggrs plugin would call the stock
+    CPU handle_requests (/root/reference/src/schedule_systems.rs:98,123,156) and never drive the device world --,
+    (c) mirror the no-session reset (schedule_systems.rs:70-78) on the device, (d) collect an enqueued batch's
+    checksums BEFORE the next advance_frame() (SyncTest compares there), (e) hand spawn payloads and the Spectator
+    confirmed-frame rule through."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = open(os.path.join(root, "rust", "bevy_ggrs_hip", "src", "lib.rs")).read()
+    rs = open(os.path.join(root, "rust", "bevy_ggrs_hip", "src", "ffi.rs")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "ggrs_hip.h")).read(), flags=re.S)
+    code = re.sub(r"//[^\n]*", "", lib)                                   # strip comments: prose may mention anything
+    used_fns = set(re.findall(r"ffi::(ggrs_hip_[a-z0-9_]+)", code))
+    used_consts = set(re.findall(r"ffi::(GGRS_[A-Z0-9_]+)", code))
+    assert len(used_fns) >= 18, used_fns
+    for f in used_fns:
+        assert re.search(r"pub fn %s\(" % f, rs), f"{f} used by lib.rs but not declared in ffi.rs"
+        assert re.search(r"\b%s\s*\(" % f, hdr), f"{f} used by lib.rs but not declared in ggrs_hip.h"
+    for c in used_consts:
+        assert re.search(r"pub const %s:" % c, rs), f"{c} used by lib.rs but not declared in ffi.rs"
+    # (b) own driver, stock plugin NOT added
+    assert "add_plugins(bevy_ggrs::GgrsPlugin" not in code
+    assert re.search(r"add_systems\(PreUpdate,\s*\(drive_session::<C>", code)
+    drive = code[code.index("pub fn drive_session"):code.index("pub fn handle_requests")]
+    assert "handle_requests::<C>(reqs, world)" in drive
+    # (c) no-session reset reaches the device
+    assert "ggrs_hip_set_frame(hip.raw, 0)" in drive and "ggrs_hip_set_confirmed(hip.raw, 1, -1)" in drive and "ggrs_hip_set_depth(hip.raw, 8)" in drive
+    # (d) collect precedes the step (advance_frame) inside the loop
+    loop = drive[drive.index("while pacer.take_step(fps)"):]
+    assert loop.index("collect_in_flight(world)") < loop.index("step_session::<C>")
+    # (e) spawn payloads + spectator rule
+    hr = code[code.index("pub fn handle_requests"):]
+    assert "q.spawn_vx = vx.as_ptr()" in hr and "Kind::Spectator" in hr and "ggrs_hip_set_synctest_check_distance(raw, 0)" in hr
