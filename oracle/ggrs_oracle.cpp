@@ -18,6 +18,12 @@
 //   * ggrs SyncTest request order and absolute checksum values: PARITY UNPINNED
 //     by reference-supplied vectors (ggrs is an un-vendored git dependency,
 //     Cargo.toml:23); restated from its published algorithm.
+//   * The WHOLE tick (save / load / entity reconcile / ring / deferred despawn /
+//     systems / checksums) is cross-checked bit for bit against an
+//     independently written second restatement, oracle/twin_np.py (numpy,
+//     dict-of-RollbackId snapshots, deque ring), on BASELINE configs 1-4:
+//     tests/test_twin_oracle.py.  That is agreement of two restatements, not a
+//     reference-produced vector: parity stays "unpinned by the reference".
 //
 // Two storage back-ends with identical observable behaviour:
 //   mode 0 FLAT      : SoA columns + memcpy ring (best-case CPU layout)

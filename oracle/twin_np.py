@@ -1,0 +1,387 @@
+"""TwinWorld -- a SECOND, independently written CPU restatement of the whole hot path -- TEST INFRASTRUCTURE.
+
+oracle/ggrs_oracle.cpp is the checker the HIP path is compared with; the reference holds no absolute checksum or f32
+vector that could pin it, so it is cross-checked end to end by this twin instead: a different
+author's-eye restatement, written from the reference's files (not from the C++ oracle), in a different language
+(numpy), with a different storage shape -- per-entity Python-dict snapshots keyed by RollbackId like the reference's
+`GgrsComponentSnapshot` (src/snapshot/mod.rs:277-315), a `collections.deque` ring like `GgrsSnapshots`
+(mod.rs:97-274), entity reconcile by set algebra over RollbackIds like `EntitySnapshotPlugin::load`
+(src/snapshot/entity.rs:55-99).  tests/test_twin_oracle.py drives both through the same request lists on BASELINE
+configs 1-4 and requires identical checksums, masks and columns.
+
+Only tests/ may import this module (tests/test_abi.py enforces that the product package does not).
+
+Reference items restated (paths relative to /root/reference):
+  ring                 src/snapshot/mod.rs:147-243 (push / confirm / rollback / peek, wrap-aware comparison)
+  save / load          src/snapshot/component_snapshot.rs:66-123, src/snapshot/entity.rs:39-99
+  identity / order     src/snapshot/rollback.rs:45-99 (RollbackOrdered: index = insertion order, restored on load)
+  checksums            src/snapshot/component_checksum.rs:67-108, entity_checksum.rs:29-52, checksum.rs:88-99
+  deferred despawn     src/snapshot/despawn.rs:69-143
+  frame counters       src/schedule_systems.rs:223-268
+  time                 src/time.rs:63-87
+  game logic           examples/stress_tests/particles.rs:254-289, examples/box_game/box_game.rs:154-206,
+                       tests/synctest.rs:37-44 (decrease_health), benches/bench.rs:30-46 (increment)
+"""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+
+from bevy_ggrs_amd.requests import AdvanceFrame, LoadGameState, SaveGameState
+from oracle import oracle_np as onp
+
+SYS_PARTICLES_UPDATE, SYS_TTL_DESPAWN, SYS_PARTICLES_SPAWN, SYS_ADD_U32, SYS_SAT_SUB_DESPAWN, SYS_BOX_MOVE = 1, 2, 3, 4, 5, 6
+
+
+class TwinError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class _Ring:
+    """GgrsSnapshots<_, _> (mod.rs:97-274): newest snapshot at the FRONT."""
+
+    def __init__(self, depth=60):
+        self.depth = depth
+        self.q = collections.deque()           # (frame, snapshot)
+
+    def push(self, frame, snap):               # mod.rs:147-181
+        while self.q:
+            cur = self.q[0][0]
+            wrapped = abs(cur - frame) > (0xFFFFFFFF // 2)       # abs_diff over i32 values as u32 distance
+            if (cur >= frame and not wrapped) or (frame >= cur and wrapped):
+                self.q.popleft()
+            else:
+                break
+        self.q.appendleft((frame, snap))
+        while len(self.q) > self.depth:
+            self.q.pop()
+
+    def confirm(self, confirmed):              # mod.rs:185-202
+        while self.q and self.q[-1][0] < confirmed:
+            self.q.pop()
+
+    def rollback(self, frame):                 # mod.rs:210-226
+        while True:
+            if not self.q:
+                return None
+            if self.q[0][0] == frame:
+                return self.q[0][1]
+            self.q.popleft()
+
+
+class TwinWorld:
+    _prefix = "twin_"                          # tests/common.py: the SyncTest confirmed rule is applied by the driver
+
+    def __init__(self, capacity, max_depth=8):
+        self.capacity = capacity
+        self._comps = []                       # (name, word_bytes, n_words) -- the surface tests/common.py reads
+        self._rb = []                          # registered for rollback?
+        self._defaults = []
+        self._cks = {}                         # comp -> hashed word indices
+        self._systems = []
+        self._cols = {}                        # (comp, word) -> array[capacity]
+        self._present = []                     # per comp: bool[capacity]
+        self._alive = np.zeros(capacity, bool)
+        self._disabled = np.zeros(capacity, bool)       # RollbackDespawned marker (despawn.rs:45-46)
+        self._dframe = np.zeros(capacity, np.int32)
+        self._len = 0                          # RollbackOrdered::len (ids are 0..len-1 in insertion order)
+        self.frame = 0
+        self._confirmed = 0                    # init_resource::<ConfirmedFrameCount>() (mod.rs:336)
+        self._has_confirmed = True
+        self._dc_local = 0                     # Local<ConfirmedFrameCount> of despawn_confirmed_entities
+        self._ring = _Ring(max_depth if max_depth else 60)
+        self._fps = 60
+        self._sealed = False
+
+    # ------------------------------------------------------------------ registration
+    def register_component(self, name, word_bytes, n_words, rollback=True):
+        if self._sealed:
+            raise TwinError(-1, "registration after the first spawn/save")
+        cid = len(self._comps)
+        self._comps.append((name, word_bytes, n_words))
+        self._rb.append(rollback)
+        dt = np.uint32 if word_bytes == 4 else np.uint64
+        for k in range(n_words):
+            self._cols[(cid, k)] = np.zeros(self.capacity, dt)
+        self._present.append(np.zeros(self.capacity, bool))
+        self._defaults.append(np.zeros(n_words, dt))
+        return cid
+
+    def set_component_default(self, comp, words):
+        _, wb, nw = self._comps[comp]
+        self._defaults[comp] = np.ascontiguousarray(words).view(np.uint32 if wb == 4 else np.uint64)[:nw].copy()
+
+    def checksum_component(self, comp, word_idx):
+        self._cks[comp] = list(word_idx)
+
+    def add_system(self, kind, comp=(), word=(), iparam=(), fparam=()):
+        self._systems.append(dict(kind=kind, comp=tuple(comp) + (0,) * (4 - len(comp)), word=tuple(word) + (0,) * (4 - len(word)),
+                                  iparam=tuple(iparam) + (0,) * (2 - len(iparam)), fparam=tuple(fparam) + (0.0,) * (4 - len(fparam))))
+
+    def set_frame_rate(self, fps):
+        self._fps = fps
+
+    def set_synctest_check_distance(self, cd):
+        self._cd = cd
+
+    # ------------------------------------------------------------------ entities
+    @property
+    def len(self):
+        return self._len
+
+    def spawn(self, count, comps):
+        """commands.spawn((bundle, Rollback)) x count: Rollback on_add pushes the new id to RollbackOrdered (rollback.rs:45-59)."""
+        self._sealed = True
+        if self._len + count > self.capacity:
+            raise TwinError(-3, "capacity")
+        first = self._len
+        sl = slice(first, first + count)
+        for cid, (_, _, nw) in enumerate(self._comps):
+            has = cid in comps
+            self._present[cid][sl] = has
+            cols = comps.get(cid) if has else None
+            for k in range(nw):
+                src = None if cols is None else cols[k]
+                self._cols[(cid, k)][sl] = self._defaults[cid][k] if src is None else np.asarray(src).view(self._cols[(cid, k)].dtype)
+        self._alive[sl] = True
+        self._disabled[sl] = False
+        self._len += count
+        return first
+
+    def despawn(self, slot):
+        self._alive[slot] = False
+
+    def despawn_rollback(self, slot):                       # despawn.rs:114-143
+        if not self._alive[slot]:
+            return
+        self._alive[slot] = False
+        if self._confirmed < self.frame:
+            self._disabled[slot] = True
+            self._dframe[slot] = self.frame
+
+    def insert_component(self, comp, slot, words):
+        _, wb, nw = self._comps[comp]
+        w = np.ascontiguousarray(words).view(np.uint32 if wb == 4 else np.uint64)
+        for k in range(nw):
+            self._cols[(comp, k)][slot] = w[k]
+        self._present[comp][slot] = True
+
+    def remove_component(self, comp, slot):
+        self._present[comp][slot] = False
+
+    def upload_word(self, comp, word, first, data):
+        self._cols[(comp, word)][first:first + len(data)] = np.asarray(data).view(self._cols[(comp, word)].dtype)
+
+    def download_word(self, comp, word, first=0, count=None):
+        if count is None:
+            count = self._len - first
+        return self._cols[(comp, word)][first:first + count].copy()
+
+    def alive_mask(self, n=None):
+        return self._alive[: self._len if n is None else n].copy()
+
+    def present_mask(self, comp, n=None):
+        n = self._len if n is None else n
+        p = self._present[comp][:n].copy()
+        if not self._rb[comp]:                               # a non-rollback component dies with its entity
+            p &= self._alive[:n] | self._disabled[:n]
+        return p
+
+    def disabled_mask(self, n=None):
+        return self._disabled[: self._len if n is None else n].copy()
+
+    def despawned_frames(self, first=0, count=None):
+        if count is None:
+            count = self._len - first
+        return self._dframe[first:first + count].copy()
+
+    def active_count(self):
+        return int(self._alive[: self._len].sum())
+
+    # ------------------------------------------------------------------ counters / ring
+    def set_frame(self, f):
+        self.frame = f
+
+    def set_depth(self, d):
+        self._ring.depth = d
+
+    def set_confirmed(self, frame):
+        self._has_confirmed = frame is not None
+        self._confirmed = 0 if frame is None else frame
+
+    def has_snapshot(self, frame):
+        return any(f == frame for f, _ in self._ring.q)
+
+    def snapshot_count(self):
+        return len(self._ring.q)
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------ SaveWorld
+    def _component_checksum(self, comp):
+        """ComponentChecksumPlugin::update (component_checksum.rs:67-108): per live entity with the component,
+        hash(order, custom_hasher(component)), XOR-folded; then hashed once more."""
+        _, wb, _ = self._comps[comp]
+        sel = np.nonzero(self._alive[: self._len] & self._present[comp][: self._len])[0]
+        units = []
+        for k in self._cks[comp]:
+            col = self._cols[(comp, k)][sel]
+            if wb == 4:
+                units.append(col.astype(np.uint32))
+            else:                                            # a u64 field is written as 8 little-endian bytes
+                units.append((col & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+                units.append((col >> np.uint64(32)).astype(np.uint32))
+        return onp.np_component_checksum(sel.astype(np.uint64), units)
+
+    def save(self):
+        self._sealed = True
+        total = 0
+        for comp in sorted(self._cks):
+            total ^= self._component_checksum(comp)
+        total ^= onp.entity_checksum(self.active_count(), self._len)          # entity_checksum.rs:29-52
+        # Snapshot set: discard_old_snapshots, then one {RollbackId: value} map per registered component + the entity
+        # map + a clone of RollbackOrdered (here: its length) -- component_snapshot.rs:66-84, entity.rs:39-51, mod.rs:342
+        if self._has_confirmed:
+            self._ring.confirm(self._confirmed)
+        ids = np.nonzero(self._alive[: self._len])[0]
+        snap = {"ordered_len": self._len, "entities": ids.copy(), "comps": {}}
+        for cid, (_, _, nw) in enumerate(self._comps):
+            if not self._rb[cid]:
+                continue
+            have = ids[self._present[cid][ids]]
+            snap["comps"][cid] = (have.copy(), [self._cols[(cid, k)][have].copy() for k in range(nw)])
+        self._ring.push(self.frame, snap)
+        return total                                         # `as u128` of a u64: the upper half is 0
+
+    # ------------------------------------------------------------------ LoadWorld
+    def load(self, frame):
+        self.frame = frame                                   # schedule_systems.rs:244-247
+        snap = self._ring.rollback(frame)
+        if snap is None:
+            raise TwinError(-2, f"Could not rollback to {frame}: no snapshot at that moment could be found.")
+        n_now = self._len
+        # LoadWorldSystems::EntityResurrect (despawn.rs:69-87): markers newer than the loaded frame go away
+        res = self._disabled[:n_now] & (self._dframe[:n_now] > frame)
+        self._disabled[:n_now][res] = False
+        self._alive[:n_now][res] = True
+        # EntitySnapshotPlugin::load (entity.rs:55-99): ids only live now are despawned, ids only in the snapshot are
+        # re-created as FRESH entities with the old RollbackId (they come back without non-rollback components),
+        # ids in both keep their entity
+        hi = max(n_now, snap["ordered_len"])
+        in_snap = np.zeros(hi, bool)
+        in_snap[snap["entities"]] = True
+        live = np.zeros(hi, bool)
+        live[:n_now] = self._alive[:n_now]
+        survives = live & in_snap
+        keep_nr = survives.copy()
+        keep_nr[:n_now] |= self._disabled[:n_now]            # a disabled entity still exists, with all its components
+        for cid in range(len(self._comps)):
+            if not self._rb[cid]:
+                self._present[cid][:hi] &= keep_nr
+        self._alive[:hi] = in_snap
+        # ComponentSnapshotPlugin::load (component_snapshot.rs:95-123): present in snapshot -> update / insert,
+        # absent -> remove
+        for cid, (have, cols) in snap["comps"].items():
+            self._present[cid][:hi] = False
+            self._present[cid][have] = True
+            for k, vals in enumerate(cols):
+                self._cols[(cid, k)][have] = vals
+        self._len = snap["ordered_len"]                      # RollbackOrdered restored by its own snapshot (mod.rs:342)
+        self._alive[self._len:hi] = False
+        for cid in range(len(self._comps)):
+            if self._rb[cid]:
+                self._present[cid][self._len:hi] = False
+
+    # ------------------------------------------------------------------ AdvanceWorld
+    def advance(self, inputs=(), dt_bits=0, spawn_vx=None, spawn_vy=None):
+        self.frame += 1                                      # schedule_systems.rs:254-259
+        if dt_bits == 0:
+            dt_bits = onp.dt_bits(self._fps, self.frame)     # GgrsTimePlugin::update, time.rs:63-87
+        n = self._len
+        # AdvanceWorldSystems::DespawnConfirmed (despawn.rs:89-112)
+        if self._confirmed != self._dc_local:
+            self._dc_local = self._confirmed
+            gone = self._disabled[:n] & (self._dframe[:n] <= self._confirmed)
+            self._disabled[:n][gone] = False
+        inputs = bytes(inputs)
+        dt = np.array([dt_bits], np.uint32).view(np.float32)[0]
+        for s in self._systems:
+            kind, comp, word = s["kind"], s["comp"], s["word"]
+            alive = self._alive[:n]
+            if kind == SYS_PARTICLES_UPDATE:                 # particles.rs:272-280
+                m = alive & self._present[comp[0]][:n] & self._present[comp[1]][:n]
+                for k in range(3):
+                    t = self._cols[(comp[0], word[0] + k)][:n].view(np.float32)
+                    v = self._cols[(comp[1], word[1] + k)][:n].view(np.float32)
+                    nv = v + np.float32(s["fparam"][k]) * dt
+                    nt = t + nv * dt
+                    v[m] = nv[m]
+                    t[m] = nt[m]
+            elif kind == SYS_TTL_DESPAWN:                    # particles.rs:282-289
+                m = alive & self._present[comp[0]][:n]
+                ttl = self._cols[(comp[0], word[0])][:n]
+                with np.errstate(over="ignore"):
+                    ttl[m] = ttl[m] - np.uint64(1)
+                kill = m & (ttl == 0)
+                self._alive[:n][kill] = False
+            elif kind == SYS_ADD_U32:                        # benches/bench.rs:30-46
+                m = alive & self._present[comp[0]][:n]
+                col = self._cols[(comp[0], word[0])][:n]
+                with np.errstate(over="ignore"):
+                    col[m] = col[m] + np.uint32(s["iparam"][0] & 0xFFFFFFFF)
+            elif kind == SYS_SAT_SUB_DESPAWN:                # tests/synctest.rs:37-44
+                m = alive & self._present[comp[0]][:n]
+                col = self._cols[(comp[0], word[0])][:n]
+                amt = np.uint32(s["iparam"][0])
+                col[m] = np.where(col[m] >= amt, col[m] - amt, 0).astype(np.uint32)
+                kill = m & (col == 0)
+                self._alive[:n][kill] = False
+                if s["iparam"][1] == 1 and self._confirmed < self.frame:     # despawn_rollback on an unconfirmed frame
+                    self._disabled[:n][kill] = True
+                    self._dframe[:n][kill] = self.frame
+            elif kind == SYS_BOX_MOVE:                       # box_game.rs:154-206
+                m = alive & self._present[comp[0]][:n] & self._present[comp[1]][:n] & self._present[comp[2]][:n]
+                handle = self._cols[(comp[2], word[2])][:n]
+                m &= handle < len(inputs)
+                idx = np.nonzero(m)[0]
+                if len(idx):
+                    t = np.stack([self._cols[(comp[0], word[0] + k)][idx].view(np.float32) for k in range(3)], axis=1)
+                    v = np.stack([self._cols[(comp[1], word[1] + k)][idx].view(np.float32) for k in range(3)], axis=1)
+                    inp = np.frombuffer(inputs, np.uint8)[handle[idx].astype(np.int64)]
+                    f = s["fparam"]
+                    nt, nv = onp.box_move(t, v, inp, dt_bits, accel=f[0], max_speed=f[1], friction=f[2], half_width=f[3])
+                    for k in range(3):
+                        self._cols[(comp[0], word[0] + k)][idx] = nt[:, k].view(np.uint32)
+                        self._cols[(comp[1], word[1] + k)][idx] = nv[:, k].view(np.uint32)
+        # Commands flush: spawns materialise after every system ran (set.rs:118-134)
+        for s in self._systems:
+            if s["kind"] != SYS_PARTICLES_SPAWN:
+                continue
+            pressed = any(b & (s["iparam"][1] & 0xFF) for b in inputs)       # spawn_pressed, particles.rs:254-256
+            if not pressed or spawn_vx is None or len(spawn_vx) == 0:
+                continue
+            cT, cV, cL = s["comp"][:3]
+            cnt = len(spawn_vx)
+            first = self.spawn(cnt, {cT: None, cV: None, cL: None})
+            self._cols[(cV, 0)][first:first + cnt] = np.asarray(spawn_vx, np.float32).view(np.uint32)
+            self._cols[(cV, 1)][first:first + cnt] = np.asarray(spawn_vy, np.float32).view(np.uint32)
+            self._cols[(cV, 2)][first:first + cnt] = 0
+            self._cols[(cL, 0)][first:first + cnt] = np.uint64(s["iparam"][0])
+
+    # ------------------------------------------------------------------ handle_requests
+    def handle_requests(self, requests):
+        out = []
+        for r in requests:
+            if isinstance(r, SaveGameState):
+                out.append(self.save())
+            elif isinstance(r, LoadGameState):
+                self.load(r.frame)
+            elif isinstance(r, AdvanceFrame):
+                self.advance(r.inputs, r.dt_bits, r.spawn_vx, r.spawn_vy)
+            else:
+                raise TypeError(r)
+        return out
