@@ -23,8 +23,9 @@ flight (a shim collects right before the next advance_frame()); `--sync` blocks 
 N > 1 (one process per GPU, launched by torch.distributed.run): speculative fan-out -- rank 0's
 confirmed snapshot is broadcast ONCE over RCCL/xGMI; per step every rank runs ONE request list of the
 same shape as the N = 1 tick (1 load + D saves + D+1 advances: the confirmed input for frame C, then its
-own predicted-input branch for the following frames), two steps in flight, and ONE all-gather of the checksums
-per desync-detection interval (10 steps, the reference stress_test's default) on a side stream (bevy_ggrs_amd/fanout.py).  Weak scaling (per-GPU work fixed).
+own predicted-input branch for the following frames), two steps in flight, and ONE ncclAllGather of the checksums per
+desync-detection interval (10 steps, the reference stress_test's default) on a side stream -- broadcast and all-gather are issued inside libggrs_hip.so (ggrs_hip_fanout_*); torch.distributed only
+carries the ncclUniqueId and the timing barrier.  Weak scaling (per-GPU work fixed).
 `--fanout` forces this code path at world size 1 (validation on a 1-GPU box).
 """
 from __future__ import annotations
@@ -252,19 +253,21 @@ def main():
         w.profile_enable(False)
         total_entities = live
     else:
-        from bevy_ggrs_amd.fanout import HipStateExchange, SpeculativeFanout, make_torch_world
-        # every rank provisions the same world shape; only rank 0 owns the confirmed world, the
-        # others receive it through ONE RCCL broadcast of the packed state block
-        tdev = torch.device("cuda", dev)
-        w, arena = make_torch_world(bg, n, D + 2, 3, BYTES_PER_ENTITY, tdev, flags=flags)
+        from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+        # every rank provisions the same world shape; only rank 0 owns the confirmed world, the others receive it through
+        # ONE ncclBroadcast of the packed state block.  The collectives are issued INSIDE libggrs_hip.so
+        # (ggrs_hip_fanout_*, RCCL dlopen'ed there); torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier.
+        w = bg.World(n, max_depth=D + 2, device=dev, stream=stream, flags=flags)
         ids = cm.build_particles(w)
         if rank == 0:
             vel, ttl = cm.synthetic_particles(n, ttl="throughput")
             cm.spawn_particles(w, ids, n, vel, ttl)
         else:
             w.spawn(0, {})                                   # seals the world (layout fixed)
-        fan = SpeculativeFanout(w, dist, depth=D, exchange=HipStateExchange(w, arena),
-                                branches_per_rank=1, max_inflight=2,
+        box = [RcclFanout.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        native = RcclFanout(w, rank, world_size, box[0])
+        fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=1, max_inflight=2,
                                 desync_detection_interval=10)   # the reference stress_test's default (particles.rs:49, README.md:84)
         fan.sync_confirmed(0)
         for _ in range(W):
@@ -361,7 +364,7 @@ def main():
         "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (RCCL broadcast of the confirmed snapshot once; one checksum all-gather per 10 steps = the reference's --desync-detection-interval default)",
+                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,

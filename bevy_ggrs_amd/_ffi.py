@@ -35,6 +35,8 @@ DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK = 0, 1
 
 REQ_SAVE, REQ_LOAD, REQ_ADVANCE = 1, 2, 3
 
+FANOUT_ID_BYTES = 128
+
 KERNEL_SAVE, KERNEL_LOAD, KERNEL_ADVANCE, KERNEL_CHECKSUM, KERNEL_TICK, KERNEL_CLASSES = 0, 1, 2, 3, 4, 5
 
 
@@ -104,6 +106,14 @@ SIGNATURES = {
     "ggrs_hip_state_bytes": (C.c_uint64, [_P]),
     "ggrs_hip_live_state_ptr": (C.c_int, [_P, C.POINTER(_P)]),
     "ggrs_hip_adopt_live_state": (C.c_int, [_P]),
+    "ggrs_hip_fanout_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "ggrs_hip_fanout_init": (C.c_int, [_P, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(_P)]),
+    "ggrs_hip_fanout_sync_confirmed": (C.c_int, [_P, C.c_int]),
+    "ggrs_hip_fanout_step": (C.c_int, [_P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ggrs_hip_fanout_set_interval": (C.c_int, [_P, C.c_uint32]),
+    "ggrs_hip_fanout_collect": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ggrs_hip_fanout_destroy": (None, [_P]),
+    "ggrs_hip_fanout_last_error": (C.c_char_p, [_P]),
     "ggrs_hip_profile_enable": (C.c_int, [_P, C.c_int]),
     "ggrs_hip_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 }

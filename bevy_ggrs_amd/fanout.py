@@ -103,6 +103,73 @@ class HipStateExchange:
         return self.all_gather_u64_finish(self.all_gather_u64_start(dist, values))
 
 
+class RcclFanout:
+    """The C ABI's fan-out entry points (include/ggrs_hip.h `ggrs_hip_fanout_*`): RCCL is called INSIDE libggrs_hip.so
+    (ncclBroadcast of the packed live block, ncclAllGather of a step's checksums on a side stream); the host only
+    carries the 128-byte ncclUniqueId from rank 0 to the other ranks."""
+
+    def __init__(self, world, rank: int, world_size: int, unique_id: bytes):
+        import ctypes as C
+        from . import _ffi
+        assert len(unique_id) == _ffi.FANOUT_ID_BYTES
+        self._lib, self.world, self.rank, self.size = _ffi.lib, world, rank, world_size
+        idb = (C.c_uint8 * _ffi.FANOUT_ID_BYTES).from_buffer_copy(unique_id)
+        p = C.c_void_p()
+        rc = self._lib.ggrs_hip_fanout_init(world._p, idb, rank, world_size, C.byref(p))
+        if rc != 0:
+            raise _ffi.GgrsHipError(rc, (self._lib.ggrs_hip_last_error(world._p) or b"").decode())
+        self._p = p
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _ffi
+        buf = (C.c_uint8 * _ffi.FANOUT_ID_BYTES)()
+        rc = _ffi.lib.ggrs_hip_fanout_unique_id(buf)
+        if rc != 0:
+            raise _ffi.GgrsHipError(rc, "ncclGetUniqueId failed (is librccl.so loadable?)")
+        return bytes(buf)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            from . import _ffi
+            raise _ffi.GgrsHipError(rc, (self._lib.ggrs_hip_fanout_last_error(self._p) or b"").decode())
+
+    def sync_confirmed(self, root: int = 0):
+        self._check(self._lib.ggrs_hip_fanout_sync_confirmed(self._p, root))
+
+    def step(self, requests) -> int:
+        import ctypes as C
+        arr, keep, n_save = self.world.build_requests(requests)
+        got = C.c_uint32(0)
+        self._check(self._lib.ggrs_hip_fanout_step(self._p, arr, len(requests), C.byref(got)))
+        return got.value
+
+    def step_raw(self, arr, n: int):
+        self._check(self._lib.ggrs_hip_fanout_step(self._p, arr, n, None))
+
+    def set_interval(self, steps_per_all_gather: int):
+        self._check(self._lib.ggrs_hip_fanout_set_interval(self._p, steps_per_all_gather))
+
+    def collect(self, max_u128_per_rank: int = 1024) -> np.ndarray:
+        """Oldest all-gather group in flight -> (world_size, n_steps, n_saves, 2) u64 array of {lo, hi} per Save."""
+        import ctypes as C
+        if getattr(self, "_out", None) is None or self._out.size < self.size * max_u128_per_rank * 2:
+            self._out = np.zeros(self.size * max_u128_per_rank * 2, dtype=np.uint64)
+        steps, saves = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.ggrs_hip_fanout_collect(self._p, self._out.ctypes.data_as(C.POINTER(C.c_uint64)), max_u128_per_rank, C.byref(steps), C.byref(saves)))
+        return self._out[: self.size * steps.value * saves.value * 2].reshape(self.size, steps.value, saves.value, 2).copy()
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._lib.ggrs_hip_fanout_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
 class _DeviceSpan:
     """A raw device allocation presented through __cuda_array_interface__ so torch can alias it without a copy."""
 
@@ -183,9 +250,12 @@ class SpeculativeFanout:
                  branch_input: Callable[[int, int], int] = default_branch_input,
                  confirmed_input: Callable[[int], int] = lambda frame: 0,
                  spawn_fn: Optional[Callable[[int], tuple]] = None, spawn_mask: int = 1 << 4,
-                 num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1):
+                 num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1, native: "Optional[RcclFanout]" = None):
         self.w, self.dist, self.D, self.x = world, dist, depth, exchange
+        self.native = native                                 # collectives inside libggrs_hip.so instead of torch.distributed (`exchange` unused)
         self.interval = max(1, desync_detection_interval)    # steps whose checksums share one all-gather (pipelined path)
+        if native is not None:
+            native.set_interval(self.interval)
         self._acc: list = []
         self.max_inflight = max_inflight                     # steps enqueued on the device before the oldest is collected
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
@@ -216,7 +286,10 @@ class SpeculativeFanout:
     def sync_confirmed(self, src: int = 0):
         """Broadcast `src`'s live world as the confirmed frame C and snapshot it on every rank."""
         self.drain()
-        self.x.broadcast(self.dist, src)
+        if self.native is not None:
+            self.native.sync_confirmed(src)
+        else:
+            self.x.broadcast(self.dist, src)
         self.w.set_confirmed(self.w.frame)
         cs = self.w.handle_requests([SaveGameState(self.w.frame)])[0]
         self.confirmed = self.w.frame
@@ -302,6 +375,9 @@ class SpeculativeFanout:
         if not self.synced:
             self.sync_confirmed(0)
         self.drain()
+        if self.native is not None:
+            self._native_enqueue()
+            return self._native_collect(want_result)        # closes the (partly filled) group: one all-gather for this step
         C = self.confirmed
         self.w.set_confirmed(C)                              # discard_old_snapshots bound
         cs = self.w.handle_requests(self._requests(C))
@@ -344,6 +420,10 @@ class SpeculativeFanout:
         than `max_inflight` are queued.  Returns that step's result (None while the pipeline fills)."""
         if not self.synced:
             self.sync_confirmed(0)
+        if self.native is not None:
+            self._native_enqueue()
+            # keep one whole all-gather group (+ max_inflight steps) in flight: the host never waits for a collective it has just issued
+            return self._native_collect(want_result) if len(self._inflight) >= self.interval + self.max_inflight else None
         if self.bpr * self.D > 256 or not hasattr(self.w, "enqueue_requests_raw"):
             return self.step(want_result)
         C = self.confirmed
@@ -359,7 +439,33 @@ class SpeculativeFanout:
         self.confirmed = C + 1
         return self._collect_one(want_result) if len(self._inflight) > self.max_inflight else None
 
+    # ---- native path: ggrs_hip_fanout_step (enqueue + all-gather on a side stream inside the library) / _collect
+    def _native_enqueue(self):
+        C = self.confirmed
+        self.w.set_confirmed(C)
+        if self.spawn_fn is None:
+            if self._tmpl is None:
+                self._tmpl = self._template()
+            self._patch(self._tmpl, C)
+            self.native.step_raw(self._tmpl["arr"], self._tmpl["n"])
+        else:
+            self.native.step(self._requests(C))
+        self._inflight.append(C)
+        self.confirmed = C + 1
+
+    def _native_collect(self, want_result: bool = True) -> Optional[dict]:
+        allv = self.native.collect()                          # (size, n_steps, n_saves, 2): the oldest all-gather group
+        out = None
+        for k in range(allv.shape[1]):
+            C = self._inflight.pop(0)
+            out = self._check(C, np.ascontiguousarray(allv[:, k]).reshape(-1), want_result)
+            if out is not None:
+                self.results.append(out)
+        return out
+
     def _collect_one(self, want_result: bool = True) -> Optional[dict]:
+        if self.native is not None:
+            return self._native_collect(want_result)
         C = self._inflight.pop(0)
         n = self.bpr * self.D
         if self._tmpl is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 4
+#define GGRS_HIP_ABI_VERSION 5
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -265,6 +265,34 @@ int ggrs_hip_live_state_ptr(ggrs_world* w, void** dev_ptr);
 /* after bytes were written into the live state block by an external producer (collective),
  * re-read its header so host-side bookkeeping (len, frame) matches */
 int ggrs_hip_adopt_live_state(ggrs_world* w);
+
+/* Speculative fan-out ACROSS GPUs, one process per GPU (north_star: "RCCL broadcast of the confirmed-frame snapshot
+ * and all-gather of per-branch checksums over xGMI").  librccl is dlopen'ed by the library (no link-time
+ * dependency); the host's only job is to carry the 128-byte ncclUniqueId from rank 0 to the other ranks (any side
+ * channel: the reference has none -- ggrs's UDP sockets, a file, MPI ...).
+ *   unique_id        rank 0: ncclGetUniqueId.
+ *   init             every rank: ncclCommInitRank on the world's device; the communicator lives until fanout_destroy.
+ *   sync_confirmed   ONE ncclBroadcast of `root`'s packed live block (ggrs_hip_state_bytes bytes, in place in HBM) on
+ *                    the world's stream; receivers adopt it (len, frame).  Start-up / desync recovery only.
+ *   set_interval     steps whose checksums travel in ONE all-gather (default 1).  The reference's stress_test exchanges
+ *                    checksums every --desync-detection-interval frames, default 10 (examples/stress_tests/particles.rs:49).
+ *   step             ggrs_hip_enqueue_requests of this rank's branch list; behind an event, on a side stream -- the next
+ *                    step's kernels are not held up -- its Checksum(u128)s join the current group, and every `interval`-th
+ *                    step issues ONE ncclAllGather for the group.  Every rank must pass lists with the same number of
+ *                    SaveGameState requests.
+ *   collect          oldest uncollected group (a partly filled one is closed first): blocks until its all-gather has
+ *                    landed; checksums_out is [world_size][n_steps][n_saves][2] u64 ({lo, hi} per Save, rank-major).
+ * At most 8 groups may be in flight. */
+#define GGRS_FANOUT_ID_BYTES 128
+typedef struct ggrs_fanout ggrs_fanout;
+int  ggrs_hip_fanout_unique_id(uint8_t id_out[GGRS_FANOUT_ID_BYTES]);
+int  ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], int rank, int world_size, ggrs_fanout** out);
+int  ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root);
+int  ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out);
+int  ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather);
+int  ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t max_u128_per_rank, uint32_t* n_steps_out, uint32_t* n_saves_out);
+void ggrs_hip_fanout_destroy(ggrs_fanout* f);
+const char* ggrs_hip_fanout_last_error(ggrs_fanout* f);
 
 /* -------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class HIP-event timing on the world's stream.

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 4;
+pub const GGRS_HIP_ABI_VERSION: c_int = 5;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -35,6 +35,10 @@ pub const GGRS_REQ_ADVANCE: u32 = 3;
 
 pub const GGRS_KERNEL_CLASSES: usize = 5;
 
+#[repr(C)]
+pub struct ggrs_fanout {
+    _private: [u8; 0],
+}
 #[repr(C)]
 pub struct ggrs_world {
     _opaque: [u8; 0],
@@ -133,6 +137,15 @@ unsafe extern "C" {
     pub fn ggrs_hip_state_bytes(w: *mut ggrs_world) -> u64;
     pub fn ggrs_hip_live_state_ptr(w: *mut ggrs_world, dev_ptr: *mut *mut c_void) -> c_int;
     pub fn ggrs_hip_adopt_live_state(w: *mut ggrs_world) -> c_int;
+    // ---- speculative fan-out across GPUs (RCCL behind the C ABI; the host carries the 128-byte ncclUniqueId between ranks)
+    pub fn ggrs_hip_fanout_unique_id(id_out: *mut u8) -> c_int;
+    pub fn ggrs_hip_fanout_init(w: *mut ggrs_world, id: *const u8, rank: c_int, world_size: c_int, out: *mut *mut ggrs_fanout) -> c_int;
+    pub fn ggrs_hip_fanout_sync_confirmed(f: *mut ggrs_fanout, root: c_int) -> c_int;
+    pub fn ggrs_hip_fanout_step(f: *mut ggrs_fanout, reqs: *const ggrs_request, n: u32, n_saves_out: *mut u32) -> c_int;
+    pub fn ggrs_hip_fanout_set_interval(f: *mut ggrs_fanout, steps_per_all_gather: u32) -> c_int;
+    pub fn ggrs_hip_fanout_collect(f: *mut ggrs_fanout, checksums_out: *mut u64, max_u128_per_rank: u32, n_steps_out: *mut u32, n_saves_out: *mut u32) -> c_int;
+    pub fn ggrs_hip_fanout_destroy(f: *mut ggrs_fanout);
+    pub fn ggrs_hip_fanout_last_error(f: *mut ggrs_fanout) -> *const c_char;
     // ---- measurement hooks
     pub fn ggrs_hip_profile_enable(w: *mut ggrs_world, on: c_int) -> c_int;
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;
