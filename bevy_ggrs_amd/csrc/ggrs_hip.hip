@@ -452,7 +452,7 @@ int seal_impl(ggrs_world* w) {
             b.off_ttl = t.off_ttl; b.rest_off = base; b.ts = t.ts;
             b.n_rest_rows = t.n_rest_rows; b.n_rest_masks = t.n_rest_masks;
             for (uint32_t m = 0; m < t.n_rest_masks; ++m) b.rest_mask_off[m] = t.rest_mask_off[m];
-            b.fold.cks_T = w->f_cksT; b.fold.cks_V = w->f_cksV;
+            b.fold.n_comp = 2; b.fold.comp_mask = (w->f_cksT ? 1u : 0u) | (w->f_cksV ? 2u : 0u);
             w->tick2_ok = true;
         }
     }
@@ -557,7 +557,7 @@ int seal_impl(ggrs_world* w) {
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
-    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max(n_tiles, 1u) * 4 * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN;   // one partial row per workgroup of the finest grid (256-slot k_tick1 workgroups) + the ticket
+    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max(n_tiles, 1u) * 4 * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;   // one partial row per workgroup of the finest grid (256-slot k_tick1 workgroups) + the ticket
     const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + tick_parts_bytes + res_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
@@ -1415,7 +1415,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                              (a.marks ? sub / 8 + sub * 4 : 0);
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
-            hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(TPB), lds, w->stream, a);
+            hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(GEN_TPB), lds, w->stream, a);
         }
         HIPCHK(w, hipGetLastError());
         group_close(w, gs, a.n_saves);
@@ -1515,7 +1515,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
                            align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
-    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * 4 * MAX_TICK_SAVES * 3 * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * 4 * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;

@@ -443,10 +443,10 @@ constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
 // In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
 // the last workgroup to arrive writes every Save's Checksum(u128).
 struct FoldArgs {
-    uint64_t* wg_parts;                    // [gridDim.x][n_saves * 3]: XOR T, XOR V, live count per Save
+    uint64_t* wg_parts;                    // [gridDim.x][n_saves * (n_comp + 1)]: per Save the XOR of each checksummed component, then the live count
     uint32_t* ticket;                      // arrival counter, zero between launches
     uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
-    uint32_t cks_T, cks_V;
+    uint32_t n_comp, comp_mask;            // component slots per Save; bit j: slot j is a registered checksum (contributes a part)
 };
 struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; uint32_t word_bytes; uint32_t pad; };
 struct TickArgs {
@@ -843,19 +843,19 @@ template <int NTHREADS>
 __device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
     if (n_saves == 0) return;
     __syncthreads();                                              // the LDS atomics of every wave have landed
-    const uint32_t n_vals = n_saves * 3u;                       // <= 48
-    if (threadIdx.x < 64) {
-        if (threadIdx.x < n_vals) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + threadIdx.x, acc[threadIdx.x]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is in memory before the ticket is taken
-        if (threadIdx.x == 0) {
-            const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
-        }
+    const uint32_t nv = f.n_comp + 1u;                            // values per Save
+    const uint32_t n_vals = n_saves * nv;
+    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + i, acc[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row is in memory before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (!*s_last) return;                                         // workgroup-uniform
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) acc[i] = 0;
     __syncthreads();
     {
         // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  24 loads in flight per lane and trip.
@@ -873,7 +873,7 @@ __device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, u
                 const uint32_t i = i0 + (uint32_t)u * NTHREADS;
                 if (i >= n_flat) continue;
                 const uint32_t c = i % n_vals;
-                if ((c % 3u) == 2u) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+                if ((c % nv) == f.n_comp) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
                 else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
             }
         }
@@ -882,9 +882,9 @@ __device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, u
     if (threadIdx.x < n_saves) {
         const uint32_t k = threadIdx.x;
         uint64_t total = 0;
-        if (f.cks_T) total ^= sea_one(acc[k * 3 + 0]);            // component_checksum.rs:92-95
-        if (f.cks_V) total ^= sea_one(acc[k * 3 + 1]);
-        total ^= sea_pair(acc[k * 3 + 2], total_len);                // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        for (uint32_t j = 0; j < f.n_comp; ++j)
+            if ((f.comp_mask >> j) & 1u) total ^= sea_one(acc[k * nv + j]);     // component_checksum.rs:92-95
+        total ^= sea_pair(acc[k * nv + f.n_comp], total_len);                  // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
         f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
     }
     if (threadIdx.x == 0) *f.ticket = 0;                          // ready for the next launch on this stream
@@ -1989,9 +1989,16 @@ struct GenArgs {
 static_assert(sizeof(GenArgs) <= 4096, "kernel argument segment limit");
 
 
-__global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
+// 512-thread workgroups, wave-specialised like k_tick3: waves 0-3 (COMPUTE) hash and step the LDS image, waves 4-7 (STORE)
+// own every transfer LDS image -> global.  At a Save: barrier A (the image is stable) -> the store waves pull the whole image
+// (<= 64 KiB = 16 chunks of 16 B per lane) and the masks into registers while the compute waves hash it -> barrier B (the
+// image may change again) -> the store waves stream it to the ring slot, blocking on the store queue for as long as it
+// takes, while the compute waves run the next Advance.
+constexpr int GEN_TPB = 512;
+__global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool store_role = threadIdx.x >= (uint32_t)TPB;             // wave-uniform
+    const uint32_t tid = threadIdx.x & (TPB - 1u), lane = tid & 63u, wave = tid >> 6;   // index inside the role
     const uint32_t sub = a.sub, mw = sub >> 6;                        // slots / mask words per workgroup
     const uint64_t s0 = (uint64_t)blockIdx.x * sub;                   // first slot of this workgroup
     const uint64_t tbase = a.cols_base + (s0 >> LT_SHIFT) * a.ts;     // its layout tile inside a block
@@ -2003,75 +2010,159 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
     // small tables staged once: global offset of every row unit of this workgroup, the checksum units
     uint32_t* grow = reinterpret_cast<uint32_t*>(lds + img + a.n_masks * mw * 8u);   // [n_rows] byte offset inside the tile
     GenUnit* lunits = reinterpret_cast<GenUnit*>(grow + ((n_rows + 3u) & ~3u));      // [n_units]
-    for (uint32_t w = tid; w < a.n_words; w += TPB) {
+    for (uint32_t w = threadIdx.x; w < a.n_words; w += GEN_TPB) {
         const GenWord gw = a.words[w];
         const uint32_t r0 = gw.pso >> 2;
         grow[r0] = gw.tcol + in_tile * gw.wb;
         if (gw.wb == 8) grow[r0 + 1] = gw.tcol + in_tile * 8u + sub * 4u;      // second half of the contiguous sub x 8 bytes
     }
-    for (uint32_t u = tid; u < a.n_units; u += TPB) lunits[u] = a.units[u];
+    for (uint32_t u = threadIdx.x; u < a.n_units; u += GEN_TPB) lunits[u] = a.units[u];
     // live-only RollbackDespawned markers of these slots: disabled bits + the frame each was despawned on.  Not part of
     // any snapshot; LoadWorld's resurrect pass (k_load_reconcile) has already run on the live copy (stream order).
     uint64_t* ldis = reinterpret_cast<uint64_t*>(lunits + a.n_units);                 // [mw]
     int32_t* ldf = reinterpret_cast<int32_t*>(ldis + mw);                             // [sub]
     if (a.marks) {
-        for (uint32_t m = tid; m < mw; m += TPB) ldis[m] = *reinterpret_cast<const uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8);
-        for (uint32_t i = tid; i < sub; i += TPB) ldf[i] = *reinterpret_cast<const int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4);
+        for (uint32_t m = threadIdx.x; m < mw; m += GEN_TPB) ldis[m] = *reinterpret_cast<const uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8);
+        for (uint32_t i = threadIdx.x; i < sub; i += GEN_TPB) ldf[i] = *reinterpret_cast<const int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4);
     }
     __syncthreads();
 
-    // LDS image <-> one state block: 16-byte chunks, chunk c lives at LDS byte c * 16, 4 chunks in flight per lane
-    const uint32_t n_chunks = img >> 4, chunks_per_row = sub >> 2;
-    auto copy_words = [&](uint8_t* block, bool to_block) {
-        uint8_t* gb = block + tbase;
-        for (uint32_t c0 = tid; c0 < n_chunks; c0 += 4 * TPB) {
-            u32x4 v[4]; uint32_t goff[4];
+    // LDS image <-> one state block: 16-byte chunks, chunk c lives at LDS byte c * 16 and belongs to row c >> row_shift
+    // (sub is 256 / 512 / 1024: a row is 64 / 128 / 256 chunks -- shifts, not the divisions of round 1), 8 chunks in flight
+    // per lane.  Snapshot stores are non-temporal like k_tick3's: the ring is written once and read a whole tick later.
+    const uint32_t n_chunks = img >> 4;
+    const uint32_t row_shift = sub == 1024u ? 8u : (sub == 512u ? 7u : 6u), row_mask = (1u << row_shift) - 1u;
+    // global -> LDS image, all 512 threads, 8 loads in flight per lane
+    auto stage_in = [&](const uint8_t* block) {
+        g_u8* gb = sgpr_base(block + tbase);
+        for (uint32_t c0 = threadIdx.x; c0 < n_chunks; c0 += 8 * GEN_TPB) {
+            u32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + j * TPB;
-                if (c < n_chunks) {
-                    goff[j] = grow[c / chunks_per_row] + (c % chunks_per_row) * 16u;
-                    v[j] = to_block ? *reinterpret_cast<const u32x4*>(lds + c * 16u) : *reinterpret_cast<const u32x4*>(gb + goff[j]);
-                }
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t c = c0 + j * GEN_TPB;
+                v[j] = u32x4{0, 0, 0, 0};
+                if (c < n_chunks) v[j] = *(const GGRS_GLOBAL u32x4*)(gb + grow[c >> row_shift] + (c & row_mask) * 16u);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + j * TPB;
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t c = c0 + j * GEN_TPB;
+                if (c < n_chunks) *reinterpret_cast<u32x4*>(lds + c * 16u) = v[j];
+            }
+        }
+        for (uint32_t m = threadIdx.x; m < a.n_masks * mw; m += GEN_TPB)
+            lmask[m] = *reinterpret_cast<const uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8);
+    };
+    // STORE waves: the image (<= 4096 chunks: 16 per lane) and the masks (<= 17 x 16 words: 2 per lane) in registers
+    u32x4 ireg[16]; uint64_t mreg[2];
+    auto image_pull = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const uint32_t c = tid + (uint32_t)j * TPB; ireg[j] = c < n_chunks ? *reinterpret_cast<const u32x4*>(lds + c * 16u) : u32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const uint32_t m = tid + (uint32_t)j * TPB; mreg[j] = m < a.n_masks * mw ? lmask[m] : 0ULL; }
+    };
+    auto image_push = [&](uint8_t* block, bool nt, bool words) {
+        g_u8* gb = sgpr_base(block + tbase);
+        if (words) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t c = tid + (uint32_t)j * TPB;
                 if (c < n_chunks) {
-                    if (to_block) *reinterpret_cast<u32x4*>(gb + goff[j]) = v[j];
-                    else *reinterpret_cast<u32x4*>(lds + c * 16u) = v[j];
+                    const uint32_t go = grow[c >> row_shift] + (c & row_mask) * 16u;
+                    if (nt) st16<true>(gb, go, ireg[j]); else st16<false>(gb, go, ireg[j]);
                 }
             }
         }
-    };
-    auto copy_masks = [&](uint8_t* block, bool to_block) {
-        for (uint32_t m = tid; m < a.n_masks * mw; m += TPB) {
-            uint64_t* g = reinterpret_cast<uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8);
-            if (to_block) *g = lmask[m]; else lmask[m] = *g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t m = tid + (uint32_t)j * TPB;
+            if (m < a.n_masks * mw) *reinterpret_cast<uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8) = mreg[j];
         }
     };
     // ---- stage the workgroup's slots
-    copy_masks(const_cast<uint8_t*>(a.src), false);
-    if (in_len) copy_words(const_cast<uint8_t*>(a.src), false);
+    stage_in(a.src);        // (slots beyond len hold whatever the block holds there: their mask bits are zero)
     __syncthreads();
+
+    if (store_role) {
+        // ================================================= STORE waves: one hand-off per Save with a ring slot + the live write
+        uint32_t si = 0;
+        for (uint32_t op = 0; op < a.n_ops; ++op) {
+            if ((a.op_bits >> op) & 1ULL) continue;
+            uint8_t* dst = a.save_dst[si];
+            if (dst) {
+                lds_barrier();                                        // A: the image is stable
+                image_pull();
+                lds_barrier();                                        // B: (pull has landed: lds_barrier waits lgkmcnt(0)) the image may change
+                image_push(dst, true, in_len);
+                if (blockIdx.x == 0 && tid == 0) {
+                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
+                    *reinterpret_cast<Header*>(dst) = h;
+                }
+            }
+            ++si;
+        }
+        if (!a.src_is_live || a.n_steps) {
+            lds_barrier();
+            image_pull();
+            lds_barrier();
+            image_push(a.live, false, in_len);
+        }
+    } else {
+    // ===================================================== COMPUTE waves
+    // diffuse(K0 ^ order) of the (up to 4) slots this lane hashes: it depends on the slot only, so one value serves every
+    // checksummed component and every Save of the group (as in k_tick)
+    uint64_t ordB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ordB[q] = sea_order_lane(s0 + tid + (uint32_t)q * TPB);
 
     uint32_t si = 0, sj = 0;
     for (uint32_t op = 0; op < a.n_ops; ++op) {
         if (!((a.op_bits >> op) & 1ULL)) {
-            // ---------------- SaveWorld: snapshot + per-entity half of every component checksum
-            // (every lane hashes the slots it also steps in Advance ops: no barrier needed before this part)
+            // ---------------- SaveWorld: snapshot (store waves) + per-entity half of every component checksum (here).
+            // Barrier A hands the stable image to the store waves; the hash below only READS it, so it overlaps their pull;
+            // barrier B (after the hash) lets the next Advance change it.
+            const bool hand_off = a.save_dst[si] != nullptr;
+            if (hand_off) lds_barrier();
             uint64_t* prow = a.parts + (uint64_t)si * (a.n_cks + 1) * a.part_stride + (uint64_t)blockIdx.x * 4 + wave;
             for (uint32_t k = 0; k < a.n_cks; ++k) {
                 const uint64_t* pm = lmask + a.cks_pmask[k] * mw;
+                const uint32_t nu = a.cks_n_units[k], ub = a.cks_unit_base[k];
                 uint64_t h = 0;
-                for (uint32_t i = tid; i < sub; i += TPB) {
-                    if (((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL) {
-                        SeaStream st;
-                        for (uint32_t u = 0; u < a.cks_n_units[k]; ++u) {
-                            const GenUnit gu = lunits[a.cks_unit_base[k] + u];
-                            st.unit(*reinterpret_cast<const uint32_t*>(lds + gu.pso * sub + gu.add + i * gu.stride));
+                if (nu <= 4u) {
+                    // the common specs (1-4 four-byte units, e.g. translation.xyz): unit addresses hoisted out of the slot
+                    // loop, the (up to 4) slots of a lane hashed as independent chains, dead slots selected away
+                    const uint8_t* ubase[4]; uint32_t ustride[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const GenUnit gu = lunits[ub + ((uint32_t)u < nu ? (uint32_t)u : 0u)];
+                        ubase[u] = lds + gu.pso * sub + gu.add; ustride[u] = gu.stride;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t i = tid + (uint32_t)q * TPB;
+                        if (i < sub) {                                     // workgroup-uniform (sub is 256, 512 or 1024)
+                            const bool on = ((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL;
+                            uint32_t x[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint32_t*>(ubase[u] + i * ustride[u]);
+                            SeaStream st;
+                            st.unit(x[0]);
+                            if (nu > 1u) st.unit(x[1]);
+                            if (nu > 2u) st.unit(x[2]);
+                            if (nu > 3u) st.unit(x[3]);
+                            const uint64_t e = sea_pair_pre(ordB[q], st.finish());
+                            h ^= on ? e : 0ULL;
                         }
-                        h ^= sea_pair(s0 + i, st.finish());              // order == slot
+                    }
+                } else {
+                    for (uint32_t i = tid; i < sub; i += TPB) {
+                        if (((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL) {
+                            SeaStream st;
+                            for (uint32_t u = 0; u < nu; ++u) {
+                                const GenUnit gu = lunits[ub + u];
+                                st.unit(*reinterpret_cast<const uint32_t*>(lds + gu.pso * sub + gu.add + i * gu.stride));
+                            }
+                            h ^= sea_pair(s0 + i, st.finish());          // order == slot
+                        }
                     }
                 }
                 h = wave_xor(h);
@@ -2079,19 +2170,8 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
             }
             uint32_t cnt = 0;
             for (uint32_t wi = wave; wi < mw; wi += 4) cnt += (uint32_t)__popcll(lmask[wi]);
-            if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;
-            // the snapshot copy moves 16-byte chunks whatever lane owns their slots: barriers on both sides
-            lds_barrier();
-            uint8_t* dst = a.save_dst[si];
-            if (dst) {
-                if (in_len) copy_words(dst, true);
-                copy_masks(dst, true);
-                if (blockIdx.x == 0 && tid == 0) {
-                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = h;
-                }
-            }
-            lds_barrier();
+            if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;   // folded by k_gen_finalize (an in-kernel tick_fold measured no gain here: 178 vs 174 us per 1 M tick)
+            if (hand_off) lds_barrier();
             ++si;
         } else {
             // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
@@ -2184,16 +2264,13 @@ __global__ __launch_bounds__(TPB) void k_tick_gen(GenArgs a) {
             ++sj;
         }
     }
-    lds_barrier();
-    // ---- the live block, written once
-    if (!a.src_is_live || a.n_steps) {
-        if (in_len) copy_words(a.live, true);
-        copy_masks(a.live, true);
-    }
+    // ---- the live block, written once (by the store waves)
+    if (!a.src_is_live || a.n_steps) { lds_barrier(); lds_barrier(); }
     if (a.marks && a.n_steps) {
         for (uint32_t m = tid; m < mw; m += TPB) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8) = ldis[m];
         for (uint32_t i = tid; i < sub; i += TPB) *reinterpret_cast<int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4) = ldf[i];
     }
+    }   // COMPUTE waves
 }
 
 // Fold of k_tick_gen's per-wave partials: one 1024-thread workgroup per Save; any number of checksummed components.
