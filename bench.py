@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (torch arena, RCCL broadcast + all-gather) even at world size 1")
+    ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
 
@@ -267,8 +268,8 @@ def main():
         box = [RcclFanout.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         native = RcclFanout(w, rank, world_size, box[0])
-        fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=1, max_inflight=2,
-                                desync_detection_interval=10)   # the reference stress_test's default (particles.rs:49, README.md:84)
+        fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
+                                desync_detection_interval=10 if args.branches == 1 else 1)   # the reference stress_test's default (particles.rs:49, README.md:84)
         fan.sync_confirmed(0)
         for _ in range(W):
             fan.step_pipelined(want_result=False)
@@ -285,7 +286,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
         live = w.active_count()
-        cnt = torch.tensor([live], dtype=torch.int64, device=f"cuda:{dev}")
+        cnt = torch.tensor([live * args.branches], dtype=torch.int64, device=f"cuda:{dev}")   # every branch resimulates the whole world
         dist.all_reduce(cnt)
         total_entities = int(cnt.item())
         w.profile_enable(True)
@@ -364,7 +365,7 @@ def main():
         "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, 1 predicted-input branch per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
+                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,

@@ -31,6 +31,7 @@ using namespace ggrs;
 namespace {
 
 constexpr uint64_t ALIGN = 256;
+constexpr uint64_t TICK_VEC1_MAX_SLOTS = 400 * 1024;   // worlds covering up to this many slots run on k_tick1 (see run_request_groups)
 constexpr int TICK2_RESTL_MAX = 7;     // untouched rows k_tick2 keeps in registers: EXACTLY this many (the stress_test world, kernels.hpp)
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -72,6 +73,7 @@ struct Knobs {
     bool tick2 = true;             // GGRS_TICK2=0          big worlds on the round-1 k_tick + k_tick_finalize pair instead of k_tick2
     int tick2_wgs_per_cu = 2;      // GGRS_TICK2_WGS=n      persistent workgroups per CU of k_tick2 (0: one workgroup per tile, not persistent)
     int tick2_nt = 1;              // GGRS_TICK2_NT=0|1     non-temporal snapshot stores in k_tick2
+    bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int tick2_ilv = 0;             // GGRS_TICK2_ILV=0|1    Save = store burst + hash (0) or stores spaced out between the hash multiplies (1)
     uint64_t tick2_min_slots = 500 * 1024;   // GGRS_TICK2_MIN_SLOTS  worlds covering more slots than this run on k_tick3 / k_tick2
     int tick3 = 2;                 // GGRS_TICK3=0|1|2      wave-specialised k_tick3 (1: workgroup barrier per hand-off, 2: per-pair LDS flags); 0: k_tick2
@@ -94,6 +96,7 @@ struct Knobs {
         k.tick2_wgs_per_cu = (int)std::min<long long>(8, std::max<long long>(0, num("GGRS_TICK2_WGS", 2)));
         k.tick2_nt = num("GGRS_TICK2_NT", 1) != 0;
         k.tick2_ilv = num("GGRS_TICK2_ILV", 0) != 0;
+        k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.tick3 = (int)std::min<long long>(2, std::max<long long>(0, num("GGRS_TICK3", 2)));
         k.tick2_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_TICK2_MIN_SLOTS", 500 * 1024));
         return k;
@@ -155,6 +158,7 @@ struct ggrs_world {
     bool tick_ok = false; uint32_t f_lw = 0;
     TickArgs tick_proto{};               // layout part of the kernel arguments, filled at seal
     uint64_t* d_tick_parts = nullptr; uint32_t tick_part_stride = 0;
+    uint32_t tick_parts_saves = MAX_TICK_SAVES;   // Save slots of d_tick_parts: > MAX_TICK_SAVES lets small worlds batch identical checksum-only groups
     // k_tick2: persistent grid + in-kernel fold (big worlds)
     bool tick2_ok = false; Tick2Args tick2_proto{};
     uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
@@ -549,10 +553,11 @@ int seal_impl(ggrs_world* w) {
     // ---- arena carve
     const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
     w->tick_part_stride = 4 * (uint32_t)(w->cap_pad / TILE1);     // one partial per wave of the finest tiling
-    const uint64_t tick_parts_bytes = align_up((uint64_t)MAX_TICK_SAVES * 3 * w->tick_part_stride * 8, ALIGN);
+    w->tick_parts_saves = w->cap_pad <= TICK_VEC1_MAX_SLOTS + 112 * 1024 ? 8 * MAX_TICK_SAVES : MAX_TICK_SAVES;   // k_tick1 worlds: room for a batch of 16 eight-Save groups
+    const uint64_t tick_parts_bytes = align_up((uint64_t)w->tick_parts_saves * 3 * w->tick_part_stride * 8, ALIGN);
     w->part_stride = n_tiles + 4096 / 1;            // + room for spawn partial blocks
     const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
-    w->max_results = 1024;
+    w->max_results = 16384;                             // pinned result ring (256 KiB): a fan-out step of 256 branches x 8 frames alone is 2048
     const uint64_t res_bytes = align_up((uint64_t)w->max_results * 16, ALIGN);
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
     w->stage_floats = 1u << 20;
@@ -1072,7 +1077,7 @@ void apply_synctest_confirmed(ggrs_world* w) {
 // ---- fused request groups: [Load?] (Save | Advance)* as ONE k_tick launch + one finalize ----
 // measured crossovers (profiles/README.md, run wpb1): the 1-slot-per-lane kernel has the shortest per-wave dependency
 // chain and wins while the chip is under-filled; single-wave workgroups of the 4-slots-per-lane kernel win in between
-constexpr uint64_t TICK_VEC1_MAX_SLOTS = 400 * 1024, TICK_WAVE_WG_MAX_SLOTS = 800 * 1024;
+constexpr uint64_t TICK_WAVE_WG_MAX_SLOTS = 800 * 1024;
 bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
     if (r.spawn_count == 0) return false;
     for (auto& s : w->systems) {
@@ -1192,11 +1197,30 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves) {
 }
 
 template <bool NT>
-void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g) {
-    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksT) hipLaunchKernelGGL((k_tick1<true, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksV) hipLaunchKernelGGL((k_tick1<false, true, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
-    else hipLaunchKernelGGL((k_tick1<false, false, NT>), dim3(g), dim3(TPB), 0, w->stream, a);
+void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g, uint32_t batch = 1) {
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick1<true, false, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick1<false, true, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick1<false, false, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
+}
+
+// Dead-snapshot elimination.  A request group whose NEXT request is a LoadGameState of a frame older than everything the
+// group saved leaves nothing behind: that rollback pops every one of its snapshots from the ring (mod.rs:210-226) before
+// anything could load them, and LoadWorld overwrites the live world.  Only the group's Checksum(u128)s are observable --
+// exactly what a speculative branch of the fan-out is ([Load(C), Adv, Save, ...] x B in one list: every branch but the last).
+// Such a group runs checksum-only: no snapshot stores, no live write.  The host ring bookkeeping is done as usual.
+// Not applied when something else reads the live world in between (a firing spawn system, live-only components or
+// RollbackDespawned markers, whose reconcile pass reads the live liveness mask).
+bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, uint32_t n, const int32_t* save_frame, uint32_t n_saves, bool spawn_pending) {
+    if (!w->knobs.dead_groups || spawn_pending || n_saves == 0 || i >= n || reqs[i].kind != GGRS_REQ_LOAD || w->has_nr || w->marks_possible) return false;
+    bool present = false;
+    for (int32_t f : w->ring_frame) present |= f == reqs[i].frame;
+    if (!present) return false;                                        // that Load is going to fail: change nothing
+    for (uint32_t k = 0; k < n_saves; ++k) {
+        const int64_t d = (int64_t)save_frame[k] - (int64_t)reqs[i].frame;
+        if (d <= 0 || d > (1 << 30)) return false;                       // not newer (or i32 wrap-around in play): keep it
+    }
+    return true;
 }
 
 constexpr int TICK_RESTL = 8;          // rest rows the register-resident variant of k_tick can carry
@@ -1264,10 +1288,44 @@ int probe_arena_placement(ggrs_world* w, uint8_t* base, uint64_t tick_parts_off,
 
 // res_base: first slot of the pinned result ring this list writes to.  wait == false only enqueues
 // (ggrs_hip_enqueue_requests); the list then must hold fewer Saves than the ring can take.
+// Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length)
+// are launched TOGETHER: one k_tick1 grid of tiles x K members and one finalize of saves x K, instead of K launch pairs.
+struct TickBatch {
+    bool active = false; TickArgs a; uint32_t g = 0, k = 0, res_first = 0;
+    void start(const TickArgs& a_, uint32_t g_, uint32_t res) { active = true; a = a_; g = g_; k = 1; res_first = res; }
+    bool try_add(const ggrs_world* w, const TickArgs& b, uint32_t g_, uint32_t res) {
+        if (!active || g_ != g || b.src != a.src || b.len != a.len || b.op_bits != a.op_bits || b.n_ops != a.n_ops || b.n_saves != a.n_saves ||
+            b.n_steps != a.n_steps || memcmp(b.dt_bits, a.dt_bits, sizeof(uint32_t) * a.n_steps) != 0) return false;
+        if ((k + 1) * a.n_saves > w->tick_parts_saves || res != res_first + k * a.n_saves) return false;
+        ++k;
+        return true;
+    }
+    int flush(ggrs_world* w) {
+        if (!active) return GGRS_OK;
+        active = false;
+        {
+            ProfScope ps(w, GGRS_KERNEL_TICK);
+            launch_tick1<false>(w, a, g, k);
+        }
+        HIPCHK(w, hipGetLastError());
+        TickFinArgs f; memset(&f, 0, sizeof f);
+        f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = 4 * g;
+        f.cks_T = w->f_cksT; f.cks_V = w->f_cksV; f.total_len = a.len;
+        f.out = w->d_results + 2 * (uint64_t)res_first;
+        {
+            ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+            hipLaunchKernelGGL(k_tick_finalize, dim3(a.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
+        }
+        HIPCHK(w, hipGetLastError());
+        return GGRS_OK;
+    }
+};
+
 int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
                        uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
     uint32_t i = 0, ns = 0;                      // ns: results pending in d_results
     int rc = GGRS_OK;
+    TickBatch batch;
     while (i < n) {
         TickArgs a = w->tick_proto;
         GroupState gs;
@@ -1293,6 +1351,8 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             }
             ++i;
         }
+        const bool dead = group_is_dead(w, reqs, i, n, a.save_frame, a.n_saves, spawn_req != nullptr);
+        if (dead) { for (uint32_t k = 0; k < a.n_saves; ++k) a.save_dst[k] = nullptr; a.skip_live = 1; }
         // ---- one pass over the tiles
         const uint64_t cover = std::max(gs.cover, w->len);
         // kernel shape by world size: k_tick1 (1 slot per lane, 256-slot workgroups) for small worlds, k_tick with
@@ -1304,6 +1364,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         a.parts = w->d_tick_parts; a.part_stride = w->tick_part_stride;
         const bool use2 = w->tick2_ok && !w->knobs.tick_vec && cover > w->knobs.tick2_min_slots;
+        if (use2) { rc = batch.flush(w); if (rc) return rc; }
         if (use2) {
             // persistent grid, in-kernel fold: ONE launch per group, the Checksum(u128)s land in the pinned result ring
             Tick2Args b = w->tick2_proto;
@@ -1311,7 +1372,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             memcpy(b.save_dst, a.save_dst, sizeof b.save_dst); memcpy(b.save_frame, a.save_frame, sizeof b.save_frame);
             memcpy(b.dt_bits, a.dt_bits, sizeof b.dt_bits);
             b.op_bits = a.op_bits; b.n_ops = a.n_ops; b.n_saves = a.n_saves; b.n_steps = a.n_steps; b.src_is_live = a.src_is_live;
-            b.n_units = n_waves;
+            b.n_units = n_waves; b.skip_live = a.skip_live;
             b.fold.wg_parts = w->d_wg_parts; b.fold.ticket = w->d_ticket;
             b.fold.out = w->d_results + 2 * (uint64_t)(res_base + ns);
             const uint32_t tiles = std::max(1u, tiles_for(cover));
@@ -1325,6 +1386,16 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
                 else { if (nt) launch_tick2<true, 0>(w, b, g2); else launch_tick2<false, 0>(w, b, g2); }
             }
             HIPCHK(w, hipGetLastError());
+            group_close(w, gs, a.n_saves);
+            ns += a.n_saves;
+        } else if (vec == 1 && dead && !w->nt_copy && batch.try_add(w, a, g, res_base + ns)) {
+            // an identical checksum-only group already waits to be launched: this one rides along as blockIdx.y = K
+            group_close(w, gs, a.n_saves);
+            ns += a.n_saves;
+        } else {
+        rc = batch.flush(w); if (rc) return rc;
+        if (vec == 1 && dead && !w->nt_copy) {
+            batch.start(a, g, res_base + ns);                          // launched when the batch is full or something else follows
             group_close(w, gs, a.n_saves);
             ns += a.n_saves;
         } else {
@@ -1349,15 +1420,18 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             ns += a.n_saves;
         }
         }
+        }
         if (spawn_req) {
             rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
             if (rc) return rc;
         }
         if (wait && ns == w->max_results) {                                // flush a full result page
+            rc = batch.flush(w); if (rc) return rc;
             rc = read_back(w, ns, checksums_out); if (rc) return rc;
             checksums_out += 2 * (uint64_t)ns; ns = 0;
         }
     }
+    rc = batch.flush(w); if (rc) return rc;
     if (n_saves_out) *n_saves_out = ns;
     if (!wait) return GGRS_OK;
     return read_back(w, ns, checksums_out);
@@ -1404,6 +1478,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             ++i;
         }
+        if (group_is_dead(w, reqs, i, n, a.save_frame, a.n_saves, spawn_req != nullptr)) { for (uint32_t k = 0; k < a.n_saves; ++k) a.save_dst[k] = nullptr; a.skip_live = 1; }
         const uint64_t cover = std::max(gs.cover, w->len);
         uint32_t sub = w->gen_sub_max;
         if (cover <= GEN_SMALL_SLOTS) sub = std::min<uint32_t>(sub, 256);
@@ -1513,9 +1588,9 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 1024 per tile)
     const uint64_t state = align_up(align_up(ALIGN + (1 + (uint64_t)n_components) * mask, 4096) + cap_pad * bytes_per_slot, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN) +
-                           align_up((uint64_t)MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
+                           align_up((uint64_t)8 * MAX_TICK_SAVES * 3 * 4 * (cap_pad / TILE1) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot / 4 + 1) * ALIGN, 4096);
-    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * 4 * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8, ALIGN) + ALIGN + 1024 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
+    return (uint64_t)(max_depth + 1) * state + side + parts + align_up((cap_pad / TILE) * 4 * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8, ALIGN) + ALIGN + 16384 * 16 + ALIGN + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20);
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;
@@ -2008,7 +2083,7 @@ struct ggrs_fanout {
                   uint32_t n_saves = 0, n_steps = 0; bool closed = false; uint32_t first[64]; };   // first[k]: step k's slot in the pinned result ring
     Slot slot[FANOUT_MAX_INFLIGHT];
     uint32_t head = 0, tail = 0;         // tail: slot being filled, head: oldest uncollected
-    uint32_t cap_u128 = 1024;            // checksums per rank a slot can hold (steps x saves)
+    uint32_t cap_u128 = 4096;            // checksums per rank a slot can hold (steps x saves)
     uint32_t interval = 1;               // steps per all-gather
     std::string err;
     int fail(int code, const char* fmt, ...) {
@@ -2157,9 +2232,10 @@ int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t ma
     if (per_rank > max_u128_per_rank || (per_rank && !checksums_out)) return f->fail(GGRS_E_INVALID, "oldest group holds %u checksums per rank, room for %u", per_rank, max_u128_per_rank);
     FANCHK_HIP(f, hipEventSynchronize(s.done));
     // keep the world's own batch queue in step (its checksums are this rank's rows of the gathered table)
+    std::vector<uint64_t> own(2 * (size_t)s.n_saves + 2);
     for (uint32_t k = 0; k < s.n_steps; ++k) {
-        uint64_t own[2 * 256 + 2]; uint32_t got = 0;
-        int rc = ggrs_hip_collect_checksums(w, own, 256, &got);
+        uint32_t got = 0;
+        int rc = ggrs_hip_collect_checksums(w, own.data(), s.n_saves, &got);
         if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
     }
     if (per_rank) memcpy(checksums_out, s.h_recv, (size_t)per_rank * 16 * f->size);

@@ -458,7 +458,7 @@ struct TickArgs {
     uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
     uint32_t n_ops, n_saves, n_steps, src_is_live;
     uint64_t len;
-    uint32_t nt_load, pad_nt;
+    uint32_t nt_load, skip_live;          // skip_live: the live block is overwritten before anyone reads it (a LoadGameState follows): do not write it
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
@@ -520,7 +520,7 @@ __device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_
             st16<NT>(sgpr_base(dst + pos[j]), lo, v[j]);
         }
     }
-    if (!a.src_is_live) {
+    if (!a.src_is_live && !a.skip_live) {
 #pragma unroll
         for (int j = 0; j < B; ++j) st16<false>(sgpr_base(a.live + pos[j]), lo, v[j]);
     }
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
         const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
         for (uint32_t k = 0; k < a.n_saves; ++k)
             if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-        if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+        if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
     }
     u32x4 restv[RESTL > 0 ? RESTL : 1];
     uint64_t restpos[RESTL > 0 ? RESTL : 1];
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
     }
 
     // ---- the live block, written once
-    if (!a.src_is_live || a.n_steps) {
+    if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
         if (in_len) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -823,6 +823,7 @@ struct Tick2Args {
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl, rest_off;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks;
+    uint32_t skip_live, pad_sl;            // skip_live: see TickArgs
     uint64_t rest_mask_off[MAX_MASKS];
     FoldArgs fold;
 };
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
             const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
             for (uint32_t k = 0; k < a.n_saves; ++k)
                 if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-            if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+            if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
         }
 
         uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
         }
 
         // ---- the live block, written once
-        if (!a.src_is_live || a.n_steps) {
+        if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
             if (in_len) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                 const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
                 for (uint32_t k = 0; k < a.n_saves; ++k)
                     if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-                if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+                if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);                       // the loads have landed: the op loop stays free of vmcnt waits
             auto put = [&](uint8_t* dst, bool snapshot, bool with_rest, bool with_presence, int32_t frame) {
@@ -1294,7 +1295,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                 if (dst) { if (!PAIRSYNC) lds_barrier(); put(dst, true, true, true, a.save_frame[si]); par ^= 1u; }
                 ++si;
             }
-            if (!a.src_is_live || a.n_steps) { if (!PAIRSYNC) lds_barrier(); put(a.live, false, !a.src_is_live, !a.src_is_live, 0); par ^= 1u; }
+            if ((!a.src_is_live || a.n_steps) && !a.skip_live) { if (!PAIRSYNC) lds_barrier(); put(a.live, false, !a.src_is_live, !a.src_is_live, 0); par ^= 1u; }
         } else {
             // ================================================= COMPUTE waves
             const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
@@ -1423,7 +1424,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                     }
                 }
             }
-            if (!a.src_is_live || a.n_steps) (void)hand_off();        // the live block, written once (by the store wave)
+            if ((!a.src_is_live || a.n_steps) && !a.skip_live) (void)hand_off();        // the live block, written once (by the store wave)
         }
     }
     tick_fold<512>(a.fold, a.n_saves, a.len, acc, &s_last);
@@ -1478,7 +1479,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
         for (uint32_t k = 0; k < a.n_saves; ++k)
             if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-        if (!a.src_is_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+        if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
     }
     if (in_len && (a.n_saves || !a.src_is_live)) {
         // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0.
@@ -1502,7 +1503,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): land the loads once
             for (uint32_t k = 0; k <= a.n_saves; ++k) {
-                uint8_t* dst = k < a.n_saves ? a.save_dst[k] : (a.src_is_live ? nullptr : a.live);
+                uint8_t* dst = k < a.n_saves ? a.save_dst[k] : ((a.src_is_live || a.skip_live) ? nullptr : a.live);
                 if (!dst) continue;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1560,7 +1561,8 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
             if (lane == 0) {
                 // per-wave partials, folded by k_tick_finalize: an in-kernel fold (tick_fold) LOSES at these sizes -- there is no
                 // long store drain to hide its ticket + acquire + gather behind (10 k: 25.5 vs 23.5 us, 300 k: 59 vs 47 us per tick)
-                uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + (uint64_t)t * 4 + wave;
+                // blockIdx.y: member of a batch of identical checksum-only groups (speculative branches off one snapshot)
+                uint64_t* p = a.parts + ((uint64_t)blockIdx.y * a.n_saves + si) * 3 * a.part_stride + (uint64_t)t * 4 + wave;
                 p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = (uint64_t)__popcll(alive_now);
             }
             ++si;
@@ -1583,7 +1585,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         }
     }
 
-    if (!a.src_is_live || a.n_steps) {
+    if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
         if (in_len) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1978,6 +1980,7 @@ struct GenArgs {
     uint8_t step_flags[MAX_TICK_STEPS];            // bit 0: DespawnConfirmed runs before this step; bit 1: its frame is unconfirmed (despawns are deferred)
     uint32_t marks, pad_m; DespawnMarks dm;
     uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
+    uint32_t skip_live, pad_sl;                        // skip_live: see TickArgs
     uint64_t len, cols_base;
     uint32_t ts, sub, n_words, n_masks, n_units, n_sys, n_cks, part_stride;
     uint64_t mask_off[MAX_MASKS];
@@ -2100,7 +2103,7 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
             }
             ++si;
         }
-        if (!a.src_is_live || a.n_steps) {
+        if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
             lds_barrier();
             image_pull();
             lds_barrier();
@@ -2265,7 +2268,7 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
         }
     }
     // ---- the live block, written once (by the store waves)
-    if (!a.src_is_live || a.n_steps) { lds_barrier(); lds_barrier(); }
+    if ((!a.src_is_live || a.n_steps) && !a.skip_live) { lds_barrier(); lds_barrier(); }
     if (a.marks && a.n_steps) {
         for (uint32_t m = tid; m < mw; m += TPB) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8) = ldis[m];
         for (uint32_t i = tid; i < sub; i += TPB) *reinterpret_cast<int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4) = ldf[i];

@@ -151,7 +151,7 @@ class RcclFanout:
     def set_interval(self, steps_per_all_gather: int):
         self._check(self._lib.ggrs_hip_fanout_set_interval(self._p, steps_per_all_gather))
 
-    def collect(self, max_u128_per_rank: int = 1024) -> np.ndarray:
+    def collect(self, max_u128_per_rank: int = 4096) -> np.ndarray:
         """Oldest all-gather group in flight -> (world_size, n_steps, n_saves, 2) u64 array of {lo, hi} per Save."""
         import ctypes as C
         if getattr(self, "_out", None) is None or self._out.size < self.size * max_u128_per_rank * 2:

@@ -246,7 +246,7 @@ int ggrs_hip_set_synctest_check_distance(ggrs_world* w, int32_t check_distance /
  * batch has finished and copies its checksums ({lo,hi} per SAVE, request order).  ggrs reads a
  * SaveGameState cell (schedule_systems.rs:231-236) no earlier than the next advance_frame(), so a shim
  * collects right before that call and the tick overlaps the rest of the host's frame.  At most 16 batches /
- * 512 checksums may be outstanding; the synchronous calls above refuse to run while any are. */
+ * 8192 checksums (4096 per list) may be outstanding; the synchronous calls above refuse to run while any are. */
 int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out);
 int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t max_saves, uint32_t* n_saves_out);
 uint32_t ggrs_hip_pending_batches(ggrs_world* w);

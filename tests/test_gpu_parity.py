@@ -355,3 +355,55 @@ def test_particles_systems_over_live_only_components_are_rejected():
         with pytest.raises(bg.GgrsHipError) as e:
             w.spawn(10, {T: None, V: None})
         assert e.value.code == bg.GGRS_E_INVALID and "not registered for rollback" in str(e.value)
+
+
+@pytest.mark.parametrize("n,flags", [(30_000, 0), (700_000, 0), (3000, bg.GGRS_WORLD_NO_GROUPS)])
+@pytest.mark.parametrize("generic", [False, True])
+def test_branch_lists_dead_snapshots_and_batches(n, flags, generic, monkeypatch):
+    """A request list holding several speculative branches off one snapshot ([Load(C), Adv, Save, ...] x B): every branch
+    but the last leaves nothing behind but its checksums (the next Load pops its snapshots, mod.rs:210-226), so the
+    library runs it checksum-only and launches identical branches together.  Must equal the oracle executing the same
+    list request by request -- checksums of every branch, ring content and live state -- also when the next Load
+    targets a frame INSIDE the group's saves (not dead) and when a branch spawns (never dead)."""
+    if generic:
+        monkeypatch.setenv("GGRS_TICK_GENERIC", "1")
+        if n > 100_000: pytest.skip("one big size is enough for the generic kernel")
+    D, B = 4, 6
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    fn = cm.frame_spawn_fn(60)
+    res = []
+    for w in (bg.World(n + 4000, max_depth=D + 2, flags=flags), OracleWorld(n + 4000, D + 2, FLAT)):
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=20)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+        w.set_confirmed(0)
+        out = w.handle_requests([bg.SaveGameState(0), bg.AdvanceFrame((0,)), bg.SaveGameState(1)])
+        C = 1
+
+        def adv(frame, spawn):
+            a = bg.AdvanceFrame((cm.INPUT_SPAWN if spawn else 0,))
+            if spawn: a.spawn_vx, a.spawn_vy = fn(frame)
+            return a
+        reqs = []
+        for b in range(B):
+            spawning = b == 2                                   # one branch spawns on every frame: its groups are never dead
+            reqs += [bg.LoadGameState(C)]
+            for i in range(D):
+                reqs += [adv(C + i, spawning), bg.SaveGameState(C + 1 + i)]
+            reqs.append(adv(C + D, spawning))
+        # a partial rollback INTO the last branch's saves: those snapshots are read, the branch before must be alive for it
+        reqs += [bg.LoadGameState(C + 2), adv(C + 2, False), bg.SaveGameState(C + 3)]
+        out += w.handle_requests(reqs)
+        # afterwards every frame the ring still holds must be loadable and hash as saved
+        tail = []
+        for f in (C + 3, C + 2, C):
+            w.handle_requests([bg.LoadGameState(f)])
+            tail.append(w.handle_requests([bg.SaveGameState(f)])[0])
+        res.append((out, tail, cm.snapshot_state(w, ids), w.snapshot_count()))
+    assert res[0][0] == res[1][0]
+    assert res[0][1] == res[1][1]
+    assert res[0][3] == res[1][3]
+    cm.assert_states_equal(res[0][2], res[1][2], "branch lists")
+    nb = D                                                     # checksums per branch
+    first = res[0][0][2:2 + nb]                                # after the two warm-up Saves
+    assert all(res[0][0][2 + b * nb:2 + (b + 1) * nb] == first for b in (1, 3, 4, 5)) and res[0][0][2 + 2 * nb:2 + 3 * nb] != first
