@@ -32,7 +32,8 @@ namespace {
 
 constexpr uint64_t ALIGN = 256;
 constexpr uint64_t TICK_VEC1_MAX_SLOTS = 400 * 1024;   // worlds covering up to this many slots run on k_tick1 (see run_request_groups)
-constexpr int TICK2_RESTL_MAX = 7;     // untouched rows k_tick2 keeps in registers: EXACTLY this many (the stress_test world, kernels.hpp)
+constexpr int TICK2_RESTL_MAX = 7;     // untouched rows k_tick2 / the straight-line k_tick3 keep in registers: EXACTLY this many (the stress_test world)
+constexpr int TICK3_RESTL_ANY = 16;    // k_tick3's general instantiation: up to this many untouched 4-byte rows
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct Comp {
@@ -443,7 +444,7 @@ int seal_impl(ggrs_world* w) {
     }
     // k_tick2 keeps the untouched rows in registers and addresses them as one contiguous run behind the schedule-owned rows
     w->tick2_ok = false;
-    if (w->tick_ok && w->knobs.tick2 && w->tick_proto.n_rest_rows == (uint32_t)TICK2_RESTL_MAX) {
+    if (w->tick_ok && w->knobs.tick2 && (w->tick_proto.n_rest_rows == (uint32_t)TICK2_RESTL_MAX || (w->knobs.tick3 && w->tick_proto.n_rest_rows <= (uint32_t)TICK3_RESTL_ANY))) {
         const TickArgs& t = w->tick_proto;
         const uint64_t base = t.n_rest_rows ? t.rest[0].col_off + t.rest[0].roff : 0;
         bool contig = true;
@@ -1251,6 +1252,13 @@ void launch_tick2(ggrs_world* w, const Tick2Args& a, uint32_t g) {
 
 template <bool NT, int PS>
 void launch_tick3(ggrs_world* w, const Tick2Args& a, uint32_t g) {
+    if (a.n_rest_rows != (uint32_t)TICK2_RESTL) {                      // not the stress_test's 7 rows: the general instantiation
+        if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, NT, TICK3_RESTL_ANY, PS, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, NT, TICK3_RESTL_ANY, PS, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, NT, TICK3_RESTL_ANY, PS, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else hipLaunchKernelGGL((k_tick3<false, false, NT, TICK3_RESTL_ANY, PS, false>), dim3(g), dim3(512), 0, w->stream, a);
+        return;
+    }
     if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
     else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);
     else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, NT, TICK2_RESTL, PS>), dim3(g), dim3(512), 0, w->stream, a);

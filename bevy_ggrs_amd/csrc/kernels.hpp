@@ -1184,7 +1184,9 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
 // PAIRSYNC 0: one workgroup-wide LDS barrier per hand-off.  PAIRSYNC 1: every compute / store pair has its own two-slot
 // ring guarded by LDS flags -- no coupling between the four pairs of a workgroup, and a store wave frees its slot as
 // soon as the rows are in its registers, i.e. BEFORE it starts issuing the (blocking) global stores.
-template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int PAIRSYNC>
+// RESTL / EXACT: the store waves keep up to RESTL untouched 4-byte rows in registers; EXACT: the world has exactly RESTL of
+// them (the stress_test: 7) and the row loops are straight-line code, else every row is guarded by `j < n_rest_rows`.
+template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int PAIRSYNC, bool EXACT = true>
 __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
     __shared__ __attribute__((aligned(16))) u32x4 rowbuf[2][4][8][64];   // [parity][quarter][row][lane]: 64 KiB
     __shared__ uint64_t maskbuf[2][4][4];                                  // the quarter's 4 liveness words per Save
@@ -1239,7 +1241,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
 #pragma unroll
             for (int j = 0; j < RESTL; ++j) {
                 restv[j] = u32x4{0, 0, 0, 0};
-                if (in_len) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
+                if (in_len && (EXACT || (uint32_t)j < a.n_rest_rows)) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
             }
             if (lane < 4u * a.n_rest_masks) {                         // untouched presence masks: fan out (+ live on load)
                 const uint32_t m = lane >> 2, mw = lane & 3u;
@@ -1265,7 +1267,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                         st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
                         st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
 #pragma unroll
-                        for (int j = 0; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        for (int j = 0; j < RESTL; ++j) if (EXACT || (uint32_t)j < a.n_rest_rows) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
                     } else {
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { st16<false>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<false>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
@@ -1273,7 +1275,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                         st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
                         if (with_rest) {
 #pragma unroll
-                            for (int j = 0; j < RESTL; ++j) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                            for (int j = 0; j < RESTL; ++j) if (EXACT || (uint32_t)j < a.n_rest_rows) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
                         }
                     }
                 }

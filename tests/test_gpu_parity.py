@@ -407,3 +407,27 @@ def test_branch_lists_dead_snapshots_and_batches(n, flags, generic, monkeypatch)
     nb = D                                                     # checksums per branch
     first = res[0][0][2:2 + nb]                                # after the two warm-up Saves
     assert all(res[0][0][2 + b * nb:2 + (b + 1) * nb] == first for b in (1, 3, 4, 5)) and res[0][0][2 + 2 * nb:2 + 3 * nb] != first
+
+
+@pytest.mark.parametrize("extra_words,n", [(5, 700_000), (9, 600_000), (12, 650_000)])
+def test_big_world_with_extra_untouched_components(extra_words, n):
+    """The stress_test world plus a component the schedule never touches (7 + extra_words untouched rows): up to 16 such rows
+    stay on the wave-specialised k_tick3 (its store waves carry them), more fall back to k_tick -- either way every Save
+    equals the oracle's and the extra columns survive rollbacks byte for byte."""
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    rng = np.random.default_rng(17)
+    extra = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for _ in range(extra_words)]
+    res = []
+    for w in (bg.World(n, max_depth=9), OracleWorld(n, 9, FLAT)):
+        T, V, L = cm.build_particles(w)
+        X = w.register_component("Extra", 4, extra_words)
+        tcols = [np.full(n, cm.f32bits(cm.TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
+        vcols = [cm.f32bits(vel[:, 0]), cm.f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
+        w.spawn(n, {T: tcols, V: vcols, L: [ttl], X: extra})
+        drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+        for _ in range(11):
+            drv.tick((0,))
+        res.append((drv.all_checksums, cm.snapshot_state(w, (T, V, L, X))))
+        w.close()
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], f"extra={extra_words}")
