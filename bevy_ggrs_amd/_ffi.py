@@ -29,6 +29,7 @@ SYS_PARTICLES_SPAWN = 3
 SYS_ADD_U32 = 4
 SYS_SAT_SUB_DESPAWN = 5
 SYS_BOX_MOVE = 6
+SYS_CUSTOM = 7
 
 COMP_ROLLBACK, COMP_NO_ROLLBACK = 0, 1
 DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK = 0, 1
@@ -48,6 +49,15 @@ class WorldDesc(C.Structure):
 
 class SystemDesc(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("comp", C.c_uint32 * 4), ("word", C.c_uint32 * 4),
+                ("iparam", C.c_int64 * 2), ("fparam", C.c_float * 4)]
+
+
+CUSTOM_MAX_BINDINGS = 8
+
+
+class CustomSystemDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("source", C.c_char_p), ("n_bindings", C.c_uint32),
+                ("comp", C.c_uint32 * CUSTOM_MAX_BINDINGS), ("word", C.c_uint32 * CUSTOM_MAX_BINDINGS),
                 ("iparam", C.c_int64 * 2), ("fparam", C.c_float * 4)]
 
 
@@ -72,6 +82,7 @@ SIGNATURES = {
     "ggrs_hip_set_component_default": (C.c_int, [_P, C.c_uint32, _P]),
     "ggrs_hip_checksum_component": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
     "ggrs_hip_add_system": (C.c_int, [_P, C.POINTER(SystemDesc)]),
+    "ggrs_hip_add_custom_system": (C.c_int, [_P, C.POINTER(CustomSystemDesc)]),
     "ggrs_hip_set_frame_rate": (C.c_int, [_P, C.c_uint64]),
     "ggrs_hip_spawn": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ggrs_hip_despawn": (C.c_int, [_P, C.c_uint64]),

@@ -10,6 +10,7 @@
 // There is NO CPU fallback: without a HIP device world creation fails with GGRS_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>   // types and prototypes only: resolved with dlsym on first use (no link-time dependency)
 #include <rccl/rccl.h>      // types and prototypes only: every entry point is resolved with dlsym (no link-time dependency)
 #include <dlfcn.h>
 #include <math.h>
@@ -117,6 +118,13 @@ struct ggrs_world {
 
     std::vector<Comp> comps;
     std::vector<ggrs_system_desc> systems;
+    struct Custom {                      // GGRS_SYS_CUSTOM: a hiprtc-compiled per-entity system (systems[i].comp[0] indexes this)
+        std::string name;
+        hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
+        uint32_t n_bind = 0, comp[GGRS_CUSTOM_MAX_BINDINGS] = {}, word[GGRS_CUSTOM_MAX_BINDINGS] = {};
+        uint32_t n_pres = 0, pres_comp[GGRS_CUSTOM_MAX_BINDINGS] = {};
+    };
+    std::vector<Custom> customs;
     bool sealed = false;
     int seal_error = 0;                  // a failed seal latches: every later call reports it instead of re-carving the arena
     Knobs knobs;
@@ -954,6 +962,156 @@ void launch_step_fused(ggrs_world* w, const StepArgs& a, uint32_t g) {
     hipLaunchKernelGGL((k_particles_step<true, true, CT, CV>), dim3(g), dim3(TPB), 0, w->stream, a);
 }
 
+// ---- GGRS_SYS_CUSTOM: user-written per-entity systems, compiled with hiprtc for gfx950 ----------------------------
+// The argument block of the generated kernel.  The SAME text is compiled on the host (below) and pasted into the
+// generated device source, and the device source static_asserts the host's sizeof: the two cannot drift.
+#define GGRS_CUSTOM_ABI_TEXT \
+    "typedef unsigned long long ggrs_u64; typedef unsigned int ggrs_u32;\n" \
+    "struct GgrsFrame { float dt; int frame; ggrs_u32 n_inputs; unsigned char input[16]; float fparam[4]; long long iparam[2]; };\n" \
+    "struct GgrsCustomArgs {\n" \
+    "    unsigned char* state;\n" \
+    "    ggrs_u64 off_alive, off_disabled, off_dframe, len_pad64;\n" \
+    "    ggrs_u64 off_present[8], col_off[8];\n" \
+    "    ggrs_u32 ts[8];\n" \
+    "    int defer, pad;\n" \
+    "    GgrsFrame fr;\n" \
+    "};\n"
+typedef unsigned long long ggrs_u64; typedef unsigned int ggrs_u32;
+struct GgrsFrame { float dt; int frame; ggrs_u32 n_inputs; unsigned char input[16]; float fparam[4]; long long iparam[2]; };
+struct GgrsCustomArgs {
+    unsigned char* state;
+    ggrs_u64 off_alive, off_disabled, off_dframe, len_pad64;
+    ggrs_u64 off_present[8], col_off[8];
+    ggrs_u32 ts[8];
+    int defer, pad;
+    GgrsFrame fr;
+};
+static_assert(GGRS_CUSTOM_MAX_BINDINGS == 8, "GgrsCustomArgs is sized for 8 bindings");
+
+struct Hiprtc {
+    void* lib = nullptr; bool tried = false; std::string why;
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    decltype(&hiprtcGetErrorString) err_str = nullptr;
+};
+Hiprtc& hiprtc() {
+    static Hiprtc r;
+    if (r.tried) return r;
+    r.tried = true;
+    const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib) { r.why = "libhiprtc.so not found (custom systems need the ROCm runtime compiler)"; return r; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) { ok = false; r.why = std::string("libhiprtc lacks ") + n; } return p; };
+    r.create = (decltype(r.create))sym("hiprtcCreateProgram");
+    r.compile = (decltype(r.compile))sym("hiprtcCompileProgram");
+    r.log_size = (decltype(r.log_size))sym("hiprtcGetProgramLogSize");
+    r.log = (decltype(r.log))sym("hiprtcGetProgramLog");
+    r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
+    r.code = (decltype(r.code))sym("hiprtcGetCode");
+    r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+    r.err_str = (decltype(r.err_str))sym("hiprtcGetErrorString");
+    if (!ok) r.lib = nullptr;
+    return r;
+}
+
+// The generated translation unit: ABI text, the entity view, the user's source, and a one-slot-per-lane kernel whose
+// binding count and word widths are compile-time constants (so e.w[] lives in registers, not scratch).
+std::string custom_source(const ggrs_world* w, const ggrs_world::Custom& c, const char* user) {
+    std::string s;
+    s += GGRS_CUSTOM_ABI_TEXT;
+    char buf[256];
+    snprintf(buf, sizeof buf, "static_assert(sizeof(GgrsCustomArgs) == %zu, \"host/device argument block mismatch\");\n", sizeof(GgrsCustomArgs));
+    s += buf;
+    s += "struct GgrsEntity {\n"
+         "    ggrs_u64 slot; ggrs_u64 w[8]; int kill;\n"
+         "    __device__ float& f32(int i) { return *reinterpret_cast<float*>(&w[i]); }\n"
+         "    __device__ ggrs_u32& u32(int i) { return *reinterpret_cast<ggrs_u32*>(&w[i]); }\n"
+         "    __device__ int& i32(int i) { return *reinterpret_cast<int*>(&w[i]); }\n"
+         "    __device__ ggrs_u64& u64(int i) { return w[i]; }\n"
+         "    __device__ void despawn() { if (kill == 0) kill = 1; }\n"
+         "    __device__ void despawn_rollback() { kill = 2; }\n"
+         "};\n"
+         "#line 1 \"ggrs_system\"\n";
+    s += user;
+    snprintf(buf, sizeof buf, "\n#line 1 \"ggrs_custom_kernel\"\n#define GGRS_N_BIND %u\n#define GGRS_N_PRES %u\n", c.n_bind, c.n_pres);
+    s += buf;
+    s += "__device__ constexpr int GGRS_WB[8] = {";
+    for (uint32_t i = 0; i < 8; ++i) { snprintf(buf, sizeof buf, "%u,", i < c.n_bind ? w->comps[c.comp[i]].word_bytes : 4u); s += buf; }
+    s += "};\n";
+    snprintf(buf, sizeof buf, "#define GGRS_LT_SHIFT %d\n", LT_SHIFT);
+    s += buf;
+    s += "extern \"C\" __global__ __launch_bounds__(256) void ggrs_custom_kernel(GgrsCustomArgs a) {\n"
+         "    const ggrs_u64 e = (ggrs_u64)blockIdx.x * 256 + threadIdx.x;\n"
+         "    if (e >= a.len_pad64) return;                         // whole waves only (len padded to 64)\n"
+         "    const ggrs_u64 aw = *reinterpret_cast<const ggrs_u64*>(a.state + a.off_alive + (e >> 6) * 8);\n"
+         "    ggrs_u64 on = aw;\n"
+         "    #pragma unroll\n"
+         "    for (int p = 0; p < GGRS_N_PRES; ++p) on &= *reinterpret_cast<const ggrs_u64*>(a.state + a.off_present[p] + (e >> 6) * 8);\n"
+         "    bool alive = (aw >> (e & 63)) & 1ULL;\n"
+         "    int kill = 0;\n"
+         "    if ((on >> (e & 63)) & 1ULL) {\n"
+         "        GgrsEntity ent; ent.slot = e; ent.kill = 0;\n"
+         "        unsigned char* at[8];\n"
+         "        #pragma unroll\n"
+         "        for (int i = 0; i < GGRS_N_BIND; ++i) {\n"
+         "            at[i] = a.state + a.col_off[i] + (e >> GGRS_LT_SHIFT) * a.ts[i] + (e & ((1ULL << GGRS_LT_SHIFT) - 1)) * GGRS_WB[i];\n"
+         "            ent.w[i] = GGRS_WB[i] == 8 ? *reinterpret_cast<const ggrs_u64*>(at[i]) : (ggrs_u64)*reinterpret_cast<const ggrs_u32*>(at[i]);\n"
+         "        }\n"
+         "        ggrs_system(ent, a.fr);\n"
+         "        #pragma unroll\n"
+         "        for (int i = 0; i < GGRS_N_BIND; ++i) {\n"
+         "            if (GGRS_WB[i] == 8) *reinterpret_cast<ggrs_u64*>(at[i]) = ent.w[i];\n"
+         "            else *reinterpret_cast<ggrs_u32*>(at[i]) = (ggrs_u32)ent.w[i];\n"
+         "        }\n"
+         "        kill = ent.kill;\n"
+         "    }\n"
+         "    if (kill) alive = false;\n"
+         "    const ggrs_u64 nw = __builtin_amdgcn_ballot_w64(alive);\n"
+         "    if ((threadIdx.x & 63u) == 0 && nw != aw) *reinterpret_cast<ggrs_u64*>(a.state + a.off_alive + (e >> 6) * 8) = nw;\n"
+         "    if (a.defer) {                                        // despawn_rollback on an unconfirmed frame: RollbackDespawned(frame)\n"
+         "        const bool mark = kill == 2;\n"
+         "        const ggrs_u64 kw = __builtin_amdgcn_ballot_w64(mark);\n"
+         "        if (mark) *reinterpret_cast<int*>(a.state + a.off_dframe + e * 4) = a.fr.frame;\n"
+         "        if ((threadIdx.x & 63u) == 0 && kw) *reinterpret_cast<ggrs_u64*>(a.state + a.off_disabled + (e >> 6) * 8) |= kw;\n"
+         "    }\n"
+         "}\n";
+    return s;
+}
+
+int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs) {
+    const ggrs_world::Custom& c = w->customs[s.comp[0]];
+    GgrsCustomArgs a; memset(&a, 0, sizeof a);
+    a.state = w->live.ptr; a.off_alive = w->off_alive;
+    a.off_disabled = w->marks.off_disabled; a.off_dframe = w->marks.off_dframe;
+    a.len_pad64 = align_up(w->len, 64);
+    for (uint32_t p = 0; p < c.n_pres; ++p) a.off_present[p] = w->off_present[c.pres_comp[p]];
+    for (uint32_t i = 0; i < c.n_bind; ++i) {
+        const uint32_t col = w->comps[c.comp[i]].col_base + c.word[i];
+        a.col_off[i] = w->col_off[col]; a.ts[i] = w->col_ts[col];
+    }
+    // despawn_rollback (despawn.rs:129-142): only an unconfirmed frame defers the despawn.  Whether the source calls it is
+    // not known to the host, so the markers are assumed possible whenever deferral is on.
+    a.defer = (w->confirmed < w->frame) ? 1 : 0;
+    if (a.defer) w->marks_possible = true;
+    memcpy(&a.fr.dt, &dt_bits, 4);
+    a.fr.frame = w->frame;
+    a.fr.n_inputs = std::min<uint32_t>(n_inputs, 16);
+    for (uint32_t k = 0; k < a.fr.n_inputs; ++k) a.fr.input[k] = inputs[k];
+    for (int k = 0; k < 4; ++k) a.fr.fparam[k] = s.fparam[k];
+    a.fr.iparam[0] = s.iparam[0]; a.fr.iparam[1] = s.iparam[1];
+    const uint32_t gx = (uint32_t)((a.len_pad64 + 255) / 256);
+    if (gx == 0) return GGRS_OK;
+    void* params[] = {&a};
+    HIPCHK(w, hipModuleLaunchKernel(c.fn, gx, 1, 1, 256, 1, 1, 0, w->stream, params, nullptr));
+    return GGRS_OK;
+}
+
 // ---- AdvanceWorld
 int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
                uint64_t spawn_count, const float* spawn_vx, const float* spawn_vy) {
@@ -1051,6 +1209,7 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                     for (uint32_t k = 0; k < a.n_inputs; ++k) a.inputs[k] = inputs[k];
                     hipLaunchKernelGGL(k_box_move, dim3((uint32_t)((w->len + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, a);
                 } break;
+                case GGRS_SYS_CUSTOM: { rc = launch_custom(w, s, dt_bits, inputs, n_inputs); if (rc) return rc; } break;
                 default: break;
                 }
             }
@@ -1607,6 +1766,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
+    for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
     if (w->d_gen_words) (void)hipFree(w->d_gen_words);
     if (w->d_gen_units) (void)hipFree(w->d_gen_units);
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
@@ -1670,6 +1830,55 @@ int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* d) {
     }
     if (!ok) return w->fail(GGRS_E_INVALID, "system %u does not match the registered components", d->kind);
     w->systems.push_back(*d);
+    return GGRS_OK;
+}
+int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* d) {
+    if (!w || !d || !d->source) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "add_custom_system after the world was sealed");
+    if (w->systems.size() >= GGRS_MAX_SYSTEMS) return w->fail(GGRS_E_INVALID, "too many systems");
+    if (d->n_bindings == 0 || d->n_bindings > GGRS_CUSTOM_MAX_BINDINGS) return w->fail(GGRS_E_INVALID, "custom system: 1..%d bindings", GGRS_CUSTOM_MAX_BINDINGS);
+    ggrs_world::Custom c;
+    c.name = d->name ? d->name : "custom";
+    c.n_bind = d->n_bindings;
+    for (uint32_t i = 0; i < c.n_bind; ++i) {
+        if (d->comp[i] >= w->comps.size() || d->word[i] >= w->comps[d->comp[i]].n_words)
+            return w->fail(GGRS_E_INVALID, "custom system '%s': binding %u names word %u of component %u, which is not registered", c.name.c_str(), i, d->word[i], d->comp[i]);
+        c.comp[i] = d->comp[i]; c.word[i] = d->word[i];
+        bool seen = false;
+        for (uint32_t p = 0; p < c.n_pres; ++p) seen |= c.pres_comp[p] == d->comp[i];
+        if (!seen) c.pres_comp[c.n_pres++] = d->comp[i];
+    }
+    Hiprtc& rtc = hiprtc();
+    if (!rtc.lib) return w->fail(GGRS_E_HIP, "custom system '%s': %s", c.name.c_str(), rtc.why.c_str());
+    DeviceGuard dg(w);
+    const std::string src = custom_source(w, c, d->source);
+    hiprtcProgram prog = nullptr;
+    hiprtcResult r = rtc.create(&prog, src.c_str(), "ggrs_custom.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return w->fail(GGRS_E_HIP, "hiprtcCreateProgram: %s", rtc.err_str(r));
+    // the same floating-point contract as the built-in kernels (csrc/Makefile): no contraction, no fast-math
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"};
+    r = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0; std::string log;
+        if (rtc.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); (void)rtc.log(prog, &log[0]); }
+        (void)rtc.destroy(&prog);
+        if (log.size() > 3000) log.resize(3000);
+        w->err = "custom system '" + c.name + "' does not compile (" + rtc.err_str(r) + "):\n" + log;   // the whole log, not fail()'s 512 bytes
+        return GGRS_E_INVALID;
+    }
+    size_t nbytes = 0;
+    std::vector<char> image;
+    if (rtc.code_size(prog, &nbytes) == HIPRTC_SUCCESS && nbytes) { image.resize(nbytes); r = rtc.code(prog, image.data()); } else r = HIPRTC_ERROR_INTERNAL_ERROR;
+    (void)rtc.destroy(&prog);
+    if (r != HIPRTC_SUCCESS) return w->fail(GGRS_E_HIP, "hiprtcGetCode: %s", rtc.err_str(r));
+    HIPCHK(w, hipModuleLoadData(&c.mod, image.data()));
+    if (hipModuleGetFunction(&c.fn, c.mod, "ggrs_custom_kernel") != hipSuccess) { (void)hipModuleUnload(c.mod); return w->fail(GGRS_E_HIP, "custom system '%s': kernel symbol missing from the compiled module", c.name.c_str()); }
+    ggrs_system_desc sd; memset(&sd, 0, sizeof sd);
+    sd.kind = GGRS_SYS_CUSTOM; sd.comp[0] = (uint32_t)w->customs.size();
+    sd.iparam[0] = d->iparam[0]; sd.iparam[1] = d->iparam[1];
+    for (int k = 0; k < 4; ++k) sd.fparam[k] = d->fparam[k];
+    w->customs.push_back(std::move(c));
+    w->systems.push_back(sd);
     return GGRS_OK;
 }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }

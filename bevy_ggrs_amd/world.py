@@ -266,6 +266,20 @@ class World(WorldBase):
         self._comps = []
         self.capacity = capacity
 
+    def add_custom_system(self, source: str, bindings: Sequence[tuple], iparam=(), fparam=(), name: str = "custom"):
+        """add_systems(GgrsSchedule, <your system>) for a per-entity system written in HIP C++ (ggrs_hip_add_custom_system):
+        `source` defines `__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f)`, `bindings` = [(comp, word), ..]
+        are the words it sees as e.f32(i)/e.u32(i)/e.i32(i)/e.u64(i).  Compiled for gfx950 when added; a compile error raises
+        GgrsHipError carrying the compiler log."""
+        d = _ffi.CustomSystemDesc()
+        d.name, d.source, d.n_bindings = name.encode(), source.encode(), len(bindings)
+        if len(bindings) > _ffi.CUSTOM_MAX_BINDINGS:
+            raise ValueError(f"at most {_ffi.CUSTOM_MAX_BINDINGS} bindings")
+        for i, (c, w) in enumerate(bindings): d.comp[i], d.word[i] = c, w
+        for i, v in enumerate(iparam): d.iparam[i] = v
+        for i, v in enumerate(fparam): d.fparam[i] = v
+        self._check(self._lib.ggrs_hip_add_custom_system(self._p, C.byref(d)))
+
     def close(self):
         if getattr(self, "_p", None):
             self._lib.ggrs_hip_world_destroy(self._p)

@@ -321,6 +321,17 @@ struct KernelSystem {                  // one system of the GgrsSchedule, execut
     float fparam[4] = {0, 0, 0, 0};
 };
 
+// A user-written per-entity system: HIP C++ source defining `__device__ void ggrs_system(GgrsEntity&, const GgrsFrame&)`,
+// compiled for gfx950 when it is added (ggrs_hip_add_custom_system).  bind<T>(word) appends the next e.f32(i)/e.u32(i)/e.u64(i).
+struct CustomKernelSystem {
+    std::string name, source;
+    std::vector<std::pair<std::string, uint32_t>> bindings;      // (component name, word)
+    int64_t iparam[2] = {0, 0};
+    float fparam[4] = {0, 0, 0, 0};
+    CustomKernelSystem(std::string n, std::string src) : name(std::move(n)), source(std::move(src)) {}
+    template <class T> CustomKernelSystem& bind(uint32_t word) { bindings.emplace_back(HipComponent<T>::name, word); return *this; }
+};
+
 namespace systems {
 // examples/stress_tests/particles.rs:272-280
 template <class TransformT, class VelocityT>
@@ -374,6 +385,7 @@ struct HipBackend {
     int set_component_default(uint32_t c, const void* p) { return ggrs_hip_set_component_default(w, c, p); }
     int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return ggrs_hip_checksum_component(w, c, idx, n); }
     int add_system(const ggrs_system_desc* d) { return ggrs_hip_add_system(w, d); }
+    int add_custom_system(const ggrs_custom_system_desc* d) { return ggrs_hip_add_custom_system(w, d); }
     int set_frame_rate(uint64_t fps) { return ggrs_hip_set_frame_rate(w, fps); }
     int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return ggrs_hip_spawn(w, count, mask, cols, first); }
     int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
@@ -436,6 +448,17 @@ class App {
         check(be_.add_system(&d));
         has_spawn_system_ |= s.kind == GGRS_SYS_PARTICLES_SPAWN;
         if (s.kind == GGRS_SYS_PARTICLES_SPAWN) spawn_mask_ = (uint8_t)s.iparam[1];
+        return *this;
+    }
+    // add_systems(GgrsSchedule, <user system>): a compile error throws with the hiprtc log
+    App& add_systems(GgrsSchedule, const CustomKernelSystem& s) {
+        if (s.bindings.size() > GGRS_CUSTOM_MAX_BINDINGS) throw std::invalid_argument("a custom kernel system binds at most 8 words");
+        ggrs_custom_system_desc d; std::memset(&d, 0, sizeof d);
+        d.name = s.name.c_str(); d.source = s.source.c_str(); d.n_bindings = (uint32_t)s.bindings.size();
+        for (size_t k = 0; k < s.bindings.size(); ++k) { d.comp[k] = comp_id(s.bindings[k].first); d.word[k] = s.bindings[k].second; }
+        for (int k = 0; k < 4; ++k) d.fparam[k] = s.fparam[k];
+        d.iparam[0] = s.iparam[0]; d.iparam[1] = s.iparam[1];
+        check(be_.add_custom_system(&d));
         return *this;
     }
     // host-side stand-in for the rolled-back ParticleRng resource (particles.rs:125,201): must be a

@@ -139,6 +139,41 @@ typedef struct {
 
 int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* desc);
 
+/* A user-written GgrsSchedule system, compiled for gfx950 at run time (hiprtc; libhiprtc is dlopen'ed on first use).
+ * The reference lets an app add ANY Bevy system to GgrsSchedule (lib.rs:76, 247-251; e.g. examples/particles/
+ * particles.rs:152-160); the kinds above are that set restated as kernels, and this is the open door next to them for a
+ * system of the common shape  Query<(&mut A, &mut B, ..), With<Rollback>>  + Commands: it sees ONE entity at a time.
+ * `source` is HIP C++ that defines
+ *
+ *     __device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f);
+ *
+ *   e.f32(i) / e.u32(i) / e.i32(i) / e.u64(i)   reference to bound word i  (binding i = word `word[i]` of component `comp[i]`;
+ *                                               4-byte words as f32/u32/i32, 8-byte words as u64), written back afterwards
+ *   e.slot                                      the entity's RollbackOrdered index (snapshot/rollback.rs:69-74)
+ *   e.despawn() / e.despawn_rollback()          commands.entity(e).despawn() / .despawn_rollback() (snapshot/despawn.rs:114-143)
+ *   f.dt  f.frame  f.n_inputs  f.input[16]      Time<GgrsTime>::delta_secs (time.rs), the frame being simulated,
+ *                                               PlayerInputs (one byte per handle; schedule_systems.rs:262-265)
+ *   f.fparam[4]  f.iparam[2]                    the desc's constants
+ *
+ * The system runs for every live entity that has all bound components, in registration order with the other systems;
+ * despawns take effect before the next system, as with the built-in kinds.  The code is compiled with -ffp-contract=off
+ * and correctly rounded fp32 divide/sqrt: what the source says is what runs, bit for bit, on every rank and every replay
+ * -- determinism is the author's contract exactly as it is for a Bevy system (no atomics, no cross-entity reads).
+ * A world with a custom system is stepped request by request (one launch per system; the fused k_tick* kernels only
+ * know the built-in kinds).  A compile error returns GGRS_E_INVALID with the compiler log in ggrs_hip_last_error. */
+#define GGRS_SYS_CUSTOM 7u
+#define GGRS_CUSTOM_MAX_BINDINGS 8
+typedef struct {
+    const char* name;                               /* for error messages and traces; may be NULL               */
+    const char* source;                             /* HIP C++ defining ggrs_system (NUL-terminated)            */
+    uint32_t n_bindings;
+    uint32_t comp[GGRS_CUSTOM_MAX_BINDINGS];
+    uint32_t word[GGRS_CUSTOM_MAX_BINDINGS];
+    int64_t  iparam[2];
+    float    fparam[4];
+} ggrs_custom_system_desc;
+int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* desc);
+
 /* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);
 

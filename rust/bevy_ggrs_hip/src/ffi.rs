@@ -26,6 +26,8 @@ pub const GGRS_SYS_PARTICLES_SPAWN: u32 = 3;
 pub const GGRS_SYS_ADD_U32: u32 = 4;
 pub const GGRS_SYS_SAT_SUB_DESPAWN: u32 = 5;
 pub const GGRS_SYS_BOX_MOVE: u32 = 6;
+pub const GGRS_SYS_CUSTOM: u32 = 7;
+pub const GGRS_CUSTOM_MAX_BINDINGS: usize = 8;
 pub const GGRS_DESPAWN_IMMEDIATE: i64 = 0;
 pub const GGRS_DESPAWN_ROLLBACK: i64 = 1;
 
@@ -69,6 +71,18 @@ pub struct ggrs_system_desc {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct ggrs_custom_system_desc {
+    pub name: *const c_char,
+    pub source: *const c_char,
+    pub n_bindings: u32,
+    pub comp: [u32; GGRS_CUSTOM_MAX_BINDINGS],
+    pub word: [u32; GGRS_CUSTOM_MAX_BINDINGS],
+    pub iparam: [i64; 2],
+    pub fparam: [f32; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct ggrs_request {
     pub kind: u32,
     pub frame: i32,
@@ -100,6 +114,7 @@ unsafe extern "C" {
     pub fn ggrs_hip_set_component_default(w: *mut ggrs_world, comp_id: u32, words: *const c_void) -> c_int;
     pub fn ggrs_hip_checksum_component(w: *mut ggrs_world, comp_id: u32, word_idx: *const u32, n_idx: u32) -> c_int;
     pub fn ggrs_hip_add_system(w: *mut ggrs_world, desc: *const ggrs_system_desc) -> c_int;
+    pub fn ggrs_hip_add_custom_system(w: *mut ggrs_world, desc: *const ggrs_custom_system_desc) -> c_int;
     pub fn ggrs_hip_set_frame_rate(w: *mut ggrs_world, fps: u64) -> c_int;
     // ---- entities and host <-> device column traffic
     pub fn ggrs_hip_spawn(w: *mut ggrs_world, count: u64, comp_mask: u64, cols: *const *const c_void, first_slot: *mut u64) -> c_int;

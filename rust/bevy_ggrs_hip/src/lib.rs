@@ -343,6 +343,33 @@ pub struct KernelSystem {
     comps: [Option<fn(&HipWorld) -> u32>; 4],
 }
 
+/// A per-entity `GgrsSchedule` system written as HIP C++ source and compiled for gfx950 when it is added
+/// (include/ggrs_hip.h `ggrs_hip_add_custom_system`): the open counterpart of [`KernelSystem`] for systems of the shape
+/// `Query<(&mut A, &mut B, ..), With<Rollback>>` + `Commands::despawn`.  `source` defines
+/// `__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f)`; binding `i` is seen as `e.f32(i)` / `e.u32(i)` / `e.u64(i)`.
+pub struct CustomKernelSystem {
+    pub name: &'static str,
+    pub source: String,
+    pub bindings: Vec<(fn(&HipWorld) -> u32, u32)>,
+    pub iparam: [i64; 2],
+    pub fparam: [f32; 4],
+}
+impl CustomKernelSystem {
+    pub fn new(name: &'static str, source: impl Into<String>) -> Self {
+        CustomKernelSystem { name, source: source.into(), bindings: Vec::new(), iparam: [0; 2], fparam: [0.0; 4] }
+    }
+    /// Bind word `word` of component `T` as the next `e.*(i)`.
+    pub fn bind<T: HipComponent>(mut self, word: u32) -> Self {
+        self.bindings.push((HipWorld::comp_id::<T>, word));
+        self
+    }
+    pub fn with_params(mut self, iparam: [i64; 2], fparam: [f32; 4]) -> Self {
+        self.iparam = iparam;
+        self.fparam = fparam;
+        self
+    }
+}
+
 pub mod systems {
     use super::*;
     /// examples/stress_tests/particles.rs:272-280
@@ -393,6 +420,8 @@ pub trait RollbackApp {
     /// (each word is fed to SeaHash as its little-endian bytes, i.e. `write_u32` / `write_u64`).
     fn checksum_component<T: HipComponent>(&mut self, hashed_words: &[u32]) -> &mut Self;
     fn add_kernel_system(&mut self, schedule: GgrsSchedule, system: KernelSystem) -> &mut Self;
+    /// `add_systems(GgrsSchedule, ..)` for a user-written per-entity system (HIP C++ source, compiled at registration).
+    fn add_custom_kernel_system(&mut self, schedule: GgrsSchedule, system: CustomKernelSystem) -> &mut Self;
     /// Keep the Bevy copy of `T` current for host-side readers (rendering); off by default: it is a device -> host
     /// copy of the whole column every rendered frame.
     fn mirror_component<T: HipComponent>(&mut self) -> &mut Self;
@@ -454,6 +483,28 @@ impl RollbackApp for App {
         }
         let rc = unsafe { ffi::ggrs_hip_add_system(w.raw, &desc) };
         w.check(rc);
+        self
+    }
+    fn add_custom_kernel_system(&mut self, _schedule: GgrsSchedule, system: CustomKernelSystem) -> &mut Self {
+        let w = hip_world(self);
+        let name = std::ffi::CString::new(system.name).expect("system name");
+        let source = std::ffi::CString::new(system.source).expect("system source");
+        let mut desc = ffi::ggrs_custom_system_desc {
+            name: name.as_ptr(),
+            source: source.as_ptr(),
+            n_bindings: system.bindings.len() as u32,
+            comp: [0; ffi::GGRS_CUSTOM_MAX_BINDINGS],
+            word: [0; ffi::GGRS_CUSTOM_MAX_BINDINGS],
+            iparam: system.iparam,
+            fparam: system.fparam,
+        };
+        assert!(system.bindings.len() <= ffi::GGRS_CUSTOM_MAX_BINDINGS, "a custom kernel system binds at most 8 words");
+        for (k, (comp, word)) in system.bindings.iter().enumerate() {
+            desc.comp[k] = comp(&w);
+            desc.word[k] = *word;
+        }
+        let rc = unsafe { ffi::ggrs_hip_add_custom_system(w.raw, &desc) };
+        w.check(rc); // a compile error panics with the hiprtc log (ggrs_hip_last_error), like a system that fails to build
         self
     }
     fn mirror_component<T: HipComponent>(&mut self) -> &mut Self {
