@@ -75,6 +75,13 @@ struct Knobs {
     bool tick2 = true;             // GGRS_TICK2=0          big worlds on the round-1 k_tick + k_tick_finalize pair instead of k_tick2
     int tick2_wgs_per_cu = 2;      // GGRS_TICK2_WGS=n      persistent workgroups per CU of k_tick2 (0: one workgroup per tile, not persistent)
     int tick2_nt = 1;              // GGRS_TICK2_NT=0|1     non-temporal snapshot stores in k_tick2
+    int tick1_dp = 1;              // GGRS_TICK1_DP=0       k_tick1 without the depth-parallel grid (one workgroup walks the whole group);
+                                   //               =2..9   A/B: that many outputs per role, up to GGRS_TICK1_DP_MAX_SLOTS2 slots
+    uint64_t tick1_dp_max_slots = 40 * 1024;    // GGRS_TICK1_DP_MAX_SLOTS   largest world that uses one output per role (x2: two, x4: three)
+    uint64_t tick1_dp_max_slots2 = 400 * 1024;
+    int gen_sub = 0;               // GGRS_GEN_SUB=256|512|1024   A/B: slots per k_tick_gen workgroup (0: by world size)
+    int gen_dp = 1;                // GGRS_GEN_DP=0         k_tick_gen without depth-parallel roles; =2..9  A/B: that many outputs per role
+    uint64_t gen_dp_max_slots = 160 * 1024;     // GGRS_GEN_DP_MAX_SLOTS     largest world the A/B setting applies to
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int tick2_ilv = 0;             // GGRS_TICK2_ILV=0|1    Save = store burst + hash (0) or stores spaced out between the hash multiplies (1)
     uint64_t tick2_min_slots = 500 * 1024;   // GGRS_TICK2_MIN_SLOTS  worlds covering more slots than this run on k_tick3 / k_tick2
@@ -99,6 +106,12 @@ struct Knobs {
         k.tick2_nt = num("GGRS_TICK2_NT", 1) != 0;
         k.tick2_ilv = num("GGRS_TICK2_ILV", 0) != 0;
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
+        { const long long v = num("GGRS_GEN_SUB", 0); k.gen_sub = (v == 256 || v == 512 || v == 1024) ? (int)v : 0; }
+        k.gen_dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_GEN_DP", 1)));
+        k.gen_dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_GEN_DP_MAX_SLOTS", 160 * 1024));
+        k.tick1_dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_TICK1_DP", 1)));
+        k.tick1_dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_TICK1_DP_MAX_SLOTS", 40 * 1024));
+        k.tick1_dp_max_slots2 = (uint64_t)std::max<long long>(0, num("GGRS_TICK1_DP_MAX_SLOTS2", 400 * 1024));
         k.tick3 = (int)std::min<long long>(2, std::max<long long>(0, num("GGRS_TICK3", 2)));
         k.tick2_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_TICK2_MIN_SLOTS", 500 * 1024));
         return k;
@@ -1356,12 +1369,37 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves) {
     w->pending_valid = false;
 }
 
+// Depth-parallel k_tick1 (kernels.hpp): the group's outputs (Saves + live world) are split over grid.z roles of dp_s outputs.
+// Every role reads the source block while the others write theirs, so the source must be none of the destinations; below
+// ~2 Saves there is no chain to split.  Returns dp_s (0: one workgroup walks the whole group).
+uint32_t tick1_depth_parallel(const ggrs_world* w, const TickArgs& a, uint64_t cover) {
+    if (!w->knobs.tick1_dp || a.n_saves < 2) return 0;
+    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
+    if (writes_live && a.src == a.live) return 0;
+    for (uint32_t k = 0; k < a.n_saves; ++k) if (a.save_dst[k] == a.src) return 0;
+    if (w->knobs.tick1_dp > 1) return cover <= w->knobs.tick1_dp_max_slots2 ? (uint32_t)w->knobs.tick1_dp : 0;    // A/B: fixed split
+    // measured crossovers, us per depth-8 tick (profiles/r02dp/ab2.txt):   10k    30k    50k    70k   100k   200k   300k
+    //   whole group per workgroup                                           23.0   23.7   24.3   26.3   27.0   37.3   45.1
+    //   1 output per role                                                   15.4   17.4   22.4   26.2   32.2   51.2   69.5
+    //   2 outputs per role                                                  16.5   17.6   19.8   22.6   27.8   40.7   54.7
+    //   3 outputs per role                                                  16.9   18.2   20.2   22.8   25.3   36.8   48.0
+    if (cover <= w->knobs.tick1_dp_max_slots) return 1;
+    if (cover <= 2 * w->knobs.tick1_dp_max_slots) return 2;
+    if (cover <= 4 * w->knobs.tick1_dp_max_slots) return 3;
+    return 0;
+}
+template <bool NT, bool DP>
+void launch_tick1_dp(ggrs_world* w, const TickArgs& a, uint32_t g, uint32_t batch) {
+    const dim3 grid(g, batch, DP ? (a.n_saves + 1 + a.dp_s - 1) / a.dp_s : 1);
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT, DP>), grid, dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick1<true, false, NT, DP>), grid, dim3(TPB), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick1<false, true, NT, DP>), grid, dim3(TPB), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick1<false, false, NT, DP>), grid, dim3(TPB), 0, w->stream, a);
+}
 template <bool NT>
-void launch_tick1(ggrs_world* w, const TickArgs& a, uint32_t g, uint32_t batch = 1) {
-    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick1<true, true, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksT) hipLaunchKernelGGL((k_tick1<true, false, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
-    else if (w->f_cksV) hipLaunchKernelGGL((k_tick1<false, true, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
-    else hipLaunchKernelGGL((k_tick1<false, false, NT>), dim3(g, batch), dim3(TPB), 0, w->stream, a);
+void launch_tick1(ggrs_world* w, TickArgs& a, uint32_t g, uint32_t batch = 1, uint32_t dp_s = 0) {
+    a.dp_s = dp_s;
+    if (dp_s) launch_tick1_dp<NT, true>(w, a, g, batch); else launch_tick1_dp<NT, false>(w, a, g, batch);
 }
 
 // Dead-snapshot elimination.  A request group whose NEXT request is a LoadGameState of a frame older than everything the
@@ -1472,7 +1510,8 @@ struct TickBatch {
         active = false;
         {
             ProfScope ps(w, GGRS_KERNEL_TICK);
-            launch_tick1<false>(w, a, g, k);
+            // a batch already fills the chip with its members: splitting the chain only adds replayed steps
+            launch_tick1<false>(w, a, g, k, k == 1 ? tick1_depth_parallel(w, a, (uint64_t)g * TILE1) : 0u);
         }
         HIPCHK(w, hipGetLastError());
         TickFinArgs f; memset(&f, 0, sizeof f);
@@ -1568,7 +1607,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
         } else {
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
-            if (vec == 1) { if (w->nt_copy) launch_tick1<true>(w, a, g); else launch_tick1<false>(w, a, g); }
+            if (vec == 1) { const uint32_t dp = tick1_depth_parallel(w, a, cover); if (w->nt_copy) launch_tick1<true>(w, a, g, 1, dp); else launch_tick1<false>(w, a, g, 1, dp); }
             else if (vec == 41) { if (w->nt_copy) launch_tick<true, 1>(w, a, g); else launch_tick<false, 1>(w, a, g); }
             else { if (w->nt_copy) launch_tick<true, 4>(w, a, g); else launch_tick<false, 4>(w, a, g); }
         }
@@ -1605,7 +1644,11 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
 }
 
 // The same grouping for worlds served by the generic LDS-staged kernel (k_tick_gen + k_gen_finalize).
-constexpr uint64_t GEN_SMALL_SLOTS = 512 * 1024;       // below this, 256 slots per workgroup fill the chip better
+// slots per workgroup by world size, us per depth-8 tick (profiles/r02gd/sub.txt):   50k   100k  200k  300k  400k  600k   1M
+//   256                                                                                 41.4  45.5  80.5 109.0 140.1 185.5 289.4
+//   512                                                                                 51.3  51.9  58.8  97.9 105.5 142.1 202.5
+//   1024                                                                                73.7  73.9  75.1  85.4  87.3 147.1 165.1
+constexpr uint64_t GEN_SUB256_MAX_SLOTS = 144 * 1024, GEN_SUB512_MAX_SLOTS = 256 * 1024;
 int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
                            uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
     uint32_t i = 0, ns = 0;
@@ -1648,16 +1691,30 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         if (group_is_dead(w, reqs, i, n, a.save_frame, a.n_saves, spawn_req != nullptr)) { for (uint32_t k = 0; k < a.n_saves; ++k) a.save_dst[k] = nullptr; a.skip_live = 1; }
         const uint64_t cover = std::max(gs.cover, w->len);
         uint32_t sub = w->gen_sub_max;
-        if (cover <= GEN_SMALL_SLOTS) sub = std::min<uint32_t>(sub, 256);
+        if (w->knobs.gen_sub) sub = std::min<uint32_t>(sub, (uint32_t)w->knobs.gen_sub);
+        else if (cover <= GEN_SUB256_MAX_SLOTS) sub = std::min<uint32_t>(sub, 256);
+        else if (cover <= GEN_SUB512_MAX_SLOTS) sub = std::min<uint32_t>(sub, 512);
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + sub - 1) / sub));
         a.sub = sub; a.src = gs.src->ptr; a.live = w->live.ptr; a.len = w->len;
         // word image + masks + the staged row-offset and checksum-unit tables
         const uint32_t n_rows = a.ts >> (LT_SHIFT + 2);
         const uint32_t lds = n_rows * sub * 4 + a.n_masks * (sub / 8) + ((n_rows + 3u) & ~3u) * 4 + a.n_units * (uint32_t)sizeof(GenUnit) +
                              (a.marks ? sub / 8 + sub * 4 : 0);
+        // depth-parallel roles (k_tick1's DP): same validity rule -- the source block is none of the destinations -- and the
+        // RollbackDespawned markers stay with the one workgroup that walks the whole group
+        a.dp_s = 0;
+        // us per depth-8 tick (profiles/r02gd/ab.txt):      10k    50k   100k
+        //   whole group per workgroup                        40.2   41.5   45.5
+        //   1 / 5 outputs per role                           25.5   33.9   56.3 (5)
+        if (w->knobs.gen_dp && a.n_saves >= 2 && !a.marks && cover <= (w->knobs.gen_dp > 1 ? w->knobs.gen_dp_max_slots : 72 * 1024)) {
+            const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
+            bool ok = !(writes_live && a.src == a.live);
+            for (uint32_t k = 0; k < a.n_saves; ++k) ok = ok && a.save_dst[k] != a.src;
+            if (ok) a.dp_s = w->knobs.gen_dp > 1 ? (uint32_t)w->knobs.gen_dp : (cover <= 32 * 1024 ? 1u : 5u);
+        }
         if (a.n_ops || !a.src_is_live) {
             ProfScope ps(w, GGRS_KERNEL_TICK);
-            hipLaunchKernelGGL(k_tick_gen, dim3(g), dim3(GEN_TPB), lds, w->stream, a);
+            hipLaunchKernelGGL(k_tick_gen, dim3(g, a.dp_s ? (a.n_saves + a.dp_s) / a.dp_s : 1u), dim3(GEN_TPB), lds, w->stream, a);
         }
         HIPCHK(w, hipGetLastError());
         group_close(w, gs, a.n_saves);

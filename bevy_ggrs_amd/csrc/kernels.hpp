@@ -462,6 +462,7 @@ struct TickArgs {
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
+    uint32_t dp_s;                         // depth-parallel k_tick1: outputs (Saves, then the live world) per workgroup role
     uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE (folded by k_tick_finalize)
     uint64_t rest_mask_off[MAX_MASKS];     // presence masks of components the schedule does not touch
     RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
@@ -1439,10 +1440,22 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
 // of leaving most of them idle behind a few long-running 1024-slot tiles, ~60 VGPRs give 8 waves/SIMD,
 // and with more workgroups than residency slots the read phase of late tiles overlaps the store phase
 // of early ones.  Accesses are 4 B (8 B for u64 columns) per lane: 256 B per wave instruction.
+//
+// DP ("depth-parallel", grid.z = roles): a tick of a small world is ONE dependent chain per lane -- load, 9 steps, 8 hashes,
+// 8 store bursts, ~2500 instructions at one wave per SIMD, ~12 us however few entities there are.  The steps are a handful
+// of flops; the hashes and stores are the chain.  The group's outputs are its Saves plus the live world; workgroup (t, z)
+// REPLAYS the steps and produces only outputs [z*dp_s, (z+1)*dp_s): dp_s = 1 gives nine times the workgroups, each a sixth of
+// the chain.  Same operations in the same order per slot, so the same bits.  Every role reads the source block and writes
+// different blocks: valid only when the source is none of the destinations (the host checks; a group that starts with
+// LoadWorld -- every SyncTest tick, every rollback -- qualifies).
 constexpr int TILE1 = 256;
-template <bool CKS_T, bool CKS_V, bool NT>
+template <bool CKS_T, bool CKS_V, bool NT, bool DP = false>
 __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
+    const uint32_t o_first = DP ? blockIdx.z * a.dp_s : 0u;         // DP: this workgroup's outputs; output n_saves is the live world
+    const uint32_t o_last = DP ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;
+    if (DP && o_first == a.n_saves && !writes_live) return;         // a role with nothing to write
     // Small worlds are latency-bound, and every dynamically indexed kernel argument (save_dst[si], dt_bits[sj], rest[r]
     // ...) is a dependent scalar load that misses the scalar cache on its first touch.  One vector load per lane
     // stages the whole argument block in LDS; the op loop then reads it with ds_read (an order of magnitude closer).
@@ -1480,8 +1493,8 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
         const uint64_t o = sa.rest_mask_off[m] + ((uint64_t)t * 4 + mw) * 8;
         const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
         for (uint32_t k = 0; k < a.n_saves; ++k)
-            if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-        if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
+            if (k >= o_first && k < o_last && a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
+        if (o_last == a.n_saves + 1u && !a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
     }
     if (in_len && (a.n_saves || !a.src_is_live)) {
         // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0.
@@ -1504,7 +1517,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): land the loads once
-            for (uint32_t k = 0; k <= a.n_saves; ++k) {
+            for (uint32_t k = o_first; k < o_last; ++k) {
                 uint8_t* dst = k < a.n_saves ? a.save_dst[k] : ((a.src_is_live || a.skip_live) ? nullptr : a.live);
                 if (!dst) continue;
 #pragma unroll
@@ -1528,6 +1541,7 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
     for (uint32_t i = 0; i < a.n_ops; ++i) {
         if (!((a.op_bits >> i) & 1ULL)) {
             // ---------------- SaveWorld
+            if (DP && si < o_first) { ++si; continue; }           // another workgroup's snapshot
             uint8_t* dst = reinterpret_cast<uint8_t*>(uni64(reinterpret_cast<uint64_t>(sa.save_dst[si])));
             const uint64_t alive_now = __ballot(alive);           // == this wave's liveness word
             if (dst) {
@@ -1561,13 +1575,16 @@ __global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
                 hV = wave_xor((alive && has_V) ? h : 0ULL);
             }
             if (lane == 0) {
-                // per-wave partials, folded by k_tick_finalize: an in-kernel fold (tick_fold) LOSES at these sizes -- there is no
-                // long store drain to hide its ticket + acquire + gather behind (10 k: 25.5 vs 23.5 us, 300 k: 59 vs 47 us per tick)
+                // per-wave partials, folded by k_tick_finalize.  In-kernel folds LOSE at these sizes: one last workgroup
+                // (tick_fold) has no long store drain to hide its ticket + acquire + gather behind (10 k: 25.5 vs 23.5 us,
+                // 300 k: 59 vs 47 us per tick), and a ticket per depth-parallel role serialises hundreds of short workgroups on
+                // one agent-scope atomic (profiles/r02dp/ab3.txt: 30 k 23.1 vs 17.4 us, 100 k 32.5 vs 25.3 us).
                 // blockIdx.y: member of a batch of identical checksum-only groups (speculative branches off one snapshot)
                 uint64_t* p = a.parts + ((uint64_t)blockIdx.y * a.n_saves + si) * 3 * a.part_stride + (uint64_t)t * 4 + wave;
                 p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = (uint64_t)__popcll(alive_now);
             }
             ++si;
+            if (DP && si == o_last) return;                       // this workgroup's snapshots are out (the live world is another role's)
         } else {
             // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
             const float dt = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sa.dt_bits[sj]));
@@ -1982,7 +1999,7 @@ struct GenArgs {
     uint8_t step_flags[MAX_TICK_STEPS];            // bit 0: DespawnConfirmed runs before this step; bit 1: its frame is unconfirmed (despawns are deferred)
     uint32_t marks, pad_m; DespawnMarks dm;
     uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
-    uint32_t skip_live, pad_sl;                        // skip_live: see TickArgs
+    uint32_t skip_live, dp_s;                          // skip_live: see TickArgs; dp_s: depth-parallel roles (k_tick1's DP), 0 = off
     uint64_t len, cols_base;
     uint32_t ts, sub, n_words, n_masks, n_units, n_sys, n_cks, part_stride;
     uint64_t mask_off[MAX_MASKS];
@@ -2009,6 +2026,13 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
     const uint64_t tbase = a.cols_base + (s0 >> LT_SHIFT) * a.ts;     // its layout tile inside a block
     const uint32_t in_tile = (uint32_t)(s0 & (uint64_t)(LAYOUT_TILE - 1));
     const bool in_len = s0 < a.len;                                   // workgroup-uniform
+    // depth-parallel roles (see k_tick1): workgroup (x, y) replays the steps and produces only outputs [y*dp_s, (y+1)*dp_s)
+    // of the group (its Saves in order, then the live world).  dp_s == 0: one workgroup produces everything.
+    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
+    const uint32_t o_first = a.dp_s ? blockIdx.y * a.dp_s : 0u;
+    const uint32_t o_last = a.dp_s ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;
+    const bool my_live = o_last == a.n_saves + 1u;
+    if (a.dp_s && o_first == a.n_saves && !writes_live) return;        // a role with nothing to write
     const uint32_t n_rows = a.ts >> (LT_SHIFT + 2);                   // 4-byte row units per slot (8-byte words = 2)
     const uint32_t img = n_rows * sub * 4u;                           // bytes of the word image
     uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + img);         // [n_masks][mw] behind the words; mask 0 = liveness
@@ -2092,6 +2116,8 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
         uint32_t si = 0;
         for (uint32_t op = 0; op < a.n_ops; ++op) {
             if ((a.op_bits >> op) & 1ULL) continue;
+            if (si < o_first) { ++si; continue; }                     // another role's snapshot
+            if (si >= o_last) break;
             uint8_t* dst = a.save_dst[si];
             if (dst) {
                 lds_barrier();                                        // A: the image is stable
@@ -2105,7 +2131,7 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
             }
             ++si;
         }
-        if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
+        if (my_live && writes_live) {
             lds_barrier();
             image_pull();
             lds_barrier();
@@ -2125,6 +2151,8 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
             // ---------------- SaveWorld: snapshot (store waves) + per-entity half of every component checksum (here).
             // Barrier A hands the stable image to the store waves; the hash below only READS it, so it overlaps their pull;
             // barrier B (after the hash) lets the next Advance change it.
+            if (si < o_first) { ++si; continue; }                     // another role's snapshot
+            if (si >= o_last) break;                                  // this role's Saves are out (a later role owns the rest)
             const bool hand_off = a.save_dst[si] != nullptr;
             if (hand_off) lds_barrier();
             uint64_t* prow = a.parts + (uint64_t)si * (a.n_cks + 1) * a.part_stride + (uint64_t)blockIdx.x * 4 + wave;
@@ -2178,6 +2206,7 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
             if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;   // folded by k_gen_finalize (an in-kernel tick_fold measured no gain here: 178 vs 174 us per 1 M tick)
             if (hand_off) lds_barrier();
             ++si;
+            if (si >= o_last) break;                                  // (no point stepping an image nobody will read)
         } else {
             // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
             const float dt = __uint_as_float(a.dt_bits[sj]);
@@ -2270,8 +2299,8 @@ __global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
         }
     }
     // ---- the live block, written once (by the store waves)
-    if ((!a.src_is_live || a.n_steps) && !a.skip_live) { lds_barrier(); lds_barrier(); }
-    if (a.marks && a.n_steps) {
+    if (my_live && writes_live) { lds_barrier(); lds_barrier(); }
+    if (my_live && a.marks && a.n_steps) {
         for (uint32_t m = tid; m < mw; m += TPB) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8) = ldis[m];
         for (uint32_t i = tid; i < sub; i += TPB) *reinterpret_cast<int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4) = ldf[i];
     }
@@ -2285,29 +2314,41 @@ struct GenFinArgs {
     uint64_t* out;
 };
 __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
+    // rows = the n_cks component XORs + the live count; the 16 waves split over the rows so that every row's loads are in
+    // flight together (one latency round, not one per row)
     const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    __shared__ uint64_t s[FIN_TPB / 64];
-    __shared__ uint64_t total_s;
-    if (tid == 0) total_s = 0;
+    constexpr uint32_t NW = FIN_TPB / 64;
+    __shared__ uint64_t acc[GEN_MAX_CKS + 1];
+    const uint32_t nc = f.n_cks + 1u;
+    if (tid < nc) acc[tid] = 0;
     __syncthreads();
-    for (uint32_t c = 0; c <= f.n_cks; ++c) {
-        const uint64_t* p = f.parts + ((uint64_t)k * (f.n_cks + 1) + c) * f.part_stride;
-        const bool is_cnt = c == f.n_cks;
+    const uint32_t wpr = nc >= NW ? 1u : NW / nc;                     // waves per row
+    for (uint32_t row = wave / wpr; row < nc; row += NW / wpr) {
+        const uint64_t* p = f.parts + ((uint64_t)k * nc + row) * f.part_stride;
+        const bool is_cnt = row == f.n_cks;
         uint64_t x = 0, sum = 0;
-        for (uint32_t i = tid; i < f.n_parts; i += FIN_TPB) { const uint64_t v = p[i]; x ^= v; sum += v; }
+        for (uint32_t i0 = (wave % wpr) * 64u + lane; i0 < f.n_parts; i0 += 4u * wpr * 64u) {
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * wpr * 64u; v[u] = i < f.n_parts ? p[i] : 0ULL; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x ^= v[u]; sum += v[u]; }
+        }
         x = wave_xor(x);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (lane == 0) s[wave] = is_cnt ? sum : x;
-        __syncthreads();
-        if (tid == 0) {
-            uint64_t acc = 0;
-            for (int w2 = 0; w2 < FIN_TPB / 64; ++w2) acc = is_cnt ? acc + s[w2] : acc ^ s[w2];
-            total_s ^= is_cnt ? sea_pair(acc, f.total_len) : sea_one(acc);      // entity_checksum.rs:29-52 / component_checksum.rs:92-95
+        if (lane == 0) {
+            if (is_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row]), (unsigned long long)sum);
+            else atomicXor(reinterpret_cast<unsigned long long*>(&acc[row]), (unsigned long long)x);
         }
-        __syncthreads();
     }
-    if (tid == 0) { f.out[2 * (uint64_t)k] = total_s; f.out[2 * (uint64_t)k + 1] = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < f.n_cks; ++c) total ^= sea_one(acc[c]);      // component_checksum.rs:92-95
+        total ^= sea_pair(acc[f.n_cks], f.total_len);                        // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
+    }
 }
 
 }  // namespace ggrs
