@@ -22,6 +22,7 @@ GGRS_WORLD_DEFAULT = 0
 GGRS_WORLD_UNFUSED = 2
 GGRS_WORLD_NT_COPY = 4
 GGRS_WORLD_NO_GROUPS = 8
+GGRS_WORLD_LAYOUT_ONLY = 16
 
 SYS_PARTICLES_UPDATE = 1
 SYS_TTL_DESPAWN = 2
@@ -83,6 +84,7 @@ SIGNATURES = {
     "ggrs_hip_checksum_component": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
     "ggrs_hip_add_system": (C.c_int, [_P, C.POINTER(SystemDesc)]),
     "ggrs_hip_add_custom_system": (C.c_int, [_P, C.POINTER(CustomSystemDesc)]),
+    "ggrs_hip_generated_kernel_source": (C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "ggrs_hip_set_frame_rate": (C.c_int, [_P, C.c_uint64]),
     "ggrs_hip_spawn": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ggrs_hip_despawn": (C.c_int, [_P, C.c_uint64]),

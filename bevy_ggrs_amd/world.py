@@ -280,6 +280,15 @@ class World(WorldBase):
         for i, v in enumerate(fparam): d.fparam[i] = v
         self._check(self._lib.ggrs_hip_add_custom_system(self._p, C.byref(d)))
 
+    def generated_kernel_source(self, compile: bool = False, slots_per_lane: int = 1) -> str:
+        """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source); with
+        compile=True it is also built for gfx950 with hiprtc.  Works on a GGRS_WORLD_LAYOUT_ONLY world (no GPU)."""
+        need = C.c_uint64(0)
+        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, slots_per_lane, None, 0, C.byref(need), 0))
+        buf = C.create_string_buffer(need.value)
+        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, slots_per_lane, buf, need.value, C.byref(need), 1 if compile else 0))
+        return buf.value.decode()
+
     def close(self):
         if getattr(self, "_p", None):
             self._lib.ggrs_hip_world_destroy(self._p)

@@ -67,6 +67,9 @@ typedef struct {
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
+#define GGRS_WORLD_LAYOUT_ONLY 16u   /* no device: registration, layout and ggrs_hip_generated_kernel_source only (every
+                                        call that would touch the GPU returns GGRS_E_NO_DEVICE) -- a build machine can check
+                                        that a schema and its custom systems compile for gfx950 before they are deployed   */
 
 int  ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggrs_world** out);
 int  ggrs_hip_world_create_ex(const ggrs_world_desc* desc, ggrs_world** out);
@@ -173,6 +176,17 @@ typedef struct {
     float    fparam[4];
 } ggrs_custom_system_desc;
 int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* desc);
+
+/* The request-group kernel the library WRITES for a world when it is sealed: one slot per lane, every
+ * registered word of the slot in a register, the GgrsSchedule systems -- built-in kinds and custom sources alike -- inlined
+ * in registration order, every checksum spec unrolled; compiled with hiprtc in two forms: slots_per_lane = 1 (4-byte
+ * accesses, worlds up to ~400 k slots) and 4 (16-byte accesses, HBM-sized worlds).  This returns that HIP C++ source
+ * (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed) bytes are copied.  compile != 0 also builds it for
+ * gfx950 (no device needed) and fails with the compiler log in ggrs_hip_last_error if it does not build.
+ * GGRS_E_INVALID: the world is outside what the generator covers (a system that writes a live-only component, more than 64
+ * -- 32 for the 4-slot form -- four-byte words per entity) or is hand-specialised (the particles world runs on k_tick3).  Registration must be complete;
+ * on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
+int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t slots_per_lane, char* buf, uint64_t cap, uint64_t* needed, int compile);
 
 /* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);

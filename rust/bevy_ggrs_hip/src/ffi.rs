@@ -16,6 +16,7 @@ pub const GGRS_WORLD_DEFAULT: u32 = 0;
 pub const GGRS_WORLD_UNFUSED: u32 = 2;
 pub const GGRS_WORLD_NT_COPY: u32 = 4;
 pub const GGRS_WORLD_NO_GROUPS: u32 = 8;
+pub const GGRS_WORLD_LAYOUT_ONLY: u32 = 16;
 
 pub const GGRS_COMP_ROLLBACK: u32 = 0;
 pub const GGRS_COMP_NO_ROLLBACK: u32 = 1;
@@ -115,6 +116,7 @@ unsafe extern "C" {
     pub fn ggrs_hip_checksum_component(w: *mut ggrs_world, comp_id: u32, word_idx: *const u32, n_idx: u32) -> c_int;
     pub fn ggrs_hip_add_system(w: *mut ggrs_world, desc: *const ggrs_system_desc) -> c_int;
     pub fn ggrs_hip_add_custom_system(w: *mut ggrs_world, desc: *const ggrs_custom_system_desc) -> c_int;
+    pub fn ggrs_hip_generated_kernel_source(w: *mut ggrs_world, slots_per_lane: u32, buf: *mut c_char, cap: u64, needed: *mut u64, compile: c_int) -> c_int;
     pub fn ggrs_hip_set_frame_rate(w: *mut ggrs_world, fps: u64) -> c_int;
     // ---- entities and host <-> device column traffic
     pub fn ggrs_hip_spawn(w: *mut ggrs_world, count: u64, comp_mask: u64, cols: *const *const c_void, first_slot: *mut u64) -> c_int;

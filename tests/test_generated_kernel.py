@@ -1,0 +1,130 @@
+"""The request-group kernel the library writes per world (ggrs_hip_generated_kernel_source) -- checked WITHOUT a GPU:
+a GGRS_WORLD_LAYOUT_ONLY world carries registration + layout only, and hiprtc cross-compiles for gfx950 on any host.
+What is pinned here: the generator covers the reference's example schemas (stress_test particles.rs:187-240, box_game
+box_game.rs:154-206, tests/synctest.rs:26-52 + despawn_rollback) and user-written systems, its output builds in both
+forms, and the shared device text (device_prelude.hpp) is what both the static and the generated kernels compile.
+The numerics of the generated kernel are the `-m gpu` parity suites: it is the default path of every fused world there."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dry(capacity=100_000, depth=8):
+    return bg.World(capacity, max_depth=depth, flags=bg.GGRS_WORLD_LAYOUT_ONLY)
+
+
+def particles():
+    w = dry()
+    cm.build_particles(w, with_spawn=True)
+    return w
+
+
+def box_game(player_rollback):
+    w = dry(4)
+    T = w.register_component("Transform", 4, 10)
+    V = w.register_component("Velocity", 4, 3)
+    P = w.register_component("Player", 8, 1, rollback=player_rollback)
+    w.checksum_component(T, [0, 1, 2]); w.checksum_component(V, [0, 1, 2])
+    w.add_system(bg.SYS_BOX_MOVE, comp=(T, V, P), word=(0, 0, 0), fparam=(18.0, 5.0, 0.0018, 4.5))
+    return w
+
+
+def health(mode):
+    w = dry(300)
+    H = w.register_component("Health", 4, 1)
+    w.register_component("Mesh", 4, 2, rollback=False)
+    w.checksum_component(H, [0])
+    w.add_system(bg.SYS_SAT_SUB_DESPAWN, comp=(H,), word=(0,), iparam=(1, mode))
+    return w
+
+
+def custom():
+    w = dry()
+    H = w.register_component("Health", 4, 1)
+    L = w.register_component("Ttl", 8, 1)
+    w.checksum_component(H, [0]); w.checksum_component(L, [0])
+    w.add_system(bg.SYS_ADD_U32, comp=(H,), word=(0,), iparam=(3,))
+    w.add_custom_system("__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) { e.u32(0) += f.input[0]; if (e.u64(1)-- == 1) e.despawn_rollback(); }",
+                        [(H, 0), (L, 0)], name="weird name: \"x\"")
+    return w
+
+
+WORLDS = {"particles": particles, "box_game": lambda: box_game(True), "box_game_live_only_player": lambda: box_game(False),
+          "health_despawn": lambda: health(bg.DESPAWN_IMMEDIATE), "health_despawn_rollback": lambda: health(bg.DESPAWN_ROLLBACK), "custom": custom}
+
+
+@pytest.mark.parametrize("name", sorted(WORLDS))
+@pytest.mark.parametrize("v", [1, 4])
+def test_generated_kernel_builds_for_gfx950(name, v):
+    w = WORLDS[name]()
+    src = w.generated_kernel_source(compile=True, slots_per_lane=v)      # raises with the hiprtc log if it does not build
+    assert 'extern "C" __global__' in src and "ggrs_jit_tick" in src
+    assert "sea_diffuse" in src and "box_move_math" in src, "the shared device prelude is part of every generated unit"
+    assert "#error" not in src
+    if name.endswith("rollback") or name == "custom":
+        assert "dis_0" in src and "df_0" in src, "RollbackDespawned markers are carried when a system can defer a despawn"
+    else:
+        assert "dis_0" not in src
+    if v == 4:
+        assert "u32x4" in src and "w0_3" in src
+    if name == "box_game_live_only_player":
+        assert "side_h0_0" in src, "a live-only Player.handle is read from the live block, not from the snapshot"
+
+
+def test_generated_kernel_unrolls_this_worlds_schema():
+    src = particles().generated_kernel_source()
+    body = src[src.index('#line 1 "ggrs_jit_tick"'):]
+    assert len(re.findall(r"#define o\d+\(blk\)", body)) == 14          # Transform 10 + Velocity 3 + Ttl 1 word columns
+    assert body.count("SeaStream st;") == 2                              # checksum_component x 2 (Velocity, Transform.translation)
+    assert "0xc3480000u" in body                                         # gravity.y = -200.0 as exact bits
+    assert "PARTICLES_SPAWN" not in body and body.count("particles.rs:272-280") == 1   # the spawn system ends a group on the host
+
+
+def test_generator_limits_and_errors():
+    w = dry()
+    for k in range(5): w.register_component(f"Big{k}", 4, 14)                          # 70 four-byte words per entity > 64
+    w.add_system(bg.SYS_ADD_U32, comp=(0,), word=(0,), iparam=(1,))
+    with pytest.raises(bg.GgrsHipError) as ei:
+        w.generated_kernel_source()
+    assert ei.value.code == bg.GGRS_E_INVALID and "does not cover" in str(ei.value)
+
+    w = dry()
+    A = w.register_component("A", 4, 1); K = w.register_component("K", 4, 1, rollback=False)
+    w.add_custom_system("__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame&) { e.u32(1) += 1; }", [(A, 0), (K, 0)])
+    with pytest.raises(bg.GgrsHipError):                                   # may WRITE a live-only word: not replayable, stays per-request
+        w.generated_kernel_source()
+
+    w = dry()
+    A = w.register_component("A", 4, 1)
+    with pytest.raises(bg.GgrsHipError) as ei:                             # a user's compile error surfaces at registration, GPU or not
+        w.add_custom_system("__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame&) { e.u32(0) += nope; }", [(A, 0)], name="broken")
+    assert "broken" in str(ei.value) and "nope" in str(ei.value)
+
+
+def test_layout_only_world_has_no_device_behind_it():
+    w = particles()
+    with pytest.raises(bg.GgrsHipError) as ei:
+        w.spawn(1, {0: None, 1: None, 2: None})
+    assert ei.value.code == bg.GGRS_E_NO_DEVICE
+    with pytest.raises(bg.GgrsHipError):
+        w.handle_requests([bg.SaveGameState(0)])
+
+
+def test_static_and_generated_kernels_share_one_device_text():
+    """kernels.hpp includes device_prelude.hpp as code, ggrs_hip.hip includes it as a string for hiprtc: no second copy of
+    the SeaHash constants or the box_game arithmetic anywhere in csrc/."""
+    csrc = os.path.join(ROOT, "bevy_ggrs_amd", "csrc")
+    k = open(os.path.join(csrc, "kernels.hpp")).read()
+    h = open(os.path.join(csrc, "ggrs_hip.hip")).read()
+    p = open(os.path.join(csrc, "device_prelude.hpp")).read()
+    assert '#include "device_prelude.hpp"' in k and '#include "device_prelude.hpp"' in h
+    assert "0x6eed0e9da4d94a4f" in p and "0x6eed0e9da4d94a4f" not in k and "0x6eed0e9da4d94a4f" not in h
+    assert "void box_move_math" in p and "void box_move_math" not in k
+    assert not re.search(r"^\s*#", p[p.index("GGRS_SHARED_CODE(\n"):], re.M), "no preprocessor directive inside the macro argument"
