@@ -328,8 +328,13 @@ def main():
         bytes_per_launch = BYTES_PER_ENTITY * (1 + D + 1) * live              # 600 B/entity at D = 8
         avg_s = per(tick_ms, tick_n)
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
-        roof = {"bound": "hbm", "kernel": ("k_tick3" if fin_n == 0 else "k_tick") + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
-                                          + (", checksum fold in-kernel)" if fin_n == 0 else "; + k_tick_finalize)"),
+        # which fused kernel served the group: k_tick3 folds in-kernel (no finalize launches); below its range the world runs on
+        # the request-group kernel the library generated for it at seal (hiprtc) unless GGRS_TICK_JIT=0 put k_tick1 / k_tick back
+        jit = fin_n != 0 and os.environ.get("GGRS_TICK_JIT", "1") != "0" and not os.environ.get("GGRS_TICK_VEC")
+        fin_name = "k_gen_finalize" if jit else "k_tick_finalize"
+        roof = {"bound": "hbm", "kernel": ("k_tick3" if fin_n == 0 else ("ggrs_jit_tick (generated for this world at seal)" if jit else "k_tick1 / k_tick"))
+                                          + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
+                                          + (", checksum fold in-kernel)" if fin_n == 0 else f"; + {fin_name})"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
                 # the two accountings, named so they cannot be confused: `frac` == frac_compulsory_600B
@@ -339,7 +344,7 @@ def main():
                 "algorithmic_bytes_note": "compulsory traffic of the fused group: 60 B/entity snapshot read + 60 B x saves + 60 B live write "
                                           "(SURVEY 8d's 1656 B/entity-tick assumes one kernel per request; that per-request equivalent is reported below)",
                 "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
-                "other_kernels": ({"k_tick_finalize": {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
+                "other_kernels": ({fin_name: {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
                 "per_request_equiv_GBps": TICK_BYTES(D) * live * K / secs / 1e9,
                 "per_request_equiv_frac": TICK_BYTES(D) * live * K / secs / 1e9 / HBM_PEAK_GBS}
     else:

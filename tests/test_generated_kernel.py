@@ -118,11 +118,11 @@ def test_layout_only_world_has_no_device_behind_it():
 
 
 def test_static_and_generated_kernels_share_one_device_text():
-    """kernels.hpp includes device_prelude.hpp as code, ggrs_hip.hip includes it as a string for hiprtc: no second copy of
+    """kernels.hpp includes device_prelude.hpp as code, kernel_gen.hpp includes it as a string for hiprtc: no second copy of
     the SeaHash constants or the box_game arithmetic anywhere in csrc/."""
     csrc = os.path.join(ROOT, "bevy_ggrs_amd", "csrc")
     k = open(os.path.join(csrc, "kernels.hpp")).read()
-    h = open(os.path.join(csrc, "ggrs_hip.hip")).read()
+    h = open(os.path.join(csrc, "kernel_gen.hpp")).read() + open(os.path.join(csrc, "ggrs_hip.hip")).read()
     p = open(os.path.join(csrc, "device_prelude.hpp")).read()
     assert '#include "device_prelude.hpp"' in k and '#include "device_prelude.hpp"' in h
     assert "0x6eed0e9da4d94a4f" in p and "0x6eed0e9da4d94a4f" not in k and "0x6eed0e9da4d94a4f" not in h
