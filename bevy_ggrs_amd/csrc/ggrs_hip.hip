@@ -656,7 +656,9 @@ int seal_impl(ggrs_world* w) {
             std::vector<uint8_t*> batch;
             for (int k = 0; k < n_cand; ++k) {
                 uint8_t* pa = nullptr;
-                const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0 : (need + al + skew) <= (1536ull << 20);
+                // contiguous (write-through) arenas are what k_tick3's dense nt store streams want; the generated
+                // kernel's 4-byte stores prefer plain pages (profiles/r02jit/big2.txt: 1 M 123 vs 144 us, 2 M 245 vs 335)
+                const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0 : (w->tick2_ok && (need + al + skew) <= (1536ull << 20));
                 hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous) : hipErrorUnknown;
                 if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need + al + skew); }   // no contiguous range free: plain pages
                 if (me != hipSuccess) { (void)hipGetLastError(); break; }
