@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
+    ap.add_argument("--paged-arena", action="store_true", help="library default: plain hipMalloc pages instead of a physically contiguous arena")
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (torch arena, RCCL broadcast + all-gather) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
@@ -207,6 +208,11 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
+    # the world is the first device allocation of this process (nothing cached has been freed before it): the documented condition
+    # under which a physically contiguous arena is safe (include/ggrs_hip.h, GGRS_WORLD_CONTIG_ARENA); --paged-arena measures without
+    # (single-GPU path only: in the fan-out path RCCL has allocated and freed device memory before the world exists)
+    contig = not args.paged_arena and not distributed
+    if contig: flags |= bg.GGRS_WORLD_CONTIG_ARENA
 
     if not distributed:
         w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum)
@@ -372,6 +378,7 @@ def main():
                    "entities_per_gpu": live, "depth": D,
                    "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
+                   "arena": "physically contiguous (GGRS_WORLD_CONTIG_ARENA: the world is this process's first device allocation)" if contig else "paged (library default)",
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }

@@ -23,6 +23,7 @@ GGRS_WORLD_UNFUSED = 2
 GGRS_WORLD_NT_COPY = 4
 GGRS_WORLD_NO_GROUPS = 8
 GGRS_WORLD_LAYOUT_ONLY = 16
+GGRS_WORLD_CONTIG_ARENA = 32
 
 SYS_PARTICLES_UPDATE = 1
 SYS_TTL_DESPAWN = 2

@@ -71,10 +71,10 @@ struct Knobs {
     uint64_t arena_align = 0, arena_skew = 0;   // GGRS_ARENA_ALIGN / GGRS_ARENA_SKEW   placement of the first block inside the allocation
     uint64_t block_pad = 0, col_pad = 0;        // GGRS_BLOCK_PAD / GGRS_COL_PAD        extra bytes between ring blocks / behind the columns
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
-    int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena (hipExtMallocWithFlags + hipDeviceMallocContiguous);
-                                   //                       default (-1): contiguous for arenas up to 1.5 GiB, where it measured faster at every
-                                   //                       size tried (profiles/r02*: 23.2 vs 23.6 us at 10 k entities, 27.4 vs 29.5 at 100 k,
-                                   //                       111.8 vs 114.5 at 1 M, equal at 2 M) -- and slower beyond (594 vs 480 us at 4 M)
+    int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena (hipExtMallocWithFlags + hipDeviceMallocContiguous) for every / no world;
+                                   //                       default (-1): only worlds created with GGRS_WORLD_CONTIG_ARENA (k_tick3 worlds up to 1.5 GiB:
+                                   //                       111.8 vs 114.5 us per tick at 1 M, slower beyond: 594 vs 480 us at 4 M) -- see the flag's
+                                   //                       note in include/ggrs_hip.h for why it is not the default any more
     bool tick2 = true;             // GGRS_TICK2=0          big worlds on the round-1 k_tick + k_tick_finalize pair instead of k_tick2
     int tick2_wgs_per_cu = 2;      // GGRS_TICK2_WGS=n      persistent workgroups per CU of k_tick2 (0: one workgroup per tile, not persistent)
     int tick2_nt = 1;              // GGRS_TICK2_NT=0|1     non-temporal snapshot stores in k_tick2
@@ -82,6 +82,7 @@ struct Knobs {
                                    //               =2..9   A/B: that many outputs per role, up to GGRS_TICK1_DP_MAX_SLOTS2 slots
     uint64_t tick1_dp_max_slots = 40 * 1024;    // GGRS_TICK1_DP_MAX_SLOTS   largest world that uses one output per role (x2: two, x4: three)
     uint64_t tick1_dp_max_slots2 = 400 * 1024;
+    bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     uint64_t jit_particles_max_slots = 416 * 1024;   // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (0: never)
     int jit_v = 0;                 // GGRS_JIT_V=1|4        A/B: slots per lane of the generated kernel (0: by world size)
@@ -116,6 +117,7 @@ struct Knobs {
         { const long long v = num("GGRS_GEN_SUB", 0); k.gen_sub = (v == 256 || v == 512 || v == 1024) ? (int)v : 0; }
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
         k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);
+        k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
         k.jit_particles_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024));
         { const long long v = num("GGRS_JIT_V", 0); k.jit_v = (v == 1 || v == 4) ? (int)v : 0; }
         k.gen_dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_GEN_DP", 1)));
@@ -656,9 +658,12 @@ int seal_impl(ggrs_world* w) {
             std::vector<uint8_t*> batch;
             for (int k = 0; k < n_cand; ++k) {
                 uint8_t* pa = nullptr;
-                // contiguous (write-through) arenas are what k_tick3's dense nt store streams want; the generated
-                // kernel's 4-byte stores prefer plain pages (profiles/r02jit/big2.txt: 1 M 123 vs 144 us, 2 M 245 vs 335)
-                const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0 : (w->tick2_ok && (need + al + skew) <= (1536ull << 20));
+                // contiguous (write-through, uncached) arenas are what k_tick3's dense nt store streams want -- and a
+                // hazard when their physical pages were used through a cached mapping earlier in the process (include/ggrs_hip.h,
+                // GGRS_WORLD_CONTIG_ARENA): opt-in per world, never for the generated kernel's worlds (its 4-byte stores prefer
+                // plain pages anyway: profiles/r02jit/big2.txt, 1 M 123 vs 144 us)
+                const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
+                                                               : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick2_ok && (need + al + skew) <= (1536ull << 20));
                 hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous) : hipErrorUnknown;
                 if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need + al + skew); }   // no contiguous range free: plain pages
                 if (me != hipSuccess) { (void)hipGetLastError(); break; }
@@ -694,6 +699,9 @@ int seal_impl(ggrs_world* w) {
         w->arena_bytes = need; w->own_arena = true;
         if (dbg) fprintf(stderr, "[ggrs arena] alloc=%p base=%p need=%llu state_bytes=%llu (0x%llx)\n", (void*)w->arena_alloc, (void*)w->arena, (unsigned long long)need, (unsigned long long)w->state_bytes, (unsigned long long)w->state_bytes);
     }
+    // GGRS_DEBUG_POISON=1: fill a library-owned arena with a garbage pattern before anything is initialised -- a read of memory the
+    // library never wrote (hidden by whatever a previous allocation left there) then fails the parity tests every time
+    if (w->knobs.debug_poison && w->own_arena) HIPCHK(w, hipMemsetAsync(w->arena, 0xA5, need, w->stream));
     uint8_t* p = w->arena;
     w->live.ptr = p; p += w->state_bytes;
     w->slots.resize(w->max_depth);
@@ -716,6 +724,7 @@ int seal_impl(ggrs_world* w) {
     HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
     HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
+    if (w->knobs.debug_poison) { memset(w->h_results, 0xA5, (size_t)w->max_results * 16); memset(w->h_stage, 0xA5, stage_bytes); }
     // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
     // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
     {
@@ -731,6 +740,7 @@ int seal_impl(ggrs_world* w) {
         HIPCHK(w, hipMalloc((void**)&w->d_gen_units, (gunits.size() + 1) * sizeof(GenUnit)));
         w->gen_parts_saves = w->tick_parts_saves;                    // same rule as k_tick1's partial rows (a batch of 16 eight-Save groups in small worlds)
         HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, (size_t)w->gen_parts_saves * (w->gen_proto.n_cks + 1) * w->tick_part_stride * 8));
+        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, (size_t)w->gen_parts_saves * (w->gen_proto.n_cks + 1) * w->tick_part_stride * 8, w->stream));
         if (!gwords.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_words, gwords.data(), gwords.size() * sizeof(GenWord), hipMemcpyHostToDevice, w->stream));
         if (!gunits.empty()) HIPCHK(w, hipMemcpyAsync(w->d_gen_units, gunits.data(), gunits.size() * sizeof(GenUnit), hipMemcpyHostToDevice, w->stream));
         w->gen_proto.words = w->d_gen_words; w->gen_proto.units = w->d_gen_units; w->gen_proto.n_units = (uint32_t)gunits.size();
@@ -2013,7 +2023,6 @@ int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t slots_per_lane, cha
         if (!w->layout_only) { DeviceGuard dg(w); const int rc = seal(w); if (rc) return rc; }
         else build_layout(w);                                      // host arithmetic only: offsets of every mask and column
     }
-    if (w->tick_ok && !w->layout_only) return w->fail(GGRS_E_INVALID, "this world runs on the hand-specialised particles kernels (k_tick3 / k_tick1)");
     std::string src;
     if (!jit_source(w, src, (int)slots_per_lane)) return w->fail(GGRS_E_INVALID, "the kernel generator does not cover this world (a system writes a live-only component, or more than %u four-byte words per entity)", JIT_MAX_UNITS);
     if (needed) *needed = src.size() + 1;

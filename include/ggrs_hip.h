@@ -67,6 +67,14 @@ typedef struct {
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
+#define GGRS_WORLD_CONTIG_ARENA 32u  /* allocate the library-owned arena physically contiguous (hipDeviceMallocContiguous; worlds of
+                                        the k_tick3 kind up to 1.5 GiB): +2-3 % on the dominant kernel (dense nt store streams
+                                        into write-through memory).  OPT-IN because such memory is mapped uncached:
+                                        if its physical pages were used through a CACHED mapping earlier in the same process
+                                        (a freed hipMalloc / another world's paged arena), stale L2 lines can be served for
+                                        them -- measured as deterministic corruption in 4 of 10 fresh processes that alternated
+                                        paged and contiguous arenas (profiles/README.md, r02fc).  Safe when the world is
+                                        created before the process has freed device memory (an app's startup; bench.py).    */
 #define GGRS_WORLD_LAYOUT_ONLY 16u   /* no device: registration, layout and ggrs_hip_generated_kernel_source only (every
                                         call that would touch the GPU returns GGRS_E_NO_DEVICE) -- a build machine can check
                                         that a schema and its custom systems compile for gfx950 before they are deployed   */
@@ -184,7 +192,7 @@ int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* des
  * (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed) bytes are copied.  compile != 0 also builds it for
  * gfx950 (no device needed) and fails with the compiler log in ggrs_hip_last_error if it does not build.
  * GGRS_E_INVALID: the world is outside what the generator covers (a system that writes a live-only component, more than 64
- * -- 32 for the 4-slot form -- four-byte words per entity) or is hand-specialised (the particles world runs on k_tick3).  Registration must be complete;
+ * -- 32 for the 4-slot form -- four-byte words per entity).  Registration must be complete;
  * on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
 int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t slots_per_lane, char* buf, uint64_t cap, uint64_t* needed, int compile);
 

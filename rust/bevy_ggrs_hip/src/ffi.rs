@@ -17,6 +17,7 @@ pub const GGRS_WORLD_UNFUSED: u32 = 2;
 pub const GGRS_WORLD_NT_COPY: u32 = 4;
 pub const GGRS_WORLD_NO_GROUPS: u32 = 8;
 pub const GGRS_WORLD_LAYOUT_ONLY: u32 = 16;
+pub const GGRS_WORLD_CONTIG_ARENA: u32 = 32;
 
 pub const GGRS_COMP_ROLLBACK: u32 = 0;
 pub const GGRS_COMP_NO_ROLLBACK: u32 = 1;

@@ -15,8 +15,8 @@ for n in 10000 100000 300000 600000 4000000; do timeout 300 python bench.py --en
 timeout 300 python bench.py --sync --no-cpu-baseline > $OUT/bench_sync.json 2>> $OUT/bench.err
 timeout 300 python bench.py --no-groups --no-cpu-baseline > $OUT/bench_nogroups.json 2>> $OUT/bench.err
 timeout 300 python bench.py --fanout --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_fanout_ws1.json
-for i in 1 2 3; do ./benches/tick_bench 1000000 8 200 16 0 0 1; done > $OUT/tick_bench_3_processes.txt 2>&1
-GGRS_ARENA_CONTIG=0 ./benches/tick_bench 1000000 8 200 16 0 0 3 > $OUT/tick_bench_paged_arena.txt 2>&1
+for i in 1 2 3; do ./benches/tick_bench 1000000 8 200 16 32 0 1; done > $OUT/tick_bench_3_processes.txt 2>&1     # flags = 32: GGRS_WORLD_CONTIG_ARENA
+./benches/tick_bench 1000000 8 200 16 0 0 3 > $OUT/tick_bench_paged_arena.txt 2>&1                                    # library default: paged
 BENCH="python bench.py --steps 100 --warmup 16 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- $BENCH > $OUT/prof_stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/prof_fetch -o fetch -- $BENCH > $OUT/prof_fetch.log 2>&1

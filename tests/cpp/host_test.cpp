@@ -156,6 +156,54 @@ static void despawn_and_rollback_does_not_panic() {
     std::puts("ok despawn_and_rollback_does_not_panic");
 }
 
+// add_systems(GgrsSchedule, <the user's own system>): tests/synctest.rs:37-44's decrease_health written as HIP C++ source
+// (CustomKernelSystem -> ggrs_hip_add_custom_system, compiled with hiprtc and inlined into the world's generated kernel) must
+// do exactly what the built-in restatement does.  Product build only: the CPU oracle has no run-time compiler.
+static void custom_system_equals_builtin() {
+#ifndef BACKEND_ORACLE
+    std::vector<uint32_t> got[2]; uint64_t active[2] = {0, 0};
+    for (int custom = 0; custom < 2; ++custom) {
+        TestApp app(512);
+        base_synctest_app(app, 5);
+        app.rollback_component_with_copy<Health>().checksum_component_with_hash<Health>();
+        if (custom) {
+            CustomKernelSystem sys("decrease_health",
+                "__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) {\n"
+                "    const unsigned a = (unsigned)f.iparam[0];\n"
+                "    e.u32(0) = e.u32(0) >= a ? e.u32(0) - a : 0u;\n"
+                "    if (e.u32(0) == 0) e.despawn();\n"
+                "}\n");
+            sys.bind<Health>(0);
+            sys.iparam[0] = 1;
+            app.add_systems(GgrsSchedule{}, sys);
+        } else {
+            app.add_systems(GgrsSchedule{}, systems::saturating_sub_despawn<Health>(1));
+        }
+        std::vector<uint32_t> h(300);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 5 + (uint32_t)(i % 40);
+        app.spawn(h.size(), {"Health"}, {h.data()});
+        int fired = 0;
+        app.add_observer([&](const SyncTestMismatch&) { ++fired; });
+        for (int i = 0; i < 30; ++i) app.update();
+        CHECK(fired == 0);
+        got[custom] = app.download<Health, uint32_t>(0);
+        active[custom] = app.active_count();
+    }
+    CHECK(got[0] == got[1]);
+    CHECK(active[0] == active[1] && active[0] > 0 && active[0] < 300);
+    bool threw = false;
+    try {
+        TestApp app(16);
+        app.rollback_component_with_copy<Health>();
+        CustomKernelSystem bad("broken", "__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame&) { e.u32(0) += nope; }");
+        bad.bind<Health>(0);
+        app.add_systems(GgrsSchedule{}, bad);
+    } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("nope") != std::string::npos; }
+    CHECK(threw);                                         // the compiler log reaches the caller
+#endif
+    std::puts("ok custom_system_equals_builtin");
+}
+
 // tests/synctest.rs:84-125: something that is NOT rolled back leaks into a checksummed component
 static void mismatch_fires_on_non_determinism() {
     TestApp app(4096);
@@ -511,6 +559,7 @@ int main(int argc, char** argv) {
     synctest_request_shape();
     print_request_traces();
     despawn_and_rollback_does_not_panic();
+    custom_system_equals_builtin();
     mismatch_fires_on_non_determinism();
     confirmed_frame_pruning();
     component_rollback_copy();
