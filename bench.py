@@ -378,7 +378,7 @@ def main():
                    "entities_per_gpu": live, "depth": D,
                    "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "arena": "physically contiguous (GGRS_WORLD_CONTIG_ARENA: the world is this process's first device allocation)" if contig else "paged (library default)",
+                   "arena": "physically contiguous requested (GGRS_WORLD_CONTIG_ARENA: the world is this process's first device allocation; honoured for k_tick3 worlds up to 1.5 GiB)" if contig else "paged (library default)",
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "roofline": roof,
     }
