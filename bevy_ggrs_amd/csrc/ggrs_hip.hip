@@ -1375,7 +1375,7 @@ uint32_t tick1_depth_parallel(const ggrs_world* w, const TickArgs& a, uint64_t c
     //   3 outputs per role                                                  16.9   18.2   20.2   22.8   25.3   36.8   48.0
     if (cover <= w->knobs.tick1_dp_max_slots) return 1;
     if (cover <= 2 * w->knobs.tick1_dp_max_slots) return 2;
-    if (cover <= 4 * w->knobs.tick1_dp_max_slots) return 3;
+    if (cover <= 6 * w->knobs.tick1_dp_max_slots) return 3;
     return 0;
 }
 template <bool NT, bool DP>
@@ -1746,7 +1746,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 bool ok = !(writes_live && j.src == j.live);
                 for (uint32_t k = 0; k < a.n_saves; ++k) ok = ok && a.save_dst[k] != j.src;
                 if (ok) j.dp_s = w->knobs.tick1_dp > 1 ? (cover <= w->knobs.tick1_dp_max_slots2 ? (uint32_t)w->knobs.tick1_dp : 0u)
-                               : (cover <= w->knobs.tick1_dp_max_slots ? 1u : (cover <= 2 * w->knobs.tick1_dp_max_slots ? 2u : (cover <= 4 * w->knobs.tick1_dp_max_slots ? 3u : 0u)));
+                               : (cover <= w->knobs.tick1_dp_max_slots ? 1u : (cover <= 2 * w->knobs.tick1_dp_max_slots ? 2u : (cover <= 6 * w->knobs.tick1_dp_max_slots ? 3u : 0u)));   // profiles/r02jit/jit_dp.txt
             }
             // identical checksum-only groups (speculative branches) ride in one launch; a batch already fills the chip, so no roles
             const bool batchable = dead && !v4 && a.n_saves > 0 && !w->jit_marks && cover <= TICK_VEC1_MAX_SLOTS;

@@ -43,13 +43,18 @@ struct Hiprtc {
     decltype(&hiprtcDestroyProgram) destroy = nullptr;
     decltype(&hiprtcGetErrorString) err_str = nullptr;
 };
+void hiprtc_load(Hiprtc& r);
 Hiprtc& hiprtc() {
     static Hiprtc r;
-    if (r.tried) return r;
+    static std::once_flag once;
+    std::call_once(once, [] { hiprtc_load(r); });          // worlds may be created from several threads
+    return r;
+}
+void hiprtc_load(Hiprtc& r) {
     r.tried = true;
     const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
     for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) { r.why = "libhiprtc.so not found (custom systems need the ROCm runtime compiler)"; return r; }
+    if (!r.lib) { r.why = "libhiprtc.so not found (custom systems and generated kernels need the ROCm runtime compiler)"; return; }
     bool ok = true;
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) { ok = false; r.why = std::string("libhiprtc lacks ") + n; } return p; };
     r.create = (decltype(r.create))sym("hiprtcCreateProgram");
@@ -61,7 +66,6 @@ Hiprtc& hiprtc() {
     r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
     r.err_str = (decltype(r.err_str))sym("hiprtcGetErrorString");
     if (!ok) r.lib = nullptr;
-    return r;
 }
 
 // The entity view a custom system sees (include/ggrs_hip.h, ggrs_hip_add_custom_system) -- one text for the per-request

@@ -140,3 +140,31 @@ def test_long_request_lists_split_into_groups():
         res.append((name, cs, cm.snapshot_state(w, (foo, big))))
     _check(res)
     assert res[0][2]["frame"] == 100 and res[0][1][21] == res[0][1][45]      # frame 21: saved before the load and again after it
+
+
+@pytest.mark.parametrize("n", [450_000, 1_100_000])
+def test_hbm_sized_generic_world_on_the_generated_kernel(n):
+    """A world k_tick3 does not cover (an extra system, an extra checksum spec, a fourth component) at HBM size: the default
+    dispatch runs the kernel generated for it (one slot per lane, non-temporal snapshot stores above 416 k slots, no
+    depth-parallel roles at this size) -- against the oracle, depth-8 SyncTest with despawns."""
+    cd, ticks = 8, 11
+    res = []
+    for name, w in [("gen", bg.World(n, max_depth=9)), ("oracle", OracleWorld(n, 9))]:
+        T = w.register_component("Transform", 4, 10); V = w.register_component("Velocity", 4, 3); L = w.register_component("Ttl", 8, 1)
+        H = w.register_component("Health", 4, 1)
+        w.set_component_default(T, cm.TRANSFORM_DEFAULT)
+        w.checksum_component(V, [0, 1, 2]); w.checksum_component(T, [0, 1, 2]); w.checksum_component(H, [0]); w.checksum_component(L, [0])
+        w.add_system(bg.SYS_PARTICLES_UPDATE, comp=(T, V), word=(0, 0), fparam=(0.0, -200.0, 0.0))
+        w.add_system(bg.SYS_TTL_DESPAWN, comp=(L,), word=(0,))
+        w.add_system(bg.SYS_ADD_U32, comp=(H,), word=(0,), iparam=(3,))
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        tcols = [np.full(n, cm.f32bits(cm.TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
+        vcols = [cm.f32bits(vel[:, 0]), cm.f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
+        w.spawn(n, {T: tcols, V: vcols, L: [ttl], H: [np.arange(n, dtype=np.uint32)]})
+        if name != "oracle": w.profile_enable(True)
+        drv = cm.SyncTestDriver(w, cd)
+        for t in range(ticks):
+            drv.tick((0,))
+        if name == "gen": assert _group_launches(w) >= ticks
+        res.append((name, drv.all_checksums, cm.snapshot_state(w, (T, V, L, H))))
+    _check(res)
