@@ -85,6 +85,7 @@ struct Knobs {
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     uint64_t jit_particles_max_slots = 416 * 1024;   // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (0: never)
+    int host_fold_max_wgs = 256;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
     int jit_v = 0;                 // GGRS_JIT_V=1|4        A/B: slots per lane of the generated kernel (0: by world size)
     bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated request-group kernel (k_tick_gen / per-request instead)
     int gen_sub = 0;               // GGRS_GEN_SUB=256|512|1024   A/B: slots per k_tick_gen workgroup (0: by world size)
@@ -117,6 +118,7 @@ struct Knobs {
         { const long long v = num("GGRS_GEN_SUB", 0); k.gen_sub = (v == 256 || v == 512 || v == 1024) ? (int)v : 0; }
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
         k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);
+        k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 256)));
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
         k.jit_particles_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024));
         { const long long v = num("GGRS_JIT_V", 0); k.jit_v = (v == 1 || v == 4) ? (int)v : 0; }
@@ -225,7 +227,14 @@ struct ggrs_world {
     std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
 
     // ---- asynchronous request batches (ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums)
-    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; };
+    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; uint32_t n_folds = 0; };
+    // Host-side checksum fold of small worlds (generated kernel): its workgroups write their partial rows straight into pinned,
+    // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected -- a
+    // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.
+    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off, total_len; };
+    std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
+    uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0;
+    bool device_results_only = false;    // a consumer reads the result ring in stream order (ggrs_hip_fanout_*): every fold stays on the device
     std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
     std::vector<hipEvent_t> event_pool;
 
@@ -367,6 +376,7 @@ int seal(ggrs_world* w) {
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
+    if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
     if (w->own_arena && w->arena_alloc) { (void)hipFree(w->arena_alloc); w->arena_alloc = nullptr; w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
     (void)hipGetLastError();
     w->slots.clear(); w->free_slots.clear(); w->live = Block{};
@@ -724,6 +734,11 @@ int seal_impl(ggrs_world* w) {
     HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
     HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
+    if (w->jit_fn && w->knobs.host_fold_max_wgs) {
+        w->rows_cap = 1u << 20;                                    // 8 MiB of partial rows between two collects
+        HIPCHK(w, hipHostMalloc((void**)&w->h_rows, w->rows_cap * 8, hipHostMallocMapped));
+        HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_rows, w->h_rows, 0));
+    }
     if (w->knobs.debug_poison) { memset(w->h_results, 0xA5, (size_t)w->max_results * 16); memset(w->h_stage, 0xA5, stage_bytes); }
     // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
     // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
@@ -1223,8 +1238,39 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
     return run_spawn_systems(w, inputs, n_inputs, spawn_count, spawn_vx, spawn_vy);
 }
 
+// component_checksum.rs:92-95 (hash the XOR of the entity hashes once more), entity_checksum.rs:29-52, checksum.rs:88-99 (XOR of all
+// parts; the upper 64 bits of the u128 are always 0) -- what k_gen_finalize does, over rows the device left in pinned memory
+void run_host_folds(ggrs_world* w, uint32_t n) {
+    for (; n && !w->folds.empty(); --n) {
+        const ggrs_world::HostFold f = w->folds.front(); w->folds.pop_front();
+        const uint32_t nc = f.n_cks + 1;
+        for (uint32_t m = 0; m < f.members; ++m)
+            for (uint32_t sv = 0; sv < f.n_saves; ++sv) {
+                uint64_t total = 0;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    const uint64_t* row = w->h_rows + f.rows_off + ((uint64_t)(m * f.n_saves + sv) * nc + c) * f.g;
+                    uint64_t x = 0, sum = 0;
+                    for (uint32_t t = 0; t < f.g; ++t) { x ^= row[t]; sum += row[t]; }
+                    total ^= c == f.n_cks ? sea_pair(sum, f.total_len) : sea_one(x);
+                }
+                uint64_t* out = w->h_results + 2 * (uint64_t)(f.res_slot + m * f.n_saves + sv);
+                out[0] = total; out[1] = 0;
+            }
+    }
+    if (w->folds.empty()) w->rows_used = 0;
+}
+// room for the partial rows of a group in the pinned row buffer?  (no: the group is folded by k_gen_finalize on the device)
+bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off) {
+    if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.host_fold_max_wgs) return false;
+    const uint64_t need = (uint64_t)g * n_saves * (n_cks + 1) * members;
+    if (w->rows_used + need > w->rows_cap) return false;
+    *off = w->rows_used; w->rows_used += need;
+    return true;
+}
+
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
+    run_host_folds(w, ~0u);
     w->stage_used = 0;
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
     return GGRS_OK;
@@ -1665,12 +1711,16 @@ struct JitBatch {
     int flush(ggrs_world* w) {
         if (!active) return GGRS_OK;
         active = false;
+        bool host_fold = false; uint64_t rows_off = 0;
         {
             ProfScope ps(w, GGRS_KERNEL_TICK);
             void* params[] = {&j};
             if (k > 1) j.dp_s = 0;
+            host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off);
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, g, j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, 1, 1, 0, w->stream, params, nullptr));
         }
+        if (host_fold) { w->folds.push_back({res_first, j.n_saves, g, n_cks, k, rows_off, j.len}); return GGRS_OK; }
         GenFinArgs f; memset(&f, 0, sizeof f);
         f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = j.len;   // one row per workgroup
         f.out = w->d_results + 2 * (uint64_t)res_first;
@@ -1756,13 +1806,17 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, a.n_cks); group_close(w, gs, a.n_saves); ns += a.n_saves; goto group_done; }
+            uint64_t rows_off = 0;
+            const bool host_fold = (a.n_ops || !a.src_is_live) && host_fold_rows(w, g, a.n_saves, a.n_cks, 1, &rows_off);
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (a.n_ops || !a.src_is_live) {
                 ProfScope ps(w, GGRS_KERNEL_TICK);
                 void* params[] = {&j};
                 HIPCHK(w, hipModuleLaunchKernel(v4 ? w->jit_fn4 : w->jit_fn, g, j.dp_s ? (a.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, 0, w->stream, params, nullptr));
             }
             group_close(w, gs, a.n_saves);
-            if (a.n_saves) {
+            if (host_fold) { w->folds.push_back({res_base + ns, a.n_saves, g, a.n_cks, 1u, rows_off, w->len}); ns += a.n_saves; }
+            else if (a.n_saves) {
                 GenFinArgs f; memset(&f, 0, sizeof f);
                 f.parts = a.parts; f.part_stride = a.part_stride; f.n_parts = g; f.n_cks = a.n_cks; f.total_len = w->len;   // one row per workgroup
                 f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
@@ -1927,6 +1981,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->h_rows) (void)hipHostFree(w->h_rows);
     if (w->own_arena && w->arena_alloc) (void)hipFree(w->arena_alloc);
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
@@ -2254,7 +2309,7 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
     rc = validate_requests(w, reqs, n); if (rc) return rc;
     if (w->tick_ok || w->gen_ok) {
         rc = use_tick_runner(w) ? run_request_groups(w, reqs, n, checksums_out) : run_request_groups_gen(w, reqs, n, checksums_out);
-        if (rc && w->stream) (void)hipStreamSynchronize(w->stream);
+        if (rc && w->stream) { (void)hipStreamSynchronize(w->stream); w->folds.clear(); w->rows_used = 0; }   // (nothing is pending in the synchronous API)
         return rc;
     }
     uint32_t ns = 0;
@@ -2295,9 +2350,10 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     ggrs_world::PendingBatch b;
     b.first = (w->res_head + n_save > w->max_results) ? 0u : w->res_head;
     b.count = n_save;
+    const size_t folds_before = w->folds.size();
     if (w->tick_ok || w->gen_ok) {
         rc = use_tick_runner(w) ? run_request_groups(w, reqs, n, nullptr, b.first, false, nullptr) : run_request_groups_gen(w, reqs, n, nullptr, b.first, false, nullptr);
-        if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
+        if (rc) { (void)hipStreamSynchronize(w->stream); while (w->folds.size() > folds_before) w->folds.pop_back(); return rc; }
     } else {
         // worlds without request-group kernels: one launch per request, enqueued like the groups are; every
         // Save's fold writes straight into its slot of the pinned result ring, nothing is waited for here
@@ -2319,6 +2375,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     b.ev = w->event_pool.back(); w->event_pool.pop_back();
     HIPCHK(w, hipEventRecord(b.ev, w->stream));
     w->res_head = b.first + n_save; w->pending_results += n_save;
+    b.n_folds = (uint32_t)(w->folds.size() - folds_before);
     if (n_saves_out) *n_saves_out = n_save;
     w->pending.push_back(std::move(b));
     return GGRS_OK;
@@ -2330,6 +2387,7 @@ int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t 
     ggrs_world::PendingBatch& b = w->pending.front();
     if (b.count > max_saves || (b.count && !checksums_out)) return w->fail(GGRS_E_INVALID, "oldest batch holds %u checksums, room for %u", b.count, max_saves);
     HIPCHK(w, hipEventSynchronize(b.ev));
+    run_host_folds(w, b.n_folds);
     if (b.count) {
         if (!b.host.empty()) memcpy(checksums_out, b.host.data(), (size_t)b.count * 16);
         else memcpy(checksums_out, w->h_results + 2 * (size_t)b.first, (size_t)b.count * 16);
@@ -2509,6 +2567,7 @@ int ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], 
     if (!rccl().ok()) return w->fail(GGRS_E_HIP, "%s", rccl().why.c_str());
     ggrs_fanout* f = new ggrs_fanout();
     f->w = w; f->rank = rank; f->size = world_size;
+    w->device_results_only = true;       // the all-gather reads the Checksum(u128)s from the result ring on the GPU's side of the stream: no host-side folds
     ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
     ncclResult_t e = rccl().CommInitRank(&f->comm, world_size, uid, rank);
     if (e != ncclSuccess) { rc = w->fail(GGRS_E_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(e)); delete f; return rc; }
