@@ -336,11 +336,14 @@ def main():
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
         # which fused kernel served the group: k_tick3 folds in-kernel (no finalize launches); below its range the world runs on
         # the request-group kernel the library generated for it at seal (hiprtc) unless GGRS_TICK_JIT=0 put k_tick1 / k_tick back
-        jit = fin_n != 0 and os.environ.get("GGRS_TICK_JIT", "1") != "0" and not os.environ.get("GGRS_TICK_VEC")
+        # (ggrs_hip.hip::use_tick_runner: particles worlds up to GGRS_JIT_PARTICLES_MAX_SLOTS = 416 k slots; groups of up to 256
+        #  workgroups leave their partial rows in pinned memory and the host folds them at collect time: no finalize launch either)
+        jit = (live <= int(os.environ.get("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024)) and os.environ.get("GGRS_TICK_JIT", "1") != "0"
+               and not os.environ.get("GGRS_TICK_VEC"))
         fin_name = "k_gen_finalize" if jit else "k_tick_finalize"
-        roof = {"bound": "hbm", "kernel": ("k_tick3" if fin_n == 0 else ("ggrs_jit_tick (generated for this world at seal)" if jit else "k_tick1 / k_tick"))
-                                          + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
-                                          + (", checksum fold in-kernel)" if fin_n == 0 else f"; + {fin_name})"),
+        kname = "ggrs_jit_tick (generated for this world at seal)" if jit else ("k_tick3" if fin_n == 0 else "k_tick1 / k_tick")
+        fold = (", checksum fold in-kernel)" if not jit else ", per-workgroup checksum partials folded by the host at collect time)") if fin_n == 0 else f"; + {fin_name})"
+        roof = {"bound": "hbm", "kernel": kname + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch" + fold,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
                 # the two accountings, named so they cannot be confused: `frac` == frac_compulsory_600B
