@@ -233,7 +233,7 @@ struct ggrs_world {
     // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.
     struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off, total_len; };
     std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
-    uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0;
+    uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
     bool device_results_only = false;    // a consumer reads the result ring in stream order (ggrs_hip_fanout_*): every fold stays on the device
     std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
     std::vector<hipEvent_t> event_pool;
@@ -1257,15 +1257,22 @@ void run_host_folds(ggrs_world* w, uint32_t n) {
                 out[0] = total; out[1] = 0;
             }
     }
-    if (w->folds.empty()) w->rows_used = 0;
+    // the row buffer is a ring: everything before the oldest unfolded group is free again
+    if (w->folds.empty()) { w->rows_used = 0; w->rows_tail = 0; } else w->rows_tail = w->folds.front().rows_off;
 }
 // room for the partial rows of a group in the pinned row buffer?  (no: the group is folded by k_gen_finalize on the device)
 bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off) {
     if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.host_fold_max_wgs) return false;
     const uint64_t need = (uint64_t)g * n_saves * (n_cks + 1) * members;
-    if (w->rows_used + need > w->rows_cap) return false;
-    *off = w->rows_used; w->rows_used += need;
-    return true;
+    if (w->folds.empty()) { w->rows_used = 0; w->rows_tail = 0; }
+    uint64_t& head = w->rows_used;                                 // ring: rows of pending folds live in [tail, head) (mod wrap)
+    if (head >= w->rows_tail) {
+        if (head + need <= w->rows_cap) { *off = head; head += need; return true; }
+        if (need < w->rows_tail) { *off = 0; head = need; return true; }          // wrap: the front of the buffer has been folded
+        return false;
+    }
+    if (head + need < w->rows_tail) { *off = head; head += need; return true; }
+    return false;
 }
 
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
@@ -2309,7 +2316,7 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
     rc = validate_requests(w, reqs, n); if (rc) return rc;
     if (w->tick_ok || w->gen_ok) {
         rc = use_tick_runner(w) ? run_request_groups(w, reqs, n, checksums_out) : run_request_groups_gen(w, reqs, n, checksums_out);
-        if (rc && w->stream) { (void)hipStreamSynchronize(w->stream); w->folds.clear(); w->rows_used = 0; }   // (nothing is pending in the synchronous API)
+        if (rc && w->stream) { (void)hipStreamSynchronize(w->stream); w->folds.clear(); w->rows_used = 0; w->rows_tail = 0; }   // (nothing is pending in the synchronous API)
         return rc;
     }
     uint32_t ns = 0;

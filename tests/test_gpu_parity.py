@@ -431,3 +431,53 @@ def test_big_world_with_extra_untouched_components(extra_words, n):
         w.close()
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], f"extra={extra_words}")
+
+
+def test_long_pipelined_run_wraps_the_host_fold_row_ring(monkeypatch):
+    """Small worlds leave their per-workgroup checksum partials in a pinned row ring and the host folds them at collect time.
+    With one batch always in flight the ring never drains: 1400 pipelined depth-8 ticks at 10 k entities wrap it (~1090 ticks
+    of rows fit).  Every checksum must equal the same run with the fold kept on the device (GGRS_HOST_FOLD_MAX_WGS=0), and
+    the first ticks the oracle's."""
+    n, D, ticks = 10_000, 8, 1400
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    out = []
+    for host_fold in (True, False):
+        if not host_fold: monkeypatch.setenv("GGRS_HOST_FOLD_MAX_WGS", "0")
+        w = bg.World(n, max_depth=D + 1)
+        ids = cm.build_particles(w)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+        w.set_synctest_check_distance(D)
+        cs = []
+        F = 0
+        for t in range(ticks):
+            reqs = []
+            if F >= D:
+                reqs.append(bg.LoadGameState(F - D))
+                for i in range(D):
+                    if i: reqs.append(bg.SaveGameState(F - D + i))
+                    reqs.append(bg.AdvanceFrame((0,)))
+            reqs += [bg.SaveGameState(F), bg.AdvanceFrame((0,))]
+            F += 1
+            w.enqueue_requests(reqs)
+            if t >= 1: cs.append(w.collect_checksums())          # one batch always in flight
+        while w.pending_batches(): cs.append(w.collect_checksums())
+        out.append((cs, cm.snapshot_state(w, ids)))
+    assert out[0][0] == out[1][0]
+    cm.assert_states_equal(out[0][1], out[1][1], "host fold vs device fold")
+    o = OracleWorld(n, D + 1, FLAT)
+    ids = cm.build_particles(o)
+    cm.spawn_particles(o, ids, n, vel, ttl)
+    o.set_depth(D + 1)
+    o.set_synctest_check_distance(D)
+    F = 0
+    for t in range(24):
+        reqs = []
+        if F >= D:
+            reqs.append(bg.LoadGameState(F - D))
+            for i in range(D):
+                if i: reqs.append(bg.SaveGameState(F - D + i))
+                reqs.append(bg.AdvanceFrame((0,)))
+        reqs += [bg.SaveGameState(F), bg.AdvanceFrame((0,))]
+        F += 1
+        assert o.handle_requests(reqs) == out[0][0][t], f"tick {t}"
