@@ -213,3 +213,71 @@ def test_compile_error_is_reported_with_the_compiler_log_and_the_world_stays_usa
     assert np.all(g.download_word(A, 0, 0, 64) == 2)
     with pytest.raises(bg.GgrsHipError):
         g.add_custom_system(ADD_SRC, [(A, 0)])                                       # sealed
+
+
+BOX_SRC = r"""
+// examples/box_game/box_game.rs:154-206 move_cube_system, written by the "user": bindings T.xyz (0..2), V.xyz (3..5), Player.handle (6)
+// fparam = {ACCELERATION, MAX_SPEED, FRICTION.powf(dt), half_width}.  sqrt and / must be the correctly rounded IEEE operations.
+__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) {
+    const unsigned long long handle = e.u64(6);
+    if (handle >= f.n_inputs) return;
+    const unsigned char in = f.input[handle];
+    const bool up = in & 1, down = in & 2, left = in & 4, right = in & 8;
+    float x = e.f32(0), y = e.f32(1), z = e.f32(2), vx = e.f32(3), vy = e.f32(4), vz = e.f32(5);
+    const float adt = f.fparam[0] * f.dt, fp = f.fparam[2], max_speed = f.fparam[1];
+    if (up && !down) vz -= adt;
+    if (!up && down) vz += adt;
+    if (left && !right) vx -= adt;
+    if (!left && right) vx += adt;
+    if (!up && !down) vz *= fp;
+    if (!left && !right) vx *= fp;
+    vy *= fp;
+    const float len_sq = vx * vx + vy * vy + vz * vz;
+    if (len_sq > max_speed * max_speed) { const float l = sqrtf(len_sq); vx = max_speed * (vx / l); vy = max_speed * (vy / l); vz = max_speed * (vz / l); }
+    x += vx * f.dt; y += vy * f.dt; z += vz * f.dt;
+    const float lo = -f.fparam[3], hi = f.fparam[3];
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    if (z < lo) z = lo;
+    if (z > hi) z = hi;
+    e.f32(0) = x; e.f32(1) = y; e.f32(2) = z; e.f32(3) = vx; e.f32(4) = vy; e.f32(5) = vz;
+}
+"""
+
+
+def test_box_game_written_as_a_custom_system_matches_the_oracle():
+    """box_game's move_cube_system as user source (branches, sqrt, divide, clamps, PlayerInputs) == the oracle's built-in
+    restatement, bit for bit, over a SyncTest with random inputs: the run-time compiler keeps the library's floating-point contract
+    (no contraction, correctly rounded sqrt and divide).  FRICTION.powf(dt) is the platform libm's, as in the reference's build."""
+    import ctypes
+    import test_box_game as tb
+    libm = ctypes.CDLL("libm.so.6"); libm.powf.restype = ctypes.c_float; libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    n, players, cd, ticks = 5000, 4, 7, 30
+    # RollbackFrameRate(50): 20 000 000 ns per frame exactly, so every frame's delta (time.rs:63-87) is the same f32 and the
+    # friction factor is one constant (at 60 fps the integer-nanosecond deltas alternate between two f32 values)
+    dt = np.float32(20_000_000) / np.float32(1_000_000_000)
+    fp = float(libm.powf(tb.BOX_PARAMS[2], float(dt)))
+    out = []
+    for custom in (True, False):
+        w = bg.World(n, max_depth=9) if custom else OracleWorld(n, 9, FLAT)
+        T = w.register_component("Transform", 4, 10); V = w.register_component("Velocity", 4, 3); P = w.register_component("Player", 8, 1)
+        w.set_component_default(T, cm.TRANSFORM_DEFAULT)
+        w.set_frame_rate(50)
+        w.checksum_component(T, [0, 1, 2]); w.checksum_component(V, [0, 1, 2])
+        if custom:
+            w.add_custom_system(BOX_SRC, [(T, 0), (T, 1), (T, 2), (V, 0), (V, 1), (V, 2), (P, 0)],
+                                fparam=(tb.BOX_PARAMS[0], tb.BOX_PARAMS[1], fp, tb.BOX_PARAMS[3]), name="move_cube_system")
+        else:
+            w.add_system(bg.SYS_BOX_MOVE, comp=(T, V, P), word=(0, 0, 0), fparam=tb.BOX_PARAMS)
+        rng = np.random.default_rng(5)
+        tr = np.tile(cm.TRANSFORM_DEFAULT, (n, 1)).astype(np.float32)
+        tr[:, 0:3] = rng.uniform(-2.6, 2.6, (n, 3)).astype(np.float32)
+        vel = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+        handle = (np.arange(n) % (players + 1)).astype(np.uint64)         # some handles have no input: inputs[handle] would panic
+        w.spawn(n, {T: [cm.f32bits(tr[:, k]) for k in range(10)], V: [cm.f32bits(vel[:, k]) for k in range(3)], P: [handle]})
+        drv = cm.SyncTestDriver(w, cd, num_players=players)
+        for t in range(ticks):
+            drv.tick(tb.input_script(t, players))
+        out.append((drv.all_checksums, cm.snapshot_state(w, (T, V, P))))
+    assert out[0][0] == out[1][0]
+    cm.assert_states_equal(out[0][1], out[1][1], "box_game as custom source")
