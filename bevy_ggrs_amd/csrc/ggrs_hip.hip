@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <cctype>
 #include <deque>
 #include <map>
@@ -135,13 +136,15 @@ struct Knobs {
 
 }  // namespace
 
+static std::atomic<int> g_paged_arena_frees{0};   // paged (cached) arenas this process has handed back: see GGRS_WORLD_CONTIG_ARENA
+
 struct ggrs_world {
     // ---- configuration
     int device = 0;
     uint64_t capacity = 0, cap_pad = 0;
     uint32_t max_depth = 0, flags = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
-    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false;
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false, arena_contiguous = false;
     uint8_t* arena_alloc = nullptr;      // what hipMalloc returned (arena may be aligned / skewed inside it)
 
     std::vector<Comp> comps;
@@ -377,7 +380,7 @@ int seal(ggrs_world* w) {
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
-    if (w->own_arena && w->arena_alloc) { (void)hipFree(w->arena_alloc); w->arena_alloc = nullptr; w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
+    if (w->own_arena && w->arena_alloc) { (void)hipFree(w->arena_alloc); if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed); w->arena_alloc = nullptr; w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
     (void)hipGetLastError();
     w->slots.clear(); w->free_slots.clear(); w->live = Block{};
     w->sealed = false; w->seal_error = rc;
@@ -672,9 +675,14 @@ int seal_impl(ggrs_world* w) {
                 // hazard when their physical pages were used through a cached mapping earlier in the process (include/ggrs_hip.h,
                 // GGRS_WORLD_CONTIG_ARENA): opt-in per world, never for the generated kernel's worlds (its 4-byte stores prefer
                 // plain pages anyway: profiles/r02jit/big2.txt, 1 M 123 vs 144 us)
+                // safety net for the one cached mapping the library knows about: once this process has freed a PAGED arena of its
+                // own, a later world's request is ignored (a session restart that re-creates the world keeps its contiguous arena:
+                // freeing uncached memory leaves no lines behind)
                 const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
-                                                               : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick2_ok && (need + al + skew) <= (1536ull << 20));
+                                                               : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick2_ok && (need + al + skew) <= (1536ull << 20) &&
+                                                                  g_paged_arena_frees.load(std::memory_order_relaxed) == 0);
                 hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need + al + skew, hipDeviceMallocContiguous) : hipErrorUnknown;
+                w->arena_contiguous = me == hipSuccess;
                 if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need + al + skew); }   // no contiguous range free: plain pages
                 if (me != hipSuccess) { (void)hipGetLastError(); break; }
                 if (dbg) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes\n", contig ? "contiguous" : "paged", (unsigned long long)(need + al + skew));
@@ -1989,7 +1997,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_rows) (void)hipHostFree(w->h_rows);
-    if (w->own_arena && w->arena_alloc) (void)hipFree(w->arena_alloc);
+    if (w->own_arena && w->arena_alloc) { (void)hipFree(w->arena_alloc); if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed); }
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }

@@ -74,7 +74,8 @@ typedef struct {
                                         (a freed hipMalloc / another world's paged arena), stale L2 lines can be served for
                                         them -- measured as deterministic corruption in 4 of 10 fresh processes that alternated
                                         paged and contiguous arenas (profiles/README.md, r02fc).  Safe when the world is
-                                        created before the process has freed device memory (an app's startup; bench.py).    */
+                                        created before the process has freed device memory (an app's startup; bench.py); the
+                                        library itself ignores the flag once it has freed a paged arena of its own.           */
 #define GGRS_WORLD_LAYOUT_ONLY 16u   /* no device: registration, layout and ggrs_hip_generated_kernel_source only (every
                                         call that would touch the GPU returns GGRS_E_NO_DEVICE) -- a build machine can check
                                         that a schema and its custom systems compile for gfx950 before they are deployed   */
