@@ -44,15 +44,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_ENTITY = 60          # registered payload R
-SAVE_BYTES = 2 * BYTES_PER_ENTITY      # read live + write ring
-ADV_BYTES = 64                 # r/w translation 12 + velocity 12 + ttl 8
-TICK_BYTES = lambda d: SAVE_BYTES + SAVE_BYTES * d + ADV_BYTES * (d + 1)   # 1656 at d = 8
+ADV_BYTES = 64                 # AdvanceWorld as its own kernel: r/w translation 12 + velocity 12 + ttl 8
 
 
-def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True):
+def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="headline"):
     w = bg.World(n, max_depth=depth + 1, stream=stream, flags=flags)
-    ids = cm.build_particles(w, checksum=checksum)
+    ids = cm.build_particles(w, checksum=checksum, schema=schema)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)
     w.set_depth(depth + 1)
@@ -99,7 +96,7 @@ def warm_ring(bg, w, depth):
         w.handle_requests([bg.SaveGameState(w.frame), bg.AdvanceFrame((0,))])
 
 
-def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks):
+def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs, parity_ticks, schema="headline"):
     """The CPU path timed beside the GPU line, and the parity check of the same run.
 
     * reference-shaped oracle (per-save hash-map rebuild, per-entity lookups: the reference's cost structure) on ONE
@@ -114,7 +111,7 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks
 
     def world(mode):
         w = OracleWorld(n, depth + 1, mode)
-        ids = cm.build_particles(w)
+        ids = cm.build_particles(w, schema=schema)
         vel, ttl = cm.synthetic_particles(n, ttl="throughput")
         cm.spawn_particles(w, ids, n, vel, ttl)
         w.set_depth(depth + 1)
@@ -134,7 +131,9 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks
     flat_threads = max(1, min(64, cores))
     wf = world(FLAT)
     lib.gor_set_num_threads(flat_threads)
-    fsecs, ocs = wf.replay_synctest(depth, (depth + 1) + warmup + P, max(P, 1))
+    # frames_before_timed = ring warm-up + warm-up ticks + pre-heat ticks: the checker fast-forwards over them (advance-only,
+    # then d + 1 plain [Save, Advance] ticks for the ring; gor_replay_synctest_from) and runs the P timed ticks for real
+    fsecs, ocs = wf.replay_synctest_from(depth, frames_before_timed - (depth + 1), max(P, 1))
     del wf
     parity = {"checked_ticks": P, "checked_saves": P * depth, "equal": None}
     if P:
@@ -163,6 +162,165 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, warmup, gpu_cs, parity_ticks
     return base, parity
 
 
+def read_clocks():
+    """sclk / mclk / power right now: sysfs (pp_dpm_*: the starred level; hwmon power) when the container exposes it, else
+    `rocm-smi`.  Telemetry for the JSON line only."""
+    import glob
+    out = {}
+    try:
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            def star(name):
+                try:
+                    for ln in open(os.path.join(card, name)).read().splitlines():
+                        if ln.rstrip().endswith("*"): return ln.split(":", 1)[1].replace("*", "").strip()
+                except OSError:
+                    return None
+            sclk, mclk = star("pp_dpm_sclk"), star("pp_dpm_mclk")
+            if sclk or mclk:
+                out = {"source": "sysfs " + card, "sclk": sclk, "mclk": mclk}
+                for pw in glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_input")):
+                    try: out["power_w"] = int(open(pw).read()) / 1e6; break
+                    except (OSError, ValueError): pass
+                return out
+    except Exception:
+        pass
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=15)
+        j = json.loads(r.stdout[r.stdout.index("{"):])
+        c = j.get("card0", next(iter(j.values())))
+        out = {"source": "rocm-smi", "sclk": c.get("sclk clock speed:"), "mclk": c.get("mclk clock speed:")}
+        for k, v in c.items():
+            if "ower" in k and "(W)" in k: out["power_w"] = v; break
+    except Exception as e:       # noqa: BLE001 -- telemetry must never fail the bench
+        out = {"source": "unavailable", "why": f"{type(e).__name__}: {e}"[:120]}
+    return out
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher around it: start the N ranks here, one process per GPU (rank r on HIP device r),
+    over 127.0.0.1; rank 0's JSON line is this process's output.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.dry_run:
+        ndev = None
+    else:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            print("bench.py: no GPU visible", file=sys.stderr); return 2
+        if n > ndev and not args.oversubscribe:
+            print(f"bench.py: --gpus {n} but only {ndev} device(s) visible (pass --oversubscribe to share devices: correctness "
+                  f"only, and RCCL builds that refuse two ranks per device will fail in ncclCommInitRank)", file=sys.stderr)
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmds = []
+    for r in range(n):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        cmds.append((env, [sys.executable, os.path.abspath(__file__)] + argv))
+    if args.dry_run:
+        for env, cmd in cmds:
+            print(json.dumps({"env": env, "cmd": cmd}))
+        return 0
+    procs = []
+    for r, (env, cmd) in enumerate(cmds):
+        procs.append(subprocess.Popen(cmd, env={**os.environ, **env}, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                c = p.poll()
+                if c is None: continue
+                pending.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for q in pending: q.terminate()        # one rank failed: the others would wait in a collective forever
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None: p.kill()
+    return rc
+
+
+def measure_single(bg, cm, torch, args, contig, light=False):
+    """One single-GPU measurement in this process: world on a paged (library default) or physically contiguous arena; warm-up,
+    pre-heat, K timed ticks, then the HIP-event pass for the per-kernel roofline.  light: no telemetry, no checksum capture."""
+    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
+    if contig: flags |= bg.GGRS_WORLD_CONTIG_ARENA
+    w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum, schema=args.schema)
+    m = {"contig_requested": bool(contig)}
+    warm_ring(bg, w, D)
+    run, _keep = tick_requests(bg, w, D)
+    m["clocks_start"] = None if light else read_clocks()
+    for _ in range(W):
+        run(w.frame)
+    torch.cuda.synchronize()
+    # ---- pre-heat: the SAME tick on the SAME world for a fixed wall time, reported on its own (not part of `warmup`): the
+    # chip clocks up over the first tens of milliseconds of load, and a 20-step timed region is 2.4 ms long
+    pre_t0 = time.perf_counter(); pre_n = 0
+    if args.preheat_ms > 0:
+        run.enqueue(w.frame); pre_n = 1
+        while (time.perf_counter() - pre_t0) * 1e3 < args.preheat_ms:
+            run.enqueue(w.frame); run.collect(); pre_n += 1
+        run.collect()
+        w.synchronize()
+    m["preheat"] = {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms}
+    torch.cuda.synchronize()
+    m["frames_before_timed"] = w.frame
+    gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
+    stamps = []
+    take = (lambda out: None) if light else (lambda out: (gpu_cs.append(bytes(out)), stamps.append(time.perf_counter())))
+    if args.sync:
+        t0 = time.perf_counter()
+        for _ in range(K):
+            take(run(w.frame))
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+    else:
+        # one tick in flight ahead of the host: enqueue tick k+1, then collect tick k's checksums
+        # (what a shim does: cell.save() right before the next advance_frame()).  Every one of the K
+        # ticks is enqueued AND collected inside the timed region.
+        w.synchronize()
+        t0 = time.perf_counter()
+        run.enqueue(w.frame)
+        for _ in range(K - 1):
+            run.enqueue(w.frame)
+            take(run.collect())
+        take(run.collect())
+        w.synchronize()
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+    m["secs"] = secs
+    m["clocks_end"] = None if light else read_clocks()
+    m["live"] = w.active_count()
+    m["gpu_cs"] = [[int.from_bytes(b[16 * k:16 * k + 16], "little") for k in range(D)] for b in gpu_cs]
+    if stamps:
+        d = [(b - a) * 1e6 for a, b in zip([t0] + stamps[:-1], stamps)]
+        m["tick_wall_us"] = {"first5": [round(x, 1) for x in d[:5]], "last5": [round(x, 1) for x in d[-5:]],
+                             "note": "host interval between consecutive collects in the timed region (tick k+1 is already enqueued when tick k is collected)"}
+    m["f_end"] = w.frame
+    # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
+    w.profile_enable(True)
+    for _ in range(min(K, 50)):
+        run(w.frame)
+    m["prof"] = w.profile_read()
+    tick_us = w.profile_launches("tick")
+    w.profile_enable(False)
+    if tick_us:
+        srt = sorted(tick_us)
+        m["launch_us"] = {"first5": [round(x, 2) for x in tick_us[:5]], "last5": [round(x, 2) for x in tick_us[-5:]],
+                          "min": round(srt[0], 2), "median": round(srt[len(srt) // 2], 2), "max": round(srt[-1], 2), "n": len(tick_us)}
+    m["info"] = w.kernel_info()
+    w.close()
+    return m
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,16 +331,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ticks", type=int, default=3)
     ap.add_argument("--parity-ticks", type=int, default=24, help="timed ticks whose checksums the CPU oracle replays and compares (N = 1 only; 0 = off)")
+    ap.add_argument("--preheat-ms", type=float, default=150.0, help="wall time of untimed ticks between warm-up and the timed region (clock ramp; reported as `preheat`)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per reference system (no fusion at all)")
     ap.add_argument("--no-groups", action="store_true", help="one launch per request (no request-group fusion)")
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
-    ap.add_argument("--paged-arena", action="store_true", help="library default: plain hipMalloc pages instead of a physically contiguous arena")
-    ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (torch arena, RCCL broadcast + all-gather) even at world size 1")
+    ap.add_argument("--arena", choices=["both", "paged", "contig"], default="both",
+                    help="single-GPU path: `value` is ALWAYS measured on the library's default paged arena unless 'contig' is forced; 'both' (default) "
+                         "also measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
+                         "as roofline.contig_arena_variant")
+    ap.add_argument("--paged-arena", action="store_true", help="same as --arena paged")
+    ap.add_argument("--schema", choices=["headline", "full"], default="headline",
+                    help="headline: BASELINE's 3 registered components (60 B/entity); full: the reference stress_test's POD schema "
+                         "(+ GlobalTransform 12 x f32, three 1-byte visibilities: examples/stress_tests/particles.rs:190-199)")
+    ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (RCCL broadcast + all-gather inside the library) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
+    ap.add_argument("--oversubscribe", action="store_true", help="--gpus N with fewer than N visible devices: rank r runs on device r %% devices (correctness only)")
+    ap.add_argument("--dry-run", action="store_true", help="--gpus N: print the N rank command lines (JSON, one per line) and exit")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
+    if args.paged_arena: args.arena = "paged"
+
+    # ---- `--gpus N` with no launcher around this process: start the N ranks here
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, [a for a in sys.argv[1:] if a != "--dry-run"]))
+    if args.dry_run:
+        print(json.dumps({"env": {}, "cmd": [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]}))
+        return
 
     import torch
     import __graft_entry__ as ge
@@ -193,74 +369,48 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size and "WORLD_SIZE" in os.environ:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s)", file=sys.stderr); sys.exit(2)
     dist = None
     distributed = world_size > 1 or args.fanout
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr); sys.exit(2)
+    if local_rank >= ndev and not args.oversubscribe:
+        print(f"bench.py: rank {rank} needs device {local_rank} but only {ndev} visible (--oversubscribe shares devices)", file=sys.stderr); sys.exit(2)
+    dev = local_rank % ndev
+    torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.cuda.current_device()
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev))
     n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+    bps = cm.schema_bytes_per_entity(args.schema)          # registered payload R (60 B for the headline schema)
+    comm_size = world_size
 
-    stream = torch.cuda.current_stream().cuda_stream
-    flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
-    # the world is the first device allocation of this process (nothing cached has been freed before it): the documented condition
-    # under which a physically contiguous arena is safe (include/ggrs_hip.h, GGRS_WORLD_CONTIG_ARENA); --paged-arena measures without
-    # (single-GPU path only: in the fan-out path RCCL has allocated and freed device memory before the world exists)
-    contig = not args.paged_arena and not distributed
-    if contig: flags |= bg.GGRS_WORLD_CONTIG_ARENA
-
+    variant = None
     if not distributed:
-        w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum)
-        warm_ring(bg, w, D)
-        run, _keep = tick_requests(bg, w, D)
-        for _ in range(W):
-            run(w.frame)
-        torch.cuda.synchronize()
-        gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
-        take = lambda out: gpu_cs.append(bytes(out))  # one 16 x D byte copy per tick inside the timed region; parsed afterwards
-        if args.sync:
-            t0 = time.perf_counter()
-            for _ in range(K):
-                take(run(w.frame))
-            torch.cuda.synchronize()
-            secs = time.perf_counter() - t0
-        else:
-            # one tick in flight ahead of the host: enqueue tick k+1, then collect tick k's checksums
-            # (what a shim does: cell.save() right before the next advance_frame()).  Every one of the K
-            # ticks is enqueued AND collected inside the timed region.
-            w.synchronize()
-            t0 = time.perf_counter()
-            run.enqueue(w.frame)
-            for _ in range(K - 1):
-                run.enqueue(w.frame)
-                take(run.collect())
-            take(run.collect())
-            w.synchronize()
-            torch.cuda.synchronize()
-            secs = time.perf_counter() - t0
-        live = w.active_count()
-        gpu_cs = [[int.from_bytes(b[16 * k:16 * k + 16], "little") for k in range(D)] for b in gpu_cs]
+        # order-safe: the contiguous arena must be this process's FIRST device allocation (include/ggrs_hip.h,
+        # GGRS_WORLD_CONTIG_ARENA), and freeing it leaves nothing cached behind -- so it is measured first, destroyed, and the
+        # headline (library default: paged) after it
+        if args.arena == "both":
+            variant = measure_single(bg, cm, torch, args, contig=True, light=True)
+        m = measure_single(bg, cm, torch, args, contig=(args.arena == "contig"))
+        secs, live, gpu_cs, prof = m["secs"], m["live"], m["gpu_cs"], m["prof"]
         # SyncTest's own check over ALL timed ticks (ggrs SyncTestSession: a resimulated frame's checksum must equal the first
         # one recorded for that frame, else MismatchedChecksum): timed tick k at frame F saved frames F-D+1 .. F
-        first_seen, resim_ok, f_end = {}, True, w.frame
+        first_seen, resim_ok, f_end = {}, True, m["f_end"]
         for k, tick in enumerate(gpu_cs):
             F = f_end - (len(gpu_cs) - k)
             for j, c in enumerate(tick):
                 resim_ok &= first_seen.setdefault(F - D + 1 + j, c) == c
-        # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
-        w.profile_enable(True)
-        for _ in range(min(K, 50)):
-            run(w.frame)
-        prof = w.profile_read()
-        w.profile_enable(False)
         total_entities = live
+        info = m["info"]
     else:
         from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+        stream = torch.cuda.current_stream().cuda_stream
+        flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
         # every rank provisions the same world shape; only rank 0 owns the confirmed world, the others receive it through
         # ONE ncclBroadcast of the packed state block.  The collectives are issued INSIDE libggrs_hip.so
         # (ggrs_hip_fanout_*, RCCL dlopen'ed there); torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier.
@@ -274,12 +424,19 @@ def main():
         box = [RcclFanout.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         native = RcclFanout(w, rank, world_size, box[0])
+        c_rank, comm_size, c_dev = native.comm_info()        # what the communicator says, not what the environment says
+        assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
         fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
                                 desync_detection_interval=10 if args.branches == 1 else 1)   # the reference stress_test's default (particles.rs:49, README.md:84)
         fan.sync_confirmed(0)
         for _ in range(W):
             fan.step_pipelined(want_result=False)
         fan.drain(want_result=False)
+        pre_t0 = time.perf_counter(); pre_n = 0
+        while (time.perf_counter() - pre_t0) * 1e3 < args.preheat_ms:
+            fan.step_pipelined(want_result=False); pre_n += 1
+        fan.drain(want_result=False)
+        m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms}}
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
@@ -300,6 +457,7 @@ def main():
             fan.step(want_result=False)
         prof = w.profile_read()
         w.profile_enable(False)
+        info = w.kernel_info()
 
     value = total_entities * (D + 1) * K / secs
     save_ms, save_n = prof["save"]
@@ -319,7 +477,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum)
+            same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum and tj.get("schema", "headline") == args.schema)
             if same:
                 traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
                 if traffic is not None:
@@ -327,70 +485,80 @@ def main():
         except Exception:
             traffic = None
 
+    save_bytes, tick_bytes = 2 * bps, 2 * bps + 2 * bps * D + ADV_BYTES * (D + 1)
     if grouped:
-        # one k_tick launch per step (N = 1): read the snapshot once, write D snapshots, write live once
+        # one fused launch per step (N = 1): read the snapshot once, write D snapshots, write live once
         launches_per_step = tick_n / max(min(K, 20 if distributed else 50), 1)
-        # N = 1 tick and fan-out step have the same shape: read one snapshot, write D, write live once
-        bytes_per_launch = BYTES_PER_ENTITY * (1 + D + 1) * live              # 600 B/entity at D = 8
+        bytes_per_launch = bps * (1 + D + 1) * live              # 600 B/entity at D = 8 for the headline schema
         avg_s = per(tick_ms, tick_n)
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
-        # which fused kernel served the group: k_tick3 folds in-kernel (no finalize launches); below its range the world runs on
-        # the request-group kernel the library generated for it at seal (hiprtc) unless GGRS_TICK_JIT=0 put k_tick1 / k_tick back
-        # (ggrs_hip.hip::use_tick_runner: particles worlds up to GGRS_JIT_PARTICLES_MAX_SLOTS = 416 k slots; groups of up to 256
-        #  workgroups leave their partial rows in pinned memory and the host folds them at collect time: no finalize launch either)
-        jit = (live <= int(os.environ.get("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024)) and os.environ.get("GGRS_TICK_JIT", "1") != "0"
-               and not os.environ.get("GGRS_TICK_VEC"))
-        fin_name = "k_gen_finalize" if jit else "k_tick_finalize"
-        kname = "ggrs_jit_tick (generated for this world at seal)" if jit else ("k_tick3" if fin_n == 0 else "k_tick1 / k_tick")
-        fold = (", checksum fold in-kernel)" if not jit else ", per-workgroup checksum partials folded by the host at collect time)") if fin_n == 0 else f"; + {fin_name})"
-        roof = {"bound": "hbm", "kernel": kname + " (fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch" + fold,
+        kname = info.get("request_group_kernel", "?")
+        fin_name = "k_gen_finalize / k_tick_finalize"
+        roof = {"bound": "hbm", "kernel": kname + " -- fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
+                                           + ("" if fin_n == 0 else f"; + {fin_name}"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
-                # the two accountings, named so they cannot be confused: `frac` == frac_compulsory_600B
-                "frac_compulsory_600B": achieved / HBM_PEAK_GBS,
-                "frac_per_request_1656B": (TICK_BYTES(D) * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
+                # the two accountings, named so they cannot be confused: `frac` == frac_compulsory
+                "frac_compulsory": achieved / HBM_PEAK_GBS,
+                "frac_per_request": (tick_bytes * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_note": "compulsory traffic of the fused group: 60 B/entity snapshot read + 60 B x saves + 60 B live write "
-                                          "(SURVEY 8d's 1656 B/entity-tick assumes one kernel per request; that per-request equivalent is reported below)",
+                "algorithmic_bytes_note": f"compulsory traffic of the fused group: {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write "
+                                          f"(SURVEY 8d's one-kernel-per-request model, {tick_bytes} B/entity-tick, is reported as *_per_request)",
                 "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
+                "launch_us": m.get("launch_us"),
                 "other_kernels": ({fin_name: {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
-                "per_request_equiv_GBps": TICK_BYTES(D) * live * K / secs / 1e9,
-                "per_request_equiv_frac": TICK_BYTES(D) * live * K / secs / 1e9 / HBM_PEAK_GBS}
+                "per_request_equiv_GBps": tick_bytes * live * K / secs / 1e9,
+                "per_request_equiv_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
+        if variant is not None:
+            v_ms, v_n = variant["prof"]["tick"]
+            v_avg = per(v_ms, v_n)
+            roof["contig_arena_variant"] = {
+                "what": "the same measurement on a physically contiguous arena (GGRS_WORLD_CONTIG_ARENA, opt-in: see include/ggrs_hip.h), "
+                        "measured first in this process; NOT the headline",
+                "arena_actual": variant["info"].get("arena"), "value": variant["live"] * (D + 1) * K / variant["secs"],
+                "ms_per_step": variant["secs"] / K * 1e3, "avg_launch_us": v_avg * 1e6,
+                "frac": (bps * (D + 2) * variant["live"] / v_avg / 1e9 / HBM_PEAK_GBS) if v_n else 0.0}
     else:
         save_avg_s = per(save_ms, save_n)
-        achieved = SAVE_BYTES * live / save_avg_s / 1e9 if save_n else 0.0
+        achieved = save_bytes * live / save_avg_s / 1e9 if save_n else 0.0
         roof = {"bound": "hbm", "kernel": "k_copy_state (SaveWorld)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": SAVE_BYTES * live,
+                "algorithmic_bytes_per_launch": save_bytes * live,
                 "avg_launch_us": save_avg_s * 1e6, "launches_timed": save_n,
                 "other_kernels": {
                     "k_particles_step (AdvanceWorld)": {"avg_launch_us": per(adv_ms, adv_n) * 1e6,
                                                        "achieved_GBps": ADV_BYTES * live / per(adv_ms, adv_n) / 1e9 if adv_n else 0.0},
                     "k_copy_state (LoadWorld)": {"avg_launch_us": per(load_ms, load_n) * 1e6,
-                                                "achieved_GBps": SAVE_BYTES * live / per(load_ms, load_n) / 1e9 if load_n else 0.0}},
-                "whole_tick_achieved_GBps": TICK_BYTES(D) * live * K / secs / 1e9,
-                "whole_tick_frac": TICK_BYTES(D) * live * K / secs / 1e9 / HBM_PEAK_GBS}
+                                                "achieved_GBps": save_bytes * live / per(load_ms, load_n) / 1e9 if load_n else 0.0}},
+                "whole_tick_achieved_GBps": tick_bytes * live * K / secs / 1e9,
+                "whole_tick_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
 
+    headline = n == 1_000_000 and D == 8 and args.schema == "headline"
     line = {
-        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak",
-        "value": value, "unit": "entity-frames/s", "n_gpus": world_size, "steps": K, "warmup": W,
+        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak" if headline else
+                  f"rollback-resim entity-frames/sec at {n} entities, depth {D}, schema {args.schema}; HBM GB/s vs peak",
+        "value": value, "unit": "entity-frames/s", "n_gpus": comm_size, "steps": K, "warmup": W,
         "ms_per_step": secs / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
-        "config": {"workload": f"stress_test {n} entities x 3 registered components (Transform, Velocity, Ttl; 60 B/entity), "
+        "config": {"workload": f"stress_test {n} entities x {cm.schema_description(args.schema)}, "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {world_size} ranks (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
+                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "arena": "physically contiguous requested (GGRS_WORLD_CONTIG_ARENA: the world is this process's first device allocation; honoured for k_tick3 worlds up to 1.5 GiB)" if contig else "paged (library default)",
+                   "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"),
+                   "hiprtc": info.get("hiprtc"), "device": dev,
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
+        "preheat": m.get("preheat"),
         "roofline": roof,
     }
+    if not distributed:
+        line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us")}
     parity_failed = False
     if rank == 0 and not distributed:
         line["parity"] = {"synctest_resim_consistent_over_timed_ticks": bool(resim_ok), "timed_ticks": len(gpu_cs)}
         parity_failed = not resim_ok
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        base, par = cpu_baseline_and_parity(n, D, args.cpu_ticks, W, gpu_cs, 0 if args.no_checksum else args.parity_ticks)
+        base, par = cpu_baseline_and_parity(n, D, args.cpu_ticks, m["frames_before_timed"], gpu_cs, 0 if args.no_checksum else args.parity_ticks, schema=args.schema)
         line["cpu_baseline"] = base
         line["parity"].update(par)
         parity_failed |= par["equal"] is False

@@ -128,8 +128,11 @@ SIGNATURES = {
     "ggrs_hip_fanout_collect": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ggrs_hip_fanout_destroy": (None, [_P]),
     "ggrs_hip_fanout_last_error": (C.c_char_p, [_P]),
+    "ggrs_hip_fanout_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ggrs_hip_profile_enable": (C.c_int, [_P, C.c_int]),
     "ggrs_hip_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ggrs_hip_profile_read_launches": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ggrs_hip_world_kernel_info": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 

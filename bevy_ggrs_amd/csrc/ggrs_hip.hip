@@ -158,6 +158,7 @@ struct ggrs_world {
     std::vector<Custom> customs;
     hipFunction_t jit_fn = nullptr;      // the request-group kernel generated for this world (jit_source), or null
     hipFunction_t jit_fn4 = nullptr;     // its 4-slots-per-lane form (worlds that can grow past JIT_V4_MIN_SLOTS)
+    std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)
     bool jit_marks = false;
     bool jit_reads_inputs = false;       // a system reads PlayerInputs (BOX_MOVE, custom): branches with different inputs differ
     uint32_t gen_parts_saves = 0;        // Save rows of d_gen_parts (room for a batch of checksum-only groups in small worlds)
@@ -247,6 +248,7 @@ struct ggrs_world {
     std::vector<EventPair> prof_events;
     double prof_ms[GGRS_KERNEL_CLASSES] = {};
     uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
+    std::vector<float> prof_launch_us[GGRS_KERNEL_CLASSES];   // every launch since enable, in submission order (ggrs_hip_profile_read_launches)
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -609,13 +611,15 @@ int seal_impl(ggrs_world* w) {
         // the kernel generated for this world (jit_source): preferred; k_tick_gen stays as the fallback for worlds it covers
         if (ok && w->knobs.tick_jit) {
             std::string src;
-            if (jit_source(w, src, 1)) {
+            if (!jit_source(w, src, 1)) w->jit_status = "not covered by the generator (a system writes a live-only component, or too many words per entity)";
+            else {
                 if (w->knobs.debug_jit > 1) fprintf(stderr, "%s\n", src.c_str());
                 const std::string keep = w->err;
                 if (jit_cached(w, src, &w->jit_fn) != GGRS_OK) {
                     if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] generated request-group kernel rejected: %s\n", w->err.c_str());
+                    w->jit_status = (hiprtc().lib ? "rejected: " : "hiprtc unavailable: ") + w->err.substr(0, 300);
                     w->jit_fn = nullptr; w->err = keep;
-                }
+                } else w->jit_status = "ok";
                 if (w->jit_fn && w->knobs.jit_v == 4 && jit_source(w, src, 4) && jit_cached(w, src, &w->jit_fn4) != GGRS_OK) {
                     if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] generated request-group kernel (4 slots per lane) rejected: %s\n", w->err.c_str());
                     w->jit_fn4 = nullptr; w->err = keep;
@@ -1413,11 +1417,15 @@ int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out, uint
     *dt_bits_out = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
     return GGRS_OK;
 }
-void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves) {
+// dead: the group ran checksum-only (dead-snapshot elimination) -- neither its ring slots nor the live block were written, so
+// their dirty extents still describe what they hold: lowering them here would leave mask bits beyond the new extent that no
+// later pass cleans (ghost entities once len grows back into those words)
+void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead = false) {
+    w->pending_valid = false;
+    if (dead) return;
     const uint64_t new_dirty = std::max(g.src->dirty_len, w->len);
     for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) g.dsts[k]->dirty_len = new_dirty;
     w->live.dirty_len = new_dirty;
-    w->pending_valid = false;
 }
 
 // Depth-parallel k_tick1 (kernels.hpp): the group's outputs (Saves + live world) are split over grid.z roles of dp_s outputs.
@@ -1643,17 +1651,17 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
                 else { if (nt) launch_tick2<true, 0>(w, b, g2); else launch_tick2<false, 0>(w, b, g2); }
             }
             HIPCHK(w, hipGetLastError());
-            group_close(w, gs, a.n_saves);
+            group_close(w, gs, a.n_saves, dead);
             ns += a.n_saves;
         } else if (vec == 1 && dead && !w->nt_copy && batch.try_add(w, a, g, res_base + ns)) {
             // an identical checksum-only group already waits to be launched: this one rides along as blockIdx.y = K
-            group_close(w, gs, a.n_saves);
+            group_close(w, gs, a.n_saves, dead);
             ns += a.n_saves;
         } else {
         rc = batch.flush(w); if (rc) return rc;
         if (vec == 1 && dead && !w->nt_copy) {
             batch.start(a, g, res_base + ns);                          // launched when the batch is full or something else follows
-            group_close(w, gs, a.n_saves);
+            group_close(w, gs, a.n_saves, dead);
             ns += a.n_saves;
         } else {
         if (a.n_ops || !a.src_is_live) {
@@ -1663,7 +1671,7 @@ int run_request_groups(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint
             else { if (w->nt_copy) launch_tick<true, 4>(w, a, g); else launch_tick<false, 4>(w, a, g); }
         }
         HIPCHK(w, hipGetLastError());
-        group_close(w, gs, a.n_saves);
+        group_close(w, gs, a.n_saves, dead);
         if (a.n_saves) {
             TickFinArgs f; memset(&f, 0, sizeof f);
             f.parts = w->d_tick_parts; f.part_stride = w->tick_part_stride; f.n_parts = vec == 4 ? 4 * g : (vec == 41 ? g : 4 * g);
@@ -1817,10 +1825,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             const bool batchable = dead && !v4 && a.n_saves > 0 && !w->jit_marks && cover <= TICK_VEC1_MAX_SLOTS;
             if (batchable && batch.active) {
                 GgrsJitArgs jb = j; jb.dp_s = 0;
-                if (batch.try_add(w, jb, g, res_base + ns)) { batch.j.dp_s = 0; group_close(w, gs, a.n_saves); ns += a.n_saves; goto group_done; }
+                if (batch.try_add(w, jb, g, res_base + ns)) { batch.j.dp_s = 0; group_close(w, gs, a.n_saves, dead); ns += a.n_saves; goto group_done; }
             }
             rc = batch.flush(w); if (rc) return rc;
-            if (batchable) { batch.start(j, g, res_base + ns, a.n_cks); group_close(w, gs, a.n_saves); ns += a.n_saves; goto group_done; }
+            if (batchable) { batch.start(j, g, res_base + ns, a.n_cks); group_close(w, gs, a.n_saves, dead); ns += a.n_saves; goto group_done; }
             uint64_t rows_off = 0;
             const bool host_fold = (a.n_ops || !a.src_is_live) && host_fold_rows(w, g, a.n_saves, a.n_cks, 1, &rows_off);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
@@ -1829,7 +1837,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 void* params[] = {&j};
                 HIPCHK(w, hipModuleLaunchKernel(v4 ? w->jit_fn4 : w->jit_fn, g, j.dp_s ? (a.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, 0, w->stream, params, nullptr));
             }
-            group_close(w, gs, a.n_saves);
+            group_close(w, gs, a.n_saves, dead);
             if (host_fold) { w->folds.push_back({res_base + ns, a.n_saves, g, a.n_cks, 1u, rows_off, w->len}); ns += a.n_saves; }
             else if (a.n_saves) {
                 GenFinArgs f; memset(&f, 0, sizeof f);
@@ -1870,7 +1878,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             hipLaunchKernelGGL(k_tick_gen, dim3(g, a.dp_s ? (a.n_saves + a.dp_s) / a.dp_s : 1u), dim3(GEN_TPB), lds, w->stream, a);
         }
         HIPCHK(w, hipGetLastError());
-        group_close(w, gs, a.n_saves);
+        group_close(w, gs, a.n_saves, dead);
         if (a.n_saves) {
             GenFinArgs f; memset(&f, 0, sizeof f);
             f.parts = a.parts; f.part_stride = a.part_stride; f.n_parts = 4 * g; f.n_cks = a.n_cks; f.total_len = w->len;
@@ -2449,23 +2457,70 @@ int ggrs_hip_adopt_live_state(ggrs_world* w) {
     return GGRS_OK;
 }
 
+// Which kernel serves this world's request lists right now, on what kind of arena, and the state of the run-time
+// compiler -- `key=value` lines (NUL-terminated, truncated to cap).  Nothing here is needed to USE the library: it is what an
+// operator reads when a world is slower than expected (e.g. libhiprtc.so missing from a deployment image).
+int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed) {
+    if (!w || (!buf && cap)) return GGRS_E_INVALID;
+    std::string s;
+    char line[768];
+    auto add = [&](const char* k, const std::string& v) { snprintf(line, sizeof line, "%s=%s\n", k, v.c_str()); s += line; };
+    add("sealed", w->sealed ? "1" : "0");
+    add("arena", !w->sealed ? "none" : (!w->own_arena ? "caller-provided" : (w->arena_contiguous ? "contiguous (hipExtMallocWithFlags, write-through)" : "paged (hipMalloc)")));
+    add("arena_bytes", std::to_string(w->arena_bytes));
+    {
+        Hiprtc& r = hiprtc();
+        add("hiprtc", r.lib ? "loaded" : ("missing: " + r.why));
+    }
+    add("generated_kernel", w->jit_fn ? "ok" : w->jit_status);
+    std::string k;
+    const uint64_t cover = std::max(w->len, w->live.dirty_len);
+    if (!w->sealed) k = "unknown (not sealed)";
+    else if (!(w->tick_ok || w->gen_ok)) k = "per-request kernels (k_copy_state, one launch per system)";
+    else if (use_tick_runner(w)) {
+        const bool use2 = w->tick2_ok && !w->knobs.tick_vec && cover > w->knobs.tick2_min_slots;
+        k = use2 ? (w->knobs.tick3 ? "k_tick3 (wave-specialised, in-kernel checksum fold)" : "k_tick2") : "k_tick1 / k_tick + k_tick_finalize";
+    } else k = w->jit_fn ? "ggrs_jit_tick (generated for this world)" : "k_tick_gen (LDS-staged interpreter)";
+    add("request_group_kernel", k);
+    add("slots_covered", std::to_string(cover));
+    if (needed) *needed = s.size() + 1;
+    if (buf && cap) { const uint64_t n = std::min<uint64_t>(cap, s.size() + 1); memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }
+    return GGRS_OK;
+}
+
 int ggrs_hip_profile_enable(ggrs_world* w, int on) {
     if (!w) return GGRS_E_INVALID;
     w->prof = on != 0;
     if (on) { for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } w->prof_events.clear();
-              for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; } }
+              for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; w->prof_launch_us[i].clear(); } }
+    return GGRS_OK;
+}
+// drains the recorded event pairs into the per-class totals and per-launch lists
+static int profile_drain(ggrs_world* w) {
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (auto& e : w->prof_events) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);
+        w->prof_ms[e.cls] += ms; w->prof_n[e.cls] += 1;
+        if (w->prof_launch_us[e.cls].size() < 65536) w->prof_launch_us[e.cls].push_back(ms * 1e3f);
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    w->prof_events.clear();
+    return GGRS_OK;
+}
+int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t cls, float* us_out, uint32_t cap, uint32_t* n_out) {
+    if (!w || cls >= GGRS_KERNEL_CLASSES || (!us_out && cap)) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
+    int rc = profile_drain(w); if (rc) return rc;
+    const std::vector<float>& v = w->prof_launch_us[cls];
+    const uint32_t n = (uint32_t)std::min<size_t>(v.size(), cap);
+    if (n) memcpy(us_out, v.data(), (size_t)n * sizeof(float));
+    if (n_out) *n_out = (uint32_t)v.size();
     return GGRS_OK;
 }
 int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out) {
     if (!w || !ms_out || !launches_out) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    HIPCHK(w, hipStreamSynchronize(w->stream));
-    for (auto& e : w->prof_events) {
-        float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);
-        w->prof_ms[e.cls] += ms; w->prof_n[e.cls] += 1;
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
-    }
-    w->prof_events.clear();
+    int rc = profile_drain(w); if (rc) return rc;
     for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { ms_out[i] = w->prof_ms[i]; launches_out[i] = w->prof_n[i]; }
     return GGRS_OK;
 }
@@ -2485,28 +2540,38 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     std::string why;
-    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && Broadcast && AllGather && GetErrorString; }
+    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && Broadcast && AllGather && GetErrorString && CommCount && CommUserRank; }
 };
 // ONE RCCL per process: a copy that is already mapped (a torch process ships its own librccl.so) wins over /opt/rocm's,
 // or two collective runtimes would each initialise the device.
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
-    const char* names[] = {"librccl.so", "librccl.so.1"};
-    for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-    for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) { r.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+void rccl_load(Rccl& r) {
+    // GGRS_RCCL_LIB=<path>: load THIS collective library instead (tests: a same-GPU transport double, tests/cpp/rccl_double.cpp,
+    // so that the rank != 0 half of the fan-out runs on a one-GPU box where RCCL refuses two ranks per device)
+    if (const char* forced = getenv("GGRS_RCCL_LIB")) { if (*forced) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL); }
+    else {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!r.lib) { const char* e = dlerror(); r.why = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return; }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     if (!r.ok()) r.why = "librccl.so lacks an expected entry point";
+}
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });                     // worlds may start their fan-out from several threads
     return r;
 }
 constexpr int FANOUT_MAX_INFLIGHT = 8;
@@ -2614,9 +2679,20 @@ void ggrs_hip_fanout_destroy(ggrs_fanout* f) {
     delete f;
 }
 const char* ggrs_hip_fanout_last_error(ggrs_fanout* f) { return f ? f->err.c_str() : "null fan-out"; }
+int ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int* device_out) {
+    if (!f || !f->comm) return GGRS_E_INVALID;
+    int n = 0, r = 0;
+    FANCHK_NCCL(f, rccl().CommCount(f->comm, &n));
+    FANCHK_NCCL(f, rccl().CommUserRank(f->comm, &r));
+    if (rank_out) *rank_out = r;
+    if (size_out) *size_out = n;
+    if (device_out) *device_out = f->w->device;
+    return GGRS_OK;
+}
 
 int ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather) {
-    if (!f || steps_per_all_gather == 0 || steps_per_all_gather > 64) return GGRS_E_INVALID;
+    // a group's steps are all outstanding batches of the world until the group is collected: at most 16 (ggrs_hip_enqueue_requests)
+    if (!f || steps_per_all_gather == 0 || steps_per_all_gather > 16) return GGRS_E_INVALID;
     if (f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps) return f->fail(GGRS_E_INVALID, "interval changed inside a partly filled group");
     f->interval = steps_per_all_gather;
     return GGRS_OK;
@@ -2646,11 +2722,15 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
     if (f->tail - f->head >= (uint32_t)FANOUT_MAX_INFLIGHT) return f->fail(GGRS_E_INVALID, "%d all-gathers in flight: call ggrs_hip_fanout_collect", FANOUT_MAX_INFLIGHT);
     ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
     if (s.n_steps == 0) { s.closed = false; s.n_saves = 0; }
+    // everything that can refuse the step is checked BEFORE the world advances: a batch enqueued here and not tracked by a slot
+    // would shift every later collect by one
+    uint32_t want = 0;
+    for (uint32_t i = 0; i < n; ++i) want += reqs[i].kind == GGRS_REQ_SAVE;
+    if (s.n_steps && want != s.n_saves) return f->fail(GGRS_E_INVALID, "steps of one all-gather group must hold the same number of SaveGameState requests (%u vs %u)", want, s.n_saves);
+    if ((uint64_t)(s.n_steps + 1) * want > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u checksums per rank in one all-gather (at most %u)", (s.n_steps + 1) * want, f->cap_u128);
     uint32_t ns = 0;
     int rc = ggrs_hip_enqueue_requests(w, reqs, n, &ns);
     if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
-    if (s.n_steps && ns != s.n_saves) return f->fail(GGRS_E_INVALID, "steps of one all-gather group must hold the same number of SaveGameState requests (%u vs %u)", ns, s.n_saves);
-    if ((uint64_t)(s.n_steps + 1) * ns > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u checksums per rank in one all-gather (at most %u)", (s.n_steps + 1) * ns, f->cap_u128);
     s.n_saves = ns;
     s.first[s.n_steps] = w->pending.back().first;        // where the kernels write this step's checksums (pinned result ring)
     ++s.n_steps;

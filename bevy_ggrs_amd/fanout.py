@@ -148,6 +148,13 @@ class RcclFanout:
     def step_raw(self, arr, n: int):
         self._check(self._lib.ggrs_hip_fanout_step(self._p, arr, n, None))
 
+    def comm_info(self):
+        """(rank, world size, HIP device) as the communicator itself reports them (ncclCommUserRank / ncclCommCount)."""
+        import ctypes as C
+        r, n, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.ggrs_hip_fanout_comm_info(self._p, C.byref(r), C.byref(n), C.byref(d)))
+        return r.value, n.value, d.value
+
     def set_interval(self, steps_per_all_gather: int):
         self._check(self._lib.ggrs_hip_fanout_set_interval(self._p, steps_per_all_gather))
 

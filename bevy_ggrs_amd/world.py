@@ -353,3 +353,19 @@ class World(WorldBase):
         self._check(self._lib.ggrs_hip_profile_read(self._p, ms, n))
         names = ["save", "load", "advance", "checksum", "tick"]
         return {names[i]: (float(ms[i]), int(n[i])) for i in range(_ffi.KERNEL_CLASSES)}
+
+    def profile_launches(self, cls: str = "tick", cap: int = 65536):
+        """Duration (us) of every launch of one kernel class since profile_enable(True), in submission order."""
+        idx = ["save", "load", "advance", "checksum", "tick"].index(cls)
+        buf = (C.c_float * cap)()
+        n = C.c_uint32(0)
+        self._check(self._lib.ggrs_hip_profile_read_launches(self._p, idx, buf, cap, C.byref(n)))
+        return [float(buf[i]) for i in range(min(cap, n.value))]
+
+    def kernel_info(self) -> dict:
+        """ggrs_hip_world_kernel_info as a dict: arena kind, run-time compiler state, which kernel serves the world."""
+        need = C.c_uint64(0)
+        self._check(self._lib.ggrs_hip_world_kernel_info(self._p, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(int(need.value))
+        self._check(self._lib.ggrs_hip_world_kernel_info(self._p, buf, need.value, None))
+        return dict(l.split("=", 1) for l in buf.value.decode().splitlines() if "=" in l)

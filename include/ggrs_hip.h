@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 5
+#define GGRS_HIP_ABI_VERSION 6
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -332,7 +332,8 @@ int ggrs_hip_adopt_live_state(ggrs_world* w);
  *   init             every rank: ncclCommInitRank on the world's device; the communicator lives until fanout_destroy.
  *   sync_confirmed   ONE ncclBroadcast of `root`'s packed live block (ggrs_hip_state_bytes bytes, in place in HBM) on
  *                    the world's stream; receivers adopt it (len, frame).  Start-up / desync recovery only.
- *   set_interval     steps whose checksums travel in ONE all-gather (default 1).  The reference's stress_test exchanges
+ *   set_interval     steps whose checksums travel in ONE all-gather (default 1, at most 16: a group's steps stay outstanding
+ *                    batches of the world until the group is collected).  The reference's stress_test exchanges
  *                    checksums every --desync-detection-interval frames, default 10 (examples/stress_tests/particles.rs:49).
  *   step             ggrs_hip_enqueue_requests of this rank's branch list; behind an event, on a side stream -- the next
  *                    step's kernels are not held up -- its Checksum(u128)s join the current group, and every `interval`-th
@@ -351,6 +352,9 @@ int  ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather)
 int  ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t max_u128_per_rank, uint32_t* n_steps_out, uint32_t* n_saves_out);
 void ggrs_hip_fanout_destroy(ggrs_fanout* f);
 const char* ggrs_hip_fanout_last_error(ggrs_fanout* f);
+/* what the communicator itself says (ncclCommUserRank / ncclCommCount) and the HIP device the world runs on: bench.py prints
+ * n_gpus from here, not from the environment. */
+int  ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int* device_out);
 
 /* -------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class HIP-event timing on the world's stream.
@@ -364,6 +368,17 @@ const char* ggrs_hip_fanout_last_error(ggrs_fanout* f);
 int ggrs_hip_profile_enable(ggrs_world* w, int on);
 /* total milliseconds and launch count per class since enable; sizes GGRS_KERNEL_CLASSES */
 int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out);
+/* duration (microseconds) of every launch of one class since enable, in submission order: min(cap, *n_out) values are
+ * copied, *n_out = launches recorded (bench.py: first vs last timed launch, clock ramp diagnosis). */
+int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t kernel_class, float* us_out, uint32_t cap, uint32_t* n_out);
+
+/* -------------------------------------------------------------------------------------------
+ * Introspection: which kernel serves this world's request lists right now and why, what kind of arena
+ * it lives on, whether the run-time compiler (libhiprtc.so, dlopen'ed) is available.  `key=value` lines,
+ * NUL-terminated; *needed = bytes incl. the NUL, min(cap, *needed) are copied.  Keys: sealed, arena,
+ * arena_bytes, hiprtc, generated_kernel, request_group_kernel, slots_covered.
+ * ------------------------------------------------------------------------------------------- */
+int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed);
 
 #ifdef __cplusplus
 }

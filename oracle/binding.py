@@ -83,6 +83,7 @@ def _load():
         "gor_handle_requests": (C.c_int, [P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64)]),
         "gor_bench_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32]),
         "gor_replay_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
+        "gor_replay_synctest_from": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
         "gor_set_ref_component_threads": (None, [C.c_int]),
         "gor_num_threads": (C.c_int, []),
         "gor_set_num_threads": (None, [C.c_int]),
@@ -134,6 +135,16 @@ class OracleWorld(WorldBase):
         buf = (C.c_uint64 * (2 * cap))()
         n = C.c_uint64(0)
         secs = float(lib.gor_replay_synctest(self._p, d, ticks, timed_ticks, buf, cap, C.byref(n)))
+        return secs, [int(buf[2 * k]) | (int(buf[2 * k + 1]) << 64) for k in range(n.value)]
+
+
+    def replay_synctest_from(self, d: int, skip_frames: int, ticks: int):
+        """Fast-forward `skip_frames` advance-only frames + d+1 plain ticks, then `ticks` SyncTest ticks;
+        returns (seconds of those ticks, [checksum per Save of those ticks])."""
+        cap = (d + 1) * ticks + 8
+        buf = (C.c_uint64 * (2 * cap))()
+        n = C.c_uint64(0)
+        secs = float(lib.gor_replay_synctest_from(self._p, d, skip_frames, ticks, buf, cap, C.byref(n)))
         return secs, [int(buf[2 * k]) | (int(buf[2 * k + 1]) << 64) for k in range(n.value)]
 
 

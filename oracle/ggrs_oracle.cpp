@@ -1176,6 +1176,21 @@ double gor_replay_synctest(void* wp, uint32_t d, uint32_t ticks, uint32_t timed_
     if (n_saves_out) *n_saves_out = n;
     return std::chrono::duration<double>(t1 - t0).count();
 }
+// bench.py's pre-heat runs hundreds of SyncTest ticks before the timed region; by determinism (what SyncTest itself asserts,
+// tests/synctest.rs) the state they leave at frame F is the state F plain AdvanceWorlds leave, so the checker gets there with
+// `skip_frames` advance-only frames, then d + 1 plain [SaveWorld, AdvanceWorld] ticks (the ring the first timed tick loads
+// from), then `ticks` real SyncTest ticks whose checksums are handed back.  Returns the seconds the real ticks took.
+double gor_replay_synctest_from(void* wp, uint32_t d, uint32_t skip_frames, uint32_t ticks, uint64_t* cs_out, uint64_t cs_cap, uint64_t* n_saves_out) {
+    World& w = *(World*)wp;
+    for (uint32_t f = 0; f < skip_frames; ++f) { AdvanceArgs a{0, nullptr, 0, 0, nullptr, nullptr}; world_advance(w, a); }
+    uint64_t cs[2];
+    for (uint32_t t = 0; t < d + 1; ++t) {
+        w.has_confirmed = (w.frame - (int32_t)d) >= 0; w.confirmed = w.frame - (int32_t)d;
+        world_save(w, cs);
+        AdvanceArgs a{0, nullptr, 0, 0, nullptr, nullptr}; world_advance(w, a);
+    }
+    return gor_replay_synctest(wp, d, ticks, ticks, cs_out, cs_cap, n_saves_out);
+}
 void gor_set_ref_component_threads(int n) { g_ref_comp_threads = n < 1 ? 1 : n; }
 
 int gor_num_threads() {

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 5;
+pub const GGRS_HIP_ABI_VERSION: c_int = 6;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -164,7 +164,10 @@ unsafe extern "C" {
     pub fn ggrs_hip_fanout_collect(f: *mut ggrs_fanout, checksums_out: *mut u64, max_u128_per_rank: u32, n_steps_out: *mut u32, n_saves_out: *mut u32) -> c_int;
     pub fn ggrs_hip_fanout_destroy(f: *mut ggrs_fanout);
     pub fn ggrs_hip_fanout_last_error(f: *mut ggrs_fanout) -> *const c_char;
+    pub fn ggrs_hip_fanout_comm_info(f: *mut ggrs_fanout, rank_out: *mut c_int, size_out: *mut c_int, device_out: *mut c_int) -> c_int;
     // ---- measurement hooks
     pub fn ggrs_hip_profile_enable(w: *mut ggrs_world, on: c_int) -> c_int;
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;
+    pub fn ggrs_hip_profile_read_launches(w: *mut ggrs_world, kernel_class: u32, us_out: *mut f32, cap: u32, n_out: *mut u32) -> c_int;
+    pub fn ggrs_hip_world_kernel_info(w: *mut ggrs_world, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
 }

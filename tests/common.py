@@ -16,11 +16,37 @@ def f32bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def build_particles(world, *, with_spawn=False, ttl_init=300, checksum=True):
-    """particles.rs:187-240 restricted to the 3 registered components of SURVEY.md section 8."""
+# examples/stress_tests/particles.rs:190-199 registers Sprite (not POD: it holds an asset handle -- out of scope), Transform,
+# GlobalTransform, Visibility, InheritedVisibility, ViewVisibility, Velocity, Ttl.  "full" = that list minus Sprite:
+# GlobalTransform is an Affine3A (3x3 matrix + translation = 12 f32), Visibility a 1-byte enum, the other two 1-byte bools.
+GLOBAL_TRANSFORM_DEFAULT = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float32)   # GlobalTransform::IDENTITY
+FULL_EXTRA = (("GlobalTransform", 4, 12), ("Visibility", 1, 1), ("InheritedVisibility", 1, 1), ("ViewVisibility", 1, 1))
+
+
+def schema_bytes_per_entity(schema="headline"):
+    return 60 if schema == "headline" else 60 + sum(wb * nw for _, wb, nw in FULL_EXTRA)
+
+
+def schema_description(schema="headline"):
+    if schema == "headline":
+        return "3 registered components (Transform, Velocity, Ttl; 60 B/entity)"
+    return (f"7 registered components (Transform, GlobalTransform, Visibility, InheritedVisibility, ViewVisibility, Velocity, Ttl; "
+            f"{schema_bytes_per_entity(schema)} B/entity: the reference stress_test's rollback list minus Sprite, particles.rs:190-199)")
+
+
+def build_particles(world, *, with_spawn=False, ttl_init=300, checksum=True, schema="headline"):
+    """particles.rs:187-240: the 3 registered components of SURVEY.md section 8 ("headline"), or the reference's whole POD
+    rollback list ("full": the extra components are registered FIRST-TO-LAST as the reference does, ids 3..6, and returned
+    after T, V, L so that callers indexing ids[:3] keep working)."""
     T = world.register_component("Transform", 4, 10)
     V = world.register_component("Velocity", 4, 3)
     L = world.register_component("Ttl", 8, 1)
+    extra = ()
+    if schema == "full":
+        extra = tuple(world.register_component(nm, wb, nw) for nm, wb, nw in FULL_EXTRA)
+        world.set_component_default(extra[0], GLOBAL_TRANSFORM_DEFAULT)
+        for c, v in zip(extra[1:], (0, 1, 0)):                  # Visibility::Inherited, InheritedVisibility(true), ViewVisibility(false)
+            world.set_component_default(c, np.array([v], dtype=np.uint8))
     world.set_component_default(T, TRANSFORM_DEFAULT)
     if checksum:
         world.checksum_component(V, [0, 1, 2])        # checksum_component_with_hash::<Velocity>()
@@ -29,7 +55,7 @@ def build_particles(world, *, with_spawn=False, ttl_init=300, checksum=True):
     world.add_system(bg.SYS_TTL_DESPAWN, comp=(L,), word=(0,))
     if with_spawn:
         world.add_system(bg.SYS_PARTICLES_SPAWN, comp=(T, V, L), iparam=(ttl_init, INPUT_SPAWN))
-    return T, V, L
+    return (T, V, L) + extra
 
 
 def synthetic_particles(n, ttl="throughput", seed=123):
@@ -46,10 +72,12 @@ def synthetic_particles(n, ttl="throughput", seed=123):
 
 
 def spawn_particles(world, ids, n, vel, ttl):
-    T, V, L = ids
+    T, V, L = ids[:3]
     tcols = [np.full(n, f32bits(TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
     vcols = [f32bits(vel[:, 0]), f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
-    return world.spawn(n, {T: tcols, V: vcols, L: [ttl]})
+    bundle = {T: tcols, V: vcols, L: [ttl]}
+    for c in ids[3:]: bundle[c] = None                           # the extra components of the "full" schema: their defaults
+    return world.spawn(n, bundle)
 
 
 def snapshot_state(world, ids):

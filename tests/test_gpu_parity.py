@@ -409,6 +409,55 @@ def test_branch_lists_dead_snapshots_and_batches(n, flags, generic, monkeypatch)
     assert all(res[0][0][2 + b * nb:2 + (b + 1) * nb] == first for b in (1, 3, 4, 5)) and res[0][0][2 + 2 * nb:2 + 3 * nb] != first
 
 
+@pytest.mark.parametrize("n", [1000, 250, 8100])
+@pytest.mark.parametrize("generic", [False, True])
+def test_dead_branches_keep_dirty_extents(n, generic, monkeypatch):
+    """a checksum-only (dead) branch writes neither its ring slots nor the live block, so it must not lower
+    their dirty extents.  A spawning branch first grows the live world past a 256- / 1024- / 8192-slot boundary, dead branches
+    follow off the OLD confirmed frame, the last branch is alive, and then spawns grow len back across the boundary: stale
+    liveness bits left above the lowered extent would come back as ghost entities (wrong count, wrong checksum)."""
+    if generic: monkeypatch.setenv("GGRS_TICK_GENERIC", "1")
+    D = 4
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    fn = cm.frame_spawn_fn(90)
+    res = []
+    for w in (bg.World(n + 4000, max_depth=D + 2), OracleWorld(n + 4000, D + 2, FLAT)):
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=50)
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+        w.set_confirmed(0)
+        out = w.handle_requests([bg.SaveGameState(0), bg.AdvanceFrame((0,)), bg.SaveGameState(1)])
+        C = 1
+
+        def adv(frame, spawn):
+            a = bg.AdvanceFrame((cm.INPUT_SPAWN if spawn else 0,))
+            if spawn: a.spawn_vx, a.spawn_vy = fn(frame)
+            return a
+
+        def branch(spawning):
+            r = [bg.LoadGameState(C)]
+            for i in range(D):
+                r += [adv(C + i, spawning), bg.SaveGameState(C + 1 + i)]
+            return r + [adv(C + D, spawning)]
+        # spawning branch (alive: 5 x 90 new slots), three dead branches, one alive branch that rewrites the live world
+        out += w.handle_requests(branch(True) + branch(False) + branch(False) + branch(False) + branch(False))
+        # now grow back across the boundary, one frame at a time, checksumming every frame
+        for i in range(3):
+            out += w.handle_requests([adv(C + D + 1 + i, True), bg.SaveGameState(C + D + 2 + i)])
+        # and once more through dead branches off the newest snapshot
+        C2 = C + D + 4
+        more = []
+        for b in range(3):
+            more += [bg.LoadGameState(C2), adv(C2, b == 0), bg.SaveGameState(C2 + 1), adv(C2 + 1, b == 0), bg.SaveGameState(C2 + 2), adv(C2 + 2, False)]
+        out += w.handle_requests(more)
+        out += w.handle_requests([bg.SaveGameState(C2 + 3)])
+        res.append((out, cm.snapshot_state(w, ids), w.snapshot_count(), w.active_count()))
+        w.close()
+    assert res[0][0] == res[1][0]
+    assert res[0][2:] == res[1][2:]
+    cm.assert_states_equal(res[0][1], res[1][1], "dead branches / dirty extents")
+
+
 @pytest.mark.parametrize("extra_words,n", [(5, 700_000), (9, 600_000), (12, 650_000)])
 def test_big_world_with_extra_untouched_components(extra_words, n):
     """The stress_test world plus a component the schedule never touches (7 + extra_words untouched rows): up to 16 such rows
