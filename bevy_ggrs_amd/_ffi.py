@@ -70,6 +70,8 @@ class Request(C.Structure):
                 ("spawn_vy", C.POINTER(C.c_float))]
 
 
+KERNEL_FORM_TILES, KERNEL_FORM_PERSISTENT = 1, 2
+
 # every symbol include/ggrs_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -83,6 +85,7 @@ SIGNATURES = {
     "ggrs_hip_register_component_ex": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ggrs_hip_set_component_default": (C.c_int, [_P, C.c_uint32, _P]),
     "ggrs_hip_checksum_component": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
+    "ggrs_hip_checksum_component_custom": (C.c_int, [_P, C.c_uint32, C.c_char_p]),
     "ggrs_hip_add_system": (C.c_int, [_P, C.POINTER(SystemDesc)]),
     "ggrs_hip_add_custom_system": (C.c_int, [_P, C.POINTER(CustomSystemDesc)]),
     "ggrs_hip_generated_kernel_source": (C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
@@ -131,6 +134,7 @@ SIGNATURES = {
     "ggrs_hip_fanout_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ggrs_hip_profile_enable": (C.c_int, [_P, C.c_int]),
     "ggrs_hip_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "ggrs_hip_profile_read_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ggrs_hip_profile_read_launches": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "ggrs_hip_world_kernel_info": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
 }

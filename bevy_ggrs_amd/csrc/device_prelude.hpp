@@ -44,18 +44,28 @@ __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) {
     uint64_t A = sea_diffuse(SEA_K0 ^ x);
     return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL);
 }
-// generic stream over n u32 units (all writes on this path are multiples of 4 bytes)
+// SeaHasher as a stream (snapshot/mod.rs:318-320 `checksum_hasher()`): `write` appends the low nb bytes of v, little-endian,
+// exactly like Hasher::write(&v.to_le_bytes()[..nb]) -- 8-byte words go through diffuse as they fill, the rest waits in a
+// tail buffer.  derive(Hash) writes a u8 / bool as 1 byte, u16 as 2, u32 / f32::to_bits as 4, u64 / usize as 8.
 struct SeaStream {
-    uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0;
-    uint32_t lo = 0; bool have_lo = false;
-    __host__ __device__ __forceinline__ void unit(uint32_t u) {
-        if (!have_lo) { lo = u; have_lo = true; return; }
-        uint64_t a = sea_diffuse(s0 ^ ((uint64_t)lo | ((uint64_t)u << 32)));
-        s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; have_lo = false;
+    uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0, tail = 0;
+    uint32_t ntail = 0;
+    __host__ __device__ __forceinline__ void write(uint64_t v, uint32_t nb) {      // 1 <= nb <= 8
+        if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL;
+        tail |= v << (8 * ntail);                                    // ntail < 8 always
+        const uint32_t tot = ntail + nb;
+        if (tot >= 8) {
+            const uint64_t a = sea_diffuse(s0 ^ tail);
+            s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8;
+            const uint32_t used = 8 - ntail;                         // bytes of v that went into the full word: 1..8
+            tail = used >= 8 ? 0ULL : (v >> (8 * used));
+            ntail = tot - 8;
+        } else ntail = tot;
     }
+    __host__ __device__ __forceinline__ void unit(uint32_t u) { write(u, 4); }
     __host__ __device__ __forceinline__ uint64_t finish() const {
-        uint64_t a = have_lo ? sea_diffuse(s0 ^ (uint64_t)lo) : s0;
-        return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + (have_lo ? 4ULL : 0ULL)));
+        const uint64_t a = ntail ? sea_diffuse(s0 ^ tail) : s0;
+        return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + ntail));
     }
 };
 
@@ -99,5 +109,74 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
     if (x > hi) x = hi;
     if (z < lo) z = lo;
     if (z > hi) z = hi;
+}
+
+// ------------------------------------------------------------------ in-launch checksum fold (k_tick3 and the persistent
+// form of the generated kernel)
+// In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
+// the last workgroup to arrive writes every Save's Checksum(u128).
+struct FoldArgs {
+    uint64_t* wg_parts;                    // [gridDim.x][n_saves * (n_comp + 1)]: per Save the XOR of each checksummed component, then the live count
+    uint32_t* ticket;                      // arrival counter, zero between launches
+    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
+    uint32_t n_comp, comp_mask;            // component slots per Save; bit j: slot j is a registered checksum (contributes a part)
+};
+// Cross-workgroup hand-off of the partial rows: relaxed agent-scope 8-byte atomics on both sides (lowered to
+// `global_store / global_load ... sc1`: write-through stores, L1-bypassing loads -- MI355X_MICROARCH.md, "Valid forms"),
+// an explicit vmcnt(0) between a workgroup's row and its ticket, one agent-scope acquire in the workgroup that folds.
+__device__ __forceinline__ void st8_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The checksum fold: one row of partials per workgroup (relaxed agent-scope stores), one
+// agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
+// entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
+template <int NTHREADS>
+__device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
+    if (n_saves == 0) return;
+    __syncthreads();                                              // the LDS atomics of every wave have landed
+    const uint32_t nv = f.n_comp + 1u;                            // values per Save
+    const uint32_t n_vals = n_saves * nv;
+    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + i, acc[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row is in memory before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!*s_last) return;                                         // workgroup-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) acc[i] = 0;
+    __syncthreads();
+    {
+        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  24 loads in flight per lane and trip.
+        const uint32_t n_flat = gridDim.x * n_vals;
+        constexpr int INFL = 24;
+        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += (uint32_t)INFL * NTHREADS) {
+            uint64_t v[INFL];
+_Pragma("unroll")
+            for (int u = 0; u < INFL; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
+                v[u] = i < n_flat ? ld8_agent(f.wg_parts + i) : 0ULL;
+            }
+_Pragma("unroll")
+            for (int u = 0; u < INFL; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
+                if (i >= n_flat) continue;
+                const uint32_t c = i % n_vals;
+                if ((c % nv) == f.n_comp) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_saves) {
+        const uint32_t k = threadIdx.x;
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < f.n_comp; ++j)
+            if ((f.comp_mask >> j) & 1u) total ^= sea_one(acc[k * nv + j]);     // component_checksum.rs:92-95
+        total ^= sea_pair(acc[k * nv + f.n_comp], total_len);                  // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
+    }
+    if (threadIdx.x == 0) *f.ticket = 0;                          // ready for the next launch on this stream
 }
 )

@@ -1,0 +1,246 @@
+// host_fanout.hpp -- speculative fan-out ACROSS GPUs over RCCL (include/ggrs_hip.h, "Speculative fan-out ACROSS GPUs").
+// Part of the single translation unit ggrs_hip.hip (included last: it uses the C ABI entry points above).
+#pragma once
+
+// =============================================================================================
+// Speculative fan-out over RCCL (include/ggrs_hip.h, "Speculative fan-out ACROSS GPUs")
+// =============================================================================================
+}  // extern "C"
+
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    std::string why;
+    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && Broadcast && AllGather && GetErrorString && CommCount && CommUserRank; }
+};
+// ONE RCCL per process: a copy that is already mapped (a torch process ships its own librccl.so) wins over /opt/rocm's,
+// or two collective runtimes would each initialise the device.
+void rccl_load(Rccl& r) {
+    // GGRS_RCCL_LIB=<path>: load THIS collective library instead (tests: a same-GPU transport double, tests/cpp/rccl_double.cpp,
+    // so that the rank != 0 half of the fan-out runs on a one-GPU box where RCCL refuses two ranks per device)
+    if (const char* forced = getenv("GGRS_RCCL_LIB")) { if (*forced) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL); }
+    else {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!r.lib) { const char* e = dlerror(); r.why = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
+    if (!r.ok()) r.why = "librccl.so lacks an expected entry point";
+}
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });                     // worlds may start their fan-out from several threads
+    return r;
+}
+constexpr int FANOUT_MAX_INFLIGHT = 8;
+}  // namespace
+
+struct ggrs_fanout {
+    ggrs_world* w = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, size = 1;
+    hipStream_t comm_stream = nullptr;
+    // one slot = one all-gather: the checksums of `interval` consecutive steps
+    struct Slot { uint64_t* d_send = nullptr; uint64_t* d_recv = nullptr; uint64_t* h_recv = nullptr; hipEvent_t ready = nullptr, done = nullptr;
+                  uint32_t n_saves = 0, n_steps = 0; bool closed = false; uint32_t first[64]; };   // first[k]: step k's slot in the pinned result ring
+    Slot slot[FANOUT_MAX_INFLIGHT];
+    uint32_t head = 0, tail = 0;         // tail: slot being filled, head: oldest uncollected
+    uint32_t cap_u128 = 4096;            // checksums per rank a slot can hold (steps x saves)
+    uint32_t interval = 1;               // steps per all-gather
+    std::string err;
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+#define FANCHK_HIP(f, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (f)->fail(GGRS_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define FANCHK_NCCL(f, call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) return (f)->fail(GGRS_E_HIP, "%s failed: %s", #call, rccl().GetErrorString(e_)); } while (0)
+
+namespace {
+// closes the slot being filled: ONE all-gather of everything it holds, then device -> pinned, on the side stream
+int fanout_close_slot(ggrs_fanout* f) {
+    ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
+    if (s.n_steps == 0 || s.closed) return GGRS_OK;
+    const size_t n = (size_t)s.n_steps * s.n_saves;
+    ggrs_world* w = f->w;
+    // everything of the group happens here, once per `interval` steps and on the side stream: wait for the group's last
+    // tick, pinned result ring -> device (consecutive steps sit in consecutive ring slots unless the ring wrapped),
+    // all-gather, device -> pinned.  A step itself adds nothing to the world's stream.
+    FANCHK_HIP(f, hipEventRecord(s.ready, w->stream));
+    FANCHK_HIP(f, hipStreamWaitEvent(f->comm_stream, s.ready, 0));
+    for (uint32_t k = 0; k < s.n_steps && s.n_saves; ) {
+        uint32_t run = 1;
+        while (k + run < s.n_steps && s.first[k + run] == s.first[k] + run * s.n_saves) ++run;
+        FANCHK_HIP(f, hipMemcpyAsync(s.d_send + (size_t)k * s.n_saves * 2, w->h_results + 2 * (size_t)s.first[k], (size_t)run * s.n_saves * 16, hipMemcpyHostToDevice, f->comm_stream));
+        k += run;
+    }
+    if (n) {
+        FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, n * 2, ncclUint64, f->comm, f->comm_stream));
+        FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, n * 16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
+    }
+    FANCHK_HIP(f, hipEventRecord(s.done, f->comm_stream));
+    s.closed = true;
+    ++f->tail;
+    return GGRS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ggrs_hip_fanout_unique_id(uint8_t id_out[GGRS_FANOUT_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == GGRS_FANOUT_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return GGRS_E_INVALID;
+    if (!rccl().ok()) return GGRS_E_HIP;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return GGRS_E_HIP;
+    memcpy(id_out, &id, sizeof id);
+    return GGRS_OK;
+}
+int ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], int rank, int world_size, ggrs_fanout** out) {
+    if (!w || !id || !out || world_size < 1 || rank < 0 || rank >= world_size) return GGRS_E_INVALID;
+    DeviceGuard dg(w);
+    int rc = seal(w); if (rc) return rc;
+    if (!rccl().ok()) return w->fail(GGRS_E_HIP, "%s", rccl().why.c_str());
+    ggrs_fanout* f = new ggrs_fanout();
+    f->w = w; f->rank = rank; f->size = world_size;
+    w->device_results_only = true;       // the all-gather reads the Checksum(u128)s from the result ring on the GPU's side of the stream: no host-side folds
+    ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
+    ncclResult_t e = rccl().CommInitRank(&f->comm, world_size, uid, rank);
+    if (e != ncclSuccess) { rc = w->fail(GGRS_E_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(e)); delete f; return rc; }
+    bool ok = hipStreamCreateWithFlags(&f->comm_stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto& s : f->slot) {
+        ok = ok && hipMalloc((void**)&s.d_send, (size_t)f->cap_u128 * 16) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_recv, (size_t)f->cap_u128 * 16 * world_size) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_recv, (size_t)f->cap_u128 * 16 * world_size) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { rc = w->fail(GGRS_E_HIP, "fan-out staging buffers could not be allocated"); ggrs_hip_fanout_destroy(f); return rc; }
+    *out = f;
+    return GGRS_OK;
+}
+void ggrs_hip_fanout_destroy(ggrs_fanout* f) {
+    if (!f) return;
+    if (f->w) (void)hipSetDevice(f->w->device);
+    if (f->comm_stream) (void)hipStreamSynchronize(f->comm_stream);
+    for (auto& s : f->slot) {
+        if (s.d_send) (void)hipFree(s.d_send);
+        if (s.d_recv) (void)hipFree(s.d_recv);
+        if (s.h_recv) (void)hipHostFree(s.h_recv);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (f->comm && rccl().ok()) (void)rccl().CommDestroy(f->comm);
+    if (f->comm_stream) (void)hipStreamDestroy(f->comm_stream);
+    delete f;
+}
+const char* ggrs_hip_fanout_last_error(ggrs_fanout* f) { return f ? f->err.c_str() : "null fan-out"; }
+int ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int* device_out) {
+    if (!f || !f->comm) return GGRS_E_INVALID;
+    int n = 0, r = 0;
+    FANCHK_NCCL(f, rccl().CommCount(f->comm, &n));
+    FANCHK_NCCL(f, rccl().CommUserRank(f->comm, &r));
+    if (rank_out) *rank_out = r;
+    if (size_out) *size_out = n;
+    if (device_out) *device_out = f->w->device;
+    return GGRS_OK;
+}
+
+int ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather) {
+    // a group's steps are all outstanding batches of the world until the group is collected: at most 16 (ggrs_hip_enqueue_requests)
+    if (!f || steps_per_all_gather == 0 || steps_per_all_gather > 16) return GGRS_E_INVALID;
+    if (f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps) return f->fail(GGRS_E_INVALID, "interval changed inside a partly filled group");
+    f->interval = steps_per_all_gather;
+    return GGRS_OK;
+}
+
+int ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root) {
+    if (!f || root < 0 || root >= f->size) return GGRS_E_INVALID;
+    ggrs_world* w = f->w;
+    DeviceGuard dg(w);
+    if (f->head != f->tail || f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps || !w->pending.empty())
+        return f->fail(GGRS_E_INVALID, "sync_confirmed while steps are in flight: collect them first");
+    void* live = nullptr;
+    int rc = ggrs_hip_live_state_ptr(w, &live);          // refreshes the block's header (len, frame) on every rank
+    if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    // xGMI is point-to-point: one flat broadcast of the packed block, in place in HBM, on the world's own stream
+    FANCHK_NCCL(f, rccl().Broadcast(live, live, (size_t)w->state_bytes, ncclUint8, root, f->comm, w->stream));
+    FANCHK_HIP(f, hipStreamSynchronize(w->stream));
+    rc = ggrs_hip_adopt_live_state(w);
+    if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    return GGRS_OK;
+}
+
+int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
+    if (!f || (!reqs && n)) return GGRS_E_INVALID;
+    ggrs_world* w = f->w;
+    DeviceGuard dg(w);
+    if (f->tail - f->head >= (uint32_t)FANOUT_MAX_INFLIGHT) return f->fail(GGRS_E_INVALID, "%d all-gathers in flight: call ggrs_hip_fanout_collect", FANOUT_MAX_INFLIGHT);
+    ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
+    if (s.n_steps == 0) { s.closed = false; s.n_saves = 0; }
+    // everything that can refuse the step is checked BEFORE the world advances: a batch enqueued here and not tracked by a slot
+    // would shift every later collect by one
+    uint32_t want = 0;
+    for (uint32_t i = 0; i < n; ++i) want += reqs[i].kind == GGRS_REQ_SAVE;
+    if (s.n_steps && want != s.n_saves) return f->fail(GGRS_E_INVALID, "steps of one all-gather group must hold the same number of SaveGameState requests (%u vs %u)", want, s.n_saves);
+    if ((uint64_t)(s.n_steps + 1) * want > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u checksums per rank in one all-gather (at most %u)", (s.n_steps + 1) * want, f->cap_u128);
+    uint32_t ns = 0;
+    int rc = ggrs_hip_enqueue_requests(w, reqs, n, &ns);
+    if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    s.n_saves = ns;
+    s.first[s.n_steps] = w->pending.back().first;        // where the kernels write this step's checksums (pinned result ring)
+    ++s.n_steps;
+    if (n_saves_out) *n_saves_out = ns;
+    if (s.n_steps >= f->interval) return fanout_close_slot(f);
+    return GGRS_OK;
+}
+
+int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t max_u128_per_rank, uint32_t* n_steps_out, uint32_t* n_saves_out) {
+    if (!f) return GGRS_E_INVALID;
+    ggrs_world* w = f->w;
+    DeviceGuard dg(w);
+    if (f->head == f->tail) {                                   // only a partly filled group is left: close it now
+        if (f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps == 0) return f->fail(GGRS_E_INVALID, "no step in flight");
+        int rc = fanout_close_slot(f); if (rc) return rc;
+    }
+    ggrs_fanout::Slot& s = f->slot[f->head % FANOUT_MAX_INFLIGHT];
+    const uint32_t per_rank = s.n_steps * s.n_saves;
+    if (per_rank > max_u128_per_rank || (per_rank && !checksums_out)) return f->fail(GGRS_E_INVALID, "oldest group holds %u checksums per rank, room for %u", per_rank, max_u128_per_rank);
+    FANCHK_HIP(f, hipEventSynchronize(s.done));
+    // keep the world's own batch queue in step (its checksums are this rank's rows of the gathered table)
+    std::vector<uint64_t> own(2 * (size_t)s.n_saves + 2);
+    for (uint32_t k = 0; k < s.n_steps; ++k) {
+        uint32_t got = 0;
+        int rc = ggrs_hip_collect_checksums(w, own.data(), s.n_saves, &got);
+        if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    }
+    if (per_rank) memcpy(checksums_out, s.h_recv, (size_t)per_rank * 16 * f->size);
+    if (n_steps_out) *n_steps_out = s.n_steps;
+    if (n_saves_out) *n_saves_out = s.n_saves;
+    s.n_steps = 0; s.closed = false;
+    ++f->head;
+    return GGRS_OK;
+}
+
+}  // extern "C"
+

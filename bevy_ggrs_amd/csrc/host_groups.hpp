@@ -1,0 +1,435 @@
+// host_groups.hpp -- fused request groups.  handle_requests (schedule_systems.rs:170-289) receives the WHOLE request list of
+// a tick, and every request of a kernel-backed world is slot-local, so a run  [Load?] (Save | Advance)*  executes as ONE
+// pass: the source block is read once (the ring slot being loaded, or live), the ops are replayed in request order with the
+// slot's words in registers, the live block is written once.  The host does, in request order and while the group is
+// assembled, everything the reference's systems do outside the per-entity loops: frame counters, ring push / confirm /
+// rollback (exact mirror of mod.rs:121-243 over slot indices), row versions, dirty extents.
+// Two kernels serve groups: the hand-written k_tick3 (HBM-sized particles worlds) and the kernel generated for the world
+// (kernel_gen.hpp; per-tile grid for small worlds, persistent grid + in-kernel fold for big ones).
+// Part of the single translation unit ggrs_hip.hip.
+#pragma once
+
+namespace {
+
+struct GroupState {
+    Block* src; uint64_t cover; uint32_t src_is_live;
+    Block* dsts[MAX_TICK_SAVES];
+    std::vector<uint32_t> save_ver[MAX_TICK_SAVES];   // the versions Save k's slot holds once the group has run
+    uint64_t save_rows[MAX_TICK_SAVES];               // bit c: column c is stored with Save k (row versions)
+};
+// LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
+int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState& g) {
+    g.src = &w->live; g.cover = w->live.dirty_len; g.src_is_live = 1;
+    if (reqs[i].kind != GGRS_REQ_LOAD) return GGRS_OK;
+    trace_request(w, reqs[i]);
+    apply_synctest_confirmed(w);
+    w->frame = reqs[i].frame;
+    if (!ring_rollback(w, reqs[i].frame))
+        return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
+    g.src = &w->slots[w->ring_slot.front()];
+    int rc = launch_load_reconcile(w, *g.src); if (rc) return rc;        // EntityResurrect: before the group rewrites live liveness
+    w->len = g.src->len;
+    w->cur_ver = g.src->ver;                                              // the logical live state is the snapshot from here on
+    g.cover = std::max(g.cover, g.src->dirty_len);
+    g.src_is_live = 0;
+    ++i;
+    return GGRS_OK;
+}
+// column mask -> what it costs per slot
+uint64_t rows_bytes_per_slot(const ggrs_world* w, uint64_t mask) {
+    uint64_t b = 0;
+    for (uint32_t c = 0; c < w->col_wb.size() && c < 64; ++c) if ((mask >> c) & 1ull) b += w->col_wb[c];
+    return b;
+}
+// columns of `dst` that differ from the logical live state
+uint64_t rows_to_store(const ggrs_world* w, const Block& dst) {
+    uint64_t m = 0;
+    for (uint32_t c = 0; c < w->col_rb.size() && c < 64; ++c) if (w->col_rb[c] && ver_differs(w, dst, w->cur_ver, c)) m |= 1ull << c;
+    return m;
+}
+// SaveGameState inside a group: discard_old_snapshots + GgrsSnapshots::push (mod.rs:147-202); the copy itself is an op of the kernel
+int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int32_t* save_frame) {
+    if (tracer().on()) { ggrs_request r{}; r.kind = GGRS_REQ_SAVE; r.frame = w->frame; trace_request(w, r); }
+    apply_synctest_confirmed(w);
+    if (w->has_confirmed) ring_confirm(w, w->confirmed);
+    int sl = -1;
+    int rc = ring_push(w, w->frame, &sl); if (rc) return rc;
+    Block* d = sl >= 0 ? &w->slots[sl] : nullptr;
+    g.dsts[k] = d;
+    save_dst[k] = d ? d->ptr : nullptr;
+    save_frame[k] = w->frame;
+    g.save_rows[k] = 0;
+    if (d) {
+        g.cover = std::max(g.cover, d->dirty_len); d->len = w->len;
+        g.save_rows[k] = rows_to_store(w, *d);
+        g.save_ver[k] = w->cur_ver;
+    }
+    return GGRS_OK;
+}
+// AdvanceFrame inside a group: RollbackFrameCount += 1 (schedule_systems.rs:254-259), DespawnConfirmed, Time<GgrsTime>.
+// DespawnConfirmed only touches the live-only marker mask, which no op inside a group reads or writes: queueing it
+// ahead of the group's launch keeps request order.
+// marks_flags != nullptr: the group kernel keeps the RollbackDespawned markers itself (generated kernel with markers);
+// it receives bit 0 = DespawnConfirmed is due before this step (its Local<ConfirmedFrameCount> changed, despawn.rs:92-99),
+// bit 1 = the step's frame is unconfirmed, i.e. despawn_rollback() defers (despawn.rs:129-137).
+int group_step(ggrs_world* w, const ggrs_request& r, uint32_t* dt_bits_out, uint8_t* marks_flags = nullptr) {
+    trace_request(w, r);
+    apply_synctest_confirmed(w);
+    w->frame += 1;
+    if (marks_flags) {
+        uint8_t f = 0;
+        if (w->confirmed != w->dc_local) { w->dc_local = w->confirmed; f |= 1; }
+        if (w->confirmed < w->frame) { f |= 2; w->marks_possible = true; }
+        *marks_flags = f;
+    } else {
+        int rc = step_despawn_confirmed(w); if (rc) return rc;
+    }
+    ver_step(w);                                                        // every system may have written its write set
+    *dt_bits_out = r.dt_bits ? r.dt_bits : dt_bits_for_frame(w->fps, w->frame);
+    return GGRS_OK;
+}
+// dead: the group ran checksum-only (dead-snapshot elimination) -- neither its ring slots nor the live block were written, so
+// their dirty extents and row versions still describe what they hold: lowering the extents here would leave mask bits beyond
+// the new extent that no later pass cleans (ghost entities once len grows back into those words)
+void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead, bool wrote_live) {
+    w->pending_valid = false;
+    if (dead) return;
+    const uint64_t new_dirty = std::max(g.src->dirty_len, w->len);
+    for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) { g.dsts[k]->dirty_len = new_dirty; g.dsts[k]->ver = g.save_ver[k]; }
+    if (wrote_live) { w->live.dirty_len = new_dirty; ver_sync_live(w); }
+}
+
+// Dead-snapshot elimination.  A request group whose NEXT request is a LoadGameState of a frame older than everything the
+// group saved leaves nothing behind: that rollback pops every one of its snapshots from the ring (mod.rs:210-226) before
+// anything could load them, and LoadWorld overwrites the live world.  Only the group's Checksum(u128)s are observable --
+// exactly what a speculative branch of the fan-out is ([Load(C), Adv, Save, ...] x B in one list: every branch but the last).
+// Such a group runs checksum-only: no snapshot stores, no live write.  The host ring bookkeeping is done as usual.
+// Not applied when something else reads the live world in between (a firing spawn system, live-only components or
+// RollbackDespawned markers, whose reconcile pass reads the live liveness mask).
+bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, uint32_t n, const int32_t* save_frame, uint32_t n_saves, bool spawn_pending) {
+    if (!w->knobs.dead_groups || spawn_pending || n_saves == 0 || i >= n || reqs[i].kind != GGRS_REQ_LOAD || w->has_nr || w->marks_possible) return false;
+    bool present = false;
+    for (int32_t f : w->ring_frame) present |= f == reqs[i].frame;
+    if (!present) return false;                                        // that Load is going to fail: change nothing
+    for (uint32_t k = 0; k < n_saves; ++k) {
+        const int64_t d = (int64_t)save_frame[k] - (int64_t)reqs[i].frame;
+        if (d <= 0 || d > (1 << 30)) return false;                       // not newer (or i32 wrap-around in play): keep it
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_tick3: HBM-sized particles worlds
+// ---------------------------------------------------------------------------------------------------------------------
+void launch_tick3(ggrs_world* w, const Tick3Args& a, uint32_t g) {
+    if (a.n_rest_rows != (uint32_t)TICK3_RESTL_EXACT) {                 // not the stress_test's 7 rows: the general instantiation
+        if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
+        else hipLaunchKernelGGL((k_tick3<false, false, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
+        return;
+    }
+    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
+    else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
+    else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
+    else hipLaunchKernelGGL((k_tick3<false, false, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
+}
+
+// res_base: first slot of the pinned result ring this list writes to.  wait == false only enqueues
+// (ggrs_hip_enqueue_requests); the list then must hold fewer Saves than the ring can take.
+int run_request_groups_tick3(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
+                             uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
+    uint32_t i = 0, ns = 0;                      // ns: results pending in d_results
+    int rc = GGRS_OK;
+    while (i < n) {
+        Tick3Args b = w->tick3_proto;
+        GroupState gs;
+        const ggrs_request* spawn_req = nullptr;
+        rc = group_open(w, reqs, i, gs); if (rc) return rc;
+        b.src_is_live = gs.src_is_live;
+        // ---- gather the ops that follow, doing the host-side bookkeeping in request order
+        while (i < n && b.n_ops < (uint32_t)MAX_TICK_OPS) {
+            const ggrs_request& r = reqs[i];
+            if (r.kind == GGRS_REQ_LOAD) break;
+            if (r.kind == GGRS_REQ_SAVE) {
+                if (b.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + b.n_saves == w->max_results)) break;
+                rc = group_save(w, gs, b.n_saves, b.save_dst, b.save_frame); if (rc) return rc;
+                ++b.n_ops; ++b.n_saves;                                     // op bit stays 0: Save
+            } else if (r.kind == GGRS_REQ_ADVANCE) {
+                if (b.n_steps == (uint32_t)MAX_TICK_STEPS) break;
+                rc = group_step(w, r, &b.dt_bits[b.n_steps]); if (rc) return rc;
+                ++b.n_steps;
+                b.op_bits |= 1ULL << b.n_ops; ++b.n_ops;                     // op bit 1: Advance
+                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }   // Commands flush ends the group
+            } else {
+                return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+            }
+            ++i;
+        }
+        const bool dead = group_is_dead(w, reqs, i, n, b.save_frame, b.n_saves, spawn_req != nullptr);
+        if (dead) { for (uint32_t k = 0; k < b.n_saves; ++k) b.save_dst[k] = nullptr; b.skip_live = 1; }
+        const bool wrote_live = (!b.src_is_live || b.n_steps) && !b.skip_live;
+        // ---- row versions -> what each Save / the live write stores, what has to be loaded
+        auto split = [&](uint64_t cols, uint32_t* sched, uint32_t* rest) {
+            *sched = 0; *rest = 0;
+            for (uint32_t c : w->tick3_sched_cols) if ((cols >> c) & 1ull) *sched = 1;
+            for (size_t j = 0; j < w->tick3_rest_cols.size(); ++j) if ((cols >> w->tick3_rest_cols[j]) & 1ull) *rest |= 1u << j;
+        };
+        uint64_t bytes_slot = 32;                                            // the 8 schedule-owned rows are always read
+        for (uint32_t k = 0; k < b.n_saves; ++k) {
+            uint32_t sc = 0, rs = 0;
+            if (b.save_dst[k]) split(gs.save_rows[k], &sc, &rs);
+            b.sched_store |= sc << k; b.rest_store[k] = rs; b.rest_load |= rs;
+            bytes_slot += (sc ? 32u : 0u) + 4u * (uint32_t)__builtin_popcount(rs);
+        }
+        if (wrote_live) {
+            uint32_t sc = 0, rs = 0;
+            split(rows_to_store(w, w->live), &sc, &rs);
+            b.sched_live = sc; b.rest_live = rs; b.rest_load |= rs;
+            bytes_slot += (sc ? 32u : 0u) + 4u * (uint32_t)__builtin_popcount(rs);
+        }
+        bytes_slot += 4u * (uint32_t)__builtin_popcount(b.rest_load);
+        // ---- one pass over the tiles: persistent grid, in-kernel fold, the Checksum(u128)s land in the pinned result ring
+        const uint64_t cover = std::max(gs.cover, w->len);
+        b.src = gs.src->ptr; b.live = w->live.ptr; b.len = w->len;
+        b.n_units = std::max(1u, (uint32_t)((cover + 255) / 256));
+        b.fold.wg_parts = w->d_wg_parts; b.fold.ticket = w->d_ticket;
+        b.fold.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+        const uint32_t tiles = std::max(1u, tiles_for(cover));
+        const uint32_t g2 = std::min<uint32_t>(tiles, (uint32_t)(w->n_cu * 2));
+        if (b.n_ops || !b.src_is_live) {
+            ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
+            launch_tick3(w, b, g2);
+        }
+        HIPCHK(w, hipGetLastError());
+        group_close(w, gs, b.n_saves, dead, wrote_live);
+        ns += b.n_saves;
+        if (spawn_req) {
+            rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
+            if (rc) return rc;
+        }
+        if (wait && ns == w->max_results) {                                // flush a full result page
+            rc = read_back(w, ns, checksums_out); if (rc) return rc;
+            checksums_out += 2 * (uint64_t)ns; ns = 0;
+        }
+    }
+    if (n_saves_out) *n_saves_out = ns;
+    if (!wait) return GGRS_OK;
+    return read_back(w, ns, checksums_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the generated kernel
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-only groups ride in one launch while the world is this small
+// The particles world has two fused paths: the hand-written k_tick3 and the kernel generated for it like for any other world.
+// Below ~416 k slots the generated kernel is the faster one (profiles/r02jit/cross.txt), so a list goes to it while the world
+// is small; a particles world without a generated kernel (no run-time compiler) runs on k_tick3 at every size.
+bool use_tick3(const ggrs_world* w) {
+    if (!w->tick3_ok) return false;
+    if (!w->jit_fn || !w->gen_ok) return true;
+    return std::max(w->len, w->live.dirty_len) > w->knobs.jit_particles_max_slots;
+}
+
+// Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
+// launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
+struct JitBatch {
+    bool active = false; GgrsJitArgs j; uint32_t g = 0, k = 0, res_first = 0, n_cks = 0;
+    void start(const GgrsJitArgs& j_, uint32_t g_, uint32_t res, uint32_t n_cks_) { active = true; j = j_; g = g_; k = 1; res_first = res; n_cks = n_cks_; }
+    bool try_add(const ggrs_world* w, const GgrsJitArgs& b, uint32_t g_, uint32_t res) {
+        if (!active || g_ != g || b.src != j.src || b.len != j.len || b.op_bits != j.op_bits || b.n_ops != j.n_ops || b.n_saves != j.n_saves ||
+            b.n_steps != j.n_steps || b.load_rows != j.load_rows || memcmp(b.dt_bits, j.dt_bits, sizeof b.dt_bits) != 0 || memcmp(b.aux_bits, j.aux_bits, sizeof b.aux_bits) != 0 ||
+            memcmp(b.step_frame, j.step_frame, sizeof b.step_frame) != 0 || memcmp(b.step_confirmed, j.step_confirmed, sizeof b.step_confirmed) != 0 ||
+            memcmp(b.step_flags, j.step_flags, sizeof b.step_flags) != 0) return false;
+        if (w->jit_reads_inputs && (memcmp(b.inputs, j.inputs, sizeof b.inputs) != 0 || memcmp(b.n_inputs, j.n_inputs, sizeof b.n_inputs) != 0)) return false;
+        if ((k + 1) * j.n_saves > w->gen_parts_saves || res != res_first + k * j.n_saves) return false;
+        ++k;
+        return true;
+    }
+    int flush(ggrs_world* w) {
+        if (!active) return GGRS_OK;
+        active = false;
+        bool host_fold = false; uint64_t rows_off = 0;
+        {
+            ProfScope ps(w, GGRS_KERNEL_TICK, rows_bytes_per_slot(w, j.load_rows) * j.len * k);
+            void* params[] = {&j};
+            if (k > 1) j.dp_s = 0;
+            host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off);
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
+            HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, g, j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, 1, 1, 0, w->stream, params, nullptr));
+        }
+        if (host_fold) { w->folds.push_back({res_first, j.n_saves, g, n_cks, k, rows_off, j.len}); return GGRS_OK; }
+        GenFinArgs f; memset(&f, 0, sizeof f);
+        f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = j.len;   // one row per workgroup
+        f.out = w->d_results + 2 * (uint64_t)res_first;
+        {
+            ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+            hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
+        }
+        HIPCHK(w, hipGetLastError());
+        return GGRS_OK;
+    }
+};
+
+int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
+                           uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
+    uint32_t i = 0, ns = 0;
+    int rc = GGRS_OK;
+    JitBatch batch;
+    const uint32_t n_cks = w->cks_args.n_cks;
+    const uint64_t static_reads = jit_static_reads(w);
+    while (i < n) {
+        GgrsJitArgs j; memset(&j, 0, sizeof j);
+        GroupState gs;
+        const ggrs_request* spawn_req = nullptr;
+        rc = group_open(w, reqs, i, gs); if (rc) return rc;
+        j.src_is_live = gs.src_is_live;
+        while (i < n && j.n_ops < (uint32_t)MAX_TICK_OPS) {
+            const ggrs_request& r = reqs[i];
+            if (r.kind == GGRS_REQ_LOAD) break;
+            if (r.kind == GGRS_REQ_SAVE) {
+                if (j.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + j.n_saves == w->max_results)) break;
+                rc = group_save(w, gs, j.n_saves, j.save_dst, j.save_frame); if (rc) return rc;
+                ++j.n_ops; ++j.n_saves;
+            } else if (r.kind == GGRS_REQ_ADVANCE) {
+                if (j.n_steps == (uint32_t)MAX_TICK_STEPS) break;
+                if (r.n_inputs > 16) return w->fail(GGRS_E_INVALID, "more than 16 player inputs");
+                uint32_t dtb = 0;
+                rc = group_step(w, r, &dtb, w->jit_marks ? &j.step_flags[j.n_steps] : nullptr); if (rc) return rc;
+                j.dt_bits[j.n_steps] = dtb;
+                j.step_frame[j.n_steps] = w->frame; j.step_confirmed[j.n_steps] = w->confirmed;
+                if (w->jit_box_sys >= 0) {                                     // FRICTION.powf(dt), platform libm (box_game.rs:189-195)
+                    float dtf; memcpy(&dtf, &dtb, 4);
+                    const float fp = powf(w->systems[w->jit_box_sys].fparam[2], dtf);
+                    memcpy(&j.aux_bits[j.n_steps], &fp, 4);
+                }
+                j.n_inputs[j.n_steps] = (uint8_t)r.n_inputs;
+                for (uint32_t k = 0; k < r.n_inputs; ++k) j.inputs[j.n_steps][k] = r.inputs[k];
+                ++j.n_steps;
+                j.op_bits |= 1ULL << j.n_ops; ++j.n_ops;
+                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }
+            } else {
+                return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
+            }
+            ++i;
+        }
+        const bool dead = group_is_dead(w, reqs, i, n, j.save_frame, j.n_saves, spawn_req != nullptr);
+        if (dead) { for (uint32_t k = 0; k < j.n_saves; ++k) j.save_dst[k] = nullptr; j.skip_live = 1; }
+        const bool wrote_live = (!j.src_is_live || j.n_steps) && !j.skip_live;
+        const uint64_t cover = std::max(gs.cover, w->len);
+        // ---- row versions -> store masks; what must be in registers = everything stored + everything a step or checksum reads
+        uint64_t bytes_slot = 0;
+        j.load_rows = j.n_ops ? static_reads : 0;
+        for (uint32_t k = 0; k < j.n_saves; ++k) {
+            j.save_rows[k] = j.save_dst[k] ? gs.save_rows[k] : 0;
+            j.load_rows |= j.save_rows[k];
+            bytes_slot += rows_bytes_per_slot(w, j.save_rows[k]);
+        }
+        if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
+        bytes_slot += rows_bytes_per_slot(w, j.load_rows);
+        j.src = gs.src->ptr; j.live = w->live.ptr; j.len = w->len;
+        j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
+        j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
+        const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
+        j.nt = (w->nt_copy || cover > w->knobs.jit_persist_min_slots) ? 1u : 0u;
+        const bool launch = j.n_ops || !j.src_is_live;
+
+        if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {
+            // ---- HBM-sized group: the persistent form -- ONE launch, every Checksum(u128) folded in it (tick_fold)
+            rc = batch.flush(w); if (rc) return rc;
+            j.fold_wg_parts = reinterpret_cast<ggrs_u64*>(w->d_wg_parts); j.fold_ticket = w->d_ticket;
+            j.fold_out = reinterpret_cast<ggrs_u64*>(w->d_results + 2 * (uint64_t)(res_base + ns));
+            const uint32_t tiles1k = (j.n_units + 15) / 16;
+            const uint32_t gp = std::max(1u, std::min<uint32_t>(tiles1k, w->jit_persist_wgs));
+            if (launch) {
+                ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
+                void* params[] = {&j};
+                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn_persist, gp, 1, 1, JIT_PERSIST_TPB, 1, 1, 0, w->stream, params, nullptr));
+            }
+            group_close(w, gs, j.n_saves, dead, wrote_live);
+            ns += j.n_saves;
+        } else {
+            // ---- per-tile grid: 256-slot workgroups, depth-parallel roles, batches, host-side or k_gen_finalize fold
+            // Depth-parallel roles: the group's outputs (Saves + live world) are split over grid.y roles of dp_s outputs.  Every role
+            // reads the source block while the others write theirs, so the source must be none of the destinations; below ~2 Saves
+            // there is no chain to split.  Crossovers: profiles/r02dp/ab2.txt, profiles/r02jit/jit_dp.txt.
+            if (w->knobs.dp && j.n_saves >= 2 && !w->jit_marks) {
+                bool ok = !(wrote_live && j.src == j.live);
+                for (uint32_t k = 0; k < j.n_saves; ++k) ok = ok && j.save_dst[k] != j.src;
+                const uint64_t m = w->knobs.dp_max_slots;
+                if (ok) j.dp_s = w->knobs.dp > 1 ? (cover <= JIT_BATCH_MAX_SLOTS ? (uint32_t)w->knobs.dp : 0u)
+                               : (cover <= m ? 1u : (cover <= 2 * m ? 2u : (cover <= 6 * m ? 3u : 0u)));
+            }
+            // identical checksum-only groups (speculative branches) ride in one launch; a batch already fills the chip, so no roles
+            const bool batchable = dead && j.n_saves > 0 && !w->jit_marks && cover <= JIT_BATCH_MAX_SLOTS;
+            if (batchable && batch.active) {
+                GgrsJitArgs jb = j; jb.dp_s = 0;
+                if (batch.try_add(w, jb, g, res_base + ns)) { batch.j.dp_s = 0; group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
+            }
+            rc = batch.flush(w); if (rc) return rc;
+            if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
+            uint64_t rows_off = 0;
+            const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off);
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
+            if (launch) {
+                ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
+                void* params[] = {&j};
+                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, g, j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, 0, w->stream, params, nullptr));
+            }
+            group_close(w, gs, j.n_saves, dead, wrote_live);
+            if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }
+            else if (j.n_saves) {
+                GenFinArgs f; memset(&f, 0, sizeof f);
+                f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup
+                f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+                {
+                    ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+                    hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves), dim3(FIN_TPB), 0, w->stream, f);
+                }
+                HIPCHK(w, hipGetLastError());
+                ns += j.n_saves;
+            }
+        }
+        group_done:
+        if (spawn_req) {
+            rc = batch.flush(w); if (rc) return rc;
+            rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
+            if (rc) return rc;
+        }
+        if (wait && ns == w->max_results) {
+            rc = batch.flush(w); if (rc) return rc;
+            rc = read_back(w, ns, checksums_out); if (rc) return rc;
+            checksums_out += 2 * (uint64_t)ns; ns = 0;
+        }
+    }
+    rc = batch.flush(w); if (rc) return rc;
+    if (n_saves_out) *n_saves_out = ns;
+    if (!wait) return GGRS_OK;
+    return read_back(w, ns, checksums_out);
+}
+
+// which runner serves this world's request lists right now (nullptr: one launch per request)
+typedef int (*GroupRunner)(ggrs_world*, const ggrs_request*, uint32_t, uint64_t*, uint32_t, bool, uint32_t*);
+GroupRunner group_runner(const ggrs_world* w) {
+    if (use_tick3(w)) return run_request_groups_tick3;
+    if (w->gen_ok) return run_request_groups_gen;
+    return nullptr;
+}
+
+// Requests are validated BEFORE any host bookkeeping (frame counters, ring) is touched: a malformed list fails with
+// GGRS_E_INVALID and leaves the world exactly as it was.
+int validate_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const ggrs_request& r = reqs[i];
+        if (r.kind != GGRS_REQ_SAVE && r.kind != GGRS_REQ_LOAD && r.kind != GGRS_REQ_ADVANCE)
+            return w->fail(GGRS_E_INVALID, "request %u: unknown request kind %u", i, r.kind);
+        if (r.kind != GGRS_REQ_ADVANCE) continue;
+        if (r.n_inputs > GGRS_MAX_PLAYERS) return w->fail(GGRS_E_INVALID, "request %u: %u player inputs (at most %d)", i, r.n_inputs, GGRS_MAX_PLAYERS);
+        if (r.n_inputs && !r.inputs) return w->fail(GGRS_E_INVALID, "request %u: n_inputs = %u but inputs is NULL", i, r.n_inputs);
+        if (advance_spawns(w, r) && (!r.spawn_vx || !r.spawn_vy)) return w->fail(GGRS_E_INVALID, "request %u: a spawn of %llu fires but spawn_vx / spawn_vy is NULL", i, (unsigned long long)r.spawn_count);
+    }
+    return GGRS_OK;
+}
+inline bool range_ok(uint64_t first, uint64_t count, uint64_t capacity) { return first <= capacity && count <= capacity - first; }
+
+}  // namespace

@@ -1,0 +1,270 @@
+// host_seal.hpp -- sealing a world: the layout is fixed, the fused paths are recognised / generated, the arena is carved.
+// Part of the single translation unit ggrs_hip.hip.
+#pragma once
+
+namespace {
+
+int seal_impl(ggrs_world* w);
+// Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
+// failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
+// reports the same error instead of carving a second arena over half-initialised bookkeeping.
+int seal(ggrs_world* w) {
+    if (w->layout_only) return w->fail(GGRS_E_NO_DEVICE, "GGRS_WORLD_LAYOUT_ONLY world: there is no device behind it");
+    if (w->sealed) return GGRS_OK;
+    if (w->seal_error) return w->seal_error;
+    const int rc = seal_impl(w);
+    if (rc == GGRS_OK) return rc;
+    const std::string why = w->err;
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
+    if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
+    if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
+    if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
+    if (w->own_arena && w->arena) { (void)hipFree(w->arena); if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed); w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
+    (void)hipGetLastError();
+    w->slots.clear(); w->free_slots.clear(); w->live = Block{};
+    w->sealed = false; w->seal_error = rc;
+    w->err = "world could not be sealed (permanent): " + why;
+    return rc;
+}
+
+// ---- recognise the particles schedule: [PARTICLES_UPDATE, TTL_DESPAWN] (+ optional SPAWN) over three distinct components.
+// fused_ok: the per-request path steps it with ONE kernel (k_particles_step, checksum partials of the post-step state);
+// tick3_ok: whole request groups run on the hand-written k_tick3.
+void recognise_particles(ggrs_world* w) {
+    w->fused_ok = false; w->f_spawn = -1; w->fused_cks = false; w->f_cksT = w->f_cksV = false; w->tick3_ok = false;
+    int upd = -1, ttl = -1, other = 0;
+    for (size_t i = 0; i < w->systems.size(); ++i) {
+        switch (w->systems[i].kind) {
+        case GGRS_SYS_PARTICLES_UPDATE: if (upd < 0) upd = (int)i; else ++other; break;
+        case GGRS_SYS_TTL_DESPAWN: if (ttl < 0) ttl = (int)i; else ++other; break;
+        case GGRS_SYS_PARTICLES_SPAWN: w->f_spawn = (int)i; break;
+        default: ++other;
+        }
+    }
+    if (upd < 0 || ttl < 0 || other != 0 || (w->flags & GGRS_WORLD_UNFUSED)) return;
+    const ggrs_system_desc& u = w->systems[upd]; const ggrs_system_desc& l = w->systems[ttl];
+    const Comp& T = w->comps[u.comp[0]]; const Comp& V = w->comps[u.comp[1]]; const Comp& L = w->comps[l.comp[0]];
+    if (!(T.word_bytes == 4 && V.word_bytes == 4 && L.word_bytes == 8 && u.word[0] + 3 <= T.n_words && u.word[1] + 3 <= V.n_words &&
+          !T.no_rollback && !V.no_rollback && !L.no_rollback)) return;
+    w->fused_ok = true;
+    w->f_T = (int)u.comp[0]; w->f_V = (int)u.comp[1]; w->f_L = (int)l.comp[0];
+    w->f_tw = u.word[0]; w->f_vw = u.word[1]; w->f_lw = l.word[0];
+    for (int k = 0; k < 3; ++k) w->f_g[k] = u.fparam[k];
+    // does the fused step cover every checksum spec?  (a word list naming exactly the three stepped words, in order)
+    bool all = true;
+    for (uint32_t c : w->cks_comp) {
+        const Comp& cc = w->comps[c];
+        const uint32_t base = ((int)c == w->f_T) ? w->f_tw : w->f_vw;
+        const bool is3 = cc.cks_source.empty() && cc.cks_words.size() == 3 && cc.cks_words[0] == base && cc.cks_words[1] == base + 1 && cc.cks_words[2] == base + 2;
+        if ((int)c == w->f_T && is3 && w->f_T != w->f_V) w->f_cksT = true;
+        else if ((int)c == w->f_V && is3 && w->f_T != w->f_V) w->f_cksV = true;
+        else all = false;
+    }
+    w->fused_cks = all;
+    if (!all) w->f_cksT = w->f_cksV = false;
+
+    // ---- k_tick3: distinct components, every spec covered, the untouched words = up to 16 contiguous 4-byte rows
+    if ((w->flags & GGRS_WORLD_NO_GROUPS) || w->f_T == w->f_V || w->f_T == w->f_L || w->f_V == w->f_L || !(w->fused_cks || w->cks_comp.empty())) return;
+    Tick3Args& b = w->tick3_proto;
+    memset(&b, 0, sizeof b);
+    b.off_alive = w->off_alive;
+    b.off_pT = w->off_present[w->f_T]; b.off_pV = w->off_present[w->f_V]; b.off_pL = w->off_present[w->f_L];
+    w->tick3_sched_cols.clear(); w->tick3_rest_cols.clear();
+    for (int k = 0; k < 3; ++k) {
+        b.off_t[k] = w->col_off[T.col_base + w->f_tw + k];
+        b.off_v[k] = w->col_off[V.col_base + w->f_vw + k];
+        b.g[k] = w->f_g[k];
+        w->tick3_sched_cols.push_back(T.col_base + w->f_tw + k); w->tick3_sched_cols.push_back(V.col_base + w->f_vw + k);
+    }
+    b.off_ttl = w->col_off[L.col_base + w->f_lw];
+    w->tick3_sched_cols.push_back(L.col_base + w->f_lw);
+    b.ts = w->ts;
+    for (uint32_t c = 0; c < w->comps.size(); ++c)
+        if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) b.rest_mask_off[b.n_rest_masks++] = w->off_present[c];
+    // the untouched rows, in layout order
+    std::vector<std::pair<uint64_t, uint32_t>> rest;               // (col_off, col)
+    for (uint32_t c = 0; c < w->comps.size(); ++c) {
+        const Comp& cc = w->comps[c];
+        if (cc.no_rollback) continue;
+        for (uint32_t k = 0; k < cc.n_words; ++k) {
+            const uint32_t col = cc.col_base + k;
+            if (std::find(w->tick3_sched_cols.begin(), w->tick3_sched_cols.end(), col) != w->tick3_sched_cols.end()) continue;
+            if (cc.word_bytes != 4) return;                             // only 4-byte untouched words ride in the store waves' registers
+            rest.push_back({w->col_off[col], col});
+        }
+    }
+    std::sort(rest.begin(), rest.end());
+    if (rest.size() > (size_t)TICK3_RESTL_ANY) return;
+    for (size_t j = 0; j < rest.size(); ++j) {
+        if (rest[j].first != rest[0].first + (uint64_t)j * REST_ROW_STRIDE) return;      // laid out back to back (build_layout: cold 4-byte words)
+        w->tick3_rest_cols.push_back(rest[j].second);
+    }
+    b.rest_off = rest.empty() ? 0 : rest[0].first;
+    b.n_rest_rows = (uint32_t)rest.size();
+    b.fold.n_comp = 2; b.fold.comp_mask = (w->f_cksT ? 1u : 0u) | (w->f_cksV ? 2u : 0u);
+    w->tick3_ok = true;
+}
+
+int seal_impl(ggrs_world* w) {
+    if (total_rows(w) > (uint32_t)MAX_ROWS) return w->fail(GGRS_E_INVALID, "too many registered words (%u rows > %d)", total_rows(w), MAX_ROWS);
+    // The particles kernels address their columns with the tile stride of the ROLLBACK columns; a live-only
+    // (GGRS_COMP_NO_ROLLBACK) column is a plain array with a different stride.  The flag is set after registration
+    // (register_component_ex), so the check lives here rather than in add_system.
+    for (auto& sd : w->systems) {
+        if (sd.kind != GGRS_SYS_PARTICLES_UPDATE && sd.kind != GGRS_SYS_TTL_DESPAWN && sd.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
+        const uint32_t nc = sd.kind == GGRS_SYS_PARTICLES_UPDATE ? 2u : (sd.kind == GGRS_SYS_TTL_DESPAWN ? 1u : 3u);
+        for (uint32_t k = 0; k < nc; ++k)
+            if (sd.comp[k] >= w->comps.size() || w->comps[sd.comp[k]].no_rollback)
+                return w->fail(GGRS_E_INVALID, "system %u runs over component %u, which is not registered for rollback (GGRS_COMP_NO_ROLLBACK): unsupported", sd.kind, sd.comp[k]);
+    }
+    HIPCHK(w, hipSetDevice(w->device));
+    build_layout(w);
+
+    // ---- checksum specs (the per-request k_checksum's view: one UnitDesc per hashed word)
+    w->cks_comp.clear(); w->custom_hashers = false;
+    std::vector<UnitDesc> units;
+    memset(&w->cks_args, 0, sizeof w->cks_args);
+    for (uint32_t c = 0; c < w->comps.size(); ++c) {
+        Comp& cc = w->comps[c];
+        if (!cc.checksummed) continue;
+        const uint32_t k = (uint32_t)w->cks_comp.size();
+        w->cks_comp.push_back(c);
+        w->custom_hashers |= !cc.cks_source.empty();
+        w->cks_args.off_present[k] = w->off_present[c];
+        w->cks_args.unit_base[k] = (uint32_t)units.size();
+        for (uint32_t wi : cc.cks_words) units.push_back({w->col_off[cc.col_base + wi], cc.word_bytes, w->col_ts[cc.col_base + wi]});
+        w->cks_args.n_units[k] = (uint32_t)units.size() - w->cks_args.unit_base[k];
+        if (w->cks_args.n_units[k] > (uint32_t)MAX_UNITS) return w->fail(GGRS_E_INVALID, "checksum spec too long");
+    }
+    w->cks_args.n_cks = (uint32_t)w->cks_comp.size();
+    w->cks_args.off_alive = w->off_alive;
+
+    recognise_particles(w);
+    if (w->knobs.tick_generic) w->tick3_ok = false;
+
+    // ---- the kernel generated for this world (kernel_gen.hpp): every world it covers, unless groups are off
+    w->gen_ok = false; w->jit_box_sys = -1; w->jit_marks = false; w->jit_reads_inputs = false;
+    if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && !w->knobs.tick_jit) w->jit_status = "disabled (GGRS_TICK_JIT=0)";
+    if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && w->knobs.tick_jit) {
+        std::string src;
+        if (!jit_source(w, src, false)) w->jit_status = "not covered by the generator (a system writes a live-only component, or too many words per entity)";
+        else {
+            if (w->knobs.debug_jit > 1) fprintf(stderr, "%s\n", src.c_str());
+            const std::string keep = w->err;
+            if (jit_cached(w, src, &w->jit_fn, &w->jit_entry) != GGRS_OK) {
+                if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] generated request-group kernel rejected: %s\n", w->err.c_str());
+                w->jit_status = (hiprtc().lib ? "rejected: " : "hiprtc unavailable: ") + w->err.substr(0, 300);
+                w->jit_fn = nullptr; w->err = keep;
+            } else w->jit_status = "ok";
+            // its persistent form, for worlds that can grow past the threshold (HBM-sized groups: one launch, fold in-kernel)
+            if (w->jit_fn && w->knobs.jit_persist_min_slots && w->cap_pad > w->knobs.jit_persist_min_slots && jit_source(w, src, true)) {
+                if (jit_cached(w, src, &w->jit_fn_persist, &w->jit_entry_persist) != GGRS_OK) {
+                    if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] persistent form of the generated kernel rejected: %s\n", w->err.c_str());
+                    w->jit_fn_persist = nullptr; w->err = keep;
+                } else {
+                    int nb = 0;
+                    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w->jit_fn_persist, JIT_PERSIST_TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+                    w->jit_persist_wgs = (uint32_t)std::min(nb, 2) * (uint32_t)w->n_cu;
+                }
+            }
+        }
+        if (w->jit_fn) {
+            for (size_t i = 0; i < w->systems.size(); ++i) {
+                const ggrs_system_desc& d = w->systems[i];
+                w->jit_reads_inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE;
+                w->jit_marks |= d.kind == GGRS_SYS_CUSTOM || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
+                if (d.kind == GGRS_SYS_BOX_MOVE) w->jit_box_sys = (int)i;
+            }
+            w->gen_ok = true;
+        }
+    }
+    if (w->custom_hashers && !w->gen_ok)
+        return w->fail(GGRS_E_INVALID, "a user-written checksum hasher needs the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
+
+    // ---- arena carve
+    const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
+    w->gen_part_stride = (uint32_t)(w->cap_pad / 256);            // one partial row entry per 256-slot workgroup of the generated kernel
+    w->gen_parts_saves = w->cap_pad <= 512 * 1024 ? 8 * MAX_TICK_SAVES : MAX_TICK_SAVES;   // small worlds: room for a batch of 16 eight-Save groups
+    w->part_stride = n_tiles + 4096 / 1;            // + room for spawn partial blocks
+    const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
+    w->max_results = 16384;                             // pinned result ring (256 KiB): a fan-out step of 256 branches x 8 frames alone is 2048
+    const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
+    w->stage_floats = 1u << 20;
+    const uint64_t stage_bytes = w->stage_floats * 4;
+    // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
+    const uint64_t wg_parts_bytes = align_up((uint64_t)(2 * w->n_cu + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
+    if (w->arena) {
+        if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
+    } else {
+        // contiguous (write-through, uncached) arenas are what k_tick3's dense nt store streams want -- and a hazard
+        // when their physical pages were used through a cached mapping earlier in the process (include/ggrs_hip.h,
+        // GGRS_WORLD_CONTIG_ARENA): opt-in per world, only for worlds k_tick3 serves, up to 1.5 GiB.  Safety net for the cached
+        // mappings the library knows about: once this process has freed a PAGED arena of its own, a later world's request is ignored
+        const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
+                                                       : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick3_ok && need <= (1536ull << 20) &&
+                                                          g_paged_arena_frees.load(std::memory_order_relaxed) == 0);
+        uint8_t* pa = nullptr;
+        hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need, hipDeviceMallocContiguous) : hipErrorUnknown;
+        w->arena_contiguous = me == hipSuccess;
+        if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need); }   // no contiguous range free: plain pages
+        if (me != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)need); }
+        if (w->knobs.debug_arena) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes at %p, state_bytes=%llu\n", w->arena_contiguous ? "contiguous" : "paged", (unsigned long long)need, (void*)pa, (unsigned long long)w->state_bytes);
+        w->arena = pa; w->arena_bytes = need; w->own_arena = true;
+    }
+    // GGRS_DEBUG_POISON=1: fill a library-owned arena with a garbage pattern before anything is initialised -- a read of memory the
+    // library never wrote (hidden by whatever a previous allocation left there) then fails the parity tests every time
+    if (w->knobs.debug_poison && w->own_arena) HIPCHK(w, hipMemsetAsync(w->arena, 0xA5, need, w->stream));
+    uint8_t* p = w->arena;
+    const uint32_t ncols = (uint32_t)w->col_off.size();
+    w->live.ptr = p; p += w->state_bytes;
+    w->live.ver.assign(ncols, 0);                                   // == cur_ver: nothing has been written yet
+    w->slots.resize(w->max_depth);
+    for (uint32_t i = 0; i < w->max_depth; ++i) {
+        w->slots[i].ptr = p; p += w->state_bytes; w->slots[i].ver.assign(ncols, VER_NONE);
+        w->free_slots.push_back((int)(w->max_depth - 1 - i));
+    }
+    uint8_t* const side = p; p += w->side_bytes;          // == live.ptr + side_off (build_layout)
+    w->d_parts = (uint64_t*)p; p += parts_bytes;
+    w->d_units = (UnitDesc*)p; p += units_bytes;
+    w->d_maskoffs = (uint64_t*)p; p += ALIGN;
+    w->d_stage = (float*)p; p += stage_bytes;
+    w->d_wg_parts = (uint64_t*)p; p += wg_parts_bytes - ALIGN;
+    w->d_ticket = (uint32_t*)p; p += ALIGN;
+    w->cks_args.parts = w->d_parts;
+    w->cks_args.part_cnt = w->d_parts + (uint64_t)w->cks_args.n_cks * w->part_stride;
+    w->cks_args.part_stride = w->part_stride;
+
+    // Checksum(u128) results are written by the kernels straight into pinned, device-mapped host memory:
+    // no device->host copy node per request list, one stream sync makes them visible.
+    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
+    HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
+    HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
+    if (w->jit_fn && w->knobs.host_fold_max_wgs) {
+        w->rows_cap = 1u << 20;                                    // 8 MiB of partial rows between two collects
+        HIPCHK(w, hipHostMalloc((void**)&w->h_rows, w->rows_cap * 8, hipHostMallocMapped));
+        HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_rows, w->h_rows, 0));
+    }
+    if (w->knobs.debug_poison) { memset(w->h_results, 0xA5, (size_t)w->max_results * 16); memset(w->h_stage, 0xA5, stage_bytes); }
+    // zero header + masks of EVERY block (columns need no init: masked by liveness).  Invariant
+    // relied on by k_copy_state: mask words beyond a block's dirty_len are zero.
+    {
+        const uint64_t head = ALIGN + (uint64_t)w->plan.n_masks * align_up(w->cap_pad / 8, ALIGN);   // header + every mask
+        HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
+        for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
+        HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
+        HIPCHK(w, hipMemsetAsync(w->d_ticket, 0, ALIGN, w->stream));      // tick_fold's arrival counter: zero between launches
+    }
+    if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
+    if (w->gen_ok) {
+        const size_t bytes = (size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8;
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes));
+        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream));
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->sealed = true;
+    return GGRS_OK;
+}
+
+}  // namespace

@@ -1,0 +1,359 @@
+// host_world.hpp -- the ggrs_world object: configuration knobs, registered components and systems, the layout of a packed
+// state block, row versions, device buffers and host mirrors.  Part of the single translation unit ggrs_hip.hip (included
+// first; everything below the C ABI's opaque `struct ggrs_world` lives in one anonymous namespace).
+#pragma once
+
+namespace {
+
+constexpr uint64_t ALIGN = 256;
+constexpr int TICK3_RESTL_EXACT = 7;   // untouched rows of the straight-line k_tick3 instantiation: EXACTLY this many (the stress_test world)
+constexpr int TICK3_RESTL_ANY = 16;    // k_tick3's general instantiation: up to this many untouched 4-byte rows
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct Comp {
+    std::string name;
+    uint32_t word_bytes = 4, n_words = 0;   // word_bytes: 1, 2, 4 or 8
+    std::vector<uint32_t> cks_words;     // as registered
+    bool checksummed = false;
+    std::string cks_source;              // ggrs_hip_checksum_component_custom: the user's hasher (HIP C++), else empty
+    std::vector<uint8_t> defaults;
+    uint32_t col_base = 0;               // index of its first column
+    bool no_rollback = false;            // GGRS_COMP_NO_ROLLBACK: lives in the side region, outside every snapshot
+};
+
+// Row versions.  Every word column of a block carries the version of the bytes it holds; a version names one state of a
+// column over all slots.  Whoever writes a live column -- a GgrsSchedule system (its write set), a spawn, an upload, an
+// insert -- gives it a fresh version; SaveWorld copies a column only when the ring slot's version differs from the live
+// one, LoadWorld likewise, and both make the destination's version equal to the source's.  A column no system writes (the
+// rotation and scale of the stress_test's Transform) therefore reaches every ring slot once and is never stored again:
+// the snapshot bytes are identical by construction, only the redundant store is gone.  GGRS_ROW_VERSIONS=0 turns the
+// bookkeeping off (every copy moves every row).
+constexpr uint32_t VER_NONE = 0xFFFFFFFFu;   // "nothing known": never equal to a live version
+
+struct Block {                           // one packed state block in the arena
+    uint8_t* ptr = nullptr;
+    uint64_t dirty_len = 0;              // slots that may hold non-zero mask bits
+    uint64_t len = 0;                    // host mirror of Header::len for ring slots
+    std::vector<uint32_t> ver;           // per column: the version of the bytes this block holds (VER_NONE: unknown)
+};
+
+struct EventPair { hipEvent_t a, b; uint32_t cls; };
+struct JitEntry;                         // kernel_gen.hpp: a cached generated module
+
+// Every environment variable the library reads, in ONE place, read ONCE per world at creation.  They are A/B and debugging
+// aids; none of them changes a result, and tests/test_gpu_knobs.py runs a bit-exact parity case under each of them.
+// (GGRS_HIP_TRACE / GGRS_HIP_ROCTX, the two tracing switches, and GGRS_RCCL_LIB are process-wide.)
+struct Knobs {
+    bool tick_generic = false;     // GGRS_TICK_GENERIC=1   the particles world runs on the generated kernel at every size (never k_tick3)
+    bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel: k_tick3 for the particles world, per-request kernels for the rest
+    uint64_t jit_particles_max_slots = 416 * 1024;   // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (profiles/r02jit/cross.txt)
+    uint64_t jit_persist_min_slots = 416 * 1024;     // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0: never
+    int host_fold_max_wgs = 256;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
+    bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
+    int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
+    uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
+    bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
+    int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
+    bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
+    bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
+    int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
+    std::string jit_cache_dir;     // GGRS_JIT_CACHE_DIR    code objects of generated kernels on disk ("" = ~/.cache/ggrs_hip; "0": no disk cache)
+    static Knobs from_env() {
+        Knobs k;
+        auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
+        k.tick_generic = num("GGRS_TICK_GENERIC", 0) != 0;
+        k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
+        k.jit_particles_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024));
+        k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 416 * 1024));
+        k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 256)));
+        k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
+        k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
+        k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
+        k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
+        k.arena_contig = (int)std::min<long long>(1, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
+        k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
+        k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
+        k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);
+        if (const char* v = getenv("GGRS_JIT_CACHE_DIR")) k.jit_cache_dir = v;
+        return k;
+    }
+};
+
+}  // namespace
+
+static std::atomic<int> g_paged_arena_frees{0};   // paged (cached) arenas this process has handed back: see GGRS_WORLD_CONTIG_ARENA
+
+struct ggrs_world {
+    // ---- configuration
+    int device = 0;
+    uint64_t capacity = 0, cap_pad = 0;
+    uint32_t max_depth = 0, flags = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false, arena_contiguous = false;
+
+    std::vector<Comp> comps;
+    std::vector<ggrs_system_desc> systems;
+    struct Custom {                      // GGRS_SYS_CUSTOM: a hiprtc-compiled per-entity system (systems[i].comp[0] indexes this)
+        std::string name, source;
+        hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
+        uint32_t n_bind = 0, comp[GGRS_CUSTOM_MAX_BINDINGS] = {}, word[GGRS_CUSTOM_MAX_BINDINGS] = {};
+        uint32_t n_pres = 0, pres_comp[GGRS_CUSTOM_MAX_BINDINGS] = {};
+    };
+    std::vector<Custom> customs;
+    // the request-group kernel generated for this world (kernel_gen.hpp): one workgroup per 256 slots (small worlds: roles,
+    // batches, host-side fold) and its persistent form (HBM-sized worlds: grid = what the chip holds, checksum fold in-kernel)
+    hipFunction_t jit_fn = nullptr, jit_fn_persist = nullptr;
+    JitEntry* jit_entry = nullptr; JitEntry* jit_entry_persist = nullptr;   // handed back to the module cache when the world is destroyed
+    uint32_t jit_persist_wgs = 0;        // workgroups of the persistent form the device holds at once (occupancy query)
+    std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)
+    bool jit_marks = false;              // the generated kernel keeps the RollbackDespawned markers (a system may defer a despawn)
+    bool jit_reads_inputs = false;       // a system reads PlayerInputs (BOX_MOVE, custom): branches with different inputs differ
+    int jit_box_sys = -1;                // index of a BOX_MOVE system (its FRICTION.powf(dt) is evaluated per step on the host)
+    uint32_t gen_parts_saves = 0;        // Save rows of d_gen_parts (room for a batch of checksum-only groups in small worlds)
+    bool layout_only = false;            // GGRS_WORLD_LAYOUT_ONLY: no device behind this world
+    bool sealed = false;
+    int seal_error = 0;                  // a failed seal latches: every later call reports it instead of re-carving the arena
+    Knobs knobs;
+    std::string err;
+
+    // ---- layout of a packed state block.  Offsets of non-rollback components and of the
+    // RollbackDespawned markers are ALSO relative to the live block's base but point past the ring,
+    // into the live-only side region (they are only ever applied to the live block).
+    uint64_t side_off = 0, side_bytes = 0;
+    DespawnMarks marks{};                // disabled mask + despawned-frame column (despawn.rs:45-46)
+    bool has_nr = false;                 // any GGRS_COMP_NO_ROLLBACK component
+    bool marks_possible = false;         // a RollbackDespawned marker may exist in the live world
+    int32_t dc_local = 0;                // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
+    uint64_t state_bytes = 0, off_alive = 0;
+    std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0
+    std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
+    std::vector<uint8_t> col_rb;                   // column is part of a rollback component (snapshotted)
+    uint32_t ts = 0;                               // tile stride of the rollback word columns: bytes of all their words x 8192 slots
+    CopyPlan plan{};                               // every mask + every row (rows carry their column index)
+    std::vector<uint32_t> row_col;                 // plan.row[r] belongs to column row_col[r]
+
+    // ---- row versions (see Block::ver)
+    uint32_t ver_counter = 0;
+    std::vector<uint32_t> cur_ver;                 // the LOGICAL live state's version per column (ahead of live.ver inside a fused group)
+    std::vector<uint8_t> col_ext;                  // a device pointer to this live column was handed out: assume it changes between any two calls
+    std::vector<std::vector<uint32_t>> sys_writes; // per system: the columns it may write (one fresh version per AdvanceWorld)
+
+    // ---- device buffers
+    Block live;
+    std::vector<Block> slots;            // ring slot pool
+    std::vector<int> free_slots;
+    uint64_t* d_parts = nullptr; uint32_t part_stride = 0;   // [(n_cks)+1][part_stride], last = counts
+    uint64_t* d_results = nullptr; uint64_t* h_results = nullptr; uint32_t max_results = 0;
+    UnitDesc* d_units = nullptr;
+    uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
+    float* d_stage = nullptr; float* h_stage = nullptr; uint64_t stage_floats = 0, stage_used = 0;
+
+    // ---- checksum specs (device view)
+    std::vector<uint32_t> cks_comp;      // checksummed component ids in id order
+    CksArgs cks_args{};
+    bool custom_hashers = false;         // some checksum spec is user source: only the generated kernel can compute it
+    bool fused_ok = false;               // schedule == particles fast path
+    bool fused_cks = false;              // ... and every checksum spec is covered by it
+    int f_T = -1, f_V = -1, f_L = -1, f_spawn = -1; uint32_t f_tw = 0, f_vw = 0, f_lw = 0;
+    bool f_cksT = false, f_cksV = false;
+    float f_g[3] = {0, 0, 0};
+    // k_tick3: the schedule is exactly the particles systems over three distinct components, every checksum spec is one the
+    // kernel computes in registers, and the untouched words are at most 16 contiguous 4-byte rows
+    bool tick3_ok = false; Tick3Args tick3_proto{};
+    std::vector<uint32_t> tick3_sched_cols, tick3_rest_cols;   // the 7 schedule-owned columns / the untouched columns in row order
+    uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
+    uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]
+    bool gen_ok = false;                 // the generated kernel serves this world's request lists
+
+    // pending partials produced by the last advance (valid for the live state as-is)
+    bool pending_valid = false; uint32_t pending_parts = 0;
+
+    // ---- host mirrors
+    uint64_t len = 0;
+    int32_t frame = 0;
+    bool has_confirmed = true; int32_t confirmed = 0;   // init_resource::<ConfirmedFrameCount>() == 0 (mod.rs:336)
+    uint64_t fps = 60;
+    int32_t synctest_cd = -1;
+    size_t depth = 60;                                   // DEFAULT_FPS until sync_depth (mod.rs:115)
+    std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
+
+    // ---- asynchronous request batches (ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums)
+    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; uint32_t n_folds = 0; };
+    // Host-side checksum fold of small worlds (generated kernel): its workgroups write their partial rows straight into pinned,
+    // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected -- a
+    // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.
+    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off, total_len; };
+    std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
+    uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
+    bool device_results_only = false;    // a consumer reads the result ring in stream order (ggrs_hip_fanout_*): every fold stays on the device
+    std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
+    std::vector<hipEvent_t> event_pool;
+
+    // ---- profiling
+    bool nt_copy = false;               // non-temporal loads/stores in k_copy_state (A/B knob)
+    bool prof = false;
+    std::vector<EventPair> prof_events;
+    double prof_ms[GGRS_KERNEL_CLASSES] = {};
+    uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
+    uint64_t prof_bytes[GGRS_KERNEL_CLASSES] = {};            // algorithmic bytes the launches of a class were asked to move (rows x their extent)
+    std::vector<float> prof_launch_us[GGRS_KERNEL_CLASSES];   // every launch since enable, in submission order (ggrs_hip_profile_read_launches)
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(w, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return (w)->fail(GGRS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                              \
+    } while (0)
+
+namespace {
+
+struct ProfScope {
+    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0) : w(w_), cls(c) {
+        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, w->stream); w->prof_bytes[c] += bytes; }
+    }
+    ~ProfScope() {
+        if (w->prof) { (void)hipEventRecord(b, w->stream); w->prof_events.push_back({a, b, cls}); }
+    }
+};
+
+// Every entry point that touches the device runs with the world's device current on the calling thread and puts the
+// caller's device back on return (two worlds on different GPUs in one process; a host thread torch switched elsewhere).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const ggrs_world* w) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != w->device) switched = hipSetDevice(w->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+// ---- row versions ---------------------------------------------------------------------------------------------------
+inline void ver_touch(ggrs_world* w, uint32_t col) { w->cur_ver[col] = ++w->ver_counter; }
+inline void ver_touch_comp(ggrs_world* w, uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) ver_touch(w, w->comps[c].col_base + k); }
+inline void ver_touch_all(ggrs_world* w) { for (uint32_t c = 0; c < w->cur_ver.size(); ++c) ver_touch(w, c); }
+// AdvanceWorld: every registered system may have written its write set
+inline void ver_step(ggrs_world* w) { for (auto& cols : w->sys_writes) for (uint32_t c : cols) ver_touch(w, c); }
+// must `dst` receive column `col` to hold the state whose versions are `want`?  (yes also when nothing is known)
+inline bool ver_differs(const ggrs_world* w, const Block& dst, const std::vector<uint32_t>& want, uint32_t col) {
+    return !w->knobs.row_versions || w->col_ext[col] || dst.ver[col] == VER_NONE || want[col] == VER_NONE || dst.ver[col] != want[col];
+}
+// the live block holds exactly the logical live state (no fused group is being assembled)
+inline void ver_sync_live(ggrs_world* w) { w->live.ver = w->cur_ver; }
+
+// Computes the packed state layout from the registered components.
+void build_layout(ggrs_world* w) {
+    const uint64_t mask_bytes = align_up(w->cap_pad / 8, ALIGN);
+    uint64_t off = ALIGN;                          // header
+    w->off_alive = off; off += mask_bytes;
+    w->off_present.assign(w->comps.size(), 0); w->col_off.clear(); w->col_wb.clear();
+    w->has_nr = false;
+    uint32_t ncols = 0;
+    for (auto& c : w->comps) { c.col_base = ncols; ncols += c.n_words; w->has_nr |= c.no_rollback; }
+    w->col_off.assign(ncols, 0); w->col_wb.assign(ncols, 4); w->col_rb.assign(ncols, 0);
+    for (size_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback) { w->off_present[c] = off; off += mask_bytes; }
+    // rollback word columns, TILE-MAJOR: tile t of every column is contiguous (ts bytes per tile).  Inside a
+    // tile the words that GgrsSchedule systems read or write come first, so a per-request AdvanceWorld kernel
+    // streams one contiguous span per tile (particles: 32 of the 60 KiB) instead of 4 KiB pieces; then the other 4- and
+    // 8-byte words, then the 2- and 1-byte ones (every column's tile stays 16-byte aligned).
+    w->col_ts.assign(ncols, 0);
+    std::vector<uint8_t> hot(ncols, 0);
+    w->sys_writes.assign(w->systems.size(), {});
+    for (size_t si = 0; si < w->systems.size(); ++si) {
+        const ggrs_system_desc& sd = w->systems[si];
+        auto mark = [&](uint32_t comp, uint32_t word, uint32_t span, bool writes) {
+            if (comp >= w->comps.size()) return;
+            for (uint32_t k = 0; k < span && word + k < w->comps[comp].n_words; ++k) {
+                hot[w->comps[comp].col_base + word + k] = 1;
+                if (writes) w->sys_writes[si].push_back(w->comps[comp].col_base + word + k);
+            }
+        };
+        switch (sd.kind) {
+        case GGRS_SYS_PARTICLES_UPDATE: mark(sd.comp[0], sd.word[0], 3, true); mark(sd.comp[1], sd.word[1], 3, true); break;
+        case GGRS_SYS_TTL_DESPAWN: case GGRS_SYS_ADD_U32: case GGRS_SYS_SAT_SUB_DESPAWN: mark(sd.comp[0], sd.word[0], 1, true); break;
+        case GGRS_SYS_BOX_MOVE: mark(sd.comp[0], sd.word[0], 3, true); mark(sd.comp[1], sd.word[1], 3, true); mark(sd.comp[2], sd.word[2], 1, false); break;
+        case GGRS_SYS_CUSTOM: {
+            const ggrs_world::Custom& c = w->customs[sd.comp[0]];
+            for (uint32_t b = 0; b < c.n_bind; ++b) mark(c.comp[b], c.word[b], 1, true);      // a bound word may be written
+        } break;
+        default: break;     // PARTICLES_SPAWN appends rows through run_spawn_systems, which versions its bundle itself
+        }
+    }
+    uint64_t tcol = 0;
+    for (int pass = 0; pass < 4; ++pass)      // 0: hot words (any width >= 4), 1: other 4-/8-byte words, 2: 2-byte words, 3: 1-byte words
+        for (auto& c : w->comps) {
+            for (uint32_t k = 0; k < c.n_words; ++k) {
+                const uint32_t col = c.col_base + k;
+                w->col_wb[col] = c.word_bytes; w->col_rb[col] = !c.no_rollback;
+                if (c.no_rollback) continue;
+                const bool wide = c.word_bytes >= 4;
+                const int want = (wide && hot[col]) ? 0 : (wide ? 1 : (c.word_bytes == 2 ? 2 : 3));
+                if (want != pass) continue;
+                w->col_off[col] = tcol;           // offset inside a tile for now
+                tcol += (uint64_t)LAYOUT_TILE * c.word_bytes;
+            }
+        }
+    w->ts = (uint32_t)tcol;
+    const uint64_t cols_base = align_up(off, 4096);
+    for (auto& c : w->comps) if (!c.no_rollback)
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] += cols_base; w->col_ts[c.col_base + k] = w->ts; }
+    off = cols_base + (w->cap_pad / LAYOUT_TILE) * (uint64_t)w->ts;
+    w->state_bytes = align_up(off, 4096);
+    // ---- live-only side region, placed right behind the ring blocks
+    w->side_off = (uint64_t)(w->max_depth + 1) * w->state_bytes;
+    uint64_t so = w->side_off;
+    w->marks.off_disabled = so; so += mask_bytes;
+    w->marks.off_dframe = so; so += align_up(w->cap_pad * 4, ALIGN);
+    for (size_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].no_rollback) { w->off_present[c] = so; so += mask_bytes; }
+    for (auto& c : w->comps) {
+        if (!c.no_rollback) continue;
+        // live-only columns are plain arrays: the same addressing formula with tile stride = 8192 words
+        for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] = so; w->col_ts[c.col_base + k] = LAYOUT_TILE * c.word_bytes; so += align_up(w->cap_pad * c.word_bytes, ALIGN); }
+    }
+    w->side_bytes = align_up(so - w->side_off, 4096);
+
+    CopyPlan& p = w->plan;
+    memset(&p, 0, sizeof p);
+    w->row_col.clear();
+    p.n_masks = 1;
+    p.mask_off[0] = w->off_alive;
+    uint32_t nr = 0;
+    for (size_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback) p.mask_off[p.n_masks++] = w->off_present[c];   // snapshots hold rollback components only
+    // a row = up to 4 KiB of one workgroup tile (1024 slots) of one column: an 8-byte word has two, a 1- / 2-byte word a short
+    // one.  The 4 KiB rows come first (k_copy_state moves them in straight-line batches), the short ones after them.
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t c = 0; c < w->comps.size(); ++c) {
+            const Comp& cc = w->comps[c];
+            if (cc.no_rollback || (cc.word_bytes >= 4) != (pass == 0)) continue;
+            for (uint32_t k = 0; k < cc.n_words; ++k)
+                for (uint32_t r = 0; r < std::max(1u, cc.word_bytes / 4); ++r) {
+                    RowDesc& rd = p.row[nr++];
+                    rd.col_off = w->col_off[cc.col_base + k]; rd.roff = r * 4096; rd.tile_stride = w->ts; rd.word_bytes = cc.word_bytes;
+                    rd.bytes = std::min<uint32_t>(4096u, (uint32_t)TILE * cc.word_bytes);
+                    w->row_col.push_back(cc.col_base + k);
+                }
+            if (pass == 0) p.n_wide = nr;
+        }
+    p.n_rows = nr;
+    w->cur_ver.assign(ncols, 0); w->col_ext.assign(ncols, 0);
+}
+
+uint32_t total_rows(const ggrs_world* w) {
+    uint32_t n = 0;
+    for (auto& c : w->comps) if (!c.no_rollback) n += c.n_words * std::max(1u, c.word_bytes / 4);
+    return n;
+}
+// bytes per slot of the rollback words
+inline uint32_t bytes_per_slot(const ggrs_world* w) { return w->ts / LAYOUT_TILE; }
+
+inline uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + TILE - 1) / TILE); }
+
+}  // namespace

@@ -53,10 +53,10 @@ struct RowDesc {          // one 4 KiB-per-tile copy row of the packed state blo
     uint32_t roff;        // byte offset of this row inside the column's tile (0 or 4096)
     uint32_t tile_stride; // bytes one tile of this column spans (TILE * word_bytes)
     uint32_t word_bytes;
-    uint32_t pad;
+    uint32_t bytes;       // bytes of this row per workgroup tile: 4096, or 1024 / 2048 for a 1- / 2-byte word
 };
 struct CopyPlan {
-    uint32_t n_rows, n_masks;
+    uint32_t n_rows, n_masks, n_wide, pad;   // rows [0, n_wide) are 4096-byte rows (moved in straight-line batches), the rest are short
     uint64_t mask_off[MAX_MASKS];
     RowDesc row[MAX_ROWS];
 };
@@ -69,7 +69,7 @@ struct StepArgs {         // fused GgrsSchedule step of the particles workload
     uint32_t ts; uint32_t pad;            // tile stride of the rollback word columns
 };
 
-struct UnitDesc { uint64_t off; uint32_t stride; uint32_t ts; };   // u32 unit e at col_at(off, ts, stride, e)
+struct UnitDesc { uint64_t off; uint32_t wb; uint32_t ts; };   // one hashed word: slot e's word of wb bytes at col_at(off, ts, wb, e)
 struct CksArgs {          // generic component checksum
     const uint8_t* state;
     uint64_t off_alive;
@@ -180,17 +180,23 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
 
     const uint32_t n_rows = plan.n_rows;
     if (((uint64_t)t + 1) * TILE <= len) {
+        const uint32_t n_wide = plan.n_wide;
         uint32_t r = 0;
-        for (; r + 8 <= n_rows; r += 8) copy_rows<8, NT>(src, dst, plan, r, t, tid);
-        if (r + 4 <= n_rows) { copy_rows<4, NT>(src, dst, plan, r, t, tid); r += 4; }
-        if (r + 2 <= n_rows) { copy_rows<2, NT>(src, dst, plan, r, t, tid); r += 2; }
-        if (r < n_rows) copy_rows<1, NT>(src, dst, plan, r, t, tid);
+        for (; r + 8 <= n_wide; r += 8) copy_rows<8, NT>(src, dst, plan, r, t, tid);
+        if (r + 4 <= n_wide) { copy_rows<4, NT>(src, dst, plan, r, t, tid); r += 4; }
+        if (r + 2 <= n_wide) { copy_rows<2, NT>(src, dst, plan, r, t, tid); r += 2; }
+        if (r < n_wide) copy_rows<1, NT>(src, dst, plan, r, t, tid);
+        for (r = n_wide; r < n_rows; ++r) {                  // 1- / 2-byte words: 1 or 2 KiB per tile, whole waves (wave-uniform predicate)
+            const RowDesc rd = plan.row[r];
+            const uint64_t pos = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + (uint64_t)tid * 16;
+            if (tid * 16u < rd.bytes) *reinterpret_cast<uint4*>(dst + pos) = *reinterpret_cast<const uint4*>(src + pos);
+        }
     } else {
         for (uint32_t r = 0; r < n_rows; ++r) {
             const RowDesc rd = plan.row[r];
             const uint64_t pos = wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff + (uint64_t)tid * 16;
             const uint64_t slot0 = (uint64_t)t * TILE + (rd.roff + tid * 16u) / rd.word_bytes;   // first slot of this lane's 16 bytes
-            if (slot0 < len)
+            if (slot0 < len && tid * 16u < rd.bytes)
                 *reinterpret_cast<uint4*>(dst + rd.col_off + pos) = *reinterpret_cast<const uint4*>(src + rd.col_off + pos);
         }
     }
@@ -378,39 +384,10 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
 // safe because every location is read by the lane that later writes it, and all reads of a
 // location precede its first write (pointers are deliberately not __restrict__).
 constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
-// In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
-// the last workgroup to arrive writes every Save's Checksum(u128).
-struct FoldArgs {
-    uint64_t* wg_parts;                    // [gridDim.x][n_saves * (n_comp + 1)]: per Save the XOR of each checksummed component, then the live count
-    uint32_t* ticket;                      // arrival counter, zero between launches
-    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
-    uint32_t n_comp, comp_mask;            // component slots per Save; bit j: slot j is a registered checksum (contributes a part)
-};
-struct RowLite { uint64_t col_off; uint32_t roff; uint32_t tile_stride; uint32_t word_bytes; uint32_t pad; };
-struct TickArgs {
-    const uint8_t* src;                    // ring slot (group starts with LoadGameState) or live
-    uint8_t* live;
-    uint8_t* save_dst[MAX_TICK_SAVES];     // nullptr: ring depth 0, checksum only
-    int32_t save_frame[MAX_TICK_SAVES];
-    uint32_t dt_bits[MAX_TICK_STEPS];
-    uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
-    uint32_t n_ops, n_saves, n_steps, src_is_live;
-    uint64_t len;
-    uint32_t nt_load, skip_live;          // skip_live: the live block is overwritten before anyone reads it (a LoadGameState follows): do not write it
-    uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl;
-    float g[3];
-    uint32_t n_rest_rows, n_rest_masks, part_stride, ts;   // ts: tile stride of the rollback word columns
-    uint32_t dp_s;                         // depth-parallel k_tick1: outputs (Saves, then the live world) per workgroup role
-    uint64_t* parts;                       // [n_saves][3 = T,V,count][part_stride], one entry per WAVE (folded by k_tick_finalize)
-    uint64_t rest_mask_off[MAX_MASKS];     // presence masks of components the schedule does not touch
-    RowLite rest[MAX_ROWS];                // word rows the schedule does not touch
-};
-
 // Pins a wave-uniform pointer into an SGPR pair so that `sgpr_base(p) + lane_offset_u32` selects the
 // saddr form of global_load/global_store (no 64-bit VALU address arithmetic per access).  The value
 // comes back as an explicit global (address space 1) pointer: laundering a generic pointer through
 // inline asm would otherwise make the compiler fall back to flat_* instructions.
-static_assert(sizeof(TickArgs) <= 4096, "kernel argument segment limit");
 #define GGRS_GLOBAL __attribute__((address_space(1)))
 typedef GGRS_GLOBAL uint8_t g_u8;
 __device__ __forceinline__ g_u8* sgpr_base(const uint8_t* p) {
@@ -436,321 +413,10 @@ __device__ __forceinline__ void st16(g_u8* base, uint32_t lo, const V& v) {
 }
 __device__ __forceinline__ void st8(g_u8* p, uint64_t v) { *(GGRS_GLOBAL uint64_t*)p = v; }
 
-template <int B, bool NT>
-__device__ __forceinline__ void fan_rows(const TickArgs& a, uint32_t r0, uint32_t t, uint32_t tid) {
-    u32x4 v[B];
-    uint64_t pos[B];                          // wave-uniform part of the address (SGPRs)
-    const uint32_t lo = tid * 16u;            // per-lane part
-#pragma unroll
-    for (int j = 0; j < B; ++j) {
-        const RowLite rd = a.rest[r0 + j];
-        pos[j] = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff;
-    }
-#pragma unroll
-    for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const u32x4*>(a.src + pos[j] + lo);
-    // gfx9 counts loads AND stores in vmcnt: land the loads once here, or the compiler throttles
-    // every store of the fan-out loop behind a conservative vmcnt(B-1)
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
-    for (uint32_t k = 0; k < a.n_saves; ++k) {
-        uint8_t* dst = a.save_dst[k];
-        if (!dst) continue;
-#pragma unroll
-        for (int j = 0; j < B; ++j) {
-            st16<NT>(sgpr_base(dst + pos[j]), lo, v[j]);
-        }
-    }
-    if (!a.src_is_live && !a.skip_live) {
-#pragma unroll
-        for (int j = 0; j < B; ++j) st16<false>(sgpr_base(a.live + pos[j]), lo, v[j]);
-    }
-}
-
-// RESTL > 0: the (up to RESTL) word rows the schedule never touches stay in registers too and every Save stores
-// its snapshot's full tile (schedule-owned rows + rest rows) together, instead of the up-front fan-out: fewer
-// workgroups resident (4 * RESTL more VGPRs), each snapshot's tile written as one burst.  Measured 128-129 us vs
-// 126-136 us (the plain variant is bimodal with the arena's placement, profiles/README.md); default when the
-// world has at most RESTL such rows, GGRS_TICK_REST=0 selects the fan-out variant.
-// WPB = waves per workgroup.  Every wave owns one 256-slot quarter of a tile and shares nothing with the other
-// waves (no LDS, no barrier), so the same code runs as 4-wave workgroups (one tile each) for big worlds and as
-// single-wave workgroups for small ones: four times as many workgroups to spread over the 256 CUs, still 16 bytes
-// per lane per access.
-template <bool CKS_T, bool CKS_V, bool NT, int RESTL = 0, int WPB = 4>
-__global__ __launch_bounds__(WPB * 64) void k_tick(TickArgs a) {
-    const uint32_t lane = threadIdx.x & 63u;
-    // readfirstlane: the wave index is uniform, and the compiler must know it (uniform bases live in SGPRs)
-    const uint32_t gw = blockIdx.x * WPB + (WPB == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));   // global wave id == 256-slot quarter tile
-    const uint32_t t = gw >> 2, wave = gw & 3u;                   // its tile, and which quarter of it
-    const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
-    const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
-    const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
-    // every access below is "uniform 64-bit base (block + column row + tile offset) + 32-bit lane
-    // offset", i.e. the saddr form of global_load/store
-    const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);   // this tile's rows of a 4- / 8-byte column inside a block
-    const uint32_t o4 = tid * 16u, o8 = tid * 32u;                // lane offsets inside a 4- / 8-byte column's tile rows
-    const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
-    const uint32_t sh = (lane & 15u) * 4;
-    const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;                 // byte offset of this lane's mask word
-
-    // ---- every load of the schedule-owned state, back to back
-    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
-    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
-    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
-    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
-    float4 tx[3], vv[3];
-    ulonglong2 tl[2];
-    // the source block is read exactly once: a.nt_load (A/B knob GGRS_TICK_NTLOAD) marks the loads non-temporal
-    auto ld16 = [&](const uint8_t* p) -> u32x4 {
-        return a.nt_load ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
-    };
-    if (in_len) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
-        { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
-        { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + 16 + o8); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
-        tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
-    }
-
-    // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
-    if (lane < 4u * a.n_rest_masks) {                             // this wave's 4 words of every such mask
-        const uint32_t m = lane >> 2, mw = lane & 3u;
-        const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
-        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
-        for (uint32_t k = 0; k < a.n_saves; ++k)
-            if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-        if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
-    }
-    u32x4 restv[RESTL > 0 ? RESTL : 1];
-    uint64_t restpos[RESTL > 0 ? RESTL : 1];
-    if (RESTL > 0) {
-#pragma unroll
-        for (int j = 0; j < RESTL; ++j) {
-            restv[j] = u32x4{0, 0, 0, 0}; restpos[j] = 0;
-            if ((uint32_t)j < a.n_rest_rows) {                   // wave-uniform
-                const RowLite rd = a.rest[j];
-                restpos[j] = rd.col_off + wtile_off(t, rd.tile_stride, rd.word_bytes) + rd.roff;
-                if (in_len) restv[j] = ld16(a.src + restpos[j] + tid * 16u);
-            }
-        }
-    } else if (in_len && (a.n_saves || !a.src_is_live)) {
-        // batches of up to 8 rows: while this phase runs only the schedule-owned state is live in
-        // registers (the hash temporaries come later), so 32 more VGPRs are free.  The particles world
-        // has 7 such rows: ONE batch, one wait shared with the state loads above, then stores only.
-        const uint32_t n_rows = a.n_rest_rows;
-        for (uint32_t r = 0; r < n_rows; r += 8) {
-            switch (n_rows - r) {
-            case 1: fan_rows<1, NT>(a, r, t, tid); break;
-            case 2: fan_rows<2, NT>(a, r, t, tid); break;
-            case 3: fan_rows<3, NT>(a, r, t, tid); break;
-            case 4: fan_rows<4, NT>(a, r, t, tid); break;
-            case 5: fan_rows<5, NT>(a, r, t, tid); break;
-            case 6: fan_rows<6, NT>(a, r, t, tid); break;
-            case 7: fan_rows<7, NT>(a, r, t, tid); break;
-            default: fan_rows<8, NT>(a, r, t, tid); break;
-            }
-        }
-    }
-
-    uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
-    const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu,
-                   n_L = (uint32_t)(pL_w >> sh) & 0xFu;
-
-    // diffuse(K0 ^ order), order == slot (RollbackOrdered::order): shared by both components and all Saves
-    uint64_t ordB[4];
-    if (CKS_T || CKS_V) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
-    }
-
-    // SaveWorld, per-entity half of the checksum (component_checksum.rs:77-90) of the registers as they
-    // are now; one partial per wave.
-    uint32_t si = 0, sj = 0;
-    auto hash_save = [&](uint32_t cnt) {
-        uint64_t hT = 0, hV = 0;
-        if (CKS_T || CKS_V) {
-            const uint32_t c_T = CKS_T ? (alive4 & n_T) : 0u, c_V = CKS_V ? (alive4 & n_V) : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (CKS_T) {
-                    const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
-                                                                        __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
-                                                                        __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
-                    hT ^= ((c_T >> j) & 1u) ? h : 0ULL;
-                }
-                if (CKS_V) {
-                    const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
-                                                                        __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
-                                                                        __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
-                    hV ^= ((c_V >> j) & 1u) ? h : 0ULL;
-                }
-            }
-            if (CKS_T) hT = wave_xor(hT);
-            if (CKS_V) hV = wave_xor(hV);
-        }
-        if (lane == 0) {
-            // plain per-wave partial stores: agent-scope atomics (tried: 64 accumulator copies + last-block
-            // fold) cost ~1 ns EACH chip-wide on gfx950 -- 94k of them added 90 us to a 134 us kernel
-            uint64_t* p = a.parts + (uint64_t)si * 3 * a.part_stride + gw;
-            p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = cnt;
-        }
-    };
-    // All waves of the chip start together and run the same op sequence, so without a stagger every
-    // wave would be storing at the same time and hashing at the same time (memory idle while the ALUs
-    // hash).  Odd waves hash a Save BEFORE storing it, even waves after: at any moment half the waves
-    // of a SIMD feed the memory pipe while the other half multiply.
-    const bool hash_first = (wave & 1u) != 0;                     // wave-uniform
-
-    // every load issued above has to land before the first op anyway; saying so explicitly keeps the
-    // compiler from guarding the op loop / the final live write with conservative vmcnt waits (gfx9
-    // counts stores in vmcnt too: such a wait would drain every snapshot store in flight)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0) expcnt(7) lgkmcnt(15)
-
-    for (uint32_t i = 0; i < a.n_ops; ++i) {
-        if (!((a.op_bits >> i) & 1ULL)) {
-            // ---------------- SaveWorld: snapshot (component_snapshot.rs:66-84, entity.rs:39-51)
-            uint8_t* dst = a.save_dst[si];
-            const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
-                           b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
-            const uint32_t cnt = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-            if (hash_first) hash_save(cnt);
-            if (dst) {
-                if (in_len) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, tx[k]);
-                        st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, vv[k]);
-                    }
-                    st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8, tl[0]);
-                    st16<NT>(sgpr_base(dst + a.off_ttl + toff8 + 16), o8, tl[1]);
-                    if (RESTL > 0) {
-#pragma unroll
-                        for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<NT>(sgpr_base(dst + restpos[j]), tid * 16u, restv[j]);
-                    }
-                }
-                uint64_t mine = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
-                                        (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
-                    if (lane == (uint32_t)w) mine = nw;
-                }
-                if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
-                if ((lane & 15u) == 0) {
-                    st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
-                    st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
-                    st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
-                }
-                if (gw == 0 && lane == 0) {
-                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
-                    h.checksum[0] = 0; h.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = h;
-                }
-            }
-            if (!hash_first) hash_save(cnt);
-            ++si;
-        } else {
-            // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
-            const float dt = __uint_as_float(a.dt_bits[sj]);
-            ++sj;
-            const uint32_t m_upd = alive4 & n_T & n_V;     // Query<(&mut Transform, &mut Velocity)>
-            const uint32_t m_ttl = alive4 & n_L;           // Query<(Entity, &mut Ttl)>
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float gd = __fmul_rn(a.g[k], dt);    // gravity * time_step
-                float* x = reinterpret_cast<float*>(&tx[k]);
-                float* v = reinterpret_cast<float*>(&vv[k]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool on = (m_upd >> j) & 1u;
-                    const float nv = __fadd_rn(v[j], gd);                     // **velocity += ...
-                    const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));      // translation += **velocity * time_step
-                    v[j] = on ? nv : v[j];
-                    x[j] = on ? nx : x[j];
-                }
-            }
-            uint32_t kill = 0;
-            uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = (m_ttl >> j) & 1u;
-                const uint64_t nq = q[j] - 1;              // usize, wrapping
-                q[j] = on ? nq : q[j];
-                kill |= (on && nq == 0) ? (1u << j) : 0u;
-            }
-            alive4 &= ~kill;                               // despawn is deferred to the end of the frame
-        }
-    }
-
-    // ---- the live block, written once
-    if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
-        if (in_len) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                st16<false>(sgpr_base(a.live + a.off_t[k] + toff), o4, tx[k]);
-                st16<false>(sgpr_base(a.live + a.off_v[k] + toff), o4, vv[k]);
-            }
-            st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8, tl[0]);
-            st16<false>(sgpr_base(a.live + a.off_ttl + toff8 + 16), o8, tl[1]);
-            if (RESTL > 0 && !a.src_is_live) {
-#pragma unroll
-                for (int j = 0; j < RESTL; ++j) if ((uint32_t)j < a.n_rest_rows) st16<false>(sgpr_base(a.live + restpos[j]), tid * 16u, restv[j]);
-            }
-        }
-        const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
-                       b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
-        uint64_t mine = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
-                                (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
-            if (lane == (uint32_t)w) mine = nw;
-        }
-        if (lane < 4) st8(sgpr_base(a.live + a.off_alive) + (w0 + lane) * 8u, mine);
-        if (!a.src_is_live && (lane & 15u) == 0) {
-            st8(sgpr_base(a.live + a.off_pT) + wi8, pT_w);
-            st8(sgpr_base(a.live + a.off_pV) + wi8, pV_w);
-            st8(sgpr_base(a.live + a.off_pL) + wi8, pL_w);
-        }
-    }
-
-}
-
-// GGRS_LDS_BARRIER_DEFINED
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
-// snapshot store still in flight (1-2 us per Save); nobody in the workgroup reads those stores back.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // vmcnt(63) expcnt(7) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// ------------------------------------------------------------------ k_tick2 (persistent fused request group, round 2)
-// The same request-group fusion as k_tick, restructured after the round-2 store-path study (scripts/ubench3.hip,
-// profiles/r02a): on MI355X the HBM write path runs closest to its ceiling when FEW waves stream stores continuously
-// (a linear fill from 256 workgroups reaches 6.2-6.4 TB/s, the same fill from 1024 workgroups 4.7-5.4 TB/s), and
-// k_tick's Save was a burst of 15 stores followed by a block of ~660 VALU instructions (80 u64 multiplies), so store
-// issue and hashing only overlapped across waves.  Here:
-//   * PERSISTENT grid: `gridDim.x` = CUs x workgroups-per-CU (host-chosen, <= the tiles); a wave walks over 256-slot
-//     units u = wave id, += waves of the grid.  No second "wave" of workgroups starting its loads while the rest of
-//     the chip is storing, a bounded number of store streams in flight;
-//   * inside a Save the eight independent SeaHash chains (4 slots x {Transform, Velocity}) are INTERLEAVED with the
-//     tile's 15 row stores -- two stores, one chain, pinned with sched_barrier -- so the store queue drains while the
-//     VALU multiplies instead of after it;
-//   * snapshot stores may be non-temporal (`nt`): with the order of stores now reaching DRAM in a dense sweep that is a
-//     gain (ubench3: 100-105 us vs 113-115 us for the same traffic);
-//   * NO finalize launch: a wave folds its partials into LDS, the workgroup publishes one 48-value row with
-//     write-through (sc0 sc1) stores, takes ONE agent-scope ticket, and the last workgroup to arrive folds the rows
-//     (component_checksum.rs:92-95, entity_checksum.rs:29-52, checksum.rs:88-99) and writes every Save's Checksum
-//     straight to pinned host memory.  256-768 tickets per launch, not one atomic per partial.
 // Register-resident rows: the 8 schedule-owned rows (translation, velocity, ttl) + up to RESTL untouched rows, which
 // the layout keeps back to back behind them (4-byte words only: rest row j of tile t at rest_off + wtile_off(t) + j * 32 KiB).
-constexpr uint32_t REST_ROW_STRIDE = LAYOUT_TILE * 4u;     // k_tick2: the untouched words are 4-byte words laid out back to back
-struct Tick2Args {
+constexpr uint32_t REST_ROW_STRIDE = LAYOUT_TILE * 4u;     // k_tick3: the untouched words are 4-byte words laid out back to back
+struct Tick3Args {
     const uint8_t* src; uint8_t* live;
     uint8_t* save_dst[MAX_TICK_SAVES];     // nullptr: ring depth 0, checksum only
     int32_t save_frame[MAX_TICK_SAVES];
@@ -762,349 +428,17 @@ struct Tick2Args {
     uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl, rest_off;
     float g[3];
     uint32_t n_rest_rows, n_rest_masks;
-    uint32_t skip_live, pad_sl;            // skip_live: see TickArgs
+    uint32_t skip_live, pad_sl;            // skip_live: the live block is overwritten before anyone reads it (a LoadGameState follows): do not write it
+    // Row versions (host_world.hpp): a Save only stores the rows whose bytes in the destination block differ from the state
+    // being saved.  sched_store bit k: Save k stores the 8 schedule-owned rows; rest_store[k] bit j: ... untouched row j.
+    // The same for the live block (written once, at the end); rest_load: the untouched rows any of those stores needs.
+    uint32_t sched_store, sched_live;
+    uint32_t rest_store[MAX_TICK_SAVES];
+    uint32_t rest_live, rest_load;
     uint64_t rest_mask_off[MAX_MASKS];
     FoldArgs fold;
 };
-static_assert(sizeof(Tick2Args) <= 1024, "keep the kernel argument block small: it is re-sent every tick");
-
-// Cross-workgroup hand-off of the partial rows: relaxed agent-scope 8-byte atomics on both sides (lowered to
-// `global_store / global_load ... sc1`: write-through stores, L1-bypassing loads -- MI355X_MICROARCH.md, "Valid forms"),
-// an explicit vmcnt(0) between a workgroup's row and its ticket, one agent-scope acquire in the workgroup that folds.
-__device__ __forceinline__ void st8_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// 16-byte store whose cache policy the instruction scheduler can see (a compiler-generated store, unlike st16<true>'s
-// inline asm): used by the ILV variant, where sched_group_barrier spaces the stores out between the hash multiplies.
-// The checksum fold shared by k_tick2 / k_tick3: one row of partials per workgroup (relaxed agent-scope stores), one
-// agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
-// entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
-template <int NTHREADS>
-__device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
-    if (n_saves == 0) return;
-    __syncthreads();                                              // the LDS atomics of every wave have landed
-    const uint32_t nv = f.n_comp + 1u;                            // values per Save
-    const uint32_t n_vals = n_saves * nv;
-    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + i, acc[i]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row is in memory before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!*s_last) return;                                         // workgroup-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) acc[i] = 0;
-    __syncthreads();
-    {
-        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  24 loads in flight per lane and trip.
-        const uint32_t n_flat = gridDim.x * n_vals;
-        constexpr int INFL = 24;
-        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += (uint32_t)INFL * NTHREADS) {
-            uint64_t v[INFL];
-#pragma unroll
-            for (int u = 0; u < INFL; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
-                v[u] = i < n_flat ? ld8_agent(f.wg_parts + i) : 0ULL;
-            }
-#pragma unroll
-            for (int u = 0; u < INFL; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
-                if (i >= n_flat) continue;
-                const uint32_t c = i % n_vals;
-                if ((c % nv) == f.n_comp) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
-                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < n_saves) {
-        const uint32_t k = threadIdx.x;
-        uint64_t total = 0;
-        for (uint32_t j = 0; j < f.n_comp; ++j)
-            if ((f.comp_mask >> j) & 1u) total ^= sea_one(acc[k * nv + j]);     // component_checksum.rs:92-95
-        total ^= sea_pair(acc[k * nv + f.n_comp], total_len);                  // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
-        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
-    }
-    if (threadIdx.x == 0) *f.ticket = 0;                          // ready for the next launch on this stream
-}
-
-__device__ __forceinline__ g_u8* sgpr_base_nv(const uint8_t* p) {      // sgpr_base without `volatile`: the statement may move
-    uint64_t x = reinterpret_cast<uint64_t>(p);
-    asm("" : "+s"(x));
-    return (g_u8*)x;
-}
-template <bool NT>
-__device__ __forceinline__ void st16v(g_u8* base, uint32_t lo, const u32x4& v) {
-    if (NT) __builtin_nontemporal_store(v, (GGRS_GLOBAL u32x4*)(base + lo));
-    else *(GGRS_GLOBAL u32x4*)(base + lo) = v;
-}
-
-// RESTL: EXACT number of untouched rows (the stress_test world: 7) -- a Save's body is then one straight-line block.
-// ILV 0: a Save = one burst of row stores + the eight hash chains scheduled by the compiler, odd waves hashing first;
-// ILV 1: the same instructions with one store placed after every ~1/15th of the hash VALU work (sched_group_barrier).
-template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int ILV>
-__global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
-    __shared__ uint64_t acc[MAX_TICK_SAVES * 3];      // this workgroup's partials: [save][T, V, count]
-    __shared__ uint32_t s_last;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
-    __syncthreads();
-
-    const uint32_t sh = (lane & 15u) * 4;
-    const uint32_t n_waves = gridDim.x * 4u;
-    for (uint32_t gw = blockIdx.x * 4u + wave_in_wg; gw < a.n_units; gw += n_waves) {       // gw: 256-slot unit
-        const uint32_t t = gw >> 2, wave = gw & 3u;                   // its tile, and which quarter of it
-        const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
-        const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
-        const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;   // first of this lane's 4 slots
-        const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);   // this tile's rows of a 4- / 8-byte column inside a block
-        const uint32_t o4 = tid * 16u;                                // lane offset inside a 4-byte column's tile row
-        // The 8-byte Ttl column: TWO fully contiguous 1 KiB accesses per wave (lane l moves bytes [16 l, 16 l + 16) of each
-        // half of the wave's 2 KiB), not two 16-byte pieces at a 32-byte lane stride -- a streaming (nt) store of half-filled
-        // lines leaves the L2 before its other half arrives.  So lane l owns the Ttl of unit slots {2l, 2l+1, 128+2l, 129+2l}
-        // ("L slots") while it owns translation / velocity of unit slots {4l .. 4l+3}; liveness crosses over by ballot.
-        const uint32_t o8a = wave * 2048u + lane * 16u, o8b = o8a + 1024u;
-        const uint32_t w0 = t * 16u + wave * 4u;                      // first mask word of this wave
-        const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;                 // byte offset of this lane's mask word
-
-        // ---- every load of the unit, back to back
-        const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
-        const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
-        const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
-        const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
-        float4 tx[3], vv[3];
-        ulonglong2 tl[2];
-        u32x4 restv[RESTL > 0 ? RESTL : 1];
-        auto ld16 = [&](const uint8_t* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
-        if (in_len) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
-            { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8a); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
-            { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8b); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
-#pragma unroll
-            for (int j = 0; j < RESTL; ++j) restv[j] = ld16(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
-            tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
-#pragma unroll
-            for (int j = 0; j < RESTL; ++j) restv[j] = u32x4{0, 0, 0, 0};
-        }
-        // presence masks of components the schedule never touches: read once, fanned out to every snapshot (+ live on load)
-        if (lane < 4u * a.n_rest_masks) {
-            const uint32_t m = lane >> 2, mw = lane & 3u;
-            const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
-            const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
-            for (uint32_t k = 0; k < a.n_saves; ++k)
-                if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-            if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
-        }
-
-        uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
-        const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu;
-        // liveness / Ttl presence of this lane's four L slots: words l >> 5 and 2 + (l >> 5) of the wave's four mask words
-        // (lanes 0, 16, 32, 48 hold them), bit pair 2 (l & 31)
-        auto word_of = [&](uint64_t v, int k) -> uint64_t {
-            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * k);
-        };
-        const uint32_t shL = 2u * (lane & 31u);
-        auto l_bits = [&](uint64_t v) -> uint32_t {
-            const uint64_t lo = lane < 32 ? word_of(v, 0) : word_of(v, 1), hi = lane < 32 ? word_of(v, 2) : word_of(v, 3);
-            return ((uint32_t)(lo >> shL) & 3u) | (((uint32_t)(hi >> shL) & 3u) << 2);
-        };
-        uint32_t aliveL = l_bits(alive_w);
-        const uint32_t presL = l_bits(pL_w);
-
-        // diffuse(K0 ^ order), order == slot (RollbackOrdered::order): shared by both components and all Saves
-        uint64_t ordB[4];
-        if (CKS_T || CKS_V) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
-        }
-        // one SeaHash chain: component_checksum.rs:81-90 for slot j of this lane (5 diffuses; the 8 chains of a Save are independent)
-        auto chainT = [&](int j) -> uint64_t {
-            const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
-                                                                __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
-                                                                __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
-            return (((alive4 & n_T) >> j) & 1u) ? h : 0ULL;
-        };
-        auto chainV = [&](int j) -> uint64_t {
-            const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
-                                                                __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
-                                                                __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
-            return (((alive4 & n_V) >> j) & 1u) ? h : 0ULL;
-        };
-        const bool hash_first = (wave & 1u) != 0;                     // wave-uniform (see k_tick)
-
-        // every load issued above has to land before the first op anyway; saying so explicitly keeps the op loop free of
-        // conservative vmcnt waits (gfx9 counts stores in vmcnt too: such a wait would drain the snapshot stores in flight)
-        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0) expcnt(7) lgkmcnt(15)
-
-        uint32_t si = 0, sj = 0;
-        for (uint32_t i = 0; i < a.n_ops; ++i) {
-            if (!((a.op_bits >> i) & 1ULL)) {
-                // ---------------- SaveWorld: snapshot (component_snapshot.rs:66-84, entity.rs:39-51) + per-entity checksum half
-                uint8_t* dst = a.save_dst[si];
-                const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
-                               b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
-                const uint32_t cnt = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-                uint64_t hT = 0, hV = 0;
-                auto hash_all = [&]() {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { if (CKS_T) hT ^= chainT(j); if (CKS_V) hV ^= chainV(j); }
-                };
-                if (dst && in_len) {
-                    if (ILV == 0) {
-                        if (hash_first) hash_all();
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, tx[k]);
-                            st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, vv[k]);
-                        }
-                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, tl[0]);
-                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, tl[1]);
-#pragma unroll
-                        for (int j = 0; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                        if (!hash_first) hash_all();
-                    } else {
-                        // four pieces: ~4 row stores, then the two chains of one slot (T_j, V_j: enough independent multiplies
-                        // to keep the VALU issue-bound), pinned in this order
-                        st16<NT>(sgpr_base(dst + a.off_t[0] + toff), o4, tx[0]); st16<NT>(sgpr_base(dst + a.off_t[1] + toff), o4, tx[1]);
-                        st16<NT>(sgpr_base(dst + a.off_t[2] + toff), o4, tx[2]); st16<NT>(sgpr_base(dst + a.off_v[0] + toff), o4, vv[0]);
-                        if (CKS_T) hT ^= chainT(0);
-                        if (CKS_V) hV ^= chainV(0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        st16<NT>(sgpr_base(dst + a.off_v[1] + toff), o4, vv[1]); st16<NT>(sgpr_base(dst + a.off_v[2] + toff), o4, vv[2]);
-                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, tl[0]); st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, tl[1]);
-                        if (CKS_T) hT ^= chainT(1);
-                        if (CKS_V) hV ^= chainV(1);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < (RESTL + 1) / 2; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                        if (CKS_T) hT ^= chainT(2);
-                        if (CKS_V) hV ^= chainV(2);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = (RESTL + 1) / 2; j < RESTL; ++j) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                        if (CKS_T) hT ^= chainT(3);
-                        if (CKS_V) hV ^= chainV(3);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-                    hash_all();
-                }
-                if (dst) {
-                    uint64_t mine = 0;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
-                                            (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
-                        if (lane == (uint32_t)w) mine = nw;
-                    }
-                    if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mine);
-                    if ((lane & 15u) == 0) {
-                        st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
-                        st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
-                        st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
-                    }
-                    if (gw == 0 && lane == 0) {
-                        Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0;
-                        h.checksum[0] = 0; h.checksum[1] = 0;
-                        *reinterpret_cast<Header*>(dst) = h;
-                    }
-                }
-                // this wave's partials of the Save -> the workgroup's LDS accumulators (fire-and-forget LDS atomics)
-                if (CKS_T) hT = wave_xor(hT);
-                if (CKS_V) hV = wave_xor(hV);
-                if (lane == 0) {
-                    if (CKS_T) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 0]), (unsigned long long)hT);
-                    if (CKS_V) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 1]), (unsigned long long)hV);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 2]), (unsigned long long)cnt);
-                }
-                ++si;
-            } else {
-                // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
-                const float dt = __uint_as_float(a.dt_bits[sj]);
-                ++sj;
-                const uint32_t m_upd = alive4 & n_T & n_V;     // Query<(&mut Transform, &mut Velocity)>
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float gd = __fmul_rn(a.g[k], dt);    // gravity * time_step
-                    float* x = reinterpret_cast<float*>(&tx[k]);
-                    float* v = reinterpret_cast<float*>(&vv[k]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool on = (m_upd >> j) & 1u;
-                        const float nv = __fadd_rn(v[j], gd);                     // **velocity += ...
-                        const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));      // translation += **velocity * time_step
-                        v[j] = on ? nv : v[j];
-                        x[j] = on ? nx : x[j];
-                    }
-                }
-                const uint32_t m_ttl = aliveL & presL;         // Query<(Entity, &mut Ttl)>, over this lane's L slots
-                uint32_t killL = 0;
-                uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool on = (m_ttl >> j) & 1u;
-                    const uint64_t nq = q[j] - 1;              // usize, wrapping
-                    q[j] = on ? nq : q[j];
-                    killL |= (on && nq == 0) ? (1u << j) : 0u;
-                }
-                aliveL &= ~killL;                              // despawn is deferred to the end of the frame
-                // the kills, seen from the lanes that own the same slots' translation / velocity: unit slot 4m + i lives in
-                // L lane (2m + (i >> 1)) & 63, L index (i & 1) for m < 32 and 2 + (i & 1) for m >= 32
-                const uint64_t k0 = __ballot((killL >> 0) & 1u), k1 = __ballot((killL >> 1) & 1u),
-                               k2 = __ballot((killL >> 2) & 1u), k3 = __ballot((killL >> 3) & 1u);
-                if ((k0 | k1 | k2 | k3) != 0) {                // wave-uniform
-                    const uint64_t ka = lane < 32 ? k0 : k2, kb = lane < 32 ? k1 : k3;
-                    const uint32_t pa = (uint32_t)(ka >> shL) & 3u, pb = (uint32_t)(kb >> shL) & 3u;
-                    const uint32_t kill4 = (pa & 1u) | ((pb & 1u) << 1) | ((pa >> 1) << 2) | ((pb >> 1) << 3);
-                    alive4 &= ~kill4;
-                }
-            }
-        }
-
-        // ---- the live block, written once
-        if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
-            if (in_len) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    st16<false>(sgpr_base(a.live + a.off_t[k] + toff), o4, tx[k]);
-                    st16<false>(sgpr_base(a.live + a.off_v[k] + toff), o4, vv[k]);
-                }
-                st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8a, tl[0]);
-                st16<false>(sgpr_base(a.live + a.off_ttl + toff8), o8b, tl[1]);
-                if (!a.src_is_live) {
-#pragma unroll
-                    for (int j = 0; j < RESTL; ++j) st16<false>(sgpr_base(a.live + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                }
-            }
-            const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
-                           b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
-            uint64_t mine = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
-                                    (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
-                if (lane == (uint32_t)w) mine = nw;
-            }
-            if (lane < 4) st8(sgpr_base(a.live + a.off_alive) + (w0 + lane) * 8u, mine);
-            if (!a.src_is_live && (lane & 15u) == 0) {
-                st8(sgpr_base(a.live + a.off_pT) + wi8, pT_w);
-                st8(sgpr_base(a.live + a.off_pV) + wi8, pV_w);
-                st8(sgpr_base(a.live + a.off_pL) + wi8, pL_w);
-            }
-        }
-    }
-
-    tick_fold<TPB>(a.fold, a.n_saves, a.len, acc, &s_last);
-}
+static_assert(sizeof(Tick3Args) <= 1024, "keep the kernel argument block small: it is re-sent every tick");
 
 // ------------------------------------------------------------------ k_tick3 (wave-specialised fused request group)
 // k_tick2's remaining cost over the memory system's floor for this traffic (scripts/ubench3.hip: ~95-99 us of stores
@@ -1125,11 +459,12 @@ __global__ __launch_bounds__(TPB) void k_tick2(Tick2Args a) {
 // soon as the rows are in its registers, i.e. BEFORE it starts issuing the (blocking) global stores.
 // RESTL / EXACT: the store waves keep up to RESTL untouched 4-byte rows in registers; EXACT: the world has exactly RESTL of
 // them (the stress_test: 7) and the row loops are straight-line code, else every row is guarded by `j < n_rest_rows`.
-template <bool CKS_T, bool CKS_V, bool NT, int RESTL, int PAIRSYNC, bool EXACT = true>
-__global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
+template <bool CKS_T, bool CKS_V, int RESTL, bool EXACT = true>
+__global__ __launch_bounds__(512, 4) void k_tick3(Tick3Args a) {
+    constexpr bool NT = true;                                            // snapshot stores are non-temporal: written once, read a tick later
     __shared__ __attribute__((aligned(16))) u32x4 rowbuf[2][4][8][64];   // [parity][quarter][row][lane]: 64 KiB
     __shared__ uint64_t maskbuf[2][4][4];                                  // the quarter's 4 liveness words per Save
-    __shared__ uint32_t full[4][2];                                        // PAIRSYNC: slot state of pair q (0 free, 1 filled)
+    __shared__ uint32_t full[4][2];                                        // slot state of pair q (0 free, 1 filled)
     __shared__ uint64_t acc[MAX_TICK_SAVES * 3];
     __shared__ uint32_t s_last;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1180,7 +515,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
 #pragma unroll
             for (int j = 0; j < RESTL; ++j) {
                 restv[j] = u32x4{0, 0, 0, 0};
-                if (in_len && (EXACT || (uint32_t)j < a.n_rest_rows)) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
+                if (in_len && (EXACT || (uint32_t)j < a.n_rest_rows) && ((a.rest_load >> j) & 1u)) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
             }
             if (lane < 4u * a.n_rest_masks) {                         // untouched presence masks: fan out (+ live on load)
                 const uint32_t m = lane >> 2, mw = lane & 3u;
@@ -1191,31 +526,33 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                 if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);                       // the loads have landed: the op loop stays free of vmcnt waits
-            auto put = [&](uint8_t* dst, bool snapshot, bool with_rest, bool with_presence, int32_t frame) {
+            auto put = [&](uint8_t* dst, bool snapshot, bool with_sched, uint32_t rest_bits, bool with_presence, int32_t frame) {
                 // rows of this quarter: 8 from LDS, RESTL from registers
-                if (PAIRSYNC) flag_wait(wave, par, 1u);
+                flag_wait(wave, par, 1u);
                 u32x4 h[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) h[r] = rowbuf[par][wave][r][lane];
                 const uint64_t mw = lane < 4 ? maskbuf[par][wave][lane] : 0ULL;
-                if (PAIRSYNC) flag_set(wave, par, 0u);                 // rows are in registers: the compute wave may refill the slot
+                flag_set(wave, par, 0u);                               // rows are in registers: the compute wave may refill the slot
                 if (in_len) {
                     if (snapshot) {
+                        if (with_sched) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
                         st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
                         st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
+                        }
 #pragma unroll
-                        for (int j = 0; j < RESTL; ++j) if (EXACT || (uint32_t)j < a.n_rest_rows) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
+                        for (int j = 0; j < RESTL; ++j) if ((rest_bits >> j) & 1u) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
                     } else {
+                        if (with_sched) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { st16<false>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<false>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
                         st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
                         st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
-                        if (with_rest) {
-#pragma unroll
-                            for (int j = 0; j < RESTL; ++j) if (EXACT || (uint32_t)j < a.n_rest_rows) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
                         }
+#pragma unroll
+                        for (int j = 0; j < RESTL; ++j) if ((rest_bits >> j) & 1u) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
                     }
                 }
                 if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mw);
@@ -1233,10 +570,10 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
             for (uint32_t i = 0; i < a.n_ops; ++i) {
                 if ((a.op_bits >> i) & 1ULL) continue;                // Advance: nothing to store
                 uint8_t* dst = a.save_dst[si];
-                if (dst) { if (!PAIRSYNC) lds_barrier(); put(dst, true, true, true, a.save_frame[si]); par ^= 1u; }
+                if (dst) { put(dst, true, (a.sched_store >> si) & 1u, a.rest_store[si], true, a.save_frame[si]); par ^= 1u; }
                 ++si;
             }
-            if ((!a.src_is_live || a.n_steps) && !a.skip_live) { if (!PAIRSYNC) lds_barrier(); put(a.live, false, !a.src_is_live, !a.src_is_live, 0); par ^= 1u; }
+            if ((!a.src_is_live || a.n_steps) && !a.skip_live) { put(a.live, false, a.sched_live != 0, a.rest_live, !a.src_is_live, 0); par ^= 1u; }
         } else {
             // ================================================= COMPUTE waves
             const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
@@ -1286,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
             };
             // the quarter's rows + rebuilt liveness words -> LDS[par]; the barrier hands them to the paired store wave
             auto hand_off = [&]() {
-                if (PAIRSYNC) flag_wait(wave, par, 0u);
+                flag_wait(wave, par, 0u);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { rowbuf[par][wave][k][lane] = reinterpret_cast<const u32x4&>(tx[k]); rowbuf[par][wave][3 + k][lane] = reinterpret_cast<const u32x4&>(vv[k]); }
                 rowbuf[par][wave][6][lane] = reinterpret_cast<const u32x4&>(tl[0]);
@@ -1301,7 +638,7 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
                     if (lane == (uint32_t)w) mine = nw;
                 }
                 if (lane < 4) maskbuf[par][wave][lane] = mine;
-                if (PAIRSYNC) flag_set(wave, par, 1u); else lds_barrier();
+                flag_set(wave, par, 1u);
                 par ^= 1u;
                 return (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
             };
@@ -1371,244 +708,8 @@ __global__ __launch_bounds__(512, 4) void k_tick3(Tick2Args a) {
     tick_fold<512>(a.fold, a.n_saves, a.len, acc, &s_last);
 }
 
-// ------------------------------------------------------------------ k_tick1 (one slot per lane)
-// The same fused request group with a 256-slot tile: one slot per lane, one wave == one 64-bit mask
-// word (the wave's __ballot IS the liveness word).  Four times as many, four times lighter
-// workgroups: small worlds (10k..100k entities: BASELINE configs 2, 4, 5) fill the 256 CUs instead
-// of leaving most of them idle behind a few long-running 1024-slot tiles, ~60 VGPRs give 8 waves/SIMD,
-// and with more workgroups than residency slots the read phase of late tiles overlaps the store phase
-// of early ones.  Accesses are 4 B (8 B for u64 columns) per lane: 256 B per wave instruction.
-//
-// DP ("depth-parallel", grid.z = roles): a tick of a small world is ONE dependent chain per lane -- load, 9 steps, 8 hashes,
-// 8 store bursts, ~2500 instructions at one wave per SIMD, ~12 us however few entities there are.  The steps are a handful
-// of flops; the hashes and stores are the chain.  The group's outputs are its Saves plus the live world; workgroup (t, z)
-// REPLAYS the steps and produces only outputs [z*dp_s, (z+1)*dp_s): dp_s = 1 gives nine times the workgroups, each a sixth of
-// the chain.  Same operations in the same order per slot, so the same bits.  Every role reads the source block and writes
-// different blocks: valid only when the source is none of the destinations (the host checks; a group that starts with
-// LoadWorld -- every SyncTest tick, every rollback -- qualifies).
-constexpr int TILE1 = 256;
-template <bool CKS_T, bool CKS_V, bool NT, bool DP = false>
-__global__ __launch_bounds__(TPB) void k_tick1(TickArgs a) {
-    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
-    const uint32_t o_first = DP ? blockIdx.z * a.dp_s : 0u;         // DP: this workgroup's outputs; output n_saves is the live world
-    const uint32_t o_last = DP ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;
-    if (DP && o_first == a.n_saves && !writes_live) return;         // a role with nothing to write
-    // Small worlds are latency-bound, and every dynamically indexed kernel argument (save_dst[si], dt_bits[sj], rest[r]
-    // ...) is a dependent scalar load that misses the scalar cache on its first touch.  One vector load per lane
-    // stages the whole argument block in LDS; the op loop then reads it with ds_read (an order of magnitude closer).
-    __shared__ __attribute__((aligned(16))) TickArgs sa;
-    static_assert(sizeof(TickArgs) % 16 == 0 && sizeof(TickArgs) <= TPB * 16, "one 16-byte piece per lane");
-    if (tid < sizeof(TickArgs) / 16) reinterpret_cast<u32x4*>(&sa)[tid] = reinterpret_cast<const u32x4*>(&a)[tid];
-    __syncthreads();
-    auto uni64 = [](uint64_t v) -> uint64_t {                      // a uniform value read through LDS, back into SGPRs
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    };
-    const bool in_len = (uint64_t)t * TILE1 < a.len;              // workgroup-uniform
-    const uint32_t e = t * TILE1 + tid;                           // this lane's slot
-    const uint64_t toff = wtile_off(t >> 2, a.ts, 4), toff8 = wtile_off(t >> 2, a.ts, 8);   // its 1024-slot tile's rows of a 4- / 8-byte column
-    const uint32_t ti = (t & 3u) * TILE1 + tid;                   // its index inside that tile
-    const uint32_t o4 = ti * 4u, o8 = ti * 8u;
-    const uint32_t wi8 = (t * 4u + wave) * 8u;                    // this wave's mask word
-
-    const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
-    const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
-    const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
-    const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
-    float tx[3] = {0, 0, 0}, vv[3] = {0, 0, 0};
-    uint64_t ttl = 0;
-    if (in_len) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tx[k] = *reinterpret_cast<const float*>(a.src + a.off_t[k] + toff + o4);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = *reinterpret_cast<const float*>(a.src + a.off_v[k] + toff + o4);
-        ttl = *reinterpret_cast<const uint64_t*>(a.src + a.off_ttl + toff8 + o8);
-    }
-
-    // ---- state the schedule never touches: read once, fan out to every snapshot (+ live on load)
-    if (tid < 4u * a.n_rest_masks) {
-        const uint32_t m = tid >> 2, mw = tid & 3u;
-        const uint64_t o = sa.rest_mask_off[m] + ((uint64_t)t * 4 + mw) * 8;
-        const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
-        for (uint32_t k = 0; k < a.n_saves; ++k)
-            if (k >= o_first && k < o_last && a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-        if (o_last == a.n_saves + 1u && !a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
-    }
-    if (in_len && (a.n_saves || !a.src_is_live)) {
-        // rest[] lists 4 KiB rows of 1024-slot tiles; a column is its row with roff == 0.
-        // Up to 8 columns per batch, one wait per batch.
-        const uint32_t n_rows = a.n_rest_rows;
-        uint32_t r = 0;
-        while (r < n_rows) {
-            uint64_t v[8]; uint64_t off[8]; uint32_t wb[8];
-            int nb = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] = 0; off[j] = 0; wb[j] = 0; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                while (r < n_rows && sa.rest[r].roff != 0) ++r;
-                if (r < n_rows) {
-                    const RowLite rd = sa.rest[r]; ++r;
-                    wb[j] = rd.word_bytes; off[j] = rd.col_off; nb = j + 1;
-                    if (wb[j] == 8) v[j] = *reinterpret_cast<const uint64_t*>(a.src + off[j] + toff8 + o8);
-                    else v[j] = *reinterpret_cast<const uint32_t*>(a.src + off[j] + toff + o4);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): land the loads once
-            for (uint32_t k = o_first; k < o_last; ++k) {
-                uint8_t* dst = k < a.n_saves ? a.save_dst[k] : ((a.src_is_live || a.skip_live) ? nullptr : a.live);
-                if (!dst) continue;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < nb) {
-                        if (wb[j] == 8) *reinterpret_cast<uint64_t*>(dst + off[j] + toff8 + o8) = v[j];
-                        else *reinterpret_cast<uint32_t*>(dst + off[j] + toff + o4) = (uint32_t)v[j];
-                    }
-                }
-            }
-        }
-    }
-
-    bool alive = (alive_w >> lane) & 1ULL;
-    const bool has_T = (pT_w >> lane) & 1ULL, has_V = (pV_w >> lane) & 1ULL, has_L = (pL_w >> lane) & 1ULL;
-    uint64_t ordB = 0;
-    if (CKS_T || CKS_V) ordB = sea_order_lane(e);
-
-    uint32_t si = 0, sj = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                           // see k_tick: keep the op loop wait-free
-    for (uint32_t i = 0; i < a.n_ops; ++i) {
-        if (!((a.op_bits >> i) & 1ULL)) {
-            // ---------------- SaveWorld
-            if (DP && si < o_first) { ++si; continue; }           // another workgroup's snapshot
-            uint8_t* dst = reinterpret_cast<uint8_t*>(uni64(reinterpret_cast<uint64_t>(sa.save_dst[si])));
-            const uint64_t alive_now = __ballot(alive);           // == this wave's liveness word
-            if (dst) {
-                if (in_len) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        *reinterpret_cast<float*>(dst + a.off_t[k] + toff + o4) = tx[k];
-                        *reinterpret_cast<float*>(dst + a.off_v[k] + toff + o4) = vv[k];
-                    }
-                    *reinterpret_cast<uint64_t*>(dst + a.off_ttl + toff8 + o8) = ttl;
-                }
-                if (lane == 0) {
-                    *reinterpret_cast<uint64_t*>(dst + a.off_alive + wi8) = alive_now;
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pT + wi8) = pT_w;
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pV + wi8) = pV_w;
-                    *reinterpret_cast<uint64_t*>(dst + a.off_pL + wi8) = pL_w;
-                }
-                if (t == 0 && tid == 0) {
-                    Header h; h.len = a.len; h.frame = sa.save_frame[si]; h.pad0 = 0; h.active = 0;
-                    h.checksum[0] = 0; h.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = h;
-                }
-            }
-            uint64_t hT = 0, hV = 0;
-            if (CKS_T) {
-                const uint64_t h = sea_pair_pre(ordB, sea_inner3(__float_as_uint(tx[0]), __float_as_uint(tx[1]), __float_as_uint(tx[2])));
-                hT = wave_xor((alive && has_T) ? h : 0ULL);
-            }
-            if (CKS_V) {
-                const uint64_t h = sea_pair_pre(ordB, sea_inner3(__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2])));
-                hV = wave_xor((alive && has_V) ? h : 0ULL);
-            }
-            if (lane == 0) {
-                // per-wave partials, folded by k_tick_finalize.  In-kernel folds LOSE at these sizes: one last workgroup
-                // (tick_fold) has no long store drain to hide its ticket + acquire + gather behind (10 k: 25.5 vs 23.5 us,
-                // 300 k: 59 vs 47 us per tick), and a ticket per depth-parallel role serialises hundreds of short workgroups on
-                // one agent-scope atomic (profiles/r02dp/ab3.txt: 30 k 23.1 vs 17.4 us, 100 k 32.5 vs 25.3 us).
-                // blockIdx.y: member of a batch of identical checksum-only groups (speculative branches off one snapshot)
-                uint64_t* p = a.parts + ((uint64_t)blockIdx.y * a.n_saves + si) * 3 * a.part_stride + (uint64_t)t * 4 + wave;
-                p[0] = hT; p[a.part_stride] = hV; p[2 * (uint64_t)a.part_stride] = (uint64_t)__popcll(alive_now);
-            }
-            ++si;
-            if (DP && si == o_last) return;                       // this workgroup's snapshots are out (the live world is another role's)
-        } else {
-            // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
-            const float dt = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)sa.dt_bits[sj]));
-            ++sj;
-            const bool upd = alive && has_T && has_V, tt = alive && has_L;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float gd = __fmul_rn(a.g[k], dt);
-                const float nv = __fadd_rn(vv[k], gd);
-                const float nx = __fadd_rn(tx[k], __fmul_rn(nv, dt));
-                vv[k] = upd ? nv : vv[k];
-                tx[k] = upd ? nx : tx[k];
-            }
-            const uint64_t nq = ttl - 1;                          // usize, wrapping
-            ttl = tt ? nq : ttl;
-            alive = alive && !(tt && nq == 0);                    // despawn is deferred to the end of the frame
-        }
-    }
-
-    if ((!a.src_is_live || a.n_steps) && !a.skip_live) {
-        if (in_len) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                *reinterpret_cast<float*>(a.live + a.off_t[k] + toff + o4) = tx[k];
-                *reinterpret_cast<float*>(a.live + a.off_v[k] + toff + o4) = vv[k];
-            }
-            *reinterpret_cast<uint64_t*>(a.live + a.off_ttl + toff8 + o8) = ttl;
-        }
-        const uint64_t alive_now = __ballot(alive);
-        if (lane == 0) {
-            *reinterpret_cast<uint64_t*>(a.live + a.off_alive + wi8) = alive_now;
-            if (!a.src_is_live) {
-                *reinterpret_cast<uint64_t*>(a.live + a.off_pT + wi8) = pT_w;
-                *reinterpret_cast<uint64_t*>(a.live + a.off_pV + wi8) = pV_w;
-                *reinterpret_cast<uint64_t*>(a.live + a.off_pL + wi8) = pL_w;
-            }
-        }
-    }
-}
-
-// Folds the per-wave partials of every Save of a fused group: one 1024-thread workgroup per Save.
-// component_checksum.rs:92-95 (hash the XOR once more), entity_checksum.rs:29-52,
-// checksum.rs:88-99 (XOR of all parts; upper 64 bits of the u128 are always 0).
-struct TickFinArgs {
-    const uint64_t* parts; uint32_t part_stride, n_parts, cks_T, cks_V;
-    uint64_t total_len;
-    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
-};
 constexpr int FIN_TPB = 1024;
-__global__ __launch_bounds__(FIN_TPB) void k_tick_finalize(TickFinArgs f) {
-    const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t* pT = f.parts + (uint64_t)k * 3 * f.part_stride;
-    const uint64_t* pV = pT + f.part_stride;
-    const uint64_t* pC = pV + f.part_stride;
-    uint64_t xT = 0, xV = 0, sum = 0;
-    // 4 independent strided loads per array per trip: the partials sit in other XCDs' L2 / HBM, so the
-    // fold is latency-bound unless every load of a thread is in flight at once
-    for (uint32_t i0 = tid; i0 < f.n_parts; i0 += 4 * FIN_TPB) {
-        uint64_t t[4], v[4], c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + u * FIN_TPB;
-            const bool in = i < f.n_parts;
-            const uint32_t ii = in ? i : i0;
-            t[u] = pT[ii]; v[u] = pV[ii]; c[u] = pC[ii];
-            if (!in) { t[u] = 0; v[u] = 0; c[u] = 0; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { xT ^= t[u]; xV ^= v[u]; sum += c[u]; }
-    }
-    xT = wave_xor(xT); xV = wave_xor(xV);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    __shared__ uint64_t s[3][FIN_TPB / 64];
-    if (lane == 0) { s[0][wave] = xT; s[1][wave] = xV; s[2][wave] = sum; }
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t aT = 0, aV = 0, active = 0;
-        for (int w = 0; w < FIN_TPB / 64; ++w) { aT ^= s[0][w]; aV ^= s[1][w]; active += s[2][w]; }
-        uint64_t total = 0;
-        if (f.cks_T) total ^= sea_one(aT);
-        if (f.cks_V) total ^= sea_one(aV);
-        total ^= sea_pair(active, f.total_len);
-        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
-    }
-}
+constexpr int GEN_MAX_CKS = 16;
 
 // ------------------------------------------------------------------ k_checksum (generic)
 // ComponentChecksumPlugin::update (component_checksum.rs:67-108) for any registered spec,
@@ -1633,7 +734,10 @@ __global__ __launch_bounds__(TPB) void k_checksum(CksArgs a, const UnitDesc* __r
 #pragma unroll 1
             for (uint32_t u = 0; u < n; ++u) {
                 const UnitDesc ud = units[ub + u];
-                s.unit(*reinterpret_cast<const uint32_t*>(a.state + col_at(ud.off, ud.ts, ud.stride, e)));
+                const uint8_t* p = a.state + col_at(ud.off, ud.ts, ud.wb, e);
+                const uint64_t v = ud.wb == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(p) : (ud.wb == 8 ? *reinterpret_cast<const uint64_t*>(p)
+                                 : (ud.wb == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(p) : (uint64_t)*p));
+                s.write(v, ud.wb);
             }
             h ^= sea_pair(e, s.finish());
         }
@@ -1827,8 +931,11 @@ __global__ __launch_bounds__(TPB) void k_fill_col(uint8_t* state, uint64_t col_o
                                                   uint64_t first, uint64_t count, uint64_t value) {
     const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= count) return;
-    if (word_bytes == 4) *reinterpret_cast<uint32_t*>(state + col_at(col_off, ts, 4, first + i)) = (uint32_t)value;
-    else *reinterpret_cast<uint64_t*>(state + col_at(col_off, ts, 8, first + i)) = value;
+    uint8_t* p = state + col_at(col_off, ts, word_bytes, first + i);
+    if (word_bytes == 4) *reinterpret_cast<uint32_t*>(p) = (uint32_t)value;
+    else if (word_bytes == 8) *reinterpret_cast<uint64_t*>(p) = value;
+    else if (word_bytes == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)value;
+    else *p = (uint8_t)value;
 }
 // spawn_particles (particles.rs:258-270) payload: Velocity(vx, vy, 0.0), Ttl(ttl); Transform gets
 // its default through k_fill_col.  Also emits checksum partials for the new rows so a fused
@@ -1872,350 +979,7 @@ __global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ k_tick_gen (generic fused request group)
-// The same request-group fusion as k_tick for ANY mix of the kernel-backed systems (box_game, add_u32, the Health
-// scenario of tests/synctest.rs, particles with extra checksum specs ...): a workgroup stages the `sub` slots it
-// owns -- every registered word and every mask -- in LDS (tile-major columns make that `n_words` contiguous global
-// spans), replays the ops of the group on the LDS image (Save = LDS -> ring slot + generic checksum partials,
-// Advance = each registered system in order over the LDS columns) and writes the live block once at the end.
-// One launch per group instead of one per request: an 18-request tick of a small world is 2 launches.
-// despawn_rollback systems are covered too: the live-only RollbackDespawned markers of the slots are staged in LDS and
-// DespawnConfirmed runs in-kernel before each step.  Not covered (one launch per request): worlds whose words do not
-// fit 64 KiB of LDS at 256 slots per workgroup.
-constexpr int GEN_MAX_SYS = 16, GEN_MAX_CKS = 16;
-// LDS image of a workgroup: the registered word columns in tile order, each `sub` slots long -- a word whose
-// preceding words take `pso` bytes per slot starts at byte pso * sub -- then the masks ([n_masks][sub / 64] u64).
-struct GenWord { uint32_t tcol, wb, pso, pad; };      // offset inside a tile, word bytes, bytes per slot before it
-struct GenUnit { uint32_t pso, add, stride, pad; };   // u32 checksum unit of slot i: pso * sub + add + i * stride
-struct GenSys {
-    uint32_t kind;
-    uint32_t pso[6];          // per-slot byte offsets (GenWord::pso) of the words the system touches (t.x t.y t.z v.x v.y v.z | word)
-    uint32_t pmask[3];        // mask index of each component's presence mask; ~0u: live-only component
-    uint32_t pso_h, side_ts;  // BOX_MOVE: Player.handle in LDS (rollback component) or in the live block (live-only)
-    uint32_t pad;
-    uint64_t side_off;        // live-only column the system reads from the live block (BOX_MOVE: Player.handle)
-    uint64_t side_pmask_off;  // and its presence mask
-    int64_t iparam[2];
-    float fparam[4];
-};
-struct GenArgs {
-    const uint8_t* src; uint8_t* live;
-    uint8_t* save_dst[MAX_TICK_SAVES]; int32_t save_frame[MAX_TICK_SAVES];
-    uint32_t dt_bits[MAX_TICK_STEPS]; uint32_t aux_bits[MAX_TICK_STEPS];      // aux: FRICTION.powf(dt) of BOX_MOVE (host libm)
-    uint8_t inputs[MAX_TICK_STEPS][16]; uint8_t n_inputs[MAX_TICK_STEPS];
-    // RollbackDespawned markers (snapshot/despawn.rs), staged only for worlds with a despawn_rollback system:
-    int32_t step_frame[MAX_TICK_STEPS], step_confirmed[MAX_TICK_STEPS];
-    uint8_t step_flags[MAX_TICK_STEPS];            // bit 0: DespawnConfirmed runs before this step; bit 1: its frame is unconfirmed (despawns are deferred)
-    uint32_t marks, pad_m; DespawnMarks dm;
-    uint64_t op_bits; uint32_t n_ops, n_saves, n_steps, src_is_live;
-    uint32_t skip_live, dp_s;                          // skip_live: see TickArgs; dp_s: depth-parallel roles (k_tick1's DP), 0 = off
-    uint64_t len, cols_base;
-    uint32_t ts, sub, n_words, n_masks, n_units, n_sys, n_cks, part_stride;
-    uint64_t mask_off[MAX_MASKS];
-    const GenWord* words; const GenUnit* units;
-    uint32_t cks_pmask[GEN_MAX_CKS], cks_unit_base[GEN_MAX_CKS], cks_n_units[GEN_MAX_CKS];   // pmask: mask index
-    uint64_t* parts;                                   // [n_saves][n_cks + 1][part_stride], one entry per wave; last = live count
-    GenSys sys[GEN_MAX_SYS];
-};
-static_assert(sizeof(GenArgs) <= 4096, "kernel argument segment limit");
-
-
-// 512-thread workgroups, wave-specialised like k_tick3: waves 0-3 (COMPUTE) hash and step the LDS image, waves 4-7 (STORE)
-// own every transfer LDS image -> global.  At a Save: barrier A (the image is stable) -> the store waves pull the whole image
-// (<= 64 KiB = 16 chunks of 16 B per lane) and the masks into registers while the compute waves hash it -> barrier B (the
-// image may change again) -> the store waves stream it to the ring slot, blocking on the store queue for as long as it
-// takes, while the compute waves run the next Advance.
-constexpr int GEN_TPB = 512;
-__global__ __launch_bounds__(GEN_TPB, 4) void k_tick_gen(GenArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const bool store_role = threadIdx.x >= (uint32_t)TPB;             // wave-uniform
-    const uint32_t tid = threadIdx.x & (TPB - 1u), lane = tid & 63u, wave = tid >> 6;   // index inside the role
-    const uint32_t sub = a.sub, mw = sub >> 6;                        // slots / mask words per workgroup
-    const uint64_t s0 = (uint64_t)blockIdx.x * sub;                   // first slot of this workgroup
-    const uint64_t tbase = a.cols_base + (s0 >> LT_SHIFT) * a.ts;     // its layout tile inside a block
-    const uint32_t in_tile = (uint32_t)(s0 & (uint64_t)(LAYOUT_TILE - 1));
-    const bool in_len = s0 < a.len;                                   // workgroup-uniform
-    // depth-parallel roles (see k_tick1): workgroup (x, y) replays the steps and produces only outputs [y*dp_s, (y+1)*dp_s)
-    // of the group (its Saves in order, then the live world).  dp_s == 0: one workgroup produces everything.
-    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
-    const uint32_t o_first = a.dp_s ? blockIdx.y * a.dp_s : 0u;
-    const uint32_t o_last = a.dp_s ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;
-    const bool my_live = o_last == a.n_saves + 1u;
-    if (a.dp_s && o_first == a.n_saves && !writes_live) return;        // a role with nothing to write
-    const uint32_t n_rows = a.ts >> (LT_SHIFT + 2);                   // 4-byte row units per slot (8-byte words = 2)
-    const uint32_t img = n_rows * sub * 4u;                           // bytes of the word image
-    uint64_t* lmask = reinterpret_cast<uint64_t*>(lds + img);         // [n_masks][mw] behind the words; mask 0 = liveness
-    // small tables staged once: global offset of every row unit of this workgroup, the checksum units
-    uint32_t* grow = reinterpret_cast<uint32_t*>(lds + img + a.n_masks * mw * 8u);   // [n_rows] byte offset inside the tile
-    GenUnit* lunits = reinterpret_cast<GenUnit*>(grow + ((n_rows + 3u) & ~3u));      // [n_units]
-    for (uint32_t w = threadIdx.x; w < a.n_words; w += GEN_TPB) {
-        const GenWord gw = a.words[w];
-        const uint32_t r0 = gw.pso >> 2;
-        grow[r0] = gw.tcol + in_tile * gw.wb;
-        if (gw.wb == 8) grow[r0 + 1] = gw.tcol + in_tile * 8u + sub * 4u;      // second half of the contiguous sub x 8 bytes
-    }
-    for (uint32_t u = threadIdx.x; u < a.n_units; u += GEN_TPB) lunits[u] = a.units[u];
-    // live-only RollbackDespawned markers of these slots: disabled bits + the frame each was despawned on.  Not part of
-    // any snapshot; LoadWorld's resurrect pass (k_load_reconcile) has already run on the live copy (stream order).
-    uint64_t* ldis = reinterpret_cast<uint64_t*>(lunits + a.n_units);                 // [mw]
-    int32_t* ldf = reinterpret_cast<int32_t*>(ldis + mw);                             // [sub]
-    if (a.marks) {
-        for (uint32_t m = threadIdx.x; m < mw; m += GEN_TPB) ldis[m] = *reinterpret_cast<const uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8);
-        for (uint32_t i = threadIdx.x; i < sub; i += GEN_TPB) ldf[i] = *reinterpret_cast<const int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4);
-    }
-    __syncthreads();
-
-    // LDS image <-> one state block: 16-byte chunks, chunk c lives at LDS byte c * 16 and belongs to row c >> row_shift
-    // (sub is 256 / 512 / 1024: a row is 64 / 128 / 256 chunks -- shifts, not the divisions of round 1), 8 chunks in flight
-    // per lane.  Snapshot stores are non-temporal like k_tick3's: the ring is written once and read a whole tick later.
-    const uint32_t n_chunks = img >> 4;
-    const uint32_t row_shift = sub == 1024u ? 8u : (sub == 512u ? 7u : 6u), row_mask = (1u << row_shift) - 1u;
-    // global -> LDS image, all 512 threads, 8 loads in flight per lane
-    auto stage_in = [&](const uint8_t* block) {
-        g_u8* gb = sgpr_base(block + tbase);
-        for (uint32_t c0 = threadIdx.x; c0 < n_chunks; c0 += 8 * GEN_TPB) {
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t c = c0 + j * GEN_TPB;
-                v[j] = u32x4{0, 0, 0, 0};
-                if (c < n_chunks) v[j] = *(const GGRS_GLOBAL u32x4*)(gb + grow[c >> row_shift] + (c & row_mask) * 16u);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t c = c0 + j * GEN_TPB;
-                if (c < n_chunks) *reinterpret_cast<u32x4*>(lds + c * 16u) = v[j];
-            }
-        }
-        for (uint32_t m = threadIdx.x; m < a.n_masks * mw; m += GEN_TPB)
-            lmask[m] = *reinterpret_cast<const uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8);
-    };
-    // STORE waves: the image (<= 4096 chunks: 16 per lane) and the masks (<= 17 x 16 words: 2 per lane) in registers
-    u32x4 ireg[16]; uint64_t mreg[2];
-    auto image_pull = [&]() {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const uint32_t c = tid + (uint32_t)j * TPB; ireg[j] = c < n_chunks ? *reinterpret_cast<const u32x4*>(lds + c * 16u) : u32x4{0, 0, 0, 0}; }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const uint32_t m = tid + (uint32_t)j * TPB; mreg[j] = m < a.n_masks * mw ? lmask[m] : 0ULL; }
-    };
-    auto image_push = [&](uint8_t* block, bool nt, bool words) {
-        g_u8* gb = sgpr_base(block + tbase);
-        if (words) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t c = tid + (uint32_t)j * TPB;
-                if (c < n_chunks) {
-                    const uint32_t go = grow[c >> row_shift] + (c & row_mask) * 16u;
-                    if (nt) st16<true>(gb, go, ireg[j]); else st16<false>(gb, go, ireg[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t m = tid + (uint32_t)j * TPB;
-            if (m < a.n_masks * mw) *reinterpret_cast<uint64_t*>(block + a.mask_off[m / mw] + ((s0 >> 6) + m % mw) * 8) = mreg[j];
-        }
-    };
-    // ---- stage the workgroup's slots
-    stage_in(a.src);        // (slots beyond len hold whatever the block holds there: their mask bits are zero)
-    __syncthreads();
-
-    if (store_role) {
-        // ================================================= STORE waves: one hand-off per Save with a ring slot + the live write
-        uint32_t si = 0;
-        for (uint32_t op = 0; op < a.n_ops; ++op) {
-            if ((a.op_bits >> op) & 1ULL) continue;
-            if (si < o_first) { ++si; continue; }                     // another role's snapshot
-            if (si >= o_last) break;
-            uint8_t* dst = a.save_dst[si];
-            if (dst) {
-                lds_barrier();                                        // A: the image is stable
-                image_pull();
-                lds_barrier();                                        // B: (pull has landed: lds_barrier waits lgkmcnt(0)) the image may change
-                image_push(dst, true, in_len);
-                if (blockIdx.x == 0 && tid == 0) {
-                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = h;
-                }
-            }
-            ++si;
-        }
-        if (my_live && writes_live) {
-            lds_barrier();
-            image_pull();
-            lds_barrier();
-            image_push(a.live, false, in_len);
-        }
-    } else {
-    // ===================================================== COMPUTE waves
-    // diffuse(K0 ^ order) of the (up to 4) slots this lane hashes: it depends on the slot only, so one value serves every
-    // checksummed component and every Save of the group (as in k_tick)
-    uint64_t ordB[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ordB[q] = sea_order_lane(s0 + tid + (uint32_t)q * TPB);
-
-    uint32_t si = 0, sj = 0;
-    for (uint32_t op = 0; op < a.n_ops; ++op) {
-        if (!((a.op_bits >> op) & 1ULL)) {
-            // ---------------- SaveWorld: snapshot (store waves) + per-entity half of every component checksum (here).
-            // Barrier A hands the stable image to the store waves; the hash below only READS it, so it overlaps their pull;
-            // barrier B (after the hash) lets the next Advance change it.
-            if (si < o_first) { ++si; continue; }                     // another role's snapshot
-            if (si >= o_last) break;                                  // this role's Saves are out (a later role owns the rest)
-            const bool hand_off = a.save_dst[si] != nullptr;
-            if (hand_off) lds_barrier();
-            uint64_t* prow = a.parts + (uint64_t)si * (a.n_cks + 1) * a.part_stride + (uint64_t)blockIdx.x * 4 + wave;
-            for (uint32_t k = 0; k < a.n_cks; ++k) {
-                const uint64_t* pm = lmask + a.cks_pmask[k] * mw;
-                const uint32_t nu = a.cks_n_units[k], ub = a.cks_unit_base[k];
-                uint64_t h = 0;
-                if (nu <= 4u) {
-                    // the common specs (1-4 four-byte units, e.g. translation.xyz): unit addresses hoisted out of the slot
-                    // loop, the (up to 4) slots of a lane hashed as independent chains, dead slots selected away
-                    const uint8_t* ubase[4]; uint32_t ustride[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const GenUnit gu = lunits[ub + ((uint32_t)u < nu ? (uint32_t)u : 0u)];
-                        ubase[u] = lds + gu.pso * sub + gu.add; ustride[u] = gu.stride;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t i = tid + (uint32_t)q * TPB;
-                        if (i < sub) {                                     // workgroup-uniform (sub is 256, 512 or 1024)
-                            const bool on = ((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL;
-                            uint32_t x[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint32_t*>(ubase[u] + i * ustride[u]);
-                            SeaStream st;
-                            st.unit(x[0]);
-                            if (nu > 1u) st.unit(x[1]);
-                            if (nu > 2u) st.unit(x[2]);
-                            if (nu > 3u) st.unit(x[3]);
-                            const uint64_t e = sea_pair_pre(ordB[q], st.finish());
-                            h ^= on ? e : 0ULL;
-                        }
-                    }
-                } else {
-                    for (uint32_t i = tid; i < sub; i += TPB) {
-                        if (((lmask[i >> 6] & pm[i >> 6]) >> (i & 63u)) & 1ULL) {
-                            SeaStream st;
-                            for (uint32_t u = 0; u < nu; ++u) {
-                                const GenUnit gu = lunits[ub + u];
-                                st.unit(*reinterpret_cast<const uint32_t*>(lds + gu.pso * sub + gu.add + i * gu.stride));
-                            }
-                            h ^= sea_pair(s0 + i, st.finish());          // order == slot
-                        }
-                    }
-                }
-                h = wave_xor(h);
-                if (lane == 0) prow[(uint64_t)k * a.part_stride] = h;
-            }
-            uint32_t cnt = 0;
-            for (uint32_t wi = wave; wi < mw; wi += 4) cnt += (uint32_t)__popcll(lmask[wi]);
-            if (lane == 0) prow[(uint64_t)a.n_cks * a.part_stride] = cnt;   // folded by k_gen_finalize (an in-kernel tick_fold measured no gain here: 178 vs 174 us per 1 M tick)
-            if (hand_off) lds_barrier();
-            ++si;
-            if (si >= o_last) break;                                  // (no point stepping an image nobody will read)
-        } else {
-            // ---------------- AdvanceWorld: the registered systems, in order, on the LDS image
-            const float dt = __uint_as_float(a.dt_bits[sj]);
-            const uint32_t sflags = a.step_flags[sj];
-            if (a.marks && (sflags & 1u)) {
-                // AdvanceWorldSystems::DespawnConfirmed (despawn.rs:89-112): marks <= ConfirmedFrameCount are freed for good
-                const int32_t confirmed = a.step_confirmed[sj];
-                for (uint32_t i = tid; i < sub; i += TPB) {
-                    const uint32_t wi = i >> 6;
-                    const uint64_t dw = ldis[wi];
-                    const uint64_t gone = __ballot(((dw >> (i & 63u)) & 1ULL) && ldf[i] <= confirmed);
-                    if (gone && lane == 0) ldis[wi] = dw & ~gone;
-                }
-            }
-            for (uint32_t s = 0; s < a.n_sys; ++s) {
-                const GenSys& y = a.sys[s];
-                const uint64_t* p0 = y.pmask[0] != ~0u ? lmask + y.pmask[0] * mw : lmask;
-                const uint64_t* p1 = y.pmask[1] != ~0u ? lmask + y.pmask[1] * mw : lmask;
-                for (uint32_t i = tid; i < sub; i += TPB) {               // a wave's 64 lanes == one mask word
-                    const uint32_t wi = i >> 6;
-                    const uint64_t alive_w = lmask[wi];
-                    bool kill = false;
-                    switch (y.kind) {
-                    case 1u: {   // GGRS_SYS_PARTICLES_UPDATE (particles.rs:272-280)
-                        if (((alive_w & p0[wi] & p1[wi]) >> (i & 63u)) & 1ULL) {
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                float* x = reinterpret_cast<float*>(lds + y.pso[k] * sub + i * 4u);
-                                float* v = reinterpret_cast<float*>(lds + y.pso[3 + k] * sub + i * 4u);
-                                const float nv = __fadd_rn(*v, __fmul_rn(y.fparam[k], dt));
-                                *v = nv; *x = __fadd_rn(*x, __fmul_rn(nv, dt));
-                            }
-                        }
-                    } break;
-                    case 2u: {   // GGRS_SYS_TTL_DESPAWN (particles.rs:282-289)
-                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
-                            uint64_t* q = reinterpret_cast<uint64_t*>(lds + y.pso[0] * sub + i * 8u);
-                            const uint64_t nq = *q - 1; *q = nq; kill = nq == 0;
-                        }
-                    } break;
-                    case 4u: {   // GGRS_SYS_ADD_U32 (benches/bench.rs:30-46)
-                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
-                            uint32_t* q = reinterpret_cast<uint32_t*>(lds + y.pso[0] * sub + i * 4u);
-                            *q = *q + (uint32_t)y.iparam[0];
-                        }
-                    } break;
-                    case 5u: {   // GGRS_SYS_SAT_SUB_DESPAWN (tests/synctest.rs:37-44): despawn() or despawn_rollback()
-                        if (((alive_w & p0[wi]) >> (i & 63u)) & 1ULL) {
-                            uint32_t* q = reinterpret_cast<uint32_t*>(lds + y.pso[0] * sub + i * 4u);
-                            const uint32_t amount = (uint32_t)y.iparam[0];
-                            const uint32_t v = *q >= amount ? *q - amount : 0u;
-                            *q = v; kill = v == 0;
-                        }
-                        // despawn_rollback() on an unconfirmed frame (despawn.rs:129-137): disabled, marked with the frame
-                        const bool defer = a.marks && y.iparam[1] == 1 && (sflags & 2u);
-                        const uint64_t marked = __ballot(kill && defer);
-                        if (kill && defer) ldf[i] = a.step_frame[sj];
-                        if (marked && lane == 0) ldis[wi] |= marked;
-                    } break;
-                    case 6u: {   // GGRS_SYS_BOX_MOVE (box_game.rs:154-206), arithmetic shared with k_box_move
-                        const uint64_t e = s0 + i;
-                        uint64_t m = alive_w & p0[wi] & p1[wi];
-                        const bool h_lds = y.pmask[2] != ~0u;                // Player registered for rollback: staged in LDS
-                        if (h_lds) m &= lmask[y.pmask[2] * mw + wi];
-                        else m &= *reinterpret_cast<const uint64_t*>(a.live + y.side_pmask_off + (e >> 6) * 8);
-                        if ((m >> (i & 63u)) & 1ULL) {
-                            const uint64_t handle = h_lds ? *reinterpret_cast<const uint64_t*>(lds + y.pso_h * sub + i * 8u)
-                                                          : *reinterpret_cast<const uint64_t*>(a.live + col_at(y.side_off, y.side_ts, 8, e));
-                            if (handle < a.n_inputs[sj]) {
-                                float* px = reinterpret_cast<float*>(lds + y.pso[0] * sub + i * 4u);
-                                float* py = reinterpret_cast<float*>(lds + y.pso[1] * sub + i * 4u);
-                                float* pz = reinterpret_cast<float*>(lds + y.pso[2] * sub + i * 4u);
-                                float* pvx = reinterpret_cast<float*>(lds + y.pso[3] * sub + i * 4u);
-                                float* pvy = reinterpret_cast<float*>(lds + y.pso[4] * sub + i * 4u);
-                                float* pvz = reinterpret_cast<float*>(lds + y.pso[5] * sub + i * 4u);
-                                float x = *px, yy = *py, z = *pz, vx = *pvx, vy = *pvy, vz = *pvz;
-                                box_move_math(x, yy, z, vx, vy, vz, a.inputs[sj][handle], dt, __uint_as_float(a.aux_bits[sj]),
-                                              y.fparam[0], y.fparam[1], y.fparam[3]);
-                                *px = x; *py = yy; *pz = z; *pvx = vx; *pvy = vy; *pvz = vz;
-                            }
-                        }
-                    } break;
-                    default: break;
-                    }
-                    const uint64_t kills = __ballot(kill);
-                    if (kills && lane == 0) lmask[wi] = alive_w & ~kills;   // word wi is only ever read by this wave: no barrier
-                }
-            }
-            ++sj;
-        }
-    }
-    // ---- the live block, written once (by the store waves)
-    if (my_live && writes_live) { lds_barrier(); lds_barrier(); }
-    if (my_live && a.marks && a.n_steps) {
-        for (uint32_t m = tid; m < mw; m += TPB) *reinterpret_cast<uint64_t*>(a.live + a.dm.off_disabled + ((s0 >> 6) + m) * 8) = ldis[m];
-        for (uint32_t i = tid; i < sub; i += TPB) *reinterpret_cast<int32_t*>(a.live + a.dm.off_dframe + (s0 + i) * 4) = ldf[i];
-    }
-    }   // COMPUTE waves
-}
-
+// ------------------------------------------------------------------ k_gen_finalize
 // Fold of k_tick_gen's per-wave partials: one 1024-thread workgroup per Save; any number of checksummed components.
 struct GenFinArgs {
     const uint64_t* parts; uint32_t part_stride, n_parts, n_cks, pad;

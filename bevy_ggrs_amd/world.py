@@ -130,7 +130,7 @@ class WorldBase:
     def download_word(self, comp: int, word: int, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         _, wb, _ = self._comps[comp]
         if count is None: count = self.len - first
-        out = np.empty(count, dtype=np.uint32 if wb == 4 else np.uint64)
+        out = np.empty(count, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[wb])
         if count: self._check(self._fn("download_word")(self._p, comp, word, first, count, _as_c(out)))
         return out
 
@@ -280,14 +280,21 @@ class World(WorldBase):
         for i, v in enumerate(fparam): d.fparam[i] = v
         self._check(self._lib.ggrs_hip_add_custom_system(self._p, C.byref(d)))
 
-    def generated_kernel_source(self, compile: bool = False, slots_per_lane: int = 1) -> str:
-        """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source); with
-        compile=True it is also built for gfx950 with hiprtc.  Works on a GGRS_WORLD_LAYOUT_ONLY world (no GPU)."""
+    def generated_kernel_source(self, compile: bool = False, persistent: bool = False) -> str:
+        """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source), in its
+        per-tile form or its persistent form; with compile=True it is also built for gfx950 with hiprtc.  Works on a
+        GGRS_WORLD_LAYOUT_ONLY world (no GPU)."""
+        form = _ffi.KERNEL_FORM_PERSISTENT if persistent else _ffi.KERNEL_FORM_TILES
         need = C.c_uint64(0)
-        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, slots_per_lane, None, 0, C.byref(need), 0))
+        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, form, None, 0, C.byref(need), 0))
         buf = C.create_string_buffer(need.value)
-        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, slots_per_lane, buf, need.value, C.byref(need), 1 if compile else 0))
+        self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, form, buf, need.value, C.byref(need), 1 if compile else 0))
         return buf.value.decode()
+
+    def checksum_component_custom(self, comp: int, source: str):
+        """checksum_component::<T>(fn(&T) -> u64) with a user-written hasher (ggrs_hip_checksum_component_custom): HIP C++
+        defining `__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c)`."""
+        self._check(self._lib.ggrs_hip_checksum_component_custom(self._p, comp, source.encode()))
 
     def close(self):
         if getattr(self, "_p", None):
@@ -353,6 +360,12 @@ class World(WorldBase):
         self._check(self._lib.ggrs_hip_profile_read(self._p, ms, n))
         names = ["save", "load", "advance", "checksum", "tick"]
         return {names[i]: (float(ms[i]), int(n[i])) for i in range(_ffi.KERNEL_CLASSES)}
+
+    def profile_bytes(self):
+        """Algorithmic bytes the launches of each kernel class were asked to move since profile_enable(True)."""
+        b = (C.c_uint64 * _ffi.KERNEL_CLASSES)()
+        self._check(self._lib.ggrs_hip_profile_read_bytes(self._p, b))
+        return dict(zip(["save", "load", "advance", "checksum", "tick"], (int(x) for x in b)))
 
     def profile_launches(self, cls: str = "tick", cap: int = 65536):
         """Duration (us) of every launch of one kernel class since profile_enable(True), in submission order."""

@@ -16,9 +16,12 @@
  *     exclusive system holding &mut World, src/lib.rs:252-257);
  *   - no callbacks into the host;
  *   - registered component data lives as SoA *word columns* in HBM: a component is
- *     n_words words of word_bytes (4 or 8) bytes; column w of component c is a dense
- *     array indexed by slot.  slot == RollbackOrdered insertion index
- *     (snapshot/rollback.rs:69-88): stable, never reused.
+ *     n_words words of word_bytes (1, 2, 4 or 8) bytes -- a bool / u8 enum is a 1-byte word, an f32 a
+ *     4-byte word, a usize an 8-byte word; column w of component c is a dense array indexed by slot.
+ *     slot == RollbackOrdered insertion index (snapshot/rollback.rs:69-88): stable, never reused.
+ *   - snapshots are complete at every observable point, but a SaveWorld only MOVES the columns whose bytes
+ *     in the ring slot differ from the live ones (row versions: every system's write set, every spawn /
+ *     upload / insert gives the columns it writes a fresh version; GGRS_ROW_VERSIONS=0 disables it).
  */
 #ifndef GGRS_HIP_H
 #define GGRS_HIP_H
@@ -119,6 +122,21 @@ int ggrs_hip_set_component_default(ggrs_world* w, uint32_t comp_id, const void* 
  * little-endian bytes (== derive(Hash) over those fields, or particles.rs:207-222). */
 int ggrs_hip_checksum_component(ggrs_world* w, uint32_t comp_id, const uint32_t* word_idx,
                                 uint32_t n_idx);
+/* RollbackApp::checksum_component::<T>(fn(&T) -> u64) with an ARBITRARY hasher (rollback_app.rs:119-121; the default one is
+ * component_checksum.rs:44-48).  `source` is HIP C++ defining
+ *
+ *     __device__ ggrs_u64 ggrs_hash(const GgrsComponent& c);
+ *
+ *   c.f32(i) / c.u32(i) / c.i32(i) / c.u64(i) / c.u16(i) / c.u8(i)   word i of the component, c.slot its RollbackOrdered index
+ *   GgrsHasher h; h.write_u8/_u16/_u32/_i32/_u64/_usize/_f32_bits(v); h.finish()   == checksum_hasher() (SeaHasher, mod.rs:318-320)
+ *
+ * e.g. the stress_test's Transform hasher (examples/stress_tests/particles.rs:207-222):
+ *     GgrsHasher h; h.write_u32(c.u32(0)); h.write_u32(c.u32(1)); h.write_u32(c.u32(2)); return h.finish();
+ * The function is inlined into the request-group kernel the library generates for the world (hiprtc), under the library's
+ * floating-point contract; a world with such a hasher needs that kernel (GGRS_E_INVALID at seal without the run-time compiler,
+ * or with GGRS_WORLD_NO_GROUPS / GGRS_WORLD_UNFUSED).  A compile error surfaces at seal with the compiler log in
+ * ggrs_hip_last_error.  Replaces any word-list spec of the component. */
+int ggrs_hip_checksum_component_custom(ggrs_world* w, uint32_t comp_id, const char* source);
 
 /* Kernel-backed systems of the GgrsSchedule (lib.rs:76, 247-251): add_systems(GgrsSchedule, ..).
  * Systems run in registration order; despawns/spawns are deferred to the end of the frame like
@@ -186,16 +204,19 @@ typedef struct {
 } ggrs_custom_system_desc;
 int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* desc);
 
-/* The request-group kernel the library WRITES for a world when it is sealed (DESIGN.md 4.3): one slot per lane, every
+/* The request-group kernel the library WRITES for a world when it is sealed (DESIGN.md 4.2): one slot per lane, every
  * registered word of the slot in a register, the GgrsSchedule systems -- built-in kinds and custom sources alike -- inlined
- * in registration order, every checksum spec unrolled; compiled with hiprtc in two forms: slots_per_lane = 1 (4-byte
- * accesses, worlds up to ~400 k slots) and 4 (16-byte accesses, HBM-sized worlds).  This returns that HIP C++ source
- * (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed) bytes are copied.  compile != 0 also builds it for
- * gfx950 (no device needed) and fails with the compiler log in ggrs_hip_last_error if it does not build.
- * GGRS_E_INVALID: the world is outside what the generator covers (a system that writes a live-only component, more than 64
- * -- 32 for the 4-slot form -- four-byte words per entity).  Registration must be complete;
- * on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
-int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t slots_per_lane, char* buf, uint64_t cap, uint64_t* needed, int compile);
+ * in registration order, every checksum spec (word lists and custom hashers) unrolled; compiled with hiprtc in two forms:
+ * GGRS_KERNEL_FORM_TILES (one 256-slot workgroup per tile: worlds that live in cache; roles, batches, host-side fold) and
+ * GGRS_KERNEL_FORM_PERSISTENT (as many 1024-thread workgroups as the device holds, checksum fold in the same launch:
+ * HBM-sized worlds).  This returns that HIP C++ source (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed)
+ * bytes are copied.  compile != 0 also builds it for gfx950 (no device needed) and fails with the compiler log in
+ * ggrs_hip_last_error if it does not build.  GGRS_E_INVALID: the world is outside what the generator covers (a system that
+ * writes a live-only component, more than 64 four-byte register units or 64 words per entity).  Registration must be
+ * complete; on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
+#define GGRS_KERNEL_FORM_TILES      1u
+#define GGRS_KERNEL_FORM_PERSISTENT 2u
+int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, uint64_t cap, uint64_t* needed, int compile);
 
 /* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);
@@ -236,7 +257,8 @@ int ggrs_hip_download_present(ggrs_world* w, uint32_t comp_id, uint64_t* host_ds
 /* device address of a live column (for zero-copy interop).  Word columns are stored tile-major: element e
  * of the column lives at dev_ptr + (e / 8192) * tile_stride + (e % 8192) * word_bytes; *tile_stride (may be
  * NULL) is 8192 * word_bytes for a plain array (non-rollback components) and the bytes of all rollback words
- * of 8192 slots otherwise (8192-slot layout tiles). */
+ * of 8192 slots otherwise (8192-slot layout tiles).  Whoever holds such a pointer may write the column
+ * behind the library's back, so from this call on the column takes no row-version shortcut: every SaveWorld / LoadWorld moves it. */
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr,
                                uint64_t* tile_stride);
 
@@ -371,12 +393,15 @@ int ggrs_hip_profile_read(ggrs_world* w, double* ms_out, uint64_t* launches_out)
 /* duration (microseconds) of every launch of one class since enable, in submission order: min(cap, *n_out) values are
  * copied, *n_out = launches recorded (bench.py: first vs last timed launch, clock ramp diagnosis). */
 int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t kernel_class, float* us_out, uint32_t cap, uint32_t* n_out);
+/* algorithmic bytes the launches of each class were asked to move since enable: the rows a launch loads and stores (after row
+ * versions) x the slots it covers -- the numerator of bench.py's roofline; size GGRS_KERNEL_CLASSES */
+int ggrs_hip_profile_read_bytes(ggrs_world* w, uint64_t* bytes_out);
 
 /* -------------------------------------------------------------------------------------------
  * Introspection: which kernel serves this world's request lists right now and why, what kind of arena
  * it lives on, whether the run-time compiler (libhiprtc.so, dlopen'ed) is available.  `key=value` lines,
  * NUL-terminated; *needed = bytes incl. the NUL, min(cap, *needed) are copied.  Keys: sealed, arena,
- * arena_bytes, hiprtc, generated_kernel, request_group_kernel, slots_covered.
+ * arena_bytes, hiprtc, generated_kernel, request_group_kernel, slots_covered, row_versions.
  * ------------------------------------------------------------------------------------------- */
 int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed);
 

@@ -115,9 +115,10 @@ unsafe extern "C" {
     pub fn ggrs_hip_register_component_ex(w: *mut ggrs_world, name: *const c_char, word_bytes: u32, n_words: u32, flags: u32, comp_id: *mut u32) -> c_int;
     pub fn ggrs_hip_set_component_default(w: *mut ggrs_world, comp_id: u32, words: *const c_void) -> c_int;
     pub fn ggrs_hip_checksum_component(w: *mut ggrs_world, comp_id: u32, word_idx: *const u32, n_idx: u32) -> c_int;
+    pub fn ggrs_hip_checksum_component_custom(w: *mut ggrs_world, comp_id: u32, source: *const c_char) -> c_int;
     pub fn ggrs_hip_add_system(w: *mut ggrs_world, desc: *const ggrs_system_desc) -> c_int;
     pub fn ggrs_hip_add_custom_system(w: *mut ggrs_world, desc: *const ggrs_custom_system_desc) -> c_int;
-    pub fn ggrs_hip_generated_kernel_source(w: *mut ggrs_world, slots_per_lane: u32, buf: *mut c_char, cap: u64, needed: *mut u64, compile: c_int) -> c_int;
+    pub fn ggrs_hip_generated_kernel_source(w: *mut ggrs_world, form: u32, buf: *mut c_char, cap: u64, needed: *mut u64, compile: c_int) -> c_int;
     pub fn ggrs_hip_set_frame_rate(w: *mut ggrs_world, fps: u64) -> c_int;
     // ---- entities and host <-> device column traffic
     pub fn ggrs_hip_spawn(w: *mut ggrs_world, count: u64, comp_mask: u64, cols: *const *const c_void, first_slot: *mut u64) -> c_int;
@@ -169,5 +170,6 @@ unsafe extern "C" {
     pub fn ggrs_hip_profile_enable(w: *mut ggrs_world, on: c_int) -> c_int;
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;
     pub fn ggrs_hip_profile_read_launches(w: *mut ggrs_world, kernel_class: u32, us_out: *mut f32, cap: u32, n_out: *mut u32) -> c_int;
+    pub fn ggrs_hip_profile_read_bytes(w: *mut ggrs_world, bytes_out: *mut u64) -> c_int;
     pub fn ggrs_hip_world_kernel_info(w: *mut ggrs_world, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
 }

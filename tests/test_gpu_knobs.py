@@ -1,0 +1,100 @@
+"""Every environment knob the library reads (csrc/host_world.hpp `Knobs`) selects among kernels / policies that must all
+produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU oracle under each setting, so the
+driver-run suite covers every kernel that ships -- k_tick3 at every size, the generated kernel in its per-tile and
+persistent forms with the fold on the host / in k_gen_finalize / in the launch, with and without depth-parallel roles,
+dead-snapshot elimination and row versions."""
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+from oracle.binding import FLAT, OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [
+    {},                                                     # the defaults
+    {"GGRS_TICK_GENERIC": "1"},                             # particles on the generated kernel at every size
+    {"GGRS_TICK_JIT": "0"},                                 # no generated kernel: k_tick3 at every size
+    {"GGRS_JIT_PARTICLES_MAX_SLOTS": "0"},                  # k_tick3 even for small worlds (a generated kernel exists)
+    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},     # generated kernel, never persistent (k_gen_finalize launch for big worlds)
+    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1"},     # generated kernel, persistent form + in-launch fold even for small worlds
+    {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # small groups folded on the device
+    {"GGRS_HOST_FOLD_MAX_WGS": "100000", "GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},   # every group folded by the host
+    {"GGRS_DEAD_GROUPS": "0"},
+    {"GGRS_JIT_DP": "0"},
+    {"GGRS_JIT_DP": "3"},
+    {"GGRS_ROW_VERSIONS": "0"},
+    {"GGRS_ARENA_CONTIG": "0"},
+    {"GGRS_DEBUG_POISON": "1"},
+]
+
+
+def _case(world, n):
+    """SyncTest ticks with spawns and Ttl despawns, then a branch list (dead groups, batches), then more ticks."""
+    D = 4
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    ids = cm.build_particles(world, with_spawn=True, ttl_init=6)
+    cm.spawn_particles(world, ids, n, vel, ttl)
+    fn = cm.frame_spawn_fn(70)
+    drv = cm.SyncTestDriver(world, D, max_prediction=D + 1)
+    for t in range(7):
+        drv.tick((cm.INPUT_SPAWN if t % 3 == 1 else 0,), spawn_fn=fn)
+    out = list(drv.all_checksums)
+    C = world.frame - 1                                       # newest snapshot
+    world.set_synctest_check_distance(-1)                     # from here on both backends get the same explicit ConfirmedFrameCount
+    world.set_confirmed(max(0, C - D))
+    reqs = []
+    for b in range(4):
+        reqs += [bg.LoadGameState(C)]
+        for i in range(3):
+            reqs += [bg.AdvanceFrame((0,)), bg.SaveGameState(C + 1 + i)]
+        reqs.append(bg.AdvanceFrame((0,)))
+    out += world.handle_requests(reqs)
+    out += world.handle_requests([bg.SaveGameState(world.frame)])
+    return out, cm.snapshot_state(world, ids)
+
+
+_ORACLE = {}
+
+
+@pytest.mark.parametrize("n", [10_000, 700_000])
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()) or "defaults")
+def test_every_knob_keeps_the_bits(env, n, monkeypatch):
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    if n not in _ORACLE:
+        o = OracleWorld(n + 4000, 6, FLAT)
+        _ORACLE[n] = _case(o, n)
+        o.close()
+    w = bg.World(n + 4000, max_depth=6)
+    got = _case(w, n)
+    info = w.kernel_info()
+    w.close()
+    assert got[0] == _ORACLE[n][0], (env, info)
+    cm.assert_states_equal(got[1], _ORACLE[n][1], f"{env} n={n}")
+    # the knob actually selected what it names
+    k = info["request_group_kernel"]
+    if env.get("GGRS_TICK_JIT") == "0" or env.get("GGRS_JIT_PARTICLES_MAX_SLOTS") == "0": assert k.startswith("k_tick3"), k
+    if env.get("GGRS_TICK_GENERIC") == "1": assert k.startswith("ggrs_jit_tick"), k
+    if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
+    if not env: assert k.startswith("k_tick3" if n > 416 * 1024 else "ggrs_jit_tick"), k
+
+
+def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
+    """GGRS_TICK_JIT=0 stands in for a deployment without libhiprtc.so: the particles world still runs fused (k_tick3), a world
+    only the generated kernel would fuse falls back to one launch per request, and ggrs_hip_world_kernel_info says so."""
+    monkeypatch.setenv("GGRS_TICK_JIT", "0")
+    res = []
+    for w in (bg.World(3000, max_depth=6), OracleWorld(3000, 6, FLAT)):
+        H = w.register_component("Health", 4, 1)
+        w.checksum_component(H, [0])
+        w.add_system(bg.SYS_ADD_U32, comp=(H,), word=(0,), iparam=(3,))
+        w.spawn(2500, {H: [np.arange(2500, dtype=np.uint32)]})
+        drv = cm.SyncTestDriver(w, 3)
+        for _ in range(8): drv.tick((0,))
+        res.append(drv.all_checksums)
+        if isinstance(w, bg.World):
+            info = w.kernel_info()
+            assert info["generated_kernel"].startswith("disabled") and info["request_group_kernel"].startswith("per-request"), info
+            assert info["hiprtc"].startswith(("loaded", "missing")), info
+    assert res[0] == res[1]
