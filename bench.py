@@ -310,6 +310,7 @@ def measure_single(bg, cm, torch, args, contig, light=False):
     for _ in range(min(K, 50)):
         run(w.frame)
     m["prof"] = w.profile_read()
+    m["prof_bytes"] = w.profile_bytes()
     tick_us = w.profile_launches("tick")
     w.profile_enable(False)
     if tick_us:
@@ -456,6 +457,7 @@ def main():
         for _ in range(min(K, 20)):
             fan.step(want_result=False)
         prof = w.profile_read()
+        m["prof_bytes"] = w.profile_bytes()
         w.profile_enable(False)
         info = w.kernel_info()
 
@@ -489,7 +491,12 @@ def main():
     if grouped:
         # one fused launch per step (N = 1): read the snapshot once, write D snapshots, write live once
         launches_per_step = tick_n / max(min(K, 20 if distributed else 50), 1)
-        bytes_per_launch = bps * (1 + D + 1) * live              # 600 B/entity at D = 8 for the headline schema
+        # algorithmic bytes of a launch = the rows it loads and stores x the slots it covers, as the library counted them when it
+        # built the launch (ggrs_hip_profile_read_bytes).  With row versions a SaveWorld moves only the columns whose bytes in the
+        # ring slot differ from the live ones (the untouched rotation / scale rows reach every slot once); with GGRS_ROW_VERSIONS=0
+        # every copy moves every row: bps x (D + 2) per entity (600 B at D = 8 for the headline schema).
+        full_copy_bytes = bps * (1 + D + 1) * live
+        bytes_per_launch = m["prof_bytes"]["tick"] / max(tick_n, 1) if m.get("prof_bytes") else full_copy_bytes
         avg_s = per(tick_ms, tick_n)
         achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
         kname = info.get("request_group_kernel", "?")
@@ -502,7 +509,12 @@ def main():
                 "frac_compulsory": achieved / HBM_PEAK_GBS,
                 "frac_per_request": (tick_bytes * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_note": f"compulsory traffic of the fused group: {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write "
+                "algorithmic_bytes_per_entity": bytes_per_launch / max(live, 1),
+                "full_copy_bytes_per_launch": full_copy_bytes,
+                "row_versions": info.get("row_versions"),
+                "algorithmic_bytes_note": f"rows the fused launch loads and stores x slots, counted by the library per launch: with row versions only columns whose bytes "
+                                          f"differ from the destination's move (every snapshot is complete; the never-written rotation / scale rows are already in every ring slot); "
+                                          f"a full copy would move {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write = {bps * (D + 2)} B/entity "
                                           f"(SURVEY 8d's one-kernel-per-request model, {tick_bytes} B/entity-tick, is reported as *_per_request)",
                 "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
                 "launch_us": m.get("launch_us"),
@@ -517,7 +529,7 @@ def main():
                         "measured first in this process; NOT the headline",
                 "arena_actual": variant["info"].get("arena"), "value": variant["live"] * (D + 1) * K / variant["secs"],
                 "ms_per_step": variant["secs"] / K * 1e3, "avg_launch_us": v_avg * 1e6,
-                "frac": (bps * (D + 2) * variant["live"] / v_avg / 1e9 / HBM_PEAK_GBS) if v_n else 0.0}
+                "frac": (variant["prof_bytes"]["tick"] / max(v_n, 1) / v_avg / 1e9 / HBM_PEAK_GBS) if v_n else 0.0}
     else:
         save_avg_s = per(save_ms, save_n)
         achieved = save_bytes * live / save_avg_s / 1e9 if save_n else 0.0
