@@ -129,7 +129,7 @@ __device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_
 // The checksum fold: one row of partials per workgroup (relaxed agent-scope stores), one
 // agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
 // entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
-template <int NTHREADS>
+template <int NTHREADS, int INFL = 24>
 __device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
     if (n_saves == 0) return;
     __syncthreads();                                              // the LDS atomics of every wave have landed
@@ -148,9 +148,8 @@ __device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, u
     for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) acc[i] = 0;
     __syncthreads();
     {
-        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  24 loads in flight per lane and trip.
+        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  INFL loads in flight per lane and trip.
         const uint32_t n_flat = gridDim.x * n_vals;
-        constexpr int INFL = 24;
         for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += (uint32_t)INFL * NTHREADS) {
             uint64_t v[INFL];
 _Pragma("unroll")

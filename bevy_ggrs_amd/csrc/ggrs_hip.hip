@@ -101,7 +101,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot + 1) * ALIGN, 4096);
     // + checksum units, mask scratch, the spawn staging buffer (4 MiB), tick_fold's row buffer (<= 1024 + 64 workgroups) and ticket
     return (uint64_t)(max_depth + 1) * state + side + parts + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20) +
-           (uint64_t)(1024 + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8 + 2 * ALIGN;
+           (uint64_t)(2048 + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8 + 2 * ALIGN;
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;

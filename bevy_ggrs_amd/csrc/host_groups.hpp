@@ -339,12 +339,12 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             rc = batch.flush(w); if (rc) return rc;
             j.fold_wg_parts = reinterpret_cast<ggrs_u64*>(w->d_wg_parts); j.fold_ticket = w->d_ticket;
             j.fold_out = reinterpret_cast<ggrs_u64*>(w->d_results + 2 * (uint64_t)(res_base + ns));
-            const uint32_t tiles1k = (j.n_units + 15) / 16;
-            const uint32_t gp = std::max(1u, std::min<uint32_t>(tiles1k, w->jit_persist_wgs));
+            const uint32_t wpb = w->jit_persist_tpb / 64;
+            const uint32_t gp = std::max(1u, std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs));
             if (launch) {
                 ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
-                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn_persist, gp, 1, 1, JIT_PERSIST_TPB, 1, 1, 0, w->stream, params, nullptr));
+                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn_persist, gp, 1, 1, w->jit_persist_tpb, 1, 1, 0, w->stream, params, nullptr));
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             ns += j.n_saves;

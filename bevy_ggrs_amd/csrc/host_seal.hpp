@@ -163,9 +163,16 @@ int seal_impl(ggrs_world* w) {
                     if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] persistent form of the generated kernel rejected: %s\n", w->err.c_str());
                     w->jit_fn_persist = nullptr; w->err = keep;
                 } else {
+                    uint32_t units = 0;
+                    for (auto& c : w->comps) if (!c.no_rollback) units += c.n_words * std::max(1u, c.word_bytes / 4);
+                    const JitPersistShape shape = jit_persist_shape(units);
+                    w->jit_persist_tpb = (uint32_t)shape.tpb;
                     int nb = 0;
-                    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w->jit_fn_persist, JIT_PERSIST_TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
-                    w->jit_persist_wgs = (uint32_t)std::min(nb, 2) * (uint32_t)w->n_cu;
+                    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w->jit_fn_persist, shape.tpb, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+                    // what the launch_bounds asked the compiler for is what the grid assumes (the occupancy query is known to
+                    // answer one block high near SGPR edges: MI355X_MICROARCH.md; tick_fold needs no co-residency, only a bound)
+                    const int want = shape.min_waves_per_simd * 256 / shape.tpb;
+                    w->jit_persist_wgs = (uint32_t)std::max(1, std::min(nb, want)) * (uint32_t)w->n_cu;
                 }
             }
         }
@@ -193,7 +200,7 @@ int seal_impl(ggrs_world* w) {
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
     // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
-    const uint64_t wg_parts_bytes = align_up((uint64_t)(2 * w->n_cu + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
+    const uint64_t wg_parts_bytes = align_up((uint64_t)(4 * w->n_cu + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
     const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);

@@ -104,7 +104,7 @@ struct ggrs_world {
     // batches, host-side fold) and its persistent form (HBM-sized worlds: grid = what the chip holds, checksum fold in-kernel)
     hipFunction_t jit_fn = nullptr, jit_fn_persist = nullptr;
     JitEntry* jit_entry = nullptr; JitEntry* jit_entry_persist = nullptr;   // handed back to the module cache when the world is destroyed
-    uint32_t jit_persist_wgs = 0;        // workgroups of the persistent form the device holds at once (occupancy query)
+    uint32_t jit_persist_wgs = 0, jit_persist_tpb = 1024;   // workgroups of the persistent form the device holds at once, and their size
     std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)
     bool jit_marks = false;              // the generated kernel keeps the RollbackDespawned markers (a system may defer a despawn)
     bool jit_reads_inputs = false;       // a system reads PlayerInputs (BOX_MOVE, custom): branches with different inputs differ

@@ -161,7 +161,15 @@ struct GgrsJitArgs {
 static_assert(MAX_TICK_SAVES == 16 && MAX_TICK_STEPS == 24, "GgrsJitArgs is sized for 16 Saves / 24 steps per group");
 constexpr uint32_t JIT_MAX_UNITS = 64;       // 4-byte register units per slot the generated kernel may hold
 constexpr uint32_t JIT_MAX_COLS = 64;        // word columns (one bit each in the row-version masks)
-constexpr int JIT_PERSIST_TPB = 1024;
+// The persistent form's workgroup: as many waves per SIMD as the world's register need allows.  Few, fat workgroups keep
+// tick_fold's row count (= tickets = rows the last arriver reads) small: 1024 threads x 2 per CU for up to 16 four-byte units per
+// slot (the stress_test: 15), 512-thread workgroups beyond (<= 80 / <= 128 VGPRs).
+struct JitPersistShape { int tpb, min_waves_per_simd; };
+inline JitPersistShape jit_persist_shape(uint32_t units) {
+    if (units <= 16) return {1024, 8};
+    if (units <= 26) return {512, 6};
+    return {512, 4};
+}
 
 // What a user-written checksum hasher sees (ggrs_hip_checksum_component_custom): the component's words of ONE entity and a
 // SeaHasher -- checksum_hasher() of the reference (snapshot/mod.rs:318-320).
@@ -244,7 +252,8 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     const uint32_t n_cks = (uint32_t)cks_comp.size();
     if (n_cks > 16) return false;
     const unsigned long long OFF_ALIVE = w->off_alive, OFF_DIS = w->marks.off_disabled, OFF_DF = w->marks.off_dframe;
-    const int TPB_ = persist ? JIT_PERSIST_TPB : 256, WPB = TPB_ / 64;
+    const JitPersistShape shape = jit_persist_shape(units);
+    const int TPB_ = persist ? shape.tpb : 256, WPB = TPB_ / 64;
 
     s.clear();
     s += "typedef unsigned long uint64_t; typedef unsigned int uint32_t; typedef unsigned short uint16_t; typedef unsigned char uint8_t;\n"
@@ -275,7 +284,9 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         s += "\n}\n";
     }
     s += "#line 1 \"ggrs_jit_tick\"\n";
-    sfmt(s, "extern \"C\" __global__ __launch_bounds__(%d) void ggrs_jit_tick(GgrsJitArgs a) {\n"
+    char lb[48];
+    if (persist) snprintf(lb, sizeof lb, "%d, %d", TPB_, shape.min_waves_per_simd); else snprintf(lb, sizeof lb, "%d", TPB_);
+    sfmt(s, "extern \"C\" __global__ __launch_bounds__(%s) void ggrs_jit_tick(GgrsJitArgs a) {\n"
             "    const uint32_t tid = threadIdx.x, lane = tid & 63u;\n"
             "    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform, and the compiler knows it\n"
             "    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;\n"
@@ -288,10 +299,10 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             "    __shared__ uint32_t s_last;\n"
             "    for (uint32_t i = tid; i < 16u * %uu; i += %du) s_acc[i] = 0;\n"
             "    __syncthreads();\n",
-         TPB_, n_cks + 1, n_cks + 1, TPB_);
-    if (persist) s += "    for (uint32_t t_ = blockIdx.x; t_ * 16u < a.n_units; t_ += gridDim.x) {       // persistent: 1024 consecutive slots per workgroup and trip\n"
-                      "    const uint32_t gu = t_ * 16u + wave;                                  // this wave's 64-slot unit == its mask word\n"
-                      "    if (gu >= a.n_units) continue;\n";
+         lb, n_cks + 1, n_cks + 1, TPB_);
+    if (persist) sfmt(s, "    for (uint32_t t_ = blockIdx.x; t_ * %du < a.n_units; t_ += gridDim.x) {       // persistent: %d consecutive slots per workgroup and trip\n"
+                         "    const uint32_t gu = t_ * %du + wave;                                  // this wave's 64-slot unit == its mask word\n"
+                         "    if (gu >= a.n_units) continue;\n", WPB, TPB_, WPB);
     else s += "    {\n"
               "    const uint32_t gu = blockIdx.x * 4u + wave;                               // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
@@ -496,7 +507,7 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     if (persist) {
         sfmt(s, "    // ---- every Save's Checksum(u128), folded in this launch (tick_fold, device_prelude.hpp)\n"
                 "    FoldArgs f; f.wg_parts = (uint64_t*)a.fold_wg_parts; f.ticket = a.fold_ticket; f.out = (uint64_t*)a.fold_out; f.n_comp = %uu; f.comp_mask = %uu;\n"
-                "    tick_fold<%d>(f, a.n_saves, a.len, (uint64_t*)s_acc, &s_last);\n", n_cks, n_cks ? ((1u << n_cks) - 1u) : 0u, TPB_);
+                "    tick_fold<%d, 8>(f, a.n_saves, a.len, (uint64_t*)s_acc, &s_last);\n", n_cks, n_cks ? ((1u << n_cks) - 1u) : 0u, TPB_);
     } else {
         sfmt(s, "    // ---- this workgroup's partial rows (blockIdx.z: member of a batch of identical checksum-only groups)\n"
                 "    (void)s_last;\n"
@@ -508,7 +519,6 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     }
     s += "}\n";
-    (void)WPB;
     return true;
 }
 

@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libggrs_oracle.so")
 
 FLAT, REFSHAPED = 0, 1
+# checksum_component::<T>(fn(&T) -> u64): the component's words of one entity (n_words * word_bytes bytes), its slot, user data
+HASH_FN = C.CFUNCTYPE(C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_void_p)
 
 
 def build(force: bool = False):
@@ -55,6 +57,7 @@ def _load():
         "gor_register_component_ex": (C.c_int, [P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
         "gor_set_component_default": (C.c_int, [P, C.c_uint32, P]),
         "gor_checksum_component": (C.c_int, [P, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
+        "gor_checksum_component_custom": (C.c_int, [P, C.c_uint32, HASH_FN, P]),
         "gor_add_system": (C.c_int, [P, C.POINTER(SystemDesc)]),
         "gor_spawn": (C.c_int, [P, C.c_uint64, C.c_uint64, C.POINTER(P), C.POINTER(C.c_uint64)]),
         "gor_despawn": (C.c_int, [P, C.c_uint64]),
@@ -122,6 +125,27 @@ class OracleWorld(WorldBase):
 
     def active_count(self) -> int:
         return int(lib.gor_active_count(self._p))
+
+    def checksum_component_custom(self, comp: int, fn):
+        """checksum_component::<T>(hasher) with an arbitrary hasher: fn(words: bytes, slot: int) -> int, `words` = the
+        component's n_words * word_bytes bytes of one entity.  (A Python callback per entity: small worlds only.)"""
+        _, wb, nw = self._comps[comp]
+        nbytes = wb * nw
+        cb = HASH_FN(lambda p, slot, _u: int(fn(bytes(p[:nbytes]), int(slot))) & 0xFFFFFFFFFFFFFFFF)
+        self._keep = getattr(self, "_keep", []) + [cb]
+        self._check(lib.gor_checksum_component_custom(self._p, comp, cb, None))
+
+    @staticmethod
+    def sea_hasher():
+        """A SeaHasher (checksum_hasher(), snapshot/mod.rs:318-320) for Python-side custom hashers: .write(bytes), .finish()."""
+        class _H:
+            def __init__(self): self.buf = b""
+            def write(self, b): self.buf += bytes(b); return self
+            def finish(self):
+                a = (C.c_uint8 * max(1, len(self.buf))).from_buffer_copy(self.buf or b"\0")
+                sizes = (C.c_uint32 * 1)(len(self.buf))
+                return int(lib.gor_seahash_stream(a, len(self.buf), sizes, 1))
+        return _H()
 
     def set_synctest_check_distance(self, cd: int):
         self._cd = cd   # the oracle applies the rule in Python (see tests/common.py)

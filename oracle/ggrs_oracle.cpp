@@ -208,7 +208,10 @@ struct SystemDesc {            // must match include/ggrs_hip.h ggrs_system_desc
 struct Comp {
     std::string name;
     uint32_t word_bytes = 4, n_words = 0;
-    std::vector<uint32_t> cks_units;          // u32 units fed to the inner SeaHash, in order
+    std::vector<uint32_t> cks_units;          // words fed to the inner SeaHash, in order (each written as word_bytes little-endian bytes)
+    // checksum_component::<T>(fn(&T) -> u64) with an arbitrary hasher (rollback_app.rs:119-121): the test hands in a C callback
+    uint64_t (*cks_fn)(const uint8_t* words, uint64_t slot, void* user) = nullptr;
+    void* cks_user = nullptr;
     bool checksummed = false;
     std::vector<uint8_t> defaults;            // n_words*word_bytes default value (zeros unless set)
     bool no_rollback = false;                 // not registered for rollback: outside every snapshot (despawn.rs:3-6)
@@ -349,17 +352,6 @@ static uint32_t dt_bits_for_frame(uint64_t fps, int32_t frame) {
     return bits;
 }
 
-// --- component value access helpers (flat columns) ---
-static inline uint32_t unit_of(const World& w, uint32_t c, uint32_t unit, uint64_t i) {
-    const Comp& cc = w.comps[c];
-    if (cc.word_bytes == 4) {
-        uint32_t v; memcpy(&v, &w.cols[w.col_base[c] + unit][i * 4], 4); return v;
-    } else {
-        uint64_t v; memcpy(&v, &w.cols[w.col_base[c] + (unit >> 1)][i * 8], 8);
-        return (unit & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
-    }
-}
-
 // custom_hasher(component) -- SeaHash stream over the selected u32 units
 // (particles.rs:107-120 Velocity Hash impl, particles.rs:207-222 Transform closure,
 // component_checksum.rs:44-48 default_hasher).  Units are 4-byte writes; a u64 field is
@@ -383,18 +375,27 @@ static inline uint64_t finalize_part(uint64_t x) {
     return h.finish();
 }
 
+// custom_hasher(&component): the registered word list through SeaHasher, each word as word_bytes little-endian bytes -- what
+// derive(Hash) / the particles closure write (a bool or u8 enum 1 byte, f32::to_bits 4, usize 8) -- or the user's function.
+// `row`: the component's words of one entity, back to back (n_words * word_bytes bytes).
+static inline uint64_t custom_hash_of(const Comp& cc, const uint8_t* row, uint64_t slot) {
+    if (cc.cks_fn) return cc.cks_fn(row, slot, cc.cks_user);
+    sea::Hasher h;
+    for (uint32_t wi : cc.cks_units) h.write(row + (size_t)wi * cc.word_bytes, cc.word_bytes);
+    return h.finish();
+}
+
 static uint64_t component_checksum_flat(const World& w, uint32_t c) {
     const Comp& cc = w.comps[c];
     uint64_t result = 0;
-    const uint32_t n = (uint32_t)cc.cks_units.size();
     const int64_t L = (int64_t)w.len;
-#pragma omp parallel for reduction(^ : result) schedule(static) if (L > 65536)
+#pragma omp parallel for reduction(^ : result) schedule(static) if (L > 65536 && !cc.cks_fn)
     for (int64_t ii = 0; ii < L; ++ii) {
         uint64_t i = (uint64_t)ii;
         if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
-        uint32_t u[MAX_UNITS];
-        for (uint32_t k = 0; k < n; ++k) u[k] = unit_of(w, c, cc.cks_units[k], i);
-        result ^= entity_part(i /* RollbackOrdered.order == slot */, inner_hash_units(u, n));
+        uint8_t row[MAX_WORDS * 8];
+        for (uint32_t k = 0; k < cc.n_words; ++k) memcpy(row + (size_t)k * cc.word_bytes, &w.cols[w.col_base[c] + k][i * cc.word_bytes], cc.word_bytes);
+        result ^= entity_part(i /* RollbackOrdered.order == slot */, custom_hash_of(cc, row, i));
     }
     return finalize_part(result);
 }
@@ -437,7 +438,6 @@ static void ref_sync_to_flat(World& w) {
 static uint64_t component_checksum_ref(const World& w, uint32_t c) {
     const Comp& cc = w.comps[c];
     uint64_t result = 0;
-    const uint32_t n = (uint32_t)cc.cks_units.size();
     const uint32_t st = w.stride(c);
     for (uint64_t i = 0; i < w.len; ++i) {          // Query<(&RollbackId,&C)>::iter()
         if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
@@ -445,9 +445,7 @@ static uint64_t component_checksum_ref(const World& w, uint32_t c) {
         const uint8_t* op = w.order_map.get(id);    // rollback_ordered.order(rollback): HashMap lookup
         uint64_t order; memcpy(&order, op, 8);
         const uint8_t* row = &w.aos[c][i * st];
-        uint32_t u[MAX_UNITS];
-        for (uint32_t k = 0; k < n; ++k) memcpy(&u[k], row + 4 * cc.cks_units[k], 4);
-        result ^= entity_part(order, inner_hash_units(u, n));
+        result ^= entity_part(order, custom_hash_of(cc, row, i));
     }
     return finalize_part(result);
 }
@@ -953,7 +951,7 @@ const char* gor_last_error(void* w) { return ((World*)w)->err.c_str(); }
 
 int gor_register_component(void* wp, const char* name, uint32_t word_bytes, uint32_t n_words, uint32_t* id) {
     World& w = *(World*)wp;
-    if (w.sealed || w.comps.size() >= MAX_COMPS || n_words == 0 || n_words > MAX_WORDS || (word_bytes != 4 && word_bytes != 8)) return -1;
+    if (w.sealed || w.comps.size() >= MAX_COMPS || n_words == 0 || n_words > MAX_WORDS || (word_bytes != 1 && word_bytes != 2 && word_bytes != 4 && word_bytes != 8)) return -1;
     Comp c; c.name = name; c.word_bytes = word_bytes; c.n_words = n_words;
     c.defaults.assign((size_t)word_bytes * n_words, 0);
     w.comps.push_back(c);
@@ -979,13 +977,22 @@ int gor_checksum_component(void* wp, uint32_t c, const uint32_t* word_idx, uint3
     World& w = *(World*)wp;
     if (c >= w.comps.size()) return -1;
     Comp& cc = w.comps[c];
-    cc.cks_units.clear();
+    cc.cks_units.clear(); cc.cks_fn = nullptr;
     for (uint32_t k = 0; k < n; ++k) {
         if (word_idx[k] >= cc.n_words) return -1;
-        if (cc.word_bytes == 4) cc.cks_units.push_back(word_idx[k]);
-        else { cc.cks_units.push_back(2 * word_idx[k]); cc.cks_units.push_back(2 * word_idx[k] + 1); }
+        cc.cks_units.push_back(word_idx[k]);
     }
     if (cc.cks_units.size() > MAX_UNITS) return -1;
+    cc.checksummed = true;
+    return 0;
+}
+// checksum_component::<T>(hasher) with an arbitrary fn(&T) -> u64 (rollback_app.rs:119-121); `words` = the component's
+// n_words * word_bytes bytes of one entity
+int gor_checksum_component_custom(void* wp, uint32_t c, uint64_t (*fn)(const uint8_t* words, uint64_t slot, void* user), void* user) {
+    World& w = *(World*)wp;
+    if (c >= w.comps.size() || !fn) return -1;
+    Comp& cc = w.comps[c];
+    cc.cks_units.clear(); cc.cks_fn = fn; cc.cks_user = user;
     cc.checksummed = true;
     return 0;
 }

@@ -85,7 +85,7 @@ def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
     only the generated kernel would fuse falls back to one launch per request, and ggrs_hip_world_kernel_info says so."""
     monkeypatch.setenv("GGRS_TICK_JIT", "0")
     res = []
-    for w in (bg.World(3000, max_depth=6), OracleWorld(3000, 6, FLAT)):
+    for w in (bg.World(3000, max_depth=9), OracleWorld(3000, 9, FLAT)):
         H = w.register_component("Health", 4, 1)
         w.checksum_component(H, [0])
         w.add_system(bg.SYS_ADD_U32, comp=(H,), word=(0,), iparam=(3,))

@@ -1,0 +1,139 @@
+"""Word sizes and checksum hashers beyond the 3-component headline schema, GPU vs CPU oracle, bit-exact:
+  * the reference stress_test's whole POD rollback list (examples/stress_tests/particles.rs:190-199 minus Sprite):
+    + GlobalTransform (12 x f32), Visibility / InheritedVisibility / ViewVisibility (1-byte words);
+  * 1- and 2-byte words through SaveWorld / LoadWorld / the hasher (derive(Hash) writes a bool as 1 byte, a u16 as 2);
+  * user-written checksum hashers, RollbackApp::checksum_component::<T>(fn(&T) -> u64) (rollback_app.rs:119-121)."""
+import struct
+
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+from oracle.binding import FLAT, OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,flags", [(5_000, 0), (300_000, 0), (700_000, 0), (9_000, bg.GGRS_WORLD_NO_GROUPS)])
+def test_full_stress_test_schema_matches_oracle(n, flags):
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    fn = cm.frame_spawn_fn(80)
+    res = []
+    for w in (bg.World(n + 3000, max_depth=9, flags=flags), OracleWorld(n + 3000, 9, FLAT)):
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=9, schema="full")
+        assert len(ids) == 7
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.upload_word(ids[4], 0, 0, (np.arange(n) % 3).astype(np.uint8))          # Visibility: Inherited / Hidden / Visible
+        drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+        for t in range(12):
+            drv.tick((cm.INPUT_SPAWN if t % 4 == 2 else 0,), spawn_fn=fn)
+        res.append((drv.all_checksums, cm.snapshot_state(w, ids)))
+        if isinstance(w, bg.World): info = w.kernel_info()
+        w.close()
+    assert res[0][0] == res[1][0], info
+    cm.assert_states_equal(res[0][1], res[1][1], f"full schema n={n}")
+    if not flags: assert info["request_group_kernel"].startswith("ggrs_jit_tick"), info   # 1-byte words: never k_tick3
+
+
+@pytest.mark.parametrize("flags", [0, bg.GGRS_WORLD_NO_GROUPS])
+@pytest.mark.parametrize("n", [777, 40_000, 600_000])
+def test_narrow_words_through_snapshots_and_the_hasher(n, flags):
+    """A component of u8 words, one of u16 words, mixed with u32 / u64: every column survives rollbacks byte for byte and the
+    hasher sees each field at its own width, in registration order of the spec (misaligned 8-byte chunks included)."""
+    rng = np.random.default_rng(5)
+    res = []
+    for w in (bg.World(n, max_depth=6, flags=flags), OracleWorld(n, 6, FLAT)):
+        A = w.register_component("Bytes", 1, 3)
+        B = w.register_component("Shorts", 2, 2)
+        H = w.register_component("Health", 4, 1)
+        Q = w.register_component("Wide", 8, 1)
+        w.checksum_component(A, [2, 0, 1])                  # 3 bytes
+        w.checksum_component(B, [1, 0])                     # 4 bytes in two 2-byte writes
+        w.checksum_component(H, [0])
+        w.checksum_component(Q, [0])
+        w.add_system(bg.SYS_ADD_U32, comp=(H,), word=(0,), iparam=(7,))
+        r = np.random.default_rng(11)
+        w.spawn(n, {A: [r.integers(0, 256, n, dtype=np.uint64).astype(np.uint8) for _ in range(3)],
+                    B: [r.integers(0, 65536, n, dtype=np.uint64).astype(np.uint16) for _ in range(2)],
+                    H: [r.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)],
+                    Q: [r.integers(0, 2 ** 63, n, dtype=np.uint64)]})
+        drv = cm.SyncTestDriver(w, 4, max_prediction=5)
+        out = []
+        for t in range(7):
+            drv.tick((0,))
+            if t == 3:                                       # host edits between ticks: versions must notice them
+                w.upload_word(A, 1, 0, np.full(n, 0xAB, dtype=np.uint8))
+                w.insert_component(B, n // 2, np.array([0x1234, 0xFFFF], dtype=np.uint16))
+        res.append((drv.all_checksums, cm.snapshot_state(w, (A, B, H, Q))))
+        w.close()
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], f"narrow words n={n}")
+    _ = rng
+
+
+PARTICLES_CLOSURE = ("__device__ ggrs_u64 ggrs_hash(const GgrsComponent& t) {\n"
+                     "    GgrsHasher h;                                   // checksum_hasher(), particles.rs:208\n"
+                     "    h.write_u32(t.u32(0)); h.write_u32(t.u32(1)); h.write_u32(t.u32(2));   // translation.{x,y,z}.to_bits()\n"
+                     "    return h.finish();\n}\n")
+
+
+@pytest.mark.parametrize("n", [3_000, 500_000])
+def test_custom_hasher_source_equals_builtin_word_list(n):
+    """The stress_test's Transform closure (particles.rs:207-222) written as hasher source must equal the word-list spec bit for
+    bit: GPU custom == GPU built-in == oracle."""
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    res = []
+    for kind in ("custom", "builtin", "oracle"):
+        w = OracleWorld(n, 9, FLAT) if kind == "oracle" else bg.World(n, max_depth=9)
+        T, V, L = cm.build_particles(w)
+        if kind == "custom": w.checksum_component_custom(T, PARTICLES_CLOSURE)
+        cm.spawn_particles(w, (T, V, L), n, vel, ttl)
+        drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+        for _ in range(11): drv.tick((0,))
+        res.append(drv.all_checksums)
+        if kind == "custom": assert w.kernel_info()["request_group_kernel"].startswith("ggrs_jit_tick")
+        w.close()
+    assert res[0] == res[1] == res[2]
+
+
+def test_custom_hasher_that_no_word_list_expresses():
+    """fn(&T) -> u64 is arbitrary: fold two fields together, skip one, mix in a byte-wide flag.  Oracle side: a C-ABI callback."""
+    n = 2_000
+    src = ("__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c) {\n"
+           "    GgrsHasher h; h.write_u32(c.u32(0) ^ (c.u32(1) * 3u)); h.write_u8(c.u8(3) & 1); h.write_u64((ggrs_u64)c.u16(2) << 7);\n"
+           "    return h.finish() ^ 0x55ull;\n}\n")
+
+    def py_hash(words: bytes, slot: int) -> int:
+        a, b, c2, d = struct.unpack("<IIII", words)        # four 4-byte words (u16 / u8 live in the low bytes of words 2 / 3)
+        h = OracleWorld.sea_hasher()
+        h.write(struct.pack("<I", (a ^ (b * 3)) & 0xFFFFFFFF)); h.write(bytes([d & 1])); h.write(struct.pack("<Q", (c2 & 0xFFFF) << 7))
+        return h.finish() ^ 0x55
+    r = np.random.default_rng(3)
+    cols = [r.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for _ in range(4)]
+    res = []
+    for w in (bg.World(n, max_depth=6), OracleWorld(n, 6, FLAT)):
+        X = w.register_component("X", 4, 4)
+        w.add_system(bg.SYS_ADD_U32, comp=(X,), word=(1,), iparam=(5,))
+        if isinstance(w, bg.World): w.checksum_component_custom(X, src)
+        else: w.checksum_component_custom(X, py_hash)
+        w.spawn(n, {X: cols})
+        drv = cm.SyncTestDriver(w, 3, max_prediction=5)
+        for _ in range(6): drv.tick((0,))
+        res.append(drv.all_checksums)
+        w.close()
+    assert res[0] == res[1]
+
+
+def test_custom_hasher_compile_error_and_unfused_world():
+    w = bg.World(100, max_depth=4)
+    X = w.register_component("X", 4, 1)
+    w.checksum_component_custom(X, "__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c) { return nope; }")
+    with pytest.raises(bg.GgrsHipError) as e:
+        w.spawn(1, {X: None})                               # seal: the generated kernel does not build -> the world cannot have this hasher
+    assert "hasher" in str(e.value)
+    w = bg.World(100, max_depth=4, flags=bg.GGRS_WORLD_NO_GROUPS)
+    X = w.register_component("X", 4, 1)
+    w.checksum_component_custom(X, "__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c) { return c.u32(0); }")
+    with pytest.raises(bg.GgrsHipError):
+        w.spawn(1, {X: None})
