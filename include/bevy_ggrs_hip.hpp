@@ -307,8 +307,8 @@ class GgrsSnapshots {
 };
 
 // ---------------------------------------------------------------- components and systems
-// A rollback component on this path is plain-old-data made of 4- or 8-byte words
-// (Transform = 10 x f32, Velocity = 3 x f32, Ttl = 1 x u64).  Specialise for each type:
+// A rollback component on this path is plain-old-data made of words of ONE size: 1, 2, 4 or 8 bytes
+// (Transform = 10 x f32, Velocity = 3 x f32, Ttl = 1 x u64, Visibility = 1 x u8).  Specialise for each type:
 //   template <> struct HipComponent<Velocity> { static constexpr const char* name = "Velocity";
 //       static constexpr uint32_t word_bytes = 4, n_words = 3; };
 template <class T> struct HipComponent;
@@ -384,6 +384,7 @@ struct HipBackend {
     int register_component_ex(const char* n, uint32_t wb, uint32_t nw, uint32_t flags, uint32_t* id) { return ggrs_hip_register_component_ex(w, n, wb, nw, flags, id); }
     int set_component_default(uint32_t c, const void* p) { return ggrs_hip_set_component_default(w, c, p); }
     int checksum_component(uint32_t c, const uint32_t* idx, uint32_t n) { return ggrs_hip_checksum_component(w, c, idx, n); }
+    int checksum_component_custom(uint32_t c, const char* source) { return ggrs_hip_checksum_component_custom(w, c, source); }
     int add_system(const ggrs_system_desc* d) { return ggrs_hip_add_system(w, d); }
     int add_custom_system(const ggrs_custom_system_desc* d) { return ggrs_hip_add_custom_system(w, d); }
     int set_frame_rate(uint64_t fps) { return ggrs_hip_set_frame_rate(w, fps); }
@@ -544,6 +545,12 @@ class App {
     }
     template <class T> App& checksum_component(const std::vector<uint32_t>& hashed_words) {     // the fn(&T)->u64 of the reference becomes the list of hashed words
         check(be_.checksum_component(comp_id(HipComponent<T>::name), hashed_words.data(), (uint32_t)hashed_words.size()));
+        return *this;
+    }
+    // checksum_component::<T>(fn(&T) -> u64) with an ARBITRARY hasher (rollback_app.rs:119-121): HIP C++ source defining
+    // `__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c)` (include/ggrs_hip.h, ggrs_hip_checksum_component_custom)
+    template <class T> App& checksum_component_with_source(const std::string& hasher_source) {
+        check(be_.checksum_component_custom(comp_id(HipComponent<T>::name), hasher_source.c_str()));
         return *this;
     }
     template <class T> App& set_component_default(const void* words) { check(be_.set_component_default(comp_id(HipComponent<T>::name), words)); return *this; }

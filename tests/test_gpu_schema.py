@@ -59,13 +59,19 @@ def test_narrow_words_through_snapshots_and_the_hasher(n, flags):
                     H: [r.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)],
                     Q: [r.integers(0, 2 ** 63, n, dtype=np.uint64)]})
         drv = cm.SyncTestDriver(w, 4, max_prediction=5)
-        out = []
         for t in range(7):
             drv.tick((0,))
-            if t == 3:                                       # host edits between ticks: versions must notice them
-                w.upload_word(A, 1, 0, np.full(n, 0xAB, dtype=np.uint8))
-                w.insert_component(B, n // 2, np.array([0x1234, 0xFFFF], dtype=np.uint16))
-        res.append((drv.all_checksums, cm.snapshot_state(w, (A, B, H, Q))))
+        out = list(drv.all_checksums)
+        # host edits between request lists (not rollback-safe under SyncTest, so compared request by request instead): the row
+        # versions must notice them -- the next SaveWorld has to carry the new bytes, a LoadWorld of an older frame the old ones
+        w.set_synctest_check_distance(-1); w.set_confirmed(max(0, w.frame - 4))
+        f = w.frame
+        out += w.handle_requests([bg.SaveGameState(f)])
+        w.upload_word(A, 1, 0, np.full(n, 0xAB, dtype=np.uint8))
+        w.insert_component(B, n // 2, np.array([0x1234, 0xFFFF], dtype=np.uint16))
+        out += w.handle_requests([bg.AdvanceFrame((0,)), bg.SaveGameState(f + 1), bg.LoadGameState(f), bg.SaveGameState(f), bg.AdvanceFrame((0,)), bg.SaveGameState(f + 1)])
+        out += w.handle_requests([bg.LoadGameState(f - 2), bg.AdvanceFrame((0,)), bg.SaveGameState(f - 1)])
+        res.append((out, cm.snapshot_state(w, (A, B, H, Q))))
         w.close()
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], f"narrow words n={n}")
