@@ -26,6 +26,13 @@ __host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, 
     uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z);
     return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL);
 }
+// the same with the tail's diffuse handed in: a = sea_diffuse(SEA_K1 ^ z) depends on z only, so a caller that knows z did not
+// change since it last hashed this entity (translation.z / velocity.z of a 2-D simulation) reuses it
+__host__ __device__ __forceinline__ uint64_t sea_tail3(uint32_t z) { return sea_diffuse(SEA_K1 ^ (uint64_t)z); }
+__host__ __device__ __forceinline__ uint64_t sea_inner3_with_tail(uint32_t x, uint32_t y, uint64_t a) {
+    uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32)));
+    return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL);
+}
 // SeaHasher::new(); write_u64(order); write_u64(inner); finish()  -- component_checksum.rs:81-90
 __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) {
     uint64_t B = sea_diffuse(SEA_K0 ^ order);
@@ -77,9 +84,20 @@ struct Header {           // first 256 B of every packed state block
     uint64_t checksum[2];
 };
 
+// XOR of v over the 64 lanes of the wave, returned wave-uniform.  DPP butterflies inside each row of 16 (quad_perm, row_half_mirror,
+// row_mirror), then row_bcast:15 / row_bcast:31 carry the row totals up to lane 63: 6 v_xor_b32_dpp per 32-bit half and one
+// readlane -- plain VALU, no LDS round trips (a __shfl_xor ladder is 12 ds_bpermute with ~6 dependent LDS latencies).
+__device__ __forceinline__ uint32_t wave_xor32(uint32_t v) {
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);     // quad_perm:[1,0,3,2]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);    // row_mirror: every lane holds its row's XOR
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint64_t wave_xor(uint64_t v) {
-    for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o, 64);
-    return v;
+    return ((uint64_t)wave_xor32((uint32_t)(v >> 32)) << 32) | wave_xor32((uint32_t)v);
 }
 constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3;   // box_game.rs:13-16
 __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in,

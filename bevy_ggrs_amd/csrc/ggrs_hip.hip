@@ -32,6 +32,7 @@
 #include <atomic>
 #include <cctype>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>

@@ -221,6 +221,13 @@ uint64_t jit_static_reads(const ggrs_world* w) {
     return m;
 }
 
+// columns some GgrsSchedule system writes: in steady state a SaveWorld stores exactly these (everything else is already in the slot)
+uint64_t jit_hot_cols(const ggrs_world* w) {
+    uint64_t m = 0;
+    for (auto& cols : w->sys_writes) for (uint32_t c : cols) if (c < 64 && w->col_rb[c]) m |= 1ull << c;
+    return m;
+}
+
 // Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
 // back to k_tick3 or to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
 // Player.handle, too many words for the register file / the 64-bit row masks.
@@ -329,23 +336,40 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n    %s w%u_0 = 0;\n", cl, (unsigned long long)w->col_off[cl], wb, wtype(c), cl);
     }
     // loads / stores of the words of the lane's slot from / to a block, each guarded by its bit of a wave-uniform row mask
+    // Row masks are wave-uniform.  The masks of a steady-state tick are known when the kernel is written -- a SaveWorld stores
+    // exactly the columns some system writes (HOT), the source block is read for those plus what steps and checksums read -- so
+    // each access block is emitted twice: straight-line for that mask (one scalar compare), column-by-column guards otherwise.
+    const uint64_t HOT = jit_hot_cols(w), LOADHOT = HOT | jit_static_reads(w);
+    auto each_col = [&](uint64_t only, const std::function<void(uint32_t, uint32_t)>& fn) {
+        for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k)
+            if ((only >> col(c, k)) & 1ull) fn(c, col(c, k));
+    };
     auto emit_load = [&](const char* blk, const char* mask, const char* indent) {
-        for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
-            const uint32_t cl = col(c, k);
-            sfmt(s, "%sif ((%s >> %uu) & 1ull) w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, mask, cl, cl, mtype(c), cl, blk);
-        }
+        sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)LOADHOT);
+        each_col(LOADHOT, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, cl, mtype(c), cl, blk); });
+        sfmt(s, "%s} else {\n", indent);
+        each_col(~0ull, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    if ((%s >> %uu) & 1ull) w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, mask, cl, cl, mtype(c), cl, blk); });
+        sfmt(s, "%s}\n", indent);
     };
     auto emit_words_out = [&](const char* dst, const char* mask, const char* indent, bool nt) {
-        for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
-            const uint32_t cl = col(c, k);
-            if (nt) sfmt(s, "%sif ((%s >> %uu) & 1ull) __builtin_nontemporal_store((%s)w%u_0, (GGRS_G %s*)o%u(%s));\n", indent, mask, cl, mtype(c), cl, mtype(c), cl, dst);
-            else sfmt(s, "%sif ((%s >> %uu) & 1ull) *(GGRS_G %s*)o%u(%s) = (%s)w%u_0;\n", indent, mask, cl, mtype(c), cl, dst, mtype(c), cl);
-        }
+        auto one = [&](uint32_t c, uint32_t cl, const char* ind, bool guard) {
+            char g[64] = "";
+            if (guard) snprintf(g, sizeof g, "if ((%s >> %uu) & 1ull) ", mask, cl);
+            if (nt) sfmt(s, "%s%s__builtin_nontemporal_store((%s)w%u_0, (GGRS_G %s*)o%u(%s));\n", ind, g, mtype(c), cl, mtype(c), cl, dst);
+            else sfmt(s, "%s%s*(GGRS_G %s*)o%u(%s) = (%s)w%u_0;\n", ind, g, mtype(c), cl, dst, mtype(c), cl);
+        };
+        const std::string in2 = std::string(indent) + "    ";
+        sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)HOT);
+        each_col(HOT, [&](uint32_t c, uint32_t cl) { one(c, cl, in2.c_str(), false); });
+        sfmt(s, "%s} else {\n", indent);
+        each_col(~0ull, [&](uint32_t c, uint32_t cl) { one(c, cl, in2.c_str(), true); });
+        sfmt(s, "%s}\n", indent);
     };
     auto emit_store = [&](const char* dst, const char* mask, const char* alive_word, const char* indent, bool nt_variant) {
         std::string in2 = std::string(indent) + "    ", in3 = in2 + "    ";
         sfmt(s, "%sif (in_len) {\n", indent);
-        if (nt_variant) {
+        if (nt_variant && persist) emit_words_out(dst, mask, in2.c_str(), true);      // the persistent form only serves HBM-sized groups: snapshots are written once, read a tick later
+        else if (nt_variant) {
             sfmt(s, "%sif (a.nt) {\n", in2.c_str());
             emit_words_out(dst, mask, in3.c_str(), true);
             sfmt(s, "%s} else {\n", in2.c_str());
@@ -361,6 +385,31 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     emit_load("a.src", "a.load_rows", "        ");
     s += "    }\n"
          "    const uint64_t ordB_0 = sea_order_lane(e0);\n";
+    // which word-list specs take the memoised form: 9..12 hashed bytes whose byte 8.. tail is made of whole fields
+    std::vector<uint32_t> spec_bytes(n_cks, 0); std::vector<uint8_t> spec_memo(n_cks, 0);
+    auto chunk_expr = [&](const Comp& cc, uint32_t c, uint32_t first, uint32_t nbytes) {      // bytes [first, first + nbytes) of the hashed stream as a u64 expression
+        std::string e; uint32_t pos = 0; char buf[160];
+        for (uint32_t wi : cc.cks_words) {
+            const uint32_t wb = cc.word_bytes, lo = std::max(pos, first), hi = std::min(pos + wb, first + nbytes);
+            if (lo < hi) {
+                snprintf(buf, sizeof buf, "%s(((uint64_t)w%u_0 >> %uu) & 0x%llxull) << %uu", e.empty() ? "" : " | ", col(c, wi), 8 * (lo - pos),
+                         (unsigned long long)((hi - lo) >= 8 ? ~0ull : ((1ull << (8 * (hi - lo))) - 1ull)), 8 * (lo - first));
+                e += buf;
+            }
+            pos += wb;
+        }
+        return e.empty() ? std::string("0ull") : e;
+    };
+    for (uint32_t k = 0; k < n_cks; ++k) {
+        const Comp& cc = w->comps[cks_comp[k]];
+        if (!cc.cks_source.empty()) continue;
+        spec_bytes[k] = (uint32_t)cc.cks_words.size() * cc.word_bytes;
+        spec_memo[k] = spec_bytes[k] > 8 && spec_bytes[k] <= 12;
+        if (spec_memo[k]) {
+            const std::string tail = chunk_expr(cc, cks_comp[k], 8, spec_bytes[k] - 8);
+            sfmt(s, "    uint32_t mt%u = (uint32_t)(%s); uint64_t ma%u = a.n_saves ? sea_diffuse(SEA_K1 ^ (uint64_t)mt%u) : 0ull;   // memoised tail of checksum spec %u\n", k, tail.c_str(), k, k, k);
+        }
+    }
     if (marks) {
         sfmt(s, "    // RollbackDespawned markers (despawn.rs:45-46): live-only, never part of a snapshot\n"
                 "    const uint64_t mk_dis = *reinterpret_cast<const uint64_t*>(a.live + %lluull + wi8);\n"
@@ -402,6 +451,17 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             s += "                { GgrsComponent cv; cv.slot = e0;\n";
             for (uint32_t wi = 0; wi < cc.n_words; ++wi) sfmt(s, "                  cv.w[%u] = w%u_0;\n", wi, col(c, wi));
             sfmt(s, "                  hx = (alive_0 && p%u_0) ? sea_pair_pre(ordB_0, ggrs_hash_%u::ggrs_hash(cv)) : 0ull; }\n", c, c);
+        } else if (spec_memo[k]) {
+            // 8 < bytes <= 12 (one full word + a tail of <= 4 bytes, the stress_test's three f32): SeaHasher spelled out, with the
+            // tail's diffuse memoised -- a word no step changed since the last SaveWorld (translation.z, velocity.z of a 2-D
+            // simulation) hashes to what it hashed to then.  Value-keyed and wave-uniform: any lane that changed recomputes all.
+            const std::string full = chunk_expr(cc, c, 0, 8), tail = chunk_expr(cc, c, 8, spec_bytes[k] - 8);
+            sfmt(s, "                { const uint32_t tv = (uint32_t)(%s);\n"
+                    "                  if (__ballot(tv != mt%u) != 0ull) { mt%u = tv; ma%u = sea_diffuse(SEA_K1 ^ (uint64_t)tv); }\n"
+                    "                  const uint64_t A = sea_diffuse(SEA_K0 ^ (%s));\n"
+                    "                  const uint64_t inner = sea_diffuse(ma%u ^ SEA_K2 ^ SEA_K3 ^ A ^ %uull);\n"
+                    "                  hx = (alive_0 && p%u_0) ? sea_pair_pre(ordB_0, inner) : 0ull; }\n",
+                 tail.c_str(), k, k, k, full.c_str(), k, spec_bytes[k], c);
         } else {
             s += "                { SeaStream st;";
             for (uint32_t wi : cc.cks_words) sfmt(s, " st.write(w%u_0, %uu);", col(c, wi), cc.word_bytes);
