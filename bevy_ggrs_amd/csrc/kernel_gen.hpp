@@ -166,6 +166,10 @@ constexpr uint32_t JIT_MAX_COLS = 64;        // word columns (one bit each in th
 // slot (the stress_test: 15), 512-thread workgroups beyond (<= 80 / <= 128 VGPRs).
 struct JitPersistShape { int tpb, min_waves_per_simd; };
 inline JitPersistShape jit_persist_shape(uint32_t units) {
+    if (const char* v = getenv("GGRS_JIT_PERSIST_TPB")) {            // A/B: workgroup size of the persistent form (256 | 512 | 1024), 8 waves per SIMD
+        const int t = atoi(v);
+        if ((t == 256 || t == 512 || t == 1024) && units <= 16) return {t, 8};
+    }
     if (units <= 16) return {1024, 8};
     if (units <= 26) return {512, 6};
     return {512, 4};
@@ -270,6 +274,15 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
          "// a wave-uniform pointer pinned into an SGPR pair: `sgpr_base(p) + lane_offset_u32` selects the saddr form of\n"
          "// global_load / global_store (no 64-bit VALU address arithmetic, no 64-bit address registers per word)\n"
          "__device__ __forceinline__ GGRS_G unsigned char* sgpr_base(const unsigned char* p) { unsigned long x = (unsigned long)p; asm volatile(\"\" : \"+s\"(x)); return (GGRS_G unsigned char*)x; }\n"
+         "// stores of one word to `base + lo` (base wave-uniform in an SGPR pair, lo a 32-bit lane offset), written as inline asm: the\n"
+         "// compiler otherwise materialises a 64-bit VGPR address per store -- into ONE register pair it recomputes before every store,\n"
+         "// which serialises a snapshot's store burst behind VALU address arithmetic (two extra VALU ops per stored word)\n"
+         "#define GGRS_ST(NAME, INSN, T, C) __device__ __forceinline__ void NAME(const unsigned char* base, uint32_t lo, T v) { const unsigned long b = (unsigned long)base; asm volatile(INSN \" %0, %1, %2\" : : \"v\"(lo), C(v), \"s\"(b) : \"memory\"); }\n"
+         "GGRS_ST(st1, \"global_store_byte\", uint32_t, \"v\") GGRS_ST(st2, \"global_store_short\", uint32_t, \"v\") GGRS_ST(st4, \"global_store_dword\", uint32_t, \"v\") GGRS_ST(st8, \"global_store_dwordx2\", uint64_t, \"v\")\n"
+         "#undef GGRS_ST\n"
+         "#define GGRS_ST(NAME, INSN, T, C) __device__ __forceinline__ void NAME(const unsigned char* base, uint32_t lo, T v) { const unsigned long b = (unsigned long)base; asm volatile(INSN \" %0, %1, %2 nt\" : : \"v\"(lo), C(v), \"s\"(b) : \"memory\"); }\n"
+         "GGRS_ST(st1nt, \"global_store_byte\", uint32_t, \"v\") GGRS_ST(st2nt, \"global_store_short\", uint32_t, \"v\") GGRS_ST(st4nt, \"global_store_dword\", uint32_t, \"v\") GGRS_ST(st8nt, \"global_store_dwordx2\", uint64_t, \"v\")\n"
+         "#undef GGRS_ST\n"
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
@@ -333,7 +346,8 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
         const uint32_t cl = col(c, k), wb = w->comps[c].word_bytes;
         if (w->col_ts[cl] != w->ts) return false;                    // every rollback column shares the tile stride
-        sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n    %s w%u_0 = 0;\n", cl, (unsigned long long)w->col_off[cl], wb, wtype(c), cl);
+        sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n#define b%u(blk) ((blk) + (%lluull + tbase))\n    %s w%u_0 = 0;\n",
+             cl, (unsigned long long)w->col_off[cl], wb, cl, (unsigned long long)w->col_off[cl], wtype(c), cl);
     }
     // loads / stores of the words of the lane's slot from / to a block, each guarded by its bit of a wave-uniform row mask
     // Row masks are wave-uniform.  The masks of a steady-state tick are known when the kernel is written -- a SaveWorld stores
@@ -355,8 +369,8 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         auto one = [&](uint32_t c, uint32_t cl, const char* ind, bool guard) {
             char g[64] = "";
             if (guard) snprintf(g, sizeof g, "if ((%s >> %uu) & 1ull) ", mask, cl);
-            if (nt) sfmt(s, "%s%s__builtin_nontemporal_store((%s)w%u_0, (GGRS_G %s*)o%u(%s));\n", ind, g, mtype(c), cl, mtype(c), cl, dst);
-            else sfmt(s, "%s%s*(GGRS_G %s*)o%u(%s) = (%s)w%u_0;\n", ind, g, mtype(c), cl, dst, mtype(c), cl);
+            const uint32_t wb = w->comps[c].word_bytes;
+            sfmt(s, "%s%sst%u%s(b%u(%s), lo%u, w%u_0);\n", ind, g, wb, nt ? "nt" : "", cl, dst, wb, cl);
         };
         const std::string in2 = std::string(indent) + "    ";
         sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)HOT);

@@ -116,19 +116,35 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
         dist.destroy_process_group()
 
 
-def _native_fanout_rank(rank, size, id_bytes, n, D, steps, bpr, q):
-    """One rank of the C-ABI fan-out (ggrs_hip_fanout_*): RCCL is called inside libggrs_hip.so; torch is not involved."""
+def _n_devices():
+    import ctypes as C
+    from bevy_ggrs_amd import _ffi
+    n = C.c_int(0)
+    hip = C.CDLL("libamdhip64.so")
+    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+
+
+def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q):
+    """One rank of the C-ABI fan-out (ggrs_hip_fanout_*): RCCL is called inside libggrs_hip.so; torch is not involved.
+    Rank r runs on HIP device r % devices (one rank per GPU wherever the box has them); rank 0 creates the ncclUniqueId and
+    hands it to the others -- the host's only job in the real thing too."""
     try:
         import bevy_ggrs_amd as bg
         import common as cm
         from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+        if rank == 0:
+            id_bytes = RcclFanout.unique_id()
+            for _ in range(size - 1): id_q.put(id_bytes)
+        else:
+            id_bytes = id_q.get(timeout=120)
+        device = rank % max(1, _n_devices())
 
         class _Dist:                                          # SpeculativeFanout only asks for rank and size here
             def get_rank(self): return rank
             def get_world_size(self): return size
 
         cap = n + 100 * (steps + D + 2) * 2
-        w = bg.World(cap, max_depth=D + 2)
+        w = bg.World(cap, max_depth=D + 2, device=device)
         ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
         if rank == 0:
             vel, ttl = cm.synthetic_particles(n, ttl="despawn")
@@ -138,6 +154,7 @@ def _native_fanout_rank(rank, size, id_bytes, n, D, steps, bpr, q):
         else:
             w.spawn(0, {})                                    # seals the world: the layout is fixed, the state arrives by broadcast
         native = RcclFanout(w, rank, size, id_bytes)
+        assert native.comm_info() == (rank, size, device)
         fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, max_inflight=2,
                                 branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
                                 confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
@@ -157,14 +174,20 @@ def _native_fanout_rank(rank, size, id_bytes, n, D, steps, bpr, q):
         q.put((rank, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
 
 
-def _run_native(size, n=700, D=4, steps=6, bpr=2):
+def _run_native(size, n=700, D=4, steps=6, bpr=2, env=None):
     import multiprocessing as mp
-    from bevy_ggrs_amd.fanout import RcclFanout
+    import os
     ctx = mp.get_context("spawn")
-    id_bytes = RcclFanout.unique_id()
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_native_fanout_rank, args=(r, size, id_bytes, n, D, steps, bpr, q)) for r in range(size)]
-    for p in procs: p.start()
+    q, id_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_native_fanout_rank, args=(r, size, id_q, n, D, steps, bpr, q)) for r in range(size)]
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})                              # spawned children inherit the parent's environment at start()
+    try:
+        for p in procs: p.start()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
     res = {}
     try:
         for _ in range(size):
@@ -194,11 +217,44 @@ def test_native_fanout_world_size_1_matches_serial_reference():
         assert (np.asarray(state[k]) == np.asarray(v)).all(), k
 
 
-def test_native_fanout_two_ranks_on_one_gpu():
-    """World size 2 over RCCL with both ranks on the one visible GPU (correctness only): rank 1 receives
-    the confirmed world by ncclBroadcast, both ranks run their own branches, the all-gathered table must equal the
-    serial reference of all 2 x bpr branches and both ranks must end in the same confirmed state.  RCCL builds that
-    refuse two ranks on one device make this a skip, not a failure."""
+def _double_lib():
+    """tests/cpp/rccl_double.cpp built on demand: the shared-memory stand-in for librccl.so (same-box transport)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, out = os.path.join(root, "tests", "cpp", "rccl_double.cpp"), os.path.join(root, "tests", "cpp", "_build", "librccl_double.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    return out
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_native_fanout_ranks_over_the_transport_double(size):
+    """The rank != 0 half of ggrs_hip_fanout_* on a ONE-GPU box: RCCL refuses two ranks per device, so the collective library is
+    swapped (GGRS_RCCL_LIB) for tests/cpp/rccl_double.cpp, which moves the same collectives through shared memory.  Everything
+    else is the product: ncclBroadcast of rank 0's packed live block into the other ranks' HBM and adoption (len, frame, row
+    versions), every rank's own branch lists, the all-gather of the Checksum(u128)s on the side stream, collect.  The gathered
+    table must equal the serial reference of all size x bpr branches and every rank must end in the same confirmed state."""
+    from test_fanout_gloo import _serial_reference
+    n, D, steps, bpr = 700, 4, 6, 2
+    res = _run_native(size, n, D, steps, bpr, env={"GGRS_RCCL_LIB": _double_lib()})
+    assert all(r[0] == "ok" for r in res.values()), res
+    ref, ref_state = _serial_reference(n, D, size * bpr, steps)
+    for r in range(size):
+        out, state = res[r][1], res[r][2]
+        assert len(out) == steps
+        for got, want in zip(out, ref):
+            assert got["confirmed_checksum"] == want["confirmed_checksum"]
+            assert got["branch_checksums"] == want["branch_checksums"]
+        for k, v in ref_state.items():
+            assert (np.asarray(state[k]) == np.asarray(v)).all(), (r, k)
+
+
+def test_native_fanout_two_ranks_over_rccl():
+    """World size 2 over the real RCCL, rank r on device r % devices: on a box with >= 2 GPUs this is the real thing; with both
+    ranks on the one visible GPU, RCCL builds that refuse two ranks per device make this a skip, not a failure (the transport
+    double above covers the library's side of it)."""
     from test_fanout_gloo import _serial_reference
     n, D, steps, bpr = 700, 4, 6, 2
     res = _run_native(2, n, D, steps, bpr)
