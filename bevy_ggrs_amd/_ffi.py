@@ -76,6 +76,7 @@ KERNEL_FORM_TILES, KERNEL_FORM_PERSISTENT = 1, 2
 _P = C.c_void_p
 SIGNATURES = {
     "ggrs_hip_abi_version": (C.c_int, []),
+    "ggrs_hip_device_count": (C.c_int, []),
     "ggrs_hip_world_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "ggrs_hip_world_create_ex": (C.c_int, [C.POINTER(WorldDesc), C.POINTER(_P)]),
     "ggrs_hip_arena_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),

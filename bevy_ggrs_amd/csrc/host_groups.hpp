@@ -262,12 +262,7 @@ struct JitBatch {
         GenFinArgs f; memset(&f, 0, sizeof f);
         f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = j.len;   // one row per workgroup
         f.out = w->d_results + 2 * (uint64_t)res_first;
-        {
-            ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
-            hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
-        }
-        HIPCHK(w, hipGetLastError());
-        return GGRS_OK;
+        return launch_gen_finalize(w, f, j.n_saves * k);
     }
 };
 
@@ -328,7 +323,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = w->len;
-        j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
+        j.parts = nullptr; j.part_stride = w->gen_part_stride;     // the row buffer is picked when the group is known to need one
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
         j.nt = (w->nt_copy || cover > w->knobs.jit_persist_min_slots) ? 1u : 0u;
@@ -367,6 +362,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 if (batch.try_add(w, jb, g, res_base + ns)) { batch.j.dp_s = 0; group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             }
             rc = batch.flush(w); if (rc) return rc;
+            { uint64_t* rows = nullptr; rc = next_gen_parts(w, &rows); if (rc) return rc; j.parts = reinterpret_cast<ggrs_u64*>(rows); }
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             uint64_t rows_off = 0;
             const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off);
@@ -382,11 +378,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 GenFinArgs f; memset(&f, 0, sizeof f);
                 f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup
                 f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
-                {
-                    ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
-                    hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves), dim3(FIN_TPB), 0, w->stream, f);
-                }
-                HIPCHK(w, hipGetLastError());
+                rc = launch_gen_finalize(w, f, j.n_saves); if (rc) return rc;
                 ns += j.n_saves;
             }
         }

@@ -5,6 +5,12 @@
 namespace {
 
 int seal_impl(ggrs_world* w);
+void release_fin_stream(ggrs_world* w) {
+    if (w->fin_stream) { (void)hipStreamSynchronize(w->fin_stream); (void)hipStreamDestroy(w->fin_stream); w->fin_stream = nullptr; }
+    for (auto& e : w->fin_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (w->fin_go) { (void)hipEventDestroy(w->fin_go); w->fin_go = nullptr; }
+    if (w->fin_tail) { (void)hipEventDestroy(w->fin_tail); w->fin_tail = nullptr; }
+}
 // Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
 // failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
 // reports the same error instead of carving a second arena over half-initialised bookkeeping.
@@ -17,6 +23,7 @@ int seal(ggrs_world* w) {
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
+    release_fin_stream(w);
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -265,9 +272,16 @@ int seal_impl(ggrs_world* w) {
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
-        const size_t bytes = (size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8;
+        w->gen_parts_buf_words = (uint64_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride;
+        const size_t bytes = (size_t)w->gen_parts_buf_words * 8 * ggrs_world::GEN_PARTS_BUFS;
         HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes));
         if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream));
+        if (w->knobs.fin_side_stream) {
+            HIPCHK(w, hipStreamCreateWithFlags(&w->fin_stream, hipStreamNonBlocking));
+            for (auto& e : w->fin_done) HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(w, hipEventCreateWithFlags(&w->fin_go, hipEventDisableTiming));
+            HIPCHK(w, hipEventCreateWithFlags(&w->fin_tail, hipEventDisableTiming));
+        }
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;

@@ -53,6 +53,7 @@ struct Knobs {
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
     bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
+    bool fin_side_stream = true;   // GGRS_FIN_SIDE_STREAM=0  k_gen_finalize on the world's own stream (a dependent launch per group)
     int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
@@ -70,6 +71,7 @@ struct Knobs {
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
+        k.fin_side_stream = num("GGRS_FIN_SIDE_STREAM", 1) != 0;
         k.arena_contig = (int)std::min<long long>(1, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
@@ -162,7 +164,15 @@ struct ggrs_world {
     bool tick3_ok = false; Tick3Args tick3_proto{};
     std::vector<uint32_t> tick3_sched_cols, tick3_rest_cols;   // the 7 schedule-owned columns / the untouched columns in row order
     uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
-    uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]
+    uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: GEN_PARTS_BUFS x [saves][n_cks + 1][one row per 256-slot workgroup]
+    // The fold of a per-tile group's partial rows (k_gen_finalize) runs on a SIDE stream behind an event: the world's stream goes
+    // straight on to the next request group instead of paying a dependent launch + its gap per tick (~10 us at 1 M).  The row
+    // buffer rotates so that the next group never waits for a fold that is still reading; a batch's completion event is recorded
+    // behind both streams.  Not used when a consumer reads the result ring in stream order (fan-out: device_results_only).
+    static constexpr int GEN_PARTS_BUFS = 4;
+    hipStream_t fin_stream = nullptr; hipEvent_t fin_done[GEN_PARTS_BUFS] = {}; hipEvent_t fin_go = nullptr, fin_tail = nullptr;
+    bool fin_buf_used[GEN_PARTS_BUFS] = {}; uint32_t gen_parts_turn = 0; uint64_t gen_parts_buf_words = 0;
+    bool fin_dirty = false;              // a fold was queued on fin_stream since the two streams were last joined
     bool gen_ok = false;                 // the generated kernel serves this world's request lists
 
     // pending partials produced by the last advance (valid for the live state as-is)
@@ -217,12 +227,12 @@ struct ggrs_world {
 namespace {
 
 struct ProfScope {
-    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0) : w(w_), cls(c) {
-        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, w->stream); w->prof_bytes[c] += bytes; }
+    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0, hipStream_t stream = nullptr) : w(w_), cls(c), st(stream ? stream : w_->stream) {
+        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); w->prof_bytes[c] += bytes; }
     }
     ~ProfScope() {
-        if (w->prof) { (void)hipEventRecord(b, w->stream); w->prof_events.push_back({a, b, cls}); }
+        if (w->prof) { (void)hipEventRecord(b, st); w->prof_events.push_back({a, b, cls}); }
     }
 };
 

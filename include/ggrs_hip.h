@@ -92,6 +92,7 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
 void ggrs_hip_world_destroy(ggrs_world* w);
 const char* ggrs_hip_last_error(ggrs_world* w);
 int  ggrs_hip_abi_version(void);
+int  ggrs_hip_device_count(void);     /* HIP devices this process sees (0: none -- world creation would fail with GGRS_E_NO_DEVICE) */
 
 /* -------------------------------------------------------------------------------------------
  * Registration (build time).  All registration must precede the first spawn/save.

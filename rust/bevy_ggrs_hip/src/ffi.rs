@@ -110,6 +110,7 @@ unsafe extern "C" {
     pub fn ggrs_hip_world_destroy(w: *mut ggrs_world);
     pub fn ggrs_hip_last_error(w: *mut ggrs_world) -> *const c_char;
     pub fn ggrs_hip_abi_version() -> c_int;
+    pub fn ggrs_hip_device_count() -> c_int;
     // ---- registration
     pub fn ggrs_hip_register_component(w: *mut ggrs_world, name: *const c_char, word_bytes: u32, n_words: u32, comp_id: *mut u32) -> c_int;
     pub fn ggrs_hip_register_component_ex(w: *mut ggrs_world, name: *const c_char, word_bytes: u32, n_words: u32, flags: u32, comp_id: *mut u32) -> c_int;

@@ -321,15 +321,42 @@ fn mirror_component_system<T: HipComponent>(hip: Res<HipWorld>, mut q: Query<(&H
     }
 }
 
-/// Entities whose slot is no longer alive on the device (despawned by a kernel system, or rolled back out of
-/// existence by LoadWorld, src/snapshot/entity.rs:62-98) are despawned on the Bevy side; slots that came back to life
-/// keep their entity (slots are never reused, so the mapping is 1:1 for the whole session).
-fn mirror_despawns(mut commands: Commands, hip: Res<HipWorld>, q: Query<(Entity, &HipSlot)>) {
+/// Marks a Bevy entity whose device slot is currently NOT alive, with the frame at which that was first seen.  A predicted
+/// despawn can still be rolled back (LoadWorld resurrects the slot, src/snapshot/entity.rs:62-98), so the Bevy entity -- and every
+/// non-mirrored component it carries (meshes, handles) -- must survive until the despawn is CONFIRMED.  Game and render queries
+/// that must not see such entities filter `Without<HipDeadSince>`.
+#[derive(Component, Clone, Copy)]
+pub struct HipDeadSince(pub i32);
+
+/// Mirrors device-side liveness onto the Bevy entities.  Slots are never reused, so slot <-> entity is 1:1 for the whole session:
+///   * slot dead, no marker        -> mark `HipDeadSince(frame)` (the entity is hidden from gameplay, not despawned);
+///   * slot alive again, marker    -> a rollback resurrected it: unmark, the entity and its non-mirrored components are intact;
+///   * slot dead, marker confirmed -> no rollback can reach a confirmed frame (ConfirmedFrameCount): despawn the Bevy entity now.
+fn mirror_despawns(
+    mut commands: Commands,
+    hip: Res<HipWorld>,
+    frame: Res<RollbackFrameCount>,
+    confirmed: Res<ConfirmedFrameCount>,
+    q: Query<(Entity, &HipSlot, Option<&HipDeadSince>)>,
+) {
     let alive = hip.alive_mask();
-    for (e, slot) in &q {
+    for (e, slot, dead) in &q {
         let s = slot.0 as usize;
-        if s < hip.len() as usize && (alive[s / 64] >> (s % 64)) & 1 == 0 {
-            commands.entity(e).despawn();
+        if s >= hip.len() as usize {
+            continue;
+        }
+        let is_alive = (alive[s / 64] >> (s % 64)) & 1 == 1;
+        match (is_alive, dead) {
+            (true, Some(_)) => {
+                commands.entity(e).remove::<HipDeadSince>();
+            }
+            (false, None) => {
+                commands.entity(e).insert(HipDeadSince(frame.0));
+            }
+            (false, Some(d)) if d.0 <= confirmed.0 => {
+                commands.entity(e).despawn();
+            }
+            _ => {}
         }
     }
 }

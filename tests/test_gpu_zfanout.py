@@ -117,11 +117,8 @@ def test_state_block_roundtrip_through_torch_arena_and_nccl():
 
 
 def _n_devices():
-    import ctypes as C
     from bevy_ggrs_amd import _ffi
-    n = C.c_int(0)
-    hip = C.CDLL("libamdhip64.so")
-    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+    return int(_ffi.lib.ggrs_hip_device_count())
 
 
 def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q):
