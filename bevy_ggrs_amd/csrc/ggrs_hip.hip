@@ -113,7 +113,6 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
-    release_fin_stream(w);
     jit_release(w->jit_entry); jit_release(w->jit_entry_persist);
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->h_results) (void)hipHostFree(w->h_results);
@@ -526,13 +525,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     }
     if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
     b.ev = w->event_pool.back(); w->event_pool.pop_back();
-    if (w->fin_dirty) {
-        // folds of this list run on the side stream: the batch is complete when BOTH streams have passed this point -- the side
-        // stream waits for the world's stream here, never the other way round (the next list's kernels must not queue behind a fold)
-        HIPCHK(w, hipEventRecord(w->fin_tail, w->stream));
-        HIPCHK(w, hipStreamWaitEvent(w->fin_stream, w->fin_tail, 0));
-        HIPCHK(w, hipEventRecord(b.ev, w->fin_stream));
-    } else HIPCHK(w, hipEventRecord(b.ev, w->stream));
+    HIPCHK(w, hipEventRecord(b.ev, w->stream));
     w->res_head = b.first + n_save; w->pending_results += n_save;
     b.n_folds = (uint32_t)(w->folds.size() - folds_before);
     if (n_saves_out) *n_saves_out = n_save;
@@ -564,7 +557,6 @@ int ggrs_hip_synchronize(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    if (w->fin_stream) HIPCHK(w, hipStreamSynchronize(w->fin_stream));
     return GGRS_OK;
 }
 
@@ -637,7 +629,6 @@ int ggrs_hip_profile_enable(ggrs_world* w, int on) {
 // drains the recorded event pairs into the per-class totals and per-launch lists
 static int profile_drain(ggrs_world* w) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    if (w->fin_stream) HIPCHK(w, hipStreamSynchronize(w->fin_stream));
     for (auto& e : w->prof_events) {
         float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);
         w->prof_ms[e.cls] += ms; w->prof_n[e.cls] += 1;

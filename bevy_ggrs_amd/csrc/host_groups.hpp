@@ -262,7 +262,12 @@ struct JitBatch {
         GenFinArgs f; memset(&f, 0, sizeof f);
         f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = j.len;   // one row per workgroup
         f.out = w->d_results + 2 * (uint64_t)res_first;
-        return launch_gen_finalize(w, f, j.n_saves * k);
+        {
+            ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+            hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
+        }
+        HIPCHK(w, hipGetLastError());
+        return GGRS_OK;
     }
 };
 
@@ -323,7 +328,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = w->len;
-        j.parts = nullptr; j.part_stride = w->gen_part_stride;     // the row buffer is picked when the group is known to need one
+        j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
         j.nt = (w->nt_copy || cover > w->knobs.jit_persist_min_slots) ? 1u : 0u;
@@ -335,7 +340,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             j.fold_wg_parts = reinterpret_cast<ggrs_u64*>(w->d_wg_parts); j.fold_ticket = w->d_ticket;
             j.fold_out = reinterpret_cast<ggrs_u64*>(w->d_results + 2 * (uint64_t)(res_base + ns));
             const uint32_t wpb = w->jit_persist_tpb / 64;
-            const uint32_t gp = std::max(1u, std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs));
+            // grid: the chunks of the group, at most `oversub` x what the device holds at once (1: strictly persistent -- every
+            // workgroup walks several chunks; more: the hardware scheduler hands out workgroups as slots free up, which balances the
+            // tail better, at the price of more rows for tick_fold's last arriver)
+            const uint32_t gp = std::max(1u, std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs * (uint32_t)w->knobs.jit_persist_oversub));
             if (launch) {
                 ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
@@ -362,7 +370,6 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 if (batch.try_add(w, jb, g, res_base + ns)) { batch.j.dp_s = 0; group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             }
             rc = batch.flush(w); if (rc) return rc;
-            { uint64_t* rows = nullptr; rc = next_gen_parts(w, &rows); if (rc) return rc; j.parts = reinterpret_cast<ggrs_u64*>(rows); }
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             uint64_t rows_off = 0;
             const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off);
@@ -378,7 +385,11 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 GenFinArgs f; memset(&f, 0, sizeof f);
                 f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup
                 f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
-                rc = launch_gen_finalize(w, f, j.n_saves); if (rc) return rc;
+                {
+                    ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+                    hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves), dim3(FIN_TPB), 0, w->stream, f);
+                }
+                HIPCHK(w, hipGetLastError());
                 ns += j.n_saves;
             }
         }

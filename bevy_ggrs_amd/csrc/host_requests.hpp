@@ -524,46 +524,8 @@ bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks,
     return false;
 }
 
-// both streams have drained: the side stream's folds are in the result ring
-int join_fin_stream(ggrs_world* w) {
-    if (w->fin_dirty) { HIPCHK(w, hipStreamSynchronize(w->fin_stream)); w->fin_dirty = false; }
-    return GGRS_OK;
-}
-// Folds the per-workgroup partial rows of a group (or a batch of groups) into its Checksum(u128)s: k_gen_finalize, on the side
-// stream behind the group's kernel when the world has one and nobody consumes the result ring in stream order.
-int launch_gen_finalize(ggrs_world* w, const GenFinArgs& f, uint32_t n_blocks) {
-    const bool side = w->fin_stream && !w->device_results_only;
-    hipStream_t st = side ? w->fin_stream : w->stream;
-    if (side) {
-        HIPCHK(w, hipEventRecord(w->fin_go, w->stream));
-        HIPCHK(w, hipStreamWaitEvent(w->fin_stream, w->fin_go, 0));
-    }
-    {
-        ProfScope ps(w, GGRS_KERNEL_CHECKSUM, 0, st);
-        hipLaunchKernelGGL(k_gen_finalize, dim3(n_blocks), dim3(FIN_TPB), 0, st, f);
-    }
-    HIPCHK(w, hipGetLastError());
-    if (side) {
-        const uint32_t turn = w->gen_parts_turn % ggrs_world::GEN_PARTS_BUFS;
-        HIPCHK(w, hipEventRecord(w->fin_done[turn], w->fin_stream));
-        w->fin_buf_used[turn] = true; w->fin_dirty = true;
-    }
-    return GGRS_OK;
-}
-// the row buffer the next per-tile group writes its partial rows to (rotating: the previous group's fold may still be reading its own)
-int next_gen_parts(ggrs_world* w, uint64_t** parts_out) {
-    if (w->fin_stream && !w->device_results_only) {
-        ++w->gen_parts_turn;
-        const uint32_t turn = w->gen_parts_turn % ggrs_world::GEN_PARTS_BUFS;
-        if (w->fin_buf_used[turn]) HIPCHK(w, hipStreamWaitEvent(w->stream, w->fin_done[turn], 0));   // long complete: GEN_PARTS_BUFS groups ago
-        *parts_out = w->d_gen_parts + (uint64_t)turn * w->gen_parts_buf_words;
-    } else *parts_out = w->d_gen_parts;
-    return GGRS_OK;
-}
-
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    { const int rc = join_fin_stream(w); if (rc) return rc; }
     run_host_folds(w, ~0u);
     w->stage_used = 0;
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);

@@ -5,12 +5,6 @@
 namespace {
 
 int seal_impl(ggrs_world* w);
-void release_fin_stream(ggrs_world* w) {
-    if (w->fin_stream) { (void)hipStreamSynchronize(w->fin_stream); (void)hipStreamDestroy(w->fin_stream); w->fin_stream = nullptr; }
-    for (auto& e : w->fin_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    if (w->fin_go) { (void)hipEventDestroy(w->fin_go); w->fin_go = nullptr; }
-    if (w->fin_tail) { (void)hipEventDestroy(w->fin_tail); w->fin_tail = nullptr; }
-}
 // Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
 // failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
 // reports the same error instead of carving a second arena over half-initialised bookkeeping.
@@ -23,7 +17,6 @@ int seal(ggrs_world* w) {
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
-    release_fin_stream(w);
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -207,7 +200,7 @@ int seal_impl(ggrs_world* w) {
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
     // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
-    const uint64_t wg_parts_bytes = align_up((uint64_t)(4 * w->n_cu + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
+    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max<uint64_t>(4 * w->n_cu + 64, w->cap_pad / 512 + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
     const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
@@ -272,16 +265,9 @@ int seal_impl(ggrs_world* w) {
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
-        w->gen_parts_buf_words = (uint64_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride;
-        const size_t bytes = (size_t)w->gen_parts_buf_words * 8 * ggrs_world::GEN_PARTS_BUFS;
+        const size_t bytes = (size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8;
         HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes));
         if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream));
-        if (w->knobs.fin_side_stream) {
-            HIPCHK(w, hipStreamCreateWithFlags(&w->fin_stream, hipStreamNonBlocking));
-            for (auto& e : w->fin_done) HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHK(w, hipEventCreateWithFlags(&w->fin_go, hipEventDisableTiming));
-            HIPCHK(w, hipEventCreateWithFlags(&w->fin_tail, hipEventDisableTiming));
-        }
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;

@@ -48,12 +48,12 @@ struct Knobs {
     bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel: k_tick3 for the particles world, per-request kernels for the rest
     uint64_t jit_particles_max_slots = 416 * 1024;   // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (profiles/r02jit/cross.txt)
     uint64_t jit_persist_min_slots = 416 * 1024;     // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0: never
+    int jit_persist_oversub = 1;   // GGRS_JIT_PERSIST_OVERSUB=n  persistent form: grid = up to n x the workgroups the device holds at once
     int host_fold_max_wgs = 256;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
     bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
-    bool fin_side_stream = true;   // GGRS_FIN_SIDE_STREAM=0  k_gen_finalize on the world's own stream (a dependent launch per group)
     int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
@@ -66,12 +66,12 @@ struct Knobs {
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
         k.jit_particles_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024));
         k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 416 * 1024));
+        k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 256)));
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
-        k.fin_side_stream = num("GGRS_FIN_SIDE_STREAM", 1) != 0;
         k.arena_contig = (int)std::min<long long>(1, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
@@ -164,15 +164,7 @@ struct ggrs_world {
     bool tick3_ok = false; Tick3Args tick3_proto{};
     std::vector<uint32_t> tick3_sched_cols, tick3_rest_cols;   // the 7 schedule-owned columns / the untouched columns in row order
     uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
-    uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: GEN_PARTS_BUFS x [saves][n_cks + 1][one row per 256-slot workgroup]
-    // The fold of a per-tile group's partial rows (k_gen_finalize) runs on a SIDE stream behind an event: the world's stream goes
-    // straight on to the next request group instead of paying a dependent launch + its gap per tick (~10 us at 1 M).  The row
-    // buffer rotates so that the next group never waits for a fold that is still reading; a batch's completion event is recorded
-    // behind both streams.  Not used when a consumer reads the result ring in stream order (fan-out: device_results_only).
-    static constexpr int GEN_PARTS_BUFS = 4;
-    hipStream_t fin_stream = nullptr; hipEvent_t fin_done[GEN_PARTS_BUFS] = {}; hipEvent_t fin_go = nullptr, fin_tail = nullptr;
-    bool fin_buf_used[GEN_PARTS_BUFS] = {}; uint32_t gen_parts_turn = 0; uint64_t gen_parts_buf_words = 0;
-    bool fin_dirty = false;              // a fold was queued on fin_stream since the two streams were last joined
+    uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]
     bool gen_ok = false;                 // the generated kernel serves this world's request lists
 
     // pending partials produced by the last advance (valid for the live state as-is)
@@ -227,12 +219,12 @@ struct ggrs_world {
 namespace {
 
 struct ProfScope {
-    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
-    ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0, hipStream_t stream = nullptr) : w(w_), cls(c), st(stream ? stream : w_->stream) {
-        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); w->prof_bytes[c] += bytes; }
+    ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0) : w(w_), cls(c) {
+        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, w->stream); w->prof_bytes[c] += bytes; }
     }
     ~ProfScope() {
-        if (w->prof) { (void)hipEventRecord(b, st); w->prof_events.push_back({a, b, cls}); }
+        if (w->prof) { (void)hipEventRecord(b, w->stream); w->prof_events.push_back({a, b, cls}); }
     }
 };
 

@@ -25,8 +25,6 @@ KNOBS = [
     {"GGRS_JIT_DP": "0"},
     {"GGRS_JIT_DP": "3"},
     {"GGRS_ROW_VERSIONS": "0"},
-    {"GGRS_FIN_SIDE_STREAM": "0"},
-    {"GGRS_FIN_SIDE_STREAM": "0", "GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},
     {"GGRS_ARENA_CONTIG": "0"},
     {"GGRS_DEBUG_POISON": "1"},
 ]
