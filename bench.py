@@ -322,6 +322,78 @@ def measure_single(bg, cm, torch, args, contig, light=False):
     return m
 
 
+def measure_p2p(bg, cm, torch, args):
+    """BASELINE config 4: a 2-player P2P session's rollbacks at 120 ms RTT, 100 k entities -- no sockets: every tick a late remote
+    input invalidates the last r predicted frames (r drawn per tick from 0..depth, as tests/common.py::P2PShapeDriver draws it), so
+    the request list is [Load(F-r), Adv, (Save, Adv) x (r-1)] + [Save(F), Adv]; ConfirmedFrameCount trails by `depth` frames.
+    One list per tick through enqueue / collect with one tick in flight; every Checksum(u128) is compared with the CPU oracle
+    driven by the same script."""
+    n, R, K, W = args.entities, args.depth, args.steps, args.warmup
+    stream = torch.cuda.current_stream().cuda_stream
+    w = bg.World(n, max_depth=R + 1, stream=stream)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    w.set_depth(R); w.set_synctest_check_distance(-1)
+    lists = {}
+    for r in range(R):                                        # r frames rolled back: one reusable ctypes list per depth
+        reqs = ([bg.LoadGameState(0)] + [x for i in range(r) for x in (([bg.SaveGameState(0)] if i else []) + [bg.AdvanceFrame((0,))])]) if r else []
+        reqs += [bg.SaveGameState(0), bg.AdvanceFrame((0,))]
+        arr, keep, n_save = w.build_requests(reqs)
+        lists[r] = (arr, keep, n_save, len(reqs), [i for i, q in enumerate(reqs) if isinstance(q, bg.SaveGameState)])
+    rng = np.random.default_rng(4)
+    out = (C.c_uint64 * (2 * R))()
+    F, script, got = 0, [], []
+
+    def enqueue():
+        nonlocal F
+        r = int(rng.integers(0, R + 1)); r = min(r, F, R - 1)
+        arr, _k, n_save, n_req, save_idx = lists[r]
+        if r: arr[0].frame = F - r
+        for k, i in enumerate(save_idx): arr[i].frame = F - r + (k + 1 if r else 0) if r else F
+        if r: arr[save_idx[-1]].frame = F
+        if F - R >= 0: w.set_confirmed(F - R)
+        w.enqueue_requests_raw(arr, n_req)
+        script.append((F, r, n_save)); F += 1
+
+    def collect(k):
+        n_save = script[k][2]
+        w.collect_checksums_raw(out, n_save)
+        got.append([int(out[2 * i]) | (int(out[2 * i + 1]) << 64) for i in range(n_save)])
+    for _ in range(W):
+        enqueue(); collect(len(got))
+    w.synchronize(); torch.cuda.synchronize()
+    first = len(got)
+    t0 = time.perf_counter()
+    enqueue()
+    for _ in range(K - 1):
+        enqueue(); collect(len(got))
+    collect(len(got))
+    w.synchronize(); torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    advances = sum(r + 1 for _f, r, _s in script[first:])
+    w.profile_enable(True)
+    for _ in range(min(K, 50)):
+        enqueue(); collect(len(got))
+    prof, pbytes, info = w.profile_read(), w.profile_bytes(), w.kernel_info()
+    w.profile_enable(False)
+    live = w.active_count(); w.close()
+    # ---- the CPU oracle under the same script
+    from oracle.binding import FLAT, OracleWorld
+    o = OracleWorld(n, R + 1, FLAT)
+    oids = cm.build_particles(o); cm.spawn_particles(o, oids, n, vel, ttl); o.set_depth(R)
+    want = []
+    for (f, r, _s) in script:
+        reqs = ([bg.LoadGameState(f - r)] + [x for i in range(r) for x in (([bg.SaveGameState(f - r + i)] if i else []) + [bg.AdvanceFrame((0,))])]) if r else []
+        reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
+        if f - R >= 0: o.set_confirmed(f - R)
+        want.append(o.handle_requests(reqs))
+    return {"secs": secs, "advances": advances, "live": live, "prof": prof, "prof_bytes": pbytes, "info": info,
+            "parity": {"checked_ticks": len(script), "checked_saves": sum(len(x) for x in want), "equal": got == want,
+                       "oracle": "oracle/ggrs_oracle.cpp FLAT variant driven by the same rollback script"},
+            "mean_rollback": sum(r for _f, r, _s in script[first:first + K]) / K}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,10 +410,10 @@ def main():
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
-    ap.add_argument("--arena", choices=["both", "paged", "contig"], default="both",
-                    help="single-GPU path: `value` is ALWAYS measured on the library's default paged arena unless 'contig' is forced; 'both' (default) "
-                         "also measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
-                         "as roofline.contig_arena_variant")
+    ap.add_argument("--arena", choices=["both", "paged", "contig"], default="paged",
+                    help="single-GPU path: `value` is measured on the library's default paged arena unless 'contig' is forced; 'both' also "
+                         "measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
+                         "as roofline.contig_arena_variant (it pays for k_tick3's 16-byte store streams: GGRS_ROW_VERSIONS=0 / GGRS_TICK_JIT=0 worlds)")
     ap.add_argument("--paged-arena", action="store_true", help="same as --arena paged")
     ap.add_argument("--schema", choices=["headline", "full"], default="headline",
                     help="headline: BASELINE's 3 registered components (60 B/entity); full: the reference stress_test's POD schema "
@@ -350,9 +422,17 @@ def main():
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
     ap.add_argument("--oversubscribe", action="store_true", help="--gpus N with fewer than N visible devices: rank r runs on device r %% devices (correctness only)")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N: print the N rank command lines (JSON, one per line) and exit")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=3,
+                    help="BASELINE.json config: 3 (default) = the headline, stress_test 1 M x depth 8; 2 = 10 k entities; 4 = P2P-shaped rollbacks "
+                         "(0..8 frames per tick) at 100 k; 5 = 256 predicted-input branches x 100 k x 8 frames (all on this node's GPUs)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
     if args.paged_arena: args.arena = "paged"
+    if args.config == 2: args.entities = 10_000
+    if args.config == 4: args.entities = 100_000
+    if args.config == 5:
+        args.entities, args.fanout = 100_000, True
+        if args.branches == 1: args.branches = max(1, 256 // max(1, args.gpus))
 
     # ---- `--gpus N` with no launcher around this process: start the N ranks here
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -391,6 +471,28 @@ def main():
     comm_size = world_size
 
     variant = None
+    if args.config == 4 and not distributed:
+        import torch  # noqa: F811
+        m4 = measure_p2p(bg, cm, torch, args)
+        t_ms, t_n = m4["prof"]["tick"]
+        avg_s = t_ms / max(t_n, 1) * 1e-3
+        bpl = m4["prof_bytes"]["tick"] / max(t_n, 1)
+        line = {"metric": f"rollback-resim entity-frames/sec, P2P-shaped rollbacks (0..{D} frames per tick) at {n} entities; GB/s vs HBM peak",
+                "value": m4["live"] * m4["advances"] / m4["secs"], "unit": "entity-frames/s", "n_gpus": 1, "steps": K, "warmup": W,
+                "ms_per_step": m4["secs"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+                "config": {"workload": f"BASELINE config 4: p2p-shaped session, {n} entities x 3 registered components, a rollback of 0..{D - 1} frames every tick "
+                                       f"(mean {m4['mean_rollback']:.2f}), ring depth {D}", "request_group_kernel": m4["info"].get("request_group_kernel"),
+                           "arena_actual": m4["info"].get("arena"), "host_api": "enqueue/collect, 1 tick in flight"},
+                "roofline": {"bound": "hbm", "kernel": m4["info"].get("request_group_kernel"), "achieved": bpl / avg_s / 1e9 if t_n else 0.0, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": bpl / avg_s / 1e9 / HBM_PEAK_GBS if t_n else 0.0, "traffic": None,
+                             "avg_launch_us": avg_s * 1e6, "launches_timed": t_n, "algorithmic_bytes_per_launch": bpl,
+                             "note": f"the whole ring ({n} x 60 B x {D + 1} blocks = {n * 60 * (D + 1) / 1e6:.0f} MB) lives in the 256 MB Infinity Cache: this line is launch / latency bound, "
+                                     "the HBM fraction is reported for completeness, not as its roofline"},
+                "parity": m4["parity"], "cpu_baseline": None}
+        print(json.dumps(line))
+        if not m4["parity"]["equal"]:
+            print("bench.py: PARITY FAILURE (config 4)", file=sys.stderr); sys.exit(1)
+        return
     if not distributed:
         # order-safe: the contiguous arena must be this process's FIRST device allocation (include/ggrs_hip.h,
         # GGRS_WORLD_CONTIG_ARENA), and freeing it leaves nothing cached behind -- so it is measured first, destroyed, and the
@@ -563,6 +665,20 @@ def main():
         "preheat": m.get("preheat"),
         "roofline": roof,
     }
+    if distributed and args.branches > 1:
+        # checksum-only branches (dead-snapshot elimination): integer-multiply bound, not HBM bound.  Roofline = SeaHash `diffuse`
+        # per second against the chip's measured ceiling (scripts/ubench_alu.hip -> profiles/alu_ceiling.json).  Algorithmic
+        # count per SURVEY 8d: 12 u64 multiplies = 6 diffuse per entity per checksummed component per SaveWorld.
+        try:
+            ceil = json.load(open(os.path.join(ROOT, "profiles", "alu_ceiling.json")))
+        except Exception:
+            ceil = None
+        diffuses = 6.0 * 2 * live * D * args.branches * comm_size * K
+        line["roofline_alu"] = {"bound": "valu-int (u64 multiply)", "achieved": diffuses / secs / 1e9, "unit": "G diffuse/s",
+                                "peak": (ceil or {}).get("diffuse_G_per_s"), "frac": (diffuses / secs / 1e9 / ceil["diffuse_G_per_s"]) if ceil else None,
+                                "peak_source": (ceil or {}).get("source"),
+                                "note": "algorithmic diffuses (6 per entity per checksummed component per SaveWorld, 2 components); the kernel hoists the order hash "
+                                        "and memoises unchanged tails, so it executes fewer"}
     if not distributed:
         line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us")}
     parity_failed = False

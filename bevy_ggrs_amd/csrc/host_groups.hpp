@@ -221,10 +221,11 @@ int run_request_groups_tick3(ggrs_world* w, const ggrs_request* reqs, uint32_t n
 // ---------------------------------------------------------------------------------------------------------------------
 // the generated kernel
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr uint64_t JIT_NT_MIN_SLOTS = 416 * 1024;      // snapshot stores of bigger groups are non-temporal: written once, read a tick later, and the ring does not fit the Infinity Cache
 constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-only groups ride in one launch while the world is this small
 // The particles world has two fused paths: the hand-written k_tick3 and the kernel generated for it like for any other world.
-// Below ~416 k slots the generated kernel is the faster one (profiles/r02jit/cross.txt), so a list goes to it while the world
-// is small; a particles world without a generated kernel (no run-time compiler) runs on k_tick3 at every size.
+// Which one serves a list is the knob jit_particles_max_slots (host_world.hpp: measured crossovers); a particles world without a
+// generated kernel (no run-time compiler) runs on k_tick3 at every size.
 bool use_tick3(const ggrs_world* w) {
     if (!w->tick3_ok) return false;
     if (!w->jit_fn || !w->gen_ok) return true;
@@ -331,7 +332,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
-        j.nt = (w->nt_copy || cover > w->knobs.jit_persist_min_slots) ? 1u : 0u;
+        j.nt = (w->nt_copy || cover > JIT_NT_MIN_SLOTS) ? 1u : 0u;
         const bool launch = j.n_ops || !j.src_is_live;
 
         if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {

@@ -44,10 +44,15 @@ struct JitEntry;                         // kernel_gen.hpp: a cached generated m
 // aids; none of them changes a result, and tests/test_gpu_knobs.py runs a bit-exact parity case under each of them.
 // (GGRS_HIP_TRACE / GGRS_HIP_ROCTX, the two tracing switches, and GGRS_RCCL_LIB are process-wide.)
 struct Knobs {
-    bool tick_generic = false;     // GGRS_TICK_GENERIC=1   the particles world runs on the generated kernel at every size (never k_tick3)
+    bool tick_generic = false;     // GGRS_TICK_GENERIC=1   never k_tick3 (the particles world runs on the generated kernel whatever else is set)
     bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel: k_tick3 for the particles world, per-request kernels for the rest
-    uint64_t jit_particles_max_slots = 416 * 1024;   // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (profiles/r02jit/cross.txt)
-    uint64_t jit_persist_min_slots = 416 * 1024;     // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0: never
+    // Which fused kernel serves the particles world (profiles/README.md, r03): with row versions on, the generated kernel wins at
+    // every size (1 M: 87.5 us per tick incl. its finalize launch vs 92.8 for k_tick3; 4 M: 279 vs 300); with GGRS_ROW_VERSIONS=0
+    // every Save moves all 15 rows and k_tick3's 16-byte store streams win above ~416 k slots (115 vs 133 us at 1 M).
+    uint64_t jit_particles_max_slots = ~0ull;        // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (default: all; 416 k with GGRS_ROW_VERSIONS=0)
+    // The persistent form (one launch, in-kernel fold) is correct at every size but measured slower than the per-tile grid + its
+    // k_gen_finalize launch (1 M: 91.8 vs 87.5 us per tick, 4 M: 308 vs 279): opt-in.
+    uint64_t jit_persist_min_slots = 0;              // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0 (default): never
     int jit_persist_oversub = 1;   // GGRS_JIT_PERSIST_OVERSUB=n  persistent form: grid = up to n x the workgroups the device holds at once
     int host_fold_max_wgs = 256;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
@@ -64,8 +69,10 @@ struct Knobs {
         auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
         k.tick_generic = num("GGRS_TICK_GENERIC", 0) != 0;
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
-        k.jit_particles_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 416 * 1024));
-        k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 416 * 1024));
+        k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
+        k.jit_particles_max_slots = getenv("GGRS_JIT_PARTICLES_MAX_SLOTS") ? (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 0))
+                                                                            : (k.row_versions ? ~0ull : 416ull * 1024);
+        k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 0));
         k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 256)));
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;

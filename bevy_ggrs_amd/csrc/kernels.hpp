@@ -1000,12 +1000,15 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
         const uint64_t* p = f.parts + ((uint64_t)k * nc + row) * f.part_stride;
         const bool is_cnt = row == f.n_cks;
         uint64_t x = 0, sum = 0;
-        for (uint32_t i0 = (wave % wpr) * 64u + lane; i0 < f.n_parts; i0 += 4u * wpr * 64u) {
-            uint64_t v[4];
+        // the rows sit in other XCDs' L2 / HBM: the fold is latency-bound unless every load of a lane is in flight at once --
+        // 16 per trip (a 1 M-entity world: 3907 values per row over 5 waves = 13 per lane: ONE round trip)
+        constexpr int INFL = 16;
+        for (uint32_t i0 = (wave % wpr) * 64u + lane; i0 < f.n_parts; i0 += (uint32_t)INFL * wpr * 64u) {
+            uint64_t v[INFL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * wpr * 64u; v[u] = i < f.n_parts ? p[i] : 0ULL; }
+            for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * wpr * 64u; v[u] = i < f.n_parts ? p[i] : 0ULL; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { x ^= v[u]; sum += v[u]; }
+            for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; }
         }
         x = wave_xor(x);
 #pragma unroll

@@ -25,7 +25,7 @@ def main():
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             per.setdefault(name, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, tv in per.items():
-        if "ggrs::k_tick" not in name or "finalize" in name:
+        if not ("ggrs::k_tick" in name or "ggrs_jit_tick" in name or "k_gen_finalize" in name):
             continue
         v = [d for _, d in sorted(tv)]
         big = [x for x in v if x > max(v) / 2]

@@ -41,17 +41,24 @@ def main():
                 d[name + "_KiB_mean"] = sum(v) / len(v)
                 d["dispatches_" + name] = len(agg[k])
         if "FETCH_SIZE_KiB_mean" in d and "WRITE_SIZE_KiB_mean" in d:
-            d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024
+            # the x2 FETCH correction is the guide's calibration for WIDE (16 B per lane) coalesced reads: k_tick3 / k_copy_state.  The
+            # generated kernel reads 4 bytes per lane (uncalibrated width): its FETCH_SIZE is reported as is AND doubled, and only
+            # WRITE_SIZE (calibrated against a known snapshot copy) is relied on -- reads are 10 % of its traffic.
+            wide = "ggrs_jit" not in k
+            d["hbm_bytes_per_launch_corrected"] = ((2 if wide else 1) * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024
+            d["fetch_correction"] = "x2 (16 B per lane reads, MI355X_MICROARCH.md)" if wide else "none (4 B per lane reads: uncalibrated width; with x2 the total would be %.0f bytes)" % ((2 * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024)
         out[k] = d
     json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     roof = {}
     for k, d in out.items():
         if isinstance(d, dict) and "hbm_bytes_per_launch_corrected" in d:
-            if ("k_tick3<" in k or "k_tick2<" in k or "k_tick<" in k or k.endswith("k_tick")) and d.get("dispatches_FETCH_SIZE", 0) >= 20:
+            if ("k_tick3<" in k or "ggrs_jit_tick" in k) and d.get("dispatches_FETCH_SIZE", 0) >= 20 and d.get("dispatches_FETCH_SIZE", 0) >= roof.get("_n", 0):
+                roof["_n"] = d["dispatches_FETCH_SIZE"]                # the kernel that served the bench's ticks: the one with the most dispatches
                 roof["k_tick_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
                 roof["kernel"] = k
             if "k_copy_state" in k:
                 roof["k_copy_state_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
+    roof.pop("_n", None)
     if roof:
         roof["source"] = os.path.join(dst, "pmc_summary.json")
         roof["entities"] = 1000000; roof["depth"] = 8       # the workload scripts/gpu_round.sh profiles (bench.py defaults)

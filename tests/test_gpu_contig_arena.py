@@ -47,7 +47,7 @@ def _child(n, ticks, free_first=False):
 def test_contiguous_arena_world_matches_oracle(n, ticks):
     out = _child(n, ticks)
     assert out["arena"].startswith("contiguous"), out          # the request was honoured: first allocation of the process, k_tick3 world, < 1.5 GiB
-    assert out["kernel"].startswith("k_tick3"), out
+    assert out["kernel"].startswith(("k_tick3", "ggrs_jit_tick")), out
     assert out["equal"] and out["saves"] >= 8 * (ticks - 9), out
 
 
