@@ -14,8 +14,8 @@ namespace {
 struct GroupState {
     Block* src; uint64_t cover; uint32_t src_is_live;
     Block* dsts[MAX_TICK_SAVES];
-    std::vector<uint32_t> save_ver[MAX_TICK_SAVES];   // the versions Save k's slot holds once the group has run
     uint64_t save_rows[MAX_TICK_SAVES];               // bit c: column c is stored with Save k (row versions)
+    // (the versions Save k's slot holds once the group has run live in w->group_save_ver, [k][column]: no allocation per group)
 };
 // LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
 int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState& g) {
@@ -62,7 +62,9 @@ int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int
     if (d) {
         g.cover = std::max(g.cover, d->dirty_len); d->len = w->len;
         g.save_rows[k] = rows_to_store(w, *d);
-        g.save_ver[k] = w->cur_ver;
+        const size_t nc = w->cur_ver.size();
+        if (w->group_save_ver.size() < (size_t)MAX_TICK_SAVES * nc) w->group_save_ver.resize((size_t)MAX_TICK_SAVES * nc);
+        std::copy(w->cur_ver.begin(), w->cur_ver.end(), w->group_save_ver.begin() + (size_t)k * nc);
     }
     return GGRS_OK;
 }
@@ -95,7 +97,11 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead, bool
     w->pending_valid = false;
     if (dead) return;
     const uint64_t new_dirty = std::max(g.src->dirty_len, w->len);
-    for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) { g.dsts[k]->dirty_len = new_dirty; g.dsts[k]->ver = g.save_ver[k]; }
+    const size_t nc = w->cur_ver.size();
+    for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) {
+        g.dsts[k]->dirty_len = new_dirty;
+        std::copy(w->group_save_ver.begin() + (size_t)k * nc, w->group_save_ver.begin() + (size_t)(k + 1) * nc, g.dsts[k]->ver.begin());
+    }
     if (wrote_live) { w->live.dirty_len = new_dirty; ver_sync_live(w); }
 }
 

@@ -144,6 +144,7 @@ struct ggrs_world {
     // ---- row versions (see Block::ver)
     uint32_t ver_counter = 0;
     std::vector<uint32_t> cur_ver;                 // the LOGICAL live state's version per column (ahead of live.ver inside a fused group)
+    std::vector<uint32_t> group_save_ver;          // scratch of the group being assembled: [Save k][column] = the versions slot k will hold
     std::vector<uint8_t> col_ext;                  // a device pointer to this live column was handed out: assume it changes between any two calls
     std::vector<std::vector<uint32_t>> sys_writes; // per system: the columns it may write (one fresh version per AdvanceWorld)
 
