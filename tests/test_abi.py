@@ -108,3 +108,34 @@ def test_rust_shim_uses_only_declared_symbols_and_owns_the_session_driver():
     # (e) spawn payloads + spectator rule
     hr = code[code.index("pub fn handle_requests"):]
     assert "q.spawn_vx = vx.as_ptr()" in hr and "Kind::Spectator" in hr and "ggrs_hip_set_synctest_check_distance(raw, 0)" in hr
+
+
+def test_bench_gpus_dry_run_builds_rank_commands():
+    """`bench.py --gpus N` without a launcher starts its own ranks: --dry-run prints one JSON line per rank --
+    rank r with RANK = LOCAL_RANK = r (bench.py binds device LOCAL_RANK), the same WORLD_SIZE / MASTER_ADDR / MASTER_PORT, the
+    same command line -- and under a launcher (WORLD_SIZE set) it does not spawn again."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ranks = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(ranks) == 2
+    for r, d in enumerate(ranks):
+        assert d["env"]["RANK"] == d["env"]["LOCAL_RANK"] == str(r) and d["env"]["WORLD_SIZE"] == "2"
+        assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and d["env"]["MASTER_PORT"] == ranks[0]["env"]["MASTER_PORT"]
+        assert d["cmd"][-4:] == ["--gpus", "2", "--steps", "7"] and d["cmd"][1].endswith("bench.py")
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert len([l for l in single.stdout.splitlines() if l.startswith("{")]) == 1
+    launched = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                              env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), timeout=120)
+    assert len([l for l in launched.stdout.splitlines() if l.startswith("{")]) == 1       # a rank of an existing launch: no re-spawn
+
+
+def test_kernel_info_without_a_device():
+    """ggrs_hip_world_kernel_info works on a GGRS_WORLD_LAYOUT_ONLY world: the run-time compiler's state is queryable anywhere."""
+    w = bg.World(1000, max_depth=4, flags=bg.GGRS_WORLD_LAYOUT_ONLY)
+    w.register_component("X", 4, 1)
+    info = w.kernel_info()
+    assert info["sealed"] == "0" and info["hiprtc"].startswith(("loaded", "missing")) and "request_group_kernel" in info and info["row_versions"] == "on"

@@ -1,0 +1,114 @@
+"""Row versions (csrc/host_world.hpp): a SaveWorld / LoadWorld moves only the columns whose bytes differ between source and
+destination.  Every way a live column can change behind a fused group's back -- uploads, inserts, spawns with and without the
+component in the bundle, a handed-out device pointer, adopt_live_state, ring depth changes, rollbacks into and out of all of it
+-- driven through the default library, the library with GGRS_ROW_VERSIONS=0 and the CPU oracle: every Checksum(u128), every
+column of the live world AND of every frame the ring still holds must agree bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bevy_ggrs_amd as bg
+import common as cm
+from oracle.binding import FLAT, OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+
+def _ring_contents(w, ids, frames):
+    """Load every frame the ring holds (newest first: a rollback pops what is newer) and record the whole state."""
+    out = {}
+    for f in sorted(frames, reverse=True):
+        if not w.has_snapshot(f): continue
+        w.handle_requests([bg.LoadGameState(f)])
+        st = cm.snapshot_state(w, ids)
+        out[f] = {k: (v.tobytes() if hasattr(v, "tobytes") else v) for k, v in st.items()}
+    return out
+
+
+def _script(w, n, flags_desc):
+    """Particles + an `Extra` component no system writes + a checksummed `Tag`; returns (checksums, live state, ring contents)."""
+    rng = np.random.default_rng(21)
+    T, V, L = cm.build_particles(w, with_spawn=True, ttl_init=30)
+    X = w.register_component("Extra", 4, 3)
+    G = w.register_component("Tag", 2, 1)
+    w.checksum_component(X, [2, 0])
+    w.checksum_component(G, [0])
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    tcols = [np.full(n, cm.f32bits(cm.TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
+    vcols = [cm.f32bits(vel[:, 0]), cm.f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
+    xcols = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for _ in range(3)]
+    w.spawn(n, {T: tcols, V: vcols, L: [ttl], X: xcols, G: [rng.integers(0, 65536, n, dtype=np.uint64).astype(np.uint16)]})
+    ids = (T, V, L, X, G)
+    w.set_depth(6); w.set_confirmed(0)
+    fn = cm.frame_spawn_fn(40)
+    out = []
+
+    def adv(spawn=False):
+        a = bg.AdvanceFrame((cm.INPUT_SPAWN if spawn else 0,))
+        if spawn: a.spawn_vx, a.spawn_vy = fn(w.frame)
+        return a
+
+    def tick(k=1, spawn=False):
+        nonlocal out
+        for _ in range(k):
+            out += w.handle_requests([bg.SaveGameState(w.frame), adv(spawn)])
+
+    tick(4)                                                        # frames 0..3 saved: Extra / Tag reach four ring slots
+    w.upload_word(X, 1, 0, np.arange(n, dtype=np.uint32))          # host edit: the NEXT save must carry it, frames 0..3 must not
+    tick(2)                                                        # 4, 5
+    out += w.handle_requests([bg.LoadGameState(2), adv(), bg.SaveGameState(3), adv(), bg.SaveGameState(4), adv()])   # back before the edit: it is gone again
+    w.insert_component(X, 5, np.array([7, 8, 9], dtype=np.uint32)); w.remove_component(G, 9)
+    tick(2, spawn=True)                                            # 5, 6: the spawn system appends rows WITHOUT Extra / Tag
+    w.spawn(17, {T: None, V: None, L: [np.full(17, 1 << 20, dtype=np.uint64)], X: None})      # API spawn: Extra in the bundle (defaults), Tag not
+    tick(1)
+    # a device pointer to a column is handed out and written behind the library's back
+    if isinstance(w, bg.World):
+        ptr, stride = w.column_device_ptr(X, 0)
+        host = np.full(min(n, 8192), 0xDEADBEEF, dtype=np.uint32)
+        hip = C.CDLL(None)
+        assert hip.hipMemcpy(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), C.c_int(1)) == 0   # H2D into layout tile 0
+    else:
+        w.upload_word(X, 0, 0, np.full(min(n, 8192), 0xDEADBEEF, dtype=np.uint32))
+    tick(2)
+    w.set_depth(3); tick(3); w.set_depth(6); tick(2)               # the ring shrinks and grows: slots are recycled with stale versions
+    out += w.handle_requests([bg.LoadGameState(w.frame - 2), adv(), bg.SaveGameState(w.frame + 1), adv()])
+    if isinstance(w, bg.World): w.adopt_live_state()               # "an external producer rewrote the live block": nothing may be assumed
+    tick(2)
+    live = cm.snapshot_state(w, ids)
+    frames = list(range(0, w.frame + 1))
+    ring = _ring_contents(w, ids, frames)
+    return out, live, ring
+
+
+@pytest.mark.parametrize("n,flags", [(3000, 0), (70_000, 0), (500_000, 0), (3000, bg.GGRS_WORLD_NO_GROUPS)])
+def test_row_versions_agree_with_copy_everything_and_the_oracle(n, flags, monkeypatch):
+    cap = n + 2000
+    a = _script(bg.World(cap, max_depth=7, flags=flags), n, "versions on")
+    monkeypatch.setenv("GGRS_ROW_VERSIONS", "0")
+    b = _script(bg.World(cap, max_depth=7, flags=flags), n, "versions off")
+    monkeypatch.delenv("GGRS_ROW_VERSIONS")
+    o = _script(OracleWorld(cap, 7, FLAT), n, "oracle")
+    assert a[0] == o[0] and b[0] == o[0]
+    cm.assert_states_equal(a[1], o[1], "live, versions on"); cm.assert_states_equal(b[1], o[1], "live, versions off")
+    assert sorted(a[2]) == sorted(o[2]) == sorted(b[2]) and len(o[2]) >= 3
+    for f in o[2]:
+        assert a[2][f] == o[2][f], f"ring frame {f} (row versions on)"
+        assert b[2][f] == o[2][f], f"ring frame {f} (row versions off)"
+
+
+def test_steady_state_tick_moves_only_what_systems_write():
+    """The point of it: in a steady SyncTest tick of the stress_test the library asks its kernel for 320 B per entity (32 loaded +
+    8 x 32 + 32 stored), not 600 -- as counted by ggrs_hip_profile_read_bytes, the numerator of bench.py's roofline."""
+    n = 20_000
+    w = bg.World(n, max_depth=9)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    drv = cm.SyncTestDriver(w, 8, max_prediction=9)
+    for _ in range(12): drv.tick((0,))
+    w.profile_enable(True)
+    for _ in range(5): drv.tick((0,))
+    prof, nbytes = w.profile_read(), w.profile_bytes()
+    w.profile_enable(False)
+    assert prof["tick"][1] == 5 and nbytes["tick"] == 5 * 320 * n, (prof, nbytes)
