@@ -209,7 +209,10 @@ int seal_impl(ggrs_world* w) {
         // when their physical pages were used through a cached mapping earlier in the process (include/ggrs_hip.h,
         // GGRS_WORLD_CONTIG_ARENA): opt-in per world, only for worlds k_tick3 serves, up to 1.5 GiB.  Safety net for the cached
         // mappings the library knows about: once this process has freed a PAGED arena of its own, a later world's request is ignored
-        const bool contig = w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
+        // GGRS_ARENA_CONTIG=2 (experiment, profiles/r03fc): contiguous for particles worlds, paged for all others, no safety net --
+        // the mix that corrupted 4 of 10 first processes in round 2
+        const bool contig = w->knobs.arena_contig == 2 ? w->fused_ok
+                          : w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
                                                        : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick3_ok && need <= (1536ull << 20) &&
                                                           g_paged_arena_frees.load(std::memory_order_relaxed) == 0);
         uint8_t* pa = nullptr;
@@ -217,6 +220,12 @@ int seal_impl(ggrs_world* w) {
         w->arena_contiguous = me == hipSuccess;
         if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need); }   // no contiguous range free: plain pages
         if (me != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)need); }
+        if (w->arena_contiguous && w->knobs.arena_flush) {
+            // GGRS_ARENA_FLUSH=1 (experiment): before the uncached mapping is first used, every XCD's L2 writes back and drops what it
+            // holds -- if lines of an earlier CACHED mapping of these physical pages are what corrupts contiguous arenas, this ends it
+            hipLaunchKernelGGL(k_flush_l2, dim3(8 * 256), dim3(64), 0, w->stream);
+            HIPCHK(w, hipStreamSynchronize(w->stream));
+        }
         if (w->knobs.debug_arena) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes at %p, state_bytes=%llu\n", w->arena_contiguous ? "contiguous" : "paged", (unsigned long long)need, (void*)pa, (unsigned long long)w->state_bytes);
         w->arena = pa; w->arena_bytes = need; w->own_arena = true;
     }

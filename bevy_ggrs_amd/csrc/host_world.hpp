@@ -60,6 +60,7 @@ struct Knobs {
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
     bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
     int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
+    bool arena_flush = false;      // GGRS_ARENA_FLUSH=1    system-scope L2 write-back + invalidate on every XCD before a contiguous arena is first used (experiment)
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
@@ -79,7 +80,8 @@ struct Knobs {
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
-        k.arena_contig = (int)std::min<long long>(1, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
+        k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
+        k.arena_flush = num("GGRS_ARENA_FLUSH", 0) != 0;
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
         k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);

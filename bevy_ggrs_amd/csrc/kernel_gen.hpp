@@ -323,8 +323,14 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     if (persist) sfmt(s, "    for (uint32_t t_ = blockIdx.x; t_ * %du < a.n_units; t_ += gridDim.x) {       // persistent: %d consecutive slots per workgroup and trip\n"
                          "    const uint32_t gu = t_ * %du + wave;                                  // this wave's 64-slot unit == its mask word\n"
                          "    if (gu >= a.n_units) continue;\n", WPB, TPB_, WPB);
-    else s += "    {\n"
-              "    const uint32_t gu = blockIdx.x * 4u + wave;                               // this wave's 64-slot unit == its mask word\n";
+    else s += "    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed placement; used for speed only), and each XCD has its own\n"
+              "    // L2.  Handing XCD x the x-th CONTIGUOUS eighth of the tiles makes the workgroups that write neighbouring 1 KiB pieces of a\n"
+              "    // row share one L2, which merges them into long runs before they go to memory -- instead of every L2 seeing every 8th piece.\n"
+              "    const uint32_t g8 = gridDim.x >> 3;                                       // the grid is 8 x ceil(tiles / 8) workgroups\n"
+              "    const uint32_t tile = (blockIdx.x & 7u) * g8 + (blockIdx.x >> 3);\n"
+              "    if (tile * 4u >= a.n_units) return;                                       // padding workgroup of the last eighth\n"
+              "    {\n"
+              "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
             "    const bool in_len = (uint64_t)gu * 64u < a.len;                           // wave-uniform\n"
             "    // word c of slot e lives at col_off[c] + (e >> 13) * tile_stride + (e & 8191) * word_bytes: the layout tile is the\n"
@@ -589,7 +595,7 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
                 "        const uint32_t sv = i / %uu;\n"
                 "        if (sv >= o_first && sv < o_last)\n"
-                "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + blockIdx.x] = s_acc[i];\n"
+                "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
                 "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     }
     s += "}\n";

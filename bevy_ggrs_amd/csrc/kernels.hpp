@@ -897,6 +897,10 @@ __global__ __launch_bounds__(TPB) void k_despawn_confirmed(uint8_t* live, Despaw
     if (lane == 0 && gone) *reinterpret_cast<uint64_t*>(live + dm.off_disabled + wi8) = dis & ~gone;
 }
 
+// System-scope release + acquire on whatever CU / XCD the wave lands on: `buffer_wbl2 sc0 sc1` writes the XCD's dirty L2 lines back,
+// `buffer_inv sc0 sc1` drops its clean ones.  2048 single-wave workgroups cover all 8 XCDs (workgroup b lands on XCD b % 8).
+__global__ void k_flush_l2() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, ""); }
+
 // ------------------------------------------------------------------ spawn / mask edits
 // Set liveness + presence bits for slots [first, first+count) (Rollback on_add hook,
 // rollback.rs:45-59) and clear the live-only masks a fresh entity does not carry (non-rollback

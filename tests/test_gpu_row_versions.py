@@ -73,7 +73,9 @@ def _script(w, n, flags_desc):
     tick(2)
     w.set_depth(3); tick(3); w.set_depth(6); tick(2)               # the ring shrinks and grows: slots are recycled with stale versions
     out += w.handle_requests([bg.LoadGameState(w.frame - 2), adv(), bg.SaveGameState(w.frame + 1), adv()])
-    if isinstance(w, bg.World): w.adopt_live_state()               # "an external producer rewrote the live block": nothing may be assumed
+    if isinstance(w, bg.World):                                    # "an external producer rewrote the live block": nothing may be assumed
+        w.live_state_ptr()                                         # (refreshes the block's header -- here the producer writes back what was there)
+        w.adopt_live_state()
     tick(2)
     live = cm.snapshot_state(w, ids)
     frames = list(range(0, w.frame + 1))
