@@ -118,7 +118,13 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_rows) (void)hipHostFree(w->h_rows);
-    if (w->own_arena && w->arena) { (void)hipFree(w->arena); if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed); }
+    if (w->own_arena && w->arena && w->arena_contiguous && (w->knobs.arena_flush & 2) && w->stream) {
+        hipLaunchKernelGGL(k_flush_l2, dim3(8 * 256), dim3(64), 0, w->stream); (void)hipStreamSynchronize(w->stream);
+    }
+    const bool quarantine = w->own_arena && w->arena && w->arena_contiguous && !w->knobs.arena_park && (w->knobs.arena_flush & 8);
+    const uint64_t q_bytes = w->arena_bytes;
+    arena_release(w);
+    if (quarantine) { void* q = nullptr; (void)hipMalloc(&q, q_bytes); (void)hipGetLastError(); }   // experiment: a paged allocation takes the pages back and is never used
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }

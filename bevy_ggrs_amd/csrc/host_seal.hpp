@@ -8,6 +8,19 @@ int seal_impl(ggrs_world* w);
 // Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
 // failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
 // reports the same error instead of carving a second arena over half-initialised bookkeeping.
+// A library-owned arena goes back when its world closes or fails to seal: paged ones to the runtime, contiguous ones to the parking list.
+void arena_release(ggrs_world* w) {
+    if (!(w->own_arena && w->arena)) return;
+    if (w->arena_contiguous && w->knobs.arena_park) {
+        std::lock_guard<std::mutex> lk(g_parked_mu);
+        g_parked.push_back(ParkedArena{w->arena, w->arena_bytes, w->device});
+    } else {
+        (void)hipFree(w->arena);
+        if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed);
+    }
+    w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false;
+}
+
 int seal(ggrs_world* w) {
     if (w->layout_only) return w->fail(GGRS_E_NO_DEVICE, "GGRS_WORLD_LAYOUT_ONLY world: there is no device behind it");
     if (w->sealed) return GGRS_OK;
@@ -20,7 +33,7 @@ int seal(ggrs_world* w) {
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
-    if (w->own_arena && w->arena) { (void)hipFree(w->arena); if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed); w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false; }
+    arena_release(w);
     (void)hipGetLastError();
     w->slots.clear(); w->free_slots.clear(); w->live = Block{};
     w->sealed = false; w->seal_error = rc;
@@ -205,29 +218,36 @@ int seal_impl(ggrs_world* w) {
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
-        // contiguous (write-through, uncached) arenas are what k_tick3's dense nt store streams want -- and a hazard
-        // when their physical pages were used through a cached mapping earlier in the process (include/ggrs_hip.h,
-        // GGRS_WORLD_CONTIG_ARENA): opt-in per world, only for worlds k_tick3 serves, up to 1.5 GiB.  Safety net for the cached
-        // mappings the library knows about: once this process has freed a PAGED arena of its own, a later world's request is ignored
-        // GGRS_ARENA_CONTIG=2 (experiment, profiles/r03fc): contiguous for particles worlds, paged for all others, no safety net --
-        // the mix that corrupted 4 of 10 first processes in round 2
-        const bool contig = w->knobs.arena_contig == 2 ? w->fused_ok
-                          : w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
-                                                       : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick3_ok && need <= (1536ull << 20) &&
-                                                          g_paged_arena_frees.load(std::memory_order_relaxed) == 0);
-        uint8_t* pa = nullptr;
-        hipError_t me = contig ? hipExtMallocWithFlags((void**)&pa, need, hipDeviceMallocContiguous) : hipErrorUnknown;
+        // contiguous (write-through, uncached) arenas are what dense nt store streams want: opt-in per world
+        // (GGRS_WORLD_CONTIG_ARENA), only for the particles worlds, up to 1.5 GiB.  A parked arena (host_world.hpp: contiguous arenas
+        // are never handed back) is taken first; a NEW contiguous allocation is made only while this process has not freed a paged
+        // arena of its own (include/ggrs_hip.h).  GGRS_ARENA_CONTIG=0|1 forces the choice for every world, =2 for the particles worlds
+        // only (the mix of profiles/r03fc).
+        const bool want = w->knobs.arena_contig == 2 ? w->fused_ok
+                        : w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
+                                                     : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick3_ok && need <= (1536ull << 20));
+        const bool may_allocate = w->knobs.arena_contig >= 0 || g_paged_arena_frees.load(std::memory_order_relaxed) == 0;
+        uint8_t* pa = nullptr; uint64_t got = need;
+        hipError_t me = hipErrorUnknown;
+        if (want) {
+            std::lock_guard<std::mutex> lk(g_parked_mu);
+            size_t best = g_parked.size();
+            for (size_t i = 0; i < g_parked.size(); ++i)
+                if (g_parked[i].device == w->device && g_parked[i].bytes >= need && (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes)) best = i;
+            if (best != g_parked.size()) { pa = g_parked[best].ptr; got = g_parked[best].bytes; g_parked.erase(g_parked.begin() + best); me = hipSuccess; }
+        }
+        if (want && me != hipSuccess && may_allocate) me = hipExtMallocWithFlags((void**)&pa, need, hipDeviceMallocContiguous);
         w->arena_contiguous = me == hipSuccess;
         if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need); }   // no contiguous range free: plain pages
         if (me != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)need); }
-        if (w->arena_contiguous && w->knobs.arena_flush) {
+        if (w->knobs.arena_flush & (w->arena_contiguous ? 1 : 4)) {
             // GGRS_ARENA_FLUSH=1 (experiment): before the uncached mapping is first used, every XCD's L2 writes back and drops what it
             // holds -- if lines of an earlier CACHED mapping of these physical pages are what corrupts contiguous arenas, this ends it
             hipLaunchKernelGGL(k_flush_l2, dim3(8 * 256), dim3(64), 0, w->stream);
             HIPCHK(w, hipStreamSynchronize(w->stream));
         }
         if (w->knobs.debug_arena) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes at %p, state_bytes=%llu\n", w->arena_contiguous ? "contiguous" : "paged", (unsigned long long)need, (void*)pa, (unsigned long long)w->state_bytes);
-        w->arena = pa; w->arena_bytes = need; w->own_arena = true;
+        w->arena = pa; w->arena_bytes = got; w->own_arena = true;
     }
     // GGRS_DEBUG_POISON=1: fill a library-owned arena with a garbage pattern before anything is initialised -- a read of memory the
     // library never wrote (hidden by whatever a previous allocation left there) then fails the parity tests every time

@@ -60,9 +60,12 @@ struct Knobs {
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
     bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
     int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
-    bool arena_flush = false;      // GGRS_ARENA_FLUSH=1    system-scope L2 write-back + invalidate on every XCD before a contiguous arena is first used (experiment)
+    int arena_flush = 0;           // GGRS_ARENA_FLUSH=bits system-scope L2 write-back + invalidate on every XCD (experiment, profiles/r03fc): 1 before a contiguous
+                                   //                       arena is first used, 2 before a contiguous arena is freed, 4 before a paged arena is first used,
+                                   //                       8 a freed contiguous arena's pages are taken back by a paged allocation nobody uses
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
+    bool arena_park = true;        // GGRS_ARENA_PARK=0     hipFree contiguous arenas when their world closes (the hazard above; experiments only)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     std::string jit_cache_dir;     // GGRS_JIT_CACHE_DIR    code objects of generated kernels on disk ("" = ~/.cache/ggrs_hip; "0": no disk cache)
     static Knobs from_env() {
@@ -81,7 +84,8 @@ struct Knobs {
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
         k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
-        k.arena_flush = num("GGRS_ARENA_FLUSH", 0) != 0;
+        k.arena_flush = (int)num("GGRS_ARENA_FLUSH", 0);
+        k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
         k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);
@@ -93,6 +97,14 @@ struct Knobs {
 }  // namespace
 
 static std::atomic<int> g_paged_arena_frees{0};   // paged (cached) arenas this process has handed back: see GGRS_WORLD_CONTIG_ARENA
+// Contiguous arenas are never handed back while the process lives (profiles/r03fc): after hipFree of a hipDeviceMallocContiguous
+// allocation, kernels of LATER worlds on this device stop being ordered / made coherent with each other by the runtime's direct
+// dispatch (a paged UNFUSED world created next fails 6 of 6 times; HIP_LAUNCH_BLOCKING=1 or AMD_DIRECT_DISPATCH=0 hide it; L2
+// write-back / invalidate kernels, poisoning, keeping the pages away from later allocations do not).  A closed world parks its
+// contiguous arena here and the next world that wants one takes the smallest parked arena that fits.
+struct ParkedArena { uint8_t* ptr; uint64_t bytes; int device; };
+static std::mutex g_parked_mu;
+static std::vector<ParkedArena> g_parked;
 
 struct ggrs_world {
     // ---- configuration

@@ -70,15 +70,17 @@ typedef struct {
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
-#define GGRS_WORLD_CONTIG_ARENA 32u  /* allocate the library-owned arena physically contiguous (hipDeviceMallocContiguous; worlds of
-                                        the k_tick3 kind up to 1.5 GiB): +2-3 % on the dominant kernel (dense nt store streams
-                                        into write-through memory).  OPT-IN because such memory is mapped uncached:
-                                        if its physical pages were used through a CACHED mapping earlier in the same process
-                                        (a freed hipMalloc / another world's paged arena), stale L2 lines can be served for
-                                        them -- measured as deterministic corruption in 4 of 10 fresh processes that alternated
-                                        paged and contiguous arenas (profiles/README.md, r02fc).  Safe when the world is
-                                        created before the process has freed device memory (an app's startup; bench.py); the
-                                        library itself ignores the flag once it has freed a paged arena of its own.           */
+#define GGRS_WORLD_CONTIG_ARENA 32u  /* allocate the library-owned arena physically contiguous (hipDeviceMallocContiguous; the
+                                        particles worlds, up to 1.5 GiB): +2-3 % on k_tick3's dense nt store streams into
+                                        write-through memory.  OPT-IN, with two rules the library enforces itself
+                                        (profiles/README.md r03fc, tests/test_gpu_contig_arena.py):
+                                        - a contiguous arena is never handed back while the process lives.  After hipFree of
+                                          such an allocation the runtime stops ordering the kernels of LATER worlds on the
+                                          device (a paged world opened next computed on stale state on 6 of 6 fresh boxes;
+                                          HIP_LAUNCH_BLOCKING=1 / AMD_DIRECT_DISPATCH=0 hide it, cache flushes do not).  A
+                                          closed world parks its arena; the next world that asks for one reuses it;
+                                        - a NEW contiguous allocation is made only while the process has not freed a paged
+                                          arena of its own (round 2's reading of the same failures; kept as a second net).   */
 #define GGRS_WORLD_LAYOUT_ONLY 16u   /* no device: registration, layout and ggrs_hip_generated_kernel_source only (every
                                         call that would touch the GPU returns GGRS_E_NO_DEVICE) -- a build machine can check
                                         that a schema and its custom systems compile for gfx950 before they are deployed   */

@@ -140,8 +140,10 @@ pub unsafe trait HipComponent: Component + Copy {
     fn from_words(words: &[u64]) -> Self;
 }
 
-/// Derive-style helper: `hip_component!(Velocity, f32, [x, y, z]);` / `hip_component!(Ttl, u64, [0]);`
-/// expands to the `unsafe impl HipComponent` with `to_words` / `from_words` over the listed fields, in order.
+/// Derive-style helper: `hip_component!(Velocity, f32, [x, y, z]);` / `hip_component!(Ttl, u64, [0]);` /
+/// `hip_component!(InheritedVisibility, u8, [0]);` -- the word type may be 1, 2, 4 or 8 bytes wide (the library stores a `bool` /
+/// u8 enum as a 1-byte word and hashes it as `derive(Hash)` does: one byte).  Expands to the `unsafe impl HipComponent` with
+/// `to_words` / `from_words` over the listed fields, in order.
 #[macro_export]
 macro_rules! hip_component {
     ($ty:ty, $word:ty, [$($field:tt),+ $(,)?]) => {
@@ -446,6 +448,11 @@ pub trait RollbackApp {
     /// `checksum_component::<T>(fn(&T) -> u64)` with the closure replaced by the list of hashed words
     /// (each word is fed to SeaHash as its little-endian bytes, i.e. `write_u32` / `write_u64`).
     fn checksum_component<T: HipComponent>(&mut self, hashed_words: &[u32]) -> &mut Self;
+    /// `checksum_component::<T>(fn(&T) -> u64)` with an ARBITRARY hasher (rollback_app.rs:119-121): HIP C++ source defining
+    /// `__device__ ggrs_u64 ggrs_hash(const GgrsComponent& c)` (include/ggrs_hip.h `ggrs_hip_checksum_component_custom`); the
+    /// closure body is written once more in device code -- `GgrsHasher h; h.write_u32(c.u32(0)); ..; return h.finish();` is
+    /// `checksum_hasher()` + `Hash::hash` calls.  Compiled into the world's generated kernel when the world is sealed.
+    fn checksum_component_with_source<T: HipComponent>(&mut self, hasher_source: &str) -> &mut Self;
     fn add_kernel_system(&mut self, schedule: GgrsSchedule, system: KernelSystem) -> &mut Self;
     /// `add_systems(GgrsSchedule, ..)` for a user-written per-entity system (HIP C++ source, compiled at registration).
     fn add_custom_kernel_system(&mut self, schedule: GgrsSchedule, system: CustomKernelSystem) -> &mut Self;
@@ -497,6 +504,13 @@ impl RollbackApp for App {
     fn checksum_component<T: HipComponent>(&mut self, hashed_words: &[u32]) -> &mut Self {
         let w = hip_world(self);
         let rc = unsafe { ffi::ggrs_hip_checksum_component(w.raw, w.comp_id::<T>(), hashed_words.as_ptr(), hashed_words.len() as u32) };
+        w.check(rc);
+        self
+    }
+    fn checksum_component_with_source<T: HipComponent>(&mut self, hasher_source: &str) -> &mut Self {
+        let w = hip_world(self);
+        let src = std::ffi::CString::new(hasher_source).expect("hasher source contains a NUL byte");
+        let rc = unsafe { ffi::ggrs_hip_checksum_component_custom(w.raw, w.comp_id::<T>(), src.as_ptr()) };
         w.check(rc);
         self
     }

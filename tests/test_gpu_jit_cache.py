@@ -16,7 +16,7 @@ import json, os, sys, time
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import bevy_ggrs_amd as bg
 import common as cm
-w = bg.World(20_000, max_depth=6)
+w = bg.World(20_000, max_depth=9)
 ids = cm.build_particles(w)
 vel, ttl = cm.synthetic_particles(5000, ttl="despawn")
 t0 = time.perf_counter()

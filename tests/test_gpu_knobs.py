@@ -2,7 +2,8 @@
 produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU oracle under each setting, so the
 driver-run suite covers every kernel that ships -- k_tick3 at every size, the generated kernel in its per-tile and
 persistent forms with the fold on the host / in k_gen_finalize / in the launch, with and without depth-parallel roles,
-dead-snapshot elimination and row versions."""
+dead-snapshot elimination and row versions, on paged and contiguous arenas.  (GGRS_ARENA_PARK=0 is the one knob without a case:
+it re-enables the runtime hazard of profiles/r03fc and exists for that experiment only.)"""
 import numpy as np
 import pytest
 
@@ -26,6 +27,8 @@ KNOBS = [
     {"GGRS_JIT_DP": "3"},
     {"GGRS_ROW_VERSIONS": "0"},
     {"GGRS_ARENA_CONTIG": "0"},
+    {"GGRS_ARENA_CONTIG": "1"},                             # every world on a physically contiguous arena (parked when its world closes, reused by the next)
+    {"GGRS_ARENA_CONTIG": "2", "GGRS_ARENA_FLUSH": "7"},    # particles worlds contiguous + the L2 write-back / invalidate kernels of the r03fc experiment
     {"GGRS_DEBUG_POISON": "1"},
 ]
 
@@ -78,6 +81,8 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     if env.get("GGRS_TICK_GENERIC") == "1": assert k.startswith("ggrs_jit_tick"), k
     if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
     if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
+    if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
+    if env.get("GGRS_ARENA_CONTIG") == "0": assert info["arena"].startswith("paged"), info
     if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("k_tick3" if n > 416 * 1024 else "ggrs_jit_tick"), k
 
 
