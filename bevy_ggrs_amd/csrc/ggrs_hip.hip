@@ -317,6 +317,7 @@ int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
     if (c >= w->comps.size() || slot >= w->len) return w->fail(GGRS_E_INVALID, "bad remove_component arguments");
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 0);
     HIPCHK(w, hipGetLastError());
+    ver_touch(w, ver_presence(w, c)); ver_sync_live(w);           // the presence mask changed, the columns did not
     w->pending_valid = false;
     return GGRS_OK;
 }

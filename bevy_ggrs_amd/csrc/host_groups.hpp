@@ -15,6 +15,7 @@ struct GroupState {
     Block* src; uint64_t cover; uint32_t src_is_live;
     Block* dsts[MAX_TICK_SAVES];
     uint64_t save_rows[MAX_TICK_SAVES];               // bit c: column c is stored with Save k (row versions)
+    uint32_t save_pmask[MAX_TICK_SAVES];              // bit c: component c's presence mask is stored with Save k
     // (the versions Save k's slot holds once the group has run live in w->group_save_ver, [k][column]: no allocation per group)
 };
 // LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
@@ -58,10 +59,11 @@ int group_save(ggrs_world* w, GroupState& g, uint32_t k, uint8_t** save_dst, int
     g.dsts[k] = d;
     save_dst[k] = d ? d->ptr : nullptr;
     save_frame[k] = w->frame;
-    g.save_rows[k] = 0;
+    g.save_rows[k] = 0; g.save_pmask[k] = 0;
     if (d) {
         g.cover = std::max(g.cover, d->dirty_len); d->len = w->len;
         g.save_rows[k] = rows_to_store(w, *d);
+        g.save_pmask[k] = pmask_differs(w, *d, w->cur_ver);
         const size_t nc = w->cur_ver.size();
         if (w->group_save_ver.size() < (size_t)MAX_TICK_SAVES * nc) w->group_save_ver.resize((size_t)MAX_TICK_SAVES * nc);
         std::copy(w->cur_ver.begin(), w->cur_ver.end(), w->group_save_ver.begin() + (size_t)k * nc);
@@ -228,6 +230,7 @@ int run_request_groups_tick3(ggrs_world* w, const ggrs_request* reqs, uint32_t n
 // the generated kernel
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint64_t JIT_NT_MIN_SLOTS = 416 * 1024;      // snapshot stores of bigger groups are non-temporal: written once, read a tick later, and the ring does not fit the Infinity Cache
+constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20;   // the first Save of an HBM-sized rollback group goes through the L2 while its rows are this small
 constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-only groups ride in one launch while the world is this small
 // The particles world has two fused paths: the hand-written k_tick3 and the kernel generated for it like for any other world.
 // Which one serves a list is the knob jit_particles_max_slots (host_world.hpp: measured crossovers); a particles world without a
@@ -332,16 +335,23 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         j.load_rows = j.n_ops ? static_reads : 0;
         for (uint32_t k = 0; k < j.n_saves; ++k) {
             j.save_rows[k] = j.save_dst[k] ? gs.save_rows[k] : 0;
+            j.save_pmask[k] = j.save_dst[k] ? gs.save_pmask[k] : 0;
             j.load_rows |= j.save_rows[k];
             bytes_slot += rows_bytes_per_slot(w, j.save_rows[k]);
         }
-        if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
+        if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = w->len;
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
         j.nt = (w->nt_copy || cover > JIT_NT_MIN_SLOTS) ? 1u : 0u;
+        // A rollback group's FIRST Save is the oldest frame it produces -- what the next rollback loads (SyncTest: always; P2P with a steady
+        // rollback depth: likewise).  Storing it through the L2 instead of around it lets the next launch's loads hit there: 72.5 -> 64.6 us
+        // per depth-8 tick at 1 M in the ring-walking harness (profiles/r03n), every other row still streams past the caches.
+        // Past ~2.5 M particles the rows no longer survive in the caches until the next launch and only displace the stream (4 M: +3 %).
+        j.cached_saves = (j.nt && w->knobs.jit_cache_first_save && !j.src_is_live && j.n_saves >= 2 &&
+                          rows_bytes_per_slot(w, j.save_rows[0]) * cover <= JIT_CACHED_SAVE_MAX_BYTES) ? 1u : 0u;
         const bool launch = j.n_ops || !j.src_is_live;
 
         if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {

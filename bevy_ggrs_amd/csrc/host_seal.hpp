@@ -255,10 +255,10 @@ int seal_impl(ggrs_world* w) {
     uint8_t* p = w->arena;
     const uint32_t ncols = (uint32_t)w->col_off.size();
     w->live.ptr = p; p += w->state_bytes;
-    w->live.ver.assign(ncols, 0);                                   // == cur_ver: nothing has been written yet
+    w->live.ver.assign(ncols + w->comps.size(), 0);                                   // == cur_ver: nothing has been written yet
     w->slots.resize(w->max_depth);
     for (uint32_t i = 0; i < w->max_depth; ++i) {
-        w->slots[i].ptr = p; p += w->state_bytes; w->slots[i].ver.assign(ncols, VER_NONE);
+        w->slots[i].ptr = p; p += w->state_bytes; w->slots[i].ver.assign(ncols + w->comps.size(), VER_NONE);
         w->free_slots.push_back((int)(w->max_depth - 1 - i));
     }
     uint8_t* const side = p; p += w->side_bytes;          // == live.ptr + side_off (build_layout)

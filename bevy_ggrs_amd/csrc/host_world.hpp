@@ -65,6 +65,9 @@ struct Knobs {
                                    //                       8 a freed contiguous arena's pages are taken back by a paged allocation nobody uses
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
+    bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
+    bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
+                                        //                       the snapshot the next rollback loads, goes through the L2)
     bool arena_park = true;        // GGRS_ARENA_PARK=0     hipFree contiguous arenas when their world closes (the hazard above; experiments only)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     std::string jit_cache_dir;     // GGRS_JIT_CACHE_DIR    code objects of generated kernels on disk ("" = ~/.cache/ggrs_hip; "0": no disk cache)
@@ -85,6 +88,8 @@ struct Knobs {
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
         k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.arena_flush = (int)num("GGRS_ARENA_FLUSH", 0);
+        k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
+        k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
         k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
@@ -262,7 +267,9 @@ struct DeviceGuard {
 
 // ---- row versions ---------------------------------------------------------------------------------------------------
 inline void ver_touch(ggrs_world* w, uint32_t col) { w->cur_ver[col] = ++w->ver_counter; }
-inline void ver_touch_comp(ggrs_world* w, uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) ver_touch(w, w->comps[c].col_base + k); }
+// versions [n_columns, n_columns + n_components) belong to the presence masks (changed by the host only: spawn, insert, remove, load, adopt)
+inline uint32_t ver_presence(const ggrs_world* w, uint32_t c) { return (uint32_t)w->col_off.size() + c; }
+inline void ver_touch_comp(ggrs_world* w, uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) ver_touch(w, w->comps[c].col_base + k); ver_touch(w, ver_presence(w, c)); }
 inline void ver_touch_all(ggrs_world* w) { for (uint32_t c = 0; c < w->cur_ver.size(); ++c) ver_touch(w, c); }
 // AdvanceWorld: every registered system may have written its write set
 inline void ver_step(ggrs_world* w) { for (auto& cols : w->sys_writes) for (uint32_t c : cols) ver_touch(w, c); }
@@ -272,6 +279,15 @@ inline bool ver_differs(const ggrs_world* w, const Block& dst, const std::vector
 }
 // the live block holds exactly the logical live state (no fused group is being assembled)
 inline void ver_sync_live(ggrs_world* w) { w->live.ver = w->cur_ver; }
+// presence masks of `dst` that differ from the ones `want` describes
+inline uint32_t pmask_differs(const ggrs_world* w, const Block& dst, const std::vector<uint32_t>& want) {
+    uint32_t m = 0;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) {
+        const uint32_t i = ver_presence(w, c);
+        if (!w->knobs.row_versions || !w->knobs.presence_versions || dst.ver[i] == VER_NONE || want[i] == VER_NONE || dst.ver[i] != want[i]) m |= 1u << c;
+    }
+    return m;
+}
 
 // Computes the packed state layout from the registered components.
 void build_layout(ggrs_world* w) {
@@ -367,7 +383,7 @@ void build_layout(ggrs_world* w) {
             if (pass == 0) p.n_wide = nr;
         }
     p.n_rows = nr;
-    w->cur_ver.assign(ncols, 0); w->col_ext.assign(ncols, 0);
+    w->cur_ver.assign(ncols + w->comps.size(), 0); w->col_ext.assign(ncols, 0);
 }
 
 uint32_t total_rows(const ggrs_world* w) {

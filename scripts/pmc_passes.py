@@ -31,9 +31,11 @@ def main():
     cmd = sys.argv[sys.argv.index("--") + 1:]
     txt = open(listing).read()
     have = lambda n: re.search(r"\b" + re.escape(n) + r"\b", txt) is not None
-    tcc = [c for c in WISH_TCC if have(c)]
-    sq = [c for c in WISH_SQ if have(c)]
-    oth = [c for c in WISH_OTHER if have(c)]
+    wish_sq = WISH_SQ + [c for c in os.environ.get("PMC_SQ_EXTRA", "").split(",") if c]      # more SQ-block counters for one study
+    only_sq = os.environ.get("PMC_ONLY_SQ") == "1"
+    tcc = [] if only_sq else [c for c in WISH_TCC if have(c)]
+    sq = [c for c in wish_sq if have(c)]
+    oth = [c for c in (["GRBM_GUI_ACTIVE"] if only_sq else WISH_OTHER) if have(c)]
     missing = [c for c in WISH_TCC + WISH_SQ + WISH_OTHER if not have(c)]
     passes = []
     while tcc or sq or oth:
@@ -71,7 +73,7 @@ def main():
     print(json.dumps({k: v for k, v in log.items() if k != "kernels"}, indent=1))
     for kn, d in summ.items():
         if "tick" in kn or "copy" in kn:
-            print(kn, json.dumps(d, indent=1))
+            print(kn, json.dumps(d, indent=1) if not only_sq else json.dumps({k: round(v) for k, v in d.items()}))
 
 
 if __name__ == "__main__":

@@ -26,6 +26,8 @@ KNOBS = [
     {"GGRS_JIT_DP": "0"},
     {"GGRS_JIT_DP": "3"},
     {"GGRS_ROW_VERSIONS": "0"},
+    {"GGRS_PRESENCE_VERSIONS": "0"},                        # presence masks stored with every Save
+    {"GGRS_JIT_CACHE_FIRST_SAVE": "0"},                     # every Save of an HBM-sized rollback group streams past the caches
     {"GGRS_ARENA_CONTIG": "0"},
     {"GGRS_ARENA_CONTIG": "1"},                             # every world on a physically contiguous arena (parked when its world closes, reused by the next)
     {"GGRS_ARENA_CONTIG": "2", "GGRS_ARENA_FLUSH": "7"},    # particles worlds contiguous + the L2 write-back / invalidate kernels of the r03fc experiment

@@ -73,6 +73,15 @@ def _script(w, n, flags_desc):
     tick(2)
     w.set_depth(3); tick(3); w.set_depth(6); tick(2)               # the ring shrinks and grows: slots are recycled with stale versions
     out += w.handle_requests([bg.LoadGameState(w.frame - 2), adv(), bg.SaveGameState(w.frame + 1), adv()])
+    # presence masks carry versions of their own (only the host changes them): a removal and an insertion with NO column write in
+    # between saves, a rollback to before both (the masks come back), and fused groups saving into slots that still hold the old masks
+    w.remove_component(X, 11); w.remove_component(T, 3)
+    tick(2)
+    w.insert_component(G, 9, np.array([4242], dtype=np.uint16))
+    tick(1)
+    out += w.handle_requests([bg.LoadGameState(w.frame - 4), adv(), bg.SaveGameState(w.frame + 1), adv(), bg.SaveGameState(w.frame + 2), adv()])
+    w.remove_component(V, 2)
+    out += w.handle_requests([bg.SaveGameState(w.frame), adv(), bg.SaveGameState(w.frame + 1), adv(), bg.LoadGameState(w.frame + 1), adv(), bg.SaveGameState(w.frame + 2), adv()])
     if isinstance(w, bg.World):                                    # "an external producer rewrote the live block": nothing may be assumed
         w.live_state_ptr()                                         # (refreshes the block's header -- here the producer writes back what was there)
         w.adopt_live_state()
