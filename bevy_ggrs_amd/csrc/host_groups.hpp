@@ -269,7 +269,7 @@ struct JitBatch {
             if (k > 1) j.dp_s = 0;
             host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
-            HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, 1, 1, 0, w->stream, params, nullptr));
+            HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, 1, 1, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), w->stream, params, nullptr));
         }
         if (host_fold) { w->folds.push_back({res_first, j.n_saves, g, n_cks, k, rows_off, j.len}); return GGRS_OK; }
         GenFinArgs f; memset(&f, 0, sizeof f);
@@ -397,7 +397,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             if (launch) {
                 ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
-                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, 0, w->stream, params, nullptr));
+                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, jit_lane_fold_bytes(w, n_cks, j.n_saves), w->stream, params, nullptr));
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }

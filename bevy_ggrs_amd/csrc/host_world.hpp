@@ -65,6 +65,8 @@ struct Knobs {
                                    //                       8 a freed contiguous arena's pages are taken back by a paged allocation nobody uses
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
+    int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
+                                   //                       of >= 400 k slots, kernel_gen.hpp jit_lane_fold)
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
                                         //                       the snapshot the next rollback loads, goes through the L2)
@@ -88,6 +90,7 @@ struct Knobs {
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
         k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.arena_flush = (int)num("GGRS_ARENA_FLUSH", 0);
+        k.jit_lane_fold = (int)num("GGRS_JIT_LANE_FOLD", -1);
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
         k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;

@@ -238,6 +238,17 @@ uint64_t jit_hot_cols(const ggrs_world* w) {
 // Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
 // back to k_tick3 or to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
 // Player.handle, too many words for the register file / the 64-bit row masks.
+// The per-tile form of a BIG world folds checksum values through per-lane LDS rows: 64 cells x 8 B per Save and checksummed component
+// (dynamic LDS, sized by the launch), one ds_xor per lane and Save, the rows folded across lanes once per workgroup -- instead of a
+// 12-step DPP ladder + a single-lane atomic per Save and component.  Small worlds keep the ladder: zeroing and folding the rows costs
+// them more than it saves (profiles/r03n/lane_fold_ab.txt).  GGRS_JIT_LANE_FOLD=0|1 forces the choice.
+constexpr uint32_t JIT_LANE_FOLD_MAX_CKS = 4;
+constexpr uint64_t JIT_LANE_FOLD_MIN_SLOTS = 400 * 1024;
+inline bool jit_lane_fold(const ggrs_world* w, uint32_t n_cks) {
+    if (n_cks < 1 || n_cks > JIT_LANE_FOLD_MAX_CKS) return false;
+    return w->knobs.jit_lane_fold >= 0 ? w->knobs.jit_lane_fold != 0 : w->cap_pad >= JIT_LANE_FOLD_MIN_SLOTS;
+}
+inline uint32_t jit_lane_fold_bytes(const ggrs_world* w, uint32_t n_cks, uint32_t n_saves) { return jit_lane_fold(w, n_cks) ? n_saves * n_cks * 512u : 0u; }
 bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     const uint32_t nc = (uint32_t)w->comps.size();
     uint32_t units = 0, ncols = 0;
@@ -264,6 +275,20 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     std::vector<uint32_t> cks_comp;                                  // checksummed components in id order (== w->cks_comp once sealed)
     for (uint32_t c = 0; c < nc; ++c) if (w->comps[c].checksummed) { if (!rb(c)) return false; cks_comp.push_back(c); }
     const uint32_t n_cks = (uint32_t)cks_comp.size();
+    const bool lane_fold = !persist && jit_lane_fold(w, n_cks);
+    std::string fold_text;
+    if (lane_fold) {
+        char ft[1024];
+        snprintf(ft, sizeof ft,
+                 "    for (uint32_t r_ = wave; r_ < a.n_saves * %uu; r_ += 4u) {                  // one row per wave and trip: XOR over its 64 lanes\n"
+                 "        const uint32_t sv = r_ / %uu;\n"
+                 "        if (sv < o_first || sv >= o_last) continue;\n"
+                 "        const ggrs_u64 v_ = wave_xor(s_lane[r_ * 64u + lane]);\n"
+                 "        if (lane == 0) s_acc[sv * %uu + r_ %% %uu] = v_;\n"
+                 "    }\n"
+                 "    __syncthreads();\n", n_cks, n_cks, n_cks + 1, n_cks);
+        fold_text = ft;
+    }
     if (n_cks > 16) return false;
     const unsigned long long OFF_ALIVE = w->off_alive, OFF_DIS = w->marks.off_disabled, OFF_DF = w->marks.off_dframe;
     const JitPersistShape shape = jit_persist_shape(units);
@@ -320,9 +345,11 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             "    // per-workgroup checksum partials [Save][component .. live count]: the waves fold into LDS\n"
             "    __shared__ ggrs_u64 s_acc[16 * %u];\n"
             "    __shared__ uint32_t s_last;\n"
-            "    for (uint32_t i = tid; i < 16u * %uu; i += %du) s_acc[i] = 0;\n"
-            "    __syncthreads();\n",
+            "    for (uint32_t i = tid; i < 16u * %uu; i += %du) s_acc[i] = 0;\n",
          lb, n_cks + 1, n_cks + 1, TPB_);
+    if (lane_fold) sfmt(s, "    extern __shared__ ggrs_u64 s_lane[];                                  // [Save][checksummed component][lane]: a.n_saves * %u * 64 cells (dynamic LDS)\n"
+                           "    for (uint32_t i = tid; i < a.n_saves * %uu; i += %du) s_lane[i] = 0;\n", n_cks, n_cks * 64u, TPB_);
+    s += "    __syncthreads();\n";
     if (persist) sfmt(s, "    for (uint32_t t_ = blockIdx.x; t_ * %du < a.n_units; t_ += gridDim.x) {       // persistent: %d consecutive slots per workgroup and trip\n"
                          "    const uint32_t gu = t_ * %du + wave;                                  // this wave's 64-slot unit == its mask word\n"
                          "    if (gu >= a.n_units) continue;\n", WPB, TPB_, WPB);
@@ -493,6 +520,8 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             for (uint32_t wi : cc.cks_words) sfmt(s, " st.write(w%u_0, %uu);", col(c, wi), cc.word_bytes);
             sfmt(s, " hx = (alive_0 && p%u_0) ? sea_pair_pre(ordB_0, st.finish()) : 0ull; }\n", c);
         }
+        if (lane_fold) sfmt(s, "                atomicXor(&s_lane[(si * %uu + %uu) * 64u + lane], (ggrs_u64)hx);\n            }\n", n_cks, k);
+        else
         sfmt(s, "                hx = wave_xor(hx);\n"
                 "                if (lane == 0) atomicXor(&acc[%u], (ggrs_u64)hx);\n"
                 "            }\n", k);
@@ -598,11 +627,12 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         sfmt(s, "    // ---- this workgroup's partial rows (blockIdx.z: member of a batch of identical checksum-only groups)\n"
                 "    (void)s_last;\n"
                 "    __syncthreads();\n"
+                "%s"
                 "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
                 "        const uint32_t sv = i / %uu;\n"
                 "        if (sv >= o_first && sv < o_last)\n"
                 "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
-                "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
+                "    }\n", fold_text.c_str(), n_cks + 1, n_cks + 1, n_cks + 1);
     }
     s += "}\n";
     return true;

@@ -26,6 +26,8 @@ KNOBS = [
     {"GGRS_JIT_DP": "0"},
     {"GGRS_JIT_DP": "3"},
     {"GGRS_ROW_VERSIONS": "0"},
+    {"GGRS_JIT_LANE_FOLD": "1"},                            # checksum fold through per-lane LDS rows even for small worlds
+    {"GGRS_JIT_LANE_FOLD": "0"},                            # ... and the per-Save DPP ladder even for big ones
     {"GGRS_PRESENCE_VERSIONS": "0"},                        # presence masks stored with every Save
     {"GGRS_JIT_CACHE_FIRST_SAVE": "0"},                     # every Save of an HBM-sized rollback group streams past the caches
     {"GGRS_ARENA_CONTIG": "0"},
