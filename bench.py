@@ -615,7 +615,7 @@ def main():
                 "full_copy_bytes_per_launch": full_copy_bytes,
                 "row_versions": info.get("row_versions"),
                 "algorithmic_bytes_note": f"rows the fused launch loads and stores x slots, counted by the library per launch: with row versions only columns whose bytes "
-                                          f"differ from the destination's move (every snapshot is complete; the never-written rotation / scale rows are already in every ring slot); "
+                                          f"differ from the destination's move (every snapshot is complete; the never-written rotation / scale rows are already in every ring slot; HBM traffic can be BELOW this figure: the group's first Save is stored through the L2 and the next launch's loads hit there); "
                                           f"a full copy would move {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write = {bps * (D + 2)} B/entity "
                                           f"(SURVEY 8d's one-kernel-per-request model, {tick_bytes} B/entity-tick, is reported as *_per_request)",
                 "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
