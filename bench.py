@@ -270,7 +270,17 @@ def measure_single(bg, cm, torch, args, contig, light=False):
             run.enqueue(w.frame); run.collect(); pre_n += 1
         run.collect()
         w.synchronize()
-    m["preheat"] = {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms}
+    # the library builds a kernel specialised for the tick's group shape on a worker thread once it has seen the shape 16 times
+    # (include/ggrs_hip.h ggrs_hip_specialise_wait): like the generated kernel's own compile at seal this is set-up, not the timed
+    # region -- wait for it, then let the new kernel run for a moment
+    spec_ready = bool(w.specialise_wait()) if not args.no_specialise_wait else False
+    if spec_ready:
+        run.enqueue(w.frame); pre_n += 1
+        for _ in range(199):
+            run.enqueue(w.frame); run.collect(); pre_n += 1
+        run.collect()
+        w.synchronize()
+    m["preheat"] = {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "specialised_kernel_ready": spec_ready}
     torch.cuda.synchronize()
     m["frames_before_timed"] = w.frame
     gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
@@ -404,6 +414,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ticks", type=int, default=3)
     ap.add_argument("--parity-ticks", type=int, default=24, help="timed ticks whose checksums the CPU oracle replays and compares (N = 1 only; 0 = off)")
+    ap.add_argument("--no-specialise-wait", action="store_true", help="do not wait for the kernel specialised for the tick's group shape before the timed region")
     ap.add_argument("--preheat-ms", type=float, default=150.0, help="wall time of untimed ticks between warm-up and the timed region (clock ramp; reported as `preheat`)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per reference system (no fusion at all)")
     ap.add_argument("--no-groups", action="store_true", help="one launch per request (no request-group fusion)")
@@ -659,7 +670,7 @@ def main():
                    "entities_per_gpu": live, "depth": D,
                    "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"),
+                   "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"), "specialised_kernel": info.get("specialised_kernel"),
                    "hiprtc": info.get("hiprtc"), "device": dev,
                    "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "preheat": m.get("preheat"),

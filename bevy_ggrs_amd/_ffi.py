@@ -138,6 +138,7 @@ SIGNATURES = {
     "ggrs_hip_profile_read_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ggrs_hip_profile_read_launches": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "ggrs_hip_world_kernel_info": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ggrs_hip_specialise_wait": (C.c_int, [_P]),
 }
 
 

@@ -35,6 +35,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -113,6 +114,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
+    jit_spec_retire(w);
     jit_release(w->jit_entry); jit_release(w->jit_entry_persist);
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->h_results) (void)hipHostFree(w->h_results);
@@ -127,6 +129,12 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (quarantine) { void* q = nullptr; (void)hipMalloc(&q, q_bytes); (void)hipGetLastError(); }   // experiment: a paged allocation takes the pages back and is never used
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
+}
+int ggrs_hip_specialise_wait(ggrs_world* w) {
+    if (!w) return GGRS_E_INVALID;
+    if (!w->spec) return 0;
+    if (w->spec->th.joinable()) w->spec->th.join();
+    return w->spec->state.load(std::memory_order_acquire) == 2 ? 1 : 0;
 }
 const char* ggrs_hip_last_error(ggrs_world* w) { return w ? w->err.c_str() : "null world"; }
 
@@ -603,6 +611,13 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
     char line[768];
     auto add = [&](const char* k, const std::string& v) { snprintf(line, sizeof line, "%s=%s\n", k, v.c_str()); s += line; };
     add("sealed", w->sealed ? "1" : "0");
+    {
+        const int st = w->spec ? w->spec->state.load(std::memory_order_acquire) : 0;
+        std::string v = !w->knobs.jit_specialise_after ? "off (GGRS_JIT_SPECIALISE_AFTER=0)" : st == 2 ? "ready (the steady group shape runs on a kernel compiled for it)"
+                      : st == 1 ? "building" : st == 3 ? "failed: " + w->spec->why : "none yet";
+        for (char& ch : v) if (ch == '\n') ch = ' ';
+        add("specialised_kernel", v);
+    }
     add("arena", !w->sealed ? "none" : (!w->own_arena ? "caller-provided" : (w->arena_contiguous ? "contiguous (hipExtMallocWithFlags, write-through)" : "paged (hipMalloc)")));
     add("arena_bytes", std::to_string(w->arena_bytes));
     {

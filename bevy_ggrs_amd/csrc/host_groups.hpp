@@ -246,6 +246,27 @@ inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 
 // Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
 // launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
+// The kernel specialised for this group's shape, once the session has sent the shape often enough and the build is done (kernel_gen.hpp
+// jit_specialise); nullptr: use the generic kernel.  Only plain HBM-sized launches qualify (no roles, no batch, every Save stored).
+hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
+    if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.nt || j.dp_s || !j.n_saves || !j.n_ops) return nullptr;
+    for (uint32_t k = 0; k < j.n_saves; ++k)
+        if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
+    JitSig g; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
+    g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask;
+    if (w->spec && w->spec->sig == g) return w->spec->state.load(std::memory_order_acquire) == 2 ? w->spec->fn : nullptr;
+    if (w->spec_last == g) ++w->spec_repeat; else { w->spec_last = g; w->spec_repeat = 1; }
+    if (w->spec_repeat < (uint32_t)w->knobs.jit_specialise_after) return nullptr;
+    if (w->spec && w->spec->state.load(std::memory_order_acquire) == 1) return nullptr;        // one build at a time
+    jit_spec_retire(w);                                                                         // the session settled on another shape
+    const std::string src = jit_specialise(w->jit_src, g);
+    if (src.empty()) { w->spec_repeat = 0; return nullptr; }
+    w->spec = new JitSpec; w->spec->sig = g; w->spec->state.store(1, std::memory_order_relaxed);
+    if (w->knobs.jit_specialise_sync) jit_spec_build(w->spec, w->device, src, w->knobs.jit_cache_dir);
+    else w->spec->th = std::thread(jit_spec_build, w->spec, w->device, src, w->knobs.jit_cache_dir);
+    return w->spec->state.load(std::memory_order_acquire) == 2 ? w->spec->fn : nullptr;
+}
+
 struct JitBatch {
     bool active = false; GgrsJitArgs j; uint32_t g = 0, k = 0, res_first = 0, n_cks = 0;
     void start(const GgrsJitArgs& j_, uint32_t g_, uint32_t res, uint32_t n_cks_) { active = true; j = j_; g = g_; k = 1; res_first = res; n_cks = n_cks_; }
@@ -397,7 +418,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             if (launch) {
                 ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
-                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, jit_lane_fold_bytes(w, n_cks, j.n_saves), w->stream, params, nullptr));
+                hipFunction_t fn = jit_spec_for(w, j);
+                if (!fn) fn = w->jit_fn;
+                HIPCHK(w, hipModuleLaunchKernel(fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, jit_lane_fold_bytes(w, n_cks, j.n_saves), w->stream, params, nullptr));
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }

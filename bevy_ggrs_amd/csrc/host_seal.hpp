@@ -165,6 +165,7 @@ int seal_impl(ggrs_world* w) {
         else {
             if (w->knobs.debug_jit > 1) fprintf(stderr, "%s\n", src.c_str());
             const std::string keep = w->err;
+            w->jit_src = src;
             if (jit_cached(w, src, &w->jit_fn, &w->jit_entry) != GGRS_OK) {
                 if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] generated request-group kernel rejected: %s\n", w->err.c_str());
                 w->jit_status = (hiprtc().lib ? "rejected: " : "hiprtc unavailable: ") + w->err.substr(0, 300);

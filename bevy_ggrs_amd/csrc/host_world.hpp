@@ -67,6 +67,9 @@ struct Knobs {
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
                                    //                       of >= 400 k slots, kernel_gen.hpp jit_lane_fold)
+    int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive HBM-sized group of one shape starts the build of a kernel specialised for
+                                   //                       it (0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
+    bool jit_specialise_sync = false;
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
                                         //                       the snapshot the next rollback loads, goes through the L2)
@@ -91,6 +94,8 @@ struct Knobs {
         k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
         k.arena_flush = (int)num("GGRS_ARENA_FLUSH", 0);
         k.jit_lane_fold = (int)num("GGRS_JIT_LANE_FOLD", -1);
+        k.jit_specialise_after = (int)num("GGRS_JIT_SPECIALISE_AFTER", 16);
+        k.jit_specialise_sync = num("GGRS_JIT_SPECIALISE_SYNC", 0) != 0;
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
         k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;
@@ -114,6 +119,21 @@ struct ParkedArena { uint8_t* ptr; uint64_t bytes; int device; };
 static std::mutex g_parked_mu;
 static std::vector<ParkedArena> g_parked;
 
+// What a specialised request-group kernel hard-codes: the op sequence and every wave-uniform mask of the group.
+struct JitSig {
+    uint64_t op_bits = 0, save_rows = 0, live_rows = 0, load_rows = 0;
+    uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0;
+    bool operator==(const JitSig& o) const {
+        return op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
+               n_steps == o.n_steps && src_is_live == o.src_is_live && skip_live == o.skip_live && nt == o.nt && cached_saves == o.cached_saves &&
+               save_pmask == o.save_pmask && live_pmask == o.live_pmask;
+    }
+};
+struct JitSpec {
+    JitSig sig; std::atomic<int> state{0};                // 1 building (worker thread), 2 ready, 3 failed
+    hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::thread th; std::string why;
+};
+
 struct ggrs_world {
     // ---- configuration
     int device = 0;
@@ -134,6 +154,9 @@ struct ggrs_world {
     // the request-group kernel generated for this world (kernel_gen.hpp): one workgroup per 256 slots (small worlds: roles,
     // batches, host-side fold) and its persistent form (HBM-sized worlds: grid = what the chip holds, checksum fold in-kernel)
     hipFunction_t jit_fn = nullptr, jit_fn_persist = nullptr;
+    // the per-tile form specialised for the group shape the session keeps sending (kernel_gen.hpp jit_specialise): its text, the
+    // shape being counted, the kernel (built on a worker thread; used once `state` says ready)
+    std::string jit_src; JitSig spec_last{}; uint32_t spec_repeat = 0; JitSpec* spec = nullptr;
     JitEntry* jit_entry = nullptr; JitEntry* jit_entry_persist = nullptr;   // handed back to the module cache when the world is destroyed
     uint32_t jit_persist_wgs = 0, jit_persist_tpb = 1024;   // workgroups of the persistent form the device holds at once, and their size
     std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)

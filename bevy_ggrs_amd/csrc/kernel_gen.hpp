@@ -646,8 +646,9 @@ constexpr size_t JIT_CACHE_MAX_MODULES = 64;     // in-process: beyond this many
 struct JitCache { std::mutex mu; std::map<std::pair<int, std::string>, JitEntry> map; uint64_t clock = 0; };
 JitCache& jit_cache() { static JitCache c; return c; }
 uint64_t fnv1a(const std::string& s, uint64_t h) { for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; } return h; }
-std::string jit_disk_path(const ggrs_world* w, const std::string& src) {
-    std::string dir = w->knobs.jit_cache_dir;
+std::string jit_disk_path_in(std::string dir, const std::string& src);
+std::string jit_disk_path(const ggrs_world* w, const std::string& src) { return jit_disk_path_in(w->knobs.jit_cache_dir, src); }
+std::string jit_disk_path_in(std::string dir, const std::string& src) {
     if (dir == "0" || dir == "off") return "";
     if (dir.empty()) {
         const char* home = getenv("HOME");
@@ -716,4 +717,86 @@ void jit_release(JitEntry* e) {
         if (victim->second.mod) (void)hipModuleUnload(victim->second.mod);
         jc.map.erase(victim);
     }
+}
+
+// ---- a kernel for ONE group shape ------------------------------------------------------------------------------------------
+// The generated kernel serves any request group: it walks an op list, and every Save / load / live write asks wave-uniform masks
+// what to move.  A session sends the same shape tick after tick ([Load, (Advance, Save) x d] with the same row masks); with the
+// shape's fields as literals and the op loop unrolled the compiler drops the walk, the role / mask / policy tests (about 40 % of
+// the scalar instructions) and a third of the registers: 59.3 -> 53.8 us per depth-8 tick at 1 M (profiles/r03n).  The text is the
+// generic kernel's with the argument fields replaced -- same body, same argument block, same launch.
+std::string jit_specialise(const std::string& generic, const JitSig& g) {
+    const size_t k = generic.find("extern \"C\" __global__");
+    if (k == std::string::npos) return "";
+    std::string head = generic.substr(0, k), body = generic.substr(k);
+    auto lit64 = [](uint64_t v) { char b[40]; snprintf(b, sizeof b, "0x%llxull", (unsigned long long)v); return std::string(b); };
+    auto lit32 = [](uint32_t v) { char b[24]; snprintf(b, sizeof b, "%uu", v); return std::string(b); };
+    const std::pair<const char*, std::string> subs[] = {
+        {"a.save_rows[si]", lit64(g.save_rows)}, {"a.save_pmask[si]", lit32(g.save_pmask)}, {"a.op_bits", lit64(g.op_bits)}, {"a.n_ops", lit32(g.n_ops)},
+        {"a.n_saves", lit32(g.n_saves)}, {"a.n_steps", lit32(g.n_steps)}, {"a.src_is_live", lit32(g.src_is_live)}, {"a.skip_live", lit32(g.skip_live)},
+        {"a.dp_s", "0u"}, {"a.nt", lit32(g.nt)}, {"a.cached_saves", lit32(g.cached_saves)}, {"a.live_rows", lit64(g.live_rows)}, {"a.load_rows", lit64(g.load_rows)},
+        {"a.live_pmask", lit32(g.live_pmask)}};
+    for (auto& sb : subs) {
+        const size_t n = strlen(sb.first);
+        for (size_t p = body.find(sb.first); p != std::string::npos; p = body.find(sb.first, p + sb.second.size())) body.replace(p, n, sb.second);
+    }
+    const std::string loop = "    for (uint32_t op = 0; op < " + lit32(g.n_ops) + "; ++op) {";
+    const size_t lp = body.find(loop);
+    if (lp == std::string::npos) return "";
+    body.insert(lp, "#pragma unroll\n");
+    char note[256];
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x\n", g.n_ops,
+             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves);
+    return head + note + body;
+}
+// Build (or load from the disk cache) without touching a world: runs on a worker thread
+void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_dir) {
+    auto done = [&](int st, const std::string& why) { sp->why = why; sp->state.store(st, std::memory_order_release); };
+    if (hipSetDevice(device) != hipSuccess) return done(3, "hipSetDevice failed");
+    Hiprtc& rtc = hiprtc();
+    if (!rtc.lib) return done(3, rtc.why);
+    std::vector<char> image;
+    const std::string path = jit_disk_path_in(cache_dir, src);
+    if (!path.empty()) if (FILE* f = fopen(path.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+        if (n > 0) { image.resize((size_t)n); if (fread(image.data(), 1, (size_t)n, f) != (size_t)n) image.clear(); }
+        fclose(f);
+        if (!image.empty() && !(hipModuleLoadData(&sp->mod, image.data()) == hipSuccess && hipModuleGetFunction(&sp->fn, sp->mod, "ggrs_jit_tick") == hipSuccess)) {
+            if (sp->mod) { (void)hipModuleUnload(sp->mod); sp->mod = nullptr; }
+            sp->fn = nullptr; image.clear(); (void)hipGetLastError();
+        }
+    }
+    if (!sp->fn) {
+        hiprtcProgram prog = nullptr;
+        if (rtc.create(&prog, src.c_str(), "ggrs_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return done(3, "hiprtcCreateProgram failed");
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"};
+        const hiprtcResult r = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+        size_t nbytes = 0;
+        if (r != HIPRTC_SUCCESS || rtc.code_size(prog, &nbytes) != HIPRTC_SUCCESS || !nbytes) {
+            size_t n = 0; std::string log;
+            if (rtc.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); (void)rtc.log(prog, &log[0]); }
+            (void)rtc.destroy(&prog);
+            if (log.size() > 2000) log.resize(2000);
+            return done(3, "the specialised kernel does not compile: " + log);
+        }
+        image.resize(nbytes);
+        const bool ok = rtc.code(prog, image.data()) == HIPRTC_SUCCESS;
+        (void)rtc.destroy(&prog);
+        if (!ok || hipModuleLoadData(&sp->mod, image.data()) != hipSuccess || hipModuleGetFunction(&sp->fn, sp->mod, "ggrs_jit_tick") != hipSuccess) {
+            if (sp->mod) { (void)hipModuleUnload(sp->mod); sp->mod = nullptr; }
+            sp->fn = nullptr; (void)hipGetLastError();
+            return done(3, "the specialised kernel's code object does not load");
+        }
+        if (!path.empty()) {
+            const std::string tmp = path + ".tmp" + std::to_string((long long)getpid()) + "s";
+            if (FILE* f = fopen(tmp.c_str(), "wb")) { const bool w_ok = fwrite(image.data(), 1, image.size(), f) == image.size(); fclose(f); if (w_ok) (void)rename(tmp.c_str(), path.c_str()); else (void)remove(tmp.c_str()); }
+        }
+    }
+    done(2, "");
+}
+void jit_spec_retire(ggrs_world* w) {                     // the worker is joined, launches that use the module have drained
+    if (!w->spec) return;
+    if (w->spec->th.joinable()) w->spec->th.join();
+    if (w->spec->mod) { if (w->stream) (void)hipStreamSynchronize(w->stream); (void)hipModuleUnload(w->spec->mod); }
+    delete w->spec; w->spec = nullptr;
 }

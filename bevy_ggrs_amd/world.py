@@ -375,6 +375,13 @@ class World(WorldBase):
         self._check(self._lib.ggrs_hip_profile_read_launches(self._p, idx, buf, cap, C.byref(n)))
         return [float(buf[i]) for i in range(min(cap, n.value))]
 
+    def specialise_wait(self) -> bool:
+        """Block until a build of the kernel specialised for the session's steady group shape (if one is in flight) has finished;
+        True when such a kernel is ready (include/ggrs_hip.h ggrs_hip_specialise_wait)."""
+        rc = int(self._lib.ggrs_hip_specialise_wait(self._p))
+        if rc < 0: self._check(rc)
+        return rc == 1
+
     def kernel_info(self) -> dict:
         """ggrs_hip_world_kernel_info as a dict: arena kind, run-time compiler state, which kernel serves the world."""
         need = C.c_uint64(0)

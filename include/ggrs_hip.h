@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 6
+#define GGRS_HIP_ABI_VERSION 7
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -404,9 +404,16 @@ int ggrs_hip_profile_read_bytes(ggrs_world* w, uint64_t* bytes_out);
  * Introspection: which kernel serves this world's request lists right now and why, what kind of arena
  * it lives on, whether the run-time compiler (libhiprtc.so, dlopen'ed) is available.  `key=value` lines,
  * NUL-terminated; *needed = bytes incl. the NUL, min(cap, *needed) are copied.  Keys: sealed, arena,
- * arena_bytes, hiprtc, generated_kernel, request_group_kernel, slots_covered, row_versions.
+ * arena_bytes, hiprtc, generated_kernel, request_group_kernel, specialised_kernel, slots_covered, row_versions.
  * ------------------------------------------------------------------------------------------- */
 int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed);
+
+/* Once a session has sent the same HBM-sized request-group shape GGRS_JIT_SPECIALISE_AFTER (16) times in a row, the library builds --
+ * on a worker thread, never on the caller's -- a copy of the world's generated kernel with that shape's op sequence and row masks as
+ * literals (about 9 % faster at 1 M entities) and switches to it when it is ready; any other shape keeps running on the general kernel.
+ * ggrs_hip_specialise_wait blocks until a build in flight has finished (a loading screen, a benchmark): 1 = a specialised kernel is
+ * ready, 0 = none (no steady shape yet, a small world, the build failed -- ggrs_hip_world_kernel_info "specialised_kernel" says which). */
+int ggrs_hip_specialise_wait(ggrs_world* w);
 
 #ifdef __cplusplus
 }

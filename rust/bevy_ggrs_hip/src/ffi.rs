@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 6;
+pub const GGRS_HIP_ABI_VERSION: c_int = 7;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -172,5 +172,6 @@ unsafe extern "C" {
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;
     pub fn ggrs_hip_profile_read_launches(w: *mut ggrs_world, kernel_class: u32, us_out: *mut f32, cap: u32, n_out: *mut u32) -> c_int;
     pub fn ggrs_hip_profile_read_bytes(w: *mut ggrs_world, bytes_out: *mut u64) -> c_int;
+    pub fn ggrs_hip_specialise_wait(w: *mut ggrs_world) -> c_int;
     pub fn ggrs_hip_world_kernel_info(w: *mut ggrs_world, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
 }

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported_and_bound():
 
 
 def test_abi_version_and_struct_sizes():
-    assert _ffi.lib.ggrs_hip_abi_version() == 6
+    assert _ffi.lib.ggrs_hip_abi_version() == 7
     assert C.sizeof(_ffi.Request) == 48
     assert C.sizeof(_ffi.SystemDesc) == 72
     assert C.sizeof(_ffi.WorldDesc) == 48

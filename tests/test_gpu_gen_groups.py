@@ -168,3 +168,51 @@ def test_hbm_sized_generic_world_on_the_generated_kernel(n):
         if name == "gen": assert _group_launches(w) >= ticks
         res.append((name, drv.all_checksums, cm.snapshot_state(w, (T, V, L, H))))
     _check(res)
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_steady_group_shape_gets_its_own_kernel(sync, monkeypatch):
+    """include/ggrs_hip.h ggrs_hip_specialise_wait: after GGRS_JIT_SPECIALISE_AFTER identical HBM-sized groups the library builds the
+    generated kernel again with that shape's op sequence and row masks as literals -- on the calling thread (sync) or on a worker
+    (the default) -- and runs the shape on it from then on.  Depth-8 SyncTest with Ttl despawns against the oracle across the switch,
+    then another shape (check distance 5: the old kernel must not be used for it, a new one replaces it), then a spawn that changes
+    the row masks for a few ticks (general kernel) and the steady state again."""
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_AFTER", "3")
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_SYNC", "1" if sync else "0")
+    n = 600_000
+    res, infos = [], []
+    for name, w in [("gen", bg.World(n + 4000, max_depth=9)), ("oracle", OracleWorld(n + 4000, 9))]:
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=50)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        fn = cm.frame_spawn_fn(64)
+        drv = cm.SyncTestDriver(w, 8)
+        for t in range(9): drv.tick((0,))
+        if name == "gen":
+            ready = w.specialise_wait()
+            infos.append((ready, w.kernel_info()["specialised_kernel"]))
+        for t in range(6): drv.tick((0,))
+        out = list(drv.all_checksums)
+        # another shape, driven by hand: roll back 5 frames every tick ([Load(F-5), (Adv, Save) x 5, Adv])
+        if hasattr(w, "set_synctest_check_distance"): w.set_synctest_check_distance(-1)
+
+        def roll5(spawn=False):
+            F = w.frame
+            w.set_confirmed(max(0, F - 7))
+            reqs = [bg.LoadGameState(F - 5)]
+            for i in range(5):
+                a = bg.AdvanceFrame((cm.INPUT_SPAWN if (spawn and i == 2) else 0,))
+                if spawn and i == 2: a.spawn_vx, a.spawn_vy = fn(F - 5 + i)
+                reqs += [a, bg.SaveGameState(F - 4 + i)]
+            reqs.append(bg.AdvanceFrame((0,)))
+            return w.handle_requests(reqs)
+
+        for t in range(9): out += roll5()
+        if name == "gen": infos.append((w.specialise_wait(), w.kernel_info()["specialised_kernel"]))
+        for t in range(4): out += roll5()
+        out += roll5(spawn=True)                                               # new rows: every column of the bundle is stored again for a while
+        for t in range(8): out += roll5()
+        if name == "gen": infos.append((w.specialise_wait(), w.kernel_info()["specialised_kernel"]))
+        res.append((name, out, cm.snapshot_state(w, ids)))
+    _check(res)
+    assert all(r for r, _ in infos) and all(s.startswith("ready") for _, s in infos), infos
