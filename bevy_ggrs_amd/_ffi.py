@@ -70,7 +70,7 @@ class Request(C.Structure):
                 ("spawn_vy", C.POINTER(C.c_float))]
 
 
-KERNEL_FORM_TILES, KERNEL_FORM_PERSISTENT = 1, 2
+KERNEL_FORM_TILES, KERNEL_FORM_PERSISTENT, KERNEL_FORM_STEADY = 1, 2, 3
 
 # every symbol include/ggrs_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

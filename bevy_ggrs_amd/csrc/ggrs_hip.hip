@@ -234,13 +234,21 @@ int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* d) 
     return GGRS_OK;
 }
 int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, uint64_t cap, uint64_t* needed, int compile) {
-    if (!w || (form != GGRS_KERNEL_FORM_TILES && form != GGRS_KERNEL_FORM_PERSISTENT)) return GGRS_E_INVALID;
+    if (!w || (form != GGRS_KERNEL_FORM_TILES && form != GGRS_KERNEL_FORM_PERSISTENT && form != GGRS_KERNEL_FORM_STEADY)) return GGRS_E_INVALID;
     if (!w->sealed) {
         if (!w->layout_only) { DeviceGuard dg(w); const int rc = seal(w); if (rc) return rc; }
         else build_layout(w);                                      // host arithmetic only: offsets of every mask and column
     }
     std::string src;
     if (!jit_source(w, src, form == GGRS_KERNEL_FORM_PERSISTENT)) return w->fail(GGRS_E_INVALID, "the kernel generator does not cover this world (a system writes a live-only component, or more than %u four-byte units / %u words per entity)", JIT_MAX_UNITS, JIT_MAX_COLS);
+    if (form == GGRS_KERNEL_FORM_STEADY) {
+        const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, MAX_TICK_SAVES);
+        JitSig g; g.n_saves = g.n_steps = d; g.n_ops = 2 * d; g.nt = 1; g.cached_saves = 1;
+        for (uint32_t k = 0; k < d; ++k) g.op_bits |= 1ull << (2 * k);                     // Advance, Save, Advance, Save, ...
+        g.save_rows = g.live_rows = jit_hot_cols(w); g.load_rows = g.save_rows | jit_static_reads(w);
+        src = jit_specialise(src, g);
+        if (src.empty()) return w->fail(GGRS_E_INVALID, "the generated kernel's text could not be specialised");
+    }
     if (needed) *needed = src.size() + 1;
     if (buf && cap) { const uint64_t n = std::min<uint64_t>(cap, src.size() + 1); memcpy(buf, src.c_str(), n); buf[n - 1] = 0; }
     if (compile) { hipFunction_t fn = nullptr; return hiprtc_build(w, src, "generated request-group kernel", "ggrs_jit_tick", nullptr, &fn); }

@@ -280,11 +280,11 @@ class World(WorldBase):
         for i, v in enumerate(fparam): d.fparam[i] = v
         self._check(self._lib.ggrs_hip_add_custom_system(self._p, C.byref(d)))
 
-    def generated_kernel_source(self, compile: bool = False, persistent: bool = False) -> str:
+    def generated_kernel_source(self, compile: bool = False, persistent: bool = False, steady: bool = False) -> str:
         """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source), in its
         per-tile form or its persistent form; with compile=True it is also built for gfx950 with hiprtc.  Works on a
         GGRS_WORLD_LAYOUT_ONLY world (no GPU)."""
-        form = _ffi.KERNEL_FORM_PERSISTENT if persistent else _ffi.KERNEL_FORM_TILES
+        form = _ffi.KERNEL_FORM_STEADY if steady else _ffi.KERNEL_FORM_PERSISTENT if persistent else _ffi.KERNEL_FORM_TILES   # steady: the copy specialised for the SyncTest tick
         need = C.c_uint64(0)
         self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, form, None, 0, C.byref(need), 0))
         buf = C.create_string_buffer(need.value)

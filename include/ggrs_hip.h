@@ -219,6 +219,9 @@ int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* des
  * complete; on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
 #define GGRS_KERNEL_FORM_TILES      1u
 #define GGRS_KERNEL_FORM_PERSISTENT 2u
+#define GGRS_KERNEL_FORM_STEADY     3u   /* the per-tile form specialised for the steady SyncTest tick of this world ([Load, (Advance,
+                                            Save) x (max_depth - 1)], the rows its systems write, nt stores, first Save cached): what
+                                            ggrs_hip_specialise_wait waits for, here for inspection / a build-machine compile check */
 int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, uint64_t cap, uint64_t* needed, int compile);
 
 /* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */

@@ -80,6 +80,23 @@ def test_generated_kernel_builds_for_gfx950(name, persistent):
         assert "side_h0_0" in src, "a live-only Player.handle is read from the live block, not from the snapshot"
 
 
+@pytest.mark.parametrize("name", sorted(WORLDS))
+def test_kernel_specialised_for_the_steady_tick_builds(name):
+    """GGRS_KERNEL_FORM_STEADY: the per-tile form with the SyncTest tick's op sequence, row masks and store policies as literals and
+    the op loop unrolled (kernel_gen.hpp jit_specialise) -- the text a running session gets from a worker thread after 16 identical
+    groups.  It must build for gfx950 (overwriting fields of the by-value argument struct instead makes the backend abort), keep the
+    argument block, and no longer ask the arguments for anything the shape fixes."""
+    w = WORLDS[name]()
+    gen = w.generated_kernel_source()
+    src = w.generated_kernel_source(compile=True, steady=True)
+    body = src[src.index('extern "C" __global__'):]
+    assert "// specialised: " in src and "#pragma unroll\n    for (uint32_t op = 0; op < " in body
+    for field in ("a.op_bits", "a.n_ops", "a.n_saves", "a.save_rows[si]", "a.save_pmask[si]", "a.live_rows", "a.load_rows", "a.nt", "a.dp_s", "a.cached_saves", "a.skip_live"):
+        assert field in gen and field not in body, field
+    assert "a.save_dst[si]" in body and "a.dt_bits[sj]" in body and "a.len" in body       # what stays an argument
+    assert src[:src.index('extern "C" __global__')].replace(src[src.index("// specialised: "):src.index('extern "C" __global__')], "") == gen[:gen.index('extern "C" __global__')]
+
+
 def test_generated_kernel_unrolls_this_worlds_schema():
     src = particles().generated_kernel_source()
     body = src[src.index('#line 1 "ggrs_jit_tick"'):]
