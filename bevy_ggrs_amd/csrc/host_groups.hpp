@@ -247,13 +247,14 @@ inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 // Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
 // launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
 // The kernel specialised for this group's shape, once the session has sent the shape often enough and the build is done (kernel_gen.hpp
-// jit_specialise); nullptr: use the generic kernel.  Only plain HBM-sized launches qualify (no roles, no batch, every Save stored).
+// jit_specialise); nullptr: use the generic kernel.  Plain launches of every size qualify (depth-parallel roles are part of the shape); batches of
+// checksum-only branches and groups with an eliminated Save do not.
 hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
-    if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.nt || j.dp_s || !j.n_saves || !j.n_ops) return nullptr;
+    if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.n_saves || !j.n_ops) return nullptr;
     for (uint32_t k = 0; k < j.n_saves; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
     JitSig g; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
-    g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask;
+    g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s;
     if (w->spec && w->spec->sig == g) return w->spec->state.load(std::memory_order_acquire) == 2 ? w->spec->fn : nullptr;
     if (w->spec_last == g) ++w->spec_repeat; else { w->spec_last = g; w->spec_repeat = 1; }
     if (w->spec_repeat < (uint32_t)w->knobs.jit_specialise_after) return nullptr;

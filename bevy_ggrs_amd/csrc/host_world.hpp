@@ -67,7 +67,7 @@ struct Knobs {
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
                                    //                       of >= 400 k slots, kernel_gen.hpp jit_lane_fold)
-    int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive HBM-sized group of one shape starts the build of a kernel specialised for
+    int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive group of one shape starts the build of a kernel specialised for
                                    //                       it (0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
@@ -122,11 +122,11 @@ static std::vector<ParkedArena> g_parked;
 // What a specialised request-group kernel hard-codes: the op sequence and every wave-uniform mask of the group.
 struct JitSig {
     uint64_t op_bits = 0, save_rows = 0, live_rows = 0, load_rows = 0;
-    uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0;
+    uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0, dp_s = 0;
     bool operator==(const JitSig& o) const {
         return op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
                n_steps == o.n_steps && src_is_live == o.src_is_live && skip_live == o.skip_live && nt == o.nt && cached_saves == o.cached_saves &&
-               save_pmask == o.save_pmask && live_pmask == o.live_pmask;
+               save_pmask == o.save_pmask && live_pmask == o.live_pmask && dp_s == o.dp_s;
     }
 };
 struct JitSpec {

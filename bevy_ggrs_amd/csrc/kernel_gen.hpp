@@ -734,7 +734,7 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const std::pair<const char*, std::string> subs[] = {
         {"a.save_rows[si]", lit64(g.save_rows)}, {"a.save_pmask[si]", lit32(g.save_pmask)}, {"a.op_bits", lit64(g.op_bits)}, {"a.n_ops", lit32(g.n_ops)},
         {"a.n_saves", lit32(g.n_saves)}, {"a.n_steps", lit32(g.n_steps)}, {"a.src_is_live", lit32(g.src_is_live)}, {"a.skip_live", lit32(g.skip_live)},
-        {"a.dp_s", "0u"}, {"a.nt", lit32(g.nt)}, {"a.cached_saves", lit32(g.cached_saves)}, {"a.live_rows", lit64(g.live_rows)}, {"a.load_rows", lit64(g.load_rows)},
+        {"a.dp_s", lit32(g.dp_s)}, {"a.nt", lit32(g.nt)}, {"a.cached_saves", lit32(g.cached_saves)}, {"a.live_rows", lit64(g.live_rows)}, {"a.load_rows", lit64(g.load_rows)},
         {"a.live_pmask", lit32(g.live_pmask)}};
     for (auto& sb : subs) {
         const size_t n = strlen(sb.first);
