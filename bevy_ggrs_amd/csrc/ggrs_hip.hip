@@ -17,6 +17,7 @@
 // There is NO CPU fallback: without a HIP device world creation fails with GGRS_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>      // hipExtModuleLaunchKernel: event pairs that ride on a dispatch (profiling)
 #include <hip/hiprtc.h>   // types and prototypes only: resolved with dlsym on first use (no link-time dependency)
 #include <rccl/rccl.h>      // types and prototypes only: every entry point is resolved with dlsym (no link-time dependency)
 #include <dlfcn.h>

@@ -246,6 +246,18 @@ inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 
 // Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
 // launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
+// Launch of a generated kernel.  With profiling on, the event pair rides on the dispatch itself (hipExtModuleLaunchKernel's start / stop events:
+// the kernel's own begin and end, what rocprofv3's kernel trace reports) instead of bracketing it with two marker packets, which read ~3 us more.
+int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tpb, uint32_t lds, void** params, uint64_t bytes) {
+    if (!w->prof) { HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr)); return GGRS_OK; }
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(w, hipEventCreate(&a)); HIPCHK(w, hipEventCreate(&b));
+    w->prof_bytes[GGRS_KERNEL_TICK] += bytes;
+    HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr, a, b, 0));
+    w->prof_events.push_back({a, b, GGRS_KERNEL_TICK});
+    return GGRS_OK;
+}
+
 // The kernel specialised for this group's shape, once the session has sent the shape often enough and the build is done (kernel_gen.hpp
 // jit_specialise); nullptr: use the generic kernel.  Plain launches of every size qualify (depth-parallel roles are part of the shape); batches of
 // checksum-only branches and groups with an eliminated Save do not.
@@ -286,12 +298,12 @@ struct JitBatch {
         active = false;
         bool host_fold = false; uint64_t rows_off = 0;
         {
-            ProfScope ps(w, GGRS_KERNEL_TICK, rows_bytes_per_slot(w, j.load_rows) * j.len * k);
             void* params[] = {&j};
             if (k > 1) j.dp_s = 0;
             host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
-            HIPCHK(w, hipModuleLaunchKernel(w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, 1, 1, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), w->stream, params, nullptr));
+            { const int lrc = launch_jit(w, w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), params,
+                                         rows_bytes_per_slot(w, j.load_rows) * j.len * k); if (lrc) return lrc; }
         }
         if (host_fold) { w->folds.push_back({res_first, j.n_saves, g, n_cks, k, rows_off, j.len}); return GGRS_OK; }
         GenFinArgs f; memset(&f, 0, sizeof f);
@@ -387,9 +399,8 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             // tail better, at the price of more rows for tick_fold's last arriver)
             const uint32_t gp = std::max(1u, std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs * (uint32_t)w->knobs.jit_persist_oversub));
             if (launch) {
-                ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
-                HIPCHK(w, hipModuleLaunchKernel(w->jit_fn_persist, gp, 1, 1, w->jit_persist_tpb, 1, 1, 0, w->stream, params, nullptr));
+                rc = launch_jit(w, w->jit_fn_persist, gp, 1, 1, w->jit_persist_tpb, 0, params, bytes_slot * w->len); if (rc) return rc;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             ns += j.n_saves;
@@ -417,11 +428,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (launch) {
-                ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
                 void* params[] = {&j};
                 hipFunction_t fn = jit_spec_for(w, j);
                 if (!fn) fn = w->jit_fn;
-                HIPCHK(w, hipModuleLaunchKernel(fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, 1, 1, jit_lane_fold_bytes(w, n_cks, j.n_saves), w->stream, params, nullptr));
+                rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, jit_lane_fold_bytes(w, n_cks, j.n_saves), params, bytes_slot * w->len); if (rc) return rc;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }
