@@ -20,8 +20,8 @@ KNOBS = [
     {"GGRS_JIT_PARTICLES_MAX_SLOTS": "0"},                  # k_tick3 even for small worlds (a generated kernel exists)
     {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},     # generated kernel, never persistent (k_gen_finalize launch for big worlds)
     {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1"},     # generated kernel, persistent form + in-launch fold even for small worlds
-    {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # small groups folded on the device
-    {"GGRS_HOST_FOLD_MAX_WGS": "100000", "GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},   # every group folded by the host
+    {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # every group folded on the device (k_gen_finalize)
+    {"GGRS_HOST_FOLD_MAX_WGS": "256"},                      # only small groups folded by the host (the round-2 default)
     {"GGRS_DEAD_GROUPS": "0"},
     {"GGRS_JIT_DP": "0"},
     {"GGRS_JIT_DP": "3"},
