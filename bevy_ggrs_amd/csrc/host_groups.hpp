@@ -293,6 +293,7 @@ struct JitBatch {
         ++k;
         return true;
     }
+    bool blocking = false;                                           // the synchronous API: see host_fold_rows
     int flush(ggrs_world* w) {
         if (!active) return GGRS_OK;
         active = false;
@@ -300,7 +301,7 @@ struct JitBatch {
         {
             void* params[] = {&j};
             if (k > 1) j.dp_s = 0;
-            host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off);
+            host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off, blocking);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             { const int lrc = launch_jit(w, w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), params,
                                          rows_bytes_per_slot(w, j.load_rows) * j.len * k); if (lrc) return lrc; }
@@ -322,7 +323,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                            uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
     uint32_t i = 0, ns = 0;
     int rc = GGRS_OK;
-    JitBatch batch;
+    JitBatch batch; batch.blocking = wait;
     const uint32_t n_cks = w->cks_args.n_cks;
     const uint64_t static_reads = jit_static_reads(w);
     while (i < n) {
@@ -425,7 +426,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             uint64_t rows_off = 0;
-            const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off);
+            const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (launch) {
                 void* params[] = {&j};
