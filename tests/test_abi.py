@@ -139,3 +139,4 @@ def test_kernel_info_without_a_device():
     w.register_component("X", 4, 1)
     info = w.kernel_info()
     assert info["sealed"] == "0" and info["hiprtc"].startswith(("loaded", "missing")) and "request_group_kernel" in info and info["row_versions"] == "on"
+    assert info["specialised_kernel"] == "none yet" and w.specialise_wait() is False              # nothing to wait for: no request group has run
