@@ -84,10 +84,14 @@ void hiprtc_load(Hiprtc& r) {
     "};\n"
 
 // hiprtc: source -> code object -> module + kernel handle.  A compile error fails with the compiler log in w->err.
+// one compile at a time in this process: a world being sealed on the caller's thread and a specialised kernel being built on a worker
+// never run the compiler concurrently
+static std::mutex g_hiprtc_mu;
 int hiprtc_build(ggrs_world* w, const std::string& src, const char* what, const char* kernel, hipModule_t* mod, hipFunction_t* fn,
                  std::vector<char>* image_out = nullptr) {
     Hiprtc& rtc = hiprtc();
     if (!rtc.lib) return w->fail(GGRS_E_HIP, "%s: %s", what, rtc.why.c_str());
+    std::lock_guard<std::mutex> compile_lock(g_hiprtc_mu);
     hiprtcProgram prog = nullptr;
     hiprtcResult r = rtc.create(&prog, src.c_str(), "ggrs_generated.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) return w->fail(GGRS_E_HIP, "hiprtcCreateProgram: %s", rtc.err_str(r));
@@ -767,6 +771,7 @@ void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_
         }
     }
     if (!sp->fn) {
+        std::lock_guard<std::mutex> compile_lock(g_hiprtc_mu);
         hiprtcProgram prog = nullptr;
         if (rtc.create(&prog, src.c_str(), "ggrs_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return done(3, "hiprtcCreateProgram failed");
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"};
