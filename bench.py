@@ -615,7 +615,7 @@ def main():
         kname = info.get("request_group_kernel", "?")
         fin_name = "k_gen_finalize / k_tick_finalize"
         roof = {"bound": "hbm", "kernel": kname + " -- fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
-                                           + ("" if fin_n == 0 else f"; + {fin_name}"),
+                                           + ("; the per-workgroup checksum rows are folded by the host at collect time" if fin_n == 0 else f"; + {fin_name}"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
                 # the two accountings, named so they cannot be confused: `frac` == frac_compulsory
