@@ -2,8 +2,9 @@
 produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU oracle under each setting, so the
 driver-run suite covers every kernel that ships -- k_tick3 at every size, the generated kernel in its per-tile and
 persistent forms with the fold on the host / in k_gen_finalize / in the launch, with and without depth-parallel roles,
-dead-snapshot elimination and row versions, on paged and contiguous arenas.  (GGRS_ARENA_PARK=0 is the one knob without a case:
-it re-enables the runtime hazard of profiles/r03fc and exists for that experiment only.)"""
+dead-snapshot elimination and row versions, on paged and contiguous arenas.  (Two knobs have no case: GGRS_ARENA_PARK=0
+re-enables the runtime hazard of profiles/r03fc and exists for that experiment only; GGRS_HIP_ROCTX=1 needs the roctx library of a
+profiler session.)"""
 import numpy as np
 import pytest
 
@@ -23,6 +24,9 @@ KNOBS = [
     {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # every group folded on the device (k_gen_finalize)
     {"GGRS_HOST_FOLD_MAX_WGS": "256"},                      # only small groups folded by the host (the round-2 default)
     {"GGRS_DEAD_GROUPS": "0"},
+    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
+    {"GGRS_JIT_DP_MAX_SLOTS": "400000"},                    # depth-parallel roles far above their default range
+    {"GGRS_HIP_TRACE": "1", "GGRS_DEBUG_JIT": "1", "GGRS_DEBUG_ARENA": "1"},   # the diagnostic prints change nothing
     {"GGRS_JIT_DP": "0"},
     {"GGRS_JIT_DP": "3"},
     {"GGRS_ROW_VERSIONS": "0"},
