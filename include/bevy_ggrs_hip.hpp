@@ -395,6 +395,7 @@ struct HipBackend {
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) { return ggrs_hip_handle_requests(w, r, n, out); }
     int enqueue_requests(const ggrs_request* r, uint32_t n) { return ggrs_hip_enqueue_requests(w, r, n, nullptr); }
     int collect_checksums(uint64_t* out, uint32_t max_saves) { return ggrs_hip_collect_checksums(w, out, max_saves, nullptr); }
+    bool specialise_wait() { return ggrs_hip_specialise_wait(w) == 1; }     // a loading screen: block until the kernel built for the session's steady tick is in (include/ggrs_hip.h)
     int32_t frame() { return ggrs_hip_frame(w); }
     int set_frame(int32_t f) { return ggrs_hip_set_frame(w, f); }
     uint64_t len() { return ggrs_hip_len(w); }

@@ -102,6 +102,12 @@ impl HipWorld {
     pub fn len(&self) -> u64 {
         unsafe { ffi::ggrs_hip_len(self.raw) }
     }
+    /// After 16 identical request groups the library builds, on a worker thread, a copy of the world's kernel specialised for that
+    /// shape (include/ggrs_hip.h `ggrs_hip_specialise_wait`).  A loading screen that has driven a few warm-up ticks can block here
+    /// until it is in; true = the steady tick now runs on its own kernel.
+    pub fn specialise_wait(&self) -> bool {
+        unsafe { ffi::ggrs_hip_specialise_wait(self.raw) == 1 }
+    }
     pub fn frame(&self) -> i32 {
         unsafe { ffi::ggrs_hip_frame(self.raw) }
     }
