@@ -132,6 +132,37 @@ def np_inner_hash_units(units: list[np.ndarray]) -> np.ndarray:
     return np_diffuse(a ^ s[1] ^ s[2] ^ s[3] ^ np.uint64(written + nt))
 
 
+def np_inner_hash_fields(fields: list[tuple[np.ndarray, int]]) -> np.ndarray:
+    """custom_hasher(component) for fields of ANY width: `checksum_hasher()` (snapshot/mod.rs:318-320, a SeaHasher) fed
+    `Hash::hash` of each field in turn -- derive(Hash) writes a u8 / bool as 1 byte, a u16 as 2, a u32 / f32::to_bits as 4, a u64 /
+    usize as 8, all little-endian.  SeaHasher::write buffers bytes until it has 8, mixes that word into the rotating 4-lane state
+    (a, b, c, d) <- (b, c, d, diffuse(a ^ word)), and `finish` mixes what is left of the buffer, then the byte count.  Every entity
+    has the same field layout, so the buffer fill level is one Python int and the buffers one uint64 column.
+    fields: [(column as unsigned integers, bytes the field contributes)]."""
+    n = len(fields[0][0]) if fields else 0
+    s = [np.full(n, k, dtype=np.uint64) for k in K]
+    tail = np.zeros(n, dtype=np.uint64)
+    ntail = 0
+    written = 0
+    for col, nb in fields:
+        v = col.astype(np.uint64)
+        if nb < 8:
+            v = v & np.uint64((1 << (8 * nb)) - 1)
+        tail = tail | (v << np.uint64(8 * ntail)) if ntail < 8 else tail
+        tot = ntail + nb
+        if tot >= 8:
+            a = np_diffuse(s[0] ^ tail)
+            s = [s[1], s[2], s[3], a]
+            written += 8
+            used = 8 - ntail                                   # bytes of this field that completed the word
+            tail = (v >> np.uint64(8 * used)) if used < 8 else np.zeros(n, dtype=np.uint64)
+            ntail = tot - 8
+        else:
+            ntail = tot
+    a = np_diffuse(s[0] ^ tail) if ntail else s[0]
+    return np_diffuse(a ^ s[1] ^ s[2] ^ s[3] ^ np.uint64(written + ntail))
+
+
 def np_entity_part(order: np.ndarray, inner: np.ndarray) -> np.ndarray:
     s = [np.uint64(k) for k in K]
     b = np_diffuse(s[0] ^ order.astype(np.uint64))

@@ -34,6 +34,9 @@ from oracle import oracle_np as onp
 SYS_PARTICLES_UPDATE, SYS_TTL_DESPAWN, SYS_PARTICLES_SPAWN, SYS_ADD_U32, SYS_SAT_SUB_DESPAWN, SYS_BOX_MOVE = 1, 2, 3, 4, 5, 6
 
 
+_WORD_DT = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}    # a registered word is 1, 2, 4 or 8 bytes (include/ggrs_hip.h)
+
+
 class TwinError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(msg)
@@ -103,7 +106,7 @@ class TwinWorld:
         cid = len(self._comps)
         self._comps.append((name, word_bytes, n_words))
         self._rb.append(rollback)
-        dt = np.uint32 if word_bytes == 4 else np.uint64
+        dt = _WORD_DT[word_bytes]
         for k in range(n_words):
             self._cols[(cid, k)] = np.zeros(self.capacity, dt)
         self._present.append(np.zeros(self.capacity, bool))
@@ -112,7 +115,7 @@ class TwinWorld:
 
     def set_component_default(self, comp, words):
         _, wb, nw = self._comps[comp]
-        self._defaults[comp] = np.ascontiguousarray(words).view(np.uint32 if wb == 4 else np.uint64)[:nw].copy()
+        self._defaults[comp] = np.ascontiguousarray(words).view(_WORD_DT[wb])[:nw].copy()
 
     def checksum_component(self, comp, word_idx):
         self._cks[comp] = list(word_idx)
@@ -164,7 +167,7 @@ class TwinWorld:
 
     def insert_component(self, comp, slot, words):
         _, wb, nw = self._comps[comp]
-        w = np.ascontiguousarray(words).view(np.uint32 if wb == 4 else np.uint64)
+        w = np.ascontiguousarray(words).view(_WORD_DT[wb])
         for k in range(nw):
             self._cols[(comp, k)][slot] = w[k]
         self._present[comp][slot] = True
@@ -227,6 +230,12 @@ class TwinWorld:
         hash(order, custom_hasher(component)), XOR-folded; then hashed once more."""
         _, wb, _ = self._comps[comp]
         sel = np.nonzero(self._alive[: self._len] & self._present[comp][: self._len])[0]
+        if wb in (1, 2):                                     # a u8 / bool / u16 field: 1 or 2 bytes of the hashed stream
+            fields = [(self._cols[(comp, k)][sel], wb) for k in self._cks[comp]]
+            x = 0
+            if len(sel):
+                x = int(np.bitwise_xor.reduce(onp.np_entity_part(sel.astype(np.uint64), onp.np_inner_hash_fields(fields))))
+            return onp.SeaHasher().write_u64(x).finish()
         units = []
         for k in self._cks[comp]:
             col = self._cols[(comp, k)][sel]

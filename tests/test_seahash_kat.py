@@ -82,3 +82,22 @@ def test_dt_bits_rule():
         seen.add(b)
     assert seen == {0x3C888888, 0x3C888889}
     assert [lib.gor_dt_bits(60, f) for f in (1, 2, 3, 4)] == [0x3C888888, 0x3C888889, 0x3C888889, 0x3C888888]
+
+
+def test_field_hasher_of_any_width_is_the_byte_stream_hasher():
+    """oracle_np.np_inner_hash_fields (vectorised: u8 / u16 / u32 / u64 fields, one fill level for all entities) against the scalar
+    SeaHasher fed the same little-endian bytes one field at a time, over random field layouts -- and against the u32-unit hasher."""
+    import numpy as np
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(1)
+    n = 129
+    for trial in range(60):
+        widths = [int(x) for x in rng.choice([1, 2, 4, 8], size=rng.integers(1, 8))]
+        cols = [rng.integers(0, 2 ** (8 * w) if w < 8 else 2 ** 63, n, dtype=np.uint64) for w in widths]
+        got = onp.np_inner_hash_fields(list(zip(cols, widths)))
+        for e in (0, 17, n - 1):
+            h = onp.SeaHasher()
+            for c, w in zip(cols, widths): h.write(int(c[e]).to_bytes(8, "little")[:w])
+            assert int(got[e]) == h.finish(), (widths, e)
+    u = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for _ in range(5)]
+    assert np.array_equal(onp.np_inner_hash_units(u), onp.np_inner_hash_fields([(x, 4) for x in u]))

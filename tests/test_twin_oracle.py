@@ -121,3 +121,31 @@ def test_presence_masks_insert_remove_and_u64_checksum_specs():
     assert res[0][0] == res[1][0]
     assert res[0][0][1] == res[0][0][3] and res[0][0][2] != res[0][0][4]
     cm.assert_states_equal(res[0][1], res[1][1], "presence")
+
+
+def test_narrow_words_one_and_two_byte_components():
+    """Components whose words are 1 or 2 bytes wide (a `bool` / u8 enum, a u16: the reference's Visibility family,
+    particles.rs:190-199): derive(Hash) feeds 1 / 2 bytes per field into the SeaHasher, so a checksum over them exercises the
+    byte-granular stream -- restated independently in numpy (oracle_np.np_inner_hash_fields) and in C (SeaStream)."""
+    res = []
+    for w in (OracleWorld(3000, 8, FLAT), TwinWorld(3000, 8)):
+        T, V, L = cm.build_particles(w, with_spawn=False)
+        vis = w.register_component("Visibility", 1, 1); flags = w.register_component("Flags", 1, 3); tag = w.register_component("Tag", 2, 2)
+        w.set_component_default(vis, np.array([1], dtype=np.uint8))
+        w.checksum_component(vis, [0]); w.checksum_component(flags, [2, 0]); w.checksum_component(tag, [1, 0])
+        n = 1500
+        rng = np.random.default_rng(5)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        tcols = [np.full(n, cm.f32bits(cm.TRANSFORM_DEFAULT)[k], dtype=np.uint32) for k in range(10)]
+        vcols = [cm.f32bits(vel[:, 0]), cm.f32bits(vel[:, 1]), np.zeros(n, dtype=np.uint32)]
+        w.spawn(n, {T: tcols, V: vcols, L: [ttl], vis: None, flags: [rng.integers(0, 256, n, dtype=np.uint64).astype(np.uint8) for _ in range(3)],
+                    tag: [rng.integers(0, 65536, n, dtype=np.uint64).astype(np.uint16) for _ in range(2)]})
+        w.set_depth(8)
+        out = w.handle_requests([bg.SaveGameState(0), bg.AdvanceFrame((0,)), bg.SaveGameState(1), bg.AdvanceFrame((0,))])
+        w.insert_component(tag, 7, np.array([513, 65535], dtype=np.uint16)); w.remove_component(flags, 9)
+        w.insert_component(vis, 11, np.array([0], dtype=np.uint8))
+        out += w.handle_requests([bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.LoadGameState(1), bg.SaveGameState(1), bg.AdvanceFrame((0,)), bg.SaveGameState(2)])
+        res.append((out, cm.snapshot_state(w, (T, V, L, vis, flags, tag))))
+    assert res[0][0] == res[1][0]
+    assert res[0][0][1] == res[0][0][3] and res[0][0][2] != res[0][0][4]          # frame 1 again after the rollback; frame 2 without the host edits
+    cm.assert_states_equal(res[0][1], res[1][1], "narrow words")
