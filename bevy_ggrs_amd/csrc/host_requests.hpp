@@ -515,7 +515,7 @@ void run_host_folds(ggrs_world* w, uint32_t n) {
 constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;
 bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off, bool blocking = false) {
     if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.host_fold_max_wgs) return false;
-    if (blocking && g > HOST_FOLD_MAX_WGS_BLOCKING && w->knobs.host_fold_max_wgs == 16384) return false;       // (an explicit knob value is taken literally)
+    if (blocking && g > HOST_FOLD_MAX_WGS_BLOCKING && !w->knobs.host_fold_explicit) return false;             // (an explicit GGRS_HOST_FOLD_MAX_WGS is taken literally)
     const uint64_t need = (uint64_t)g * n_saves * (n_cks + 1) * members;
     if (w->folds.empty()) { w->rows_used = 0; w->rows_tail = 0; }
     uint64_t& head = w->rows_used;                                 // ring: rows of pending folds live in [tail, head) (mod wrap)

@@ -55,6 +55,7 @@ struct Knobs {
     uint64_t jit_persist_min_slots = 0;              // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0 (default): never
     int jit_persist_oversub = 1;   // GGRS_JIT_PERSIST_OVERSUB=n  persistent form: grid = up to n x the workgroups the device holds at once
     int host_fold_max_wgs = 16384;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
+    bool host_fold_explicit = false;   //                            (set: the limit also applies to blocking calls, which otherwise keep the device fold above 1024 workgroups)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
@@ -87,6 +88,7 @@ struct Knobs {
         k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 0));
         k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
+        k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
