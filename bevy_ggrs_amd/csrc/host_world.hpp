@@ -67,7 +67,7 @@ struct Knobs {
     bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
-                                   //                       of >= 400 k slots, kernel_gen.hpp jit_lane_fold)
+                                   //                       of >= 96 k slots, kernel_gen.hpp jit_lane_fold)
     int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive group of one shape starts the build of a kernel specialised for
                                    //                       it (0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;

@@ -242,12 +242,12 @@ uint64_t jit_hot_cols(const ggrs_world* w) {
 // Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
 // back to k_tick3 or to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
 // Player.handle, too many words for the register file / the 64-bit row masks.
-// The per-tile form of a BIG world folds checksum values through per-lane LDS rows: 64 cells x 8 B per Save and checksummed component
+// The per-tile form of a world of ~100 k slots and more folds checksum values through per-lane LDS rows: 64 cells x 8 B per Save and checksummed component
 // (dynamic LDS, sized by the launch), one ds_xor per lane and Save, the rows folded across lanes once per workgroup -- instead of a
 // 12-step DPP ladder + a single-lane atomic per Save and component.  Small worlds keep the ladder: zeroing and folding the rows costs
 // them more than it saves (profiles/r03n/lane_fold_ab.txt).  GGRS_JIT_LANE_FOLD=0|1 forces the choice.
 constexpr uint32_t JIT_LANE_FOLD_MAX_CKS = 4;
-constexpr uint64_t JIT_LANE_FOLD_MIN_SLOTS = 400 * 1024;
+constexpr uint64_t JIT_LANE_FOLD_MIN_SLOTS = 96 * 1024;       // (with the specialised kernel in: 100 k -2 %, 300 k -4 %, 50 k even: profiles/r03zg)
 inline bool jit_lane_fold(const ggrs_world* w, uint32_t n_cks) {
     if (n_cks < 1 || n_cks > JIT_LANE_FOLD_MAX_CKS) return false;
     return w->knobs.jit_lane_fold >= 0 ? w->knobs.jit_lane_fold != 0 : w->cap_pad >= JIT_LANE_FOLD_MIN_SLOTS;
