@@ -527,9 +527,14 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     b.first = (w->res_head + n_save > w->max_results) ? 0u : w->res_head;
     b.count = n_save;
     const size_t folds_before = w->folds.size();
+    if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
+    b.ev = w->event_pool.back(); w->event_pool.pop_back();
+    w->batch_ev_attached = false;
     if (GroupRunner run = group_runner(w)) {
+        w->batch_ev = b.ev;
         rc = run(w, reqs, n, nullptr, b.first, false, nullptr);
-        if (rc) { (void)hipStreamSynchronize(w->stream); while (w->folds.size() > folds_before) w->folds.pop_back(); return rc; }
+        w->batch_ev = nullptr;
+        if (rc) { w->event_pool.push_back(b.ev); (void)hipStreamSynchronize(w->stream); while (w->folds.size() > folds_before) w->folds.pop_back(); return rc; }
     } else {
         // worlds without request-group kernels: one launch per request, enqueued like the groups are; every
         // Save's fold writes straight into its slot of the pinned result ring, nothing is waited for here
@@ -547,9 +552,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
         }
         if (rc) { (void)hipStreamSynchronize(w->stream); return rc; }
     }
-    if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
-    b.ev = w->event_pool.back(); w->event_pool.pop_back();
-    HIPCHK(w, hipEventRecord(b.ev, w->stream));
+    if (!w->batch_ev_attached) HIPCHK(w, hipEventRecord(b.ev, w->stream));      // (else the event rides on the list's last kernel)
     w->res_head = b.first + n_save; w->pending_results += n_save;
     b.n_folds = (uint32_t)(w->folds.size() - folds_before);
     if (n_saves_out) *n_saves_out = n_save;

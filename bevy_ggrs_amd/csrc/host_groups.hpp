@@ -248,8 +248,13 @@ inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 // launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
 // Launch of a generated kernel.  With profiling on, the event pair rides on the dispatch itself (hipExtModuleLaunchKernel's start / stop events:
 // the kernel's own begin and end, what rocprofv3's kernel trace reports) instead of bracketing it with two marker packets, which read ~3 us more.
-int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tpb, uint32_t lds, void** params, uint64_t bytes) {
-    if (!w->prof) { HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr)); return GGRS_OK; }
+// `done`: an event that completes with THIS launch (enqueue's batch event riding on the list's last kernel instead of a marker packet behind it).
+int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tpb, uint32_t lds, void** params, uint64_t bytes, hipEvent_t done = nullptr) {
+    if (!w->prof) {
+        if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
+        else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr));
+        return GGRS_OK;
+    }
     hipEvent_t a = nullptr, b = nullptr;
     HIPCHK(w, hipEventCreate(&a)); HIPCHK(w, hipEventCreate(&b));
     w->prof_bytes[GGRS_KERNEL_TICK] += bytes;
@@ -297,6 +302,7 @@ struct JitBatch {
     int flush(ggrs_world* w) {
         if (!active) return GGRS_OK;
         active = false;
+        w->batch_ev_attached = false;                                // this launch comes after whatever carried the batch event
         bool host_fold = false; uint64_t rows_off = 0;
         {
             void* params[] = {&j};
@@ -327,6 +333,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     const uint32_t n_cks = w->cks_args.n_cks;
     const uint64_t static_reads = jit_static_reads(w);
     while (i < n) {
+        w->batch_ev_attached = false;                                   // only the list's LAST launch may carry the batch event
         GgrsJitArgs j; memset(&j, 0, sizeof j);
         GroupState gs;
         const ggrs_request* spawn_req = nullptr;
@@ -432,7 +439,12 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 void* params[] = {&j};
                 hipFunction_t fn = jit_spec_for(w, j);
                 if (!fn) fn = w->jit_fn;
-                rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, jit_lane_fold_bytes(w, n_cks, j.n_saves), params, bytes_slot * w->len); if (rc) return rc;
+                // nothing is queued behind this kernel when the host folds its rows (or there is nothing to fold) and no spawn system follows:
+                // the batch event of an enqueued list then completes WITH it (no marker packet between this tick's kernel and the next one's)
+                const bool last_gpu_op = (host_fold || !j.n_saves) && !spawn_req && !w->prof;
+                hipEvent_t done = last_gpu_op ? w->batch_ev : nullptr;
+                rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, jit_lane_fold_bytes(w, n_cks, j.n_saves), params, bytes_slot * w->len, done); if (rc) return rc;
+                w->batch_ev_attached = done != nullptr;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }

@@ -242,6 +242,7 @@ struct ggrs_world {
     struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off, total_len; };
     std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
     uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
+    hipEvent_t batch_ev = nullptr; bool batch_ev_attached = false;   // enqueue: the batch's event, offered to the list's last kernel launch (launch_jit)
     bool device_results_only = false;    // a consumer reads the result ring in stream order (ggrs_hip_fanout_*): every fold stays on the device
     std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
     std::vector<hipEvent_t> event_pool;
