@@ -441,7 +441,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 if (!fn) fn = w->jit_fn;
                 // nothing is queued behind this kernel when the host folds its rows (or there is nothing to fold) and no spawn system follows:
                 // the batch event of an enqueued list then completes WITH it (no marker packet between this tick's kernel and the next one's)
-                const bool last_gpu_op = (host_fold || !j.n_saves) && !spawn_req && !w->prof;
+                const bool last_gpu_op = (host_fold || !j.n_saves) && !spawn_req && !w->prof && w->knobs.event_on_kernel;
                 hipEvent_t done = last_gpu_op ? w->batch_ev : nullptr;
                 rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, jit_lane_fold_bytes(w, n_cks, j.n_saves), params, bytes_slot * w->len, done); if (rc) return rc;
                 w->batch_ev_attached = done != nullptr;

@@ -71,6 +71,7 @@ struct Knobs {
     int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive group of one shape starts the build of a kernel specialised for
                                    //                       it (0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
+    bool event_on_kernel = true;   // GGRS_EVENT_ON_KERNEL=0     an enqueued list ends with a marker packet (hipEventRecord) even when its last GPU operation is the group kernel
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
                                         //                       the snapshot the next rollback loads, goes through the L2)
@@ -98,6 +99,7 @@ struct Knobs {
         k.jit_lane_fold = (int)num("GGRS_JIT_LANE_FOLD", -1);
         k.jit_specialise_after = (int)num("GGRS_JIT_SPECIALISE_AFTER", 16);
         k.jit_specialise_sync = num("GGRS_JIT_SPECIALISE_SYNC", 0) != 0;
+        k.event_on_kernel = num("GGRS_EVENT_ON_KERNEL", 1) != 0;
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
         k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;

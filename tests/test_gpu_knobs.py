@@ -34,6 +34,7 @@ KNOBS = [
     {"GGRS_JIT_SPECIALISE_AFTER": "0"},                     # never
     {"GGRS_JIT_LANE_FOLD": "1"},                            # checksum fold through per-lane LDS rows even for small worlds
     {"GGRS_JIT_LANE_FOLD": "0"},                            # ... and the per-Save DPP ladder even for big ones
+    {"GGRS_EVENT_ON_KERNEL": "0"},                          # an enqueued list ends with a marker packet again
     {"GGRS_PRESENCE_VERSIONS": "0"},                        # presence masks stored with every Save
     {"GGRS_JIT_CACHE_FIRST_SAVE": "0"},                     # every Save of an HBM-sized rollback group streams past the caches
     {"GGRS_ARENA_CONTIG": "0"},
