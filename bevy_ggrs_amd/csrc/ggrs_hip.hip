@@ -133,9 +133,13 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
 }
 int ggrs_hip_specialise_wait(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
-    if (!w->spec) return 0;
-    if (w->spec->th.joinable()) w->spec->th.join();
-    return w->spec->state.load(std::memory_order_acquire) == 2 ? 1 : 0;
+    int ready = 0;
+    for (auto& s : w->spec_tab) {
+        if (!s.spec) continue;
+        if (s.spec->th.joinable()) s.spec->th.join();
+        if (s.spec->state.load(std::memory_order_acquire) == 2) ready = 1;
+    }
+    return ready;
 }
 const char* ggrs_hip_last_error(ggrs_world* w) { return w ? w->err.c_str() : "null world"; }
 
@@ -624,9 +628,16 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
     auto add = [&](const char* k, const std::string& v) { snprintf(line, sizeof line, "%s=%s\n", k, v.c_str()); s += line; };
     add("sealed", w->sealed ? "1" : "0");
     {
-        const int st = w->spec ? w->spec->state.load(std::memory_order_acquire) : 0;
-        std::string v = !w->knobs.jit_specialise_after ? "off (GGRS_JIT_SPECIALISE_AFTER=0)" : st == 2 ? "ready (the steady group shape runs on a kernel compiled for it)"
-                      : st == 1 ? "building" : st == 3 ? "failed: " + w->spec->why : "none yet";
+        uint32_t n_ready = 0, n_building = 0, n_failed = 0; std::string why;
+        for (auto& t : w->spec_tab) {
+            const int st = t.spec ? t.spec->state.load(std::memory_order_acquire) : 0;
+            n_ready += st == 2; n_building += st == 1;
+            if (st == 3) { ++n_failed; why = t.spec->why; }
+        }
+        std::string v = !w->knobs.jit_specialise_after ? "off (GGRS_JIT_SPECIALISE_AFTER=0)"
+                      : n_ready ? "ready (" + std::to_string(n_ready) + " of " + std::to_string(w->spec_tab.size()) + " group shapes seen run on kernels compiled for them" +
+                                  (n_building ? ", 1 building" : "") + (n_failed ? ", " + std::to_string(n_failed) + " failed: " + why : "") + ")"
+                      : n_building ? "building" : n_failed ? "failed: " + why : "none yet";
         for (char& ch : v) if (ch == '\n') ch = ' ';
         add("specialised_kernel", v);
     }

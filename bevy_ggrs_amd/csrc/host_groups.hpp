@@ -265,24 +265,43 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
 
 // The kernel specialised for this group's shape, once the session has sent the shape often enough and the build is done (kernel_gen.hpp
 // jit_specialise); nullptr: use the generic kernel.  Plain launches of every size qualify (depth-parallel roles are part of the shape); batches of
-// checksum-only branches and groups with an eliminated Save do not.
+// checksum-only branches and groups with an eliminated Save do not.  Shapes are counted one by one (host_world.hpp JitSpecSlot): a SyncTest
+// session has one, a P2P session one per rollback length; the row masks right after a spawn make a few more that never reach the threshold.
 hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.n_saves || !j.n_ops) return nullptr;
     for (uint32_t k = 0; k < j.n_saves; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
     JitSig g; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
     g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s;
-    if (w->spec && w->spec->sig == g) return w->spec->state.load(std::memory_order_acquire) == 2 ? w->spec->fn : nullptr;
-    if (w->spec_last == g) ++w->spec_repeat; else { w->spec_last = g; w->spec_repeat = 1; }
-    if (w->spec_repeat < (uint32_t)w->knobs.jit_specialise_after) return nullptr;
-    if (w->spec && w->spec->state.load(std::memory_order_acquire) == 1) return nullptr;        // one build at a time
-    jit_spec_retire(w);                                                                         // the session settled on another shape
+    auto building = [](const JitSpecSlot& s) { return s.spec && s.spec->state.load(std::memory_order_acquire) == 1; };
+    JitSpecSlot* s = nullptr;
+    for (auto& t : w->spec_tab) if (t.sig == g) { s = &t; break; }
+    if (!s) {
+        if (w->spec_tab.size() < JIT_SPEC_SHAPES) { w->spec_tab.emplace_back(); s = &w->spec_tab.back(); }
+        else {                                                                   // least recently used out: a shape without a kernel if there is one
+            for (auto& t : w->spec_tab) {
+                if (building(t)) continue;
+                if (!s || (!t.spec && s->spec) || ((!t.spec) == (!s->spec) && t.last_use < s->last_use)) s = &t;
+            }
+            if (!s) return nullptr;
+            jit_spec_drop(w, *s);
+        }
+        *s = JitSpecSlot{}; s->sig = g;
+    }
+    s->last_use = ++w->spec_clock;
+    w->spec_last_slot = (int)(s - w->spec_tab.data());
+    if (s->spec) return s->spec->state.load(std::memory_order_acquire) == 2 ? s->spec->fn : nullptr;
+    if (++s->seen < (uint32_t)w->knobs.jit_specialise_after) return nullptr;
+    if (w->spec_builds >= JIT_SPEC_MAX_BUILDS) return nullptr;
+    for (auto& t : w->spec_tab) if (building(t)) return nullptr;                 // one build at a time; this shape asks again with its next group
+    ++w->spec_builds;
+    s->spec = new JitSpec; s->spec->sig = g;
     const std::string src = jit_specialise(w->jit_src, g);
-    if (src.empty()) { w->spec_repeat = 0; return nullptr; }
-    w->spec = new JitSpec; w->spec->sig = g; w->spec->state.store(1, std::memory_order_relaxed);
-    if (w->knobs.jit_specialise_sync) jit_spec_build(w->spec, w->device, src, w->knobs.jit_cache_dir);
-    else w->spec->th = std::thread(jit_spec_build, w->spec, w->device, src, w->knobs.jit_cache_dir);
-    return w->spec->state.load(std::memory_order_acquire) == 2 ? w->spec->fn : nullptr;
+    if (src.empty()) { s->spec->why = "the generated kernel's text could not be specialised"; s->spec->state.store(3, std::memory_order_release); return nullptr; }
+    s->spec->state.store(1, std::memory_order_relaxed);
+    if (w->knobs.jit_specialise_sync) jit_spec_build(s->spec, w->device, src, w->knobs.jit_cache_dir);
+    else s->spec->th = std::thread(jit_spec_build, s->spec, w->device, src, w->knobs.jit_cache_dir);
+    return s->spec->state.load(std::memory_order_acquire) == 2 ? s->spec->fn : nullptr;
 }
 
 struct JitBatch {

@@ -68,8 +68,8 @@ struct Knobs {
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
     int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
                                    //                       of >= 96 k slots, kernel_gen.hpp jit_lane_fold)
-    int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th consecutive group of one shape starts the build of a kernel specialised for
-                                   //                       it (0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
+    int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th group of one shape starts the build of a kernel specialised for it (counted
+                                   //                       per shape, 16 shapes per world; 0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
     bool event_on_kernel = true;   // GGRS_EVENT_ON_KERNEL=0     an enqueued list ends with a marker packet (hipEventRecord) even when its last GPU operation is the group kernel
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
@@ -137,6 +137,12 @@ struct JitSpec {
     JitSig sig; std::atomic<int> state{0};                // 1 building (worker thread), 2 ready, 3 failed
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::thread th; std::string why;
 };
+// One group shape the session has sent: how often, when last, and its kernel once it earned one.  A SyncTest session has one steady
+// shape; a P2P session has one per rollback length (0 .. max prediction) -- the table holds JIT_SPEC_SHAPES of them, least recently
+// used first out (shapes without a kernel before shapes with one).
+struct JitSpecSlot { JitSig sig; uint32_t seen = 0; uint64_t last_use = 0; JitSpec* spec = nullptr; };
+constexpr size_t JIT_SPEC_SHAPES = 16;
+constexpr uint32_t JIT_SPEC_MAX_BUILDS = 64;               // per world: a session whose shapes never settle stops asking for kernels
 
 struct ggrs_world {
     // ---- configuration
@@ -158,9 +164,9 @@ struct ggrs_world {
     // the request-group kernel generated for this world (kernel_gen.hpp): one workgroup per 256 slots (small worlds: roles,
     // batches, host-side fold) and its persistent form (HBM-sized worlds: grid = what the chip holds, checksum fold in-kernel)
     hipFunction_t jit_fn = nullptr, jit_fn_persist = nullptr;
-    // the per-tile form specialised for the group shape the session keeps sending (kernel_gen.hpp jit_specialise): its text, the
-    // shape being counted, the kernel (built on a worker thread; used once `state` says ready)
-    std::string jit_src; JitSig spec_last{}; uint32_t spec_repeat = 0; JitSpec* spec = nullptr;
+    // the per-tile form specialised for the group shapes the session keeps sending (kernel_gen.hpp jit_specialise): its text, the
+    // shapes being counted and their kernels (built on a worker thread, one at a time; used once `state` says ready)
+    std::string jit_src; std::vector<JitSpecSlot> spec_tab; uint64_t spec_clock = 0; uint32_t spec_builds = 0; int spec_last_slot = -1;
     JitEntry* jit_entry = nullptr; JitEntry* jit_entry_persist = nullptr;   // handed back to the module cache when the world is destroyed
     uint32_t jit_persist_wgs = 0, jit_persist_tpb = 1024;   // workgroups of the persistent form the device holds at once, and their size
     std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)

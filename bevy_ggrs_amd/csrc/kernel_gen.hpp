@@ -799,9 +799,14 @@ void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_
     }
     done(2, "");
 }
-void jit_spec_retire(ggrs_world* w) {                     // the worker is joined, launches that use the module have drained
-    if (!w->spec) return;
-    if (w->spec->th.joinable()) w->spec->th.join();
-    if (w->spec->mod) { if (w->stream) (void)hipStreamSynchronize(w->stream); (void)hipModuleUnload(w->spec->mod); }
-    delete w->spec; w->spec = nullptr;
+// a shape leaves the table (or the world goes): the worker is joined, launches that use the module have drained
+void jit_spec_drop(ggrs_world* w, JitSpecSlot& s) {
+    if (!s.spec) return;
+    if (s.spec->th.joinable()) s.spec->th.join();
+    if (s.spec->mod) { if (w->stream) (void)hipStreamSynchronize(w->stream); (void)hipModuleUnload(s.spec->mod); }
+    delete s.spec; s.spec = nullptr;
+}
+void jit_spec_retire(ggrs_world* w) {
+    for (auto& s : w->spec_tab) jit_spec_drop(w, s);
+    w->spec_tab.clear(); w->spec_last_slot = -1;
 }

@@ -413,11 +413,14 @@ int ggrs_hip_profile_read_bytes(ggrs_world* w, uint64_t* bytes_out);
  * ------------------------------------------------------------------------------------------- */
 int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed);
 
-/* Once a session has sent the same request-group shape GGRS_JIT_SPECIALISE_AFTER (16) times in a row, the library builds --
- * on a worker thread, never on the caller's -- a copy of the world's generated kernel with that shape's op sequence and row masks as
- * literals (12 % faster at 1 M entities, 15-20 % at 10 k - 300 k) and switches to it when it is ready; any other shape keeps running on the general kernel.
- * ggrs_hip_specialise_wait blocks until a build in flight has finished (a loading screen, a benchmark): 1 = a specialised kernel is
- * ready, 0 = none (no steady shape yet, the build failed -- ggrs_hip_world_kernel_info "specialised_kernel" says which). */
+/* Once a session has sent a request-group shape GGRS_JIT_SPECIALISE_AFTER (16) times, the library builds -- on a worker thread, never
+ * on the caller's, one build at a time -- a copy of the world's generated kernel with that shape's op sequence and row masks as literals
+ * (12 % faster at 1 M entities, 15-20 % at 10 k - 300 k) and switches to it when it is ready; a shape without a kernel runs on the
+ * general one.  Shapes are counted one by one, 16 per world (least recently used out): a SyncTest session has one steady shape, a P2P
+ * session one per rollback length (BASELINE config 4 at 100 k: 8 kernels, the tick's kernel time 8.9 -> 6.9 us, profiles/r03zi).
+ * ggrs_hip_specialise_wait blocks until the build in flight has finished (a loading screen, a benchmark; shapes still waiting for their
+ * turn start theirs with their next group): 1 = at least one specialised kernel is ready, 0 = none (no shape has come up often enough,
+ * the build failed -- ggrs_hip_world_kernel_info "specialised_kernel" says which and how many). */
 int ggrs_hip_specialise_wait(ggrs_world* w);
 
 #ifdef __cplusplus

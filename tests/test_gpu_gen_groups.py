@@ -216,3 +216,24 @@ def test_steady_group_shape_gets_its_own_kernel(sync, monkeypatch):
         res.append((name, out, cm.snapshot_state(w, ids)))
     _check(res)
     assert all(r for r, _ in infos) and all(s.startswith("ready") for _, s in infos), infos
+
+
+@pytest.mark.parametrize("n", [100_000, 450_000])
+def test_every_rollback_length_of_a_p2p_session_gets_its_own_kernel(n, monkeypatch):
+    """host_world.hpp JitSpecSlot: shapes are counted one by one, so a P2P session -- whose rollback length changes from tick to tick
+    (BASELINE config 4: [Load(F-r), Adv, (Save, Adv) x (r-1), Save(F), Adv], r drawn per tick) -- ends up with one specialised kernel per
+    length instead of none.  Ttl despawns all along, a spawn in the middle (its row masks are shapes of their own for a few ticks);
+    every Save's checksum and the final state against the oracle, across all the kernel switches."""
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_AFTER", "2")
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_SYNC", "1")
+    res, info = [], None
+    for name, w in [("gen", bg.World(n + 4000, max_depth=9)), ("oracle", OracleWorld(n + 4000, 9))]:
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=50)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        drv = cm.P2PShapeDriver(w, 8, inputs=lambda f: (cm.INPUT_SPAWN if f in (60, 61) else 0, 0), spawn_fn=cm.frame_spawn_fn(64))
+        for _ in range(110): drv.tick()
+        if name == "gen": info = w.kernel_info()["specialised_kernel"]
+        res.append((name, drv.all_checksums, cm.snapshot_state(w, ids)))
+    _check(res)
+    assert info.startswith("ready (") and int(info[len("ready ("):].split()[0]) >= 6, info
