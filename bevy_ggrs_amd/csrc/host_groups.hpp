@@ -277,7 +277,7 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     JitSpecSlot* s = nullptr;
     for (auto& t : w->spec_tab) if (t.sig == g) { s = &t; break; }
     if (!s) {
-        if (w->spec_tab.size() < JIT_SPEC_SHAPES) { w->spec_tab.emplace_back(); s = &w->spec_tab.back(); }
+        if (w->spec_tab.size() < (size_t)w->knobs.jit_spec_shapes) { w->spec_tab.emplace_back(); s = &w->spec_tab.back(); }
         else {                                                                   // least recently used out: a shape without a kernel if there is one
             for (auto& t : w->spec_tab) {
                 if (building(t)) continue;

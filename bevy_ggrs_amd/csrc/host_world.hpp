@@ -71,6 +71,7 @@ struct Knobs {
     int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th group of one shape starts the build of a kernel specialised for it (counted
                                    //                       per shape, 16 shapes per world; 0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
+    int jit_spec_shapes = 16;      // GGRS_JIT_SPEC_SHAPES=n    group shapes counted (and specialised kernels kept) per world, 1..64; the least recently used one makes room
     bool event_on_kernel = true;   // GGRS_EVENT_ON_KERNEL=0     an enqueued list ends with a marker packet (hipEventRecord) even when its last GPU operation is the group kernel
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
@@ -99,6 +100,7 @@ struct Knobs {
         k.jit_lane_fold = (int)num("GGRS_JIT_LANE_FOLD", -1);
         k.jit_specialise_after = (int)num("GGRS_JIT_SPECIALISE_AFTER", 16);
         k.jit_specialise_sync = num("GGRS_JIT_SPECIALISE_SYNC", 0) != 0;
+        k.jit_spec_shapes = (int)std::min<long long>(64, std::max<long long>(1, num("GGRS_JIT_SPEC_SHAPES", 16)));
         k.event_on_kernel = num("GGRS_EVENT_ON_KERNEL", 1) != 0;
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
@@ -138,10 +140,9 @@ struct JitSpec {
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::thread th; std::string why;
 };
 // One group shape the session has sent: how often, when last, and its kernel once it earned one.  A SyncTest session has one steady
-// shape; a P2P session has one per rollback length (0 .. max prediction) -- the table holds JIT_SPEC_SHAPES of them, least recently
+// shape; a P2P session has one per rollback length (0 .. max prediction) -- the table holds Knobs::jit_spec_shapes (16) of them, least recently
 // used first out (shapes without a kernel before shapes with one).
 struct JitSpecSlot { JitSig sig; uint32_t seen = 0; uint64_t last_use = 0; JitSpec* spec = nullptr; };
-constexpr size_t JIT_SPEC_SHAPES = 16;
 constexpr uint32_t JIT_SPEC_MAX_BUILDS = 64;               // per world: a session whose shapes never settle stops asking for kernels
 
 struct ggrs_world {

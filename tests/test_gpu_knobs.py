@@ -32,6 +32,7 @@ KNOBS = [
     {"GGRS_ROW_VERSIONS": "0"},
     {"GGRS_JIT_SPECIALISE_AFTER": "1", "GGRS_JIT_SPECIALISE_SYNC": "1"},   # every HBM-sized group shape gets its own kernel at once (built on the calling thread)
     {"GGRS_JIT_SPECIALISE_AFTER": "0"},                     # never
+    {"GGRS_JIT_SPECIALISE_AFTER": "1", "GGRS_JIT_SPECIALISE_SYNC": "1", "GGRS_JIT_SPEC_SHAPES": "1"},   # one place in the shape table: every new shape unloads the previous kernel
     {"GGRS_JIT_LANE_FOLD": "1"},                            # checksum fold through per-lane LDS rows even for small worlds
     {"GGRS_JIT_LANE_FOLD": "0"},                            # ... and the per-Save DPP ladder even for big ones
     {"GGRS_EVENT_ON_KERNEL": "0"},                          # an enqueued list ends with a marker packet again
