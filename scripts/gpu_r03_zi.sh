@@ -1,19 +1,22 @@
 #!/bin/bash
-# r03zi: one kernel per group shape (P2P sessions): the new parity test + the suites that drive the specialised kernel, then BASELINE config 4
-# with and without waiting for the kernels
+# r03zi: one specialised kernel per group shape (P2P sessions) + the interpreter's collector out of bench.py's timed regions.
+# ONE gpurun call: the GPU suite, per-tick host times of a P2P-shaped session with / without specialisation (scripts/p2p_diag.py),
+# BASELINE config 4 (waiting for the kernels / not / specialisation off), config 2, 100 k, the headline in both forms.
 OUT=gpurun_out/r03zi; mkdir -p $OUT
-timeout 400 python -m pytest tests/test_gpu_gen_groups.py tests/test_gpu_knobs.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -5 > $OUT/pytest.log
-cat $OUT/pytest.log
-for i in 1 2; do
-  timeout 200 python bench.py --config 4 --no-cpu-baseline --no-specialise-wait 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config4_nowait_$i.json
-  timeout 200 python bench.py --config 4 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config4_$i.json
-done
-python - <<'PY'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/r03zi/bench_config4*.json")):
-    try:
-        d = json.loads(open(f).read())
-        print(f.split("/")[-1], round(d["value"] / 1e9, 2), "G", round(d["ms_per_step"] * 1e3, 2), "us", d["config"].get("specialised_kernel"), d["config"].get("specialise_settle"), d["parity"]["equal"])
-    except Exception as e: print(f, "unreadable", e)
-PY
-tail -5 $OUT/bench.err
+timeout 400 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu_full.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_full.log
+{
+GGRS_JIT_SPECIALISE_AFTER=4 GGRS_JIT_SPECIALISE_SYNC=1 timeout 100 python scripts/p2p_diag.py
+GGRS_JIT_SPECIALISE_AFTER=0 timeout 100 python scripts/p2p_diag.py
+} > $OUT/p2p_diag.txt 2>&1
+{
+GGRS_JIT_SPECIALISE_AFTER=4 DIAG_SETTLE=1 timeout 100 python scripts/p2p_diag.py
+GGRS_JIT_SPECIALISE_AFTER=4 DIAG_SETTLE=1 DIAG_TORCH=1 timeout 100 python scripts/p2p_diag.py
+} > $OUT/p2p_diag_async.txt 2>&1
+timeout 200 python bench.py --config 4 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config4_gc.json
+timeout 200 python bench.py --config 4 --no-cpu-baseline --no-specialise-wait 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config4_gc_nowait.json
+GGRS_JIT_SPECIALISE_AFTER=0 timeout 200 python bench.py --config 4 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config4_gc_generic.json
+timeout 200 python bench.py --config 2 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config2.json
+timeout 200 python bench.py --entities 100000 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_100000.json
+timeout 300 python bench.py 2>> $OUT/bench.err | grep '^{' > $OUT/bench.json
+for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_driver_form_$i.json; done
+grep -E "passed|failed|rc=" $OUT/pytest_gpu_full.log | tail -3
