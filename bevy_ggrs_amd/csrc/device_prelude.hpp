@@ -15,7 +15,10 @@ constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cUL
 
 __host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) {
     x *= SEA_P;
-    x ^= (x >> 32) >> (x >> 60);
+    // x ^= (x >> 32) >> (x >> 60), spelled in 32-bit terms: the shifted value is the high half, the shift count its top 4 bits, and
+    // only the low half changes -- two 32-bit shifts and one 32-bit XOR where the 64-bit form costs a v_lshrrev_b64 per diffuse
+    const uint32_t hi = (uint32_t)(x >> 32);
+    x ^= (uint64_t)(hi >> (hi >> 28));
     x *= SEA_P;
     return x;
 }
