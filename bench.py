@@ -163,6 +163,56 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs,
     return base, parity
 
 
+def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_input, threads):
+    """N > 1 / --fanout parity gate: the gathered Checksum(u128) table of the first timed steps against ONE process walking every
+    branch of every rank on the CPU oracle (tests/test_fanout_gloo.py::_serial_reference is the same recipe).  `raw` = what
+    SpeculativeFanout kept: [(C, (size, bpr * depth, 2) u64)] for consecutive confirmed frames C = c_timed, c_timed + 1, ...
+    The checker reaches frame c_timed by plain AdvanceWorlds with the confirmed inputs (what the steps before the timed
+    region left behind, by determinism), saves it, and then runs for every step and every branch b of every rank
+        [Load(C), Advance(confirmed input), Save(C+1), (Advance(predicted input of b), Save) x (depth-1), Advance(predicted)]."""
+    from oracle.binding import FLAT, OracleWorld, lib
+    import bevy_ggrs_amd as bg
+    import common as cm
+    lib.gor_set_num_threads(threads)
+    t0 = time.perf_counter()
+    o = OracleWorld(n, depth + 1, FLAT)
+    ids = cm.build_particles(o)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(o, ids, n, vel, ttl)
+    o.set_depth(depth + 1)
+    for f in range(c_timed):
+        o.advance((confirmed_input(f),))
+    assert o.frame == c_timed, (o.frame, c_timed)
+    o.set_confirmed(c_timed)
+    o.handle_requests([bg.SaveGameState(c_timed)])
+    out = {"checked_steps": len(raw), "checked_branches": size * bpr, "checked_saves": 0, "equal": None,
+           "oracle": "oracle/ggrs_oracle.cpp FLAT variant: one process walks every branch of every rank (serial reference), same seeded inputs"}
+    bad = None
+    for k, (C, table) in enumerate(raw):
+        if C != c_timed + k:
+            bad = {"step": k, "why": f"gathered step carries confirmed frame {C}, expected {c_timed + k}"}; break
+        o.set_confirmed(C)
+        for r in range(size):
+            for j in range(bpr):
+                b = r * bpr + j
+                reqs = [bg.LoadGameState(C), bg.AdvanceFrame((confirmed_input(C),)), bg.SaveGameState(C + 1)]
+                for i in range(1, depth):
+                    reqs += [bg.AdvanceFrame((branch_input(b, C + i),)), bg.SaveGameState(C + 1 + i)]
+                reqs.append(bg.AdvanceFrame((branch_input(b, C + depth),)))
+                want = o.handle_requests(reqs)
+                got = [int(table[r, j * depth + i, 0]) | (int(table[r, j * depth + i, 1]) << 64) for i in range(depth)]
+                out["checked_saves"] += depth
+                if got != want and bad is None:
+                    i = next(i for i in range(depth) if got[i] != want[i])
+                    bad = {"step": k, "rank": r, "branch": b, "save": i, "gpu": hex(got[i]), "oracle": hex(want[i])}
+        if bad: break
+    out["equal"] = bad is None and len(raw) > 0
+    if bad: out["first_mismatch"] = bad
+    out["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+    lib.gor_set_num_threads(1)
+    return out
+
+
 def read_clocks():
     """sclk / mclk / power right now: sysfs (pp_dpm_*: the starred level; hwmon power) when the container exposes it, else
     `rocm-smi`.  Telemetry for the JSON line only."""
@@ -455,11 +505,16 @@ def main():
                          "measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
                          "as roofline.contig_arena_variant (it pays for k_tick3's 16-byte store streams: GGRS_ROW_VERSIONS=0 / GGRS_TICK_JIT=0 worlds)")
     ap.add_argument("--paged-arena", action="store_true", help="same as --arena paged")
-    ap.add_argument("--schema", choices=["headline", "full"], default="headline",
+    ap.add_argument("--schema", choices=["headline", "full", "allhot"], default="headline",
                     help="headline: BASELINE's 3 registered components (60 B/entity); full: the reference stress_test's POD schema "
-                         "(+ GlobalTransform 12 x f32, three 1-byte visibilities: examples/stress_tests/particles.rs:190-199)")
+                         "(+ GlobalTransform 12 x f32, three 1-byte visibilities: examples/stress_tests/particles.rs:190-199); allhot: the headline "
+                         "components with every column written every frame (+ increase_component over rotation / scale): every Save moves all 15 rows")
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (RCCL broadcast + all-gather inside the library) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
+    ap.add_argument("--parity-steps", type=int, default=-1, help="N > 1 / --fanout: timed steps whose gathered checksum table rank 0 replays on the CPU oracle "
+                    "(every branch of every rank); default: about 16 branch walks in all, at least one step")
+    ap.add_argument("--control-backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend of the control plane (unique id, barrier, max over "
+                    "ranks); default nccl, gloo when ranks share a device.  The data-path collectives are always issued inside libggrs_hip.so")
     ap.add_argument("--oversubscribe", action="store_true", help="--gpus N with fewer than N visible devices: rank r runs on device r %% devices (correctness only)")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N: print the N rank command lines (JSON, one per line) and exit")
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=3,
@@ -501,11 +556,20 @@ def main():
         print(f"bench.py: rank {rank} needs device {local_rank} but only {ndev} visible (--oversubscribe shares devices)", file=sys.stderr); sys.exit(2)
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
+    ctl_dev = f"cuda:{dev}"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev))
+        # torch.distributed is the CONTROL plane only (the ncclUniqueId, the timing barrier, the max over ranks); the data-path
+        # collectives are issued inside libggrs_hip.so.  Ranks that share a device (--oversubscribe: correctness runs on a one-GPU
+        # box) cannot form a torch NCCL group -- RCCL refuses two ranks per device -- so their control plane is gloo.
+        backend = args.control_backend or ("gloo" if world_size > ndev else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+            ctl_dev = "cpu"
     n, D, K, W = args.entities, args.depth, args.steps, args.warmup
     bps = cm.schema_bytes_per_entity(args.schema)          # registered payload R (60 B for the headline schema)
     comm_size = world_size
@@ -582,6 +646,11 @@ def main():
             fan.step_pipelined(want_result=False); pre_n += 1
         fan.drain(want_result=False)
         m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms}}
+        # parity gate: the gathered table (every rank's every branch) of the first P timed steps stays as raw u64 arrays and is
+        # compared on rank 0, after the clock stops, with a serial walk of the same branches on the CPU oracle
+        P_fan = 0 if (args.no_cpu_baseline or args.no_checksum) else max(0, min(K, args.parity_steps if args.parity_steps >= 0 else max(1, 16 // max(1, world_size * args.branches))))
+        c_timed = fan.confirmed
+        fan.raw, fan.raw_keep = [], (P_fan if rank == 0 else 0)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
@@ -591,11 +660,13 @@ def main():
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         secs = time.perf_counter() - t0
         gc.enable()
-        t = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{dev}")
+        m["fanout"] = {"c_timed": c_timed, "raw": list(fan.raw), "parity_steps": P_fan}
+        fan.raw_keep = 0
+        t = torch.tensor([secs], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
         live = w.active_count()
-        cnt = torch.tensor([live * args.branches], dtype=torch.int64, device=f"cuda:{dev}")   # every branch resimulates the whole world
+        cnt = torch.tensor([live * args.branches], dtype=torch.int64, device=ctl_dev)   # every branch resimulates the whole world
         dist.all_reduce(cnt)
         total_entities = int(cnt.item())
         w.profile_enable(True)
@@ -733,6 +804,18 @@ def main():
         line["cpu_baseline"] = base
         line["parity"].update(par)
         parity_failed |= par["equal"] is False
+    elif rank == 0 and not args.no_cpu_baseline:
+        # N > 1 (and --fanout): the same CPU figures as the N = 1 line, timed once on rank 0 after the clock stopped (the other ranks
+        # wait at the closing barrier), and the parity gate over the gathered table
+        fo = m["fanout"]
+        base, _ = cpu_baseline_and_parity(n, D, args.cpu_ticks, D + 1, [], 0)
+        line["cpu_baseline"] = base
+        from bevy_ggrs_amd.fanout import default_branch_input
+        par = fanout_parity(n, D, fo["c_timed"], fo["raw"], comm_size, args.branches, default_branch_input, lambda f: 0,
+                            threads=max(1, min(64, os.cpu_count() or 1)))
+        par["cross_rank_confirmed_frames_agree"] = True     # SpeculativeFanout raises DesyncDetected otherwise (every step, every rank)
+        line["parity"] = par
+        parity_failed = par["equal"] is not True
     elif rank == 0:
         line["cpu_baseline"] = None
     if dist is not None:

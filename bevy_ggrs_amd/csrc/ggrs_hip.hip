@@ -111,6 +111,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
+    if (w->fanout_backref) *w->fanout_backref = nullptr;          // a ggrs_fanout destroyed after its world (interpreter shutdown order) finds no world
     for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
@@ -657,6 +658,18 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
                                : "ggrs_jit_tick (generated for this world; one workgroup per 256 slots)";
     else k = "per-request kernels (k_copy_state, one launch per system)";
     add("request_group_kernel", k);
+    if (w->sealed && w->gen_ok && !use_tick3(w)) {
+        // who folds the per-workgroup checksum rows of a plain (no roles, no batch) request group of this size
+        const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
+        const bool gf = w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs && w->d_gf_tickets;
+        const uint32_t rows = gf ? (jit_grid(g) + 63u) / 64u : g;
+        const bool host = w->h_rows && !w->device_results_only && rows <= (uint32_t)w->knobs.host_fold_max_wgs;
+        const bool host_blocking = host && (rows <= HOST_FOLD_MAX_WGS_BLOCKING || w->knobs.host_fold_explicit);
+        std::string f = gf ? "group fold on the chip (64 workgroups per ticket: " + std::to_string(rows) + " rows of " + std::to_string(g) + " leave the kernel), then " : "";
+        f += host ? (host_blocking ? "the host folds the rows at collect time (blocking calls too)" : "the host folds the rows at collect time (blocking calls: k_gen_finalize)")
+                  : "k_gen_finalize";
+        add("checksum_fold", f);
+    }
     add("slots_covered", std::to_string(cover));
     add("row_versions", w->knobs.row_versions ? "on" : "off (GGRS_ROW_VERSIONS=0)");
     if (needed) *needed = s.size() + 1;

@@ -65,6 +65,7 @@ struct ggrs_fanout {
     uint32_t head = 0, tail = 0;         // tail: slot being filled, head: oldest uncollected
     uint32_t cap_u128 = 4096;            // checksums per rank a slot can hold (steps x saves)
     uint32_t interval = 1;               // steps per all-gather
+    bool owns_results_flag = false;      // this object switched its world to device-side folds (ggrs_world::device_results_only)
     std::string err;
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -121,9 +122,12 @@ int ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], 
     DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     if (!rccl().ok()) return w->fail(GGRS_E_HIP, "%s", rccl().why.c_str());
+    // the fan-out's all-gather reads the result ring in stream order: a list enqueued earlier whose rows the HOST is still to fold would
+    // hand it slots nobody has written yet
+    if (!w->pending.empty() || !w->folds.empty()) return w->fail(GGRS_E_INVALID, "fan-out init while %zu enqueued batches are uncollected", w->pending.size());
+    if (w->device_results_only) return w->fail(GGRS_E_INVALID, "this world already drives a fan-out");
     ggrs_fanout* f = new ggrs_fanout();
     f->w = w; f->rank = rank; f->size = world_size;
-    w->device_results_only = true;       // the all-gather reads the Checksum(u128)s from the result ring on the GPU's side of the stream: no host-side folds
     ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
     ncclResult_t e = rccl().CommInitRank(&f->comm, world_size, uid, rank);
     if (e != ncclSuccess) { rc = w->fail(GGRS_E_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(e)); delete f; return rc; }
@@ -136,6 +140,10 @@ int ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], 
         ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { rc = w->fail(GGRS_E_HIP, "fan-out staging buffers could not be allocated"); ggrs_hip_fanout_destroy(f); return rc; }
+    // from here on the all-gather reads the Checksum(u128)s from the result ring on the GPU's side of the stream: no host-side folds.
+    // Set only once everything above succeeded, and cleared by ggrs_hip_fanout_destroy: a failed or finished fan-out leaves the world
+    // with its host-side fold and event-on-kernel path
+    w->device_results_only = true; f->owns_results_flag = true; w->fanout_backref = &f->w;
     *out = f;
     return GGRS_OK;
 }
@@ -152,11 +160,18 @@ void ggrs_hip_fanout_destroy(ggrs_fanout* f) {
     }
     if (f->comm && rccl().ok()) (void)rccl().CommDestroy(f->comm);
     if (f->comm_stream) (void)hipStreamDestroy(f->comm_stream);
+    if (f->w) f->w->fanout_backref = nullptr;
+    if (f->owns_results_flag && f->w) {
+        // device-side folds may still be queued on the world's stream; they write the result ring whoever reads it.  What must not be
+        // left behind is a batch whose checksums nobody collected through this object
+        if (f->w->stream) (void)hipStreamSynchronize(f->w->stream);
+        f->w->device_results_only = false;
+    }
     delete f;
 }
 const char* ggrs_hip_fanout_last_error(ggrs_fanout* f) { return f ? f->err.c_str() : "null fan-out"; }
 int ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int* device_out) {
-    if (!f || !f->comm) return GGRS_E_INVALID;
+    if (!f || !f->comm || !f->w) return GGRS_E_INVALID;
     int n = 0, r = 0;
     FANCHK_NCCL(f, rccl().CommCount(f->comm, &n));
     FANCHK_NCCL(f, rccl().CommUserRank(f->comm, &r));
@@ -175,7 +190,7 @@ int ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather) 
 }
 
 int ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root) {
-    if (!f || root < 0 || root >= f->size) return GGRS_E_INVALID;
+    if (!f || !f->w || root < 0 || root >= f->size) return GGRS_E_INVALID;
     ggrs_world* w = f->w;
     DeviceGuard dg(w);
     if (f->head != f->tail || f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps || !w->pending.empty())
@@ -192,7 +207,7 @@ int ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root) {
 }
 
 int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
-    if (!f || (!reqs && n)) return GGRS_E_INVALID;
+    if (!f || !f->w || (!reqs && n)) return GGRS_E_INVALID;
     ggrs_world* w = f->w;
     DeviceGuard dg(w);
     if (f->tail - f->head >= (uint32_t)FANOUT_MAX_INFLIGHT) return f->fail(GGRS_E_INVALID, "%d all-gathers in flight: call ggrs_hip_fanout_collect", FANOUT_MAX_INFLIGHT);
@@ -216,7 +231,7 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
 }
 
 int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t max_u128_per_rank, uint32_t* n_steps_out, uint32_t* n_saves_out) {
-    if (!f) return GGRS_E_INVALID;
+    if (!f || !f->w) return GGRS_E_INVALID;
     ggrs_world* w = f->w;
     DeviceGuard dg(w);
     if (f->head == f->tail) {                                   // only a partly filled group is left: close it now

@@ -300,7 +300,7 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     if (src.empty()) { s->spec->why = "the generated kernel's text could not be specialised"; s->spec->state.store(3, std::memory_order_release); return nullptr; }
     s->spec->state.store(1, std::memory_order_relaxed);
     if (w->knobs.jit_specialise_sync) jit_spec_build(s->spec, w->device, src, w->knobs.jit_cache_dir);
-    else s->spec->th = std::thread(jit_spec_build, s->spec, w->device, src, w->knobs.jit_cache_dir);
+    else { s->spec->th = std::thread(jit_spec_build, s->spec, w->device, src, w->knobs.jit_cache_dir); jit_spec_worker_register(s->spec); }
     return s->spec->state.load(std::memory_order_acquire) == 2 ? s->spec->fn : nullptr;
 }
 
@@ -424,7 +424,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             // grid: the chunks of the group, at most `oversub` x what the device holds at once (1: strictly persistent -- every
             // workgroup walks several chunks; more: the hardware scheduler hands out workgroups as slots free up, which balances the
             // tail better, at the price of more rows for tick_fold's last arriver)
-            const uint32_t gp = std::max(1u, std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs * (uint32_t)w->knobs.jit_persist_oversub));
+            // ... and never more workgroups than tick_fold's row buffer holds (A/B shapes: GGRS_JIT_PERSIST_TPB=256, a large oversubscription): the
+            // kernel walks its chunks with a grid stride, so a smaller grid is always correct
+            const uint32_t gp = std::max(1u, std::min<uint32_t>(std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs * (uint32_t)w->knobs.jit_persist_oversub), w->wg_parts_rows));
             if (launch) {
                 void* params[] = {&j};
                 rc = launch_jit(w, w->jit_fn_persist, gp, 1, 1, w->jit_persist_tpb, 0, params, bytes_slot * w->len); if (rc) return rc;
@@ -439,6 +441,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             if (w->knobs.dp && j.n_saves >= 2 && !w->jit_marks) {
                 bool ok = !(wrote_live && j.src == j.live);
                 for (uint32_t k = 0; k < j.n_saves; ++k) ok = ok && j.save_dst[k] != j.src;
+                // ... and the destinations pairwise distinct: a ring shallower than the group's Saves hands an evicted slot to a later Save, and two
+                // roles writing one block concurrently could leave the OLDER frame's rows there (in op order on one lane the newer one wins)
+                for (uint32_t k = 1; k < j.n_saves && ok; ++k) for (uint32_t q = 0; q < k; ++q) ok = ok && (!j.save_dst[k] || j.save_dst[k] != j.save_dst[q]);
                 const uint64_t m = w->knobs.dp_max_slots;
                 if (ok) j.dp_s = w->knobs.dp > 1 ? (cover <= JIT_BATCH_MAX_SLOTS ? (uint32_t)w->knobs.dp : 0u)
                                : (cover <= m ? 1u : (cover <= 2 * m ? 2u : (cover <= 6 * m ? 3u : 0u)));
@@ -451,9 +456,18 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
+            // Group fold (kernel_gen.hpp): a launch of many workgroups folds its rows 64 to 1 on the chip; what the consumer reads -- the host at
+            // collect time or right away (blocking calls), k_gen_finalize when results stay on the device -- is `rows` group rows, not g
+            const bool group_fold = launch && j.n_saves && !j.dp_s && w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs &&
+                                    j.n_saves * (n_cks + 1) <= 256u && w->d_gf_tickets;
+            const uint32_t rows = group_fold ? (jit_grid(g) + 63u) / 64u : g;
             uint64_t rows_off = 0;
-            const bool host_fold = launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
-            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
+            const bool host_fold = launch && host_fold_rows(w, rows, j.n_saves, n_cks, 1, &rows_off, wait);
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = rows; }
+            if (group_fold) {
+                j.gf_rows = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.gf_tickets = w->d_gf_tickets;
+                if (!host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_gf_out); j.part_stride = rows; }
+            }
             if (launch) {
                 void* params[] = {&j};
                 hipFunction_t fn = jit_spec_for(w, j);
@@ -466,10 +480,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 w->batch_ev_attached = done != nullptr;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
-            if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, g, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }
+            if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, rows, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }
             else if (j.n_saves) {
                 GenFinArgs f; memset(&f, 0, sizeof f);
-                f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup
+                f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = rows; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup (per group of 64 with the group fold)
                 f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
                 {
                     ProfScope ps(w, GGRS_KERNEL_CHECKSUM);

@@ -29,7 +29,7 @@ int seal(ggrs_world* w) {
     if (rc == GGRS_OK) return rc;
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; }
+    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_gf_out = nullptr; w->d_gf_tickets = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -214,7 +214,8 @@ int seal_impl(ggrs_world* w) {
     w->stage_floats = 1u << 20;
     const uint64_t stage_bytes = w->stage_floats * 4;
     // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
-    const uint64_t wg_parts_bytes = align_up((uint64_t)std::max<uint64_t>(4 * w->n_cu + 64, w->cap_pad / 512 + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
+    w->wg_parts_rows = (uint32_t)std::max<uint64_t>(4 * w->n_cu + 64, w->cap_pad / 512 + 64);      // the persistent form's grid is clamped to this (host_groups.hpp)
+    const uint64_t wg_parts_bytes = align_up((uint64_t)w->wg_parts_rows * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
     const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
@@ -295,9 +296,17 @@ int seal_impl(ggrs_world* w) {
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
-        const size_t bytes = (size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8;
-        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes));
-        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream));
+        // [saves][n_cks + 1][one row per 256-slot workgroup] for k_gen_finalize -- or, group fold, [workgroup][saves x (n_cks + 1)]: the same
+        // count -- then the groups' folded rows (when they stay on the device) and one ticket per 64 workgroups of the largest grid
+        const size_t bytes = align_up((size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * (w->gen_part_stride + 8) * 8, ALIGN);
+        w->gf_groups_max = (w->gen_part_stride + 8 + 63) / 64 + 1;
+        const size_t out_bytes = align_up((size_t)w->gf_groups_max * MAX_TICK_SAVES * (w->cks_args.n_cks + 1) * 8, ALIGN);
+        const size_t ticket_bytes = align_up((size_t)w->gf_groups_max * 4, ALIGN);
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes + out_bytes + ticket_bytes));
+        w->d_gf_out = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(w->d_gen_parts) + bytes);
+        w->d_gf_tickets = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(w->d_gen_parts) + bytes + out_bytes);
+        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + out_bytes, w->stream));
+        HIPCHK(w, hipMemsetAsync(w->d_gf_tickets, 0, ticket_bytes, w->stream));                // arrival counters: zero between launches
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;

@@ -149,6 +149,7 @@ static const char kJitPrelude[] =
     "    ggrs_u64* parts; ggrs_u32 part_stride, nt;\n" \
     "    ggrs_u32 n_units, cached_saves;\n" \
     "    ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;\n" \
+    "    ggrs_u64* gf_rows; ggrs_u32* gf_tickets;\n" \
     "};\n"
 struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
@@ -164,6 +165,10 @@ struct GgrsJitArgs {
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
     ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;   // persistent form: tick_fold's row buffer, ticket and result slots
+    // per-tile form, GROUP FOLD (non-null): every workgroup leaves its row of partials in device memory (gf_rows, [workgroup][n_saves x
+    // (n_cks + 1)]) and takes a ticket of its group of 64 workgroups (dispatch order); the group's last arriver XORs / adds the 64 rows
+    // into ONE row and stores that to `parts` (column = group): the consumer -- the host, or k_gen_finalize -- reads 1/64 of the rows
+    ggrs_u64* gf_rows; ggrs_u32* gf_tickets;
 };
 static_assert(MAX_TICK_SAVES == 16 && MAX_TICK_STEPS == 24, "GgrsJitArgs is sized for 16 Saves / 24 steps per group");
 constexpr uint32_t JIT_MAX_UNITS = 64;       // 4-byte register units per slot the generated kernel may hold
@@ -362,8 +367,9 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
               "    // row share one L2, which merges them into long runs before they go to memory -- instead of every L2 seeing every 8th piece.\n"
               "    const uint32_t g8 = gridDim.x >> 3;                                       // the grid is 8 x ceil(tiles / 8) workgroups\n"
               "    const uint32_t tile = (blockIdx.x & 7u) * g8 + (blockIdx.x >> 3);\n"
-              "    if (tile * 4u >= a.n_units) return;                                       // padding workgroup of the last eighth\n"
-              "    {\n"
+              "    const bool pad_wg = tile * 4u >= a.n_units;                               // padding workgroup of the last eighth\n"
+              "    if (pad_wg && !a.gf_rows) return;                                         // (group fold: it still hands in its -- empty -- row and takes its ticket)\n"
+              "    if (!pad_wg) {\n"
               "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
             "    const bool in_len = (uint64_t)gu * 64u < a.len;                           // wave-uniform\n"
@@ -629,14 +635,51 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "    tick_fold<%d, 8>(f, a.n_saves, a.len, (uint64_t*)s_acc, &s_last);\n", n_cks, n_cks ? ((1u << n_cks) - 1u) : 0u, TPB_);
     } else {
         sfmt(s, "    // ---- this workgroup's partial rows (blockIdx.z: member of a batch of identical checksum-only groups)\n"
-                "    (void)s_last;\n"
                 "    __syncthreads();\n"
-                "%s"
+                "%s", fold_text.c_str());
+        sfmt(s,
+                "    if (a.gf_rows) {\n"
+                "        // GROUP FOLD (HBM-sized groups; no roles, no batch): 64 workgroups in dispatch order share a ticket; their rows travel through\n"
+                "        // device memory as relaxed agent-scope 8-byte accesses on both sides (write-through stores, L1-bypassing loads:\n"
+                "        // MI355X_MICROARCH.md 'Valid forms'), an explicit vmcnt(0) between a workgroup's row and its ticket.  The last arriver folds\n"
+                "        // the group's rows (component_checksum.rs:88-89 is an XOR, the live count a sum: any grouping gives the same result)\n"
+                "        const uint32_t nv = a.n_saves * %uu;                                   // values per row (<= 256: the host checks)\n"
+                "        const uint32_t grp = blockIdx.x >> 6, members = min(64u, gridDim.x - (grp << 6));\n"
+                "        ggrs_u64* rows = a.gf_rows + (uint64_t)(grp << 6) * nv;\n"
+                "        for (uint32_t i = tid; i < nv; i += 256u) st8_agent((uint64_t*)rows + (uint64_t)(blockIdx.x & 63u) * nv + i, (uint64_t)s_acc[i]);\n"
+                "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");                       // the row is in memory before the ticket is taken\n"
+                "        __syncthreads();\n"
+                "        if (tid == 0) s_last = __hip_atomic_fetch_add(a.gf_tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u ? 1u : 0u;\n"
+                "        __syncthreads();\n"
+                "        if (!s_last) return;                                                    // workgroup-uniform\n"
+                "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");\n", n_cks + 1);
+        sfmt(s,
+                "        const uint32_t K = 256u / nv, c = tid %% nv, r0 = tid / nv;              // thread (r0, c): value c of rows r0, r0 + K, ...\n"
+                "        const bool is_cnt = (c %% %uu) == %uu;\n"
+                "        uint64_t v = 0;\n"
+                "        if (r0 < K) {\n"
+                "            uint64_t x[8];\n"
+                "            for (uint32_t rb = r0; rb < members; rb += 8u * K) {                  // up to 8 loads in flight per lane and trip\n"
+                "_Pragma(\"unroll\")\n"
+                "                for (int u = 0; u < 8; ++u) { const uint32_t r = rb + (uint32_t)u * K; x[u] = r < members ? ld8_agent((const uint64_t*)rows + (uint64_t)r * nv + c) : 0ull; }\n"
+                "_Pragma(\"unroll\")\n"
+                "                for (int u = 0; u < 8; ++u) v = is_cnt ? v + x[u] : v ^ x[u];\n"
+                "            }\n"
+                "        }\n"
+                "        for (uint32_t i = tid; i < nv; i += 256u) s_acc[i] = 0;                 // (every thread read its s_acc values before the barriers above)\n"
+                "        __syncthreads();\n"
+                "        if (r0 < K) { if (is_cnt) atomicAdd(&s_acc[c], (ggrs_u64)v); else atomicXor(&s_acc[c], (ggrs_u64)v); }\n"
+                "        __syncthreads();\n"
+                "        for (uint32_t i = tid; i < nv; i += 256u) a.parts[(uint64_t)i * a.part_stride + grp] = s_acc[i];\n"
+                "        if (tid == 0) a.gf_tickets[grp] = 0;                                    // ready for the next launch on this stream\n"
+                "        return;\n"
+                "    }\n", n_cks + 1, n_cks);
+        sfmt(s,
                 "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
                 "        const uint32_t sv = i / %uu;\n"
                 "        if (sv >= o_first && sv < o_last)\n"
                 "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
-                "    }\n", fold_text.c_str(), n_cks + 1, n_cks + 1, n_cks + 1);
+                "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     }
     s += "}\n";
     return true;
@@ -799,9 +842,30 @@ void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_
     }
     done(2, "");
 }
+// Worker threads still building when the PROCESS exits (a host that never destroyed its world; Python's interpreter shutdown without
+// World.close) would run hiprtc and the HIP runtime into static destruction.  Every spec that owns a thread is listed here and an atexit
+// handler -- registered with the first worker, i.e. after the HIP runtime's own statics, so it runs before their destructors -- joins them.
+static std::mutex g_spec_workers_mu;
+static std::vector<JitSpec*> g_spec_workers;
+void jit_spec_workers_join_all() {
+    std::vector<JitSpec*> live;
+    { std::lock_guard<std::mutex> lk(g_spec_workers_mu); live.swap(g_spec_workers); }
+    for (JitSpec* sp : live) if (sp->th.joinable()) sp->th.join();
+}
+void jit_spec_worker_register(JitSpec* sp) {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)atexit(jit_spec_workers_join_all); });
+    std::lock_guard<std::mutex> lk(g_spec_workers_mu);
+    g_spec_workers.push_back(sp);
+}
+void jit_spec_worker_forget(JitSpec* sp) {
+    std::lock_guard<std::mutex> lk(g_spec_workers_mu);
+    g_spec_workers.erase(std::remove(g_spec_workers.begin(), g_spec_workers.end(), sp), g_spec_workers.end());
+}
 // a shape leaves the table (or the world goes): the worker is joined, launches that use the module have drained
 void jit_spec_drop(ggrs_world* w, JitSpecSlot& s) {
     if (!s.spec) return;
+    jit_spec_worker_forget(s.spec);
     if (s.spec->th.joinable()) s.spec->th.join();
     if (s.spec->mod) { if (w->stream) (void)hipStreamSynchronize(w->stream); (void)hipModuleUnload(s.spec->mod); }
     delete s.spec; s.spec = nullptr;

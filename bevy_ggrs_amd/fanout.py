@@ -277,6 +277,9 @@ class SpeculativeFanout:
         self._inflight: List[int] = []
         self._gathers: list = []
         self.results: list = []                              # every result the pipelined path completes, in step order
+        # the gathered table of the next `raw_keep` completed steps, undecoded: (C, (size, bpr * D, 2) u64 array).  bench.py's parity
+        # gate reads it AFTER its timed region (no Python ints per checksum while the clock runs)
+        self.raw_keep, self.raw = 0, []
         world.set_depth(depth + 1)
 
     # ------------------------------------------------------------------ helpers
@@ -323,6 +326,8 @@ class SpeculativeFanout:
             self.synced = False                              # caller may sync_confirmed() again
             raise DesyncDetected(C + 1, [int(p[0]) | (int(p[1]) << 64) for p in conf])
         self._last_raw = (C, allv)
+        if len(self.raw) < self.raw_keep:
+            self.raw.append((C, allv.copy()))
         return self.last if want_result else None
 
     def _finish(self, C: int, mine: np.ndarray, want_result: bool = True, defer: bool = False) -> Optional[dict]:

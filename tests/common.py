@@ -24,12 +24,16 @@ FULL_EXTRA = (("GlobalTransform", 4, 12), ("Visibility", 1, 1), ("InheritedVisib
 
 
 def schema_bytes_per_entity(schema="headline"):
-    return 60 if schema == "headline" else 60 + sum(wb * nw for _, wb, nw in FULL_EXTRA)
+    return 60 if schema in ("headline", "allhot") else 60 + sum(wb * nw for _, wb, nw in FULL_EXTRA)
 
 
 def schema_description(schema="headline"):
     if schema == "headline":
         return "3 registered components (Transform, Velocity, Ttl; 60 B/entity)"
+    if schema == "allhot":
+        return ("3 registered components (Transform, Velocity, Ttl; 60 B/entity) with EVERY column written every frame: the stress_test systems plus the "
+                "reference bench's increase_component (benches/bench.rs:30-46) over the 7 words of Transform.rotation / .scale -- every SaveWorld moves all 15 rows, "
+                "as the reference's clone-everything save does (component_snapshot.rs:66-84)")
     return (f"7 registered components (Transform, GlobalTransform, Visibility, InheritedVisibility, ViewVisibility, Velocity, Ttl; "
             f"{schema_bytes_per_entity(schema)} B/entity: the reference stress_test's rollback list minus Sprite, particles.rs:190-199)")
 
@@ -53,6 +57,11 @@ def build_particles(world, *, with_spawn=False, ttl_init=300, checksum=True, sch
         world.checksum_component(T, [0, 1, 2])        # checksum_component::<Transform>(translation)
     world.add_system(bg.SYS_PARTICLES_UPDATE, comp=(T, V), word=(0, 0), fparam=(0.0, -200.0, 0.0))
     world.add_system(bg.SYS_TTL_DESPAWN, comp=(L,), word=(0,))
+    if schema == "allhot":
+        # a game whose systems touch rotation and scale too: no column keeps its bytes from one frame to the next, so row versions
+        # cannot skip anything -- the all-columns-hot case of VERDICT r3 (What's missing 3)
+        for k in range(3, 10):
+            world.add_system(bg.SYS_ADD_U32, comp=(T,), word=(k,), iparam=(1,))
     if with_spawn:
         world.add_system(bg.SYS_PARTICLES_SPAWN, comp=(T, V, L), iparam=(ttl_init, INPUT_SPAWN))
     return (T, V, L) + extra

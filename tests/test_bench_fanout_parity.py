@@ -1,0 +1,55 @@
+"""bench.py's N > 1 parity gate (fanout_parity) on the CPU: the gathered-table layout SpeculativeFanout keeps (`raw`), the
+fast-forward to the first timed step and the serial walk of every branch -- driven here by a fan-out over an ORACLE world
+(world size 1, no collectives), so the checker's plumbing is pinned without a GPU.  The GPU leg runs bench.py itself
+(tests/test_gpu_zfanout.py::test_bench_two_ranks_line_carries_parity_cpu_baseline_and_roofline)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import common as cm  # noqa: E402
+from bevy_ggrs_amd.fanout import SpeculativeFanout, default_branch_input  # noqa: E402
+from oracle.binding import FLAT, OracleWorld  # noqa: E402
+
+
+class _OneRank:
+    def get_rank(self): return 0
+    def get_world_size(self): return 1
+
+
+class _NoExchange:
+    def broadcast(self, dist, src): pass
+    def all_gather_u64(self, dist, values): return np.ascontiguousarray(values).reshape(1, -1)
+
+
+def test_parity_gate_accepts_the_serial_walk_and_names_a_flipped_bit():
+    import bench
+    n, D, bpr, warm, P = 3000, 4, 3, 5, 2
+    w = OracleWorld(n, D + 1, FLAT)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    fan = SpeculativeFanout(w, _OneRank(), D, _NoExchange(), branches_per_rank=bpr)
+    fan.sync_confirmed(0)
+    for _ in range(warm):
+        fan.step(want_result=False)
+    c_timed = fan.confirmed
+    assert c_timed == warm
+    fan.raw, fan.raw_keep = [], P
+    for _ in range(P + 2):
+        fan.step(want_result=False)
+    assert len(fan.raw) == P and [c for c, _ in fan.raw] == [c_timed, c_timed + 1]
+    par = bench.fanout_parity(n, D, c_timed, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2)
+    assert par["equal"] is True and par["checked_steps"] == P and par["checked_branches"] == bpr and par["checked_saves"] == P * bpr * D, par
+    # one flipped bit in one branch's one Save is found and named
+    bad = [(c, t.copy()) for c, t in fan.raw]
+    bad[1][1][0, 1 * D + 2, 0] ^= np.uint64(1)
+    par = bench.fanout_parity(n, D, c_timed, bad, 1, bpr, default_branch_input, lambda f: 0, threads=2)
+    assert par["equal"] is False and par["first_mismatch"]["step"] == 1 and par["first_mismatch"]["branch"] == 1 and par["first_mismatch"]["save"] == 2, par
+    # a table that starts at the wrong confirmed frame is refused, not compared
+    par = bench.fanout_parity(n, D, c_timed + 1, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2)
+    assert par["equal"] is False and "confirmed frame" in par["first_mismatch"]["why"], par

@@ -23,6 +23,9 @@ KNOBS = [
     {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1"},     # generated kernel, persistent form + in-launch fold even for small worlds
     {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # every group folded on the device (k_gen_finalize)
     {"GGRS_HOST_FOLD_MAX_WGS": "256"},                      # only small groups folded by the host (the round-2 default)
+    {"GGRS_GROUP_FOLD_MIN_WGS": "0"},                       # no group fold: one row per workgroup leaves the kernel at every size
+    {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0"},   # group fold even for the 10 k world (one group of 56 workgroups incl. a padding one)
+    {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0", "GGRS_HOST_FOLD_MAX_WGS": "0"},   # ... with the groups' rows staying on the device (k_gen_finalize over rows / 64)
     {"GGRS_DEAD_GROUPS": "0"},
     {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
     {"GGRS_JIT_DP_MAX_SLOTS": "400000"},                    # depth-parallel roles far above their default range
@@ -93,6 +96,9 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     if env.get("GGRS_TICK_GENERIC") == "1": assert k.startswith("ggrs_jit_tick"), k
     if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
     if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
+    if not env: assert info["checksum_fold"].startswith("group fold" if n > 1024 * 256 else "the host folds"), info
+    if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "0": assert "group fold" not in info["checksum_fold"], info
+    if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
     if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
     if env.get("GGRS_ARENA_CONTIG") == "0": assert info["arena"].startswith("paged"), info
     if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("k_tick3" if n > 416 * 1024 else "ggrs_jit_tick"), k

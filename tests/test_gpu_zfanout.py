@@ -268,3 +268,42 @@ def test_native_fanout_two_ranks_over_rccl():
         for got, want in zip(out, ref):
             assert got["confirmed_checksum"] == want["confirmed_checksum"]
             assert got["branch_checksums"] == want["branch_checksums"]
+
+
+def _bench_line(args, env=None, timeout=900):
+    """Run bench.py as the driver does (a fresh process) and return its ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env={**os.environ, **(env or {})}, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_line_carries_parity_cpu_baseline_and_roofline():
+    """`bench.py --gpus 2` end to end on the one GPU of this box: bench.py starts its two ranks itself, both on device 0
+    (--oversubscribe; control plane gloo, the library's collectives over the shared-memory stand-in for RCCL), times its steps, and rank 0
+    prints the line a SCALE run would record: n_gpus from ncclCommCount, the in-run parity of the gathered checksum table against the
+    oracle's serial walk of every branch of both ranks, the CPU baseline and the roofline of rank 0's kernel."""
+    line = _bench_line(["--gpus", "2", "--oversubscribe", "--steps", "6", "--warmup", "2", "--preheat-ms", "20", "--entities", "300000", "--cpu-ticks", "1"],
+                       env={"GGRS_RCCL_LIB": _double_lib()})
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
+    par = line["parity"]
+    assert par["equal"] is True and par["checked_branches"] == 2 and par["checked_steps"] >= 1 and par["checked_saves"] == par["checked_steps"] * 2 * 8, par
+    cb = line["cpu_baseline"]
+    assert cb and cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] == 1 and cb["flat_soa_port"]["value"] > 0, cb
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["launches_timed"] > 0 and roof["algorithmic_bytes_per_launch"] > 0, roof
+    assert line["value"] > 0 and "2 ranks" in line["config"]["parallelism"]
+
+
+def test_bench_config5_fanout_line_on_one_gpu():
+    """BASELINE config 5 through bench.py at world size 1 (the real RCCL): 256 branches, the parity gate walks every one of them on the
+    oracle, and the line carries the integer-multiply roofline next to the HBM one."""
+    line = _bench_line(["--config", "5", "--steps", "4", "--warmup", "2", "--preheat-ms", "20", "--cpu-ticks", "1"])
+    assert line["n_gpus"] == 1 and line["parity"]["equal"] is True and line["parity"]["checked_branches"] == 256, line.get("parity")
+    assert line["cpu_baseline"]["value"] > 0
+    assert line["roofline_alu"]["achieved"] > 0
