@@ -456,8 +456,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
-            // Group fold (kernel_gen.hpp): a launch of many workgroups folds its rows 64 to 1 on the chip; what the consumer reads -- the host at
-            // collect time or right away (blocking calls), k_gen_finalize when results stay on the device -- is `rows` group rows, not g
+            // Group fold (kernel_gen.hpp): a launch of many workgroups combines its rows 64 to 1 on the chip (atomics into one accumulator row per
+            // group); what the consumer reads -- the host at collect time or right away (blocking calls), k_gen_finalize when results stay on the
+            // device -- is `rows` group rows, not g
             const bool group_fold = launch && j.n_saves && !j.dp_s && w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs &&
                                     j.n_saves * (n_cks + 1) <= 256u && w->d_gf_tickets;
             const uint32_t rows = group_fold ? (jit_grid(g) + 63u) / 64u : g;
@@ -465,7 +466,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             const bool host_fold = launch && host_fold_rows(w, rows, j.n_saves, n_cks, 1, &rows_off, wait);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = rows; }
             if (group_fold) {
-                j.gf_rows = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.gf_tickets = w->d_gf_tickets;
+                j.gf_rows = reinterpret_cast<ggrs_u64*>(w->d_gf_acc); j.gf_tickets = w->d_gf_tickets;
                 if (!host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_gf_out); j.part_stride = rows; }
             }
             if (launch) {

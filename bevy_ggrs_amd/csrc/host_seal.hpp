@@ -29,7 +29,7 @@ int seal(ggrs_world* w) {
     if (rc == GGRS_OK) return rc;
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_gf_out = nullptr; w->d_gf_tickets = nullptr; }
+    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_gf_acc = nullptr; w->d_gf_out = nullptr; w->d_gf_tickets = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -296,17 +296,21 @@ int seal_impl(ggrs_world* w) {
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
-        // [saves][n_cks + 1][one row per 256-slot workgroup] for k_gen_finalize -- or, group fold, [workgroup][saves x (n_cks + 1)]: the same
-        // count -- then the groups' folded rows (when they stay on the device) and one ticket per 64 workgroups of the largest grid
-        const size_t bytes = align_up((size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * (w->gen_part_stride + 8) * 8, ALIGN);
+        // k_gen_finalize's row buffer [saves][n_cks + 1][one row per 256-slot workgroup]; then, for the group fold (kernel_gen.hpp): one
+        // accumulator row [saves x (n_cks + 1)] per 64 workgroups of the largest grid (zero between launches), the groups' finished rows when
+        // they stay on the device, and one ticket per group (zero between launches)
+        const size_t bytes = align_up((size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8, ALIGN);
         w->gf_groups_max = (w->gen_part_stride + 8 + 63) / 64 + 1;
-        const size_t out_bytes = align_up((size_t)w->gf_groups_max * MAX_TICK_SAVES * (w->cks_args.n_cks + 1) * 8, ALIGN);
+        const size_t acc_bytes = align_up((size_t)w->gf_groups_max * MAX_TICK_SAVES * (w->cks_args.n_cks + 1) * 8, ALIGN);
         const size_t ticket_bytes = align_up((size_t)w->gf_groups_max * 4, ALIGN);
-        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes + out_bytes + ticket_bytes));
-        w->d_gf_out = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(w->d_gen_parts) + bytes);
-        w->d_gf_tickets = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(w->d_gen_parts) + bytes + out_bytes);
-        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + out_bytes, w->stream));
-        HIPCHK(w, hipMemsetAsync(w->d_gf_tickets, 0, ticket_bytes, w->stream));                // arrival counters: zero between launches
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes + 2 * acc_bytes + ticket_bytes));
+        uint8_t* const base = reinterpret_cast<uint8_t*>(w->d_gen_parts);
+        w->d_gf_acc = reinterpret_cast<uint64_t*>(base + bytes);
+        w->d_gf_out = reinterpret_cast<uint64_t*>(base + bytes + acc_bytes);
+        w->d_gf_tickets = reinterpret_cast<uint32_t*>(base + bytes + 2 * acc_bytes);
+        if (w->knobs.debug_poison) { HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream)); HIPCHK(w, hipMemsetAsync(w->d_gf_out, 0xA5, acc_bytes, w->stream)); }
+        HIPCHK(w, hipMemsetAsync(w->d_gf_acc, 0, acc_bytes, w->stream));
+        HIPCHK(w, hipMemsetAsync(w->d_gf_tickets, 0, ticket_bytes, w->stream));
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;

@@ -56,9 +56,11 @@ struct Knobs {
     int jit_persist_oversub = 1;   // GGRS_JIT_PERSIST_OVERSUB=n  persistent form: grid = up to n x the workgroups the device holds at once
     int host_fold_max_wgs = 16384;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
     bool host_fold_explicit = false;   //                            (set: the limit also applies to blocking calls, which otherwise keep the device fold above 1024 workgroups)
-    int group_fold_min_wgs = 1024; // GGRS_GROUP_FOLD_MIN_WGS=n  generated kernel, per-tile grid: launches of MORE than n workgroups fold their partial rows on the chip first,
-                                   //                       64 workgroups per ticket (the group's last arriver XORs the 64 rows): the host -- or k_gen_finalize -- reads 1/64 of the
-                                   //                       rows, blocking calls included (0: never; rows go to the consumer one per workgroup)
+    int group_fold_min_wgs = 12288; // GGRS_GROUP_FOLD_MIN_WGS=n  generated kernel, per-tile grid: launches of MORE than n workgroups combine their partial rows on the chip,
+                                   //                       64 workgroups per accumulator row and ticket (agent-scope atomics by wave 0; the group's last arriver hands the row on):
+                                   //                       the host -- or k_gen_finalize -- reads 1/64 of the rows, blocking calls included (0: never).  The in-launch hand-off
+                                   //                       costs a constant 3-4.5 us at the end of the launch (profiles/r04b): it pays from ~3 M slots up, where the host's fold of
+                                   //                       one row per workgroup (3 MB per tick at 4 M) no longer hides behind the next tick's kernel
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
@@ -94,7 +96,7 @@ struct Knobs {
         k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
         k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
-        k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 1024)));
+        k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 12288)));
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
@@ -234,7 +236,7 @@ struct ggrs_world {
     uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
     uint32_t wg_parts_rows = 0;          // rows (workgroups) d_wg_parts has room for: every grid that uses tick_fold is clamped to it
     uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]
-    uint32_t* d_gf_tickets = nullptr; uint64_t* d_gf_out = nullptr; uint32_t gf_groups_max = 0;   // group fold: one ticket per 64 workgroups; the groups' rows when they stay on the device
+    uint32_t* d_gf_tickets = nullptr; uint64_t* d_gf_acc = nullptr; uint64_t* d_gf_out = nullptr; uint32_t gf_groups_max = 0;   // group fold: ticket and accumulator row per 64 workgroups; the finished rows when they stay on the device
     bool gen_ok = false;                 // the generated kernel serves this world's request lists
 
     // pending partials produced by the last advance (valid for the live state as-is)

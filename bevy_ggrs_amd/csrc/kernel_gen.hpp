@@ -165,9 +165,9 @@ struct GgrsJitArgs {
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
     ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;   // persistent form: tick_fold's row buffer, ticket and result slots
-    // per-tile form, GROUP FOLD (non-null): every workgroup leaves its row of partials in device memory (gf_rows, [workgroup][n_saves x
-    // (n_cks + 1)]) and takes a ticket of its group of 64 workgroups (dispatch order); the group's last arriver XORs / adds the 64 rows
-    // into ONE row and stores that to `parts` (column = group): the consumer -- the host, or k_gen_finalize -- reads 1/64 of the rows
+    // per-tile form, GROUP FOLD (non-null): every workgroup XORs / adds its partials into the accumulator row of its group of 64 workgroups
+    // (dispatch order) in device memory (gf_rows, [group][n_saves x (n_cks + 1)], zero between launches) and takes the group's ticket; the
+    // last arriver hands the row to `parts` (column = group): the consumer -- the host, or k_gen_finalize -- reads 1/64 of the rows
     ggrs_u64* gf_rows; ggrs_u32* gf_tickets;
 };
 static_assert(MAX_TICK_SAVES == 16 && MAX_TICK_STEPS == 24, "GgrsJitArgs is sized for 16 Saves / 24 steps per group");
@@ -639,41 +639,34 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "%s", fold_text.c_str());
         sfmt(s,
                 "    if (a.gf_rows) {\n"
-                "        // GROUP FOLD (HBM-sized groups; no roles, no batch): 64 workgroups in dispatch order share a ticket; their rows travel through\n"
-                "        // device memory as relaxed agent-scope 8-byte accesses on both sides (write-through stores, L1-bypassing loads:\n"
-                "        // MI355X_MICROARCH.md 'Valid forms'), an explicit vmcnt(0) between a workgroup's row and its ticket.  The last arriver folds\n"
-                "        // the group's rows (component_checksum.rs:88-89 is an XOR, the live count a sum: any grouping gives the same result)\n"
+                "        // GROUP FOLD (HBM-sized groups; no roles, no batch).  64 workgroups in dispatch order share one accumulator row in device memory and\n"
+                "        // one ticket.  Wave 0 of every workgroup XORs / adds the workgroup's partials into the row with agent-scope atomics (performed at the\n"
+                "        // memory side: coherent across the XCDs' L2s), drains them -- an explicit vmcnt(0): the atomics are in memory before the ticket is\n"
+                "        // taken -- and takes the ticket; the other waves are gone by then, so a workgroup waiting for its stores to drain holds one wave\n"
+                "        // slot, not four.  The group's last arriver reads the row (L1-bypassing loads), hands it to `parts` (column = group) and clears it.\n"
+                "        // component_checksum.rs:88-89 is an XOR and the live count a sum: any grouping and any order give the same result.\n"
+                "        if (wave != 0u) return;\n"
                 "        const uint32_t nv = a.n_saves * %uu;                                   // values per row (<= 256: the host checks)\n"
                 "        const uint32_t grp = blockIdx.x >> 6, members = min(64u, gridDim.x - (grp << 6));\n"
-                "        ggrs_u64* rows = a.gf_rows + (uint64_t)(grp << 6) * nv;\n"
-                "        for (uint32_t i = tid; i < nv; i += 256u) st8_agent((uint64_t*)rows + (uint64_t)(blockIdx.x & 63u) * nv + i, (uint64_t)s_acc[i]);\n"
-                "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");                       // the row is in memory before the ticket is taken\n"
-                "        __syncthreads();\n"
-                "        if (tid == 0) s_last = __hip_atomic_fetch_add(a.gf_tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u ? 1u : 0u;\n"
-                "        __syncthreads();\n"
-                "        if (!s_last) return;                                                    // workgroup-uniform\n"
-                "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");\n", n_cks + 1);
-        sfmt(s,
-                "        const uint32_t K = 256u / nv, c = tid %% nv, r0 = tid / nv;              // thread (r0, c): value c of rows r0, r0 + K, ...\n"
-                "        const bool is_cnt = (c %% %uu) == %uu;\n"
-                "        uint64_t v = 0;\n"
-                "        if (r0 < K) {\n"
-                "            uint64_t x[8];\n"
-                "            for (uint32_t rb = r0; rb < members; rb += 8u * K) {                  // up to 8 loads in flight per lane and trip\n"
-                "_Pragma(\"unroll\")\n"
-                "                for (int u = 0; u < 8; ++u) { const uint32_t r = rb + (uint32_t)u * K; x[u] = r < members ? ld8_agent((const uint64_t*)rows + (uint64_t)r * nv + c) : 0ull; }\n"
-                "_Pragma(\"unroll\")\n"
-                "                for (int u = 0; u < 8; ++u) v = is_cnt ? v + x[u] : v ^ x[u];\n"
-                "            }\n"
+                "        uint64_t* row = (uint64_t*)a.gf_rows + (uint64_t)grp * nv;\n"
+                "        for (uint32_t i = lane; i < nv; i += 64u) {\n"
+                "            const uint64_t v = (uint64_t)s_acc[i];\n"
+                "            if (v == 0ull) continue;                                            // (a padding workgroup, a tile without live entities)\n"
+                "            if ((i %% %uu) == %uu) (void)__hip_atomic_fetch_add(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                "            else (void)__hip_atomic_fetch_xor(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
                 "        }\n"
-                "        for (uint32_t i = tid; i < nv; i += 256u) s_acc[i] = 0;                 // (every thread read its s_acc values before the barriers above)\n"
-                "        __syncthreads();\n"
-                "        if (r0 < K) { if (is_cnt) atomicAdd(&s_acc[c], (ggrs_u64)v); else atomicXor(&s_acc[c], (ggrs_u64)v); }\n"
-                "        __syncthreads();\n"
-                "        for (uint32_t i = tid; i < nv; i += 256u) a.parts[(uint64_t)i * a.part_stride + grp] = s_acc[i];\n"
-                "        if (tid == 0) a.gf_tickets[grp] = 0;                                    // ready for the next launch on this stream\n"
+                "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+                "        uint32_t t_ = 0;\n"
+                "        if (lane == 0) t_ = __hip_atomic_fetch_add(a.gf_tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                "        t_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_);\n"
+                "        if (t_ != members - 1u) return;                                         // wave-uniform\n"
+                "        for (uint32_t i = lane; i < nv; i += 64u) {\n"
+                "            a.parts[(uint64_t)i * a.part_stride + grp] = ld8_agent(row + i);\n"
+                "            st8_agent(row + i, 0ull);                                           // ready for the next launch on this stream\n"
+                "        }\n"
+                "        if (lane == 0) a.gf_tickets[grp] = 0;\n"
                 "        return;\n"
-                "    }\n", n_cks + 1, n_cks);
+                "    }\n", n_cks + 1, n_cks + 1, n_cks);
         sfmt(s,
                 "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
                 "        const uint32_t sv = i / %uu;\n"

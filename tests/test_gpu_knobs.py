@@ -96,7 +96,7 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     if env.get("GGRS_TICK_GENERIC") == "1": assert k.startswith("ggrs_jit_tick"), k
     if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
     if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
-    if not env: assert info["checksum_fold"].startswith("group fold" if n > 1024 * 256 else "the host folds"), info
+    if not env: assert info["checksum_fold"].startswith("the host folds"), info           # (the group fold's default range starts at 12288 workgroups: test_group_fold_default_range)
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "0": assert "group fold" not in info["checksum_fold"], info
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
     if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
@@ -122,3 +122,16 @@ def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
             assert info["generated_kernel"].startswith("disabled") and info["request_group_kernel"].startswith("per-request"), info
             assert info["hiprtc"].startswith(("loaded", "missing")), info
     assert res[0] == res[1]
+
+
+def test_group_fold_default_range():
+    """Default policy of the checksum fold by world size (host_world.hpp Knobs::group_fold_min_wgs, profiles/r04b): one row per workgroup to the
+    host up to 12288 workgroups, the on-chip group fold beyond (4 M slots: 245 rows of 15625 leave the kernel)."""
+    for n, want in ((1_000_000, "the host folds"), (3_300_000, "group fold on the chip")):
+        w = bg.World(n, max_depth=2)
+        ids = cm.build_particles(w)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        info = w.kernel_info()
+        w.close()
+        assert info["checksum_fold"].startswith(want), (n, info["checksum_fold"])
