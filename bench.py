@@ -503,7 +503,7 @@ def main():
     ap.add_argument("--arena", choices=["both", "paged", "contig"], default="paged",
                     help="single-GPU path: `value` is measured on the library's default paged arena unless 'contig' is forced; 'both' also "
                          "measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
-                         "as roofline.contig_arena_variant (it pays for k_tick3's 16-byte store streams: GGRS_ROW_VERSIONS=0 / GGRS_TICK_JIT=0 worlds)")
+                         "as roofline.contig_arena_variant (round 3: it paid for k_tick3's 16-byte store streams; the generated kernel is faster on paged memory)")
     ap.add_argument("--paged-arena", action="store_true", help="same as --arena paged")
     ap.add_argument("--schema", choices=["headline", "full", "allhot"], default="headline",
                     help="headline: BASELINE's 3 registered components (60 B/entity); full: the reference stress_test's POD schema "

@@ -132,8 +132,8 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
     if (z > hi) z = hi;
 }
 
-// ------------------------------------------------------------------ in-launch checksum fold (k_tick3 and the persistent
-// form of the generated kernel)
+// ------------------------------------------------------------------ in-launch checksum fold (the persistent form of the
+// generated kernel)
 // In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
 // the last workgroup to arrive writes every Save's Checksum(u128).
 struct FoldArgs {

@@ -1,10 +1,10 @@
 // ggrs_hip.hip -- libggrs_hip.so: host runtime + C ABI (see include/ggrs_hip.h).  ONE translation unit, in parts:
-//   kernels.hpp / device_prelude.hpp   gfx950 device code (k_tick3, the per-request kernels, the checksum folds)
+//   kernels.hpp / device_prelude.hpp   gfx950 device code (the per-request kernels, the checksum folds, the text shared with generated kernels)
 //   host_world.hpp                     struct ggrs_world, knobs, layout of a packed state block, row versions
 //   kernel_gen.hpp                     hiprtc plumbing, custom systems, the per-world request-group kernel generator, module cache
 //   host_seal.hpp                      sealing: fused-path recognition, kernel generation, arena carve
 //   host_requests.hpp                  one launch per request (SaveWorld / LoadWorld / AdvanceWorld), ring, spawns, host-side fold
-//   host_groups.hpp                    fused request groups: run_request_groups_tick3 / run_request_groups_gen
+//   host_groups.hpp                    fused request groups: run_request_groups_gen
 //   host_fanout.hpp                    speculative fan-out over RCCL (ggrs_hip_fanout_*)
 //   this file                          the C ABI entry points
 //
@@ -652,13 +652,12 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
     std::string k;
     const uint64_t cover = std::max(w->len, w->live.dirty_len);
     if (!w->sealed) k = "unknown (not sealed)";
-    else if (use_tick3(w)) k = "k_tick3 (hand-written for the particles schedule: wave-specialised, in-kernel checksum fold)";
     else if (w->gen_ok) k = (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots)
                                ? "ggrs_jit_tick (generated for this world; persistent grid, in-kernel checksum fold)"
                                : "ggrs_jit_tick (generated for this world; one workgroup per 256 slots)";
     else k = "per-request kernels (k_copy_state, one launch per system)";
     add("request_group_kernel", k);
-    if (w->sealed && w->gen_ok && !use_tick3(w)) {
+    if (w->sealed && w->gen_ok) {
         // who folds the per-workgroup checksum rows of a plain (no roles, no batch) request group of this size
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
         const bool gf = w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs && w->d_gf_tickets;

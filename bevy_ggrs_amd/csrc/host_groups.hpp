@@ -4,8 +4,8 @@
 // slot's words in registers, the live block is written once.  The host does, in request order and while the group is
 // assembled, everything the reference's systems do outside the per-entity loops: frame counters, ring push / confirm /
 // rollback (exact mirror of mod.rs:121-243 over slot indices), row versions, dirty extents.
-// Two kernels serve groups: the hand-written k_tick3 (HBM-sized particles worlds) and the kernel generated for the world
-// (kernel_gen.hpp; per-tile grid for small worlds, persistent grid + in-kernel fold for big ones).
+// One kernel serves groups: the one generated for the world (kernel_gen.hpp; per-tile grid by default, a persistent grid with the
+// fold in the launch as an opt-in).
 // Part of the single translation unit ggrs_hip.hip.
 #pragma once
 
@@ -127,120 +127,11 @@ bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, ui
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_tick3: HBM-sized particles worlds
-// ---------------------------------------------------------------------------------------------------------------------
-void launch_tick3(ggrs_world* w, const Tick3Args& a, uint32_t g) {
-    if (a.n_rest_rows != (uint32_t)TICK3_RESTL_EXACT) {                 // not the stress_test's 7 rows: the general instantiation
-        if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
-        else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
-        else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
-        else hipLaunchKernelGGL((k_tick3<false, false, TICK3_RESTL_ANY, false>), dim3(g), dim3(512), 0, w->stream, a);
-        return;
-    }
-    if (w->f_cksT && w->f_cksV) hipLaunchKernelGGL((k_tick3<true, true, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
-    else if (w->f_cksT) hipLaunchKernelGGL((k_tick3<true, false, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
-    else if (w->f_cksV) hipLaunchKernelGGL((k_tick3<false, true, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
-    else hipLaunchKernelGGL((k_tick3<false, false, TICK3_RESTL_EXACT>), dim3(g), dim3(512), 0, w->stream, a);
-}
-
-// res_base: first slot of the pinned result ring this list writes to.  wait == false only enqueues
-// (ggrs_hip_enqueue_requests); the list then must hold fewer Saves than the ring can take.
-int run_request_groups_tick3(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
-                             uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
-    uint32_t i = 0, ns = 0;                      // ns: results pending in d_results
-    int rc = GGRS_OK;
-    while (i < n) {
-        Tick3Args b = w->tick3_proto;
-        GroupState gs;
-        const ggrs_request* spawn_req = nullptr;
-        rc = group_open(w, reqs, i, gs); if (rc) return rc;
-        b.src_is_live = gs.src_is_live;
-        // ---- gather the ops that follow, doing the host-side bookkeeping in request order
-        while (i < n && b.n_ops < (uint32_t)MAX_TICK_OPS) {
-            const ggrs_request& r = reqs[i];
-            if (r.kind == GGRS_REQ_LOAD) break;
-            if (r.kind == GGRS_REQ_SAVE) {
-                if (b.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + b.n_saves == w->max_results)) break;
-                rc = group_save(w, gs, b.n_saves, b.save_dst, b.save_frame); if (rc) return rc;
-                ++b.n_ops; ++b.n_saves;                                     // op bit stays 0: Save
-            } else if (r.kind == GGRS_REQ_ADVANCE) {
-                if (b.n_steps == (uint32_t)MAX_TICK_STEPS) break;
-                rc = group_step(w, r, &b.dt_bits[b.n_steps]); if (rc) return rc;
-                ++b.n_steps;
-                b.op_bits |= 1ULL << b.n_ops; ++b.n_ops;                     // op bit 1: Advance
-                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }   // Commands flush ends the group
-            } else {
-                return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
-            }
-            ++i;
-        }
-        const bool dead = group_is_dead(w, reqs, i, n, b.save_frame, b.n_saves, spawn_req != nullptr);
-        if (dead) { for (uint32_t k = 0; k < b.n_saves; ++k) b.save_dst[k] = nullptr; b.skip_live = 1; }
-        const bool wrote_live = (!b.src_is_live || b.n_steps) && !b.skip_live;
-        // ---- row versions -> what each Save / the live write stores, what has to be loaded
-        auto split = [&](uint64_t cols, uint32_t* sched, uint32_t* rest) {
-            *sched = 0; *rest = 0;
-            for (uint32_t c : w->tick3_sched_cols) if ((cols >> c) & 1ull) *sched = 1;
-            for (size_t j = 0; j < w->tick3_rest_cols.size(); ++j) if ((cols >> w->tick3_rest_cols[j]) & 1ull) *rest |= 1u << j;
-        };
-        uint64_t bytes_slot = 32;                                            // the 8 schedule-owned rows are always read
-        for (uint32_t k = 0; k < b.n_saves; ++k) {
-            uint32_t sc = 0, rs = 0;
-            if (b.save_dst[k]) split(gs.save_rows[k], &sc, &rs);
-            b.sched_store |= sc << k; b.rest_store[k] = rs; b.rest_load |= rs;
-            bytes_slot += (sc ? 32u : 0u) + 4u * (uint32_t)__builtin_popcount(rs);
-        }
-        if (wrote_live) {
-            uint32_t sc = 0, rs = 0;
-            split(rows_to_store(w, w->live), &sc, &rs);
-            b.sched_live = sc; b.rest_live = rs; b.rest_load |= rs;
-            bytes_slot += (sc ? 32u : 0u) + 4u * (uint32_t)__builtin_popcount(rs);
-        }
-        bytes_slot += 4u * (uint32_t)__builtin_popcount(b.rest_load);
-        // ---- one pass over the tiles: persistent grid, in-kernel fold, the Checksum(u128)s land in the pinned result ring
-        const uint64_t cover = std::max(gs.cover, w->len);
-        b.src = gs.src->ptr; b.live = w->live.ptr; b.len = w->len;
-        b.n_units = std::max(1u, (uint32_t)((cover + 255) / 256));
-        b.fold.wg_parts = w->d_wg_parts; b.fold.ticket = w->d_ticket;
-        b.fold.out = w->d_results + 2 * (uint64_t)(res_base + ns);
-        const uint32_t tiles = std::max(1u, tiles_for(cover));
-        const uint32_t g2 = std::min<uint32_t>(tiles, (uint32_t)(w->n_cu * 2));
-        if (b.n_ops || !b.src_is_live) {
-            ProfScope ps(w, GGRS_KERNEL_TICK, bytes_slot * w->len);
-            launch_tick3(w, b, g2);
-        }
-        HIPCHK(w, hipGetLastError());
-        group_close(w, gs, b.n_saves, dead, wrote_live);
-        ns += b.n_saves;
-        if (spawn_req) {
-            rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
-            if (rc) return rc;
-        }
-        if (wait && ns == w->max_results) {                                // flush a full result page
-            rc = read_back(w, ns, checksums_out); if (rc) return rc;
-            checksums_out += 2 * (uint64_t)ns; ns = 0;
-        }
-    }
-    if (n_saves_out) *n_saves_out = ns;
-    if (!wait) return GGRS_OK;
-    return read_back(w, ns, checksums_out);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // the generated kernel
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint64_t JIT_NT_MIN_SLOTS = 416 * 1024;      // snapshot stores of bigger groups are non-temporal: written once, read a tick later, and the ring does not fit the Infinity Cache
 constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20;   // the first Save of an HBM-sized rollback group goes through the L2 while its rows are this small
 constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-only groups ride in one launch while the world is this small
-// The particles world has two fused paths: the hand-written k_tick3 and the kernel generated for it like for any other world.
-// Which one serves a list is the knob jit_particles_max_slots (host_world.hpp: measured crossovers); a particles world without a
-// generated kernel (no run-time compiler) runs on k_tick3 at every size.
-bool use_tick3(const ggrs_world* w) {
-    if (!w->tick3_ok) return false;
-    if (!w->jit_fn || !w->gen_ok) return true;
-    return std::max(w->len, w->live.dirty_len) > w->knobs.jit_particles_max_slots;
-}
-
 // grid of the per-tile form: 8 x ceil(tiles / 8) workgroups, mapped to tiles XCD by XCD inside the kernel (kernel_gen.hpp)
 inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 
@@ -515,7 +406,6 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
 // which runner serves this world's request lists right now (nullptr: one launch per request)
 typedef int (*GroupRunner)(ggrs_world*, const ggrs_request*, uint32_t, uint64_t*, uint32_t, bool, uint32_t*);
 GroupRunner group_runner(const ggrs_world* w) {
-    if (use_tick3(w)) return run_request_groups_tick3;
     if (w->gen_ok) return run_request_groups_gen;
     return nullptr;
 }

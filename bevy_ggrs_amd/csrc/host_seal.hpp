@@ -42,10 +42,9 @@ int seal(ggrs_world* w) {
 }
 
 // ---- recognise the particles schedule: [PARTICLES_UPDATE, TTL_DESPAWN] (+ optional SPAWN) over three distinct components.
-// fused_ok: the per-request path steps it with ONE kernel (k_particles_step, checksum partials of the post-step state);
-// tick3_ok: whole request groups run on the hand-written k_tick3.
+// fused_ok: the per-request path steps it with ONE kernel (k_particles_step, checksum partials of the post-step state).
 void recognise_particles(ggrs_world* w) {
-    w->fused_ok = false; w->f_spawn = -1; w->fused_cks = false; w->f_cksT = w->f_cksV = false; w->tick3_ok = false;
+    w->fused_ok = false; w->f_spawn = -1; w->fused_cks = false; w->f_cksT = w->f_cksV = false;
     int upd = -1, ttl = -1, other = 0;
     for (size_t i = 0; i < w->systems.size(); ++i) {
         switch (w->systems[i].kind) {
@@ -77,46 +76,6 @@ void recognise_particles(ggrs_world* w) {
     w->fused_cks = all;
     if (!all) w->f_cksT = w->f_cksV = false;
 
-    // ---- k_tick3: distinct components, every spec covered, the untouched words = up to 16 contiguous 4-byte rows
-    if ((w->flags & GGRS_WORLD_NO_GROUPS) || w->f_T == w->f_V || w->f_T == w->f_L || w->f_V == w->f_L || !(w->fused_cks || w->cks_comp.empty())) return;
-    Tick3Args& b = w->tick3_proto;
-    memset(&b, 0, sizeof b);
-    b.off_alive = w->off_alive;
-    b.off_pT = w->off_present[w->f_T]; b.off_pV = w->off_present[w->f_V]; b.off_pL = w->off_present[w->f_L];
-    w->tick3_sched_cols.clear(); w->tick3_rest_cols.clear();
-    for (int k = 0; k < 3; ++k) {
-        b.off_t[k] = w->col_off[T.col_base + w->f_tw + k];
-        b.off_v[k] = w->col_off[V.col_base + w->f_vw + k];
-        b.g[k] = w->f_g[k];
-        w->tick3_sched_cols.push_back(T.col_base + w->f_tw + k); w->tick3_sched_cols.push_back(V.col_base + w->f_vw + k);
-    }
-    b.off_ttl = w->col_off[L.col_base + w->f_lw];
-    w->tick3_sched_cols.push_back(L.col_base + w->f_lw);
-    b.ts = w->ts;
-    for (uint32_t c = 0; c < w->comps.size(); ++c)
-        if ((int)c != w->f_T && (int)c != w->f_V && (int)c != w->f_L && !w->comps[c].no_rollback) b.rest_mask_off[b.n_rest_masks++] = w->off_present[c];
-    // the untouched rows, in layout order
-    std::vector<std::pair<uint64_t, uint32_t>> rest;               // (col_off, col)
-    for (uint32_t c = 0; c < w->comps.size(); ++c) {
-        const Comp& cc = w->comps[c];
-        if (cc.no_rollback) continue;
-        for (uint32_t k = 0; k < cc.n_words; ++k) {
-            const uint32_t col = cc.col_base + k;
-            if (std::find(w->tick3_sched_cols.begin(), w->tick3_sched_cols.end(), col) != w->tick3_sched_cols.end()) continue;
-            if (cc.word_bytes != 4) return;                             // only 4-byte untouched words ride in the store waves' registers
-            rest.push_back({w->col_off[col], col});
-        }
-    }
-    std::sort(rest.begin(), rest.end());
-    if (rest.size() > (size_t)TICK3_RESTL_ANY) return;
-    for (size_t j = 0; j < rest.size(); ++j) {
-        if (rest[j].first != rest[0].first + (uint64_t)j * REST_ROW_STRIDE) return;      // laid out back to back (build_layout: cold 4-byte words)
-        w->tick3_rest_cols.push_back(rest[j].second);
-    }
-    b.rest_off = rest.empty() ? 0 : rest[0].first;
-    b.n_rest_rows = (uint32_t)rest.size();
-    b.fold.n_comp = 2; b.fold.comp_mask = (w->f_cksT ? 1u : 0u) | (w->f_cksV ? 2u : 0u);
-    w->tick3_ok = true;
 }
 
 int seal_impl(ggrs_world* w) {
@@ -154,7 +113,6 @@ int seal_impl(ggrs_world* w) {
     w->cks_args.off_alive = w->off_alive;
 
     recognise_particles(w);
-    if (w->knobs.tick_generic) w->tick3_ok = false;
 
     // ---- the kernel generated for this world (kernel_gen.hpp): every world it covers, unless groups are off
     w->gen_ok = false; w->jit_box_sys = -1; w->jit_marks = false; w->jit_reads_inputs = false;
@@ -227,7 +185,7 @@ int seal_impl(ggrs_world* w) {
         // only (the mix of profiles/r03fc).
         const bool want = w->knobs.arena_contig == 2 ? w->fused_ok
                         : w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
-                                                     : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->tick3_ok && need <= (1536ull << 20));
+                                                     : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->fused_ok && need <= (1536ull << 20));
         const bool may_allocate = w->knobs.arena_contig >= 0 || g_paged_arena_frees.load(std::memory_order_relaxed) == 0;
         uint8_t* pa = nullptr; uint64_t got = need;
         hipError_t me = hipErrorUnknown;

@@ -6,8 +6,6 @@
 namespace {
 
 constexpr uint64_t ALIGN = 256;
-constexpr int TICK3_RESTL_EXACT = 7;   // untouched rows of the straight-line k_tick3 instantiation: EXACTLY this many (the stress_test world)
-constexpr int TICK3_RESTL_ANY = 16;    // k_tick3's general instantiation: up to this many untouched 4-byte rows
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 struct Comp {
@@ -44,12 +42,7 @@ struct JitEntry;                         // kernel_gen.hpp: a cached generated m
 // aids; none of them changes a result, and tests/test_gpu_knobs.py runs a bit-exact parity case under each of them.
 // (GGRS_HIP_TRACE / GGRS_HIP_ROCTX, the two tracing switches, and GGRS_RCCL_LIB are process-wide.)
 struct Knobs {
-    bool tick_generic = false;     // GGRS_TICK_GENERIC=1   never k_tick3 (the particles world runs on the generated kernel whatever else is set)
-    bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel: k_tick3 for the particles world, per-request kernels for the rest
-    // Which fused kernel serves the particles world (profiles/README.md, r03): with row versions on, the generated kernel wins at
-    // every size (1 M: 87.5 us per tick incl. its finalize launch vs 92.8 for k_tick3; 4 M: 279 vs 300); with GGRS_ROW_VERSIONS=0
-    // every Save moves all 15 rows and k_tick3's 16-byte store streams win above ~416 k slots (115 vs 133 us at 1 M).
-    uint64_t jit_particles_max_slots = ~0ull;        // GGRS_JIT_PARTICLES_MAX_SLOTS  particles worlds up to this size run on the generated kernel (default: all; 416 k with GGRS_ROW_VERSIONS=0)
+    bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel (what a deployment without libhiprtc.so gets): one launch per request
     // The persistent form (one launch, in-kernel fold) is correct at every size but measured slower than the per-tile grid + its
     // k_gen_finalize launch (1 M: 91.8 vs 87.5 us per tick, 4 M: 308 vs 279): opt-in.
     uint64_t jit_persist_min_slots = 0;              // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0 (default): never
@@ -87,11 +80,8 @@ struct Knobs {
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
-        k.tick_generic = num("GGRS_TICK_GENERIC", 0) != 0;
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
-        k.jit_particles_max_slots = getenv("GGRS_JIT_PARTICLES_MAX_SLOTS") ? (uint64_t)std::max<long long>(0, num("GGRS_JIT_PARTICLES_MAX_SLOTS", 0))
-                                                                            : (k.row_versions ? ~0ull : 416ull * 1024);
         k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 0));
         k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
@@ -229,10 +219,6 @@ struct ggrs_world {
     int f_T = -1, f_V = -1, f_L = -1, f_spawn = -1; uint32_t f_tw = 0, f_vw = 0, f_lw = 0;
     bool f_cksT = false, f_cksV = false;
     float f_g[3] = {0, 0, 0};
-    // k_tick3: the schedule is exactly the particles systems over three distinct components, every checksum spec is one the
-    // kernel computes in registers, and the untouched words are at most 16 contiguous 4-byte rows
-    bool tick3_ok = false; Tick3Args tick3_proto{};
-    std::vector<uint32_t> tick3_sched_cols, tick3_rest_cols;   // the 7 schedule-owned columns / the untouched columns in row order
     uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
     uint32_t wg_parts_rows = 0;          // rows (workgroups) d_wg_parts has room for: every grid that uses tick_fold is clamped to it
     uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]

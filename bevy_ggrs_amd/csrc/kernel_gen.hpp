@@ -119,7 +119,7 @@ int hiprtc_build(ggrs_world* w, const std::string& src, const char* what, const 
 }
 
 // ---- the generated request-group kernel ("ggrs_jit_tick") ---------------------------------------------------------------
-// k_tick3 is hand-specialised to the particles world.  For every world the library WRITES the fused kernel at seal -- one
+// For every world the library WRITES the fused kernel at seal -- one
 // slot per lane, every registered word of the slot in a named register, the systems (built-in kinds and the user's sources
 // alike) inlined in registration order, every checksum spec (word lists and user-written hashers) unrolled -- and compiles
 // it with hiprtc.  A wave owns one 64-slot unit (== one 64-bit mask word); two forms of the same body:
@@ -245,7 +245,7 @@ uint64_t jit_hot_cols(const ggrs_world* w) {
 }
 
 // Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
-// back to k_tick3 or to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
+// back to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
 // Player.handle, too many words for the register file / the 64-bit row masks.
 // The per-tile form of a world of ~100 k slots and more folds checksum values through per-lane LDS rows: 64 cells x 8 B per Save and checksummed component
 // (dynamic LDS, sized by the launch), one ds_xor per lane and Save, the rows folded across lanes once per workgroup -- instead of a

@@ -365,348 +365,13 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ k_tick (fused request group)
-// handle_requests (schedule_systems.rs:170-289) receives the WHOLE request list of a ggrs tick at
-// once, and every request of the particles world is tile-local: LoadWorld, SaveWorld's snapshot
-// copy, the per-entity half of the checksum and the GgrsSchedule step only ever touch a slot's own
-// words.  So a run of requests  [Load?] (Save | Advance)*  executes as ONE pass over the tiles:
-//   * the tile's state is read ONCE (from the ring slot being loaded, or from the live block),
-//   * it stays in registers while the ops are replayed in request order -- a Save stores the
-//     registers to its ring slot and emits that frame's checksum partials, an Advance runs
-//     update_particles + despawn_particles on the registers,
-//   * the live block is written ONCE at the end.
-// Compulsory HBM traffic of a SyncTest tick at depth D drops from 1656 B/entity (one kernel per
-// request: every Save re-reads the live block, every Advance re-reads and re-writes it) to
-// 60 (read snapshot) + 60*D (write D snapshots) + 60 (write live) = 600 B at D = 8.  No work is
-// skipped: every snapshot is written in full, every checksum is computed, every frame stepped.
-//
-// Aliasing: a Save's ring slot may be the slot the group was loaded from (ring depth 1); this is
-// safe because every location is read by the lane that later writes it, and all reads of a
-// location precede its first write (pointers are deliberately not __restrict__).
+// ------------------------------------------------------------------ fused request groups
+// handle_requests (schedule_systems.rs:170-289) receives the WHOLE request list of a ggrs tick at once, and every request of a
+// kernel-backed world is slot-local, so a run of requests  [Load?] (Save | Advance)*  executes as ONE pass: the kernel the library
+// writes for the world at seal (kernel_gen.hpp, `ggrs_jit_tick`).  The hand-written kernels of rounds 1-3 (k_tick .. k_tick3) are gone:
+// round 4 measured the generated kernel ahead of k_tick3 in every mode it still served (all 15 rows stored by every Save:
+// 88.5 vs 115.5 us per launch at 1 M, profiles/r04a).  What is left here are the limits of a group's argument block.
 constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
-// Pins a wave-uniform pointer into an SGPR pair so that `sgpr_base(p) + lane_offset_u32` selects the
-// saddr form of global_load/global_store (no 64-bit VALU address arithmetic per access).  The value
-// comes back as an explicit global (address space 1) pointer: laundering a generic pointer through
-// inline asm would otherwise make the compiler fall back to flat_* instructions.
-#define GGRS_GLOBAL __attribute__((address_space(1)))
-typedef GGRS_GLOBAL uint8_t g_u8;
-__device__ __forceinline__ g_u8* sgpr_base(const uint8_t* p) {
-    uint64_t x = reinterpret_cast<uint64_t>(p);
-    asm volatile("" : "+s"(x));
-    return (g_u8*)x;
-}
-
-// 16-byte store to `base + lo` (base wave-uniform, lo a 32-bit lane offset).  The non-temporal form is written
-// as inline asm: __builtin_nontemporal_store on the same expression makes hipcc fall back to a 64-bit VGPR
-// address that it recomputes into ONE register pair before every store, which serialises the whole store
-// burst behind VALU address arithmetic (measured: NT 6 % slower than plain stores; saddr-form NT is faster).
-template <bool NT, class V>
-__device__ __forceinline__ void st16(g_u8* base, uint32_t lo, const V& v) {
-    static_assert(sizeof(V) == 16, "16-byte register tuple");
-    const u32x4 x = reinterpret_cast<const u32x4&>(v);
-    if (NT) {
-        const uint64_t b = reinterpret_cast<uint64_t>(base);
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(lo), "v"(x), "s"(b) : "memory");
-    } else {
-        *(GGRS_GLOBAL u32x4*)(base + lo) = x;
-    }
-}
-__device__ __forceinline__ void st8(g_u8* p, uint64_t v) { *(GGRS_GLOBAL uint64_t*)p = v; }
-
-// Register-resident rows: the 8 schedule-owned rows (translation, velocity, ttl) + up to RESTL untouched rows, which
-// the layout keeps back to back behind them (4-byte words only: rest row j of tile t at rest_off + wtile_off(t) + j * 32 KiB).
-constexpr uint32_t REST_ROW_STRIDE = LAYOUT_TILE * 4u;     // k_tick3: the untouched words are 4-byte words laid out back to back
-struct Tick3Args {
-    const uint8_t* src; uint8_t* live;
-    uint8_t* save_dst[MAX_TICK_SAVES];     // nullptr: ring depth 0, checksum only
-    int32_t save_frame[MAX_TICK_SAVES];
-    uint32_t dt_bits[MAX_TICK_STEPS];
-    uint64_t op_bits;                      // bit i = 1: op i is an Advance, 0: a Save (request order)
-    uint32_t n_ops, n_saves, n_steps, src_is_live;
-    uint64_t len;                          // slots of the source state == RollbackOrdered::len at every Save (a spawn ends the group)
-    uint32_t n_units, ts;                  // 256-slot units to walk (covers every dirty mask word); tile stride
-    uint64_t off_alive, off_pT, off_pV, off_pL, off_t[3], off_v[3], off_ttl, rest_off;
-    float g[3];
-    uint32_t n_rest_rows, n_rest_masks;
-    uint32_t skip_live, pad_sl;            // skip_live: the live block is overwritten before anyone reads it (a LoadGameState follows): do not write it
-    // Row versions (host_world.hpp): a Save only stores the rows whose bytes in the destination block differ from the state
-    // being saved.  sched_store bit k: Save k stores the 8 schedule-owned rows; rest_store[k] bit j: ... untouched row j.
-    // The same for the live block (written once, at the end); rest_load: the untouched rows any of those stores needs.
-    uint32_t sched_store, sched_live;
-    uint32_t rest_store[MAX_TICK_SAVES];
-    uint32_t rest_live, rest_load;
-    uint64_t rest_mask_off[MAX_MASKS];
-    FoldArgs fold;
-};
-static_assert(sizeof(Tick3Args) <= 1024, "keep the kernel argument block small: it is re-sent every tick");
-
-// ------------------------------------------------------------------ k_tick3 (wave-specialised fused request group)
-// k_tick2's remaining cost over the memory system's floor for this traffic (scripts/ubench3.hip: ~95-99 us of stores
-// with no ALU at all vs 112-118 us) is ISSUE COUPLING: a wave that is blocked issuing a store (the TA queue is full
-// 55 % of the time, SQ_WAIT_INST_ANY) cannot hash, and a wave that hashes does not feed the store queue.  So the two
-// jobs get their own waves.  A 512-thread workgroup owns one 1024-slot tile:
-//   * waves 0-3, COMPUTE: keep the 8 schedule-owned rows of their 256-slot quarter in registers, replay the ops, hash;
-//     at every Save they drop the 8 rows (+ the 4 rebuilt liveness words) into LDS and go on hashing / stepping;
-//   * waves 4-7, STORE: keep the 7 untouched rows of the same quarter in registers; per Save they pick the 8 rows up
-//     from LDS and stream all 15 rows (nt) + the mask words to the ring slot, blocking on the store queue as long as
-//     it takes -- nobody is waiting for them but the next barrier.
-// One LDS-only barrier per Save, LDS double-buffered (2 x 32 KiB): compute runs at most one Save ahead.  Two
-// workgroups per CU (64.5 KiB LDS, <= 128 VGPRs): while one workgroup's store waves wait at a barrier the other's keep
-// the queue fed.  ubench3 `fan_spec` (same structure, hash stand-in): 98.7-102.5 us vs 108.9-110.4 us for the uniform
-// kernel at the engine's occupancy.  Checksum fold: tick_fold (as k_tick2).
-// PAIRSYNC 0: one workgroup-wide LDS barrier per hand-off.  PAIRSYNC 1: every compute / store pair has its own two-slot
-// ring guarded by LDS flags -- no coupling between the four pairs of a workgroup, and a store wave frees its slot as
-// soon as the rows are in its registers, i.e. BEFORE it starts issuing the (blocking) global stores.
-// RESTL / EXACT: the store waves keep up to RESTL untouched 4-byte rows in registers; EXACT: the world has exactly RESTL of
-// them (the stress_test: 7) and the row loops are straight-line code, else every row is guarded by `j < n_rest_rows`.
-template <bool CKS_T, bool CKS_V, int RESTL, bool EXACT = true>
-__global__ __launch_bounds__(512, 4) void k_tick3(Tick3Args a) {
-    constexpr bool NT = true;                                            // snapshot stores are non-temporal: written once, read a tick later
-    __shared__ __attribute__((aligned(16))) u32x4 rowbuf[2][4][8][64];   // [parity][quarter][row][lane]: 64 KiB
-    __shared__ uint64_t maskbuf[2][4][4];                                  // the quarter's 4 liveness words per Save
-    __shared__ uint32_t full[4][2];                                        // slot state of pair q (0 free, 1 filled)
-    __shared__ uint64_t acc[MAX_TICK_SAVES * 3];
-    __shared__ uint32_t s_last;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool store_role = wave8 >= 4u;                              // wave-uniform
-    const uint32_t wave = wave8 & 3u;                                 // the quarter both waves of a pair serve
-    if (threadIdx.x < MAX_TICK_SAVES * 3) acc[threadIdx.x] = 0;
-    if (threadIdx.x < 8) full[threadIdx.x >> 1][threadIdx.x & 1u] = 0;
-    __syncthreads();
-    // LDS-only flag traffic of a pair (LDS operations of one wave execute in issue order; the waits are lgkmcnt-only so
-    // that a store wave's global stores stay in flight)
-    auto flag_wait = [&](uint32_t q, uint32_t p, uint32_t want) {
-        for (;;) {
-            const uint32_t v = __hip_atomic_load(&full[q][p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (v == want) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-    };
-    auto flag_set = [&](uint32_t q, uint32_t p, uint32_t v) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): this wave's LDS reads / writes of the slot are done
-        __hip_atomic_store(&full[q][p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    const uint32_t sh = (lane & 15u) * 4;
-    const uint32_t n_tiles = (a.n_units + 3u) >> 2;
-    uint32_t par = 0;                                                 // LDS buffer parity, advances with every hand-off
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t gw = t * 4u + wave;                            // 256-slot unit
-        const uint32_t tid = wave * 64u + lane;                       // lane index inside the tile
-        const bool in_len = (uint64_t)gw * 256u < a.len;              // wave-uniform
-        const uint64_t e0 = (uint64_t)t * TILE + (uint64_t)tid * 4;
-        const uint64_t toff = wtile_off(t, a.ts, 4), toff8 = wtile_off(t, a.ts, 8);
-        const uint32_t o4 = tid * 16u;
-        const uint32_t o8a = wave * 2048u + lane * 16u, o8b = o8a + 1024u;   // contiguous Ttl halves (see k_tick2)
-        const uint32_t w0 = t * 16u + wave * 4u;
-        const uint32_t wi8 = (w0 + (lane >> 4)) * 8u;
-
-        // both roles need the presence words (the store waves write them into every snapshot)
-        const uint64_t pT_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pT + wi8);
-        const uint64_t pV_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pV + wi8);
-        const uint64_t pL_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_pL + wi8);
-
-        if (store_role) {
-            // ================================================= STORE waves
-            u32x4 restv[RESTL > 0 ? RESTL : 1];
-#pragma unroll
-            for (int j = 0; j < RESTL; ++j) {
-                restv[j] = u32x4{0, 0, 0, 0};
-                if (in_len && (EXACT || (uint32_t)j < a.n_rest_rows) && ((a.rest_load >> j) & 1u)) restv[j] = *reinterpret_cast<const u32x4*>(a.src + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE + o4);
-            }
-            if (lane < 4u * a.n_rest_masks) {                         // untouched presence masks: fan out (+ live on load)
-                const uint32_t m = lane >> 2, mw = lane & 3u;
-                const uint64_t o = a.rest_mask_off[m] + ((uint64_t)gw * 4 + mw) * 8;
-                const uint64_t v = *reinterpret_cast<const uint64_t*>(a.src + o);
-                for (uint32_t k = 0; k < a.n_saves; ++k)
-                    if (a.save_dst[k]) *reinterpret_cast<uint64_t*>(a.save_dst[k] + o) = v;
-                if (!a.src_is_live && !a.skip_live) *reinterpret_cast<uint64_t*>(a.live + o) = v;
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);                       // the loads have landed: the op loop stays free of vmcnt waits
-            auto put = [&](uint8_t* dst, bool snapshot, bool with_sched, uint32_t rest_bits, bool with_presence, int32_t frame) {
-                // rows of this quarter: 8 from LDS, RESTL from registers
-                flag_wait(wave, par, 1u);
-                u32x4 h[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) h[r] = rowbuf[par][wave][r][lane];
-                const uint64_t mw = lane < 4 ? maskbuf[par][wave][lane] : 0ULL;
-                flag_set(wave, par, 0u);                               // rows are in registers: the compute wave may refill the slot
-                if (in_len) {
-                    if (snapshot) {
-                        if (with_sched) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { st16<NT>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<NT>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
-                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
-                        st16<NT>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
-                        }
-#pragma unroll
-                        for (int j = 0; j < RESTL; ++j) if ((rest_bits >> j) & 1u) st16<NT>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                    } else {
-                        if (with_sched) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { st16<false>(sgpr_base(dst + a.off_t[k] + toff), o4, h[k]); st16<false>(sgpr_base(dst + a.off_v[k] + toff), o4, h[3 + k]); }
-                        st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8a, h[6]);
-                        st16<false>(sgpr_base(dst + a.off_ttl + toff8), o8b, h[7]);
-                        }
-#pragma unroll
-                        for (int j = 0; j < RESTL; ++j) if ((rest_bits >> j) & 1u) st16<false>(sgpr_base(dst + a.rest_off + toff + (uint32_t)j * REST_ROW_STRIDE), o4, restv[j]);
-                    }
-                }
-                if (lane < 4) st8(sgpr_base(dst + a.off_alive) + (w0 + lane) * 8u, mw);
-                if (with_presence && (lane & 15u) == 0) {
-                    st8(sgpr_base(dst + a.off_pT) + wi8, pT_w);
-                    st8(sgpr_base(dst + a.off_pV) + wi8, pV_w);
-                    st8(sgpr_base(dst + a.off_pL) + wi8, pL_w);
-                }
-                if (snapshot && gw == 0 && lane == 0) {
-                    Header hd; hd.len = a.len; hd.frame = frame; hd.pad0 = 0; hd.active = 0; hd.checksum[0] = 0; hd.checksum[1] = 0;
-                    *reinterpret_cast<Header*>(dst) = hd;
-                }
-            };
-            uint32_t si = 0;
-            for (uint32_t i = 0; i < a.n_ops; ++i) {
-                if ((a.op_bits >> i) & 1ULL) continue;                // Advance: nothing to store
-                uint8_t* dst = a.save_dst[si];
-                if (dst) { put(dst, true, (a.sched_store >> si) & 1u, a.rest_store[si], true, a.save_frame[si]); par ^= 1u; }
-                ++si;
-            }
-            if ((!a.src_is_live || a.n_steps) && !a.skip_live) { put(a.live, false, a.sched_live != 0, a.rest_live, !a.src_is_live, 0); par ^= 1u; }
-        } else {
-            // ================================================= COMPUTE waves
-            const uint64_t alive_w = *reinterpret_cast<const uint64_t*>(a.src + a.off_alive + wi8);
-            float4 tx[3], vv[3];
-            ulonglong2 tl[2];
-            auto ld16 = [&](const uint8_t* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
-            if (in_len) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_t[k] + toff + o4); tx[k] = reinterpret_cast<const float4&>(x); }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const u32x4 x = ld16(a.src + a.off_v[k] + toff + o4); vv[k] = reinterpret_cast<const float4&>(x); }
-                { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8a); tl[0] = reinterpret_cast<const ulonglong2&>(x); }
-                { const u32x4 x = ld16(a.src + a.off_ttl + toff8 + o8b); tl[1] = reinterpret_cast<const ulonglong2&>(x); }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { tx[k] = make_float4(0, 0, 0, 0); vv[k] = make_float4(0, 0, 0, 0); }
-                tl[0] = make_ulonglong2(0, 0); tl[1] = make_ulonglong2(0, 0);
-            }
-            uint32_t alive4 = (uint32_t)(alive_w >> sh) & 0xFu;
-            const uint32_t n_T = (uint32_t)(pT_w >> sh) & 0xFu, n_V = (uint32_t)(pV_w >> sh) & 0xFu;
-            auto word_of = [&](uint64_t v, int k) -> uint64_t {
-                return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * k);
-            };
-            const uint32_t shL = 2u * (lane & 31u);
-            auto l_bits = [&](uint64_t v) -> uint32_t {
-                const uint64_t lo = lane < 32 ? word_of(v, 0) : word_of(v, 1), hi = lane < 32 ? word_of(v, 2) : word_of(v, 3);
-                return ((uint32_t)(lo >> shL) & 3u) | (((uint32_t)(hi >> shL) & 3u) << 2);
-            };
-            uint32_t aliveL = l_bits(alive_w);
-            const uint32_t presL = l_bits(pL_w);
-            uint64_t ordB[4];
-            if (CKS_T || CKS_V) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ordB[j] = sea_order_lane(e0 + j);
-            }
-            auto chainT = [&](int j) -> uint64_t {
-                const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&tx[0])[j]),
-                                                                    __float_as_uint(reinterpret_cast<float*>(&tx[1])[j]),
-                                                                    __float_as_uint(reinterpret_cast<float*>(&tx[2])[j])));
-                return (((alive4 & n_T) >> j) & 1u) ? h : 0ULL;
-            };
-            auto chainV = [&](int j) -> uint64_t {
-                const uint64_t h = sea_pair_pre(ordB[j], sea_inner3(__float_as_uint(reinterpret_cast<float*>(&vv[0])[j]),
-                                                                    __float_as_uint(reinterpret_cast<float*>(&vv[1])[j]),
-                                                                    __float_as_uint(reinterpret_cast<float*>(&vv[2])[j])));
-                return (((alive4 & n_V) >> j) & 1u) ? h : 0ULL;
-            };
-            // the quarter's rows + rebuilt liveness words -> LDS[par]; the barrier hands them to the paired store wave
-            auto hand_off = [&]() {
-                flag_wait(wave, par, 0u);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { rowbuf[par][wave][k][lane] = reinterpret_cast<const u32x4&>(tx[k]); rowbuf[par][wave][3 + k][lane] = reinterpret_cast<const u32x4&>(vv[k]); }
-                rowbuf[par][wave][6][lane] = reinterpret_cast<const u32x4&>(tl[0]);
-                rowbuf[par][wave][7][lane] = reinterpret_cast<const u32x4&>(tl[1]);
-                const uint64_t b0 = __ballot((alive4 >> 0) & 1u), b1 = __ballot((alive4 >> 1) & 1u),
-                               b2 = __ballot((alive4 >> 2) & 1u), b3 = __ballot((alive4 >> 3) & 1u);
-                uint64_t mine = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint64_t nw = spread4(b0 >> (16 * w)) | (spread4(b1 >> (16 * w)) << 1) |
-                                        (spread4(b2 >> (16 * w)) << 2) | (spread4(b3 >> (16 * w)) << 3);
-                    if (lane == (uint32_t)w) mine = nw;
-                }
-                if (lane < 4) maskbuf[par][wave][lane] = mine;
-                flag_set(wave, par, 1u);
-                par ^= 1u;
-                return (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-            };
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-
-            uint32_t si = 0, sj = 0;
-            for (uint32_t i = 0; i < a.n_ops; ++i) {
-                if (!((a.op_bits >> i) & 1ULL)) {
-                    // ---------------- SaveWorld: hand the rows to the store wave, then hash them
-                    uint32_t cnt;
-                    if (a.save_dst[si]) cnt = hand_off();
-                    else cnt = (uint32_t)(__popcll(__ballot((alive4 >> 0) & 1u)) + __popcll(__ballot((alive4 >> 1) & 1u)) +
-                                          __popcll(__ballot((alive4 >> 2) & 1u)) + __popcll(__ballot((alive4 >> 3) & 1u)));
-                    uint64_t hT = 0, hV = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { if (CKS_T) hT ^= chainT(j); if (CKS_V) hV ^= chainV(j); }
-                    if (CKS_T) hT = wave_xor(hT);
-                    if (CKS_V) hV = wave_xor(hV);
-                    if (lane == 0) {
-                        if (CKS_T) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 0]), (unsigned long long)hT);
-                        if (CKS_V) atomicXor(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 1]), (unsigned long long)hV);
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[si * 3 + 2]), (unsigned long long)cnt);
-                    }
-                    ++si;
-                } else {
-                    // ---------------- AdvanceWorld: update_particles + despawn_particles (particles.rs:272-289)
-                    const float dt = __uint_as_float(a.dt_bits[sj]);
-                    ++sj;
-                    const uint32_t m_upd = alive4 & n_T & n_V;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float gd = __fmul_rn(a.g[k], dt);
-                        float* x = reinterpret_cast<float*>(&tx[k]);
-                        float* v = reinterpret_cast<float*>(&vv[k]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool on = (m_upd >> j) & 1u;
-                            const float nv = __fadd_rn(v[j], gd);
-                            const float nx = __fadd_rn(x[j], __fmul_rn(nv, dt));
-                            v[j] = on ? nv : v[j];
-                            x[j] = on ? nx : x[j];
-                        }
-                    }
-                    const uint32_t m_ttl = aliveL & presL;
-                    uint32_t killL = 0;
-                    uint64_t* q = reinterpret_cast<uint64_t*>(&tl[0]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool on = (m_ttl >> j) & 1u;
-                        const uint64_t nq = q[j] - 1;
-                        q[j] = on ? nq : q[j];
-                        killL |= (on && nq == 0) ? (1u << j) : 0u;
-                    }
-                    aliveL &= ~killL;
-                    const uint64_t k0 = __ballot((killL >> 0) & 1u), k1 = __ballot((killL >> 1) & 1u),
-                                   k2 = __ballot((killL >> 2) & 1u), k3 = __ballot((killL >> 3) & 1u);
-                    if ((k0 | k1 | k2 | k3) != 0) {
-                        const uint64_t ka = lane < 32 ? k0 : k2, kb = lane < 32 ? k1 : k3;
-                        const uint32_t pa = (uint32_t)(ka >> shL) & 3u, pb = (uint32_t)(kb >> shL) & 3u;
-                        alive4 &= ~((pa & 1u) | ((pb & 1u) << 1) | ((pa >> 1) << 2) | ((pb >> 1) << 3));
-                    }
-                }
-            }
-            if ((!a.src_is_live || a.n_steps) && !a.skip_live) (void)hand_off();        // the live block, written once (by the store wave)
-        }
-    }
-    tick_fold<512>(a.fold, a.n_saves, a.len, acc, &s_last);
-}
 
 constexpr int FIN_TPB = 1024;
 constexpr int GEN_MAX_CKS = 16;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """gpurun_out/<tag> (scratch) -> profiles/<tag> (committed): the small files of scripts/gpu_round2.sh plus the rocprofv3
-summaries of the two profiled commands (bench.py = k_tick3; tick_bench under GGRS_TICK_GENERIC=1 = the generated kernel).
+summaries of the profiled bench command (dominant kernel: ggrs_jit_tick).
 
 usage: collect_round.py <tag>"""
 import collections, csv, glob, json, os, shutil, subprocess, sys

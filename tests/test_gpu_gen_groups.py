@@ -144,7 +144,7 @@ def test_long_request_lists_split_into_groups():
 
 @pytest.mark.parametrize("n", [450_000, 1_100_000])
 def test_hbm_sized_generic_world_on_the_generated_kernel(n):
-    """A world k_tick3 does not cover (an extra system, an extra checksum spec, a fourth component) at HBM size: the default
+    """A world beyond the stress_test schema (an extra system, an extra checksum spec, a fourth component) at HBM size: the default
     dispatch runs the kernel generated for it (one slot per lane, non-temporal snapshot stores above 416 k slots, no
     depth-parallel roles at this size) -- against the oracle, depth-8 SyncTest with despawns."""
     cd, ticks = 8, 11

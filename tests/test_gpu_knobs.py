@@ -1,8 +1,8 @@
 """Every environment knob the library reads (csrc/host_world.hpp `Knobs`) selects among kernels / policies that must all
 produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU oracle under each setting, so the
-driver-run suite covers every kernel that ships -- k_tick3 at every size, the generated kernel in its per-tile and
-persistent forms with the fold on the host / in k_gen_finalize / in the launch, with and without depth-parallel roles,
-dead-snapshot elimination and row versions, on paged and contiguous arenas.  (Two knobs have no case: GGRS_ARENA_PARK=0
+driver-run suite covers every kernel that ships -- the generated kernel in its per-tile and persistent forms with the fold
+on the host / in k_gen_finalize / in the launch (tick_fold) / per group of 64 workgroups, with and without depth-parallel
+roles, dead-snapshot elimination and row versions, the per-request kernels (no run-time compiler), on paged and contiguous arenas.  (Two knobs have no case: GGRS_ARENA_PARK=0
 re-enables the runtime hazard of profiles/r03fc and exists for that experiment only; GGRS_HIP_ROCTX=1 needs the roctx library of a
 profiler session.)"""
 import numpy as np
@@ -16,18 +16,16 @@ pytestmark = pytest.mark.gpu
 
 KNOBS = [
     {},                                                     # the defaults
-    {"GGRS_TICK_GENERIC": "1"},                             # particles on the generated kernel at every size
-    {"GGRS_TICK_JIT": "0"},                                 # no generated kernel: k_tick3 at every size
-    {"GGRS_JIT_PARTICLES_MAX_SLOTS": "0"},                  # k_tick3 even for small worlds (a generated kernel exists)
-    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "0"},     # generated kernel, never persistent (k_gen_finalize launch for big worlds)
-    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1"},     # generated kernel, persistent form + in-launch fold even for small worlds
+    {"GGRS_TICK_JIT": "0"},                                 # no generated kernel (a deployment without libhiprtc.so): one launch per request
+    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1"},                    # generated kernel, persistent form + in-launch fold even for small worlds
     {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # every group folded on the device (k_gen_finalize)
     {"GGRS_HOST_FOLD_MAX_WGS": "256"},                      # only small groups folded by the host (the round-2 default)
     {"GGRS_GROUP_FOLD_MIN_WGS": "0"},                       # no group fold: one row per workgroup leaves the kernel at every size
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0"},   # group fold even for the 10 k world (one group of 56 workgroups incl. a padding one)
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0", "GGRS_HOST_FOLD_MAX_WGS": "0"},   # ... with the groups' rows staying on the device (k_gen_finalize over rows / 64)
     {"GGRS_DEAD_GROUPS": "0"},
-    {"GGRS_TICK_GENERIC": "1", "GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
+    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
+    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "64", "GGRS_JIT_PERSIST_TPB": "256"},  # ... and one whose grid must be clamped to tick_fold's row buffer
     {"GGRS_JIT_DP_MAX_SLOTS": "400000"},                    # depth-parallel roles far above their default range
     {"GGRS_HIP_TRACE": "1", "GGRS_DEBUG_JIT": "1", "GGRS_DEBUG_ARENA": "1"},   # the diagnostic prints change nothing
     {"GGRS_JIT_DP": "0"},
@@ -92,8 +90,7 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     cm.assert_states_equal(got[1], _ORACLE[n][1], f"{env} n={n}")
     # the knob actually selected what it names
     k = info["request_group_kernel"]
-    if env.get("GGRS_TICK_JIT") == "0" or env.get("GGRS_JIT_PARTICLES_MAX_SLOTS") == "0": assert k.startswith("k_tick3"), k
-    if env.get("GGRS_TICK_GENERIC") == "1": assert k.startswith("ggrs_jit_tick"), k
+    if env.get("GGRS_TICK_JIT") == "0": assert k.startswith("per-request"), k
     if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
     if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
     if not env: assert info["checksum_fold"].startswith("the host folds"), info           # (the group fold's default range starts at 12288 workgroups: test_group_fold_default_range)
@@ -101,12 +98,12 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
     if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
     if env.get("GGRS_ARENA_CONTIG") == "0": assert info["arena"].startswith("paged"), info
-    if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("k_tick3" if n > 416 * 1024 else "ggrs_jit_tick"), k
+    if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("ggrs_jit_tick"), k
 
 
 def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
-    """GGRS_TICK_JIT=0 stands in for a deployment without libhiprtc.so: the particles world still runs fused (k_tick3), a world
-    only the generated kernel would fuse falls back to one launch per request, and ggrs_hip_world_kernel_info says so."""
+    """GGRS_TICK_JIT=0 stands in for a deployment without libhiprtc.so: every world falls back to one launch per request (the particles
+    schedule with its fused step kernel), and ggrs_hip_world_kernel_info says so."""
     monkeypatch.setenv("GGRS_TICK_JIT", "0")
     res = []
     for w in (bg.World(3000, max_depth=9), OracleWorld(3000, 9, FLAT)):

@@ -136,10 +136,10 @@ def test_errors_match_reference_panics():
 @pytest.mark.parametrize("n,ticks", [(300_000, 12), (600_000, 12), (1_000_000, 12), (4_000_000, 11)])
 @pytest.mark.parametrize("ttl_mode", ["despawn"])
 def test_headline_depth8_matches_oracle(n, ticks, ttl_mode):
-    """BASELINE config 3 at its own size (and the sizes either side of every k_tick dispatch tier: k_tick1 <= 400 k slots,
-    single-wave k_tick <= 800 k, 4-wave k_tick above -- ggrs_hip.hip TICK_VEC1_MAX_SLOTS / TICK_WAVE_WG_MAX_SLOTS), DEFAULT
-    dispatch, SyncTest check distance 8 with max_prediction 9: every Save's Checksum(u128) == the oracle's
-    (component_checksum.rs:67-108, tests/synctest.rs:84-125) and the final live state is byte-equal."""
+    """BASELINE config 3 at its own size and the sizes either side of the generated kernel's policy thresholds (host_groups.hpp:
+    cached vs non-temporal snapshot stores at 416 k slots, the first Save through the L2 up to 80 MB of rows, the on-chip group fold
+    from 12288 workgroups = 3 M slots), DEFAULT dispatch, SyncTest check distance 8 with max_prediction 9: every Save's
+    Checksum(u128) == the oracle's (component_checksum.rs:67-108, tests/synctest.rs:84-125) and the final live state is byte-equal."""
     from oracle.binding import lib as olib
     import os
     olib.gor_set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
@@ -358,16 +358,16 @@ def test_particles_systems_over_live_only_components_are_rejected():
 
 
 @pytest.mark.parametrize("n,flags", [(30_000, 0), (700_000, 0), (3000, bg.GGRS_WORLD_NO_GROUPS)])
-@pytest.mark.parametrize("generic", [False, True])
-def test_branch_lists_dead_snapshots_and_batches(n, flags, generic, monkeypatch):
+@pytest.mark.parametrize("per_request", [False, True])
+def test_branch_lists_dead_snapshots_and_batches(n, flags, per_request, monkeypatch):
     """A request list holding several speculative branches off one snapshot ([Load(C), Adv, Save, ...] x B): every branch
     but the last leaves nothing behind but its checksums (the next Load pops its snapshots, mod.rs:210-226), so the
     library runs it checksum-only and launches identical branches together.  Must equal the oracle executing the same
     list request by request -- checksums of every branch, ring content and live state -- also when the next Load
     targets a frame INSIDE the group's saves (not dead) and when a branch spawns (never dead)."""
-    if generic:
-        monkeypatch.setenv("GGRS_TICK_GENERIC", "1")
-        if n > 100_000: pytest.skip("one big size is enough for the generic kernel")
+    if per_request:                                            # the same lists without the run-time compiler: one launch per request, nothing eliminated
+        monkeypatch.setenv("GGRS_TICK_JIT", "0")
+        if n > 100_000: pytest.skip("one big size is enough for the per-request path")
     D, B = 4, 6
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     fn = cm.frame_spawn_fn(60)
@@ -410,13 +410,13 @@ def test_branch_lists_dead_snapshots_and_batches(n, flags, generic, monkeypatch)
 
 
 @pytest.mark.parametrize("n", [1000, 250, 8100])
-@pytest.mark.parametrize("generic", [False, True])
-def test_dead_branches_keep_dirty_extents(n, generic, monkeypatch):
+@pytest.mark.parametrize("per_request", [False, True])
+def test_dead_branches_keep_dirty_extents(n, per_request, monkeypatch):
     """a checksum-only (dead) branch writes neither its ring slots nor the live block, so it must not lower
     their dirty extents.  A spawning branch first grows the live world past a 256- / 1024- / 8192-slot boundary, dead branches
     follow off the OLD confirmed frame, the last branch is alive, and then spawns grow len back across the boundary: stale
     liveness bits left above the lowered extent would come back as ghost entities (wrong count, wrong checksum)."""
-    if generic: monkeypatch.setenv("GGRS_TICK_GENERIC", "1")
+    if per_request: monkeypatch.setenv("GGRS_TICK_JIT", "0")
     D = 4
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     fn = cm.frame_spawn_fn(90)
@@ -460,9 +460,8 @@ def test_dead_branches_keep_dirty_extents(n, generic, monkeypatch):
 
 @pytest.mark.parametrize("extra_words,n", [(5, 700_000), (9, 600_000), (12, 650_000)])
 def test_big_world_with_extra_untouched_components(extra_words, n):
-    """The stress_test world plus a component the schedule never touches (7 + extra_words untouched rows): up to 16 such rows
-    stay on the wave-specialised k_tick3 (its store waves carry them), more fall back to k_tick -- either way every Save
-    equals the oracle's and the extra columns survive rollbacks byte for byte."""
+    """The stress_test world plus a component the schedule never touches (7 + extra_words untouched rows, which row versions store
+    once per ring slot): every Save equals the oracle's and the extra columns survive rollbacks byte for byte."""
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     rng = np.random.default_rng(17)
     extra = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for _ in range(extra_words)]
