@@ -511,6 +511,8 @@ def main():
                          "components with every column written every frame (+ increase_component over rotation / scale): every Save moves all 15 rows")
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (RCCL broadcast + all-gather inside the library) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
+    ap.add_argument("--no-share-prefix", action="store_true", help="fan-out A/B: every branch replays [Load(C), Advance(confirmed input), Save(C+1)] itself "
+                    "(the round-3 request lists) instead of starting from the ONE saved C+1")
     ap.add_argument("--parity-steps", type=int, default=-1, help="N > 1 / --fanout: timed steps whose gathered checksum table rank 0 replays on the CPU oracle "
                     "(every branch of every rank); default: about 16 branch walks in all, at least one step")
     ap.add_argument("--control-backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend of the control plane (unique id, barrier, max over "
@@ -635,7 +637,8 @@ def main():
         c_rank, comm_size, c_dev = native.comm_info()        # what the communicator says, not what the environment says
         assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
         fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
-                                desync_detection_interval=10 if args.branches == 1 else 1)   # the reference stress_test's default (particles.rs:49, README.md:84)
+                                desync_detection_interval=10 if args.branches == 1 else 1,   # the reference stress_test's default (particles.rs:49, README.md:84)
+                                share_prefix=not args.no_share_prefix)
         fan.sync_confirmed(0)
         gc.collect(); gc.disable()                           # see measure_single
         for _ in range(W):
@@ -791,8 +794,10 @@ def main():
         line["roofline_alu"] = {"bound": "valu-int (u64 multiply)", "achieved": diffuses / secs / 1e9, "unit": "G diffuse/s",
                                 "peak": (ceil or {}).get("diffuse_G_per_s"), "frac": (diffuses / secs / 1e9 / ceil["diffuse_G_per_s"]) if ceil else None,
                                 "peak_source": (ceil or {}).get("source"),
-                                "note": "algorithmic diffuses (6 per entity per checksummed component per SaveWorld, 2 components); the kernel hoists the order hash "
-                                        "and memoises unchanged tails, so it executes fewer"}
+                                "shared_prefix": not args.no_share_prefix,
+                                "note": "algorithmic diffuses: 6 per entity per checksummed component per SaveWorld, 2 components, D SaveWorlds per branch -- every branch's D "
+                                        "Checksum(u128)s are delivered.  The kernel hoists the order hash and memoises unchanged tails, and the step computes the "
+                                        "branch-invariant Save(C+1) once per rank instead of once per branch (shared_prefix), so fewer are executed"}
     if not distributed:
         line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us")}
     parity_failed = False

@@ -130,7 +130,6 @@ bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, ui
 // the generated kernel
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint64_t JIT_NT_MIN_SLOTS = 416 * 1024;      // snapshot stores of bigger groups are non-temporal: written once, read a tick later, and the ring does not fit the Infinity Cache
-constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20;   // the first Save of an HBM-sized rollback group goes through the L2 while its rows are this small
 constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-only groups ride in one launch while the world is this small
 // grid of the per-tile form: 8 x ceil(tiles / 8) workgroups, mapped to tiles XCD by XCD inside the kernel (kernel_gen.hpp)
 inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
@@ -303,7 +302,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         // per depth-8 tick at 1 M in the ring-walking harness (profiles/r03n), every other row still streams past the caches.
         // Past ~2.5 M particles the rows no longer survive in the caches until the next launch and only displace the stream (4 M: +3 %).
         j.cached_saves = (j.nt && w->knobs.jit_cache_first_save && !j.src_is_live && j.n_saves >= 2 &&
-                          rows_bytes_per_slot(w, j.save_rows[0]) * cover <= JIT_CACHED_SAVE_MAX_BYTES) ? 1u : 0u;
+                          rows_bytes_per_slot(w, j.save_rows[0]) * cover <= w->knobs.jit_cached_save_max_bytes) ? 1u : 0u;
         const bool launch = j.n_ops || !j.src_is_live;
 
         if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {

@@ -74,6 +74,8 @@ struct Knobs {
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
                                         //                       the snapshot the next rollback loads, goes through the L2)
+    uint64_t jit_cached_save_max_bytes = 80ull << 20;   // GGRS_JIT_CACHED_SAVE_MAX_MB=n  ... while that Save's rows are at most this many MiB (default 80: beyond, the rows no longer
+                                        //                       survive in the caches until the next launch reads them, profiles/r03n)
     bool arena_park = true;        // GGRS_ARENA_PARK=0     hipFree contiguous arenas when their world closes (the hazard above; experiments only)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     std::string jit_cache_dir;     // GGRS_JIT_CACHE_DIR    code objects of generated kernels on disk ("" = ~/.cache/ggrs_hip; "0": no disk cache)
@@ -100,6 +102,7 @@ struct Knobs {
         k.event_on_kernel = num("GGRS_EVENT_ON_KERNEL", 1) != 0;
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
+        k.jit_cached_save_max_bytes = (uint64_t)std::max<long long>(0, num("GGRS_JIT_CACHED_SAVE_MAX_MB", 80)) << 20;
         k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;
         k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;

@@ -10,16 +10,16 @@ per GPU (torch.distributed, backend "nccl" == RCCL over xGMI):
                      include/ggrs_hip.h `ggrs_hip_live_state_ptr`) -- ONE RCCL broadcast.  xGMI is
                      point-to-point, so this costs ~state_bytes / per-link bandwidth; it is done at
                      start-up and after a detected desync, NOT every step.
-  step()             the true input of the confirmed frame C has arrived.  Every rank, for each of
-                     its branches b, runs ONE request list of the same shape as a rollback tick
-                       [Load(C), Advance(confirmed input), Save(C+1),
-                        (Advance(predicted input of branch b), Save(C+1+i)) x (D-1), Advance(predicted)]
-                     = 1 LoadWorld + D SaveWorld + (D+1) AdvanceWorld: ONE fused launch per branch.
+  step()             the true input of the confirmed frame C has arrived.  Every rank runs ONE request list:
+                       [Load(C), Advance(confirmed input), Save(C+1)]                      once -- the prefix every branch shares
+                       [Load(C+1), (Advance(predicted input of branch b), Save(C+1+i)) x (D-1), Advance(predicted)]   per branch b
                      Frame C+1 is the new confirmed frame -- rollback netcode's determinism keeps it
                      bit-identical on every rank, so moving the 1-byte input replaces re-broadcasting
-                     60 B/entity -- and frames C+2.. are the branch's speculative future.  ONE
-                     all-gather carries every branch's D Checksum(u128)s; the C+1 entries double as
-                     cross-rank desync detection (GgrsEvent::DesyncDetected analogue).
+                     60 B/entity -- and frames C+2.. are the branch's speculative future.  A branch's D
+                     Checksum(u128)s are the shared C+1 entry followed by its own D-1; ONE all-gather carries
+                     them, and the C+1 entries double as cross-rank desync detection (GgrsEvent::DesyncDetected
+                     analogue).  (share_prefix=False: every branch replays Load(C), Advance, Save(C+1) itself --
+                     1/D of the hashing done B times over, the round-3 shape.)
   step_pipelined()   the same, with one step in flight: step k+1 is enqueued on the device
                      (ggrs_hip_enqueue_requests) before step k's checksums are collected and
                      all-gathered on a side stream, so the collective and the host work overlap
@@ -257,7 +257,8 @@ class SpeculativeFanout:
                  branch_input: Callable[[int, int], int] = default_branch_input,
                  confirmed_input: Callable[[int], int] = lambda frame: 0,
                  spawn_fn: Optional[Callable[[int], tuple]] = None, spawn_mask: int = 1 << 4,
-                 num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1, native: "Optional[RcclFanout]" = None):
+                 num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1, native: "Optional[RcclFanout]" = None,
+                 share_prefix: bool = True):
         self.w, self.dist, self.D, self.x = world, dist, depth, exchange
         self.native = native                                 # collectives inside libggrs_hip.so instead of torch.distributed (`exchange` unused)
         self.interval = max(1, desync_detection_interval)    # steps whose checksums share one all-gather (pipelined path)
@@ -267,6 +268,9 @@ class SpeculativeFanout:
         self.max_inflight = max_inflight                     # steps enqueued on the device before the oldest is collected
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.bpr = branches_per_rank
+        self.share_prefix = bool(share_prefix) and depth >= 1
+        # SaveGameState requests of one step's list on this rank == Checksum(u128)s it contributes to the all-gather
+        self.saves_per_step = 1 + branches_per_rank * (depth - 1) if self.share_prefix else branches_per_rank * depth
         self.branch_input, self.confirmed_input = branch_input, confirmed_input
         self.spawn_fn, self.spawn_mask = spawn_fn, spawn_mask
         self.num_players = num_players
@@ -311,6 +315,16 @@ class SpeculativeFanout:
         D = self.D
         c_in = self.confirmed_input(C)
         reqs: list = []
+        if self.share_prefix:
+            # the branch-invariant prefix, once: the confirmed input takes frame C to C+1 and C+1 is saved -- it is what every branch
+            # starts from AND the snapshot the next step loads
+            reqs += [LoadGameState(C), self._advance(C, c_in), SaveGameState(C + 1)]
+            for b in self.branch_ids():
+                reqs.append(LoadGameState(C + 1))
+                for i in range(1, D):
+                    reqs += [self._advance(C + i, self.branch_input(b, C + i)), SaveGameState(C + 1 + i)]
+                reqs.append(self._advance(C + D, self.branch_input(b, C + D)))  # the newest predicted frame stays live-only
+            return reqs
         for b in self.branch_ids():
             reqs += [LoadGameState(C), self._advance(C, c_in), SaveGameState(C + 1)]
             for i in range(1, D):
@@ -318,9 +332,19 @@ class SpeculativeFanout:
             reqs.append(self._advance(C + D, self.branch_input(b, C + D)))      # the newest predicted frame stays live-only
         return reqs
 
+    def _expand(self, allv: np.ndarray) -> np.ndarray:
+        """What the ranks gathered -> the canonical table (size, bpr * D, 2): every branch's D checksums, C+1 first."""
+        D, bpr = self.D, self.bpr
+        if not self.share_prefix:
+            return allv.reshape(self.size, max(bpr * D, 1), 2)
+        a = allv.reshape(self.size, self.saves_per_step, 2)
+        conf = np.broadcast_to(a[:, 0:1][:, None], (self.size, bpr, 1, 2))
+        own = a[:, 1:].reshape(self.size, bpr, D - 1, 2)
+        return np.ascontiguousarray(np.concatenate([conf, own], axis=2)).reshape(self.size, bpr * D, 2)
+
     def _check(self, C: int, allv: np.ndarray, want_result: bool = True) -> Optional[dict]:
         D, n = self.D, self.bpr * self.D
-        allv = allv.reshape(self.size, max(n, 1), 2)
+        allv = self._expand(allv)
         conf = allv[:, 0:n:D, :].reshape(-1, 2)              # the C+1 entry of every branch of every rank
         if (conf != conf[0]).any():
             self.synced = False                              # caller may sync_confirmed() again
@@ -402,7 +426,7 @@ class SpeculativeFanout:
         import ctypes as C_
         reqs = self._requests(0)
         arr, keep, n_save = self.w.build_requests(reqs)
-        loads = [i for i, r in enumerate(reqs) if isinstance(r, LoadGameState)]
+        loads = [(i, r.frame) for i, r in enumerate(reqs) if isinstance(r, LoadGameState)]
         saves = [(i, r.frame) for i, r in enumerate(reqs) if isinstance(r, SaveGameState)]
         advs = [i for i, r in enumerate(reqs) if isinstance(r, AdvanceFrame)]
         out = (C_.c_uint64 * (2 * max(n_save, 1)))()
@@ -411,14 +435,17 @@ class SpeculativeFanout:
 
     def _patch(self, t, C: int):
         arr, D = t["arr"], self.D
-        for i in t["loads"]:
-            arr[i].frame = C
+        for i, rel in t["loads"]:
+            arr[i].frame = C + rel
         for i, rel in t["saves"]:
             arr[i].frame = C + rel
-        per_branch = D + 1
         c_in = self.confirmed_input(C)
         ids = self.branch_ids()
-        inputs = [c_in if k % per_branch == 0 else self.branch_input(ids[k // per_branch], C + k % per_branch) for k in range(len(t["advs"]))]
+        if self.share_prefix:                                # advance 0: the confirmed input; then D predicted ones per branch (frames C+1 .. C+D)
+            inputs = [c_in] + [self.branch_input(ids[(k - 1) // D], C + 1 + (k - 1) % D) for k in range(1, len(t["advs"]))]
+        else:
+            per_branch = D + 1
+            inputs = [c_in if k % per_branch == 0 else self.branch_input(ids[k // per_branch], C + k % per_branch) for k in range(len(t["advs"]))]
         if inputs == t.get("inputs"):                        # the usual case: predictions repeat, nothing to rewrite
             return
         t["inputs"] = inputs
@@ -436,7 +463,7 @@ class SpeculativeFanout:
             self._native_enqueue()
             # keep one whole all-gather group (+ max_inflight steps) in flight: the host never waits for a collective it has just issued
             return self._native_collect(want_result) if len(self._inflight) >= self.interval + self.max_inflight else None
-        if self.bpr * self.D > 256 or not hasattr(self.w, "enqueue_requests_raw"):
+        if self.saves_per_step > 256 or not hasattr(self.w, "enqueue_requests_raw"):
             return self.step(want_result)
         C = self.confirmed
         self.w.set_confirmed(C)
@@ -479,7 +506,7 @@ class SpeculativeFanout:
         if self.native is not None:
             return self._native_collect(want_result)
         C = self._inflight.pop(0)
-        n = self.bpr * self.D
+        n = self.saves_per_step
         if self._tmpl is not None:
             self.w.collect_checksums_raw(self._tmpl["out"], n)
             return self._finish(C, self._tmpl["out_np"][:max(n, 1)].copy(), want_result, defer=True)

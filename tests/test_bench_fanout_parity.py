@@ -53,3 +53,25 @@ def test_parity_gate_accepts_the_serial_walk_and_names_a_flipped_bit():
     # a table that starts at the wrong confirmed frame is refused, not compared
     par = bench.fanout_parity(n, D, c_timed + 1, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2)
     assert par["equal"] is False and "confirmed frame" in par["first_mismatch"]["why"], par
+
+
+def test_shared_prefix_and_per_branch_prefix_gather_the_same_table():
+    """SpeculativeFanout(share_prefix=True) computes [Load(C), Advance(confirmed), Save(C+1)] once per step instead of once per branch; the
+    canonical table (every branch's D checksums, C+1 first) and the confirmed state must not change -- with spawning inputs too."""
+    n, D, bpr, steps = 1500, 4, 3, 5
+    out = []
+    for share in (True, False):
+        w = OracleWorld(n + 100 * (steps + D + 2) * 2, D + 1, FLAT)
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        fan = SpeculativeFanout(w, _OneRank(), D, _NoExchange(), branches_per_rank=bpr, share_prefix=share,
+                                branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
+                                confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0, spawn_fn=cm.frame_spawn_fn(50))
+        assert fan.saves_per_step == (1 + bpr * (D - 1) if share else bpr * D)
+        fan.raw_keep = steps
+        res = [fan.step() for _ in range(steps)]
+        fan.settle()
+        out.append((res, [(c, t.tolist()) for c, t in fan.raw], cm.snapshot_state(w, ids)))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    cm.assert_states_equal(out[0][2], out[1][2], "share_prefix")
