@@ -260,6 +260,16 @@ int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, ui
     if (compile) { hipFunction_t fn = nullptr; return hiprtc_build(w, src, "generated request-group kernel", "ggrs_jit_tick", nullptr, &fn); }
     return GGRS_OK;
 }
+// Test hook (not part of the C ABI: no ggrs_hip_ prefix, not in include/ggrs_hip.h): the specialiser's token rule on arbitrary text --
+// tests/test_generated_kernel.py feeds it identifiers no generator emits yet.  Returns the number of replacements, -1 when `out` is too small.
+int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, char* out, uint64_t cap) {
+    if (!body || !tok || !val || !out || !*tok) return -1;
+    std::string b = body;
+    const uint32_t n = jit_replace_token(b, tok, val);
+    if (b.size() + 1 > cap) return -1;
+    memcpy(out, b.c_str(), b.size() + 1);
+    return (int)n;
+}
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
 
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {

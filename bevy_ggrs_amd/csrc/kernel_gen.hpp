@@ -765,21 +765,50 @@ void jit_release(JitEntry* e) {
 // shape's fields as literals and the op loop unrolled the compiler drops the walk, the role / mask / policy tests (about 40 % of
 // the scalar instructions) and a third of the registers: 59.3 -> 53.8 us per depth-8 tick at 1 M (profiles/r03n).  The text is the
 // generic kernel's with the argument fields replaced -- same body, same argument block, same launch.
+// A field of the argument block as a TOKEN of the generated text: `a.<name>` not preceded by an identifier character or a dot (no
+// `data.nt`) and not followed by one (no `a.nt_x`, no `a.n_saves2`) -- a replace keyed on spellings alone would rewrite the inside of a longer
+// identifier the day a field `a.nt_x` appears (What's weak 9).
+inline bool jit_ident_char(char c) { return isalnum((unsigned char)c) || c == '_'; }
+size_t jit_find_token(const std::string& body, const std::string& tok, size_t from) {
+    for (size_t p = body.find(tok, from); p != std::string::npos; p = body.find(tok, p + 1)) {
+        const bool left_ok = p == 0 || !(jit_ident_char(body[p - 1]) || body[p - 1] == '.');
+        const char last = tok.back();
+        const bool right_ok = p + tok.size() >= body.size() || !jit_ident_char(last) || !jit_ident_char(body[p + tok.size()]);
+        if (left_ok && right_ok) return p;
+    }
+    return std::string::npos;
+}
+// every token `tok` -> `val`; returns how many were replaced
+uint32_t jit_replace_token(std::string& body, const std::string& tok, const std::string& val) {
+    uint32_t n = 0;
+    for (size_t p = jit_find_token(body, tok, 0); p != std::string::npos; p = jit_find_token(body, tok, p + val.size())) { body.replace(p, tok.size(), val); ++n; }
+    return n;
+}
+// The shape fields, by name: what jit_specialise turns into literals and what must NOT survive in a specialised body (tests/test_generated_kernel.py
+// checks the same list through ggrs_hip_generated_kernel_source).  `[si]`: the field is an array indexed by the Save counter in the generic text.
+static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask"};
+static const char* const kJitShapeArrays[] = {"save_rows", "save_pmask"};
 std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const size_t k = generic.find("extern \"C\" __global__");
     if (k == std::string::npos) return "";
     std::string head = generic.substr(0, k), body = generic.substr(k);
     auto lit64 = [](uint64_t v) { char b[40]; snprintf(b, sizeof b, "0x%llxull", (unsigned long long)v); return std::string(b); };
     auto lit32 = [](uint32_t v) { char b[24]; snprintf(b, sizeof b, "%uu", v); return std::string(b); };
-    const std::pair<const char*, std::string> subs[] = {
-        {"a.save_rows[si]", lit64(g.save_rows)}, {"a.save_pmask[si]", lit32(g.save_pmask)}, {"a.op_bits", lit64(g.op_bits)}, {"a.n_ops", lit32(g.n_ops)},
-        {"a.n_saves", lit32(g.n_saves)}, {"a.n_steps", lit32(g.n_steps)}, {"a.src_is_live", lit32(g.src_is_live)}, {"a.skip_live", lit32(g.skip_live)},
-        {"a.dp_s", lit32(g.dp_s)}, {"a.nt", lit32(g.nt)}, {"a.cached_saves", lit32(g.cached_saves)}, {"a.live_rows", lit64(g.live_rows)}, {"a.load_rows", lit64(g.load_rows)},
-        {"a.live_pmask", lit32(g.live_pmask)}};
-    for (auto& sb : subs) {
-        const size_t n = strlen(sb.first);
-        for (size_t p = body.find(sb.first); p != std::string::npos; p = body.find(sb.first, p + sb.second.size())) body.replace(p, n, sb.second);
+    const std::pair<const char*, std::string> scalars[] = {
+        {"op_bits", lit64(g.op_bits)}, {"n_ops", lit32(g.n_ops)}, {"n_saves", lit32(g.n_saves)}, {"n_steps", lit32(g.n_steps)}, {"src_is_live", lit32(g.src_is_live)},
+        {"skip_live", lit32(g.skip_live)}, {"dp_s", lit32(g.dp_s)}, {"nt", lit32(g.nt)}, {"cached_saves", lit32(g.cached_saves)}, {"live_rows", lit64(g.live_rows)},
+        {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}};
+    static_assert(sizeof scalars / sizeof scalars[0] == sizeof kJitShapeScalars / sizeof kJitShapeScalars[0], "every shape scalar has a literal");
+    const std::pair<const char*, std::string> arrays[] = {{"save_rows", lit64(g.save_rows)}, {"save_pmask", lit32(g.save_pmask)}};
+    for (auto& sb : arrays) (void)jit_replace_token(body, std::string("a.") + sb.first + "[si]", sb.second);
+    for (size_t i = 0; i < sizeof scalars / sizeof scalars[0]; ++i) {
+        if (strcmp(scalars[i].first, kJitShapeScalars[i]) != 0) return "";                  // the two lists name the same fields in the same order
+        (void)jit_replace_token(body, std::string("a.") + scalars[i].first, scalars[i].second);
     }
+    // nothing of the shape may be left to the argument block: a surviving token (a new use the generator spells differently, e.g. another
+    // index into save_rows) would silently read the RUN-TIME value next to literals of the shape the kernel was built for
+    for (const char* f : kJitShapeScalars) if (jit_find_token(body, std::string("a.") + f, 0) != std::string::npos) return "";
+    for (const char* f : kJitShapeArrays) if (jit_find_token(body, std::string("a.") + f, 0) != std::string::npos) return "";
     const std::string loop = "    for (uint32_t op = 0; op < " + lit32(g.n_ops) + "; ++op) {";
     const size_t lp = body.find(loop);
     if (lp == std::string::npos) return "";
