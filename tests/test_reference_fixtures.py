@@ -1,53 +1,265 @@
-"""Parity against the REAL bevy_ggrs.  tests/golden/reference_checksums.json is produced by the Rust
-fixture run (rust/fixtures: real bevy_ggrs 0.22 + ggrs under the reference's own SyncTest harness, fed this repo's synthetic
-inputs).  No Rust toolchain exists in the builder's image, so the file is absent there and these tests SKIP; the day it
-exists they are what turns "parity unpinned by the reference" into a pinned oracle: every Checksum(u128) the reference saved
-for a frame must equal the CPU oracle's -- and, under -m gpu, the HIP path's -- for that frame."""
+"""Parity against the REAL bevy_ggrs.  tests/golden/reference_checksums.json is produced by the Rust fixture run (rust/fixtures:
+real bevy_ggrs 0.22 + ggrs under the reference's own SyncTest harness, fed this repo's synthetic inputs; rust/fixtures/README.md has
+the one-command run line).  No Rust toolchain exists in the builder's image, so the file is absent there and these tests SKIP; the
+day it exists they are what turns "parity unpinned by the reference" into a pinned oracle: every Checksum(u128) the reference saved
+for a frame must equal the CPU oracle's -- and, under -m gpu, the HIP path's -- for that frame.
+
+Scenarios (keys of the JSON): BASELINE configs 2 / 3 (stress_test at 10 k / 1 M, check distance 8), config 4's rollback shapes (100 k,
+one SyncTest session per rollback length 1..7), two despawn scenarios (tests/synctest.rs:26-75 with despawn() / despawn_rollback()) and
+config 1 (box_game: cube bits per tick).  Frame 0 is checked on its own (the first SaveWorld creates the ChecksumPart entities through
+Commands: rust/fixtures/README.md), and a mismatch is localised to the ChecksumPart that differs."""
 import json
 import os
 
+import numpy as np
 import pytest
 
 import bevy_ggrs_amd as bg
 import common as cm
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_checksums.json")
-CASES = {"config2_particles_10k": 10_000, "config3_particles_1m": 1_000_000}
+GOLDEN = os.environ.get("GGRS_REFERENCE_GOLDEN") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_checksums.json")
+PARTICLES = {"config2_particles_10k": (10_000, "config2"), "config3_particles_1m": (1_000_000, "config3")}
+PARTICLES.update({f"config4_rollback_{r}": (100_000, "config3") for r in range(1, 8)})
+DESPAWN = ("despawn_immediate", "despawn_rollback")
 
 
-def _reference(case):
+def _load(case):
     if not os.path.exists(GOLDEN):
-        pytest.skip("tests/golden/reference_checksums.json is absent: run rust/fixtures (cargo test --release) on a machine with a Rust toolchain")
-    ref = json.load(open(GOLDEN))[case]
+        pytest.skip("tests/golden/reference_checksums.json is absent: run rust/fixtures (README.md there) on a machine with a Rust toolchain")
+    doc = json.load(open(GOLDEN))
+    if case not in doc:
+        pytest.skip(f"{case} is not in the dump (config1_box_game needs `--features box_game`)")
+    assert "after SaveWorldSystems::Snapshot" in doc.get("recorder", ""), \
+        "this dump was made by the round-3 recorder, which was not ordered after ChecksumPlugin::update: regenerate it"
+    return doc[case]
+
+
+def _first_saves(ref):
+    """frame -> (checksum, parts) of the FIRST time the reference saved that frame; a later save of the same frame (a resimulation) must
+    agree with it -- that is what SyncTest itself asserts (tests/synctest.rs:84-125)."""
     first = {}
-    for f, c in ref["saves"]:
-        assert first.setdefault(f, int(c, 16)) == int(c, 16), "the reference itself resimulated a frame to a different checksum"
-    return ref, first
+    for s in ref["saves"]:
+        c = int(s["checksum"], 16)
+        if s["frame"] in first:
+            assert first[s["frame"]][0] == c, f"the reference itself resimulated frame {s['frame']} to a different checksum"
+        else:
+            first[s["frame"]] = (c, {k: int(v, 16) for k, v in s.get("parts", {}).items()})
+    return first
 
 
-def _ours(world, n, ticks):
-    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+def _particles_world(world, n, tag_n):
+    vel, ttl = cm.synthetic_particles(tag_n, ttl="despawn")          # the fixture takes the first n rows of the tag's inputs
     ids = cm.build_particles(world)
-    cm.spawn_particles(world, ids, n, vel, ttl)
-    drv = cm.SyncTestDriver(world, 8, max_prediction=9)
+    cm.spawn_particles(world, ids, n, vel[:n], ttl[:n])
+    return ids
+
+
+def _run_particles(world, n, tag_n, cd, ticks):
+    _particles_world(world, n, tag_n)
+    drv = cm.SyncTestDriver(world, cd, max_prediction=cd + 1)
     for _ in range(ticks): drv.tick((0,))
     return dict(drv.all_checksums)          # resimulated frames agree with their first save (SyncTest asserts it)
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_oracle_equals_the_reference(case):
+def _particle_parts_at(n, tag_n, frame):
+    """The three ChecksumParts of the stress_test world at `frame`, recomputed from the oracle's columns with the numpy formulas
+    (component_checksum.rs:77-95, entity_checksum.rs:35-43) -- used only to say WHICH part of a mismatching total differs."""
+    from oracle import oracle_np as onp
     from oracle.binding import FLAT, OracleWorld
-    ref, first = _reference(case)
-    got = _ours(OracleWorld(CASES[case], 9, FLAT), CASES[case], ref["ticks"])
-    assert set(first) <= set(got) | {max(first)}, "the reference saved frames we never did"
-    for f, c in first.items():
-        if f in got: assert got[f] == c, f"frame {f}: ours {got[f]:#x} reference {c:#x}"
+    w = OracleWorld(n, 2, FLAT)
+    T, V, L = _particles_world(w, n, tag_n)
+    for _ in range(frame): w.advance((0,))
+    alive = w.alive_mask(w.len)
+    order = np.nonzero(alive)[0].astype(np.uint64)
+    parts = {}
+    for name, comp in (("Transform", T), ("Velocity", V)):
+        units = [w.download_word(comp, k, 0, w.len)[alive] for k in range(3)]
+        parts[name] = onp.np_component_checksum(order, units)
+    parts["Entity"] = onp.entity_checksum(int(alive.sum()), w.len)
+    return parts
+
+
+def _compare(case, first, got, parts_at=None):
+    assert set(first) - {max(first)} <= set(got), "the reference saved frames we never did"
+    bad = [f for f in sorted(first) if f in got and got[f] != first[f][0]]
+    if not bad: return
+    f = bad[0]
+    msg = f"{case}: frame {f}: ours {got[f]:#x} reference {first[f][0]:#x}"
+    if f == 0:
+        msg += ("  [frame 0: the first SaveWorld creates the ChecksumPart entities through Commands (component_checksum.rs:103-107); if ONLY "
+                "frame 0 differs, the reference folded fewer parts than exist -- compare `parts`]")
+    if parts_at is not None and first[f][1]:
+        ours = parts_at(f)
+        diff = {k: (hex(ours.get(k, 0)), hex(v)) for k, v in first[f][1].items() if ours.get(k) != v}
+        fold = 0
+        for v in first[f][1].values(): fold ^= v
+        msg += f"  differing parts (ours, reference): {diff or 'none -- the parts agree'}; the reference's parts fold to {fold:#x}"
+    raise AssertionError(msg + f"  ({len(bad)} of {len(first)} saved frames differ)")
+
+
+@pytest.mark.parametrize("case", sorted(PARTICLES))
+def test_oracle_equals_the_reference_particles(case):
+    from oracle.binding import FLAT, OracleWorld
+    ref = _load(case)
+    n, tag = PARTICLES[case]
+    tag_n = 10_000 if tag == "config2" else 1_000_000
+    assert ref["entities"] == n
+    got = _run_particles(OracleWorld(n, ref["check_distance"] + 1, FLAT), n, tag_n, ref["check_distance"], ref["ticks"])
+    first = _first_saves(ref)
+    assert first[0][0] == got[0], f"{case}: FRAME 0 differs (ours {got[0]:#x}, reference {first[0][0]:#x}, reference parts {first[0][1]})"
+    _compare(case, first, got, parts_at=lambda f: _particle_parts_at(n, tag_n, f))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_hip_equals_the_reference(case):
-    ref, first = _reference(case)
-    got = _ours(bg.World(CASES[case], max_depth=9), CASES[case], ref["ticks"])
-    for f, c in first.items():
-        if f in got: assert got[f] == c, f"frame {f}: HIP {got[f]:#x} reference {c:#x}"
+@pytest.mark.parametrize("case", sorted(PARTICLES))
+def test_hip_equals_the_reference_particles(case):
+    ref = _load(case)
+    n, tag = PARTICLES[case]
+    tag_n = 10_000 if tag == "config2" else 1_000_000
+    got = _run_particles(bg.World(n, max_depth=ref["check_distance"] + 1), n, tag_n, ref["check_distance"], ref["ticks"])
+    _compare(case, _first_saves(ref), got)
+
+
+def _run_despawn(world, ref):
+    """tests/synctest.rs:26-75 over 64 entities with health 1 + (i % 10) (rust/fixtures despawn_scenario)."""
+    n = ref["entities"]
+    H = world.register_component("Health", 4, 1)
+    world.checksum_component(H, [0])
+    world.add_system(bg.SYS_SAT_SUB_DESPAWN, comp=(H,), word=(0,), iparam=(1, bg.DESPAWN_ROLLBACK if ref["deferred"] else bg.DESPAWN_IMMEDIATE))
+    world.spawn(n, {H: [(1 + np.arange(n) % 10).astype(np.uint32)]})
+    drv = cm.SyncTestDriver(world, ref["check_distance"], max_prediction=ref["check_distance"] + 1)
+    alive = []
+    for _ in range(ref["ticks"]):
+        drv.tick((0,))
+        a = world.alive_mask(world.len)
+        if ref["deferred"]: a = a & ~world.disabled_mask(world.len)           # RollbackDespawned entities are hidden from default queries
+        alive.append(int(a.sum()))
+    return dict(drv.all_checksums), alive
+
+
+@pytest.mark.parametrize("case", DESPAWN)
+def test_oracle_equals_the_reference_despawn(case):
+    from oracle.binding import FLAT, OracleWorld
+    ref = _load(case)
+    got, alive = _run_despawn(OracleWorld(ref["entities"], ref["check_distance"] + 1, FLAT), ref)
+    assert alive == ref["alive_after_tick"], f"{case}: live entities per tick differ"
+    _compare(case, _first_saves(ref), got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DESPAWN)
+def test_hip_equals_the_reference_despawn(case):
+    ref = _load(case)
+    got, alive = _run_despawn(bg.World(ref["entities"], max_depth=ref["check_distance"] + 1), ref)
+    assert alive == ref["alive_after_tick"]
+    _compare(case, _first_saves(ref), got)
+
+
+def _run_box_game(world, ref):
+    """box_game_synctest.rs (2 players, check distance 7, input delay 2) under the scripted inputs of config1_inputs.bin; the cubes start
+    from the reference's own initial translations (setup_system evaluates cos / sin with the platform's libm)."""
+    from test_box_game import BOX_PARAMS, box_state, input_script
+    players = ref["players"]
+    T = world.register_component("Transform", 4, 10)
+    V = world.register_component("Velocity", 4, 3)
+    P = world.register_component("Player", 8, 1, rollback=False)
+    world.set_component_default(T, cm.TRANSFORM_DEFAULT)
+    world.add_system(bg.SYS_BOX_MOVE, comp=(T, V, P), word=(0, 0, 0), fparam=BOX_PARAMS)
+    tr = np.tile(cm.f32bits(cm.TRANSFORM_DEFAULT), (players, 1)).astype(np.uint32)
+    tr[:, 0:3] = np.array(ref["initial_translation_bits"], dtype=np.uint32)
+    world.spawn(players, {T: [tr[:, k].copy() for k in range(10)], V: [np.zeros(players, np.uint32)] * 3, P: [np.arange(players, dtype=np.uint64)]})
+    drv = cm.SyncTestDriver(world, ref["check_distance"], num_players=players, input_delay=ref["input_delay"])
+    out = []
+    for t in range(ref["ticks"]):
+        drv.tick(input_script(t % 40, players))
+        tb, vb = box_state(world, (T, V, P))
+        out.append(np.concatenate([tb, vb], axis=1).tolist())
+    return out
+
+
+def test_oracle_equals_the_reference_box_game():
+    from oracle.binding import FLAT, OracleWorld
+    ref = _load("config1_box_game")
+    got = _run_box_game(OracleWorld(8, ref["check_distance"] + 2, FLAT), ref)
+    for t, (ours, theirs) in enumerate(zip(got, ref["after_tick"])):
+        assert ours == theirs["cubes"], f"box_game: tick {t} (frame {theirs['frame']}): cube bits differ: ours {ours} reference {theirs['cubes']}"
+    # the example checksums only FrameCount (checksum_resource_with_hash) and the entity part: both are host arithmetic here
+    from oracle import oracle_np as onp
+    for s in ref["saves"]:
+        want = onp.checksum_part_from_u32(s["frame"]) ^ onp.entity_checksum(ref["players"], ref["players"])
+        assert int(s["checksum"], 16) == want, f"box_game: frame {s['frame']}: FrameCount part ^ entity part = {want:#x}, reference {s['checksum']}"
+
+
+@pytest.mark.gpu
+def test_hip_equals_the_reference_box_game():
+    ref = _load("config1_box_game")
+    got = _run_box_game(bg.World(8, max_depth=ref["check_distance"] + 2), ref)
+    for t, (ours, theirs) in enumerate(zip(got, ref["after_tick"])):
+        assert ours == theirs["cubes"], f"box_game (HIP): tick {t}: cube bits differ"
+
+
+def test_consumer_plumbing_on_a_dump_the_oracle_made_itself(tmp_path, monkeypatch):
+    """NOT a reference pin: the Rust recipe cannot run in this image, so this test writes a dump of the SAME SHAPE with the oracle itself
+    (small sizes) and runs every consumer above against it -- frame bookkeeping, the per-part recomputation, the despawn / box_game drivers.
+    It proves the consumers execute and accept a self-consistent dump, and that a corrupted part is localised; the day the real file
+    exists, the tests above do the pinning."""
+    import sys
+    from oracle import oracle_np as onp
+    from oracle.binding import FLAT, OracleWorld
+    from test_box_game import build_box
+    me = sys.modules[__name__]
+    doc = {"bevy_ggrs": "SELF-MADE BY THE ORACLE (plumbing test)", "recorder": "after SaveWorldSystems::Snapshot (behind ChecksumPlugin::update)"}
+
+    def saves_of(cs, parts_at=None):
+        return [{"frame": f, "checksum": hex(c), "parts": ({k: hex(v) for k, v in parts_at(f).items()} if parts_at else {})} for f, c in cs]
+    # particles: 2000 entities under check distance 3 stand in for the big cases
+    monkeypatch.setitem(PARTICLES, "config2_particles_10k", (2000, "config2"))
+    w = OracleWorld(2000, 4, FLAT)
+    _particles_world(w, 2000, 10_000)
+    drv = cm.SyncTestDriver(w, 3, max_prediction=4)
+    for _ in range(9): drv.tick((0,))
+    doc["config2_particles_10k"] = {"entities": 2000, "check_distance": 3, "ticks": 9, "saves": saves_of(drv.all_checksums, lambda f: _particle_parts_at(2000, 10_000, f))}
+    for case, deferred in (("despawn_immediate", False), ("despawn_rollback", True)):
+        ref = {"entities": 64, "check_distance": 5, "ticks": 30, "deferred": deferred}
+        o = OracleWorld(64, 6, FLAT)
+        H = o.register_component("Health", 4, 1); o.checksum_component(H, [0])
+        o.add_system(bg.SYS_SAT_SUB_DESPAWN, comp=(H,), word=(0,), iparam=(1, bg.DESPAWN_ROLLBACK if deferred else bg.DESPAWN_IMMEDIATE))
+        o.spawn(64, {H: [(1 + np.arange(64) % 10).astype(np.uint32)]})
+        d2 = cm.SyncTestDriver(o, 5, max_prediction=6)
+        alive = []
+        for _ in range(30):
+            d2.tick((0,))
+            a = o.alive_mask(o.len)
+            if deferred: a = a & ~o.disabled_mask(o.len)
+            alive.append(int(a.sum()))
+        doc[case] = dict(ref, alive_after_tick=alive, saves=saves_of(d2.all_checksums))
+    # box_game: the oracle's own walk, dumped in the fixture's shape
+    ob = OracleWorld(8, 9, FLAT)
+    ids, tr, _vel, _h = build_box(ob, 2, 2)
+    init = [[int(x) for x in cm.f32bits(tr[k])] for k in range(2)]
+    ref_box = {"players": 2, "check_distance": 7, "input_delay": 2, "ticks": 12, "initial_translation_bits": init}
+    from test_box_game import box_state, input_script
+    d3 = cm.SyncTestDriver(ob, 7, num_players=2, input_delay=2)
+    after = []
+    for t in range(12):
+        d3.tick(input_script(t % 40, 2))
+        tb, vb = box_state(ob, ids)
+        after.append({"frame": ob.frame, "cubes": np.concatenate([tb, vb], axis=1).tolist()})
+    saves = [{"frame": f, "checksum": hex(onp.checksum_part_from_u32(f) ^ onp.entity_checksum(2, 2))} for f, _ in d3.all_checksums]
+    doc["config1_box_game"] = dict(ref_box, after_tick=after, saves=saves)
+    path = tmp_path / "reference_checksums.json"
+    path.write_text(json.dumps(doc))
+    monkeypatch.setattr(me, "GOLDEN", str(path))
+    test_oracle_equals_the_reference_particles("config2_particles_10k")
+    for case in DESPAWN: test_oracle_equals_the_reference_despawn(case)
+    test_oracle_equals_the_reference_box_game()
+    # a corrupted Velocity part of one frame is found and named
+    victim = doc["config2_particles_10k"]["saves"][5]["frame"]
+    for sv in doc["config2_particles_10k"]["saves"]:                      # every save of that frame, resimulations included
+        if sv["frame"] == victim:
+            sv["checksum"] = hex(int(sv["checksum"], 16) ^ 1)
+            sv["parts"]["Velocity"] = hex(int(sv["parts"]["Velocity"], 16) ^ 1)
+    path.write_text(json.dumps(doc))
+    with pytest.raises(AssertionError) as ei:
+        test_oracle_equals_the_reference_particles("config2_particles_10k")
+    assert "Velocity" in str(ei.value) and "differing parts" in str(ei.value), str(ei.value)
