@@ -213,6 +213,17 @@ def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_inp
     return out
 
 
+def latency_floor(kernel_us, launches_per_tick, tick_us):
+    """Small worlds (the whole ring lives in L2 / the Infinity Cache) are bound by launch latency, not by HBM: a tick cannot be shorter than
+    its kernels plus one dependent same-stream boundary per launch -- 1.45 us between trivial kernels, 1.7-1.9 us between real streaming
+    ones (MI355X_MICROARCH.md, price list row `boundary`).  Reported next to `roofline` for BASELINE configs 2 and 4."""
+    lo, hi = kernel_us * launches_per_tick + 1.45 * launches_per_tick, kernel_us * launches_per_tick + 1.9 * launches_per_tick
+    return {"bound": "launch latency (dependent same-stream kernel boundary)", "boundary_us": [1.45, 1.9], "source": "MI355X_MICROARCH.md, 'Persistent kernels: synchronisation and hand-off price list', row boundary",
+            "kernel_us_per_tick": kernel_us * launches_per_tick, "launches_per_tick": launches_per_tick,
+            "floor_us_per_tick": [round(lo, 2), round(hi, 2)], "achieved_us_per_tick": tick_us,
+            "frac": [round(lo / tick_us, 3), round(hi / tick_us, 3)] if tick_us else None}
+
+
 def read_clocks():
     """sclk / mclk / power right now: sysfs (pp_dpm_*: the starred level; hwmon power) when the container exposes it, else
     `rocm-smi`.  Telemetry for the JSON line only."""
@@ -477,7 +488,24 @@ def measure_p2p(bg, cm, torch, args):
         reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
         if f - R >= 0: o.set_confirmed(f - R)
         want.append(o.handle_requests(reqs))
-    return {"secs": secs, "advances": advances, "live": live, "prof": prof, "prof_bytes": pbytes, "info": info,
+    # ---- the CPU path beside it: the oracle's reference-shaped storage, one thread, the first ticks of the same script
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle.binding import REFSHAPED, lib as olib
+        olib.gor_set_num_threads(1)
+        r_ = OracleWorld(n, R + 1, REFSHAPED)
+        rids = cm.build_particles(r_); cm.spawn_particles(r_, rids, n, vel, ttl); r_.set_depth(R)
+        sample, adv_n = script[:max(8, 8 * args.cpu_ticks)], 0
+        tc = time.perf_counter()
+        for (f, r, _s) in sample:
+            reqs = ([bg.LoadGameState(f - r)] + [x for i in range(r) for x in (([bg.SaveGameState(f - r + i)] if i else []) + [bg.AdvanceFrame((0,))])]) if r else []
+            reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
+            if f - R >= 0: r_.set_confirmed(f - R)
+            r_.handle_requests(reqs); adv_n += r + 1
+        tc = time.perf_counter() - tc
+        cpu = {"value": n * adv_n / tc, "unit": "entity-frames/s", "cores": 1, "kind": "port", "host_cores_available": os.cpu_count(),
+               "sample": f"the first {len(sample)} ticks of the same rollback script ({adv_n} AdvanceWorlds) on the oracle's reference-shaped storage (per-save HashMap rebuild), {tc:.1f} s"}
+    return {"secs": secs, "advances": advances, "live": live, "prof": prof, "prof_bytes": pbytes, "info": info, "cpu_baseline": cpu,
             "parity": {"checked_ticks": len(script), "checked_saves": sum(len(x) for x in want), "equal": got == want,
                        "oracle": "oracle/ggrs_oracle.cpp FLAT variant driven by the same rollback script"},
             "mean_rollback": sum(r for _f, r, _s in script[first:first + K]) / K, "settle": settle, "tick_wall_us": tick_wall}
@@ -595,7 +623,8 @@ def main():
                              "avg_launch_us": avg_s * 1e6, "launches_timed": t_n, "algorithmic_bytes_per_launch": bpl,
                              "note": f"the whole ring ({n} x 60 B x {D + 1} blocks = {n * 60 * (D + 1) / 1e6:.0f} MB) lives in the 256 MB Infinity Cache: this line is launch / latency bound, "
                                      "the HBM fraction is reported for completeness, not as its roofline"},
-                "telemetry": {"tick_wall_us": m4["tick_wall_us"]}, "parity": m4["parity"], "cpu_baseline": None}
+                "latency_floor": latency_floor(avg_s * 1e6, t_n / max(min(K, 50), 1), m4["secs"] / K * 1e6),
+                "telemetry": {"tick_wall_us": m4["tick_wall_us"]}, "parity": m4["parity"], "cpu_baseline": m4["cpu_baseline"]}
         print(json.dumps(line))
         if not m4["parity"]["equal"]:
             print("bench.py: PARITY FAILURE (config 4)", file=sys.stderr); sys.exit(1)
@@ -782,6 +811,9 @@ def main():
         "preheat": m.get("preheat"),
         "roofline": roof,
     }
+    if not distributed and grouped and n * bps * (D + 1) <= (256 << 20):
+        # the whole ring fits the 256 MB Infinity Cache: launch / latency bound ("report it but do not judge it against HBM peak")
+        line["latency_floor"] = latency_floor(per(tick_ms, tick_n) * 1e6, launches_per_step, secs / K * 1e6)
     if distributed and args.branches > 1:
         # checksum-only branches (dead-snapshot elimination): integer-multiply bound, not HBM bound.  Roofline = SeaHash `diffuse`
         # per second against the chip's measured ceiling (scripts/ubench_alu.hip -> profiles/alu_ceiling.json).  Algorithmic
