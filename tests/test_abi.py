@@ -74,6 +74,100 @@ def test_rust_ffi_declares_every_header_symbol():
         assert m and int(m.group(1)) == int(const[1]), const
 
 
+_C2RS = {"int": "c_int", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "float": "f32", "double": "f64",
+         "char": "c_char", "void": "c_void"}
+
+
+def _c_type_to_rust(t: str, name_has_array: bool = False) -> str:
+    """`const ggrs_request*` -> `*const ggrs_request`, `void**` -> `*mut *mut c_void`, `const void* const*` -> `*const *const c_void`;
+    an array parameter (`uint64_t out[2]`) is a pointer to its element."""
+    import re
+    t = re.sub(r"\s+", " ", t.strip())
+    toks = re.findall(r"\*|const|[A-Za-z_]\w*", t)
+    base = [x for x in toks if x not in ("*", "const")]
+    assert len(base) == 1, t
+    out = _C2RS.get(base[0], base[0])
+    # walk the declarator left to right: a `const` belongs to what precedes the next `*` (or to the base when it leads)
+    pending_const = False
+    seen_base = False
+    for x in toks:
+        if x == "const": pending_const = True
+        elif x == "*":
+            out = ("*const " if pending_const else "*mut ") + out
+            pending_const = False
+        else:
+            seen_base = True
+    if name_has_array:
+        out = ("*const " if pending_const else "*mut ") + out
+    return out
+
+
+def _parse_header():
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ggrs_hip.h")).read()
+    h = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))
+    fns = {}
+    for m in re.finditer(r"^\s*([A-Za-z_][\w\s\*]*?)\b(ggrs_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", h, flags=re.M):
+        ret, name, args = m.group(1).strip(), m.group(2), re.sub(r"\s+", " ", m.group(3)).strip()
+        params = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip()
+                arr = bool(re.search(r"\[[^\]]*\]$", a))
+                a = re.sub(r"\[[^\]]*\]$", "", a).strip()
+                mm = re.match(r"(.*?)([A-Za-z_]\w*)$", a)
+                params.append((mm.group(2), _c_type_to_rust(mm.group(1), arr)))
+        fns[name] = (None if ret == "void" else _c_type_to_rust(ret), params)
+    structs = {}
+    for m in re.finditer(r"typedef struct \{(.*?)\}\s*(ggrs_\w+)\s*;", h, flags=re.S):
+        fields = []
+        for line in m.group(1).split(";"):
+            line = re.sub(r"\s+", " ", line).strip()
+            if not line: continue
+            mm = re.match(r"(.*?)([A-Za-z_]\w*)\s*(\[[^\]]*\])?$", line)
+            ty = _c_type_to_rust(mm.group(1))
+            if mm.group(3): ty = f"[{ty}; {mm.group(3)[1:-1].strip()}]"
+            fields.append((mm.group(2), ty))
+        structs[m.group(2)] = fields
+    return fns, structs
+
+
+def _parse_ffi_rs():
+    import re
+    rs = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "bevy_ggrs_hip", "src", "ffi.rs")).read())
+    norm = lambda t: re.sub(r"\s+", " ", t.strip())
+    fns = {}
+    for m in re.finditer(r"pub fn (ggrs_hip_[a-z0-9_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", rs):
+        params = [(a.split(":", 1)[0].strip(), norm(a.split(":", 1)[1])) for a in m.group(2).split(",") if a.strip()]
+        fns[m.group(1)] = (norm(m.group(3)) if m.group(3) else None, params)
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (ggrs_\w+)\s*\{(.*?)\}", rs, flags=re.S):
+        fields = [(f.split(":", 1)[0].replace("pub", "").strip(), norm(f.split(":", 1)[1])) for f in m.group(2).split(",") if ":" in f]
+        structs[m.group(1)] = fields
+    return fns, structs
+
+
+def test_rust_ffi_signatures_and_struct_layouts_match_the_header():
+    """Beyond names and argument counts: every parameter's NAME and TYPE, every return type and every field of the
+    three argument structs in rust/bevy_ggrs_hip/src/ffi.rs must be what a bindgen run over include/ggrs_hip.h would emit -- checked by
+    translating the header's C declarators to Rust (`const ggrs_request*` -> `*const ggrs_request`, `uint64_t out[2]` -> `*mut u64`,
+    `uint32_t comp[GGRS_CUSTOM_MAX_BINDINGS]` -> `[u32; GGRS_CUSTOM_MAX_BINDINGS]`) and comparing token for token."""
+    c_fns, c_structs = _parse_header()
+    r_fns, r_structs = _parse_ffi_rs()
+    assert len(c_fns) >= 60 and set(c_fns) == set(r_fns)
+    for name, (ret, params) in c_fns.items():
+        r_ret, r_params = r_fns[name]
+        assert r_ret == ret, f"{name}: returns {r_ret} in ffi.rs, {ret} per the header"
+        assert r_params == params, f"{name}: ffi.rs {r_params} vs header {params}"
+    for sname in ("ggrs_world_desc", "ggrs_system_desc", "ggrs_custom_system_desc", "ggrs_request"):
+        assert sname in c_structs and sname in r_structs, sname
+        c = [(n, t.replace("[u32; 4]", "[u32; 4]")) for n, t in c_structs[sname]]
+        assert r_structs[sname] == c, f"{sname}: ffi.rs {r_structs[sname]} vs header {c}"
+    # the translator itself, on the declarator shapes the header uses
+    assert _c_type_to_rust("const void* const*") == "*const *const c_void" and _c_type_to_rust("ggrs_world**") == "*mut *mut ggrs_world"
+    assert _c_type_to_rust("const uint8_t", True) == "*const u8" and _c_type_to_rust("uint64_t", True) == "*mut u64" and _c_type_to_rust("const char*") == "*const c_char"
+
+
 def test_rust_shim_uses_only_declared_symbols_and_owns_the_session_driver():
     """rust/bevy_ggrs_hip/src/lib.rs (un-built source) must (a) use only `ffi::` items that ffi.rs declares and the
     header exports, (b) install its OWN session-driving system -- the stock bevy_ggrs plugin would call the stock
