@@ -163,7 +163,7 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs,
     return base, parity
 
 
-def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_input, threads):
+def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_input, threads, spawn_rate=0):
     """N > 1 / --fanout parity gate: the gathered Checksum(u128) table of the first timed steps against ONE process walking every
     branch of every rank on the CPU oracle (tests/test_fanout_gloo.py::_serial_reference is the same recipe).  `raw` = what
     SpeculativeFanout kept: [(C, (size, bpr * depth, 2) u64)] for consecutive confirmed frames C = c_timed, c_timed + 1, ...
@@ -175,12 +175,20 @@ def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_inp
     import common as cm
     lib.gor_set_num_threads(threads)
     t0 = time.perf_counter()
-    o = OracleWorld(n, depth + 1, FLAT)
-    ids = cm.build_particles(o)
+    cap = n + (2 * spawn_rate * (depth + 2) if spawn_rate else 0)
+    o = OracleWorld(cap, depth + 1, FLAT)
+    ids = cm.build_particles(o, with_spawn=bool(spawn_rate))
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(o, ids, n, vel, ttl)
     o.set_depth(depth + 1)
+    spawn_fn = cm.frame_spawn_fn(spawn_rate) if spawn_rate else None
+
+    def adv(frame, inp):
+        a = bg.AdvanceFrame((inp,))
+        if spawn_fn is not None and (inp & cm.INPUT_SPAWN): a.spawn_vx, a.spawn_vy = spawn_fn(frame)
+        return a
     for f in range(c_timed):
+        assert not (spawn_rate and confirmed_input(f) & cm.INPUT_SPAWN), "the bench's confirmed inputs never spawn"
         o.advance((confirmed_input(f),))
     assert o.frame == c_timed, (o.frame, c_timed)
     o.set_confirmed(c_timed)
@@ -195,10 +203,10 @@ def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_inp
         for r in range(size):
             for j in range(bpr):
                 b = r * bpr + j
-                reqs = [bg.LoadGameState(C), bg.AdvanceFrame((confirmed_input(C),)), bg.SaveGameState(C + 1)]
+                reqs = [bg.LoadGameState(C), adv(C, confirmed_input(C)), bg.SaveGameState(C + 1)]
                 for i in range(1, depth):
-                    reqs += [bg.AdvanceFrame((branch_input(b, C + i),)), bg.SaveGameState(C + 1 + i)]
-                reqs.append(bg.AdvanceFrame((branch_input(b, C + depth),)))
+                    reqs += [adv(C + i, branch_input(b, C + i)), bg.SaveGameState(C + 1 + i)]
+                reqs.append(adv(C + depth, branch_input(b, C + depth)))
                 want = o.handle_requests(reqs)
                 got = [int(table[r, j * depth + i, 0]) | (int(table[r, j * depth + i, 1]) << 64) for i in range(depth)]
                 out["checked_saves"] += depth
@@ -539,6 +547,9 @@ def main():
                          "components with every column written every frame (+ increase_component over rotation / scale): every Save moves all 15 rows")
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (RCCL broadcast + all-gather inside the library) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
+    ap.add_argument("--spawn", action="store_true", help="fan-out: register the stress_test's spawn system (100 particles per frame while INPUT_SPAWN is held): the "
+                    "branches whose predicted input byte carries the bit diverge from the others (SURVEY 8d's wording of config 5).  A firing spawn system "
+                    "ends a request group (Bevy Commands flush), so those branches run frame by frame and are not batched")
     ap.add_argument("--no-share-prefix", action="store_true", help="fan-out A/B: every branch replays [Load(C), Advance(confirmed input), Save(C+1)] itself "
                     "(the round-3 request lists) instead of starting from the ONE saved C+1")
     ap.add_argument("--parity-steps", type=int, default=-1, help="N > 1 / --fanout: timed steps whose gathered checksum table rank 0 replays on the CPU oracle "
@@ -653,8 +664,11 @@ def main():
         # every rank provisions the same world shape; only rank 0 owns the confirmed world, the others receive it through
         # ONE ncclBroadcast of the packed state block.  The collectives are issued INSIDE libggrs_hip.so
         # (ggrs_hip_fanout_*, RCCL dlopen'ed there); torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier.
-        w = bg.World(n, max_depth=D + 2, device=dev, stream=stream, flags=flags)
-        ids = cm.build_particles(w)
+        # --spawn (config 5 as SURVEY 8d words it): inputs with INPUT_SPAWN set spawn `rate` particles per frame (particles.rs:258-270), so
+        # branches whose predicted input byte carries the bit really diverge from the others; room for the spawns of one branch's D frames
+        spawn_rate = 100 if args.spawn else 0
+        w = bg.World(n + 2 * spawn_rate * (D + 2), max_depth=D + 2, device=dev, stream=stream, flags=flags)
+        ids = cm.build_particles(w, with_spawn=bool(spawn_rate))
         if rank == 0:
             vel, ttl = cm.synthetic_particles(n, ttl="throughput")
             cm.spawn_particles(w, ids, n, vel, ttl)
@@ -667,7 +681,7 @@ def main():
         assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
         fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
                                 desync_detection_interval=10 if args.branches == 1 else 1,   # the reference stress_test's default (particles.rs:49, README.md:84)
-                                share_prefix=not args.no_share_prefix)
+                                share_prefix=not args.no_share_prefix, spawn_fn=cm.frame_spawn_fn(spawn_rate) if spawn_rate else None)
         fan.sync_confirmed(0)
         gc.collect(); gc.disable()                           # see measure_single
         for _ in range(W):
@@ -803,7 +817,7 @@ def main():
         "config": {"workload": f"stress_test {n} entities x {cm.schema_description(args.schema)}, "
                                f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
                    "entities_per_gpu": live, "depth": D,
-                   "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
+                   "spawn_system": bool(args.spawn), "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
                    "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
                    "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"), "specialised_kernel": info.get("specialised_kernel"),
                    "hiprtc": info.get("hiprtc"), "device": dev,
@@ -849,7 +863,7 @@ def main():
         line["cpu_baseline"] = base
         from bevy_ggrs_amd.fanout import default_branch_input
         par = fanout_parity(n, D, fo["c_timed"], fo["raw"], comm_size, args.branches, default_branch_input, lambda f: 0,
-                            threads=max(1, min(64, os.cpu_count() or 1)))
+                            threads=max(1, min(64, os.cpu_count() or 1)), spawn_rate=100 if args.spawn else 0)
         par["cross_rank_confirmed_frames_agree"] = True     # SpeculativeFanout raises DesyncDetected otherwise (every step, every rank)
         line["parity"] = par
         parity_failed = par["equal"] is not True

@@ -75,3 +75,25 @@ def test_shared_prefix_and_per_branch_prefix_gather_the_same_table():
         out.append((res, [(c, t.tolist()) for c, t in fan.raw], cm.snapshot_state(w, ids)))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     cm.assert_states_equal(out[0][2], out[1][2], "share_prefix")
+
+
+def test_parity_gate_with_the_spawn_system():
+    """bench.py --config 5 --spawn: branches whose predicted input byte carries INPUT_SPAWN (branch ids 16..31, ...) spawn particles every
+    frame and diverge; the gate's oracle walk hands the same per-frame spawn payloads to the same branches."""
+    import bench
+    n, D, bpr, rate = 600, 3, 20, 100
+    w = OracleWorld(n + 2 * rate * (D + 2), D + 1, FLAT)
+    ids = cm.build_particles(w, with_spawn=True)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    fan = SpeculativeFanout(w, _OneRank(), D, _NoExchange(), branches_per_rank=bpr, spawn_fn=cm.frame_spawn_fn(rate))
+    fan.sync_confirmed(0)
+    for _ in range(3): fan.step(want_result=False)
+    c_timed = fan.confirmed
+    fan.raw, fan.raw_keep = [], 2
+    res = [fan.step() for _ in range(2)]
+    cs = res[-1]["branch_checksums"]
+    assert cs[0] == cs[15] and cs[16] == cs[19] and cs[0][0] == cs[16][0] and cs[0][1:] != cs[16][1:]     # spawning branches diverge after the confirmed frame
+    par = bench.fanout_parity(n, D, c_timed, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2, spawn_rate=rate)
+    assert par["equal"] is True and par["checked_saves"] == 2 * bpr * D, par
+    assert bench.fanout_parity(n, D, c_timed, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2, spawn_rate=0)["equal"] is False
