@@ -741,6 +741,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
+            if "k_tick_hbm_bytes_per_launch" not in tj: tj = tj.get(args.schema, {})     # one entry per schema (scripts/pmc_summary.py); the round-3 file was flat
             same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum and tj.get("schema", "headline") == args.schema)
             if same:
                 traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")

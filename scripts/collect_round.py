@@ -11,10 +11,12 @@ os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "*")):
     if os.path.isfile(f) and os.path.getsize(f) < 2 << 20 and not f.endswith((".err", ".log")) or f.endswith(("pytest_gpu.log", "smoke.log")):
         shutil.copy(f, dst)
-for name, sub in (("kernel_stats.csv", "prof_stats"),):
+for name, sub in (("kernel_stats.csv", "prof_stats"), ("kernel_stats_allhot.csv", "prof_stats_allhot")):
     hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if hits: shutil.copy(hits[0], os.path.join(dst, name))
 subprocess.check_call([sys.executable, "scripts/pmc_summary.py", src, dst], stdout=subprocess.DEVNULL)
+if glob.glob(os.path.join(src, "prof_allhot_fetch", "**", "*counter_collection.csv"), recursive=True):
+    subprocess.check_call([sys.executable, "scripts/pmc_summary.py", src, dst, "allhot", "prof_allhot"], stdout=subprocess.DEVNULL)
 
 # the SQ / GRBM pass of the same command: VALU occupancy of the dominant kernel and the clock it ran at
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -7,7 +7,9 @@ Corrections, as that guide prescribes: FETCH_SIZE under-reports wide (16 B/lane)
 exactly 2x on gfx950 -> doubled; WRITE_SIZE is calibrated against this engine's own known byte
 count (one snapshot copy writes 60.5 MB -> reported 59 082 KiB: exact, no correction).
 
-usage: pmc_summary.py <gpurun_out/tag> <profiles/tag>
+usage: pmc_summary.py <gpurun_out/tag> <profiles/tag> [schema [prefix]]
+       schema: which bench.py --schema the profiled command ran (default headline); prefix: the pass directories are <prefix>_fetch / <prefix>_write
+       (default prof).  profiles/roofline_traffic.json keeps one entry per schema.
 """
 import collections
 import csv
@@ -28,10 +30,12 @@ def collect(pattern, counter):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    schema = sys.argv[3] if len(sys.argv) > 3 else "headline"
+    prefix = sys.argv[4] if len(sys.argv) > 4 else "prof"
     os.makedirs(dst, exist_ok=True)
     out = {"note": __doc__.split("usage:")[0].strip()}
-    fetch = collect(os.path.join(src, "prof_fetch", "**", "*counter_collection.csv"), "FETCH_SIZE")
-    write = collect(os.path.join(src, "prof_write", "**", "*counter_collection.csv"), "WRITE_SIZE")
+    fetch = collect(os.path.join(src, prefix + "_fetch", "**", "*counter_collection.csv"), "FETCH_SIZE")
+    write = collect(os.path.join(src, prefix + "_write", "**", "*counter_collection.csv"), "WRITE_SIZE")
     for k in sorted(set(fetch) | set(write)):
         d = {}
         for name, agg in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
@@ -48,11 +52,12 @@ def main():
             d["hbm_bytes_per_launch_corrected"] = ((2 if wide else 1) * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024
             d["fetch_correction"] = "x2 (16 B per lane reads, MI355X_MICROARCH.md)" if wide else "none (4 B per lane reads: uncalibrated width; with x2 the total would be %.0f bytes)" % ((2 * d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024)
         out[k] = d
-    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+    summary_name = "pmc_summary.json" if schema == "headline" else f"pmc_summary_{schema}.json"
+    json.dump(out, open(os.path.join(dst, summary_name), "w"), indent=1)
     roof = {}
     for k, d in out.items():
         if isinstance(d, dict) and "hbm_bytes_per_launch_corrected" in d:
-            if ("k_tick3<" in k or "ggrs_jit_tick" in k) and d.get("dispatches_FETCH_SIZE", 0) >= 20 and d.get("dispatches_FETCH_SIZE", 0) >= roof.get("_n", 0):
+            if "ggrs_jit_tick" in k and d.get("dispatches_FETCH_SIZE", 0) >= 20 and d.get("dispatches_FETCH_SIZE", 0) >= roof.get("_n", 0):
                 roof["_n"] = d["dispatches_FETCH_SIZE"]                # the kernel that served the bench's ticks: the one with the most dispatches
                 roof["k_tick_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
                 roof["kernel"] = k
@@ -60,9 +65,17 @@ def main():
                 roof["k_copy_state_hbm_bytes_per_launch"] = d["hbm_bytes_per_launch_corrected"]
     roof.pop("_n", None)
     if roof:
-        roof["source"] = os.path.join(dst, "pmc_summary.json")
-        roof["entities"] = 1000000; roof["depth"] = 8       # the workload scripts/gpu_round.sh profiles (bench.py defaults)
-        json.dump(roof, open(os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json"), "w"), indent=1)
+        roof["source"] = os.path.join(dst, summary_name)
+        roof["entities"] = 1000000; roof["depth"] = 8; roof["schema"] = schema       # the workload scripts/gpu_round4.sh profiles (bench.py defaults)
+        tpath = os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json")
+        try:
+            cur = json.load(open(tpath))
+        except Exception:
+            cur = {}
+        if "k_tick_hbm_bytes_per_launch" in cur:                                        # the round-3 flat form: one entry, the headline schema
+            cur = {cur.get("schema", "headline"): cur}
+        cur[schema] = roof
+        json.dump(cur, open(tpath, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
