@@ -268,7 +268,9 @@ class SpeculativeFanout:
         self.max_inflight = max_inflight                     # steps enqueued on the device before the oldest is collected
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.bpr = branches_per_rank
-        self.share_prefix = bool(share_prefix) and depth >= 1
+        # with ONE branch per rank there is nothing to share: the prefix as its own group would cost a second launch and a save / re-load of
+        # C+1 (measured: 62.7 -> 87 us per step at 1 M, profiles/r04d/bench_fanout_ws1.json), so the list stays one fused group
+        self.share_prefix = bool(share_prefix) and depth >= 1 and branches_per_rank > 1
         # SaveGameState requests of one step's list on this rank == Checksum(u128)s it contributes to the all-gather
         self.saves_per_step = 1 + branches_per_rank * (depth - 1) if self.share_prefix else branches_per_rank * depth
         self.branch_input, self.confirmed_input = branch_input, confirmed_input

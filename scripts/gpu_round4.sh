@@ -35,8 +35,8 @@ g++ -shared -fPIC -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/rccl_
 GGRS_RCCL_LIB=$PWD/tests/cpp/_build/librccl_double.so $B --gpus 2 --oversubscribe --steps 20 --warmup 5 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gpus2_oversubscribed.json; echo "bench --gpus 2 rc=$?"
 # ---- soak of the on-chip group fold under UNEVEN load: a 4 M world (group fold on) with its in-run oracle parity gate over 24 ticks, while a
 # second process streams the allhot world on the same GPU (the hand-off's failure modes only show under load, MI355X_MICROARCH.md)
-( $B --schema allhot --steps 3000 --no-cpu-baseline > $OUT/soak_background_allhot.json 2>> $OUT/bench.err & )
-sleep 4
+( $B --schema allhot --steps 400000 --no-cpu-baseline --preheat-ms 0 > $OUT/soak_background_allhot.json 2>> $OUT/bench.err & )
+sleep 12
 $B --entities 4000000 --steps 400 --cpu-ticks 1 --parity-ticks 24 > $OUT/soak_4000000_group_fold_under_load.json 2>> $OUT/bench.err; echo "soak rc=$?"
 GGRS_GROUP_FOLD_MIN_WGS=8 $B --entities 700000 --steps 600 --cpu-ticks 1 --parity-ticks 48 > $OUT/soak_700000_group_fold_under_load.json 2>> $OUT/bench.err; echo "soak2 rc=$?"
 wait; sleep 2
@@ -58,6 +58,7 @@ find $OUT -name '*.db' -size +20M -delete
 python - <<'PY'
 import json, glob, os
 for f in sorted(glob.glob(os.path.join("gpurun_out", os.environ.get("TAG", "r04"), "*.json"))):
+    if not os.path.basename(f).startswith(("bench", "soak")): continue
     try:
         j = json.loads(open(f).read().strip().splitlines()[-1])
         if "value" not in j: continue
