@@ -71,10 +71,10 @@ typedef struct {
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
 #define GGRS_WORLD_CONTIG_ARENA 32u  /* allocate the library-owned arena physically contiguous (hipDeviceMallocContiguous; the
-                                        particles worlds, up to 1.5 GiB): +2-3 % on k_tick3's dense nt store streams into
-                                        write-through memory -- i.e. without the run-time compiler or with
-                                        GGRS_ROW_VERSIONS=0; the generated kernel (the default) is FASTER on plain pages (1 M:
-                                        169 vs 149 G entity-frames/s).  OPT-IN, with two rules the library enforces itself
+                                        particles worlds, up to 1.5 GiB): write-through memory.  It paid +2-3 % for
+                                        round 3's hand-written k_tick3 (removed in round 4); the generated kernel that serves every
+                                        world now is FASTER on plain pages (1 M: 169 vs 149 G entity-frames/s), so nothing in the
+                                        library asks for it any more.  OPT-IN, with two rules the library enforces itself
                                         (profiles/README.md r03fc, tests/test_gpu_contig_arena.py):
                                         - a contiguous arena is never handed back while the process lives.  After hipFree of
                                           such an allocation the runtime stops ordering the kernels of LATER worlds on the
