@@ -1,14 +1,14 @@
 #!/bin/bash
-# round 3: counter passes of the three fused kernels on the headline world with row versions on (320 B/entity-tick)
+# counter passes (9 rocprofv3 --pmc runs each, scripts/pmc_passes.py) of the generated kernel's two forms on the headline world (320 B/entity-tick);
+# round 3 ran a third arm, k_tick3, which no longer exists (profiles/r03p)
 set -u
-TAG=${1:-r03p}; OUT=gpurun_out/$TAG; mkdir -p $OUT/tick3 $OUT/jit_tiles $OUT/jit_persist; export TMPDIR=/tmp
+TAG=${1:-r03p}; OUT=gpurun_out/$TAG; mkdir -p $OUT/jit_tiles $OUT/jit_persist; export TMPDIR=/tmp
 timeout 120 rocprofv3 -L > $OUT/counters.txt 2>&1
 timeout 600 python -m pytest tests/test_gpu_schema.py -x -q -m gpu > $OUT/pytest_schema.log 2>&1; tail -3 $OUT/pytest_schema.log
-for v in tick3 jit_tiles jit_persist; do
+for v in jit_tiles jit_persist; do
   case $v in
-    tick3) ENVV="";;
-    jit_tiles) ENVV="GGRS_TICK_GENERIC=1 GGRS_JIT_PERSIST_MIN_SLOTS=0";;
-    jit_persist) ENVV="GGRS_TICK_GENERIC=1";;
+    jit_tiles) ENVV="GGRS_JIT_PERSIST_MIN_SLOTS=0";;
+    jit_persist) ENVV="GGRS_JIT_PERSIST_MIN_SLOTS=1";;
   esac
   echo "== $v: $(env $ENVV timeout 120 benches/tick_bench 1000000 8 100 16 0 0 1 2>&1 | tail -n 1 | cut -c1-300)" | tee -a $OUT/plain.txt
   env $ENVV PMC_MAX_PASSES=9 timeout 900 python scripts/pmc_passes.py $OUT/$v $OUT/counters.txt -- ./benches/tick_bench 1000000 8 40 8 0 1 1 > $OUT/${v}_passes.log 2>&1
@@ -16,7 +16,7 @@ for v in tick3 jit_tiles jit_persist; do
 done
 python - <<'PY'
 import json
-for v in ("tick3","jit_tiles","jit_persist"):
+for v in ("jit_tiles","jit_persist"):
     try:
         j=json.load(open(f"gpurun_out/%s/%s/pmc_counters.json" % (__import__("os").environ.get("TAG","r03p"), v)))
     except Exception as e:

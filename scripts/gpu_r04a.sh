@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the two full-copy lines below drove GGRS_TICK_GENERIC / k_tick3, which the commit after this run removed)
 # Round 4, first GPU call: the suite on the new code (group fold, allhot schema, bench.py --gpus 2 over the transport double), then
 # A/B of the group fold (GGRS_GROUP_FOLD_MIN_WGS=0 = round-3 behaviour) in the async and blocking host APIs, the all-columns-hot world,
 # the N = 2 line at 1 M, 2 M / 4 M.   Usage: gpurun -- 'bash scripts/gpu_r04a.sh [tag]'

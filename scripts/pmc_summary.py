@@ -45,7 +45,7 @@ def main():
                 d[name + "_KiB_mean"] = sum(v) / len(v)
                 d["dispatches_" + name] = len(agg[k])
         if "FETCH_SIZE_KiB_mean" in d and "WRITE_SIZE_KiB_mean" in d:
-            # the x2 FETCH correction is the guide's calibration for WIDE (16 B per lane) coalesced reads: k_tick3 / k_copy_state.  The
+            # the x2 FETCH correction is the guide's calibration for WIDE (16 B per lane) coalesced reads: k_copy_state (and round 3's k_tick3).  The
             # generated kernel reads 4 bytes per lane (uncalibrated width): its FETCH_SIZE is reported as is AND doubled, and only
             # WRITE_SIZE (calibrated against a known snapshot copy) is relied on -- reads are 10 % of its traffic.
             wide = "ggrs_jit" not in k
