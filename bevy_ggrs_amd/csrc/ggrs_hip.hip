@@ -678,6 +678,9 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
         f += host ? (host_blocking ? "the host folds the rows at collect time (blocking calls too)" : "the host folds the rows at collect time (blocking calls: k_gen_finalize)")
                   : "k_gen_finalize";
         add("checksum_fold", f);
+        bool any_spawn = false;
+        for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN;
+        if (any_spawn) add("spawn_system", w->jit_spawn_sys >= 0 ? "runs inside the request group (rows appended by the group's launch)" : "ends the request group (its own launches)");
     }
     add("slots_covered", std::to_string(cover));
     add("row_versions", w->knobs.row_versions ? "on" : "off (GGRS_ROW_VERSIONS=0)");

@@ -194,6 +194,19 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     return s->spec->state.load(std::memory_order_acquire) == 2 ? s->spec->fn : nullptr;
 }
 
+inline ggrs_world::HostFold make_host_fold(const GgrsJitArgs& j, uint32_t res_slot, uint32_t rows, uint32_t n_cks, uint32_t members, uint64_t rows_off) {
+    ggrs_world::HostFold f{}; f.res_slot = res_slot; f.n_saves = j.n_saves; f.g = rows; f.n_cks = n_cks; f.members = members; f.rows_off = rows_off;
+    for (uint32_t k = 0; k < j.n_saves && k < (uint32_t)MAX_TICK_SAVES; ++k) f.save_len[k] = j.save_len[k];
+    return f;
+}
+inline GenFinArgs make_gen_fin(const GgrsJitArgs& j, uint32_t rows, uint32_t n_cks, uint64_t* out) {
+    GenFinArgs f; memset(&f, 0, sizeof f);
+    f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = rows; f.n_cks = n_cks; f.n_saves = std::max(1u, j.n_saves);
+    for (uint32_t k = 0; k < j.n_saves && k < (uint32_t)MAX_TICK_SAVES; ++k) f.save_len[k] = j.save_len[k];
+    f.out = out;
+    return f;
+}
+
 struct JitBatch {
     bool active = false; GgrsJitArgs j; uint32_t g = 0, k = 0, res_first = 0, n_cks = 0;
     void start(const GgrsJitArgs& j_, uint32_t g_, uint32_t res, uint32_t n_cks_) { active = true; j = j_; g = g_; k = 1; res_first = res; n_cks = n_cks_; }
@@ -203,6 +216,8 @@ struct JitBatch {
             memcmp(b.step_frame, j.step_frame, sizeof b.step_frame) != 0 || memcmp(b.step_confirmed, j.step_confirmed, sizeof b.step_confirmed) != 0 ||
             memcmp(b.step_flags, j.step_flags, sizeof b.step_flags) != 0) return false;
         if (w->jit_reads_inputs && (memcmp(b.inputs, j.inputs, sizeof b.inputs) != 0 || memcmp(b.n_inputs, j.n_inputs, sizeof b.n_inputs) != 0)) return false;
+        if (memcmp(b.spawn_count, j.spawn_count, sizeof b.spawn_count) != 0 || memcmp(b.save_len, j.save_len, sizeof b.save_len) != 0) return false;
+        for (uint32_t q = 0; q < b.n_steps; ++q) if (b.spawn_count[q]) return false;      // (same counts, but the staged payloads are not compared)
         if ((k + 1) * j.n_saves > w->gen_parts_saves || res != res_first + k * j.n_saves) return false;
         ++k;
         return true;
@@ -221,10 +236,8 @@ struct JitBatch {
             { const int lrc = launch_jit(w, w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), params,
                                          rows_bytes_per_slot(w, j.load_rows) * j.len * k); if (lrc) return lrc; }
         }
-        if (host_fold) { w->folds.push_back({res_first, j.n_saves, g, n_cks, k, rows_off, j.len}); return GGRS_OK; }
-        GenFinArgs f; memset(&f, 0, sizeof f);
-        f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = g; f.n_cks = n_cks; f.total_len = j.len;   // one row per workgroup
-        f.out = w->d_results + 2 * (uint64_t)res_first;
+        if (host_fold) { w->folds.push_back(make_host_fold(j, res_first, g, n_cks, k, rows_off)); return GGRS_OK; }
+        GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)res_first);   // one row per workgroup
         {
             ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
             hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
@@ -248,12 +261,14 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         const ggrs_request* spawn_req = nullptr;
         rc = group_open(w, reqs, i, gs); if (rc) return rc;
         j.src_is_live = gs.src_is_live;
+        const uint64_t len_start = w->len;                              // the source block's len: a fused spawn grows w->len while the group is assembled
         while (i < n && j.n_ops < (uint32_t)MAX_TICK_OPS) {
             const ggrs_request& r = reqs[i];
             if (r.kind == GGRS_REQ_LOAD) break;
             if (r.kind == GGRS_REQ_SAVE) {
                 if (j.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + j.n_saves == w->max_results)) break;
                 rc = group_save(w, gs, j.n_saves, j.save_dst, j.save_frame); if (rc) return rc;
+                j.save_len[j.n_saves] = w->len;
                 ++j.n_ops; ++j.n_saves;
             } else if (r.kind == GGRS_REQ_ADVANCE) {
                 if (j.n_steps == (uint32_t)MAX_TICK_STEPS) break;
@@ -269,9 +284,26 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 }
                 j.n_inputs[j.n_steps] = (uint8_t)r.n_inputs;
                 for (uint32_t k = 0; k < r.n_inputs; ++k) j.inputs[j.n_steps][k] = r.inputs[k];
+                const uint32_t step = j.n_steps;
                 ++j.n_steps;
                 j.op_bits |= 1ULL << j.n_ops; ++j.n_ops;
-                if (advance_spawns(w, r)) { spawn_req = &r; ++i; break; }
+                if (advance_spawns(w, r)) {
+                    // The spawn system fires.  Fused (kernel_gen.hpp): the step's launch appends the rows itself -- the payload is staged now, the
+                    // host does in request order what run_spawn_systems does around its kernel (capacity, versions of the bundle, len) and the
+                    // group goes on.  Otherwise (no fusable spawn system, or no room left in the staging buffer without waiting for the
+                    // stream) the group ends here and the spawn runs as its own launches, as Bevy's Commands flush ends the schedule.
+                    const bool room = w->stage_used + 2 * r.spawn_count <= w->stage_floats;
+                    if (w->jit_spawn_sys >= 0 && room && r.spawn_count <= 0xFFFFFFFFull) {
+                        if (w->len + r.spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)r.spawn_count, (unsigned long long)w->capacity);
+                        const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
+                        float *dvx = nullptr, *dvy = nullptr;
+                        rc = stage_floats(w, r.spawn_vx, r.spawn_count, &dvx); if (rc) return rc;
+                        rc = stage_floats(w, r.spawn_vy, r.spawn_count, &dvy); if (rc) return rc;
+                        j.spawn_vx[step] = dvx; j.spawn_vy[step] = dvy; j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
+                        ver_touch_comp(w, sd.comp[0]); ver_touch_comp(w, sd.comp[1]); ver_touch_comp(w, sd.comp[2]);   // new rows in every column (and the presence mask) of the bundle
+                        w->len += r.spawn_count;
+                    } else { spawn_req = &r; ++i; break; }
+                }
             } else {
                 return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
             }
@@ -292,7 +324,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         }
         if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows);
-        j.src = gs.src->ptr; j.live = w->live.ptr; j.len = w->len;
+        j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
@@ -371,11 +403,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 w->batch_ev_attached = done != nullptr;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
-            if (host_fold) { w->folds.push_back({res_base + ns, j.n_saves, rows, n_cks, 1u, rows_off, w->len}); ns += j.n_saves; }
+            if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, rows, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {
-                GenFinArgs f; memset(&f, 0, sizeof f);
-                f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = rows; f.n_cks = n_cks; f.total_len = w->len;   // one row per workgroup (per group of 64 with the group fold)
-                f.out = w->d_results + 2 * (uint64_t)(res_base + ns);
+                GenFinArgs f = make_gen_fin(j, rows, n_cks, w->d_results + 2 * (uint64_t)(res_base + ns));   // one row per workgroup (per group of 64 with the group fold)
                 {
                     ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
                     hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves), dim3(FIN_TPB), 0, w->stream, f);

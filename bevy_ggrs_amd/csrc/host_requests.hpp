@@ -500,7 +500,7 @@ void run_host_folds(ggrs_world* w, uint32_t n) {
                     const uint64_t* row = w->h_rows + f.rows_off + ((uint64_t)(m * f.n_saves + sv) * nc + c) * f.g;
                     uint64_t x = 0, sum = 0;
                     for (uint32_t t = 0; t < f.g; ++t) { x ^= row[t]; sum += row[t]; }
-                    total ^= c == f.n_cks ? sea_pair(sum, f.total_len) : sea_one(x);
+                    total ^= c == f.n_cks ? sea_pair(sum, f.save_len[sv]) : sea_one(x);
                 }
                 uint64_t* out = w->h_results + 2 * (uint64_t)(f.res_slot + m * f.n_saves + sv);
                 out[0] = total; out[1] = 0;

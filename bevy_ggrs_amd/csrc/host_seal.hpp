@@ -115,7 +115,7 @@ int seal_impl(ggrs_world* w) {
     recognise_particles(w);
 
     // ---- the kernel generated for this world (kernel_gen.hpp): every world it covers, unless groups are off
-    w->gen_ok = false; w->jit_box_sys = -1; w->jit_marks = false; w->jit_reads_inputs = false;
+    w->gen_ok = false; w->jit_box_sys = -1; w->jit_marks = false; w->jit_reads_inputs = false; w->jit_spawn_sys = -1;
     if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && !w->knobs.tick_jit) w->jit_status = "disabled (GGRS_TICK_JIT=0)";
     if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && w->knobs.tick_jit) {
         std::string src;
@@ -156,6 +156,8 @@ int seal_impl(ggrs_world* w) {
                 if (d.kind == GGRS_SYS_BOX_MOVE) w->jit_box_sys = (int)i;
             }
             w->gen_ok = true;
+            // the spawn system runs inside request groups unless the persistent form may serve them (it folds with ONE len) or the knob says no
+            if (!w->jit_fn_persist && w->knobs.jit_fuse_spawn) w->jit_spawn_sys = jit_fused_spawn_system(w);
         }
     }
     if (w->custom_hashers && !w->gen_ok)

@@ -54,6 +54,7 @@ struct Knobs {
                                    //                       the host -- or k_gen_finalize -- reads 1/64 of the rows, blocking calls included (0: never).  The in-launch hand-off
                                    //                       costs a constant 3-4.5 us at the end of the launch (profiles/r04b): it pays from ~3 M slots up, where the host's fold of
                                    //                       one row per workgroup (3 MB per tick at 4 M) no longer hides behind the next tick's kernel
+    bool jit_fuse_spawn = true;    // GGRS_JIT_FUSE_SPAWN=0  a firing spawn system ends the request group (k_spawn_particles + mask edits as their own launches: rounds 1-3)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
     uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
@@ -89,6 +90,7 @@ struct Knobs {
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
         k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
         k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 12288)));
+        k.jit_fuse_spawn = num("GGRS_JIT_FUSE_SPAWN", 1) != 0;
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
         k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
@@ -173,6 +175,7 @@ struct ggrs_world {
     bool jit_marks = false;              // the generated kernel keeps the RollbackDespawned markers (a system may defer a despawn)
     bool jit_reads_inputs = false;       // a system reads PlayerInputs (BOX_MOVE, custom): branches with different inputs differ
     int jit_box_sys = -1;                // index of a BOX_MOVE system (its FRICTION.powf(dt) is evaluated per step on the host)
+    int jit_spawn_sys = -1;              // index of the PARTICLES_SPAWN system the generated kernel runs inside request groups (kernel_gen.hpp jit_fused_spawn_system); -1: a firing spawn ends the group
     uint32_t gen_parts_saves = 0;        // Save rows of d_gen_parts (room for a batch of checksum-only groups in small worlds)
     bool layout_only = false;            // GGRS_WORLD_LAYOUT_ONLY: no device behind this world
     bool sealed = false;
@@ -245,7 +248,7 @@ struct ggrs_world {
     // Host-side checksum fold of small worlds (generated kernel): its workgroups write their partial rows straight into pinned,
     // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected -- a
     // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.
-    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off, total_len; };
+    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off; uint64_t save_len[16]; };   // save_len[k]: RollbackOrdered::len at Save k (a fused spawn grows it inside a group)
     std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
     uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
     hipEvent_t batch_ev = nullptr; bool batch_ev_attached = false;   // enqueue: the batch's event, offered to the list's last kernel launch (launch_jit)

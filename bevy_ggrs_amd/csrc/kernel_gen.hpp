@@ -150,6 +150,8 @@ static const char kJitPrelude[] =
     "    ggrs_u32 n_units, cached_saves;\n" \
     "    ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;\n" \
     "    ggrs_u64* gf_rows; ggrs_u32* gf_tickets;\n" \
+    "    ggrs_u64 save_len[16];\n" \
+    "    const float* spawn_vx[24]; const float* spawn_vy[24]; ggrs_u64 spawn_first[24]; ggrs_u32 spawn_count[24];\n" \
     "};\n"
 struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
@@ -169,6 +171,12 @@ struct GgrsJitArgs {
     // (dispatch order) in device memory (gf_rows, [group][n_saves x (n_cks + 1)], zero between launches) and takes the group's ticket; the
     // last arriver hands the row to `parts` (column = group): the consumer -- the host, or k_gen_finalize -- reads 1/64 of the rows
     ggrs_u64* gf_rows; ggrs_u32* gf_tickets;
+    // A spawn system that fires inside the group (particles.rs:258-270; worlds with exactly one GGRS_SYS_PARTICLES_SPAWN): step j appends
+    // spawn_count[j] rows at slots [spawn_first[j], +count) -- RollbackOrdered's next indices -- with velocities from the staged payload, AFTER
+    // the step's other systems (Bevy applies Commands at the end of the schedule).  len therefore grows inside a group: save_len[k] is
+    // RollbackOrdered::len at Save k (Header::len of the snapshot, the second operand of the entity checksum), `len` the source block's.
+    ggrs_u64 save_len[16];
+    const float* spawn_vx[24]; const float* spawn_vy[24]; ggrs_u64 spawn_first[24]; ggrs_u32 spawn_count[24];
 };
 static_assert(MAX_TICK_SAVES == 16 && MAX_TICK_STEPS == 24, "GgrsJitArgs is sized for 16 Saves / 24 steps per group");
 constexpr uint32_t JIT_MAX_UNITS = 64;       // 4-byte register units per slot the generated kernel may hold
@@ -258,8 +266,25 @@ inline bool jit_lane_fold(const ggrs_world* w, uint32_t n_cks) {
     return w->knobs.jit_lane_fold >= 0 ? w->knobs.jit_lane_fold != 0 : w->cap_pad >= JIT_LANE_FOLD_MIN_SLOTS;
 }
 inline uint32_t jit_lane_fold_bytes(const ggrs_world* w, uint32_t n_cks, uint32_t n_saves) { return jit_lane_fold(w, n_cks) ? n_saves * n_cks * 512u : 0u; }
+// The world's spawn system, when the generated kernel can run it INSIDE a request group (a firing spawn system otherwise ends the
+// group: Bevy applies Commands at the end of the schedule): exactly one GGRS_SYS_PARTICLES_SPAWN over three distinct rollback
+// components -- a Transform-like one whose words take their registered defaults, a Velocity-like one of >= 3 four-byte words, a Ttl of
+// one 8-byte word.  -1: none / not fusable.
+int jit_fused_spawn_system(const ggrs_world* w) {
+    int found = -1;
+    for (size_t i = 0; i < w->systems.size(); ++i) if (w->systems[i].kind == GGRS_SYS_PARTICLES_SPAWN) { if (found >= 0) return -1; found = (int)i; }
+    if (found < 0) return -1;
+    const ggrs_system_desc& d = w->systems[found];
+    const uint32_t nc = (uint32_t)w->comps.size();
+    for (int k = 0; k < 3; ++k) if (d.comp[k] >= nc || w->comps[d.comp[k]].no_rollback) return -1;
+    if (d.comp[0] == d.comp[1] || d.comp[0] == d.comp[2] || d.comp[1] == d.comp[2]) return -1;
+    const Comp& V = w->comps[d.comp[1]]; const Comp& L = w->comps[d.comp[2]];
+    if (V.word_bytes != 4 || V.n_words < 3 || L.word_bytes != 8 || L.n_words < 1) return -1;
+    return found;
+}
 bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     const uint32_t nc = (uint32_t)w->comps.size();
+    const int spawn_sys = persist ? -1 : jit_fused_spawn_system(w);     // (the persistent form folds with ONE len: a spawn still ends its groups)
     uint32_t units = 0, ncols = 0;
     for (auto& c : w->comps) { ncols += c.n_words; if (!c.no_rollback) units += c.n_words * std::max(1u, c.word_bytes / 4); }
     if (units == 0 || units > JIT_MAX_UNITS || ncols > JIT_MAX_COLS) return false;
@@ -372,7 +397,7 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
               "    if (!pad_wg) {\n"
               "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
-            "    const bool in_len = (uint64_t)gu * 64u < a.len;                           // wave-uniform\n"
+            "    %sbool in_len = (uint64_t)gu * 64u < a.len;                                 // wave-uniform%s\n"
             "    // word c of slot e lives at col_off[c] + (e >> 13) * tile_stride + (e & 8191) * word_bytes: the layout tile is the\n"
             "    // wave's (uniform: SGPRs), the lane contributes one 32-bit offset per word size -> saddr-form accesses\n"
             "    const uint64_t tbase = (uint64_t)(gu >> %d) * %uull;\n"
@@ -380,13 +405,13 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             "    (void)lo1; (void)lo2; (void)lo4; (void)lo8;\n"
             "    const uint64_t wi8 = (uint64_t)gu * 8u;                                    // byte offset of this wave's mask word: bit `lane` is this slot\n"
             "    const uint32_t sh = lane;\n",
-         LT_SHIFT - 6, w->ts, (unsigned)(LAYOUT_TILE / 64 - 1));
+         spawn_sys >= 0 ? "" : "const ", spawn_sys >= 0 ? " (a spawn inside the group grows len)" : "", LT_SHIFT - 6, w->ts, (unsigned)(LAYOUT_TILE / 64 - 1));
     // ---- masks and words of the lane's slot
     sfmt(s, "    const uint64_t mk_alive = *reinterpret_cast<const uint64_t*>(a.src + %lluull + wi8);\n"
             "    bool alive_0 = (mk_alive >> sh) & 1ull;\n", OFF_ALIVE);
     for (uint32_t c = 0; c < nc; ++c) if (rb(c))
         sfmt(s, "    const uint64_t mk%u = *reinterpret_cast<const uint64_t*>(a.src + %lluull + wi8);\n"
-                "    const bool p%u_0 = (mk%u >> sh) & 1ull;\n", c, (unsigned long long)w->off_present[c], c, c);
+                "    %sbool p%u_0 = (mk%u >> sh) & 1ull;\n", c, (unsigned long long)w->off_present[c], spawn_sys >= 0 ? "" : "const ", c, c);
     auto wtype = [&](uint32_t c) { return w->comps[c].word_bytes == 8 ? "uint64_t" : "uint32_t"; };                    // register type
     auto mtype = [&](uint32_t c) { const uint32_t b = w->comps[c].word_bytes; return b == 8 ? "uint64_t" : (b == 4 ? "uint32_t" : (b == 2 ? "uint16_t" : "uint8_t")); };   // memory type
     for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
@@ -436,12 +461,16 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             emit_words_out(dst, mask, in3.c_str(), false);
             sfmt(s, "%s}\n", in2.c_str());
         } else emit_words_out(dst, mask, in2.c_str(), false);
-        sfmt(s, "%s}\n%sif (lane == 0) {\n%s    *reinterpret_cast<uint64_t*>(%s + %lluull + wi8) = %s;\n", indent, indent, indent, dst, OFF_ALIVE, alive_word);
-        // presence masks change on the host only (spawn, insert, remove, load, adopt): they carry versions like the columns, and a
-        // mask the destination already holds is not stored again (8-byte single-lane stores into lines nothing else of the launch
-        // touches: 2-5 % of a depth-8 tick at 1 M, 8 % at 4 M, profiles/r03n)
+        sfmt(s, "%s}\n", indent);
+        // a spawn inside the group sets presence bits of its bundle: the mask words are then rebuilt from the lanes (as the liveness word
+        // always is); without a fusable spawn system only the host changes them and the word read from the source is what is stored
+        if (spawn_sys >= 0) for (uint32_t c = 0; c < nc; ++c) if (rb(c)) sfmt(s, "%sconst uint64_t pm%u = __ballot(p%u_0);\n", indent, c, c);
+        sfmt(s, "%sif (lane == 0) {\n%s    *reinterpret_cast<uint64_t*>(%s + %lluull + wi8) = %s;\n", indent, indent, dst, OFF_ALIVE, alive_word);
+        // presence masks change on the host (spawn, insert, remove, load, adopt) or through a fused spawn: they carry versions like the
+        // columns, and a mask the destination already holds is not stored again (8-byte single-lane stores into lines nothing else of
+        // the launch touches: 2-5 % of a depth-8 tick at 1 M, 8 % at 4 M, profiles/r03n)
         for (uint32_t c = 0; c < nc; ++c) if (rb(c))
-            sfmt(s, "%s    if ((%s >> %uu) & 1u) *reinterpret_cast<uint64_t*>(%s + %lluull + wi8) = mk%u;\n", indent, pmask, c, dst, (unsigned long long)w->off_present[c], c);
+            sfmt(s, "%s    if ((%s >> %uu) & 1u) *reinterpret_cast<uint64_t*>(%s + %lluull + wi8) = %s%u;\n", indent, pmask, c, dst, (unsigned long long)w->off_present[c], spawn_sys >= 0 ? "pm" : "mk", c);
         sfmt(s, "%s}\n", indent);
     };
     s += "    if (in_len) {\n";
@@ -500,7 +529,7 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
          "                const uint64_t rows = a.save_rows[si];\n";
     emit_store("dst", "rows", "a.save_pmask[si]", "alive_now", "                ", true);
     s += "                if (gu == 0 && lane == 0) {\n"
-         "                    Header h; h.len = a.len; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
+         "                    Header h; h.len = a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
          "                    *reinterpret_cast<Header*>(dst) = h;\n"
          "                }\n"
          "            }\n";
@@ -612,6 +641,30 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         } break;
         default: break;
         }
+    }
+    if (spawn_sys >= 0) {
+        // spawn_particles (particles.rs:258-270), applied where Bevy applies its Commands: after the step's other systems.  The new rows are
+        // RollbackOrdered's next indices == the next slots; a lane whose slot falls into the range takes the bundle: Transform's registered
+        // defaults, Velocity (vx, vy, 0) from the staged payload, Ttl = iparam[0]; liveness and the bundle's presence bits are set
+        const ggrs_system_desc& d = w->systems[spawn_sys];
+        const Comp& T = w->comps[d.comp[0]];
+        s += "            if (a.spawn_count[sj]) {                                                   // wave-uniform\n"
+             "                const uint64_t sf_ = a.spawn_first[sj], sn_ = a.spawn_count[sj];\n"
+             "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
+             "                    alive_0 = true;\n";
+        sfmt(s, "                    p%u_0 = true; p%u_0 = true; p%u_0 = true;\n", d.comp[0], d.comp[1], d.comp[2]);
+        for (uint32_t k = 0; k < T.n_words; ++k) {
+            unsigned long long v = 0;
+            if (T.defaults.size() >= (size_t)(k + 1) * T.word_bytes) memcpy(&v, &T.defaults[(size_t)k * T.word_bytes], T.word_bytes);
+            sfmt(s, "                    w%u_0 = (%s)0x%llxull;\n", col(d.comp[0], k), wtype(d.comp[0]), v);
+        }
+        sfmt(s, "                    w%u_0 = __float_as_uint(a.spawn_vx[sj][e0 - sf_]); w%u_0 = __float_as_uint(a.spawn_vy[sj][e0 - sf_]); w%u_0 = 0u;\n",
+             col(d.comp[1], 0), col(d.comp[1], 1), col(d.comp[1], 2));
+        sfmt(s, "                    w%u_0 = %lluull;\n", col(d.comp[2], 0), (unsigned long long)d.iparam[0]);
+        if (marks) s += "                    dis_0 = false;\n";
+        s += "                }\n"
+             "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n"
+             "            }\n";
     }
     s += "            ++sj;\n"
          "        }\n"

@@ -651,8 +651,8 @@ __global__ __launch_bounds__(TPB) void k_spawn_particles(SpawnArgs a) {
 // ------------------------------------------------------------------ k_gen_finalize
 // Fold of k_tick_gen's per-wave partials: one 1024-thread workgroup per Save; any number of checksummed components.
 struct GenFinArgs {
-    const uint64_t* parts; uint32_t part_stride, n_parts, n_cks, pad;
-    uint64_t total_len;
+    const uint64_t* parts; uint32_t part_stride, n_parts, n_cks, n_saves;     // grid = n_saves x members (batch of identical groups)
+    uint64_t save_len[MAX_TICK_SAVES];                                        // RollbackOrdered::len at each Save of the group (a fused spawn grows it)
     uint64_t* out;
 };
 __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
     if (tid == 0) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < f.n_cks; ++c) total ^= sea_one(acc[c]);      // component_checksum.rs:92-95
-        total ^= sea_pair(acc[f.n_cks], f.total_len);                        // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
+        total ^= sea_pair(acc[f.n_cks], f.save_len[k % f.n_saves]);          // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
         f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
     }
 }

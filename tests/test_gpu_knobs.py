@@ -23,6 +23,7 @@ KNOBS = [
     {"GGRS_GROUP_FOLD_MIN_WGS": "0"},                       # no group fold: one row per workgroup leaves the kernel at every size
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0"},   # group fold even for the 10 k world (one group of 56 workgroups incl. a padding one)
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0", "GGRS_HOST_FOLD_MAX_WGS": "0"},   # ... with the groups' rows staying on the device (k_gen_finalize over rows / 64)
+    {"GGRS_JIT_FUSE_SPAWN": "0"},                          # a firing spawn system ends the request group (rounds 1-3: k_spawn_particles + mask edits as their own launches)
     {"GGRS_DEAD_GROUPS": "0"},
     {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
     {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "64", "GGRS_JIT_PERSIST_TPB": "256"},  # ... and one whose grid must be clamped to tick_fold's row buffer
@@ -94,6 +95,8 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
     if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
     if not env: assert info["checksum_fold"].startswith("the host folds"), info           # (the group fold's default range starts at 12288 workgroups: test_group_fold_default_range)
+    if env.get("GGRS_TICK_JIT") != "0" and "GGRS_JIT_PERSIST_MIN_SLOTS" not in env:
+        assert info["spawn_system"].startswith("ends the request group" if env.get("GGRS_JIT_FUSE_SPAWN") == "0" else "runs inside"), info
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "0": assert "group fold" not in info["checksum_fold"], info
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
     if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
