@@ -687,15 +687,33 @@ def main():
         for _ in range(W):
             fan.step_pipelined(want_result=False)
         fan.drain(want_result=False)
+        # pre-heat: EVERY rank must run the same number of steps -- the all-gathers pair up by order, and a rank that left a clock-based loop
+        # a few steps early would pair its closing (partial) group with another rank's full one (found by the two-rank GPU test in round 4:
+        # a DesyncDetected whose "wrong" checksum was the right one of a frame 8 steps later).  So: time a short calibration run, agree on
+        # the slowest rank's step time, and derive ONE step count from the requested wall time.
         pre_t0 = time.perf_counter(); pre_n = 0
-        while (time.perf_counter() - pre_t0) * 1e3 < args.preheat_ms:
-            fan.step_pipelined(want_result=False); pre_n += 1
-        fan.drain(want_result=False)
-        m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms}}
+        if args.preheat_ms > 0:
+            calib = 20
+            tc = time.perf_counter()
+            for _ in range(calib):
+                fan.step_pipelined(want_result=False)
+            fan.drain(want_result=False)
+            tstep = torch.tensor([(time.perf_counter() - tc) / calib], dtype=torch.float64, device=ctl_dev)
+            dist.all_reduce(tstep, op=dist.ReduceOp.MAX)
+            pre_n = calib + int(min(200_000, max(0, args.preheat_ms * 1e-3 / max(float(tstep.item()), 1e-6) - calib)))
+            for _ in range(pre_n - calib):
+                fan.step_pipelined(want_result=False)
+            fan.drain(want_result=False)
+        m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "same_step_count_on_every_rank": True}}
         # parity gate: the gathered table (every rank's every branch) of the first P timed steps stays as raw u64 arrays and is
         # compared on rank 0, after the clock stops, with a serial walk of the same branches on the CPU oracle
         P_fan = 0 if (args.no_cpu_baseline or args.no_checksum) else max(0, min(K, args.parity_steps if args.parity_steps >= 0 else max(1, 16 // max(1, world_size * args.branches))))
         c_timed = fan.confirmed
+        cf = torch.tensor([c_timed, -c_timed], dtype=torch.int64, device=ctl_dev)
+        dist.all_reduce(cf, op=dist.ReduceOp.MAX)                # max(C) == -max(-C): every rank enters the timed region at the same confirmed frame
+        if int(cf[0].item()) != -int(cf[1].item()):
+            print(f"bench.py: rank {rank} is at confirmed frame {c_timed}, another rank at {int(cf[0].item())} / {-int(cf[1].item())}: the ranks ran different step counts", file=sys.stderr)
+            sys.exit(3)
         fan.raw, fan.raw_keep = [], (P_fan if rank == 0 else 0)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
