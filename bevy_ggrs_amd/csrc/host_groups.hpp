@@ -296,10 +296,14 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                     if (w->jit_spawn_sys >= 0 && room && r.spawn_count <= 0xFFFFFFFFull) {
                         if (w->len + r.spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)r.spawn_count, (unsigned long long)w->capacity);
                         const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
-                        float *dvx = nullptr, *dvy = nullptr;
-                        rc = stage_floats(w, r.spawn_vx, r.spawn_count, &dvx); if (rc) return rc;
-                        rc = stage_floats(w, r.spawn_vy, r.spawn_count, &dvy); if (rc) return rc;
-                        j.spawn_vx[step] = dvx; j.spawn_vy[step] = dvy; j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
+                        // the payload goes into the pinned, device-mapped staging buffer and the launch reads it from there (a few hundred bytes
+                        // per step over PCIe): no copy command per spawning step -- 2 x 8 of them per branch cost a 256-branch fan-out step
+                        // 20 ms of host time (profiles/r04e).  The region is recycled when every batch has been collected, like the copies' was.
+                        float* const hx = w->h_stage + w->stage_used; float* const hy = hx + r.spawn_count;
+                        memcpy(hx, r.spawn_vx, r.spawn_count * 4); memcpy(hy, r.spawn_vy, r.spawn_count * 4);
+                        j.spawn_vx[step] = w->d_hstage + w->stage_used; j.spawn_vy[step] = w->d_hstage + w->stage_used + r.spawn_count;
+                        w->stage_used += 2 * r.spawn_count;
+                        j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
                         ver_touch_comp(w, sd.comp[0]); ver_touch_comp(w, sd.comp[1]); ver_touch_comp(w, sd.comp[2]);   // new rows in every column (and the presence mask) of the bundle
                         w->len += r.spawn_count;
                     } else { spawn_req = &r; ++i; break; }

@@ -31,7 +31,7 @@ int seal(ggrs_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_gf_acc = nullptr; w->d_gf_out = nullptr; w->d_gf_tickets = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
-    if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; }
+    if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; w->d_hstage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
     arena_release(w);
     (void)hipGetLastError();
@@ -238,7 +238,8 @@ int seal_impl(ggrs_world* w) {
     // no device->host copy node per request list, one stream sync makes them visible.
     HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
-    HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes));
+    HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes, hipHostMallocMapped));       // pinned AND device-mapped: a fused spawn's payload is read by the group's launch straight from here
+    HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_hstage, w->h_stage, 0));
     if (w->jit_fn && w->knobs.host_fold_max_wgs) {
         w->rows_cap = 1u << 20;                                    // 8 MiB of partial rows between two collects
         HIPCHK(w, hipHostMalloc((void**)&w->h_rows, w->rows_cap * 8, hipHostMallocMapped));

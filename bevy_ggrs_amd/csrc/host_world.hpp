@@ -214,7 +214,7 @@ struct ggrs_world {
     uint64_t* d_results = nullptr; uint64_t* h_results = nullptr; uint32_t max_results = 0;
     UnitDesc* d_units = nullptr;
     uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
-    float* d_stage = nullptr; float* h_stage = nullptr; uint64_t stage_floats = 0, stage_used = 0;
+    float* d_stage = nullptr; float* h_stage = nullptr; float* d_hstage = nullptr; uint64_t stage_floats = 0, stage_used = 0;   // d_hstage: h_stage as the device sees it (zero-copy payloads of fused spawns)
 
     // ---- checksum specs (device view)
     std::vector<uint32_t> cks_comp;      // checksummed component ids in id order
