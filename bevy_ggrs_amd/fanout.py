@@ -275,6 +275,7 @@ class SpeculativeFanout:
         self.saves_per_step = 1 + branches_per_rank * (depth - 1) if self.share_prefix else branches_per_rank * depth
         self.branch_input, self.confirmed_input = branch_input, confirmed_input
         self.spawn_fn, self.spawn_mask = spawn_fn, spawn_mask
+        self._spawn_cache: dict = {}
         self.num_players = num_players
         self.synced = False
         self._last_raw = None
@@ -296,7 +297,13 @@ class SpeculativeFanout:
     def _advance(self, frame: int, inp: int) -> AdvanceFrame:
         a = AdvanceFrame((inp,) * self.num_players)
         if self.spawn_fn is not None and (inp & self.spawn_mask):
-            a.spawn_vx, a.spawn_vy = self.spawn_fn(frame)      # pure function of the frame (rollback RNG)
+            # pure function of the frame (the rolled-back RNG): every branch that spawns in frame f draws the same payload, so it is
+            # drawn once per frame, not once per branch (a 256-branch step asks 1024 times for 8 distinct frames)
+            pay = self._spawn_cache.get(frame)
+            if pay is None:
+                if len(self._spawn_cache) > 64: self._spawn_cache.clear()
+                pay = self._spawn_cache[frame] = self.spawn_fn(frame)
+            a.spawn_vx, a.spawn_vy = pay
         return a
 
     def sync_confirmed(self, src: int = 0):
