@@ -307,3 +307,24 @@ def test_bench_config5_fanout_line_on_one_gpu():
     assert line["n_gpus"] == 1 and line["parity"]["equal"] is True and line["parity"]["checked_branches"] == 256, line.get("parity")
     assert line["cpu_baseline"]["value"] > 0
     assert line["roofline_alu"]["achieved"] > 0
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The driver's launch form for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` -- with N = 2 on the one GPU of this box: the ranks read RANK / LOCAL_RANK / WORLD_SIZE from the launcher's
+    environment (no re-spawn), agree on ONE pre-heat step count, and rank 0 prints the one JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "12", "--warmup", "3", "--preheat-ms", "30", "--entities", "300000", "--cpu-ticks", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, "GGRS_RCCL_LIB": _double_lib()}, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["parity"]["equal"] is True and line["cpu_baseline"]["value"] > 0
+    assert line["preheat"]["same_step_count_on_every_rank"] is True and line["preheat"]["ticks"] >= 20
