@@ -251,6 +251,10 @@ int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, u
         const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
         const uint64_t first = w->len;
         float *dvx = nullptr, *dvy = nullptr;
+        // both payload arrays must sit in the staging buffer together: make room for the pair BEFORE staging the first (a wrap between
+        // the two would overwrite vx before the spawn kernel has read it)
+        if (2 * spawn_count > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of 2 x %llu floats exceeds the staging buffer (%llu floats)", (unsigned long long)spawn_count, (unsigned long long)w->stage_floats);
+        if (w->stage_used + 2 * spawn_count > w->stage_floats) { HIPCHK(w, hipStreamSynchronize(w->stream)); w->stage_used = 0; }
         rc = stage_floats(w, spawn_vx, spawn_count, &dvx); if (rc) return rc;
         rc = stage_floats(w, spawn_vy, spawn_count, &dvy); if (rc) return rc;
         rc = fill_defaults(w, cT, first, spawn_count); if (rc) return rc;
