@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call (round 4): GPU parity tests, smoke, every bench line -- headline in the driver's exact form and the long form, the
 # all-columns-hot schema, the reference's full POD schema, the blocking API, 2 M / 4 M, BASELINE configs 2 / 4 / 5 (+ its diverging-branches
-# variant), the N = 2 line over the transport double, the full-copy mode -- rocprofv3 kernel-trace stats of the headline and allhot
+# variant, fused and unfused), a spawning SyncTest session, the N = 2 line over the transport double in both launch forms, the full-copy mode -- rocprofv3 kernel-trace stats of the headline and allhot
 # commands and their FETCH_SIZE / WRITE_SIZE / SQ passes (separate runs, as MI355X_MICROARCH.md prescribes), a soak of the on-chip
 # group fold at 4 M beside a second process loading the GPU, tick_bench through the C ABI.
 # Usage: gpurun -- 'bash scripts/gpu_round4.sh [tag]';   then   python scripts/collect_round.py <tag>
@@ -29,10 +29,13 @@ $B --config 2 > $OUT/bench_config2.json 2>> $OUT/bench.err
 $B --config 4 > $OUT/bench_config4.json 2>> $OUT/bench.err
 $B --config 5 --steps 20 --warmup 3 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config5_1gpu.json
 $B --config 5 --steps 20 --warmup 3 --no-share-prefix --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config5_1gpu_per_branch_prefix.json
-$B --config 5 --spawn --steps 4 --warmup 1 --preheat-ms 0 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config5_1gpu_spawn.json
+$B --config 5 --spawn --steps 8 --warmup 2 --preheat-ms 0 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config5_1gpu_spawn.json
+GGRS_JIT_FUSE_SPAWN=0 $B --config 5 --spawn --steps 4 --warmup 1 --preheat-ms 0 --no-cpu-baseline 2>> $OUT/bench.err | grep '^{' > $OUT/bench_config5_1gpu_spawn_unfused.json
+python scripts/spawn_session_bench.py > $OUT/spawn_session.txt 2>&1
 $B --fanout 2>> $OUT/bench.err | grep '^{' > $OUT/bench_fanout_ws1.json
 g++ -shared -fPIC -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/rccl_double.cpp -o tests/cpp/_build/librccl_double.so -L/opt/rocm/lib -lamdhip64 -lrt 2>> $OUT/bench.err
 GGRS_RCCL_LIB=$PWD/tests/cpp/_build/librccl_double.so $B --gpus 2 --oversubscribe --steps 20 --warmup 5 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gpus2_oversubscribed.json; echo "bench --gpus 2 rc=$?"
+GGRS_RCCL_LIB=$PWD/tests/cpp/_build/librccl_double.so timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29931 bench.py --gpus 2 --oversubscribe --steps 20 --warmup 5 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gpus2_torchrun.json; echo "torchrun --gpus 2 rc=$?"
 # ---- soak of the on-chip group fold under UNEVEN load: a 4 M world (group fold on) with its in-run oracle parity gate over 24 ticks, while a
 # second process streams the allhot world on the same GPU (the hand-off's failure modes only show under load, MI355X_MICROARCH.md)
 ( $B --schema allhot --steps 400000 --no-cpu-baseline --preheat-ms 0 > $OUT/soak_background_allhot.json 2>> $OUT/bench.err & )
