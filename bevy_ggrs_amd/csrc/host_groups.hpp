@@ -216,8 +216,11 @@ struct JitBatch {
             memcmp(b.step_frame, j.step_frame, sizeof b.step_frame) != 0 || memcmp(b.step_confirmed, j.step_confirmed, sizeof b.step_confirmed) != 0 ||
             memcmp(b.step_flags, j.step_flags, sizeof b.step_flags) != 0) return false;
         if (w->jit_reads_inputs && (memcmp(b.inputs, j.inputs, sizeof b.inputs) != 0 || memcmp(b.n_inputs, j.n_inputs, sizeof b.n_inputs) != 0)) return false;
-        if (memcmp(b.spawn_count, j.spawn_count, sizeof b.spawn_count) != 0 || memcmp(b.save_len, j.save_len, sizeof b.save_len) != 0) return false;
-        for (uint32_t q = 0; q < b.n_steps; ++q) if (b.spawn_count[q]) return false;      // (same counts, but the staged payloads are not compared)
+        // fused spawns: the same rows from the same staged payload at the same steps (one request list stages a payload it is handed twice
+        // -- the same host arrays: every branch that spawns in frame f -- only once, so identical spawning branches share pointers)
+        if (memcmp(b.spawn_count, j.spawn_count, sizeof b.spawn_count) != 0 || memcmp(b.save_len, j.save_len, sizeof b.save_len) != 0 ||
+            memcmp(b.spawn_first, j.spawn_first, sizeof b.spawn_first) != 0 || memcmp(b.spawn_vx, j.spawn_vx, sizeof b.spawn_vx) != 0 ||
+            memcmp(b.spawn_vy, j.spawn_vy, sizeof b.spawn_vy) != 0) return false;
         if ((k + 1) * j.n_saves > w->gen_parts_saves || res != res_first + k * j.n_saves) return false;
         ++k;
         return true;
@@ -252,6 +255,8 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     uint32_t i = 0, ns = 0;
     int rc = GGRS_OK;
     JitBatch batch; batch.blocking = wait;
+    struct Staged { const float* hx; const float* hy; uint64_t count; const float* dx; const float* dy; };
+    std::vector<Staged> staged;                                        // payloads this list has staged already (by the caller's host arrays)
     const uint32_t n_cks = w->cks_args.n_cks;
     const uint64_t static_reads = jit_static_reads(w);
     while (i < n) {
@@ -299,10 +304,16 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                         // the payload goes into the pinned, device-mapped staging buffer and the launch reads it from there (a few hundred bytes
                         // per step over PCIe): no copy command per spawning step -- 2 x 8 of them per branch cost a 256-branch fan-out step
                         // 20 ms of host time (profiles/r04e).  The region is recycled when every batch has been collected, like the copies' was.
-                        float* const hx = w->h_stage + w->stage_used; float* const hy = hx + r.spawn_count;
-                        memcpy(hx, r.spawn_vx, r.spawn_count * 4); memcpy(hy, r.spawn_vy, r.spawn_count * 4);
-                        j.spawn_vx[step] = w->d_hstage + w->stage_used; j.spawn_vy[step] = w->d_hstage + w->stage_used + r.spawn_count;
-                        w->stage_used += 2 * r.spawn_count;
+                        const Staged* hit = nullptr;
+                        for (auto& st : staged) if (st.hx == r.spawn_vx && st.hy == r.spawn_vy && st.count == r.spawn_count) { hit = &st; break; }
+                        if (hit) { j.spawn_vx[step] = hit->dx; j.spawn_vy[step] = hit->dy; }
+                        else {
+                            float* const hx = w->h_stage + w->stage_used; float* const hy = hx + r.spawn_count;
+                            memcpy(hx, r.spawn_vx, r.spawn_count * 4); memcpy(hy, r.spawn_vy, r.spawn_count * 4);
+                            j.spawn_vx[step] = w->d_hstage + w->stage_used; j.spawn_vy[step] = w->d_hstage + w->stage_used + r.spawn_count;
+                            w->stage_used += 2 * r.spawn_count;
+                            if (staged.size() < 256) staged.push_back({r.spawn_vx, r.spawn_vy, r.spawn_count, j.spawn_vx[step], j.spawn_vy[step]});
+                        }
                         j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
                         ver_touch_comp(w, sd.comp[0]); ver_touch_comp(w, sd.comp[1]); ver_touch_comp(w, sd.comp[2]);   // new rows in every column (and the presence mask) of the bundle
                         w->len += r.spawn_count;
