@@ -391,10 +391,21 @@ def measure_single(bg, cm, torch, args, contig, light=False):
                              "after_last_collect": round((t0 + secs - stamps[-1]) * 1e6, 1),      # the two synchronize calls that close the region
                              "note": "host interval between consecutive collects in the timed region (tick k+1 is already enqueued when tick k is collected)"}
     m["f_end"] = w.frame
-    # ---- instrumented pass (HIP events on the world's stream) for the per-kernel roofline
+    # ---- instrumented pass for the per-kernel roofline: HIP events riding on every dispatch (kernel begin / end, what rocprofv3's kernel
+    # trace reports), through the SAME host API as the timed region -- pipelined ticks run back to back on a busy device with the previous
+    # tick's first Save still in the caches, exactly the conditions of the timed ticks (the pass used to go through the
+    # blocking API, where the device idles between ticks)
     w.profile_enable(True)
-    for _ in range(min(K, 50)):
-        run(w.frame)
+    n_prof = min(K, 50)
+    if args.sync:
+        for _ in range(n_prof):
+            run(w.frame)
+    else:
+        run.enqueue(w.frame)
+        for _ in range(n_prof - 1):
+            run.enqueue(w.frame); run.collect()
+        run.collect()
+        w.synchronize()
     m["prof"] = w.profile_read()
     m["prof_bytes"] = w.profile_bytes()
     tick_us = w.profile_launches("tick")
