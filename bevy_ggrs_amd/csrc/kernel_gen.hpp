@@ -696,7 +696,7 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "        // one ticket.  Wave 0 of every workgroup XORs / adds the workgroup's partials into the row with agent-scope atomics (performed at the\n"
                 "        // memory side: coherent across the XCDs' L2s), drains them -- an explicit vmcnt(0): the atomics are in memory before the ticket is\n"
                 "        // taken -- and takes the ticket; the other waves are gone by then, so a workgroup waiting for its stores to drain holds one wave\n"
-                "        // slot, not four.  The group's last arriver reads the row (L1-bypassing loads), hands it to `parts` (column = group) and clears it.\n"
+                "        // slot, not four.  The group's last arriver takes the row with atomic exchanges (read + clear), hands it to `parts` (column = group).\n"
                 "        // component_checksum.rs:88-89 is an XOR and the live count a sum: any grouping and any order give the same result.\n"
                 "        if (wave != 0u) return;\n"
                 "        const uint32_t nv = a.n_saves * %uu;                                   // values per row (<= 256: the host checks)\n"
@@ -713,10 +713,10 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "        if (lane == 0) t_ = __hip_atomic_fetch_add(a.gf_tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
                 "        t_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_);\n"
                 "        if (t_ != members - 1u) return;                                         // wave-uniform\n"
-                "        for (uint32_t i = lane; i < nv; i += 64u) {\n"
-                "            a.parts[(uint64_t)i * a.part_stride + grp] = ld8_agent(row + i);\n"
-                "            st8_agent(row + i, 0ull);                                           // ready for the next launch on this stream\n"
-                "        }\n"
+                "        // read AND clear each accumulator with one agent-scope exchange: it is performed where the producers' atomics were (never served\n"
+                "        // from a cache line that predates them) and leaves the row zero for the next launch on this stream\n"
+                "        for (uint32_t i = lane; i < nv; i += 64u)\n"
+                "            a.parts[(uint64_t)i * a.part_stride + grp] = __hip_atomic_exchange(row + i, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
                 "        if (lane == 0) a.gf_tickets[grp] = 0;\n"
                 "        return;\n"
                 "    }\n", n_cks + 1, n_cks + 1, n_cks);
