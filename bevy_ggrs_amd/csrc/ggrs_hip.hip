@@ -570,6 +570,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     if (!w->batch_ev_attached) HIPCHK(w, hipEventRecord(b.ev, w->stream));      // (else the event rides on the list's last kernel)
     w->res_head = b.first + n_save; w->pending_results += n_save;
     b.n_folds = (uint32_t)(w->folds.size() - folds_before);
+    b.stage_end = w->stage_used;
     if (n_saves_out) *n_saves_out = n_save;
     w->pending.push_back(std::move(b));
     return GGRS_OK;
@@ -589,8 +590,10 @@ int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t 
     if (n_saves_out) *n_saves_out = b.count;
     w->pending_results -= b.count;
     w->event_pool.push_back(b.ev);
+    const uint64_t stage_end = b.stage_end;
     w->pending.pop_front();
-    if (w->pending.empty()) w->stage_used = 0;       // every staged spawn payload has been consumed
+    // the batch's launches are done: its spawn payloads (and everything staged before them) are free again
+    if (w->pending.empty()) stage_ring_reset(w); else if (stage_end) w->stage_tail = stage_end;
     return GGRS_OK;
 }
 uint32_t ggrs_hip_pending_batches(ggrs_world* w) { return w ? (uint32_t)w->pending.size() : 0; }

@@ -295,23 +295,22 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 if (advance_spawns(w, r)) {
                     // The spawn system fires.  Fused (kernel_gen.hpp): the step's launch appends the rows itself -- the payload is staged now, the
                     // host does in request order what run_spawn_systems does around its kernel (capacity, versions of the bundle, len) and the
-                    // group goes on.  Otherwise (no fusable spawn system, or no room left in the staging buffer without waiting for the
-                    // stream) the group ends here and the spawn runs as its own launches, as Bevy's Commands flush ends the schedule.
-                    const bool room = w->stage_used + 2 * r.spawn_count <= w->stage_floats;
-                    if (w->jit_spawn_sys >= 0 && room && r.spawn_count <= 0xFFFFFFFFull) {
-                        if (w->len + r.spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)r.spawn_count, (unsigned long long)w->capacity);
+                    // group goes on.  Otherwise (no fusable spawn system, no room in the payload ring without waiting for the stream, or a
+                    // spawn beyond capacity -- which the unfused path reports) the group ends here and the spawn runs as its own launches,
+                    // as Bevy's Commands flush ends the schedule.
+                    const Staged* hit = nullptr;
+                    for (auto& st : staged) if (st.hx == r.spawn_vx && st.hy == r.spawn_vy && st.count == r.spawn_count) { hit = &st; break; }
+                    uint64_t soff = 0;
+                    const bool fusable = w->jit_spawn_sys >= 0 && r.spawn_count <= 0xFFFFFFFFull && w->len + r.spawn_count <= w->capacity;
+                    if (fusable && (hit || stage_ring_alloc(w, 2 * r.spawn_count, &soff))) {
                         const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
                         // the payload goes into the pinned, device-mapped staging buffer and the launch reads it from there (a few hundred bytes
                         // per step over PCIe): no copy command per spawning step -- 2 x 8 of them per branch cost a 256-branch fan-out step
                         // 20 ms of host time (profiles/r04e).  The region is recycled when every batch has been collected, like the copies' was.
-                        const Staged* hit = nullptr;
-                        for (auto& st : staged) if (st.hx == r.spawn_vx && st.hy == r.spawn_vy && st.count == r.spawn_count) { hit = &st; break; }
                         if (hit) { j.spawn_vx[step] = hit->dx; j.spawn_vy[step] = hit->dy; }
                         else {
-                            float* const hx = w->h_stage + w->stage_used; float* const hy = hx + r.spawn_count;
-                            memcpy(hx, r.spawn_vx, r.spawn_count * 4); memcpy(hy, r.spawn_vy, r.spawn_count * 4);
-                            j.spawn_vx[step] = w->d_hstage + w->stage_used; j.spawn_vy[step] = w->d_hstage + w->stage_used + r.spawn_count;
-                            w->stage_used += 2 * r.spawn_count;
+                            memcpy(w->h_stage + soff, r.spawn_vx, r.spawn_count * 4); memcpy(w->h_stage + soff + r.spawn_count, r.spawn_vy, r.spawn_count * 4);
+                            j.spawn_vx[step] = w->d_hstage + soff; j.spawn_vy[step] = w->d_hstage + soff + r.spawn_count;
                             if (staged.size() < 256) staged.push_back({r.spawn_vx, r.spawn_vy, r.spawn_count, j.spawn_vx[step], j.spawn_vy[step]});
                         }
                         j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;

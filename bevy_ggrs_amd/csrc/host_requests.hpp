@@ -211,13 +211,33 @@ int fill_defaults(ggrs_world* w, uint32_t c, uint64_t first, uint64_t count) {
     return GGRS_OK;
 }
 
-int stage_floats(ggrs_world* w, const float* src, uint64_t n, float** dev_out) {
-    if (n > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of %llu floats exceeds the staging buffer", (unsigned long long)n);
-    if (w->stage_used + n > w->stage_floats) { HIPCHK(w, hipStreamSynchronize(w->stream)); w->stage_used = 0; }
-    memcpy(w->h_stage + w->stage_used, src, n * 4);
-    HIPCHK(w, hipMemcpyAsync(w->d_stage + w->stage_used, w->h_stage + w->stage_used, n * 4, hipMemcpyHostToDevice, w->stream));
-    *dev_out = w->d_stage + w->stage_used;
-    w->stage_used += n;
+// The spawn-payload ring (host_world.hpp): n contiguous floats, or false when the region in front of the oldest uncollected batch's
+// payloads is too small (the caller then waits for the stream, which frees everything, or -- a fused spawn -- ends its group).
+bool stage_ring_alloc(ggrs_world* w, uint64_t n, uint64_t* off) {
+    uint64_t& head = w->stage_used; const uint64_t tail = w->stage_tail, cap = w->stage_floats;
+    if (n > cap) return false;
+    if (head >= tail) {
+        if (head + n <= cap) { *off = head; head += n; return true; }
+        if (n < tail) { *off = 0; head = n; return true; }              // wrap: the front of the buffer has been consumed
+        return false;
+    }
+    if (head + n < tail) { *off = head; head += n; return true; }
+    return false;
+}
+// every launch that could read a staged payload has completed (the stream was waited for / every batch collected)
+void stage_ring_reset(ggrs_world* w) { w->stage_used = w->stage_tail = 0; for (auto& b : w->pending) b.stage_end = 0; }
+// vx and vy of one spawn, side by side in the ring, copied to the device twin for the unfused spawn kernel
+int stage_pair(ggrs_world* w, const float* vx, const float* vy, uint64_t n, float** dvx, float** dvy) {
+    if (2 * n > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of 2 x %llu floats exceeds the staging buffer (%llu floats)", (unsigned long long)n, (unsigned long long)w->stage_floats);
+    uint64_t off = 0;
+    if (!stage_ring_alloc(w, 2 * n, &off)) {
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        stage_ring_reset(w);
+        (void)stage_ring_alloc(w, 2 * n, &off);
+    }
+    memcpy(w->h_stage + off, vx, n * 4); memcpy(w->h_stage + off + n, vy, n * 4);
+    HIPCHK(w, hipMemcpyAsync(w->d_stage + off, w->h_stage + off, 2 * n * 4, hipMemcpyHostToDevice, w->stream));
+    *dvx = w->d_stage + off; *dvy = w->d_stage + off + n;
     return GGRS_OK;
 }
 
@@ -251,12 +271,7 @@ int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, u
         const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
         const uint64_t first = w->len;
         float *dvx = nullptr, *dvy = nullptr;
-        // both payload arrays must sit in the staging buffer together: make room for the pair BEFORE staging the first (a wrap between
-        // the two would overwrite vx before the spawn kernel has read it)
-        if (2 * spawn_count > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of 2 x %llu floats exceeds the staging buffer (%llu floats)", (unsigned long long)spawn_count, (unsigned long long)w->stage_floats);
-        if (w->stage_used + 2 * spawn_count > w->stage_floats) { HIPCHK(w, hipStreamSynchronize(w->stream)); w->stage_used = 0; }
-        rc = stage_floats(w, spawn_vx, spawn_count, &dvx); if (rc) return rc;
-        rc = stage_floats(w, spawn_vy, spawn_count, &dvy); if (rc) return rc;
+        rc = stage_pair(w, spawn_vx, spawn_vy, spawn_count, &dvx, &dvy); if (rc) return rc;
         rc = fill_defaults(w, cT, first, spawn_count); if (rc) return rc;
         SpawnArgs a; memset(&a, 0, sizeof a);
         a.state = w->live.ptr;
@@ -535,7 +550,7 @@ bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks,
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
     run_host_folds(w, ~0u);
-    w->stage_used = 0;
+    stage_ring_reset(w);
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
     return GGRS_OK;
 }

@@ -171,7 +171,7 @@ int seal_impl(ggrs_world* w) {
     const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
     w->max_results = 16384;                             // pinned result ring (256 KiB): a fan-out step of 256 branches x 8 frames alone is 2048
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
-    w->stage_floats = 1u << 20;
+    w->stage_floats = w->knobs.stage_floats; w->stage_used = w->stage_tail = 0;
     const uint64_t stage_bytes = w->stage_floats * 4;
     // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
     w->wg_parts_rows = (uint32_t)std::max<uint64_t>(4 * w->n_cu + 64, w->cap_pad / 512 + 64);      // the persistent form's grid is clamped to this (host_groups.hpp)

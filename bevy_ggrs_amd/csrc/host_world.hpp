@@ -54,6 +54,7 @@ struct Knobs {
                                    //                       the host -- or k_gen_finalize -- reads 1/64 of the rows, blocking calls included (0: never).  The in-launch hand-off
                                    //                       costs a constant 3-4.5 us at the end of the launch (profiles/r04b): it pays from ~3 M slots up, where the host's fold of
                                    //                       one row per workgroup (3 MB per tick at 4 M) no longer hides behind the next tick's kernel
+    uint64_t stage_floats = 1u << 20;   // GGRS_STAGE_FLOATS=n   floats of the spawn-payload staging ring (default 1 M = 4 MB; tests shrink it to exercise the wrap)
     bool jit_fuse_spawn = true;    // GGRS_JIT_FUSE_SPAWN=0  a firing spawn system ends the request group (k_spawn_particles + mask edits as their own launches: rounds 1-3)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
@@ -90,6 +91,7 @@ struct Knobs {
         k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
         k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
         k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 12288)));
+        k.stage_floats = (uint64_t)std::max<long long>(1024, std::min<long long>(1ll << 28, num("GGRS_STAGE_FLOATS", 1 << 20)));
         k.jit_fuse_spawn = num("GGRS_JIT_FUSE_SPAWN", 1) != 0;
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
@@ -214,7 +216,10 @@ struct ggrs_world {
     uint64_t* d_results = nullptr; uint64_t* h_results = nullptr; uint32_t max_results = 0;
     UnitDesc* d_units = nullptr;
     uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
-    float* d_stage = nullptr; float* h_stage = nullptr; float* d_hstage = nullptr; uint64_t stage_floats = 0, stage_used = 0;   // d_hstage: h_stage as the device sees it (zero-copy payloads of fused spawns)
+    // spawn payloads: a ring of floats in pinned, device-mapped memory (h_stage; d_hstage = the same bytes as the device sees them: fused spawns read
+    // them zero-copy) with a device twin (d_stage) for the unfused spawn kernel.  [stage_tail, stage_used) (mod wrap) is what launches of
+    // uncollected batches may still read; a collected batch frees everything up to its stage_end
+    float* d_stage = nullptr; float* h_stage = nullptr; float* d_hstage = nullptr; uint64_t stage_floats = 0, stage_used = 0, stage_tail = 0;
 
     // ---- checksum specs (device view)
     std::vector<uint32_t> cks_comp;      // checksummed component ids in id order
@@ -244,7 +249,7 @@ struct ggrs_world {
     std::deque<int> ring_slot; std::deque<int32_t> ring_frame;   // newest at the front
 
     // ---- asynchronous request batches (ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums)
-    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; uint32_t n_folds = 0; };
+    struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; uint32_t n_folds = 0; uint64_t stage_end = 0; };
     // Host-side checksum fold of small worlds (generated kernel): its workgroups write their partial rows straight into pinned,
     // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected -- a
     // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.

@@ -95,3 +95,53 @@ def test_spawn_beyond_capacity_is_an_error_not_a_corruption():
         g.handle_requests([bg.SaveGameState(1), b])               # 1200 > 1150
     assert e.value.code == bg.GGRS_E_CAPACITY and "exceeds capacity" in str(e.value)
     assert g.len == n + 100
+
+
+@pytest.mark.parametrize("stage_floats", [1024, 4096, 1 << 20])
+def test_payload_ring_wraps_and_falls_back_under_the_pipelined_api(stage_floats, monkeypatch):
+    """Spawn payloads live in a ring that a collected batch frees (host_world.hpp).  With the ring shrunk (GGRS_STAGE_FLOATS) a session that
+    holds the spawn key through enqueue / collect with one tick in flight wraps it every other tick (4096 floats) or overflows it inside one
+    list (1024: the spawn then ends its group and runs unfused after a stream wait) -- the checksums must not care."""
+    from bevy_ggrs_amd.session import SyncTestSession
+    monkeypatch.setenv("GGRS_STAGE_FLOATS", str(stage_floats))
+    n, D, rate, ticks = 5000, 8, 100, 40
+    cap = n + rate * (ticks + 2 * D + 4)
+    fn = cm.frame_spawn_fn(rate)
+
+    def lists():
+        sess = SyncTestSession(1, D, D + 1, 0)
+        frame = 0
+        for _ in range(ticks):
+            sess.add_local_input(0, cm.INPUT_SPAWN)
+            reqs = sess.advance_frame()
+            cur = frame
+            for r in reqs:
+                if isinstance(r, bg.LoadGameState): cur = r.frame
+                elif isinstance(r, bg.AdvanceFrame):
+                    r.spawn_vx, r.spawn_vy = fn(cur); cur += 1
+            frame += 1
+            yield sess, reqs
+    g = bg.World(cap, max_depth=D + 1)
+    o = OracleWorld(cap, D + 1, FLAT)
+    got, want = [], []
+    for w in (g, o):
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=37)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+    g.set_synctest_check_distance(D)
+    pending = []
+    for sess, reqs in lists():                                    # GPU: enqueue tick k+1, then collect tick k
+        pending.append(g.enqueue_requests(reqs))
+        if len(pending) > 1:
+            got += g.collect_checksums(pending.pop(0))
+        sess.record_checksums([0] * sum(isinstance(r, bg.SaveGameState) for r in reqs))     # (the session only counts them here)
+    while pending: got += g.collect_checksums(pending.pop(0))
+    for sess, reqs in lists():                                    # oracle: the same lists, request by request (its confirmed rule applied per request)
+        for r in reqs:
+            c = o.frame - D
+            if c >= 0: o.set_confirmed(c)
+            want += o.handle_requests([r])
+        sess.record_checksums([0] * sum(isinstance(r, bg.SaveGameState) for r in reqs))
+    assert len(got) == len(want) > ticks and got == want
+    cm.assert_states_equal(cm.snapshot_state(g, (0, 1, 2)), cm.snapshot_state(o, (0, 1, 2)), f"payload ring {stage_floats}")
