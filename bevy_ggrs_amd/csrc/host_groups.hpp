@@ -306,7 +306,8 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                         const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
                         // the payload goes into the pinned, device-mapped staging buffer and the launch reads it from there (a few hundred bytes
                         // per step over PCIe): no copy command per spawning step -- 2 x 8 of them per branch cost a 256-branch fan-out step
-                        // 20 ms of host time (profiles/r04e).  The region is recycled when every batch has been collected, like the copies' was.
+                        // 20 ms of host time (profiles/r04e).  The bytes sit in the payload ring (host_requests.hpp) until this list's batch is collected;
+                        // the caller's arrays are free again when the call returns, as with the copies.
                         if (hit) { j.spawn_vx[step] = hit->dx; j.spawn_vy[step] = hit->dy; }
                         else {
                             memcpy(w->h_stage + soff, r.spawn_vx, r.spawn_count * 4); memcpy(w->h_stage + soff + r.spawn_count, r.spawn_vy, r.spawn_count * 4);
