@@ -59,7 +59,10 @@ struct ggrs_fanout {
     int rank = 0, size = 1;
     hipStream_t comm_stream = nullptr;
     // one slot = one all-gather: the checksums of `interval` consecutive steps
-    struct Slot { uint64_t* d_send = nullptr; uint64_t* d_recv = nullptr; uint64_t* h_recv = nullptr; hipEvent_t ready = nullptr, done = nullptr;
+    // What a rank sends per group: [n_steps x n_saves Checksum(u128)][n_steps tags].  A tag = {frame of the step's first request, number of its
+    // SaveGameState requests}: collectives pair up by ORDER, so ranks that ran different step counts would silently gather different frames'
+    // checksums into one table (bench.py's clock-based pre-heat did exactly that in round 4) -- the tags make collect refuse such a table.
+    struct Slot { uint64_t* d_send = nullptr; uint64_t* d_recv = nullptr; uint64_t* h_recv = nullptr; uint64_t* h_tags = nullptr; hipEvent_t ready = nullptr, done = nullptr;
                   uint32_t n_saves = 0, n_steps = 0; bool closed = false; uint32_t first[64]; };   // first[k]: step k's slot in the pinned result ring
     Slot slot[FANOUT_MAX_INFLIGHT];
     uint32_t head = 0, tail = 0;         // tail: slot being filled, head: oldest uncollected
@@ -95,10 +98,11 @@ int fanout_close_slot(ggrs_fanout* f) {
         FANCHK_HIP(f, hipMemcpyAsync(s.d_send + (size_t)k * s.n_saves * 2, w->h_results + 2 * (size_t)s.first[k], (size_t)run * s.n_saves * 16, hipMemcpyHostToDevice, f->comm_stream));
         k += run;
     }
-    if (n) {
-        FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, n * 2, ncclUint64, f->comm, f->comm_stream));
-        FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, n * 16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
-    }
+    // the steps' tags ride behind the checksums (one small pinned -> device copy per group)
+    const size_t per_rank = n + s.n_steps;
+    FANCHK_HIP(f, hipMemcpyAsync(s.d_send + n * 2, s.h_tags, (size_t)s.n_steps * 16, hipMemcpyHostToDevice, f->comm_stream));
+    FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, per_rank * 2, ncclUint64, f->comm, f->comm_stream));
+    FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, per_rank * 16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
     FANCHK_HIP(f, hipEventRecord(s.done, f->comm_stream));
     s.closed = true;
     ++f->tail;
@@ -133,9 +137,10 @@ int ggrs_hip_fanout_init(ggrs_world* w, const uint8_t id[GGRS_FANOUT_ID_BYTES], 
     if (e != ncclSuccess) { rc = w->fail(GGRS_E_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(e)); delete f; return rc; }
     bool ok = hipStreamCreateWithFlags(&f->comm_stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& s : f->slot) {
-        ok = ok && hipMalloc((void**)&s.d_send, (size_t)f->cap_u128 * 16) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s.d_recv, (size_t)f->cap_u128 * 16 * world_size) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&s.h_recv, (size_t)f->cap_u128 * 16 * world_size) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_send, (size_t)(f->cap_u128 + 64) * 16) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_recv, (size_t)(f->cap_u128 + 64) * 16 * world_size) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_recv, (size_t)(f->cap_u128 + 64) * 16 * world_size) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_tags, 64 * 16) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
     }
@@ -155,6 +160,7 @@ void ggrs_hip_fanout_destroy(ggrs_fanout* f) {
         if (s.d_send) (void)hipFree(s.d_send);
         if (s.d_recv) (void)hipFree(s.d_recv);
         if (s.h_recv) (void)hipHostFree(s.h_recv);
+        if (s.h_tags) (void)hipHostFree(s.h_tags);
         if (s.ready) (void)hipEventDestroy(s.ready);
         if (s.done) (void)hipEventDestroy(s.done);
     }
@@ -224,6 +230,8 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
     if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
     s.n_saves = ns;
     s.first[s.n_steps] = w->pending.back().first;        // where the kernels write this step's checksums (pinned result ring)
+    s.h_tags[2 * s.n_steps] = n ? (uint64_t)(uint32_t)reqs[0].frame | ((uint64_t)reqs[0].kind << 32) : 0;   // (slot not closed: the side stream does not read h_tags yet)
+    s.h_tags[2 * s.n_steps + 1] = ns;
     ++s.n_steps;
     if (n_saves_out) *n_saves_out = ns;
     if (s.n_steps >= f->interval) return fanout_close_slot(f);
@@ -249,7 +257,24 @@ int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t ma
         int rc = ggrs_hip_collect_checksums(w, own.data(), s.n_saves, &got);
         if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
     }
-    if (per_rank) memcpy(checksums_out, s.h_recv, (size_t)per_rank * 16 * f->size);
+    // every rank must have gathered the SAME steps: compare the tags, then hand out the checksums without them
+    const size_t stride = ((size_t)per_rank + s.n_steps) * 2;                    // u64 per rank in h_recv
+    const uint64_t* mine = s.h_recv + (size_t)f->rank * stride + (size_t)per_rank * 2;
+    int out_of_step = -1; uint32_t bad_step = 0;
+    for (int r = 0; r < f->size && out_of_step < 0; ++r) {
+        const uint64_t* theirs = s.h_recv + (size_t)r * stride + (size_t)per_rank * 2;
+        for (uint32_t k = 0; k < s.n_steps; ++k) if (theirs[2 * k] != mine[2 * k] || theirs[2 * k + 1] != mine[2 * k + 1]) { out_of_step = r; bad_step = k; break; }
+    }
+    if (out_of_step >= 0) {
+        const uint64_t* theirs = s.h_recv + (size_t)out_of_step * stride + (size_t)per_rank * 2;
+        const int rc = f->fail(GGRS_E_INVALID, "ranks are out of step: step %u of this all-gather starts at frame %d with %llu saves on rank %d, at frame %d with %llu saves on rank %d "
+                               "(every rank must call ggrs_hip_fanout_step the same number of times with lists of the same shape)", bad_step,
+                               (int32_t)(uint32_t)mine[2 * bad_step], (unsigned long long)mine[2 * bad_step + 1], f->rank,
+                               (int32_t)(uint32_t)theirs[2 * bad_step], (unsigned long long)theirs[2 * bad_step + 1], out_of_step);
+        s.n_steps = 0; s.closed = false; ++f->head;
+        return rc;
+    }
+    for (int r = 0; r < f->size && per_rank; ++r) memcpy(checksums_out + (size_t)r * per_rank * 2, s.h_recv + (size_t)r * stride, (size_t)per_rank * 16);
     if (n_steps_out) *n_steps_out = s.n_steps;
     if (n_saves_out) *n_saves_out = s.n_saves;
     s.n_steps = 0; s.closed = false;

@@ -371,6 +371,10 @@ int ggrs_hip_adopt_live_state(ggrs_world* w);
  *                    SaveGameState requests.
  *   collect          oldest uncollected group (a partly filled one is closed first): blocks until its all-gather has
  *                    landed; checksums_out is [world_size][n_steps][n_saves][2] u64 ({lo, hi} per Save, rank-major).
+ *                    Collectives pair up by ORDER: every rank must call step the same number of times, with the same group
+ *                    boundaries.  Each step therefore carries a tag {frame of its first request, number of saves} behind its
+ *                    checksums through the all-gather, and collect fails with GGRS_E_INVALID ("ranks are out of step", naming
+ *                    both frames) instead of handing out a table whose rows belong to different frames.
  * At most 8 groups may be in flight. */
 #define GGRS_FANOUT_ID_BYTES 128
 typedef struct ggrs_fanout ggrs_fanout;

@@ -328,3 +328,77 @@ def test_bench_two_ranks_under_torch_distributed_run():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["parity"]["equal"] is True and line["cpu_baseline"]["value"] > 0
     assert line["preheat"]["same_step_count_on_every_rank"] is True and line["preheat"]["ticks"] >= 20
+
+
+def _skewed_rank(rank, size, id_q, q):
+    """Rank 1 advances its confirmed frame once on its own before the common step: the ranks' lists then start at different frames."""
+    try:
+        import bevy_ggrs_amd as bg
+        import common as cm
+        from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+        if rank == 0:
+            id_bytes = RcclFanout.unique_id()
+            for _ in range(size - 1): id_q.put(id_bytes)
+        else:
+            id_bytes = id_q.get(timeout=120)
+
+        class _Dist:
+            def get_rank(self): return rank
+            def get_world_size(self): return size
+        n, D = 900, 4
+        w = bg.World(n + 64, max_depth=D + 2, device=0)
+        ids = cm.build_particles(w)
+        if rank == 0:
+            vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+            cm.spawn_particles(w, ids, n, vel, ttl)
+        else:
+            w.spawn(0, {})
+        native = RcclFanout(w, rank, size, id_bytes)
+        fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=2, native=native)
+        fan.sync_confirmed(0)
+        first = fan.step()                                            # in step: fine
+        if rank == 1:                                                 # ... then rank 1 runs ahead by one confirmed frame
+            C = fan.confirmed
+            w.set_confirmed(C)
+            w.handle_requests([bg.LoadGameState(C), bg.AdvanceFrame((0,)), bg.SaveGameState(C + 1)])
+            fan.confirmed = C + 1
+        try:
+            fan.step()
+            verdict = "no error"
+        except bg.GgrsHipError as e:
+            verdict = f"GgrsHipError {e.code}: {e}"
+        except Exception as e:                                        # noqa: BLE001
+            verdict = f"{type(e).__name__}: {e}"
+        native.close()
+        q.put((rank, "ok", first is not None, verdict))
+    except Exception as e:                                            # noqa: BLE001
+        import traceback
+        q.put((rank, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
+
+
+def test_ranks_out_of_step_are_refused_by_the_library():
+    """Collectives pair up by order: a rank that ran ahead would gather ANOTHER frame's checksums into the table (bench.py's clock-based
+    pre-heat did, round 4).  Every step now carries a tag {frame of its first request, saves} behind its checksums through the all-gather,
+    and ggrs_hip_fanout_collect refuses a table whose ranks disagree -- on every rank, naming both frames."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, id_q = ctx.Queue(), ctx.Queue()
+    old = os.environ.get("GGRS_RCCL_LIB")
+    os.environ["GGRS_RCCL_LIB"] = _double_lib()
+    try:
+        procs = [ctx.Process(target=_skewed_rank, args=(r, 2, id_q, q)) for r in range(2)]
+        for p in procs: p.start()
+    finally:
+        if old is None: os.environ.pop("GGRS_RCCL_LIB", None)
+        else: os.environ["GGRS_RCCL_LIB"] = old
+    res = {}
+    try:
+        for _ in range(2):
+            r = q.get(timeout=240); res[r[0]] = r[1:]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive(): p.kill()
+    for r in (0, 1):
+        assert res[r][0] == "ok" and res[r][1] is True, res[r]
+        assert "GgrsHipError" in res[r][2] and "out of step" in res[r][2] and "frame" in res[r][2], res[r]
