@@ -162,7 +162,7 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     for (uint32_t k = 0; k < j.n_saves; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
     JitSig g; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
-    g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s;
+    g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s; g.nt_loads = j.nt_loads;
     auto building = [](const JitSpecSlot& s) { return s.spec && s.spec->state.load(std::memory_order_acquire) == 1; };
     JitSpecSlot* s = nullptr;
     for (auto& t : w->spec_tab) if (t.sig == g) { s = &t; break; }
@@ -350,6 +350,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         // Past ~2.5 M particles the rows no longer survive in the caches until the next launch and only displace the stream (4 M: +3 %).
         j.cached_saves = (j.nt && w->knobs.jit_cache_first_save && !j.src_is_live && j.n_saves >= 2 &&
                           rows_bytes_per_slot(w, j.save_rows[0]) * cover <= w->knobs.jit_cached_save_max_bytes) ? 1u : 0u;
+        // the source block of an HBM-sized rollback group is in the caches only if the previous group kept a Save there (the steady session: the
+        // same decision as this group's): otherwise its lines come from HBM once and are dead after the load
+        j.nt_loads = w->knobs.jit_nt_loads >= 0 ? (uint32_t)(w->knobs.jit_nt_loads != 0) : (j.nt && !j.cached_saves && !j.src_is_live ? 1u : 0u);
         const bool launch = j.n_ops || !j.src_is_live;
 
         if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {

@@ -55,6 +55,9 @@ struct Knobs {
                                    //                       costs a constant 3-4.5 us at the end of the launch (profiles/r04b): it pays from ~3 M slots up, where the host's fold of
                                    //                       one row per workgroup (3 MB per tick at 4 M) no longer hides behind the next tick's kernel
     uint64_t stage_floats = 1u << 20;   // GGRS_STAGE_FLOATS=n   floats of the spawn-payload staging ring (default 1 M = 4 MB; tests shrink it to exercise the wrap)
+    int jit_nt_loads = -1;         // GGRS_JIT_NT_LOADS=0|1 generated kernel: never / always load the source block non-temporally; default (-1): when the block is not expected in the
+                                   //                       caches -- an HBM-sized rollback group none of whose Saves is kept in the L2 for the next one (profiles/r04n: allhot 4 M -8 %,
+                                   //                       headline 4 M even; it costs 3 % where the loads DO hit, 1 M)
     bool jit_fuse_spawn = true;    // GGRS_JIT_FUSE_SPAWN=0  a firing spawn system ends the request group (k_spawn_particles + mask edits as their own launches: rounds 1-3)
     bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
     int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
@@ -92,6 +95,7 @@ struct Knobs {
         k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
         k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 12288)));
         k.stage_floats = (uint64_t)std::max<long long>(1024, std::min<long long>(1ll << 28, num("GGRS_STAGE_FLOATS", 1 << 20)));
+        k.jit_nt_loads = (int)num("GGRS_JIT_NT_LOADS", -1);
         k.jit_fuse_spawn = num("GGRS_JIT_FUSE_SPAWN", 1) != 0;
         k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
         k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
@@ -131,11 +135,11 @@ static std::vector<ParkedArena> g_parked;
 // What a specialised request-group kernel hard-codes: the op sequence and every wave-uniform mask of the group.
 struct JitSig {
     uint64_t op_bits = 0, save_rows = 0, live_rows = 0, load_rows = 0;
-    uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0, dp_s = 0;
+    uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0, dp_s = 0, nt_loads = 0;
     bool operator==(const JitSig& o) const {
         return op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
                n_steps == o.n_steps && src_is_live == o.src_is_live && skip_live == o.skip_live && nt == o.nt && cached_saves == o.cached_saves &&
-               save_pmask == o.save_pmask && live_pmask == o.live_pmask && dp_s == o.dp_s;
+               save_pmask == o.save_pmask && live_pmask == o.live_pmask && dp_s == o.dp_s && nt_loads == o.nt_loads;
     }
 };
 struct JitSpec {

@@ -140,7 +140,7 @@ static const char kJitPrelude[] =
     "    const unsigned char* src; unsigned char* live;\n" \
     "    unsigned char* save_dst[16]; int save_frame[16];\n" \
     "    ggrs_u64 save_rows[16]; ggrs_u64 live_rows, load_rows;\n" \
-    "    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, pad1;\n" \
+    "    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, nt_loads;\n" \
     "    ggrs_u32 dt_bits[24]; ggrs_u32 aux_bits[24];\n" \
     "    unsigned char inputs[24][16]; unsigned char n_inputs[24];\n" \
     "    int step_frame[24]; int step_confirmed[24]; unsigned char step_flags[24];\n" \
@@ -157,7 +157,8 @@ struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
     unsigned char* save_dst[16]; int save_frame[16];
     ggrs_u64 save_rows[16]; ggrs_u64 live_rows, load_rows;   // row versions: bit c = column c is stored with that Save / with the live block / must be loaded at all
-    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, pad1;       // the same for the presence masks: bit c = component c's mask is stored (the liveness mask always is)
+    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, nt_loads;   // the same for the presence masks: bit c = component c's mask is stored (the liveness mask always is);
+                                                              // nt_loads: the source block is not expected in the caches (an HBM-sized group whose predecessor cached no Save): its lines are dead after the load
     ggrs_u32 dt_bits[24]; ggrs_u32 aux_bits[24];
     unsigned char inputs[24][16]; unsigned char n_inputs[24];
     int step_frame[24]; int step_confirmed[24]; unsigned char step_flags[24];
@@ -431,7 +432,11 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     };
     auto emit_load = [&](const char* blk, const char* mask, const char* indent) {
         sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)LOADHOT);
+        sfmt(s, "%s  if (a.nt_loads) {\n", indent);
+        each_col(LOADHOT, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    w%u_0 = __builtin_nontemporal_load((const GGRS_G %s*)o%u(%s));\n", indent, cl, mtype(c), cl, blk); });
+        sfmt(s, "%s  } else {\n", indent);
         each_col(LOADHOT, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, cl, mtype(c), cl, blk); });
+        sfmt(s, "%s  }\n", indent);
         sfmt(s, "%s} else {\n", indent);
         each_col(~0ull, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    if ((%s >> %uu) & 1ull) w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, mask, cl, cl, mtype(c), cl, blk); });
         sfmt(s, "%s}\n", indent);
@@ -839,7 +844,7 @@ uint32_t jit_replace_token(std::string& body, const std::string& tok, const std:
 }
 // The shape fields, by name: what jit_specialise turns into literals and what must NOT survive in a specialised body (tests/test_generated_kernel.py
 // checks the same list through ggrs_hip_generated_kernel_source).  `[si]`: the field is an array indexed by the Save counter in the generic text.
-static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask"};
+static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads"};
 static const char* const kJitShapeArrays[] = {"save_rows", "save_pmask"};
 std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const size_t k = generic.find("extern \"C\" __global__");
@@ -850,7 +855,7 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const std::pair<const char*, std::string> scalars[] = {
         {"op_bits", lit64(g.op_bits)}, {"n_ops", lit32(g.n_ops)}, {"n_saves", lit32(g.n_saves)}, {"n_steps", lit32(g.n_steps)}, {"src_is_live", lit32(g.src_is_live)},
         {"skip_live", lit32(g.skip_live)}, {"dp_s", lit32(g.dp_s)}, {"nt", lit32(g.nt)}, {"cached_saves", lit32(g.cached_saves)}, {"live_rows", lit64(g.live_rows)},
-        {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}};
+        {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}, {"nt_loads", lit32(g.nt_loads)}};
     static_assert(sizeof scalars / sizeof scalars[0] == sizeof kJitShapeScalars / sizeof kJitShapeScalars[0], "every shape scalar has a literal");
     const std::pair<const char*, std::string> arrays[] = {{"save_rows", lit64(g.save_rows)}, {"save_pmask", lit32(g.save_pmask)}};
     for (auto& sb : arrays) (void)jit_replace_token(body, std::string("a.") + sb.first + "[si]", sb.second);
@@ -867,8 +872,8 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     if (lp == std::string::npos) return "";
     body.insert(lp, "#pragma unroll\n");
     char note[256];
-    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x\n", g.n_ops,
-             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves);
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u\n", g.n_ops,
+             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads);
     return head + note + body;
 }
 // Build (or load from the disk cache) without touching a world: runs on a worker thread

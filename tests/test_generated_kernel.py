@@ -98,7 +98,7 @@ def test_kernel_specialised_for_the_steady_tick_builds(name):
 
 
 # the argument-block fields a specialised kernel turns into literals: kernel_gen.hpp kJitShapeScalars / kJitShapeArrays
-SHAPE_SCALARS = ("op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask")
+SHAPE_SCALARS = ("op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads")
 SHAPE_ARRAYS = ("save_rows", "save_pmask")
 
 
@@ -132,10 +132,10 @@ def test_specialiser_substitutes_whole_tokens_and_nothing_else(name):
     assert not left & (set(SHAPE_SCALARS) | set(SHAPE_ARRAYS)), left & (set(SHAPE_SCALARS) | set(SHAPE_ARRAYS))
     assert {"src", "live", "save_dst", "save_frame", "dt_bits", "len", "parts", "part_stride", "n_units", "gf_rows", "gf_tickets"} <= left, left
     # (b) the literals, as the specialised text's own header line states them
-    m = re.search(r"// specialised: (\d+) ops \(bits ([0-9a-f]+)\), (\d+) Saves, rows ([0-9a-f]+) / live ([0-9a-f]+) / load ([0-9a-f]+), masks ([0-9a-f]+) / ([0-9a-f]+), nt (\d+), cached ([0-9a-f]+)", spec)
-    n_ops, op_bits, n_saves, rows, live, load, pm, lpm, nt, cached = (int(m.group(i), 16 if i in (2, 4, 5, 6, 7, 8, 10) else 10) for i in range(1, 11))
+    m = re.search(r"// specialised: (\d+) ops \(bits ([0-9a-f]+)\), (\d+) Saves, rows ([0-9a-f]+) / live ([0-9a-f]+) / load ([0-9a-f]+), masks ([0-9a-f]+) / ([0-9a-f]+), nt (\d+), cached ([0-9a-f]+), nt loads (\d+)", spec)
+    n_ops, op_bits, n_saves, rows, live, load, pm, lpm, nt, cached, ntl = (int(m.group(i), 16 if i in (2, 4, 5, 6, 7, 8, 10) else 10) for i in range(1, 12))
     lit = {"op_bits": f"0x{op_bits:x}ull", "n_ops": f"{n_ops}u", "n_saves": f"{n_saves}u", "n_steps": f"{bin(op_bits).count('1')}u", "src_is_live": "0u", "skip_live": "0u", "dp_s": "0u",
-           "nt": f"{nt}u", "cached_saves": f"{cached}u", "live_rows": f"0x{live:x}ull", "load_rows": f"0x{load:x}ull", "live_pmask": f"{lpm}u"}
+           "nt": f"{nt}u", "cached_saves": f"{cached}u", "live_rows": f"0x{live:x}ull", "load_rows": f"0x{load:x}ull", "live_pmask": f"{lpm}u", "nt_loads": f"{ntl}u"}
     want = gbody
     want = re.sub(r"(?<![\w.])a\.save_rows\[si\]", f"0x{rows:x}ull", want)
     want = re.sub(r"(?<![\w.])a\.save_pmask\[si\]", f"{pm}u", want)

@@ -23,6 +23,8 @@ KNOBS = [
     {"GGRS_GROUP_FOLD_MIN_WGS": "0"},                       # no group fold: one row per workgroup leaves the kernel at every size
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0"},   # group fold even for the 10 k world (one group of 56 workgroups incl. a padding one)
     {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0", "GGRS_HOST_FOLD_MAX_WGS": "0"},   # ... with the groups' rows staying on the device (k_gen_finalize over rows / 64)
+    {"GGRS_JIT_NT_LOADS": "1"},                            # the source block is always loaded non-temporally (default: only when it is not expected in the caches)
+    {"GGRS_JIT_NT_LOADS": "0"},
     {"GGRS_JIT_FUSE_SPAWN": "0"},                          # a firing spawn system ends the request group (rounds 1-3: k_spawn_particles + mask edits as their own launches)
     {"GGRS_DEAD_GROUPS": "0"},
     {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
