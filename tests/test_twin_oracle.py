@@ -149,3 +149,24 @@ def test_narrow_words_one_and_two_byte_components():
     assert res[0][0] == res[1][0]
     assert res[0][0][1] == res[0][0][3] and res[0][0][2] != res[0][0][4]          # frame 1 again after the rollback; frame 2 without the host edits
     cm.assert_states_equal(res[0][1], res[1][1], "narrow words")
+
+
+@pytest.mark.parametrize("mode", [FLAT, REFSHAPED])
+def test_allhot_schema_oracle_vs_twin(mode):
+    """bench.py --schema allhot (tests/common.py): the stress_test systems plus increase_component (benches/bench.rs:30-46) over the 7 words of
+    Transform.rotation / .scale -- the all-columns-hot world of DESIGN.md section 6.  Both restatements must agree on every checksum and on
+    the bits of every column, spawns and Ttl despawns included, before the GPU line's parity gate means anything."""
+    n, cd, ticks = 3000, 8, 20
+    res = []
+    for w in (OracleWorld(n + 100 * (ticks + 20), cd + 1, mode), TwinWorld(n + 100 * (ticks + 20), cd + 1)):
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        ids = cm.build_particles(w, with_spawn=True, ttl_init=40, schema="allhot")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        drv = cm.SyncTestDriver(w, cd, max_prediction=cd + 1)
+        fn = cm.frame_spawn_fn(100)
+        for t in range(ticks):
+            drv.tick((cm.INPUT_SPAWN if t % 4 == 1 else 0,), spawn_fn=fn)
+        res.append((drv.all_checksums, cm.snapshot_state(w, ids)))
+    _same(res[0], res[1], "allhot")
+    rot_w = res[0][1]["c0w6"]                                           # rotation.w started at 1.0f and was incremented as a u32 once per net frame
+    assert int(rot_w[250]) == int(cm.f32bits(cm.TRANSFORM_DEFAULT)[6]) + ticks       # (slot 250: Ttl 251, still alive)
