@@ -25,7 +25,8 @@ def _session(world, n, ticks, D, schema, rate, hold):
 
 
 @pytest.mark.parametrize("fuse", [True, False])
-@pytest.mark.parametrize("n,schema,rate,D", [(3000, "headline", 100, 8), (3000, "full", 70, 5), (300_000, "full", 100, 8), (700_000, "headline", 130, 8)])
+@pytest.mark.parametrize("n,schema,rate,D", [(3000, "headline", 100, 8), (3000, "full", 70, 5), (300_000, "full", 100, 8), (700_000, "headline", 130, 8),
+                                             (5000, "allhot", 100, 8), (450_000, "allhot", 100, 8)])
 def test_spawn_key_held_matches_the_oracle(n, schema, rate, D, fuse, monkeypatch):
     """The stress_test with the spawn key down: every frame of every tick -- resimulated ones included -- spawns `rate` particles, Ttl despawns
     run beside them, the world grows across 64-slot, 256-slot and layout-tile boundaries.  `full`: the spawn bundle carries Transform,
