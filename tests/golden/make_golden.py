@@ -95,6 +95,8 @@ def main():
         "despawn_rollback_synctest": {"n200_cd3": {"n": 200, "ticks": 16, "check_distance": 3},
                                       "n5000_cd2": {"n": 5000, "ticks": 14, "check_distance": 2}},
         "p2p_shape": {"n600": {"n": 600, "ticks": 60}, "n3000": {"n": 3000, "ticks": 80}},
+        "allhot_spawn_held": {"n300_cd3": {"n": 300, "check_distance": 3, "ticks": 14, "rate": 70, "ttl_init": 9},
+                              "n9000_cd8": {"n": 9000, "check_distance": 8, "ticks": 18, "rate": 100, "ttl_init": 40}},
     }
     out["scenarios"] = {}
     for kind, cases_ in scen.items():

@@ -67,7 +67,25 @@ def run_p2p_shape(make_world, a):
             "final": _state_folds(st), "len": int(st["len"]), "frame": int(st["frame"])}
 
 
-SCENARIOS = {"box_game_synctest": run_box_game, "despawn_rollback_synctest": run_despawn_rollback, "p2p_shape": run_p2p_shape}
+def run_allhot_spawn_held(make_world, a):
+    """The all-columns-hot schema (tests/common.py: stress_test systems + increase_component over rotation / scale) under a SyncTest session that
+    HOLDS the spawn key: every frame, resimulated ones included, spawns `rate` particles -- on the HIP path inside the request group's launch."""
+    n, cd, ticks, rate = a["n"], a["check_distance"], a["ticks"], a["rate"]
+    w = make_world(n + rate * (ticks + 2 * cd + 4), cd + 1)
+    ids = cm.build_particles(w, with_spawn=True, ttl_init=a["ttl_init"], schema="allhot")
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    drv = cm.SyncTestDriver(w, cd, max_prediction=cd + 1)
+    fn = cm.frame_spawn_fn(rate)
+    for _ in range(ticks):
+        drv.tick((cm.INPUT_SPAWN,), spawn_fn=fn)
+    st = cm.snapshot_state(w, ids)
+    return {"checksums": [[int(f), f"{c:032x}"] for f, c in drv.all_checksums], "final": _state_folds(st), "len": int(st["len"]), "frame": int(st["frame"]),
+            "active": int(st["alive"].sum())}
+
+
+SCENARIOS = {"box_game_synctest": run_box_game, "despawn_rollback_synctest": run_despawn_rollback, "p2p_shape": run_p2p_shape,
+             "allhot_spawn_held": run_allhot_spawn_held}
 
 
 def replay_scenario(make_world, kind, case):
