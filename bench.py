@@ -68,10 +68,14 @@ def tick_requests(bg, w, depth):
     out = (C.c_uint64 * (2 * n_save))()
     save_idx = [i for i, r in enumerate(reqs) if isinstance(r, bg.SaveGameState)]
 
+    # the frames of the Load and of the Saves are the only fields that change from tick to tick: written through ONE strided numpy view of the
+    # ctypes array (a per-field ctypes store costs ~0.3 us each; at 10 k entities the tick is bound by exactly this kind of host work)
+    fv = np.ndarray((len(reqs),), dtype=np.int32, buffer=arr, offset=type(arr[0]).frame.offset, strides=(C.sizeof(arr[0]),))
+    idx = np.array([0] + save_idx, dtype=np.intp)
+    rel = np.array([-depth] + [-depth + 1 + k for k in range(len(save_idx))], dtype=np.int32)
+
     def patch(F):
-        arr[0].frame = F - depth
-        for k, i in enumerate(save_idx):
-            arr[i].frame = F - depth + 1 + k
+        fv[idx] = rel + np.int32(F)
 
     def run(F):
         patch(F)
