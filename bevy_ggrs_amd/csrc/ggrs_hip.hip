@@ -32,6 +32,7 @@
 #include <cstring>
 #include <atomic>
 #include <cctype>
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <map>
@@ -685,6 +686,9 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
         for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN;
         if (any_spawn) add("spawn_system", w->jit_spawn_sys >= 0 ? "runs inside the request group (rows appended by the group's launch)" : "ends the request group (its own launches)");
     }
+    add("blocking_wait", w->knobs.spin_wait_us > 0 ? "polls k_gen_finalize's completion tags when that kernel ends the list (" + std::to_string(w->spin_hits) + " calls so far, " +
+                                                      std::to_string(w->spin_misses) + " fell back to the stream wait), else hipStreamSynchronize"
+                                                    : "hipStreamSynchronize (GGRS_SPIN_WAIT_US=0)");
     add("slots_covered", std::to_string(cover));
     add("row_versions", w->knobs.row_versions ? "on" : "off (GGRS_ROW_VERSIONS=0)");
     if (needed) *needed = s.size() + 1;

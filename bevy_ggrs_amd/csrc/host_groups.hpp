@@ -140,6 +140,7 @@ inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 // the kernel's own begin and end, what rocprofv3's kernel trace reports) instead of bracketing it with two marker packets, which read ~3 us more.
 // `done`: an event that completes with THIS launch (enqueue's batch event riding on the list's last kernel instead of a marker packet behind it).
 int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tpb, uint32_t lds, void** params, uint64_t bytes, hipEvent_t done = nullptr) {
+    w->spin_n = 0;                                               // a finalize before this launch is no longer the list's last GPU operation (arm_spin)
     if (!w->prof) {
         if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
         else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr));
@@ -207,6 +208,14 @@ inline GenFinArgs make_gen_fin(const GgrsJitArgs& j, uint32_t rows, uint32_t n_c
     return f;
 }
 
+// A blocking call whose LAST GPU operation is this k_gen_finalize polls the tags the kernel leaves behind its results instead of asking the
+// runtime for the stream (read_back): every later launch of the list disarms it again (launch_jit, the spawn systems)
+inline void arm_spin(ggrs_world* w, GenFinArgs& f, uint32_t n_wgs, bool blocking) {
+    w->spin_n = 0;
+    if (!blocking || w->knobs.spin_wait_us <= 0 || !w->d_done || n_wgs > ggrs_world::SPIN_TAGS || w->prof || w->device_results_only) return;
+    f.done = w->d_done; f.seq = ++w->spin_seq; w->spin_n = n_wgs;
+}
+
 struct JitBatch {
     bool active = false; GgrsJitArgs j; uint32_t g = 0, k = 0, res_first = 0, n_cks = 0;
     void start(const GgrsJitArgs& j_, uint32_t g_, uint32_t res, uint32_t n_cks_) { active = true; j = j_; g = g_; k = 1; res_first = res; n_cks = n_cks_; }
@@ -241,6 +250,7 @@ struct JitBatch {
         }
         if (host_fold) { w->folds.push_back(make_host_fold(j, res_first, g, n_cks, k, rows_off)); return GGRS_OK; }
         GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)res_first);   // one row per workgroup
+        arm_spin(w, f, j.n_saves * k, blocking);
         {
             ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
             hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves * k), dim3(FIN_TPB), 0, w->stream, f);
@@ -255,6 +265,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     uint32_t i = 0, ns = 0;
     int rc = GGRS_OK;
     JitBatch batch; batch.blocking = wait;
+    w->spin_n = 0;
     struct Staged { const float* hx; const float* hy; uint64_t count; const float* dx; const float* dy; };
     std::vector<Staged> staged;                                        // payloads this list has staged already (by the caller's host arrays)
     const uint32_t n_cks = w->cks_args.n_cks;
@@ -424,6 +435,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, rows, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {
                 GenFinArgs f = make_gen_fin(j, rows, n_cks, w->d_results + 2 * (uint64_t)(res_base + ns));   // one row per workgroup (per group of 64 with the group fold)
+                arm_spin(w, f, j.n_saves, wait);
                 {
                     ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
                     hipLaunchKernelGGL(k_gen_finalize, dim3(j.n_saves), dim3(FIN_TPB), 0, w->stream, f);
@@ -435,6 +447,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         group_done:
         if (spawn_req) {
             rc = batch.flush(w); if (rc) return rc;
+            w->spin_n = 0;
             rc = run_spawn_systems(w, spawn_req->inputs, spawn_req->n_inputs, spawn_req->spawn_count, spawn_req->spawn_vx, spawn_req->spawn_vy);
             if (rc) return rc;
         }

@@ -548,7 +548,26 @@ bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks,
 }
 
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    // When the list's last GPU operation is a k_gen_finalize (arm_spin), its workgroups write a tag behind their results in the same pinned
+    // allocation: seeing every tag means every kernel of the list has run (one in-order stream) and the results are in host memory -- the
+    // runtime's own wait (a marker packet + its completion signal) costs several us more per call, which is all a blocking caller has to
+    // hide behind.  Bounded: past GGRS_SPIN_WAIT_US, with host-folded rows pending, and every 256th call (so that the runtime retires its
+    // command records) it is the stream wait.
+    bool seen = false;
+    if (w->spin_n && w->folds.empty() && (w->spin_seq & 255u) != 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t k = 0;
+        for (uint32_t it = 1; ; ++it) {
+            while (k < w->spin_n && w->h_done[k] == w->spin_seq) ++k;
+            if (k == w->spin_n) { seen = true; break; }
+            if ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(w->knobs.spin_wait_us)) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        ++(seen ? w->spin_hits : w->spin_misses);
+    }
+    w->spin_n = 0;
+    if (!seen) HIPCHK(w, hipStreamSynchronize(w->stream));
     run_host_folds(w, ~0u);
     stage_ring_reset(w);
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);

@@ -236,8 +236,10 @@ int seal_impl(ggrs_world* w) {
 
     // Checksum(u128) results are written by the kernels straight into pinned, device-mapped host memory:
     // no device->host copy node per request list, one stream sync makes them visible.
-    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16, hipHostMallocMapped));
+    HIPCHK(w, hipHostMalloc((void**)&w->h_results, (size_t)w->max_results * 16 + ggrs_world::SPIN_TAGS * 8, hipHostMallocMapped));
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_results, w->h_results, 0));
+    w->h_done = w->h_results + 2 * (size_t)w->max_results; w->d_done = w->d_results + 2 * (size_t)w->max_results;
+    memset((void*)w->h_done, 0, ggrs_world::SPIN_TAGS * 8); w->spin_seq = 0; w->spin_n = 0;
     HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes, hipHostMallocMapped));       // pinned AND device-mapped: a fused spawn's payload is read by the group's launch straight from here
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_hstage, w->h_stage, 0));
     if (w->jit_fn && w->knobs.host_fold_max_wgs) {

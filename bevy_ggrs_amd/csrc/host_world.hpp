@@ -75,6 +75,8 @@ struct Knobs {
                                    //                       per shape, 16 shapes per world; 0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
     int jit_spec_shapes = 16;      // GGRS_JIT_SPEC_SHAPES=n    group shapes counted (and specialised kernels kept) per world, 1..64; the least recently used one makes room
+    int spin_wait_us = 200;        // GGRS_SPIN_WAIT_US=0        blocking calls whose last GPU operation is k_gen_finalize poll the tags that kernel leaves in pinned memory for up to this long
+                                   //                            before falling back to hipStreamSynchronize (0: always the stream wait)
     bool event_on_kernel = true;   // GGRS_EVENT_ON_KERNEL=0     an enqueued list ends with a marker packet (hipEventRecord) even when its last GPU operation is the group kernel
     bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
     bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
@@ -108,6 +110,7 @@ struct Knobs {
         k.jit_specialise_sync = num("GGRS_JIT_SPECIALISE_SYNC", 0) != 0;
         k.jit_spec_shapes = (int)std::min<long long>(64, std::max<long long>(1, num("GGRS_JIT_SPEC_SHAPES", 16)));
         k.event_on_kernel = num("GGRS_EVENT_ON_KERNEL", 1) != 0;
+        k.spin_wait_us = (int)num("GGRS_SPIN_WAIT_US", 200);
         k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
         k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
         k.jit_cached_save_max_bytes = (uint64_t)std::max<long long>(0, num("GGRS_JIT_CACHED_SAVE_MAX_MB", 80)) << 20;
@@ -218,6 +221,10 @@ struct ggrs_world {
     std::vector<int> free_slots;
     uint64_t* d_parts = nullptr; uint32_t part_stride = 0;   // [(n_cks)+1][part_stride], last = counts
     uint64_t* d_results = nullptr; uint64_t* h_results = nullptr; uint32_t max_results = 0;
+    // completion tags of the list's closing k_gen_finalize (one per workgroup, behind the results in the same pinned allocation): a blocking
+    // call polls them instead of asking the runtime for the stream (read_back)
+    static constexpr uint32_t SPIN_TAGS = 256;
+    uint64_t* d_done = nullptr; volatile uint64_t* h_done = nullptr; uint64_t spin_seq = 0; uint32_t spin_n = 0; uint64_t spin_hits = 0, spin_misses = 0;
     UnitDesc* d_units = nullptr;
     uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
     // spawn payloads: a ring of floats in pinned, device-mapped memory (h_stage; d_hstage = the same bytes as the device sees them: fused spawns read

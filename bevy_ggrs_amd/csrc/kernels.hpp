@@ -654,6 +654,7 @@ struct GenFinArgs {
     const uint64_t* parts; uint32_t part_stride, n_parts, n_cks, n_saves;     // grid = n_saves x members (batch of identical groups)
     uint64_t save_len[MAX_TICK_SAVES];                                        // RollbackOrdered::len at each Save of the group (a fused spawn grows it)
     uint64_t* out;
+    uint64_t* done; uint64_t seq;                                             // completion tag per workgroup in pinned host memory (nullptr: none), see read_back
 };
 __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
     // rows = the n_cks component XORs + the live count; the 16 waves split over the rows so that every row's loads are in
@@ -693,6 +694,8 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
         for (uint32_t c = 0; c < f.n_cks; ++c) total ^= sea_one(acc[c]);      // component_checksum.rs:92-95
         total ^= sea_pair(acc[f.n_cks], f.save_len[k % f.n_saves]);          // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
         f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
+        // the result first, then the tag the waiting host polls (both in the same pinned allocation; release at system scope orders them)
+        if (f.done) __hip_atomic_store(f.done + k, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -40,6 +40,9 @@ KNOBS = [
     {"GGRS_JIT_LANE_FOLD": "1"},                            # checksum fold through per-lane LDS rows even for small worlds
     {"GGRS_JIT_LANE_FOLD": "0"},                            # ... and the per-Save DPP ladder even for big ones
     {"GGRS_EVENT_ON_KERNEL": "0"},                          # an enqueued list ends with a marker packet again
+    {"GGRS_HOST_FOLD_MAX_WGS": "0", "GGRS_SPIN_WAIT_US": "0"},   # every fold by k_gen_finalize (blocking calls then poll its completion tags, default 200 us) with the poll off:
+                                                                 # hipStreamSynchronize per blocking call, as in rounds 1-3
+    {"GGRS_HOST_FOLD_MAX_WGS": "0", "GGRS_SPIN_WAIT_US": "1"},   # ... and a poll that gives up at once (falls back to the stream wait mid-flight)
     {"GGRS_PRESENCE_VERSIONS": "0"},                        # presence masks stored with every Save
     {"GGRS_JIT_CACHE_FIRST_SAVE": "0"},                     # every Save of an HBM-sized rollback group streams past the caches
     {"GGRS_ARENA_CONTIG": "0"},
@@ -101,6 +104,8 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
         assert info["spawn_system"].startswith("ends the request group" if env.get("GGRS_JIT_FUSE_SPAWN") == "0" else "runs inside"), info
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "0": assert "group fold" not in info["checksum_fold"], info
     if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
+    if env == {"GGRS_HOST_FOLD_MAX_WGS": "0"}: assert " 0 calls so far" not in info["blocking_wait"] and info["blocking_wait"].startswith("polls"), info
+    if env.get("GGRS_SPIN_WAIT_US") == "0": assert info["blocking_wait"].startswith("hipStreamSynchronize"), info
     if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
     if env.get("GGRS_ARENA_CONTIG") == "0": assert info["arena"].startswith("paged"), info
     if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("ggrs_jit_tick"), k
