@@ -58,6 +58,12 @@ def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="head
     return w, ids
 
 
+def rss_mb():
+    try:
+        with open("/proc/self/statm") as f: return round(int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20, 1)
+    except Exception: return None
+
+
 def tick_requests(bg, w, depth):
     """Steady-state SyncTest tick as a reusable ctypes array; frames patched per tick."""
     reqs = [bg.LoadGameState(0), bg.AdvanceFrame((0,))]
@@ -360,6 +366,7 @@ def measure_single(bg, cm, torch, args, contig, light=False):
     m["preheat"] = {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "specialised_kernel_ready": spec_ready}
     torch.cuda.synchronize()
     m["frames_before_timed"] = w.frame
+    rss0 = rss_mb()
     gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
     stamps = []
     take = (lambda out: None) if light else (lambda out: (gpu_cs.append(bytes(out)), stamps.append(time.perf_counter())))
@@ -380,12 +387,12 @@ def measure_single(bg, cm, torch, args, contig, light=False):
             run.enqueue(w.frame)
             take(run.collect())
         take(run.collect())
-        w.synchronize()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                 # device-wide: covers the world's stream (it IS torch's current stream); a second, per-stream wait here only cost a marker packet
         secs = time.perf_counter() - t0
     gc.enable()
     m["secs"] = secs
     m["clocks_end"] = None if light else read_clocks()
+    m["rss_mb"] = [rss0, rss_mb()]               # resident set of this process before / after the timed region (soaks: the runtime must not grow with the tick count)
     m["live"] = w.active_count()
     m["gpu_cs"] = [[int.from_bytes(b[16 * k:16 * k + 16], "little") for k in range(D)] for b in gpu_cs]
     if stamps:
@@ -883,7 +890,7 @@ def main():
                                         "Checksum(u128)s are delivered.  The kernel hoists the order hash and memoises unchanged tails, and the step computes the "
                                         "branch-invariant Save(C+1) once per rank instead of once per branch (shared_prefix), so fewer are executed"}
     if not distributed:
-        line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us")}
+        line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us"), "rss_mb": m.get("rss_mb")}
     parity_failed = False
     if rank == 0 and not distributed:
         line["parity"] = {"synctest_resim_consistent_over_timed_ticks": bool(resim_ok), "timed_ticks": len(gpu_cs)}
