@@ -164,9 +164,9 @@ def _gen_list(sc, st):
         while st["F"] < F:
             save(); adv()
         save(); adv()
-    elif shape < 0.55 and cand and sc.depth >= 2:
+    elif shape < 0.55 and cand and ring.depth >= 2:
         # speculative branches off one snapshot: every branch but the last leaves nothing behind (fanout.py's list shape)
-        C = max(cand); B = int(r.integers(2, 7)); D = int(r.integers(1, min(5, sc.depth)))      # (the branches' Saves must not evict C)
+        C = max(cand); B = int(r.integers(2, 7)); D = int(r.integers(1, min(5, ring.depth)))      # (the branches' Saves must not evict C)
         for b in range(B):
             load(C)
             for i in range(D):
@@ -190,6 +190,11 @@ def _mutate(sc, st, A, B, ids):
         st["confirmed"] = c
         A.set_confirmed(c); B.set_confirmed(c)
         return f"confirmed={c}"
+    if x < 0.38:
+        d = int(r.integers(1, 9))                          # sync_depth: MaxPredictionWindow changed (mod.rs:123-138, 263-273); the next push trims the ring
+        st["ring"].depth = d
+        A.set_depth(d); B.set_depth(d)
+        return f"depth={d}"
     n = A.len
     if n == 0: return None
     alive = np.nonzero(A.alive_mask(n))[0]
@@ -235,18 +240,30 @@ def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=Fals
         assert tuple(ids) == tuple(idsb)
         st = {"F": A.frame, "ring": _Ring(sc.depth), "confirmed": 0, "spawns_left": sc.spawn_budget}
         use_async = hasattr(B, "enqueue_requests")
+        pending = []
+
+        def drain():
+            while pending:
+                k0, want, ctx0 = pending.pop(0)
+                got = B.collect_checksums()
+                assert want == list(got), f"checksums of the enqueued list {k0} differ:\n{ctx0}\n{want}\n{got}"
+
         for k in range(n_lists):
-            m = _mutate(sc, st, A, B, ids)
+            if sc.rng.random() < 0.6: drain()            # host edits with lists still in flight are part of the game (they are stream-ordered behind them)
+            m = _mutate(sc, st, A, B, ids) if not pending or sc.rng.random() < 0.5 else None
             if m: log.append(m)
             reqs = _gen_list(sc, st)
             log.append(" ".join(("S%d" % q.frame) if isinstance(q, bg.SaveGameState) else ("L%d" % q.frame) if isinstance(q, bg.LoadGameState)
                                 else ("A*" if q.inputs[0] else "A") for q in reqs))
             ca = A.handle_requests(reqs)
-            if use_async and sc.rng.random() < 0.3:
-                B.enqueue_requests(reqs); cb = B.collect_checksums()
-            else:
-                cb = B.handle_requests(reqs)
             ctx = "\n".join(log[:1] + log[-6:])
+            if use_async and sc.rng.random() < 0.4 and len(pending) < 3 and k != n_lists - 1:
+                # up to three lists in flight on B (enqueue / collect: the host-side bookkeeping of a list happens at enqueue time)
+                B.enqueue_requests(reqs); pending.append((k, list(ca), ctx))
+                log[-1] += "   (enqueued)"
+                continue
+            drain()
+            cb = B.handle_requests(reqs)
             assert list(ca) == list(cb), f"checksums differ after list {k}:\n{ctx}\n{ca}\n{cb}"
             assert (A.frame, A.len, A.snapshot_count()) == (B.frame, B.len, B.snapshot_count()) == (st["F"], A.len, A.snapshot_count()), \
                 f"frame / len / snapshots differ after list {k}: {(A.frame, A.len, A.snapshot_count())} vs {(B.frame, B.len, B.snapshot_count())} (model frame {st['F']})\n{ctx}"
