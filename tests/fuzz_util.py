@@ -37,14 +37,15 @@ class _Ring:
 
 
 class Scenario:
-    def __init__(self, seed, *, big=False):
+    def __init__(self, seed, *, big=False, max_n=None):
         r = self.rng = np.random.default_rng([0xF022, seed])
         self.seed = seed
         sizes = [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097, 8191, 8192, 8193, 20_000] if not big else [300_000, 700_001]
-        self.n = int(r.choice(sizes))
+        self.n = int(r.choice([s for s in sizes if not max_n or s <= max_n]))
         self.schema = str(r.choice(["headline", "headline", "allhot", "full"]))
         self.with_spawn = bool(r.random() < 0.6)
         self.rate = int(r.choice([1, 7, 64, 300])) if not big else int(r.choice([100, 5000]))
+        if max_n: self.rate = min(self.rate, 7)
         self.spawn_budget = 24
         self.ttl_mode = str(r.choice(["despawn", "throughput", "short"]))
         self.ttl_init = int(r.choice([2, 5, 300]))
@@ -75,10 +76,10 @@ class GenericScenario:
     despawns at zero, immediately or with a RollbackDespawned marker (tests/synctest.rs:37-44, snapshot/despawn.rs:114-143)."""
     with_spawn, spawn_budget, spawn_fn = False, 0, None
 
-    def __init__(self, seed, *, big=False):
+    def __init__(self, seed, *, big=False, max_n=None):
         r = self.rng = np.random.default_rng([0x6E6E, seed])
         self.seed = seed
-        self.n = int(r.choice([1, 64, 65, 257, 3000, 8193, 20_000] if not big else [300_000, 600_001]))
+        self.n = int(r.choice([s for s in ([1, 64, 65, 257, 3000, 8193, 20_000] if not big else [300_000, 600_001]) if not max_n or s <= max_n]))
         self.depth = int(r.integers(1, 9))
         self.comps = [(f"C{i}", int(r.choice([1, 2, 4, 4, 8])), int(r.integers(1, 4))) for i in range(int(r.integers(2, 6)))]
         self.comps[0] = ("C0", 4, self.comps[0][2])                                     # add_u32 needs a 4-byte word somewhere
@@ -231,8 +232,8 @@ def _extra_state(w):
     return out
 
 
-def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False):
-    sc = (GenericScenario if generic else Scenario)(seed, big=big)
+def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False, max_n=None):
+    sc = (GenericScenario if generic else Scenario)(seed, big=big, max_n=max_n)
     A, B = make_a(sc), make_b(sc)
     log = [sc.describe()]
     try:

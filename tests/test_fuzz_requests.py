@@ -28,6 +28,15 @@ def test_oracle_modes_agree_on_random_request_lists_generic_worlds(seed):
     fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: OracleWorld(sc.capacity, 8, REFSHAPED), n_lists=24, generic=True)
 
 
+@pytest.mark.parametrize("generic", [False, True], ids=["particles", "generic"])
+@pytest.mark.parametrize("seed", seeds(120))
+def test_oracle_matches_the_numpy_twin_on_random_request_lists(seed, generic):
+    """The two INDEPENDENT restatements (C++ columns vs numpy per-entity snapshots, oracle/twin_np.py) on lists no session would
+    emit: what pins the oracle while the reference's own checksums cannot be had."""
+    from oracle.twin_np import TwinWorld
+    fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: TwinWorld(sc.capacity, 8), n_lists=20, generic=generic, max_n=1000)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", seeds(120))
 def test_hip_matches_the_oracle_on_random_request_lists(seed):
