@@ -975,7 +975,7 @@ int gor_set_component_default(void* wp, uint32_t c, const void* words) {
 // checksum_component / checksum_component_with_hash (rollback_app.rs:99-101,119-121)
 int gor_checksum_component(void* wp, uint32_t c, const uint32_t* word_idx, uint32_t n) {
     World& w = *(World*)wp;
-    if (c >= w.comps.size()) return -1;
+    if (c >= w.comps.size() || w.sealed) return -1;                  // registration ends with the first spawn, as in the library (and in an App: plugins are added at build time)
     Comp& cc = w.comps[c];
     cc.cks_units.clear(); cc.cks_fn = nullptr;
     for (uint32_t k = 0; k < n; ++k) {

@@ -121,7 +121,39 @@ class GenericScenario:
         return tuple(ids) + ((H,) if self.health else ())
 
 
+class BoxScenario:
+    """box_game (examples/box_game/box_game.rs:89-206): cubes steered by 1-4 players' input bytes, Transform and Velocity under
+    rollback, Player outside it; arbitrary starting states so that every branch of move_cube_system is taken."""
+    with_spawn, spawn_budget, spawn_fn = False, 0, None
+
+    def __init__(self, seed, *, big=False, max_n=None):
+        r = self.rng = np.random.default_rng([0xB0C5, seed])
+        self.seed = seed
+        self.n = int(r.choice([s for s in ([2, 64, 257, 5000, 8193] if not big else [300_000]) if not max_n or s <= max_n]))
+        self.players = int(r.integers(1, 5))
+        self.depth = int(r.integers(1, 9))
+        self.cks = [bool(r.random() < 0.7), bool(r.random() < 0.7)]
+        self.fps = int(r.choice([60, 60, 30, 144]))
+        self.capacity = self.n + 8
+
+    def describe(self):
+        return f"box_game seed {self.seed}: n={self.n} players={self.players} depth={self.depth} checksums(T, V)={self.cks} fps={self.fps}"
+
+    def build(self, world):
+        from test_box_game import build_box
+        ids, *_ = build_box(world, self.n, self.players, seed=self.seed, spread=True, checksums=[(c, [0, 1, 2]) for c in (0, 1) if self.cks[c]])
+        world.set_frame_rate(self.fps)
+        world.set_depth(self.depth)
+        if hasattr(world, "set_synctest_check_distance"): world.set_synctest_check_distance(-1)
+        return ids
+
+    def inputs(self, frame):
+        # a predicted input may differ from the one confirmed later: the same frame is not always advanced with the same bytes
+        return tuple(int(x) for x in self.rng.integers(0, 16, self.players))
+
+
 def _adv(sc, frame, spawn):
+    if isinstance(sc, BoxScenario): return bg.AdvanceFrame(sc.inputs(frame))
     a = bg.AdvanceFrame((cm.INPUT_SPAWN if spawn else 0,))
     if spawn: a.spawn_vx, a.spawn_vy = sc.spawn_fn(frame)
     return a
@@ -182,6 +214,12 @@ def _gen_list(sc, st):
     return reqs
 
 
+def _box_words(sc, r, wb, count):
+    """Finite floats for Transform / Velocity words, a valid handle for Player (the game never holds a NaN or a handle without a player)."""
+    if wb == 8: return r.integers(0, sc.players, count).astype(np.uint64)
+    return cm.f32bits(r.uniform(-3, 3, count).astype(np.float32))
+
+
 def _mutate(sc, st, A, B, ids):
     """Host-side edits between two lists, the same on both backends."""
     r = sc.rng
@@ -214,12 +252,14 @@ def _mutate(sc, st, A, B, ids):
             return f"remove c{V}({s})"
         w = r.integers(0, 2 ** (8 * wb), nw, dtype=np.uint64).astype(_DT[wb])
         if isinstance(sc, Scenario): w = cm.f32bits(np.array([r.uniform(-50, 50), r.uniform(-50, 50), 0.0], dtype=np.float32))
+        if isinstance(sc, BoxScenario): w = _box_words(sc, r, wb, nw)
         A.insert_component(V, s, w); B.insert_component(V, s, w)
         return f"insert c{V}({s})"
     if x < 0.68:
         first = int(r.integers(0, n)); cnt = int(r.integers(1, min(n - first, 700) + 1)); k = int(r.integers(nw))
         data = r.integers(0, 2 ** (8 * wb), cnt, dtype=np.uint64).astype(_DT[wb])
         if isinstance(sc, Scenario): data = cm.f32bits(r.uniform(-100, 100, cnt).astype(np.float32))
+        if isinstance(sc, BoxScenario): data = _box_words(sc, r, wb, cnt)
         A.upload_word(V, k, first, data); B.upload_word(V, k, first, data)
         return f"upload c{V}w{k}[{first}:{first + cnt}]"
     return None
@@ -232,8 +272,8 @@ def _extra_state(w):
     return out
 
 
-def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False, max_n=None):
-    sc = (GenericScenario if generic else Scenario)(seed, big=big, max_n=max_n)
+def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False, max_n=None, box=False):
+    sc = (BoxScenario if box else GenericScenario if generic else Scenario)(seed, big=big, max_n=max_n)
     A, B = make_a(sc), make_b(sc)
     log = [sc.describe()]
     try:
@@ -255,7 +295,7 @@ def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=Fals
             if m: log.append(m)
             reqs = _gen_list(sc, st)
             log.append(" ".join(("S%d" % q.frame) if isinstance(q, bg.SaveGameState) else ("L%d" % q.frame) if isinstance(q, bg.LoadGameState)
-                                else ("A*" if q.inputs[0] else "A") for q in reqs))
+                                else ("A*" if q.inputs[0] and not box else "A") for q in reqs))
             ca = A.handle_requests(reqs)
             ctx = "\n".join(log[:1] + log[-6:])
             if use_async and sc.rng.random() < 0.4 and len(pending) < 3 and k != n_lists - 1:

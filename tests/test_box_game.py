@@ -18,13 +18,14 @@ HALF_WIDTH = float((np.float32(5.0) - np.float32(0.2)) * np.float32(0.5))
 BOX_PARAMS = (18.0, 3.0, 0.0018, HALF_WIDTH)          # ACCELERATION, MAX_SPEED, FRICTION, half_width (box_game.rs:18-22,202)
 
 
-def build_box(world, n, num_players, seed=5, spread=False):
+def build_box(world, n, num_players, seed=5, spread=False, checksums=()):
     """setup_system (box_game.rs:89-143): cube `handle` on a circle of radius PLANE_SIZE/4; Transform (clone) and
     Velocity (copy) are registered for rollback, Player is a plain component (box_game_synctest.rs:44-45)."""
     T = world.register_component("Transform", 4, 10)
     V = world.register_component("Velocity", 4, 3)
     P = world.register_component("Player", 8, 1, rollback=False)
     world.set_component_default(T, cm.TRANSFORM_DEFAULT)
+    for c, words in checksums: world.checksum_component((T, V, P)[c], words)      # (registration ends with the first spawn)
     world.add_system(bg.SYS_BOX_MOVE, comp=(T, V, P), word=(0, 0, 0), fparam=BOX_PARAMS)
     handle = (np.arange(n) % num_players).astype(np.uint64)
     r = np.float32(5.0) / np.float32(4.0)

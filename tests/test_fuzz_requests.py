@@ -37,6 +37,18 @@ def test_oracle_matches_the_numpy_twin_on_random_request_lists(seed, generic):
     fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: TwinWorld(sc.capacity, 8), n_lists=20, generic=generic, max_n=1000)
 
 
+@pytest.mark.parametrize("seed", seeds(60))
+def test_oracle_matches_the_numpy_twin_on_random_request_lists_box_game(seed):
+    from oracle.twin_np import TwinWorld
+    fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: TwinWorld(sc.capacity, 8), n_lists=20, box=True, max_n=5000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", seeds(60))
+def test_hip_matches_the_oracle_on_random_request_lists_box_game(seed):
+    fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: bg.World(sc.capacity, max_depth=8), n_lists=30, box=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", seeds(120))
 def test_hip_matches_the_oracle_on_random_request_lists(seed):
