@@ -252,6 +252,9 @@ def default_branch_input(branch: int, frame: int) -> int:
     return branch & 0xFF
 
 
+default_branch_input.frame_invariant = True       # same byte for every frame: the driver asks once per branch, not once per branch and step
+
+
 class SpeculativeFanout:
     def __init__(self, world, dist, depth: int, exchange, branches_per_rank: int = 1,
                  branch_input: Callable[[int, int], int] = default_branch_input,
@@ -429,39 +432,81 @@ class SpeculativeFanout:
         self.confirmed = C + 1
         return self._finish(C, self._as_u64_pairs(cs), want_result)
 
-    # ---- pre-marshalled request list for the pipelined path: with no spawn payloads a step's list only
-    # differs from the previous one in its frame numbers and input bytes, which are patched in place
+    # ---- pre-marshalled request list for the pipelined path: a step's list differs from the previous one only in its frame numbers,
+    # input bytes and -- with a spawn system -- in which payload each spawning AdvanceFrame points at; all of it is patched in place
+    # (marshalling ~4000 request objects per step was 6 of the 7.4 ms of a 256-branch step with diverging branches, profiles/r04i)
     def _template(self):
         import ctypes as C_
-        reqs = self._requests(0)
+        spawn_fn, self.spawn_fn = self.spawn_fn, None        # the template carries no payload: _patch points the spawning advances at theirs
+        try: reqs = self._requests(0)
+        finally: self.spawn_fn = spawn_fn
         arr, keep, n_save = self.w.build_requests(reqs)
         loads = [(i, r.frame) for i, r in enumerate(reqs) if isinstance(r, LoadGameState)]
         saves = [(i, r.frame) for i, r in enumerate(reqs) if isinstance(r, SaveGameState)]
         advs = [i for i, r in enumerate(reqs) if isinstance(r, AdvanceFrame)]
         out = (C_.c_uint64 * (2 * max(n_save, 1)))()
-        return {"arr": arr, "keep": keep, "n": len(reqs), "n_save": n_save, "loads": loads, "saves": saves, "advs": advs,
-                "out": out, "out_np": np.frombuffer(out, dtype=np.uint64).reshape(-1, 2)}
+        t = {"arr": arr, "keep": keep, "n": len(reqs), "n_save": n_save, "loads": loads, "saves": saves, "advs": advs,
+             "out": out, "out_np": np.frombuffer(out, dtype=np.uint64).reshape(-1, 2)}
+        # frame of every AdvanceFrame relative to C, in list order (a Load sets the frame, an Advance moves it on by one)
+        rel, cur = [], 0
+        for r in reqs:
+            if isinstance(r, LoadGameState): cur = r.frame
+            elif isinstance(r, AdvanceFrame): rel.append(cur); cur += 1
+        t["adv_rel"] = np.array(rel, dtype=np.intp)
+        # the frame field of every Load / Save as one strided view: a step rewrites them with one assignment
+        R = type(arr[0]); sz = C_.sizeof(R)
+        t["frame_view"] = np.ndarray((len(reqs),), dtype=np.int32, buffer=arr, offset=R.frame.offset, strides=(sz,))
+        t["frame_idx"] = np.array([i for i, _ in loads + saves], dtype=np.intp)
+        t["frame_rel"] = np.array([f for _, f in loads + saves], dtype=np.int64)
+        if spawn_fn is not None:
+            # the three spawn fields of every request as strided views of the ctypes array (pointers as u64): one assignment per field per step
+            view = lambda field: np.ndarray((len(reqs),), dtype=np.uint64, buffer=arr, offset=getattr(R, field).offset, strides=(sz,))
+            t["spawn_views"] = (view("spawn_count"), view("spawn_vx"), view("spawn_vy"))
+            t["adv_idx"] = np.array(advs, dtype=np.intp)
+        return t
+
+    def _payload(self, frame: int):
+        """(count, address of vx, address of vy, arrays) of the frame's spawn payload: a pure function of the frame, drawn once."""
+        pay = self._spawn_cache.get(frame)
+        if pay is None:
+            if len(self._spawn_cache) > 64: self._spawn_cache.clear()
+            pay = self._spawn_cache[frame] = self.spawn_fn(frame)
+        vx, vy = (np.ascontiguousarray(a, dtype=np.float32) for a in pay)
+        if vx is not pay[0] or vy is not pay[1]: self._spawn_cache[frame] = (vx, vy)
+        return vx.size, vx.ctypes.data, vy.ctypes.data, (vx, vy)
 
     def _patch(self, t, C: int):
         arr, D = t["arr"], self.D
-        for i, rel in t["loads"]:
-            arr[i].frame = C + rel
-        for i, rel in t["saves"]:
-            arr[i].frame = C + rel
+        t["frame_view"][t["frame_idx"]] = (t["frame_rel"] + C).astype(np.int32)
         c_in = self.confirmed_input(C)
         ids = self.branch_ids()
+        pred = t.get("pred") if getattr(self.branch_input, "frame_invariant", False) else None
         if self.share_prefix:                                # advance 0: the confirmed input; then D predicted ones per branch (frames C+1 .. C+D)
-            inputs = [c_in] + [self.branch_input(ids[(k - 1) // D], C + 1 + (k - 1) % D) for k in range(1, len(t["advs"]))]
+            if pred is None: pred = [self.branch_input(ids[(k - 1) // D], C + 1 + (k - 1) % D) for k in range(1, len(t["advs"]))]
+            inputs = [c_in] + pred
         else:
             per_branch = D + 1
-            inputs = [c_in if k % per_branch == 0 else self.branch_input(ids[k // per_branch], C + k % per_branch) for k in range(len(t["advs"]))]
-        if inputs == t.get("inputs"):                        # the usual case: predictions repeat, nothing to rewrite
-            return
-        t["inputs"] = inputs
-        for k, i in enumerate(t["advs"]):
-            q = arr[i]
-            for p in range(q.n_inputs):
-                q.inputs[p] = inputs[k]
+            if pred is None: pred = [0 if k % per_branch == 0 else self.branch_input(ids[k // per_branch], C + k % per_branch) for k in range(len(t["advs"]))]
+            inputs = list(pred); inputs[::per_branch] = [c_in] * len(inputs[::per_branch])
+        t["pred"] = pred
+        if inputs != t.get("inputs"):                        # (the usual case: predictions repeat, nothing to rewrite)
+            t["inputs"] = inputs
+            t["spawning"] = (np.array(inputs, dtype=np.int64) & self.spawn_mask) != 0
+            for k, i in enumerate(t["advs"]):
+                q = arr[i]
+                for p in range(q.n_inputs):
+                    q.inputs[p] = inputs[k]
+        if self.spawn_fn is not None:
+            # every spawning AdvanceFrame points at the payload of ITS frame (C + its relative frame): D + 1 payloads per step at most,
+            # the library copies them into its own ring while it enqueues (they only have to live until that call returns)
+            rels = np.unique(t["adv_rel"][t["spawning"]])
+            cnt = np.zeros(D + 2, dtype=np.uint64); px = np.zeros(D + 2, dtype=np.uint64); py = np.zeros(D + 2, dtype=np.uint64)
+            t["pay_keep"] = []
+            for r in rels:
+                cnt[r], px[r], py[r], keep = self._payload(C + int(r)); t["pay_keep"].append(keep)
+            vc, vx, vy = t["spawn_views"]
+            sel, idx = t["adv_rel"], t["adv_idx"]
+            vc[idx] = np.where(t["spawning"], cnt[sel], 0); vx[idx] = np.where(t["spawning"], px[sel], 0); vy[idx] = np.where(t["spawning"], py[sel], 0)
 
     def step_pipelined(self, want_result: bool = True) -> Optional[dict]:
         """Enqueue the step of confirmed frame C on the device, THEN collect and all-gather the oldest step once more
@@ -476,13 +521,10 @@ class SpeculativeFanout:
             return self.step(want_result)
         C = self.confirmed
         self.w.set_confirmed(C)
-        if self.spawn_fn is None:
-            if self._tmpl is None:
-                self._tmpl = self._template()
-            self._patch(self._tmpl, C)
-            self.w.enqueue_requests_raw(self._tmpl["arr"], self._tmpl["n"])
-        else:
-            self.w.enqueue_requests(self._requests(C))
+        if self._tmpl is None:
+            self._tmpl = self._template()
+        self._patch(self._tmpl, C)
+        self.w.enqueue_requests_raw(self._tmpl["arr"], self._tmpl["n"])
         self._inflight.append(C)
         self.confirmed = C + 1
         return self._collect_one(want_result) if len(self._inflight) > self.max_inflight else None
@@ -491,13 +533,10 @@ class SpeculativeFanout:
     def _native_enqueue(self):
         C = self.confirmed
         self.w.set_confirmed(C)
-        if self.spawn_fn is None:
-            if self._tmpl is None:
-                self._tmpl = self._template()
-            self._patch(self._tmpl, C)
-            self.native.step_raw(self._tmpl["arr"], self._tmpl["n"])
-        else:
-            self.native.step(self._requests(C))
+        if self._tmpl is None:
+            self._tmpl = self._template()
+        self._patch(self._tmpl, C)
+        self.native.step_raw(self._tmpl["arr"], self._tmpl["n"])
         self._inflight.append(C)
         self.confirmed = C + 1
 
