@@ -58,6 +58,21 @@ def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="head
     return w, ids
 
 
+def alu_view(diffuses_per_launch, launch_s):
+    """The dominant kernel priced against the chip's OTHER ceiling: SeaHash `diffuse` (two u64 multiplies) per second against what
+    scripts/ubench_alu.hip measured on every CU (profiles/alu_ceiling.json).  Informational next to `roofline` (the kernel is bound by
+    HBM): it says how far the hashing is from becoming the bound.  Never raises: a missing ceiling file gives frac None."""
+    try:
+        ceil = json.load(open(os.path.join(ROOT, "profiles", "alu_ceiling.json")))
+        peak = float(ceil["diffuse_G_per_s"])
+    except Exception:
+        ceil, peak = {}, None
+    ach = diffuses_per_launch / launch_s / 1e9 if launch_s > 0 else 0.0
+    return {"bound": "valu-int (u64 multiply)", "achieved": ach, "unit": "G diffuse/s", "peak": peak, "frac": (ach / peak) if peak else None,
+            "peak_source": ceil.get("source"),
+            "note": "algorithmic count (SURVEY 8d): 6 diffuse per entity per checksummed component per SaveWorld; the kernel executes fewer (hoisted order hash, memoised tails)"}
+
+
 def rss_mb():
     try:
         with open("/proc/self/statm") as f: return round(int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20, 1)
@@ -824,6 +839,10 @@ def main():
                 "other_kernels": ({fin_name: {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
                 "per_request_equiv_GBps": tick_bytes * live * K / secs / 1e9,
                 "per_request_equiv_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
+        if tick_n and not distributed and not args.no_checksum:
+            # (the particles schemas checksum two components: Velocity and Transform.translation, tests/common.py build_particles)
+            try: roof["alu"] = alu_view(6.0 * 2 * live * D, avg_s)
+            except Exception: pass
         if variant is not None:
             v_ms, v_n = variant["prof"]["tick"]
             v_avg = per(v_ms, v_n)

@@ -97,3 +97,15 @@ def test_parity_gate_with_the_spawn_system():
     par = bench.fanout_parity(n, D, c_timed, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2, spawn_rate=rate)
     assert par["equal"] is True and par["checked_saves"] == 2 * bpr * D, par
     assert bench.fanout_parity(n, D, c_timed, fan.raw, 1, bpr, default_branch_input, lambda f: 0, threads=2, spawn_rate=0)["equal"] is False
+
+
+def test_alu_view_prices_a_launch_against_the_measured_ceiling():
+    """bench.py's informational `roofline.alu`: 1 M entities x 8 Saves x 2 components x 6 diffuse in 49.2 us against profiles/alu_ceiling.json."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    v = b.alu_view(6.0 * 2 * 1_000_000 * 8, 49.2e-6)
+    peak = json.load(open(os.path.join(root, "profiles", "alu_ceiling.json")))["diffuse_G_per_s"]
+    assert abs(v["achieved"] - 96e6 / 49.2e-6 / 1e9) < 1e-6 and v["peak"] == peak and abs(v["frac"] - v["achieved"] / peak) < 1e-12
+    assert 0.5 < v["frac"] < 0.8
+    assert b.alu_view(1.0, 0.0)["achieved"] == 0.0
