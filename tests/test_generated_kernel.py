@@ -231,3 +231,33 @@ def test_narrow_words_and_custom_hashers_generate():
         src = w.generated_kernel_source(compile=True, persistent=persistent)
         assert "GGRS_G uint8_t*" in src and "GGRS_G uint16_t*" in src and "ggrs_hash_0::ggrs_hash(cv)" in src
         assert re.search(r"st\.write\(w\d+_0, 1u\)", src) and re.search(r"st\.write\(w\d+_0, 2u\)", src)
+
+
+# ---- register / scratch budget of the kernels the library writes (static: hiprtc cross-compiles, the code object's metadata says what the
+# kernel needs).  The generated kernel is HBM-bound and hides latency with occupancy: 8 waves per SIMD need <= 64 VGPRs, and a spill to
+# scratch would add HBM traffic of its own.  VGPRs when this test was written (steady / generic): headline 28 / 43, allhot 38 / 47, full 28 / 63 (the steady copy of the full schema
+# does not even load the rows no system writes).
+def _resources(src: str) -> dict:
+    import ctypes as C, subprocess, tempfile
+    rtc = C.CDLL("libhiprtc.so")
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-ffp-contract=off", b"-fno-fast-math", b"-fhip-fp32-correctly-rounded-divide-sqrt"]
+    prog = C.c_void_p()
+    assert rtc.hiprtcCreateProgram(C.byref(prog), src.encode(), b"k.hip", 0, None, None) == 0
+    arr = (C.c_char_p * len(opts))(*opts)
+    assert rtc.hiprtcCompileProgram(prog, len(opts), arr) == 0
+    n = C.c_size_t(); rtc.hiprtcGetCodeSize(prog, C.byref(n)); code = C.create_string_buffer(n.value); rtc.hiprtcGetCode(prog, code)
+    with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
+        f.write(code.raw); f.flush()
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    return {k: int(re.search(re.escape(k) + r":\s*(\d+)", notes)[1]) for k in (".vgpr_count", ".sgpr_count", ".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count")}
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="no llvm-readelf")
+@pytest.mark.parametrize("schema,steady_vgprs", [("headline", 32), ("allhot", 48), ("full", 64)])
+def test_generated_kernels_keep_their_register_budget(schema, steady_vgprs):
+    w = dry(1_000_000, 9)
+    cm.build_particles(w, schema=schema)
+    for steady, limit in ((True, steady_vgprs), (False, 64)):
+        r = _resources(w.generated_kernel_source(steady=steady))
+        assert r[".private_segment_fixed_size"] == 0 and r[".vgpr_spill_count"] == 0 and r[".sgpr_spill_count"] == 0, (schema, steady, r)
+        assert r[".vgpr_count"] <= limit, (schema, steady, r)
