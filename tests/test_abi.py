@@ -234,3 +234,15 @@ def test_kernel_info_without_a_device():
     info = w.kernel_info()
     assert info["sealed"] == "0" and info["hiprtc"].startswith(("loaded", "missing")) and "request_group_kernel" in info and info["row_versions"] == "on"
     assert info["specialised_kernel"] == "none yet" and w.specialise_wait() is False              # nothing to wait for: no request group has run
+
+
+def test_every_environment_knob_is_documented():
+    """Every GGRS_* variable the library reads (csrc/) has a row in INTEGRATION.md's knob table."""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "bevy_ggrs_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'"(GGRS_[A-Z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(names) > 30
+    assert not [n for n in sorted(names) if n not in doc]
