@@ -59,7 +59,42 @@ class HostExchange:
         return torch.stack(out).numpy().view(np.uint64)
 
 
-def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
+def _queued_oracle_world():
+    """An oracle world with the library's enqueue / collect entry points (run at once, results queued): what SpeculativeFanout's
+    pipelined path needs, so that its pre-marshalled request template, its steps in flight and its one all-gather per
+    `desync_detection_interval` steps run on the CPU too."""
+    import ctypes as C
+    from bevy_ggrs_amd import _ffi
+    from oracle.binding import OracleWorld, lib
+
+    class QueuedOracleWorld(OracleWorld):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k); self._queue = []
+
+        def enqueue_requests_raw(self, arr, n):
+            n_save = sum(1 for i in range(n) if arr[i].kind == _ffi.REQ_SAVE)
+            out = (C.c_uint64 * max(2, 2 * n_save))()
+            self.handle_requests_raw(arr, n, out)
+            self._queue.append((out, n_save))
+
+        def collect_checksums_raw(self, out, max_saves):
+            src, n_save = self._queue.pop(0)
+            assert n_save <= max_saves
+            C.memmove(out, src, 16 * n_save)
+
+        def enqueue_requests(self, requests):
+            arr, keep, n_save = self.build_requests(requests)
+            self.enqueue_requests_raw(arr, len(requests))
+            return n_save
+
+        def collect_checksums(self, max_saves=256):
+            src, n_save = self._queue.pop(0)
+            return [int(src[2 * i]) | (int(src[2 * i + 1]) << 64) for i in range(n_save)]
+
+    return QueuedOracleWorld
+
+
+def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q, pipelined=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
@@ -68,7 +103,7 @@ def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
         from bevy_ggrs_amd import SaveGameState as bg_SaveGameState
         from oracle.binding import OracleWorld
         cap = n + 100 * (steps + D + 2) * 2
-        w = OracleWorld(cap, D + 1)
+        w = (_queued_oracle_world() if pipelined else OracleWorld)(cap, D + 1)
         ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
         if rank == 0:                              # only the root owns the confirmed world
             vel, ttl = cm.synthetic_particles(n, ttl="despawn")
@@ -80,7 +115,7 @@ def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
         fan = SpeculativeFanout(w, dist, D, HostExchange(w, ids), branches_per_rank=bpr,
                                 branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
                                 confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
-                                spawn_fn=fn)
+                                spawn_fn=fn, max_inflight=2 if pipelined else 1, desync_detection_interval=pipelined or 1)
         out = []
         err = None
         for s in range(steps):
@@ -91,10 +126,15 @@ def _worker(rank, world_size, port, n, D, bpr, steps, corrupt, q):
                 w.upload_word(ids[1], 0, 250, np.array([0x3f800000], dtype=np.uint32))
                 w.handle_requests([bg_SaveGameState(fan.confirmed)])
             try:
-                out.append(fan.step())
+                if pipelined: fan.step_pipelined()          # results arrive later, in order: fan.results
+                else: out.append(fan.step())
             except DesyncDetected as e:
                 err = ("desync", e.frame, len(set(e.checksums)))
                 break
+        if err is None and pipelined:
+            try: fan.drain()
+            except DesyncDetected as e: err = ("desync", e.frame, len(set(e.checksums)))
+            out = list(fan.results)
         if err is None:
             fan.settle()                           # back to the confirmed frame: identical on every rank
         q.put((rank, out, err, cm.snapshot_state(w, ids) if err is None else None))
@@ -106,7 +146,7 @@ def _run(world_size, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    args = (world_size, port, kw["n"], kw["D"], kw["bpr"], kw["steps"], kw.get("corrupt", 0), q)
+    args = (world_size, port, kw["n"], kw["D"], kw["bpr"], kw["steps"], kw.get("corrupt", 0), q, kw.get("pipelined", 0))
     procs = [ctx.Process(target=_worker, args=(r,) + args) for r in range(world_size)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
@@ -160,10 +200,12 @@ def _serial_reference(n, D, n_branches, steps, branch_input=None, confirmed_inpu
     return out, cm.snapshot_state(w, ids)
 
 
-@pytest.mark.parametrize("bpr", [1, 3])
-def test_fanout_two_ranks_matches_serial_walk(bpr):
-    n, D, steps = 700, 4, 6
-    res = _run(2, n=n, D=D, bpr=bpr, steps=steps)
+@pytest.mark.parametrize("bpr,pipelined", [(1, 0), (3, 0), (1, 3), (3, 3), (5, 1)])
+def test_fanout_two_ranks_matches_serial_walk(bpr, pipelined):
+    """pipelined = desync_detection_interval of the pipelined path (0: one synchronous step at a time): the request list is the patched
+    template (spawn payloads included), two steps are in flight and `pipelined` steps share one all-gather."""
+    n, D, steps = 700, 4, 6 if not pipelined else 7      # (7 steps: the last all-gather group is a partly filled one)
+    res = _run(2, n=n, D=D, bpr=bpr, steps=steps, pipelined=pipelined)
     ref, ref_state = _serial_reference(n, D, 2 * bpr, steps)
     import common as cm
     for rank, out, err, state in res:
@@ -178,7 +220,7 @@ def test_fanout_two_ranks_matches_serial_walk(bpr):
     # branches with the same inputs agree
     last = res[0][1][-1]["branch_checksums"]
     assert last[0][0] == last[1][0] and last[0][1:] != last[1][1:]
-    if bpr == 3:
+    if bpr >= 3:
         assert last[0] == last[2] == last[4] and last[1] == last[3] == last[5]
 
 
