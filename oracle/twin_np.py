@@ -307,7 +307,7 @@ class TwinWorld:
 
     # ------------------------------------------------------------------ AdvanceWorld
     def advance(self, inputs=(), dt_bits=0, spawn_vx=None, spawn_vy=None):
-        self.frame += 1                                      # schedule_systems.rs:254-259
+        self.frame = ((self.frame + 1 + 2**31) % 2**32) - 2**31   # schedule_systems.rs:254-259 `frame_count.0 += 1` on an i32: a release build wraps (mod.rs:159 expects it)
         if dt_bits == 0:
             dt_bits = onp.dt_bits(self._fps, self.frame)     # GgrsTimePlugin::update, time.rs:63-87
         n = self._len

@@ -21,19 +21,39 @@ import bevy_ggrs_amd as bg
 import common as cm
 
 
+def w32(x):
+    """i32 arithmetic of the frame counters (Frame = i32; RollbackFrameCount wraps: schedule_systems.rs:223-268)."""
+    return ((int(x) + 2**31) % 2**32) - 2**31
+
+
+def ahead(a, b):
+    """How many frames `a` is ahead of `b`, modulo 2^32."""
+    return (int(a) - int(b)) % 2**32
+
+
 class _Ring:
     """Which frames the snapshot ring holds (mod.rs:147-226), without confirmation: the generator only loads frames at or
-    above ConfirmedFrameCount, which confirmation never prunes (mod.rs:185-202 pops frames BELOW it)."""
+    above ConfirmedFrameCount, which confirmation never prunes (mod.rs:185-202 pops frames BELOW it -- by a plain signed
+    comparison, also across the i32 wrap, which this model therefore never relies on)."""
 
     def __init__(self, depth): self.frames, self.depth = deque(), depth
 
     def push(self, f):
-        while self.frames and self.frames[0] >= f: self.frames.popleft()
+        while self.frames:                                   # mod.rs:147-181: "newer" is decided wrap-aware (abs_diff > u32::MAX / 2)
+            cur = self.frames[0]
+            wrapped = abs(cur - f) > (2**32 - 1) // 2
+            if (cur >= f and not wrapped) or (f >= cur and wrapped): self.frames.popleft()
+            else: break
         self.frames.appendleft(f)
         while len(self.frames) > self.depth: self.frames.pop()
 
     def rollback(self, f):
         while self.frames[0] != f: self.frames.popleft()
+
+    def confirm(self, c):
+        """mod.rs:185-202, applied no later than the backends do (at every push and whenever ConfirmedFrameCount moves): across the i32
+        wrap a frame pruned while ConfirmedFrameCount was a large positive number must not look loadable again once it has wrapped."""
+        while self.frames and self.frames[-1] < c: self.frames.pop()
 
 
 class Scenario:
@@ -170,10 +190,10 @@ def _gen_list(sc, st):
         return True
 
     def adv():
-        reqs.append(_adv(sc, st["F"], spawn_now())); st["F"] += 1
+        reqs.append(_adv(sc, st["F"], spawn_now())); st["F"] = w32(st["F"] + 1)
 
     def save():
-        reqs.append(bg.SaveGameState(st["F"])); ring.push(st["F"])
+        reqs.append(bg.SaveGameState(st["F"])); ring.push(st["F"]); ring.confirm(st["confirmed"])
 
     def loadable():
         return [f for f in ring.frames if f >= st["confirmed"]]
@@ -185,21 +205,21 @@ def _gen_list(sc, st):
     cand = loadable()
     if shape < 0.2 and cand:
         # SyncTest tick: roll back to the oldest loadable frame, resimulate with a Save per frame (schedule_systems.rs:85-118)
-        f0, F = min(cand), st["F"]
+        f0, F = cand[-1], st["F"]                            # (the ring's frames run newest first)
         load(f0)
-        while st["F"] < F:
+        for _ in range(ahead(F, f0)):
             adv(); save()
         adv()
     elif shape < 0.35 and cand:
         # P2P-shaped: [Load(F - r), Adv, (Save, Adv) x (r - 1)] + [Save(F), Adv]
         F = st["F"]; f0 = int(r.choice(cand))
         load(f0); adv()
-        while st["F"] < F:
+        for _ in range(max(0, ahead(F, f0) - 1)):
             save(); adv()
         save(); adv()
     elif shape < 0.55 and cand and ring.depth >= 2:
         # speculative branches off one snapshot: every branch but the last leaves nothing behind (fanout.py's list shape)
-        C = max(cand); B = int(r.integers(2, 7)); D = int(r.integers(1, min(5, ring.depth)))      # (the branches' Saves must not evict C)
+        C = cand[0]; B = int(r.integers(2, 7)); D = int(r.integers(1, min(5, ring.depth)))      # (the branches' Saves must not evict C)
         for b in range(B):
             load(C)
             for i in range(D):
@@ -225,8 +245,9 @@ def _mutate(sc, st, A, B, ids):
     r = sc.rng
     x = r.random()
     if x < 0.35:
-        c = int(r.integers(st["confirmed"], st["F"] + 1))
+        c = w32(st["confirmed"] + int(r.integers(0, ahead(st["F"], st["confirmed"]) + 1)))
         st["confirmed"] = c
+        st["ring"].confirm(c)
         A.set_confirmed(c); B.set_confirmed(c)
         return f"confirmed={c}"
     if x < 0.38:
@@ -272,14 +293,18 @@ def _extra_state(w):
     return out
 
 
-def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False, max_n=None, box=False):
+def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=False, max_n=None, box=False, start_frame=None):
     sc = (BoxScenario if box else GenericScenario if generic else Scenario)(seed, big=big, max_n=max_n)
     A, B = make_a(sc), make_b(sc)
     log = [sc.describe()]
     try:
         ids = sc.build(A); idsb = sc.build(B)
         assert tuple(ids) == tuple(idsb)
-        st = {"F": A.frame, "ring": _Ring(sc.depth), "confirmed": 0, "spawns_left": sc.spawn_budget}
+        if start_frame is not None:                          # e.g. a session that has been running for 2^31 frames: the counters wrap
+            A.set_frame(start_frame); B.set_frame(start_frame)
+            A.set_confirmed(start_frame); B.set_confirmed(start_frame)
+            log[0] += f" start_frame={start_frame}"
+        st = {"F": A.frame, "ring": _Ring(sc.depth), "confirmed": 0 if start_frame is None else start_frame, "spawns_left": sc.spawn_budget}
         use_async = hasattr(B, "enqueue_requests")
         pending = []
 
@@ -311,7 +336,7 @@ def run(seed, make_a, make_b, n_lists=30, big=False, state_every=6, generic=Fals
             if k % state_every == state_every - 1 or k == n_lists - 1:
                 cm.assert_states_equal(cm.snapshot_state(A, ids), cm.snapshot_state(B, ids), f"after list {k}:\n{ctx}\n")
                 cm.assert_states_equal(_extra_state(A), _extra_state(B), f"RollbackDespawned markers after list {k}:\n{ctx}\n")
-                for f in range(st["F"] - 10, st["F"] + 2):
+                for f in (w32(st["F"] + d) for d in range(-10, 2)):
                     assert A.has_snapshot(f) == B.has_snapshot(f), f"has_snapshot({f}) differs after list {k}:\n{ctx}"
         return log
     finally:

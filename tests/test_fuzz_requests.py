@@ -71,3 +71,17 @@ def test_hip_matches_the_oracle_on_random_request_lists_generic_worlds(seed):
 @pytest.mark.parametrize("seed", range(3))
 def test_hip_matches_the_oracle_on_random_request_lists_generic_worlds_hbm_sized(seed):
     fuzz_util.run(2000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: bg.World(sc.capacity, max_depth=8), n_lists=10, big=True, state_every=10, generic=True)
+
+
+@pytest.mark.parametrize("seed", seeds(60))
+def test_restatements_agree_across_the_i32_frame_wrap(seed):
+    """A session whose RollbackFrameCount passes i32::MAX while it runs (Frame = i32: the counters wrap, `GgrsSnapshots::push` decides
+    "newer" wrap-aware while `confirm` compares plainly, mod.rs:147-202): the C++ oracle in both storage shapes and the numpy twin must
+    agree on every checksum, on the state and on which frames the ring holds.  Worlds WITHOUT a time-dependent system only: past the
+    wrap `GgrsTimePlugin::update` computes `frame.0 as u64 * 1_000_000_000` (src/time.rs:69-74), which overflows -- a panic in a debug
+    build, garbage in a release build -- so what `Time<GgrsTime>` holds there is not defined by the reference and is not pinned here
+    (stress_test and box_game integrate with it)."""
+    from oracle.twin_np import TwinWorld
+    kw = dict(n_lists=20, generic=True, max_n=1000, start_frame=2**31 - 1 - (seed * 3) % 40)
+    fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: TwinWorld(sc.capacity, 8), **kw)
+    fuzz_util.run(seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: OracleWorld(sc.capacity, 8, REFSHAPED), **kw)
