@@ -347,7 +347,6 @@ def measure_single(bg, cm, torch, args, contig, light=False):
     n, D, K, W = args.entities, args.depth, args.steps, args.warmup
     stream = torch.cuda.current_stream().cuda_stream
     flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
-    if contig: flags |= bg.GGRS_WORLD_CONTIG_ARENA
     w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum, schema=args.schema)
     m = {"contig_requested": bool(contig)}
     warm_ring(bg, w, D)
@@ -681,9 +680,7 @@ def main():
         # order-safe: the contiguous arena must be this process's FIRST device allocation (include/ggrs_hip.h,
         # GGRS_WORLD_CONTIG_ARENA), and freeing it leaves nothing cached behind -- so it is measured first, destroyed, and the
         # headline (library default: paged) after it
-        if args.arena == "both":
-            variant = measure_single(bg, cm, torch, args, contig=True, light=True)
-        m = measure_single(bg, cm, torch, args, contig=(args.arena == "contig"))
+        m = measure_single(bg, cm, torch, args, contig=False)
         secs, live, gpu_cs, prof = m["secs"], m["live"], m["gpu_cs"], m["prof"]
         # SyncTest's own check over ALL timed ticks (ggrs SyncTestSession: a resimulated frame's checksum must equal the first
         # one recorded for that frame, else MismatchedChecksum): timed tick k at frame F saved frames F-D+1 .. F

@@ -23,7 +23,6 @@ GGRS_WORLD_UNFUSED = 2
 GGRS_WORLD_NT_COPY = 4
 GGRS_WORLD_NO_GROUPS = 8
 GGRS_WORLD_LAYOUT_ONLY = 16
-GGRS_WORLD_CONTIG_ARENA = 32
 
 SYS_PARTICLES_UPDATE = 1
 SYS_TTL_DESPAWN = 2
@@ -32,6 +31,11 @@ SYS_ADD_U32 = 4
 SYS_SAT_SUB_DESPAWN = 5
 SYS_BOX_MOVE = 6
 SYS_CUSTOM = 7
+SYS_SPAWN_CUSTOM = 8
+
+INPUT_CONFIRMED, INPUT_PREDICTED, INPUT_DISCONNECTED = 0, 1, 2
+MAX_INPUT_BYTES, MAX_PLAYERS = 16, 16
+TIMELINE_FIELDS = 7
 
 COMP_ROLLBACK, COMP_NO_ROLLBACK = 0, 1
 DESPAWN_IMMEDIATE, DESPAWN_ROLLBACK = 0, 1
@@ -63,14 +67,20 @@ class CustomSystemDesc(C.Structure):
                 ("iparam", C.c_int64 * 2), ("fparam", C.c_float * 4)]
 
 
+class SpawnSystemDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("source", C.c_char_p), ("bundle_mask", C.c_uint64), ("payload_stride", C.c_uint32), ("n_bindings", C.c_uint32),
+                ("comp", C.c_uint32 * CUSTOM_MAX_BINDINGS), ("word", C.c_uint32 * CUSTOM_MAX_BINDINGS),
+                ("iparam", C.c_int64 * 2), ("fparam", C.c_float * 4)]
+
+
 class Request(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("frame", C.c_int32), ("dt_bits", C.c_uint32),
-                ("n_inputs", C.c_uint32), ("inputs", C.POINTER(C.c_uint8)),
+                ("n_inputs", C.c_uint32), ("inputs", C.POINTER(C.c_uint8)), ("status", C.POINTER(C.c_uint8)),
                 ("spawn_count", C.c_uint64), ("spawn_vx", C.POINTER(C.c_float)),
-                ("spawn_vy", C.POINTER(C.c_float))]
+                ("spawn_vy", C.POINTER(C.c_float)), ("spawn_payload", C.c_void_p), ("spawn_payload_bytes", C.c_uint64)]
 
 
-KERNEL_FORM_TILES, KERNEL_FORM_PERSISTENT, KERNEL_FORM_STEADY = 1, 2, 3
+KERNEL_FORM_TILES, KERNEL_FORM_STEADY = 1, 3
 
 # every symbol include/ggrs_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -89,7 +99,12 @@ SIGNATURES = {
     "ggrs_hip_checksum_component_custom": (C.c_int, [_P, C.c_uint32, C.c_char_p]),
     "ggrs_hip_add_system": (C.c_int, [_P, C.POINTER(SystemDesc)]),
     "ggrs_hip_add_custom_system": (C.c_int, [_P, C.POINTER(CustomSystemDesc)]),
+    "ggrs_hip_register_component_strategy": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p]),
+    "ggrs_hip_set_input_layout": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ggrs_hip_add_spawn_system": (C.c_int, [_P, C.POINTER(SpawnSystemDesc)]),
     "ggrs_hip_generated_kernel_source": (C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
+    "ggrs_hip_aot_object_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64]),
+    "ggrs_hip_host_timeline": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ggrs_hip_set_frame_rate": (C.c_int, [_P, C.c_uint64]),
     "ggrs_hip_spawn": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ggrs_hip_despawn": (C.c_int, [_P, C.c_uint64]),

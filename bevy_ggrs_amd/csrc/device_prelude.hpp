@@ -132,71 +132,31 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
     if (z > hi) z = hi;
 }
 
-// ------------------------------------------------------------------ in-launch checksum fold (the persistent form of the
-// generated kernel)
-// In-kernel checksum fold of a fused group (tick_fold below): one row of partials per workgroup, one arrival ticket,
-// the last workgroup to arrive writes every Save's Checksum(u128).
-struct FoldArgs {
-    uint64_t* wg_parts;                    // [gridDim.x][n_saves * (n_comp + 1)]: per Save the XOR of each checksummed component, then the live count
-    uint32_t* ticket;                      // arrival counter, zero between launches
-    uint64_t* out;                         // {lo, hi} per Save (pinned, device-mapped host memory)
-    uint32_t n_comp, comp_mask;            // component slots per Save; bit j: slot j is a registered checksum (contributes a part)
-};
-// Cross-workgroup hand-off of the partial rows: relaxed agent-scope 8-byte atomics on both sides (lowered to
-// `global_store / global_load ... sc1`: write-through stores, L1-bypassing loads -- MI355X_MICROARCH.md, "Valid forms"),
-// an explicit vmcnt(0) between a workgroup's row and its ticket, one agent-scope acquire in the workgroup that folds.
-__device__ __forceinline__ void st8_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t ld8_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// The checksum fold: one row of partials per workgroup (relaxed agent-scope stores), one
-// agent-scope ticket, and the LAST workgroup to arrive folds every row (component_checksum.rs:92-95,
-// entity_checksum.rs:29-52, checksum.rs:88-99) and writes each Save's Checksum(u128) to pinned host memory.
-template <int NTHREADS, int INFL = 24>
-__device__ __forceinline__ void tick_fold(const FoldArgs& f, uint32_t n_saves, uint64_t total_len, uint64_t* acc, uint32_t* s_last) {
-    if (n_saves == 0) return;
-    __syncthreads();                                              // the LDS atomics of every wave have landed
-    const uint32_t nv = f.n_comp + 1u;                            // values per Save
-    const uint32_t n_vals = n_saves * nv;
-    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) st8_agent(f.wg_parts + (uint64_t)blockIdx.x * n_vals + i, acc[i]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the row is in memory before the ticket is taken
+// ------------------------------------------------------------------ fold-forward (host_groups.hpp)
+// One row of per-workgroup checksum partials -- n values the PREVIOUS launch of the stream left in device memory -- becomes one value in
+// pinned host memory, followed by its tag: XOR for a component's entity hashes (component_checksum.rs:88-89), the sum for the live counts
+// (entity_checksum.rs:40).  Run by the first workgroups of the next request-group launch (256 threads), or by k_ff_fold when no launch follows.
+// The value first, then the tag the collecting host polls (same pinned allocation; a system-scope release orders them).
+__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t n, bool is_cnt, uint64_t* out, uint64_t* tag, uint64_t seq) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    __shared__ unsigned long long ff_acc;
+    if (tid == 0) ff_acc = 0ull;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!*s_last) return;                                         // workgroup-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (uint32_t i = threadIdx.x; i < n_vals; i += NTHREADS) acc[i] = 0;
-    __syncthreads();
-    {
-        // rows are [gridDim.x][n_vals] u64 (compact): flat index i -> value i % n_vals.  INFL loads in flight per lane and trip.
-        const uint32_t n_flat = gridDim.x * n_vals;
-        for (uint32_t i0 = threadIdx.x; i0 < n_flat; i0 += (uint32_t)INFL * NTHREADS) {
-            uint64_t v[INFL];
+    uint64_t x = 0, sum = 0;
+    constexpr int INFL = 16;                                       // loads in flight per lane and trip: a 1 M-entity world's row (3907 values) is ONE trip
+    for (uint32_t i0 = tid; i0 < n; i0 += (uint32_t)INFL * 256u) {
+        uint64_t v[INFL];
 _Pragma("unroll")
-            for (int u = 0; u < INFL; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
-                v[u] = i < n_flat ? ld8_agent(f.wg_parts + i) : 0ULL;
-            }
+        for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < n ? p[i] : 0ULL; }
 _Pragma("unroll")
-            for (int u = 0; u < INFL; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * NTHREADS;
-                if (i >= n_flat) continue;
-                const uint32_t c = i % n_vals;
-                if ((c % nv) == f.n_comp) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
-                else atomicXor(reinterpret_cast<unsigned long long*>(&acc[c]), (unsigned long long)v[u]);
-            }
-        }
+        for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; }
     }
+    if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); }          // workgroup-uniform branch
+    else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); }
     __syncthreads();
-    if (threadIdx.x < n_saves) {
-        const uint32_t k = threadIdx.x;
-        uint64_t total = 0;
-        for (uint32_t j = 0; j < f.n_comp; ++j)
-            if ((f.comp_mask >> j) & 1u) total ^= sea_one(acc[k * nv + j]);     // component_checksum.rs:92-95
-        total ^= sea_pair(acc[k * nv + f.n_comp], total_len);                  // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
-        f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
+    if (tid == 0) {
+        __hip_atomic_store(out, (uint64_t)ff_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (threadIdx.x == 0) *f.ticket = 0;                          // ready for the next launch on this stream
 }
 )

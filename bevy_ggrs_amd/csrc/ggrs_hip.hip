@@ -100,13 +100,14 @@ int ggrs_hip_world_create(int device, uint64_t capacity, uint32_t max_depth, ggr
 uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_components, uint32_t bytes_per_slot) {
     const uint64_t cap_pad = align_up(capacity, LAYOUT_TILE);
     const uint64_t mask = align_up(cap_pad / 8, ALIGN);
-    // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 8192 per layout tile)
+    // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 8192 per layout tile; for a component
+    // under a Strategy count its Stored words too)
     const uint64_t state = align_up(align_up(ALIGN + (1 + (uint64_t)n_components) * mask, 4096) + cap_pad * bytes_per_slot, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot + 1) * ALIGN, 4096);
-    // + checksum units, mask scratch, the spawn staging buffer (4 MiB), tick_fold's row buffer (<= 1024 + 64 workgroups) and ticket
-    return (uint64_t)(max_depth + 1) * state + side + parts + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + (4ULL << 20) +
-           (uint64_t)(2048 + 64) * MAX_TICK_SAVES * std::max<uint64_t>(3, n_components + 1) * 8 + 2 * ALIGN;
+    // + checksum units, mask scratch, the spawn staging buffer's device twin (GGRS_STAGE_BYTES, default 8 MiB; at most 1 GiB is accounted for here)
+    const Knobs k = Knobs::from_env();
+    return (uint64_t)(max_depth + 1) * state + side + parts + (uint64_t)(GGRS_MAX_COMPONENTS * GGRS_MAX_CKS_UNITS + 1) * sizeof(UnitDesc) + ALIGN * 4 + k.stage_bytes + 2 * ALIGN;
 }
 void ggrs_hip_world_destroy(ggrs_world* w) {
     if (!w) return;
@@ -118,18 +119,13 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
     jit_spec_retire(w);
-    jit_release(w->jit_entry); jit_release(w->jit_entry_persist);
+    jit_release(w->jit_entry);
+    delete w->jl; w->jl = nullptr;
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_rows) (void)hipHostFree(w->h_rows);
-    if (w->own_arena && w->arena && w->arena_contiguous && (w->knobs.arena_flush & 2) && w->stream) {
-        hipLaunchKernelGGL(k_flush_l2, dim3(8 * 256), dim3(64), 0, w->stream); (void)hipStreamSynchronize(w->stream);
-    }
-    const bool quarantine = w->own_arena && w->arena && w->arena_contiguous && !w->knobs.arena_park && (w->knobs.arena_flush & 8);
-    const uint64_t q_bytes = w->arena_bytes;
     arena_release(w);
-    if (quarantine) { void* q = nullptr; (void)hipMalloc(&q, q_bytes); (void)hipGetLastError(); }   // experiment: a paged allocation takes the pages back and is never used
     if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
@@ -240,20 +236,71 @@ int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* d) 
     w->systems.push_back(sd);
     return GGRS_OK;
 }
+// RollbackApp::rollback_component_with_{copy,clone,reflect} are instances of  ComponentSnapshotPlugin<S: Strategy>  (snapshot/strategy.rs:22-40,
+// component_snapshot.rs:42-63): S::Stored is what a snapshot holds.  Here: the Stored words and the HIP C++ of store / load.
+int ggrs_hip_register_component_strategy(ggrs_world* w, uint32_t c, uint32_t stored_word_bytes, uint32_t stored_n_words, const char* source) {
+    if (!w || c >= w->comps.size() || !source || !*source) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "register_component_strategy after the world was sealed");
+    Comp& cc = w->comps[c];
+    if (cc.no_rollback) return w->fail(GGRS_E_INVALID, "component %u is not registered for rollback: it has no snapshot strategy", c);
+    if (stored_n_words == 0 || stored_n_words > GGRS_MAX_WORDS || (stored_word_bytes != 1 && stored_word_bytes != 2 && stored_word_bytes != 4 && stored_word_bytes != 8))
+        return w->fail(GGRS_E_INVALID, "bad Stored shape (word bytes must be 1, 2, 4 or 8; 1..%d words)", GGRS_MAX_WORDS);
+    cc.s_word_bytes = stored_word_bytes; cc.s_n_words = stored_n_words; cc.strat_source = source;
+    return GGRS_OK;
+}
+// PlayerInputs<T>(Vec<(T::Input, InputStatus)>)  (src/lib.rs:98; inserted by AdvanceFrame, schedule_systems.rs:262-265)
+int ggrs_hip_set_input_layout(ggrs_world* w, uint32_t input_bytes, uint32_t max_players) {
+    if (!w) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "set_input_layout after the world was sealed");
+    if (!w->customs.empty()) return w->fail(GGRS_E_INVALID, "set_input_layout must precede the first custom system (its kernel is compiled against the layout)");
+    if (input_bytes == 0 || input_bytes > GGRS_MAX_INPUT_BYTES || max_players == 0 || max_players > GGRS_MAX_PLAYERS)
+        return w->fail(GGRS_E_INVALID, "input layout: 1..%d bytes per player, 1..%d players", GGRS_MAX_INPUT_BYTES, GGRS_MAX_PLAYERS);
+    w->input_bytes = input_bytes; w->max_players = max_players;
+    return GGRS_OK;
+}
+// A GgrsSchedule system that spawns Rollback entities (snapshot/rollback.rs:45-59; examples/stress_tests/particles.rs:258-270 is the built-in
+// GGRS_SYS_PARTICLES_SPAWN): how many is the host's decision per AdvanceFrame (ggrs_request::spawn_count), what they are is the user's source.
+int ggrs_hip_add_spawn_system(ggrs_world* w, const ggrs_spawn_system_desc* d) {
+    if (!w || !d || !d->source) return GGRS_E_INVALID;
+    if (w->sealed) return w->fail(GGRS_E_INVALID, "add_spawn_system after the world was sealed");
+    if (w->systems.size() >= GGRS_MAX_SYSTEMS) return w->fail(GGRS_E_INVALID, "too many systems");
+    for (auto& s : w->systems) if (s.kind == GGRS_SYS_SPAWN_CUSTOM || s.kind == GGRS_SYS_PARTICLES_SPAWN) return w->fail(GGRS_E_INVALID, "the schedule already holds a spawn system (one per world)");
+    if (d->n_bindings > GGRS_CUSTOM_MAX_BINDINGS) return w->fail(GGRS_E_INVALID, "spawn system: at most %d bindings", GGRS_CUSTOM_MAX_BINDINGS);
+    if (d->bundle_mask == 0 || (w->comps.size() < 64 && (d->bundle_mask >> w->comps.size()) != 0)) return w->fail(GGRS_E_INVALID, "spawn system: bundle_mask names no / unregistered components");
+    ggrs_world::SpawnSys sp;
+    sp.name = d->name ? d->name : "spawn"; sp.source = d->source; sp.n_bind = d->n_bindings; sp.bundle_mask = d->bundle_mask; sp.payload_stride = d->payload_stride;
+    for (uint32_t c = 0; c < w->comps.size(); ++c) if (((sp.bundle_mask >> c) & 1ull) && w->comps[c].no_rollback)
+        return w->fail(GGRS_E_INVALID, "spawn system '%s': component %u of the bundle is not registered for rollback", sp.name.c_str(), c);
+    for (uint32_t i = 0; i < sp.n_bind; ++i) {
+        if (d->comp[i] >= w->comps.size() || d->word[i] >= w->comps[d->comp[i]].n_words || !((sp.bundle_mask >> d->comp[i]) & 1ull))
+            return w->fail(GGRS_E_INVALID, "spawn system '%s': binding %u names word %u of component %u, which is not a word of the bundle", sp.name.c_str(), i, d->word[i], d->comp[i]);
+        sp.comp[i] = d->comp[i]; sp.word[i] = d->word[i];
+    }
+    ggrs_system_desc sd; memset(&sd, 0, sizeof sd);
+    sd.kind = GGRS_SYS_SPAWN_CUSTOM; sd.comp[0] = (uint32_t)w->spawn_customs.size();
+    sd.iparam[0] = d->iparam[0]; sd.iparam[1] = d->iparam[1];
+    for (int k = 0; k < 4; ++k) sd.fparam[k] = d->fparam[k];
+    w->spawn_customs.push_back(std::move(sp));
+    w->systems.push_back(sd);
+    return GGRS_OK;
+}
+// the file name a shipped code object of this source must carry (scripts/aot_build.py): NUL-terminated into buf
+int ggrs_hip_aot_object_name(const char* source, char* buf, uint64_t cap) {
+    if (!source || !buf || cap < 40) return GGRS_E_INVALID;
+    const std::string n = jit_aot_name(source);
+    memcpy(buf, n.c_str(), n.size() + 1);
+    return GGRS_OK;
+}
 int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, uint64_t cap, uint64_t* needed, int compile) {
-    if (!w || (form != GGRS_KERNEL_FORM_TILES && form != GGRS_KERNEL_FORM_PERSISTENT && form != GGRS_KERNEL_FORM_STEADY)) return GGRS_E_INVALID;
+    if (!w || (form != GGRS_KERNEL_FORM_TILES && form != GGRS_KERNEL_FORM_STEADY)) return GGRS_E_INVALID;
     if (!w->sealed) {
         if (!w->layout_only) { DeviceGuard dg(w); const int rc = seal(w); if (rc) return rc; }
         else build_layout(w);                                      // host arithmetic only: offsets of every mask and column
     }
     std::string src;
-    if (!jit_source(w, src, form == GGRS_KERNEL_FORM_PERSISTENT)) return w->fail(GGRS_E_INVALID, "the kernel generator does not cover this world (a system writes a live-only component, or more than %u four-byte units / %u words per entity)", JIT_MAX_UNITS, JIT_MAX_COLS);
+    if (!jit_source(w, src)) return w->fail(GGRS_E_INVALID, "the kernel generator does not cover this world (a system writes a live-only component, or more than %u four-byte units / %u words per entity)", JIT_MAX_UNITS, JIT_MAX_COLS);
     if (form == GGRS_KERNEL_FORM_STEADY) {
-        const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, MAX_TICK_SAVES);
-        JitSig g; g.n_saves = g.n_steps = d; g.n_ops = 2 * d; g.nt = 1; g.cached_saves = 1;
-        for (uint32_t k = 0; k < d; ++k) g.op_bits |= 1ull << (2 * k);                     // Advance, Save, Advance, Save, ...
-        g.save_rows = g.live_rows = jit_hot_cols(w); g.load_rows = g.save_rows | jit_static_reads(w);
-        src = jit_specialise(src, g);
+        src = jit_specialise(src, jit_steady_sig(w));
         if (src.empty()) return w->fail(GGRS_E_INVALID, "the generated kernel's text could not be specialised");
     }
     if (needed) *needed = src.size() + 1;
@@ -271,6 +318,9 @@ int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, c
     memcpy(out, b.c_str(), b.size() + 1);
     return (int)n;
 }
+// Test hook (no ggrs_hip_ prefix, not in the header): places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight
+// rollback lengths exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
+int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
 
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {
@@ -489,7 +539,7 @@ int ggrs_hip_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uin
     r.spawn_count = spawn_count; r.spawn_vx = vx; r.spawn_vy = vy;
     rc = validate_requests(w, &r, 1); if (rc) return rc;
     if (GroupRunner run = group_runner(w)) return run(w, &r, 1, nullptr, 0, true, nullptr);
-    return do_advance(w, dt_bits, inputs, n_inputs, spawn_count, vx, vy);
+    return do_advance(w, r);
 }
 
 int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out) {
@@ -517,7 +567,7 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
             }
             rc = do_save(w, ns); ++ns; break;
         case GGRS_REQ_LOAD: rc = do_load(w, r.frame); break;
-        case GGRS_REQ_ADVANCE: rc = do_advance(w, r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy); break;
+        case GGRS_REQ_ADVANCE: rc = do_advance(w, r); break;
         default: rc = w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
         }
     }
@@ -534,7 +584,9 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     TraceRange tr("HandleRequests");
     DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
+    const double t_in = w->tl.on ? tl_now_us() : 0;
     rc = validate_requests(w, reqs, n); if (rc) return rc;
+    if (w->tl.on) w->tl.validate_us += tl_now_us() - t_in;
     uint32_t n_save = 0;
     for (uint32_t i = 0; i < n; ++i) n_save += reqs[i].kind == GGRS_REQ_SAVE;
     if (n_save > w->max_results / 4 || w->pending_results + n_save > w->max_results / 2 || w->pending.size() >= 16)
@@ -543,6 +595,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     b.first = (w->res_head + n_save > w->max_results) ? 0u : w->res_head;
     b.count = n_save;
     const size_t folds_before = w->folds.size();
+    const uint64_t ff_id0 = w->ff_next_id;
     if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
     b.ev = w->event_pool.back(); w->event_pool.pop_back();
     w->batch_ev_attached = false;
@@ -550,7 +603,12 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
         w->batch_ev = b.ev;
         rc = run(w, reqs, n, nullptr, b.first, false, nullptr);
         w->batch_ev = nullptr;
-        if (rc) { w->event_pool.push_back(b.ev); (void)hipStreamSynchronize(w->stream); while (w->folds.size() > folds_before) w->folds.pop_back(); return rc; }
+        if (rc) {
+            w->event_pool.push_back(b.ev); (void)hipStreamSynchronize(w->stream);
+            while (w->folds.size() > folds_before) w->folds.pop_back();
+            if (w->ff_pending.valid && w->ff_pending.id >= ff_id0) w->ff_pending.valid = false;      // its HostFold is gone with the failed list
+            return rc;
+        }
     } else {
         // worlds without request-group kernels: one launch per request, enqueued like the groups are; every
         // Save's fold writes straight into its slot of the pinned result ring, nothing is waited for here
@@ -562,7 +620,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
             switch (r.kind) {
             case GGRS_REQ_SAVE: rc = do_save(w, b.first + ns); ++ns; break;
             case GGRS_REQ_LOAD: rc = do_load(w, r.frame); break;
-            case GGRS_REQ_ADVANCE: rc = do_advance(w, r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy); break;
+            case GGRS_REQ_ADVANCE: rc = do_advance(w, r); break;
             default: rc = w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
             }
         }
@@ -574,6 +632,24 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     b.stage_end = w->stage_used;
     if (n_saves_out) *n_saves_out = n_save;
     w->pending.push_back(std::move(b));
+    if (w->tl.on) { w->tl.enqueue_us += tl_now_us() - t_in; ++w->tl.n_enqueue; }
+    return GGRS_OK;
+}
+// the batch's event, waited for by polling (hipEventQuery returns in 0.06 us; hipEventSynchronize on an event that is NOT complete yet costs
+// 0.7 us more per tick of a 5.6 us kernel: scripts/ubench_launch, profiles/r05a) for up to GGRS_SPIN_WAIT_US, then by the runtime's wait
+static int wait_batch_event(ggrs_world* w, hipEvent_t ev) {
+    if (w->knobs.spin_wait_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 1; ; ++it) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return GGRS_OK;
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if ((it & 31u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(w->knobs.spin_wait_us)) break;
+            cpu_relax();
+        }
+        (void)hipGetLastError();                                     // (hipErrorNotReady is sticky in hipGetLastError)
+    }
+    HIPCHK(w, hipEventSynchronize(ev));
     return GGRS_OK;
 }
 int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t max_saves, uint32_t* n_saves_out) {
@@ -582,8 +658,12 @@ int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t 
     DeviceGuard dg(w);
     ggrs_world::PendingBatch& b = w->pending.front();
     if (b.count > max_saves || (b.count && !checksums_out)) return w->fail(GGRS_E_INVALID, "oldest batch holds %u checksums, room for %u", b.count, max_saves);
-    HIPCHK(w, hipEventSynchronize(b.ev));
-    run_host_folds(w, b.n_folds);
+    const double t_in = w->tl.on ? tl_now_us() : 0;
+    // a fold-forward group whose rows nothing took along yet: queue k_ff_fold BEFORE waiting (it runs right behind the batch's kernel)
+    if (w->ff_pending.valid) for (uint32_t k = 0; k < b.n_folds && k < w->folds.size(); ++k) if (w->folds[k].ff_id == w->ff_pending.id) { int rc = ff_flush(w); if (rc) return rc; break; }
+    int rc = wait_batch_event(w, b.ev); if (rc) return rc;
+    if (w->tl.on) w->tl.wait_us += tl_now_us() - t_in;
+    rc = run_host_folds(w, b.n_folds); if (rc) return rc;
     if (b.count) {
         if (!b.host.empty()) memcpy(checksums_out, b.host.data(), (size_t)b.count * 16);
         else memcpy(checksums_out, w->h_results + 2 * (size_t)b.first, (size_t)b.count * 16);
@@ -595,6 +675,18 @@ int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t 
     w->pending.pop_front();
     // the batch's launches are done: its spawn payloads (and everything staged before them) are free again
     if (w->pending.empty()) stage_ring_reset(w); else if (stage_end) w->stage_tail = stage_end;
+    if (w->tl.on) { w->tl.collect_us += tl_now_us() - t_in; ++w->tl.n_collect; }
+    return GGRS_OK;
+}
+// Where the HOST spends a tick.  enable: 1 = reset and start, 0 = stop, -1 = leave as is.  us_out[GGRS_TIMELINE_FIELDS] = microseconds
+// summed since the start: {enqueue call, of it: validation, of it: launch calls (hipModuleLaunchKernel / hipExtModuleLaunchKernel), collect call, of it: the
+// batch event, of it: fold-forward tags, of it: hashing / folding on the host}; counts_out[3] = {enqueue calls, collect calls, launches}.
+int ggrs_hip_host_timeline(ggrs_world* w, int enable, double* us_out, uint64_t* counts_out) {
+    if (!w) return GGRS_E_INVALID;
+    if (us_out) { const HostTimeline& t = w->tl; const double v[GGRS_TIMELINE_FIELDS] = {t.enqueue_us, t.validate_us, t.launch_us, t.collect_us, t.wait_us, t.tag_wait_us, t.fold_us}; memcpy(us_out, v, sizeof v); }
+    if (counts_out) { counts_out[0] = w->tl.n_enqueue; counts_out[1] = w->tl.n_collect; counts_out[2] = w->tl.n_launches; }
+    if (enable == 1) { w->tl = HostTimeline{}; w->tl.on = true; }
+    else if (enable == 0) w->tl.on = false;
     return GGRS_OK;
 }
 uint32_t ggrs_hip_pending_batches(ggrs_world* w) { return w ? (uint32_t)w->pending.size() : 0; }
@@ -602,6 +694,7 @@ uint32_t ggrs_hip_pending_batches(ggrs_world* w) { return w ? (uint32_t)w->pendi
 int ggrs_hip_synchronize(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
+    if (w->sealed) { const int rc = ff_flush(w); if (rc) return rc; }          // rows a fold-forward launch left behind: nothing may be left half-done on the stream
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return GGRS_OK;
 }
@@ -656,34 +749,34 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
         for (char& ch : v) if (ch == '\n') ch = ' ';
         add("specialised_kernel", v);
     }
-    add("arena", !w->sealed ? "none" : (!w->own_arena ? "caller-provided" : (w->arena_contiguous ? "contiguous (hipExtMallocWithFlags, write-through)" : "paged (hipMalloc)")));
+    add("arena", !w->sealed ? "none" : (!w->own_arena ? "caller-provided" : "paged (hipMalloc)"));
     add("arena_bytes", std::to_string(w->arena_bytes));
     {
-        Hiprtc& r = hiprtc();
+        Hiprtc& r = hiprtc_for(w);
         add("hiprtc", r.lib ? "loaded" : ("missing: " + r.why));
     }
     add("generated_kernel", w->jit_fn ? "ok" : w->jit_status);
+    if (w->jit_fn) add("generated_kernel_origin", w->jit_origin);
     std::string k;
     const uint64_t cover = std::max(w->len, w->live.dirty_len);
     if (!w->sealed) k = "unknown (not sealed)";
-    else if (w->gen_ok) k = (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots)
-                               ? "ggrs_jit_tick (generated for this world; persistent grid, in-kernel checksum fold)"
-                               : "ggrs_jit_tick (generated for this world; one workgroup per 256 slots)";
+    else if (w->gen_ok) k = "ggrs_jit_tick (generated for this world; one workgroup per 256 slots)";
     else k = "per-request kernels (k_copy_state, one launch per system)";
     add("request_group_kernel", k);
     if (w->sealed && w->gen_ok) {
-        // who folds the per-workgroup checksum rows of a plain (no roles, no batch) request group of this size
+        // who folds the per-workgroup checksum rows of a plain (no batch) request group of this size
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
-        const bool gf = w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs && w->d_gf_tickets;
-        const uint32_t rows = gf ? (jit_grid(g) + 63u) / 64u : g;
-        const bool host = w->h_rows && !w->device_results_only && rows <= (uint32_t)w->knobs.host_fold_max_wgs;
-        const bool host_blocking = host && (rows <= HOST_FOLD_MAX_WGS_BLOCKING || w->knobs.host_fold_explicit);
-        std::string f = gf ? "group fold on the chip (64 workgroups per ticket: " + std::to_string(rows) + " rows of " + std::to_string(g) + " leave the kernel), then " : "";
-        f += host ? (host_blocking ? "the host folds the rows at collect time (blocking calls too)" : "the host folds the rows at collect time (blocking calls: k_gen_finalize)")
-                  : "k_gen_finalize";
+        const bool ff = w->h_rows && !w->device_results_only && g > (uint32_t)w->knobs.fold_forward_min_wgs;
+        const bool host = w->h_rows && !w->device_results_only && !ff;
+        std::string f = ff ? "fold-forward: the next launch on the stream folds the rows (k_ff_fold when nothing follows) and the host hashes one value per Save and part; blocking calls: " +
+                             std::string(g <= HOST_FOLD_MAX_WGS_BLOCKING && g <= (uint32_t)w->knobs.fold_forward_min_wgs ? "the host folds the rows" : "k_gen_finalize")
+                      : host ? (g <= HOST_FOLD_MAX_WGS_BLOCKING ? "the host folds the rows at collect time (blocking calls too)" : "the host folds the rows at collect time (blocking calls: k_gen_finalize)")
+                             : "k_gen_finalize";
         add("checksum_fold", f);
+        add("kernarg_bytes", std::to_string(w->jl ? w->jl->bytes : 0));
+        add("group_caps", std::to_string(w->cap_saves) + " saves / " + std::to_string(w->cap_steps) + " steps");
         bool any_spawn = false;
-        for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN;
+        for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN || sd.kind == GGRS_SYS_SPAWN_CUSTOM;
         if (any_spawn) add("spawn_system", w->jit_spawn_sys >= 0 ? "runs inside the request group (rows appended by the group's launch)" : "ends the request group (its own launches)");
     }
     add("blocking_wait", w->knobs.spin_wait_us > 0 ? "polls k_gen_finalize's completion tags when that kernel ends the list (" + std::to_string(w->spin_hits) + " calls so far, " +

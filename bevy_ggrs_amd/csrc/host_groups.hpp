@@ -4,8 +4,7 @@
 // slot's words in registers, the live block is written once.  The host does, in request order and while the group is
 // assembled, everything the reference's systems do outside the per-entity loops: frame counters, ring push / confirm /
 // rollback (exact mirror of mod.rs:121-243 over slot indices), row versions, dirty extents.
-// One kernel serves groups: the one generated for the world (kernel_gen.hpp; per-tile grid by default, a persistent grid with the
-// fold in the launch as an opt-in).
+// One kernel serves groups: the one generated for the world (kernel_gen.hpp: one 256-slot workgroup per tile).
 // Part of the single translation unit ggrs_hip.hip.
 #pragma once
 
@@ -36,16 +35,23 @@ int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState&
     ++i;
     return GGRS_OK;
 }
-// column mask -> what it costs per slot
-uint64_t rows_bytes_per_slot(const ggrs_world* w, uint64_t mask) {
+// column mask -> what it costs per slot.  ring_side: the block is a snapshot -- a component under a Strategy moves as its Stored words there
+// (all of them as soon as one of its columns is in the mask), as its own words in the live block
+uint64_t rows_bytes_per_slot(const ggrs_world* w, uint64_t mask, bool ring_side) {
     uint64_t b = 0;
-    for (uint32_t c = 0; c < w->col_wb.size() && c < 64; ++c) if ((mask >> c) & 1ull) b += w->col_wb[c];
+    for (const Comp& cc : w->comps) {
+        if (cc.no_rollback) continue;
+        uint64_t cm = 0;
+        for (uint32_t k = 0; k < cc.n_words && cc.col_base + k < 64; ++k) cm |= 1ull << (cc.col_base + k);
+        if (ring_side && cc.s_n_words) { if (mask & cm) b += (uint64_t)cc.s_n_words * cc.s_word_bytes; }
+        else b += (uint64_t)__builtin_popcountll(mask & cm) * cc.word_bytes;
+    }
     return b;
 }
 // columns of `dst` that differ from the logical live state
 uint64_t rows_to_store(const ggrs_world* w, const Block& dst) {
     uint64_t m = 0;
-    for (uint32_t c = 0; c < w->col_rb.size() && c < 64; ++c) if (w->col_rb[c] && ver_differs(w, dst, w->cur_ver, c)) m |= 1ull << c;
+    for (uint32_t c = 0; c < w->n_tcols && c < 64; ++c) if (w->col_rb[c] && ver_differs(w, dst, w->cur_ver, c)) m |= 1ull << c;
     return m;
 }
 // SaveGameState inside a group: discard_old_snapshots + GgrsSnapshots::push (mod.rs:147-202); the copy itself is an op of the kernel
@@ -115,7 +121,7 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead, bool
 // Not applied when something else reads the live world in between (a firing spawn system, live-only components or
 // RollbackDespawned markers, whose reconcile pass reads the live liveness mask).
 bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, uint32_t n, const int32_t* save_frame, uint32_t n_saves, bool spawn_pending) {
-    if (!w->knobs.dead_groups || spawn_pending || n_saves == 0 || i >= n || reqs[i].kind != GGRS_REQ_LOAD || w->has_nr || w->marks_possible) return false;
+    if (spawn_pending || n_saves == 0 || i >= n || reqs[i].kind != GGRS_REQ_LOAD || w->has_nr || w->marks_possible) return false;
     bool present = false;
     for (int32_t f : w->ring_frame) present |= f == reqs[i].frame;
     if (!present) return false;                                        // that Load is going to fail: change nothing
@@ -134,23 +140,65 @@ constexpr uint64_t JIT_BATCH_MAX_SLOTS = 400 * 1024;   // identical checksum-onl
 // grid of the per-tile form: 8 x ceil(tiles / 8) workgroups, mapped to tiles XCD by XCD inside the kernel (kernel_gen.hpp)
 inline uint32_t jit_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 
-// Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
-// launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
-// Launch of a generated kernel.  With profiling on, the event pair rides on the dispatch itself (hipExtModuleLaunchKernel's start / stop events:
-// the kernel's own begin and end, what rocprofv3's kernel trace reports) instead of bracketing it with two marker packets, which read ~3 us more.
+// FOLD-FORWARD.  Every Save of a group leaves one partial per workgroup and checksummed part (the XOR of a component's entity hashes,
+// the live count).  Up to GGRS_FOLD_FORWARD_MIN_WGS workgroups the rows go to pinned memory and the host XORs them at collect time; beyond, that
+// fold -- 94 k values = 750 KB per tick at 1 M entities, ~30 us of a host core -- sat between collect(k) and enqueue(k + 2) of a session that
+// keeps one tick in flight, i.e. on the path that must stay shorter than one kernel (60 us per step around a 48.7 us kernel).
+// Now such a launch leaves its rows in DEVICE memory (two buffers, used alternately) and the NEXT launch on the stream starts with
+// saves x parts extra workgroups that fold one row each and write the value, then a tag, into the pinned ring: no atomics, no ticket, no
+// second launch, nothing at the end of the producing kernel -- the fold runs beside the next tick's tiles.  collect(k) waits for the batch's
+// event, then for the tags (they arrive a few microseconds after kernel k + 1 starts), and hashes 24 values.  When nothing follows on the
+// stream by the time the batch is collected, k_ff_fold does the same as its own launch (ff_flush).
+// What the previous launch left behind rides along with THIS one:
+inline void ff_attach(ggrs_world* w, GgrsJitArgs& j) {
+    ggrs_world::FfPending& p = w->ff_pending;
+    if (!p.valid) return;
+    j.ff_rows = reinterpret_cast<const ggrs_u64*>(w->d_ff_rows[p.buf]); j.ff_out = reinterpret_cast<ggrs_u64*>(w->d_rows + p.out_off); j.ff_seq = p.seq;
+    j.ff_nvals = p.nvals; j.ff_blocks = (p.nvals + 7u) & ~7u; j.ff_g = p.g; j.ff_stride = p.stride;
+    w->ff_done_id = p.id; p.valid = false;
+}
+
+// The shape of a steady SyncTest tick of this world at full length -- [Load(F - D), Advance, (Save, Advance) x D] with D = max_depth - 1, every
+// slot live, the rows the systems write -- under the same store / load / role policies run_request_groups_gen applies: what
+// ggrs_hip_generated_kernel_source(GGRS_KERNEL_FORM_STEADY) specialises for and what `make aot` ships, so that a session's 16th steady tick finds its kernel
+// among the shipped objects when there is no run-time compiler.
+JitSig jit_steady_sig(const ggrs_world* w) {
+    const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, std::min<uint32_t>(w->cap_saves, w->cap_steps - 1));
+    const uint64_t cover = w->capacity;
+    JitSig g;
+    g.n_saves = d; g.n_steps = d + 1; g.n_ops = 2 * d + 1;
+    for (uint32_t k = 0; k <= d; ++k) g.op_bits |= 1ull << (2 * k);                       // Advance, Save, Advance, ..., Save, Advance
+    g.save_rows = g.live_rows = jit_hot_cols(w); g.load_rows = g.save_rows | jit_static_reads(w);
+    g.nt = cover > JIT_NT_MIN_SLOTS ? 1u : 0u;
+    g.cached_saves = (g.nt && d >= 2 && rows_bytes_per_slot(w, g.save_rows, true) * cover <= JIT_CACHED_SAVE_MAX_BYTES) ? 1u : 0u;
+    g.nt_loads = (g.nt && !g.cached_saves) ? 1u : 0u;
+    const JitNeeds need = jit_needs(w);
+    if (d >= 2 && !need.marks) g.dp_s = cover <= JIT_DP_MAX_SLOTS ? 1u : (cover <= 2 * JIT_DP_MAX_SLOTS ? 2u : (cover <= 6 * JIT_DP_MAX_SLOTS ? 3u : 0u));
+    return g;
+}
+
+// Launch of a generated kernel: the host-side argument block is packed into the world's device layout (kernel_gen.hpp jit_pack).  With
+// profiling on, the event pair rides on the dispatch itself (hipExtModuleLaunchKernel's start / stop events: the kernel's own begin and end,
+// what rocprofv3's kernel trace reports) instead of bracketing it with two marker packets, which read ~3 us more.
 // `done`: an event that completes with THIS launch (enqueue's batch event riding on the list's last kernel instead of a marker packet behind it).
-int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tpb, uint32_t lds, void** params, uint64_t bytes, hipEvent_t done = nullptr) {
+int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t lds, GgrsJitArgs& j, uint64_t bytes, hipEvent_t done = nullptr) {
     w->spin_n = 0;                                               // a finalize before this launch is no longer the list's last GPU operation (arm_spin)
+    ff_attach(w, j);
+    jit_pack(*w->jl, j, w->jit_argbuf.data());
+    void* params[] = {w->jit_argbuf.data()};
+    gx += j.ff_blocks;
+    const double t0 = w->tl.on ? tl_now_us() : 0;
     if (!w->prof) {
-        if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
-        else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr));
-        return GGRS_OK;
+        if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * TPB, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
+        else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr));
+    } else {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(w, hipEventCreate(&a)); HIPCHK(w, hipEventCreate(&b));
+        w->prof_bytes[GGRS_KERNEL_TICK] += bytes;
+        HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * TPB, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr, a, b, 0));
+        w->prof_events.push_back({a, b, GGRS_KERNEL_TICK});
     }
-    hipEvent_t a = nullptr, b = nullptr;
-    HIPCHK(w, hipEventCreate(&a)); HIPCHK(w, hipEventCreate(&b));
-    w->prof_bytes[GGRS_KERNEL_TICK] += bytes;
-    HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, lds, w->stream, params, nullptr, a, b, 0));
-    w->prof_events.push_back({a, b, GGRS_KERNEL_TICK});
+    if (w->tl.on) { w->tl.launch_us += tl_now_us() - t0; ++w->tl.n_launches; }
     return GGRS_OK;
 }
 
@@ -168,7 +216,7 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     JitSpecSlot* s = nullptr;
     for (auto& t : w->spec_tab) if (t.sig == g) { s = &t; break; }
     if (!s) {
-        if (w->spec_tab.size() < (size_t)w->knobs.jit_spec_shapes) { w->spec_tab.emplace_back(); s = &w->spec_tab.back(); }
+        if (w->spec_tab.size() < (size_t)w->spec_shapes) { w->spec_tab.emplace_back(); s = &w->spec_tab.back(); }
         else {                                                                   // least recently used out: a shape without a kernel if there is one
             for (auto& t : w->spec_tab) {
                 if (building(t)) continue;
@@ -190,8 +238,8 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
     const std::string src = jit_specialise(w->jit_src, g);
     if (src.empty()) { s->spec->why = "the generated kernel's text could not be specialised"; s->spec->state.store(3, std::memory_order_release); return nullptr; }
     s->spec->state.store(1, std::memory_order_relaxed);
-    if (w->knobs.jit_specialise_sync) jit_spec_build(s->spec, w->device, src, w->knobs.jit_cache_dir);
-    else { s->spec->th = std::thread(jit_spec_build, s->spec, w->device, src, w->knobs.jit_cache_dir); jit_spec_worker_register(s->spec); }
+    if (w->knobs.jit_specialise_sync) jit_spec_build(s->spec, w->device, src, w->knobs.jit_cache_dir, w->knobs.aot_dir, w->knobs.no_hiprtc);
+    else { s->spec->th = std::thread(jit_spec_build, s->spec, w->device, src, w->knobs.jit_cache_dir, w->knobs.aot_dir, w->knobs.no_hiprtc); jit_spec_worker_register(s->spec); }
     return s->spec->state.load(std::memory_order_acquire) == 2 ? s->spec->fn : nullptr;
 }
 
@@ -216,6 +264,8 @@ inline void arm_spin(ggrs_world* w, GenFinArgs& f, uint32_t n_wgs, bool blocking
     f.done = w->d_done; f.seq = ++w->spin_seq; w->spin_n = n_wgs;
 }
 
+// Identical checksum-only groups off the same source block (speculative branches: same ops, same frames, same length) are
+// launched TOGETHER: one grid of tiles x K members (blockIdx.z) and one finalize of saves x K, instead of K launch pairs.
 struct JitBatch {
     bool active = false; GgrsJitArgs j; uint32_t g = 0, k = 0, res_first = 0, n_cks = 0;
     void start(const GgrsJitArgs& j_, uint32_t g_, uint32_t res, uint32_t n_cks_) { active = true; j = j_; g = g_; k = 1; res_first = res; n_cks = n_cks_; }
@@ -224,12 +274,15 @@ struct JitBatch {
             b.n_steps != j.n_steps || b.load_rows != j.load_rows || memcmp(b.dt_bits, j.dt_bits, sizeof b.dt_bits) != 0 || memcmp(b.aux_bits, j.aux_bits, sizeof b.aux_bits) != 0 ||
             memcmp(b.step_frame, j.step_frame, sizeof b.step_frame) != 0 || memcmp(b.step_confirmed, j.step_confirmed, sizeof b.step_confirmed) != 0 ||
             memcmp(b.step_flags, j.step_flags, sizeof b.step_flags) != 0) return false;
-        if (w->jit_reads_inputs && (memcmp(b.inputs, j.inputs, sizeof b.inputs) != 0 || memcmp(b.n_inputs, j.n_inputs, sizeof b.n_inputs) != 0)) return false;
+        if (w->jit_reads_inputs) {
+            if (memcmp(b.n_inputs, j.n_inputs, sizeof b.n_inputs) != 0) return false;
+            const size_t row = (size_t)w->max_players * (w->input_bytes + 1);            // what pack_inputs wrote of every step's row
+            for (uint32_t q = 0; q < j.n_steps; ++q) if (memcmp(b.inputs[q], j.inputs[q], row) != 0) return false;
+        }
         // fused spawns: the same rows from the same staged payload at the same steps (one request list stages a payload it is handed twice
         // -- the same host arrays: every branch that spawns in frame f -- only once, so identical spawning branches share pointers)
         if (memcmp(b.spawn_count, j.spawn_count, sizeof b.spawn_count) != 0 || memcmp(b.save_len, j.save_len, sizeof b.save_len) != 0 ||
-            memcmp(b.spawn_first, j.spawn_first, sizeof b.spawn_first) != 0 || memcmp(b.spawn_vx, j.spawn_vx, sizeof b.spawn_vx) != 0 ||
-            memcmp(b.spawn_vy, j.spawn_vy, sizeof b.spawn_vy) != 0) return false;
+            memcmp(b.spawn_first, j.spawn_first, sizeof b.spawn_first) != 0 || memcmp(b.spawn_payload, j.spawn_payload, sizeof b.spawn_payload) != 0) return false;
         if ((k + 1) * j.n_saves > w->gen_parts_saves || res != res_first + k * j.n_saves) return false;
         ++k;
         return true;
@@ -241,12 +294,11 @@ struct JitBatch {
         w->batch_ev_attached = false;                                // this launch comes after whatever carried the batch event
         bool host_fold = false; uint64_t rows_off = 0;
         {
-            void* params[] = {&j};
             if (k > 1) j.dp_s = 0;
             host_fold = host_fold_rows(w, g, j.n_saves, n_cks, k, &rows_off, blocking);
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
-            { const int lrc = launch_jit(w, w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), params,
-                                         rows_bytes_per_slot(w, j.load_rows) * j.len * k); if (lrc) return lrc; }
+            { const int lrc = launch_jit(w, w->jit_fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, k, jit_lane_fold_bytes(w, w->cks_args.n_cks, j.n_saves), j,
+                                         rows_bytes_per_slot(w, j.load_rows, !j.src_is_live) * j.len * k); if (lrc) return lrc; }
         }
         if (host_fold) { w->folds.push_back(make_host_fold(j, res_first, g, n_cks, k, rows_off)); return GGRS_OK; }
         GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)res_first);   // one row per workgroup
@@ -266,13 +318,15 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     int rc = GGRS_OK;
     JitBatch batch; batch.blocking = wait;
     w->spin_n = 0;
-    struct Staged { const float* hx; const float* hy; uint64_t count; const float* dx; const float* dy; };
-    std::vector<Staged> staged;                                        // payloads this list has staged already (by the caller's host arrays)
+    // payloads this list has staged already (by the caller's host pointer): every branch of a fan-out step that spawns in frame f hands in the same
+    // arrays.  Offsets into the ring die with the ring's generation (a reset: the ring was full and the stream was waited for; a result page was read back)
+    struct Staged { const void* host; const void* host2; uint64_t bytes; const unsigned char* dev; };
+    std::vector<Staged> staged; uint64_t staged_gen = w->stage_gen;
     const uint32_t n_cks = w->cks_args.n_cks;
     const uint64_t static_reads = jit_static_reads(w);
     while (i < n) {
         w->batch_ev_attached = false;                                   // only the list's LAST launch may carry the batch event
-        GgrsJitArgs j; memset(&j, 0, sizeof j);
+        GgrsJitArgs j; memset(&j, 0, offsetof(GgrsJitArgs, inputs));
         GroupState gs;
         const ggrs_request* spawn_req = nullptr;
         rc = group_open(w, reqs, i, gs); if (rc) return rc;
@@ -282,13 +336,51 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             const ggrs_request& r = reqs[i];
             if (r.kind == GGRS_REQ_LOAD) break;
             if (r.kind == GGRS_REQ_SAVE) {
-                if (j.n_saves == (uint32_t)MAX_TICK_SAVES || (wait && ns + j.n_saves == w->max_results)) break;
+                if (j.n_saves == w->cap_saves || (wait && ns + j.n_saves == w->max_results)) break;
                 rc = group_save(w, gs, j.n_saves, j.save_dst, j.save_frame); if (rc) return rc;
                 j.save_len[j.n_saves] = w->len;
                 ++j.n_ops; ++j.n_saves;
             } else if (r.kind == GGRS_REQ_ADVANCE) {
-                if (j.n_steps == (uint32_t)MAX_TICK_STEPS) break;
-                if (r.n_inputs > 16) return w->fail(GGRS_E_INVALID, "more than 16 player inputs");
+                if (j.n_steps == w->cap_steps) break;
+                // A spawn system fires in this frame.  Fused (kernel_gen.hpp): the step's launch appends the rows itself -- the payload is staged
+                // now (pinned, device-mapped ring: no copy command per spawning step), the host does in request order what run_spawn_systems does
+                // around its kernel (capacity, versions of the bundle, len) and the group goes on.  Worlds whose spawn system the generator cannot
+                // fuse end the group after the step and run the spawn as its own launches, as Bevy's Commands flush ends the schedule.
+                const bool spawns = advance_spawns(w, r);
+                const bool fused_spawn = spawns && w->jit_spawn_sys >= 0;
+                const unsigned char* payload_dev = nullptr;
+                if (fused_spawn) {
+                    const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
+                    const bool custom = sd.kind == GGRS_SYS_SPAWN_CUSTOM;
+                    if (r.spawn_count > 0xFFFFFFFFull || w->len + r.spawn_count > w->capacity)
+                        return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)r.spawn_count, (unsigned long long)w->capacity);
+                    // what the spawner reads: particles -- count f32 of vx, then count f32 of vy; user-written -- the request's payload blob
+                    const ggrs_world::SpawnSys* sp = custom ? &w->spawn_customs[sd.comp[0]] : nullptr;
+                    const uint64_t pbytes = custom ? (sp->payload_stride ? (uint64_t)sp->payload_stride * r.spawn_count : r.spawn_payload_bytes) : 8 * r.spawn_count;
+                    const void* key = custom ? r.spawn_payload : (const void*)r.spawn_vx;
+                    const void* key2 = custom ? nullptr : (const void*)r.spawn_vy;
+                    if (staged_gen != w->stage_gen) { staged.clear(); staged_gen = w->stage_gen; }
+                    const Staged* hit = nullptr;
+                    if (pbytes) for (auto& st : staged) if (st.host == key && st.host2 == key2 && st.bytes == pbytes) { hit = &st; break; }
+                    if (hit) payload_dev = hit->dev;
+                    else if (pbytes) {
+                        uint64_t soff = 0;
+                        if (!stage_ring_alloc(w, pbytes, &soff)) {
+                            // the ring is full of payloads that launches already queued -- or the steps of THIS group -- still have to read
+                            if (pbytes > w->stage_bytes) return w->fail(GGRS_E_CAPACITY, "spawn payload of %llu bytes exceeds the staging buffer (%llu bytes: GGRS_STAGE_BYTES)", (unsigned long long)pbytes, (unsigned long long)w->stage_bytes);
+                            if (j.n_ops) break;                              // the group ends BEFORE this frame: it is launched, then the frame opens the next group
+                            rc = batch.flush(w); if (rc) return rc;
+                            HIPCHK(w, hipStreamSynchronize(w->stream));      // let everything queued run, then start the ring over
+                            stage_ring_reset(w); staged.clear(); staged_gen = w->stage_gen;
+                            if (!stage_ring_alloc(w, pbytes, &soff)) return w->fail(GGRS_E_CAPACITY, "spawn payload of %llu bytes does not fit the staging buffer", (unsigned long long)pbytes);
+                        }
+                        // (the caller's arrays are free again when the call returns; the bytes sit in the ring until this list's batch is collected)
+                        if (custom) memcpy(w->h_stage + soff, r.spawn_payload, pbytes);
+                        else { memcpy(w->h_stage + soff, r.spawn_vx, r.spawn_count * 4); memcpy(w->h_stage + soff + r.spawn_count * 4, r.spawn_vy, r.spawn_count * 4); }
+                        payload_dev = w->d_hstage + soff;
+                        if (staged.size() < 256) staged.push_back({key, key2, pbytes, payload_dev});
+                    }
+                }
                 uint32_t dtb = 0;
                 rc = group_step(w, r, &dtb, w->jit_marks ? &j.step_flags[j.n_steps] : nullptr); if (rc) return rc;
                 j.dt_bits[j.n_steps] = dtb;
@@ -298,38 +390,20 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                     const float fp = powf(w->systems[w->jit_box_sys].fparam[2], dtf);
                     memcpy(&j.aux_bits[j.n_steps], &fp, 4);
                 }
-                j.n_inputs[j.n_steps] = (uint8_t)r.n_inputs;
-                for (uint32_t k = 0; k < r.n_inputs; ++k) j.inputs[j.n_steps][k] = r.inputs[k];
+                j.n_inputs[j.n_steps] = (uint8_t)std::min<uint32_t>(r.n_inputs, w->max_players);
+                if (w->jit_reads_inputs) pack_inputs(w, r, j.inputs[j.n_steps]);      // PlayerInputs<T>: (T::Input, InputStatus) per player (src/lib.rs:98)
                 const uint32_t step = j.n_steps;
                 ++j.n_steps;
                 j.op_bits |= 1ULL << j.n_ops; ++j.n_ops;
-                if (advance_spawns(w, r)) {
-                    // The spawn system fires.  Fused (kernel_gen.hpp): the step's launch appends the rows itself -- the payload is staged now, the
-                    // host does in request order what run_spawn_systems does around its kernel (capacity, versions of the bundle, len) and the
-                    // group goes on.  Otherwise (no fusable spawn system, no room in the payload ring without waiting for the stream, or a
-                    // spawn beyond capacity -- which the unfused path reports) the group ends here and the spawn runs as its own launches,
-                    // as Bevy's Commands flush ends the schedule.
-                    const Staged* hit = nullptr;
-                    for (auto& st : staged) if (st.hx == r.spawn_vx && st.hy == r.spawn_vy && st.count == r.spawn_count) { hit = &st; break; }
-                    uint64_t soff = 0;
-                    const bool fusable = w->jit_spawn_sys >= 0 && r.spawn_count <= 0xFFFFFFFFull && w->len + r.spawn_count <= w->capacity;
-                    if (fusable && (hit || stage_ring_alloc(w, 2 * r.spawn_count, &soff))) {
-                        const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
-                        // the payload goes into the pinned, device-mapped staging buffer and the launch reads it from there (a few hundred bytes
-                        // per step over PCIe): no copy command per spawning step -- 2 x 8 of them per branch cost a 256-branch fan-out step
-                        // 20 ms of host time (profiles/r04e).  The bytes sit in the payload ring (host_requests.hpp) until this list's batch is collected;
-                        // the caller's arrays are free again when the call returns, as with the copies.
-                        if (hit) { j.spawn_vx[step] = hit->dx; j.spawn_vy[step] = hit->dy; }
-                        else {
-                            memcpy(w->h_stage + soff, r.spawn_vx, r.spawn_count * 4); memcpy(w->h_stage + soff + r.spawn_count, r.spawn_vy, r.spawn_count * 4);
-                            j.spawn_vx[step] = w->d_hstage + soff; j.spawn_vy[step] = w->d_hstage + soff + r.spawn_count;
-                            if (staged.size() < 256) staged.push_back({r.spawn_vx, r.spawn_vy, r.spawn_count, j.spawn_vx[step], j.spawn_vy[step]});
-                        }
-                        j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
-                        ver_touch_comp(w, sd.comp[0]); ver_touch_comp(w, sd.comp[1]); ver_touch_comp(w, sd.comp[2]);   // new rows in every column (and the presence mask) of the bundle
-                        w->len += r.spawn_count;
-                    } else { spawn_req = &r; ++i; break; }
-                }
+                if (fused_spawn) {
+                    const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
+                    j.spawn_payload[step] = payload_dev;
+                    j.spawn_first[step] = w->len; j.spawn_count[step] = (uint32_t)r.spawn_count;
+                    // new rows in every column (and the presence mask) of the bundle
+                    if (sd.kind == GGRS_SYS_SPAWN_CUSTOM) { const ggrs_world::SpawnSys& sp = w->spawn_customs[sd.comp[0]]; for (uint32_t c = 0; c < w->comps.size(); ++c) if ((sp.bundle_mask >> c) & 1ull) ver_touch_comp(w, c); }
+                    else { ver_touch_comp(w, sd.comp[0]); ver_touch_comp(w, sd.comp[1]); ver_touch_comp(w, sd.comp[2]); }
+                    w->len += r.spawn_count;
+                } else if (spawns) { spawn_req = &r; ++i; break; }
             } else {
                 return w->fail(GGRS_E_INVALID, "unknown request kind %u", r.kind);
             }
@@ -346,10 +420,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             j.save_rows[k] = j.save_dst[k] ? gs.save_rows[k] : 0;
             j.save_pmask[k] = j.save_dst[k] ? gs.save_pmask[k] : 0;
             j.load_rows |= j.save_rows[k];
-            bytes_slot += rows_bytes_per_slot(w, j.save_rows[k]);
+            bytes_slot += rows_bytes_per_slot(w, j.save_rows[k], true);
         }
-        if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows); }
-        bytes_slot += rows_bytes_per_slot(w, j.load_rows);
+        if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows, false); }
+        bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
@@ -358,46 +432,26 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         // A rollback group's FIRST Save is the oldest frame it produces -- what the next rollback loads (SyncTest: always; P2P with a steady
         // rollback depth: likewise).  Storing it through the L2 instead of around it lets the next launch's loads hit there: 72.5 -> 64.6 us
         // per depth-8 tick at 1 M in the ring-walking harness (profiles/r03n), every other row still streams past the caches.
-        // Past ~2.5 M particles the rows no longer survive in the caches until the next launch and only displace the stream (4 M: +3 %).
-        j.cached_saves = (j.nt && w->knobs.jit_cache_first_save && !j.src_is_live && j.n_saves >= 2 &&
-                          rows_bytes_per_slot(w, j.save_rows[0]) * cover <= w->knobs.jit_cached_save_max_bytes) ? 1u : 0u;
+        // Past ~2.5 M particles the rows no longer survive in the caches until the next launch and only displace the stream (4 M: +3 %; r04c).
+        j.cached_saves = (j.nt && !j.src_is_live && j.n_saves >= 2 && rows_bytes_per_slot(w, j.save_rows[0], true) * cover <= JIT_CACHED_SAVE_MAX_BYTES) ? 1u : 0u;
         // the source block of an HBM-sized rollback group is in the caches only if the previous group kept a Save there (the steady session: the
-        // same decision as this group's): otherwise its lines come from HBM once and are dead after the load
-        j.nt_loads = w->knobs.jit_nt_loads >= 0 ? (uint32_t)(w->knobs.jit_nt_loads != 0) : (j.nt && !j.cached_saves && !j.src_is_live ? 1u : 0u);
+        // same decision as this group's): otherwise its lines come from HBM once and are dead after the load (4 M: -3.5 %, allhot 4 M -8 %; it costs
+        // 3 % where the loads DO hit: profiles/r04o)
+        j.nt_loads = (j.nt && !j.cached_saves && !j.src_is_live) ? 1u : 0u;
         const bool launch = j.n_ops || !j.src_is_live;
-
-        if (w->jit_fn_persist && w->knobs.jit_persist_min_slots && cover > w->knobs.jit_persist_min_slots) {
-            // ---- HBM-sized group: the persistent form -- ONE launch, every Checksum(u128) folded in it (tick_fold)
-            rc = batch.flush(w); if (rc) return rc;
-            j.fold_wg_parts = reinterpret_cast<ggrs_u64*>(w->d_wg_parts); j.fold_ticket = w->d_ticket;
-            j.fold_out = reinterpret_cast<ggrs_u64*>(w->d_results + 2 * (uint64_t)(res_base + ns));
-            const uint32_t wpb = w->jit_persist_tpb / 64;
-            // grid: the chunks of the group, at most `oversub` x what the device holds at once (1: strictly persistent -- every
-            // workgroup walks several chunks; more: the hardware scheduler hands out workgroups as slots free up, which balances the
-            // tail better, at the price of more rows for tick_fold's last arriver)
-            // ... and never more workgroups than tick_fold's row buffer holds (A/B shapes: GGRS_JIT_PERSIST_TPB=256, a large oversubscription): the
-            // kernel walks its chunks with a grid stride, so a smaller grid is always correct
-            const uint32_t gp = std::max(1u, std::min<uint32_t>(std::min<uint32_t>((j.n_units + wpb - 1) / wpb, w->jit_persist_wgs * (uint32_t)w->knobs.jit_persist_oversub), w->wg_parts_rows));
-            if (launch) {
-                void* params[] = {&j};
-                rc = launch_jit(w, w->jit_fn_persist, gp, 1, 1, w->jit_persist_tpb, 0, params, bytes_slot * w->len); if (rc) return rc;
-            }
-            group_close(w, gs, j.n_saves, dead, wrote_live);
-            ns += j.n_saves;
-        } else {
-            // ---- per-tile grid: 256-slot workgroups, depth-parallel roles, batches, host-side or k_gen_finalize fold
+        {
+            // ---- per-tile grid: 256-slot workgroups, depth-parallel roles, batches; the partial rows go to the host, forward, or to k_gen_finalize
             // Depth-parallel roles: the group's outputs (Saves + live world) are split over grid.y roles of dp_s outputs.  Every role
             // reads the source block while the others write theirs, so the source must be none of the destinations; below ~2 Saves
             // there is no chain to split.  Crossovers: profiles/r02dp/ab2.txt, profiles/r02jit/jit_dp.txt.
-            if (w->knobs.dp && j.n_saves >= 2 && !w->jit_marks) {
+            if (j.n_saves >= 2 && !w->jit_marks) {
                 bool ok = !(wrote_live && j.src == j.live);
                 for (uint32_t k = 0; k < j.n_saves; ++k) ok = ok && j.save_dst[k] != j.src;
                 // ... and the destinations pairwise distinct: a ring shallower than the group's Saves hands an evicted slot to a later Save, and two
                 // roles writing one block concurrently could leave the OLDER frame's rows there (in op order on one lane the newer one wins)
                 for (uint32_t k = 1; k < j.n_saves && ok; ++k) for (uint32_t q = 0; q < k; ++q) ok = ok && (!j.save_dst[k] || j.save_dst[k] != j.save_dst[q]);
-                const uint64_t m = w->knobs.dp_max_slots;
-                if (ok) j.dp_s = w->knobs.dp > 1 ? (cover <= JIT_BATCH_MAX_SLOTS ? (uint32_t)w->knobs.dp : 0u)
-                               : (cover <= m ? 1u : (cover <= 2 * m ? 2u : (cover <= 6 * m ? 3u : 0u)));
+                const uint64_t m = JIT_DP_MAX_SLOTS;
+                if (ok) j.dp_s = cover <= m ? 1u : (cover <= 2 * m ? 2u : (cover <= 6 * m ? 3u : 0u));
             }
             // identical checksum-only groups (speculative branches) ride in one launch; a batch already fills the chip, so no roles
             const bool batchable = dead && j.n_saves > 0 && !w->jit_marks && cover <= JIT_BATCH_MAX_SLOTS;
@@ -407,34 +461,39 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
-            // Group fold (kernel_gen.hpp): a launch of many workgroups combines its rows 64 to 1 on the chip (atomics into one accumulator row per
-            // group); what the consumer reads -- the host at collect time or right away (blocking calls), k_gen_finalize when results stay on the
-            // device -- is `rows` group rows, not g
-            const bool group_fold = launch && j.n_saves && !j.dp_s && w->knobs.group_fold_min_wgs && g > (uint32_t)w->knobs.group_fold_min_wgs &&
-                                    j.n_saves * (n_cks + 1) <= 256u && w->d_gf_tickets;
-            const uint32_t rows = group_fold ? (jit_grid(g) + 63u) / 64u : g;
+            // who folds this launch's partial rows: the next launch on the stream (fold-forward: enqueued lists of more than
+            // GGRS_FOLD_FORWARD_MIN_WGS workgroups), the host from pinned rows (smaller groups), or k_gen_finalize (blocking calls of more than 1024
+            // workgroups, results that stay on the device, no room in the pinned ring)
             uint64_t rows_off = 0;
-            const bool host_fold = launch && host_fold_rows(w, rows, j.n_saves, n_cks, 1, &rows_off, wait);
-            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = rows; }
-            if (group_fold) {
-                j.gf_rows = reinterpret_cast<ggrs_u64*>(w->d_gf_acc); j.gf_tickets = w->d_gf_tickets;
-                if (!host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_gf_out); j.part_stride = rows; }
-            }
+            const uint32_t nvals = j.n_saves * (n_cks + 1);
+            bool ff = launch && j.n_saves && !wait && !w->device_results_only && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
+                      rows_ring_alloc(w, 2ull * nvals, &rows_off);
+            const bool host_fold = !ff && launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
+            uint32_t ff_buf = 0;
+            if (ff) { ff_buf = w->ff_cur; w->ff_cur ^= 1u; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[ff_buf]); j.part_stride = g; }
+            if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (launch) {
-                void* params[] = {&j};
                 hipFunction_t fn = jit_spec_for(w, j);
                 if (!fn) fn = w->jit_fn;
-                // nothing is queued behind this kernel when the host folds its rows (or there is nothing to fold) and no spawn system follows:
+                // nothing is queued behind this kernel when its rows are folded later (or there is nothing to fold) and no spawn system follows:
                 // the batch event of an enqueued list then completes WITH it (no marker packet between this tick's kernel and the next one's)
-                const bool last_gpu_op = (host_fold || !j.n_saves) && !spawn_req && !w->prof && w->knobs.event_on_kernel;
+                const bool last_gpu_op = (host_fold || ff || !j.n_saves) && !spawn_req && !w->prof;
                 hipEvent_t done = last_gpu_op ? w->batch_ev : nullptr;
-                rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, TPB, jit_lane_fold_bytes(w, n_cks, j.n_saves), params, bytes_slot * w->len, done); if (rc) return rc;
+                rc = launch_jit(w, fn, jit_grid(g), j.dp_s ? (j.n_saves + j.dp_s) / j.dp_s : 1u, 1, jit_lane_fold_bytes(w, n_cks, j.n_saves), j, bytes_slot * w->len, done); if (rc) return rc;
                 w->batch_ev_attached = done != nullptr;
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
-            if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, rows, n_cks, 1u, rows_off)); ns += j.n_saves; }
+            if (ff) {
+                ggrs_world::HostFold f = make_host_fold(j, res_base + ns, 1u, n_cks, 1u, rows_off);
+                f.ff_id = w->ff_next_id++; f.ff_seq = (0xA5ull << 56) | ++w->ff_seq;      // (a tag no live count and -- but for 2^-64 -- no hash equals)
+                memset(w->h_rows + rows_off + nvals, 0, (size_t)nvals * 8);              // the tag cells: whatever an earlier fold left there is gone
+                w->folds.push_back(f);
+                ggrs_world::FfPending& p = w->ff_pending;
+                p.valid = true; p.id = f.ff_id; p.seq = f.ff_seq; p.buf = ff_buf; p.nvals = nvals; p.g = g; p.stride = g; p.out_off = rows_off;
+                ns += j.n_saves;
+            } else if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, g, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {
-                GenFinArgs f = make_gen_fin(j, rows, n_cks, w->d_results + 2 * (uint64_t)(res_base + ns));   // one row per workgroup (per group of 64 with the group fold)
+                GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)(res_base + ns));   // one row per workgroup
                 arm_spin(w, f, j.n_saves, wait);
                 {
                     ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
@@ -478,9 +537,18 @@ int validate_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n) {
         if (r.kind != GGRS_REQ_SAVE && r.kind != GGRS_REQ_LOAD && r.kind != GGRS_REQ_ADVANCE)
             return w->fail(GGRS_E_INVALID, "request %u: unknown request kind %u", i, r.kind);
         if (r.kind != GGRS_REQ_ADVANCE) continue;
-        if (r.n_inputs > GGRS_MAX_PLAYERS) return w->fail(GGRS_E_INVALID, "request %u: %u player inputs (at most %d)", i, r.n_inputs, GGRS_MAX_PLAYERS);
+        if (r.n_inputs > w->max_players) return w->fail(GGRS_E_INVALID, "request %u: %u player inputs (at most %u: ggrs_hip_set_input_layout)", i, r.n_inputs, w->max_players);
         if (r.n_inputs && !r.inputs) return w->fail(GGRS_E_INVALID, "request %u: n_inputs = %u but inputs is NULL", i, r.n_inputs);
-        if (advance_spawns(w, r) && (!r.spawn_vx || !r.spawn_vy)) return w->fail(GGRS_E_INVALID, "request %u: a spawn of %llu fires but spawn_vx / spawn_vy is NULL", i, (unsigned long long)r.spawn_count);
+        if (r.status) for (uint32_t k = 0; k < r.n_inputs; ++k) if (r.status[k] > GGRS_INPUT_DISCONNECTED) return w->fail(GGRS_E_INVALID, "request %u: InputStatus %u of player %u is none of Confirmed / Predicted / Disconnected", i, r.status[k], k);
+        if (!advance_spawns(w, r)) continue;
+        bool custom = false; const ggrs_world::SpawnSys* sp = nullptr;
+        for (auto& s : w->systems) if (s.kind == GGRS_SYS_SPAWN_CUSTOM) { custom = true; sp = &w->spawn_customs[s.comp[0]]; }
+        if (!custom && (!r.spawn_vx || !r.spawn_vy)) return w->fail(GGRS_E_INVALID, "request %u: a spawn of %llu fires but spawn_vx / spawn_vy is NULL", i, (unsigned long long)r.spawn_count);
+        if (custom) {
+            const uint64_t need = sp->payload_stride ? (uint64_t)sp->payload_stride * r.spawn_count : r.spawn_payload_bytes;
+            if (need && !r.spawn_payload) return w->fail(GGRS_E_INVALID, "request %u: the spawn system reads %llu payload bytes but spawn_payload is NULL", i, (unsigned long long)need);
+            if (sp->payload_stride && r.spawn_payload_bytes && r.spawn_payload_bytes < need) return w->fail(GGRS_E_INVALID, "request %u: spawn_payload_bytes = %llu, the spawn of %llu needs %llu", i, (unsigned long long)r.spawn_payload_bytes, (unsigned long long)r.spawn_count, (unsigned long long)need);
+        }
     }
     return GGRS_OK;
 }

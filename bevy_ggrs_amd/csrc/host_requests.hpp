@@ -211,10 +211,11 @@ int fill_defaults(ggrs_world* w, uint32_t c, uint64_t first, uint64_t count) {
     return GGRS_OK;
 }
 
-// The spawn-payload ring (host_world.hpp): n contiguous floats, or false when the region in front of the oldest uncollected batch's
-// payloads is too small (the caller then waits for the stream, which frees everything, or -- a fused spawn -- ends its group).
+// The spawn-payload ring (host_world.hpp): n contiguous bytes (16-byte granules), or false when the region in front of the oldest uncollected
+// batch's payloads is too small (the caller then waits for the stream, which frees everything).
 bool stage_ring_alloc(ggrs_world* w, uint64_t n, uint64_t* off) {
-    uint64_t& head = w->stage_used; const uint64_t tail = w->stage_tail, cap = w->stage_floats;
+    n = (n + 15u) & ~15ull;
+    uint64_t& head = w->stage_used; const uint64_t tail = w->stage_tail, cap = w->stage_bytes;
     if (n > cap) return false;
     if (head >= tail) {
         if (head + n <= cap) { *off = head; head += n; return true; }
@@ -224,20 +225,22 @@ bool stage_ring_alloc(ggrs_world* w, uint64_t n, uint64_t* off) {
     if (head + n < tail) { *off = head; head += n; return true; }
     return false;
 }
-// every launch that could read a staged payload has completed (the stream was waited for / every batch collected)
-void stage_ring_reset(ggrs_world* w) { w->stage_used = w->stage_tail = 0; for (auto& b : w->pending) b.stage_end = 0; }
-// vx and vy of one spawn, side by side in the ring, copied to the device twin for the unfused spawn kernel
+// every launch that could read a staged payload has completed (the stream was waited for / every batch collected).  Offsets handed out before
+// this point are dead: stage_gen tells whoever cached one (a request list's payload dedup)
+void stage_ring_reset(ggrs_world* w) { w->stage_used = w->stage_tail = 0; ++w->stage_gen; for (auto& b : w->pending) b.stage_end = 0; }
+// vx and vy of one particles spawn, side by side in the ring (2 x n floats must fit: the default ring of 8 MiB takes a spawn of 1 M particles;
+// GGRS_STAGE_BYTES), copied to the device twin for the unfused spawn kernel
 int stage_pair(ggrs_world* w, const float* vx, const float* vy, uint64_t n, float** dvx, float** dvy) {
-    if (2 * n > w->stage_floats) return w->fail(GGRS_E_CAPACITY, "spawn payload of 2 x %llu floats exceeds the staging buffer (%llu floats)", (unsigned long long)n, (unsigned long long)w->stage_floats);
+    if (2 * n * 4 > w->stage_bytes) return w->fail(GGRS_E_CAPACITY, "spawn payload of 2 x %llu floats exceeds the staging buffer (%llu bytes: GGRS_STAGE_BYTES)", (unsigned long long)n, (unsigned long long)w->stage_bytes);
     uint64_t off = 0;
-    if (!stage_ring_alloc(w, 2 * n, &off)) {
+    if (!stage_ring_alloc(w, 2 * n * 4, &off)) {
         HIPCHK(w, hipStreamSynchronize(w->stream));
         stage_ring_reset(w);
-        (void)stage_ring_alloc(w, 2 * n, &off);
+        (void)stage_ring_alloc(w, 2 * n * 4, &off);
     }
-    memcpy(w->h_stage + off, vx, n * 4); memcpy(w->h_stage + off + n, vy, n * 4);
+    memcpy(w->h_stage + off, vx, n * 4); memcpy(w->h_stage + off + n * 4, vy, n * 4);
     HIPCHK(w, hipMemcpyAsync(w->d_stage + off, w->h_stage + off, 2 * n * 4, hipMemcpyHostToDevice, w->stream));
-    *dvx = w->d_stage + off; *dvy = w->d_stage + off + n;
+    *dvx = reinterpret_cast<float*>(w->d_stage + off); *dvy = reinterpret_cast<float*>(w->d_stage + off + n * 4);
     return GGRS_OK;
 }
 
@@ -256,6 +259,11 @@ uint32_t dt_bits_for_frame(uint64_t fps, int32_t frame) {
 }
 
 // Commands are deferred: spawns materialise after every system of the frame ran (set.rs:118-134).
+// `pressed`: any player's input (its first byte: the whole input of a Config<Input = u8> session) carries the system's bit
+inline bool spawn_pressed(const ggrs_world* w, const ggrs_system_desc& s, const uint8_t* inputs, uint32_t n_inputs) {
+    for (uint32_t k = 0; k < n_inputs; ++k) if (inputs[(size_t)k * w->input_bytes] & (uint8_t)s.iparam[1]) return true;
+    return false;
+}
 int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, uint64_t spawn_count,
                       const float* spawn_vx, const float* spawn_vy) {
     int rc = GGRS_OK;
@@ -263,9 +271,7 @@ int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, u
     uint64_t* part_cnt = w->cks_args.part_cnt;
     for (auto& s : w->systems) {
         if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
-        bool pressed = false;                                   // spawn_pressed, particles.rs:254-256
-        for (uint32_t k = 0; k < n_inputs; ++k) pressed |= (inputs[k] & (uint8_t)s.iparam[1]) != 0;
-        if (!pressed || spawn_count == 0) continue;
+        if (!spawn_pressed(w, s, inputs, n_inputs) || spawn_count == 0) continue;      // spawn_pressed, particles.rs:254-256
         if (w->len + spawn_count > w->capacity) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)spawn_count, (unsigned long long)w->capacity);
         const uint32_t cT = s.comp[0], cV = s.comp[1], cL = s.comp[2];
         const Comp& T = w->comps[cT]; const Comp& V = w->comps[cV]; const Comp& L = w->comps[cL];
@@ -321,6 +327,7 @@ std::string custom_source(const ggrs_world* w, const ggrs_world::Custom& c, cons
     char buf[256];
     snprintf(buf, sizeof buf, "static_assert(sizeof(GgrsCustomArgs) == %zu, \"host/device argument block mismatch\");\n", sizeof(GgrsCustomArgs));
     s += buf;
+    s += GGRS_FRAME_TEXT;
     s += GGRS_ENTITY_TEXT;
     s += "#line 1 \"ggrs_system\"\n";
     s += user;
@@ -332,6 +339,13 @@ std::string custom_source(const ggrs_world* w, const ggrs_world::Custom& c, cons
     snprintf(buf, sizeof buf, "#define GGRS_LT_SHIFT %d\n", LT_SHIFT);
     s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(256) void ggrs_custom_kernel(GgrsCustomArgs a) {\n"
+         "    __shared__ unsigned char s_in[272];                   // PlayerInputs: a handle read from a component may index them\n"
+         "    for (int i = threadIdx.x; i < 272; i += 256) s_in[i] = a.fr.in[i];\n"
+         "    __syncthreads();\n"
+         "    GgrsFrame fr; fr.dt = a.fr.dt; fr.frame = a.fr.frame; fr.n_inputs = a.fr.n_inputs; fr.input_bytes = a.fr.input_bytes;\n"
+         "    fr.input.p = s_in; fr.input.ib = a.fr.input_bytes; fr.status = s_in + a.fr.status_off;\n"
+         "    for (int k = 0; k < 4; ++k) fr.fparam[k] = a.fr.fparam[k];\n"
+         "    fr.iparam[0] = a.fr.iparam[0]; fr.iparam[1] = a.fr.iparam[1];\n"
          "    const ggrs_u64 e = (ggrs_u64)blockIdx.x * 256 + threadIdx.x;\n"
          "    if (e >= a.len_pad64) return;                         // whole waves only (len padded to 64)\n"
          "    const ggrs_u64 aw = *reinterpret_cast<const ggrs_u64*>(a.state + a.off_alive + (e >> 6) * 8);\n"
@@ -348,7 +362,7 @@ std::string custom_source(const ggrs_world* w, const ggrs_world::Custom& c, cons
          "            at[i] = a.state + a.col_off[i] + (e >> GGRS_LT_SHIFT) * a.ts[i] + (e & ((1ULL << GGRS_LT_SHIFT) - 1)) * GGRS_WB[i];\n"
          "            ent.w[i] = GGRS_WB[i] == 8 ? *reinterpret_cast<const ggrs_u64*>(at[i]) : (ggrs_u64)*reinterpret_cast<const ggrs_u32*>(at[i]);\n"
          "        }\n"
-         "        ggrs_system(ent, a.fr);\n"
+         "        ggrs_system(ent, fr);\n"
          "        #pragma unroll\n"
          "        for (int i = 0; i < GGRS_N_BIND; ++i) {\n"
          "            if (GGRS_WB[i] == 8) *reinterpret_cast<ggrs_u64*>(at[i]) = ent.w[i];\n"
@@ -369,7 +383,16 @@ std::string custom_source(const ggrs_world* w, const ggrs_world::Custom& c, cons
     return s;
 }
 
-int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs) {
+// PlayerInputs of one AdvanceFrame in the layout the device sees: n x input_bytes bytes, then (at max_players x input_bytes) one InputStatus byte per player
+inline void pack_inputs(const ggrs_world* w, const ggrs_request& r, unsigned char* dst /* >= max_players * (input_bytes + 1) */) {
+    const uint32_t ib = w->input_bytes, mp = w->max_players;
+    memset(dst, 0, (size_t)mp * (ib + 1));
+    const uint32_t n = std::min<uint32_t>(r.n_inputs, mp);
+    if (n && r.inputs) memcpy(dst, r.inputs, (size_t)n * ib);
+    if (n && r.status) memcpy(dst + (size_t)mp * ib, r.status, n);       // NULL: every input Confirmed (0)
+}
+
+int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, const ggrs_request& r) {
     const ggrs_world::Custom& c = w->customs[s.comp[0]];
     GgrsCustomArgs a; memset(&a, 0, sizeof a);
     a.state = w->live.ptr; a.off_alive = w->off_alive;
@@ -386,8 +409,9 @@ int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, co
     if (a.defer) w->marks_possible = true;
     memcpy(&a.fr.dt, &dt_bits, 4);
     a.fr.frame = w->frame;
-    a.fr.n_inputs = std::min<uint32_t>(n_inputs, 16);
-    for (uint32_t k = 0; k < a.fr.n_inputs; ++k) a.fr.input[k] = inputs[k];
+    a.fr.n_inputs = std::min<uint32_t>(r.n_inputs, w->max_players);
+    a.fr.input_bytes = w->input_bytes; a.fr.status_off = w->max_players * w->input_bytes;
+    pack_inputs(w, r, a.fr.in);
     for (int k = 0; k < 4; ++k) a.fr.fparam[k] = s.fparam[k];
     a.fr.iparam[0] = s.iparam[0]; a.fr.iparam[1] = s.iparam[1];
     const uint32_t gx = (uint32_t)((a.len_pad64 + 255) / 256);
@@ -398,8 +422,9 @@ int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, co
 }
 
 // ---- AdvanceWorld
-int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_inputs,
-               uint64_t spawn_count, const float* spawn_vx, const float* spawn_vy) {
+int do_advance(ggrs_world* w, const ggrs_request& r) {
+    uint32_t dt_bits = r.dt_bits; const uint8_t* inputs = r.inputs; const uint32_t n_inputs = r.n_inputs;
+    const uint64_t spawn_count = r.spawn_count; const float* spawn_vx = r.spawn_vx; const float* spawn_vy = r.spawn_vy;
     int rc = seal(w); if (rc) return rc;
     w->frame += 1;                                              // schedule_systems.rs:254-259
     if (dt_bits == 0) dt_bits = dt_bits_for_frame(w->fps, w->frame);
@@ -492,10 +517,10 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
                     memcpy(&a.friction_pow_bits, &fp, 4);
                     a.accel = s.fparam[0]; a.max_speed = s.fparam[1]; a.half_width = s.fparam[3];
                     a.n_inputs = std::min<uint32_t>(n_inputs, 16);
-                    for (uint32_t k = 0; k < a.n_inputs; ++k) a.inputs[k] = inputs[k];
+                    for (uint32_t k = 0; k < a.n_inputs; ++k) a.inputs[k] = inputs[(size_t)k * w->input_bytes];      // box_game's input is one byte (box_game.rs:13-16)
                     hipLaunchKernelGGL(k_box_move, dim3((uint32_t)((w->len + TPB - 1) / TPB)), dim3(TPB), 0, w->stream, a);
                 } break;
-                case GGRS_SYS_CUSTOM: { rc = launch_custom(w, s, dt_bits, inputs, n_inputs); if (rc) return rc; } break;
+                case GGRS_SYS_CUSTOM: { rc = launch_custom(w, s, dt_bits, r); if (rc) return rc; } break;
                 default: break;
                 }
             }
@@ -506,38 +531,82 @@ int do_advance(ggrs_world* w, uint32_t dt_bits, const uint8_t* inputs, uint32_t 
     return run_spawn_systems(w, inputs, n_inputs, spawn_count, spawn_vx, spawn_vy);
 }
 
+// Bounded poll of tags in pinned host memory: true once tags[0..n) all equal seq.  The producer writes each value, then its tag with a
+// system-scope release (k_gen_finalize, ff_fold_row); seeing every tag means the values are in host memory.
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+bool spin_for_tags(const volatile uint64_t* tags, uint32_t n, uint64_t seq, int budget_us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t k = 0;
+    for (uint32_t it = 1; ; ++it) {
+        while (k < n && tags[k] == seq) ++k;
+        if (k == n) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        if ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget_us)) return false;
+        cpu_relax();
+    }
+}
+
+// Fold-forward: the rows of the last launch are still unfolded and no later launch took them along -- k_ff_fold does it now (a collect with
+// nothing enqueued behind the batch, a blocking call, a world being synchronised)
+int ff_flush(ggrs_world* w) {
+    ggrs_world::FfPending& p = w->ff_pending;
+    if (!p.valid) return GGRS_OK;
+    FfArgs f; memset(&f, 0, sizeof f);
+    f.rows = w->d_ff_rows[p.buf]; f.out = w->d_rows + p.out_off; f.seq = p.seq; f.nvals = p.nvals; f.g = p.g; f.stride = p.stride; f.nc1 = w->cks_args.n_cks + 1;
+    hipLaunchKernelGGL(k_ff_fold, dim3(p.nvals), dim3(TPB), 0, w->stream, f);
+    HIPCHK(w, hipGetLastError());
+    w->ff_done_id = p.id; p.valid = false;
+    return GGRS_OK;
+}
+
 // component_checksum.rs:92-95 (hash the XOR of the entity hashes once more), entity_checksum.rs:29-52, checksum.rs:88-99 (XOR of all
-// parts; the upper 64 bits of the u128 are always 0) -- what k_gen_finalize does, over rows the device left in pinned memory
-void run_host_folds(ggrs_world* w, uint32_t n) {
+// parts; the upper 64 bits of the u128 are always 0) -- what k_gen_finalize does, over rows the device left in pinned memory: one row per
+// workgroup (small groups) or one value per row (fold-forward: the device folded the rows, the tags say when the values are there)
+int run_host_folds(ggrs_world* w, uint32_t n) {
     for (; n && !w->folds.empty(); --n) {
         const ggrs_world::HostFold f = w->folds.front(); w->folds.pop_front();
         const uint32_t nc = f.n_cks + 1;
+        if (f.ff_id) {
+            // the values arrive with the launch (or k_ff_fold) that follows this group's on the stream
+            if (f.ff_id > w->ff_done_id) { const int rc = ff_flush(w); if (rc) return rc; }
+            const double t0 = w->tl.on ? tl_now_us() : 0;
+            const uint32_t nvals = f.n_saves * nc;
+            if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, std::max(w->knobs.spin_wait_us, 0))) {
+                HIPCHK(w, hipStreamSynchronize(w->stream));
+                if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, 1000000)) return w->fail(GGRS_E_HIP, "fold-forward: the tags of group %llu never arrived", (unsigned long long)f.ff_id);
+            }
+            if (w->tl.on) w->tl.tag_wait_us += tl_now_us() - t0;
+        }
+        const double t1 = w->tl.on ? tl_now_us() : 0;
         for (uint32_t m = 0; m < f.members; ++m)
             for (uint32_t sv = 0; sv < f.n_saves; ++sv) {
                 uint64_t total = 0;
                 for (uint32_t c = 0; c < nc; ++c) {
                     const uint64_t* row = w->h_rows + f.rows_off + ((uint64_t)(m * f.n_saves + sv) * nc + c) * f.g;
-                    uint64_t x = 0, sum = 0;
-                    for (uint32_t t = 0; t < f.g; ++t) { x ^= row[t]; sum += row[t]; }
-                    total ^= c == f.n_cks ? sea_pair(sum, f.save_len[sv]) : sea_one(x);
+                    if (c == f.n_cks) { uint64_t sum = 0; for (uint32_t t = 0; t < f.g; ++t) sum += row[t]; total ^= sea_pair(sum, f.save_len[sv]); }
+                    else { uint64_t x = 0; for (uint32_t t = 0; t < f.g; ++t) x ^= row[t]; total ^= sea_one(x); }
                 }
                 uint64_t* out = w->h_results + 2 * (uint64_t)(f.res_slot + m * f.n_saves + sv);
                 out[0] = total; out[1] = 0;
             }
+        if (w->tl.on) w->tl.fold_us += tl_now_us() - t1;
     }
     // the row buffer is a ring: everything before the oldest unfolded group is free again
     if (w->folds.empty()) { w->rows_used = 0; w->rows_tail = 0; } else w->rows_tail = w->folds.front().rows_off;
+    return GGRS_OK;
 }
-// room for the partial rows of a group in the pinned row buffer?  (no: the group is folded by k_gen_finalize on the device)
-// `blocking`: the caller waits for this group's checksums right away (the synchronous API) -- the host's fold is then serial with the
-// kernel instead of hidden behind the next tick's (750 KB of rows at 1 M: ~30 us of a host core), so only small groups take it.
-constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;
-bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off, bool blocking = false) {
-    if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.host_fold_max_wgs) return false;
-    if (blocking && g > HOST_FOLD_MAX_WGS_BLOCKING && !w->knobs.host_fold_explicit) return false;             // (an explicit GGRS_HOST_FOLD_MAX_WGS is taken literally)
-    const uint64_t need = (uint64_t)g * n_saves * (n_cks + 1) * members;
+// `need` u64 of the pinned row ring (rows of pending folds live in [tail, head), mod wrap); false: no room (the group is folded by k_gen_finalize)
+bool rows_ring_alloc(ggrs_world* w, uint64_t need, uint64_t* off) {
+    if (!w->h_rows) return false;
     if (w->folds.empty()) { w->rows_used = 0; w->rows_tail = 0; }
-    uint64_t& head = w->rows_used;                                 // ring: rows of pending folds live in [tail, head) (mod wrap)
+    uint64_t& head = w->rows_used;
     if (head >= w->rows_tail) {
         if (head + need <= w->rows_cap) { *off = head; head += need; return true; }
         if (need < w->rows_tail) { *off = 0; head = need; return true; }          // wrap: the front of the buffer has been folded
@@ -545,6 +614,14 @@ bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks,
     }
     if (head + need < w->rows_tail) { *off = head; head += need; return true; }
     return false;
+}
+// room for the partial rows of a small group in the pinned row buffer?  (no: the group is folded on the device)
+// `blocking`: the caller waits for this group's checksums right away (the synchronous API) -- the host's fold is then serial with the
+// kernel instead of hidden behind the next tick's, so only small groups take it.
+bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off, bool blocking = false) {
+    if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.fold_forward_min_wgs) return false;
+    if (blocking && g > HOST_FOLD_MAX_WGS_BLOCKING) return false;
+    return rows_ring_alloc(w, (uint64_t)g * n_saves * (n_cks + 1) * members, off);
 }
 
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
@@ -555,20 +632,15 @@ int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
     // command records) it is the stream wait.
     bool seen = false;
     if (w->spin_n && w->folds.empty() && (w->spin_seq & 255u) != 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        uint32_t k = 0;
-        for (uint32_t it = 1; ; ++it) {
-            while (k < w->spin_n && w->h_done[k] == w->spin_seq) ++k;
-            if (k == w->spin_n) { seen = true; break; }
-            if ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(w->knobs.spin_wait_us)) break;
-            __builtin_ia32_pause();
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        seen = spin_for_tags(w->h_done, w->spin_n, w->spin_seq, w->knobs.spin_wait_us);
         ++(seen ? w->spin_hits : w->spin_misses);
     }
     w->spin_n = 0;
-    if (!seen) HIPCHK(w, hipStreamSynchronize(w->stream));
-    run_host_folds(w, ~0u);
+    if (!seen) {
+        int rc = ff_flush(w); if (rc) return rc;                     // (nothing is pending in the synchronous API: a no-op there)
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+    }
+    int rc = run_host_folds(w, ~0u); if (rc) return rc;
     stage_ring_reset(w);
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
     return GGRS_OK;
@@ -581,11 +653,13 @@ void apply_synctest_confirmed(ggrs_world* w) {
     if (c >= 0) { w->has_confirmed = true; w->confirmed = c; }
 }
 
+// does a spawn system fire in this AdvanceFrame?  spawn_particles (particles.rs:254-270): a player holds the system's input bit and the host
+// drew spawn_count velocities; a user-written spawner (ggrs_hip_add_spawn_system): the host decided -- spawn_count is what the system spawns
 bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
     if (r.spawn_count == 0) return false;
     for (auto& s : w->systems) {
-        if (s.kind != GGRS_SYS_PARTICLES_SPAWN) continue;
-        for (uint32_t k = 0; k < r.n_inputs; ++k) if (r.inputs[k] & (uint8_t)s.iparam[1]) return true;
+        if (s.kind == GGRS_SYS_SPAWN_CUSTOM) return true;
+        if (s.kind == GGRS_SYS_PARTICLES_SPAWN && r.inputs && spawn_pressed(w, s, r.inputs, r.n_inputs)) return true;
     }
     return false;
 }

@@ -8,16 +8,10 @@ int seal_impl(ggrs_world* w);
 // Sealing fixes the layout and carves the arena, lazily, on the first call that needs device state.  It is
 // failure-atomic: whatever a failed attempt allocated is released, and the failure LATCHES -- every later call
 // reports the same error instead of carving a second arena over half-initialised bookkeeping.
-// A library-owned arena goes back when its world closes or fails to seal: paged ones to the runtime, contiguous ones to the parking list.
+// A library-owned arena goes back to the runtime when its world closes or fails to seal.
 void arena_release(ggrs_world* w) {
     if (!(w->own_arena && w->arena)) return;
-    if (w->arena_contiguous && w->knobs.arena_park) {
-        std::lock_guard<std::mutex> lk(g_parked_mu);
-        g_parked.push_back(ParkedArena{w->arena, w->arena_bytes, w->device});
-    } else {
-        (void)hipFree(w->arena);
-        if (!w->arena_contiguous) g_paged_arena_frees.fetch_add(1, std::memory_order_relaxed);
-    }
+    (void)hipFree(w->arena);
     w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false;
 }
 
@@ -29,7 +23,7 @@ int seal(ggrs_world* w) {
     if (rc == GGRS_OK) return rc;
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_gf_acc = nullptr; w->d_gf_out = nullptr; w->d_gf_tickets = nullptr; }
+    if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_ff_rows[0] = w->d_ff_rows[1] = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; w->d_hstage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -119,49 +113,38 @@ int seal_impl(ggrs_world* w) {
     if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && !w->knobs.tick_jit) w->jit_status = "disabled (GGRS_TICK_JIT=0)";
     if (!(w->flags & (GGRS_WORLD_NO_GROUPS | GGRS_WORLD_UNFUSED)) && w->ts > 0 && w->knobs.tick_jit) {
         std::string src;
-        if (!jit_source(w, src, false)) w->jit_status = "not covered by the generator (a system writes a live-only component, or too many words per entity)";
+        if (!jit_source(w, src)) w->jit_status = "not covered by the generator (a system writes a live-only component, or too many words per entity)";
         else {
             if (w->knobs.debug_jit > 1) fprintf(stderr, "%s\n", src.c_str());
             const std::string keep = w->err;
             w->jit_src = src;
-            if (jit_cached(w, src, &w->jit_fn, &w->jit_entry) != GGRS_OK) {
+            if (jit_cached(w, src, &w->jit_fn, &w->jit_entry, &w->jit_origin) != GGRS_OK) {
                 if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] generated request-group kernel rejected: %s\n", w->err.c_str());
-                w->jit_status = (hiprtc().lib ? "rejected: " : "hiprtc unavailable: ") + w->err.substr(0, 300);
+                w->jit_status = (hiprtc_for(w).lib ? "rejected: " : "no run-time compiler and no shipped code object for this world: ") + w->err.substr(0, 300);
                 w->jit_fn = nullptr; w->err = keep;
             } else w->jit_status = "ok";
-            // its persistent form, for worlds that can grow past the threshold (HBM-sized groups: one launch, fold in-kernel)
-            if (w->jit_fn && w->knobs.jit_persist_min_slots && w->cap_pad > w->knobs.jit_persist_min_slots && jit_source(w, src, true)) {
-                if (jit_cached(w, src, &w->jit_fn_persist, &w->jit_entry_persist) != GGRS_OK) {
-                    if (w->knobs.debug_jit) fprintf(stderr, "[ggrs_hip] persistent form of the generated kernel rejected: %s\n", w->err.c_str());
-                    w->jit_fn_persist = nullptr; w->err = keep;
-                } else {
-                    uint32_t units = 0;
-                    for (auto& c : w->comps) if (!c.no_rollback) units += c.n_words * std::max(1u, c.word_bytes / 4);
-                    const JitPersistShape shape = jit_persist_shape(units);
-                    w->jit_persist_tpb = (uint32_t)shape.tpb;
-                    int nb = 0;
-                    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, w->jit_fn_persist, shape.tpb, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
-                    // what the launch_bounds asked the compiler for is what the grid assumes (the occupancy query is known to
-                    // answer one block high near SGPR edges: MI355X_MICROARCH.md; tick_fold needs no co-residency, only a bound)
-                    const int want = shape.min_waves_per_simd * 256 / shape.tpb;
-                    w->jit_persist_wgs = (uint32_t)std::max(1, std::min(nb, want)) * (uint32_t)w->n_cu;
-                }
-            }
         }
         if (w->jit_fn) {
             for (size_t i = 0; i < w->systems.size(); ++i) {
                 const ggrs_system_desc& d = w->systems[i];
-                w->jit_reads_inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE;
+                w->jit_reads_inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
                 w->jit_marks |= d.kind == GGRS_SYS_CUSTOM || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
                 if (d.kind == GGRS_SYS_BOX_MOVE) w->jit_box_sys = (int)i;
             }
             w->gen_ok = true;
-            // the spawn system runs inside request groups unless the persistent form may serve them (it folds with ONE len) or the knob says no
-            if (!w->jit_fn_persist && w->knobs.jit_fuse_spawn) w->jit_spawn_sys = jit_fused_spawn_system(w);
+            w->jit_spawn_sys = jit_fused_spawn_system(w);              // the spawn system runs inside request groups
+            delete w->jl; w->jl = new JitLayout(jit_layout(w));
+            w->cap_saves = w->jl->cap_saves; w->cap_steps = w->jl->cap_steps;
+            w->jit_argbuf.assign(w->jl->bytes, 0);
         }
     }
     if (w->custom_hashers && !w->gen_ok)
         return w->fail(GGRS_E_INVALID, "a user-written checksum hasher needs the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
+    if (w->has_strategy && !w->gen_ok)
+        return w->fail(GGRS_E_INVALID, "a component under a Strategy (ggrs_hip_register_component_strategy) needs the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
+    for (auto& sd : w->systems) if (sd.kind == GGRS_SYS_SPAWN_CUSTOM && !(w->gen_ok && w->jit_spawn_sys >= 0))
+        return w->fail(GGRS_E_INVALID, "a user-written spawn system (ggrs_hip_add_spawn_system) runs inside the generated request-group kernel, which this world does not have "
+                                       "(or the schedule holds a second spawn system): %s", w->jit_status.c_str());
 
     // ---- arena carve
     const uint32_t n_tiles = (uint32_t)(w->cap_pad / TILE);
@@ -171,45 +154,17 @@ int seal_impl(ggrs_world* w) {
     const uint64_t parts_bytes = align_up((uint64_t)(w->cks_args.n_cks + 1) * w->part_stride * 8, ALIGN);
     w->max_results = 16384;                             // pinned result ring (256 KiB): a fan-out step of 256 branches x 8 frames alone is 2048
     const uint64_t units_bytes = align_up((units.size() + 1) * sizeof(UnitDesc), ALIGN);
-    w->stage_floats = w->knobs.stage_floats; w->stage_used = w->stage_tail = 0;
-    const uint64_t stage_bytes = w->stage_floats * 4;
-    // tick_fold's row buffer: one row of saves x (components + 1) values per workgroup of a persistent grid (<= 2 per CU) + the ticket
-    w->wg_parts_rows = (uint32_t)std::max<uint64_t>(4 * w->n_cu + 64, w->cap_pad / 512 + 64);      // the persistent form's grid is clamped to this (host_groups.hpp)
-    const uint64_t wg_parts_bytes = align_up((uint64_t)w->wg_parts_rows * MAX_TICK_SAVES * std::max<uint64_t>(3, w->cks_args.n_cks + 1) * 8, ALIGN) + ALIGN;
-    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + wg_parts_bytes;
+    w->stage_bytes = w->knobs.stage_bytes; w->stage_used = w->stage_tail = 0;
+    const uint64_t stage_bytes = w->stage_bytes;
+    const uint64_t need = (uint64_t)(w->max_depth + 1) * w->state_bytes + w->side_bytes + parts_bytes + units_bytes + ALIGN + stage_bytes + ALIGN;
     if (w->arena) {
         if (w->arena_bytes < need) return w->fail(GGRS_E_INVALID, "arena too small: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)w->arena_bytes);
     } else {
-        // contiguous (write-through, uncached) arenas are what dense nt store streams want: opt-in per world
-        // (GGRS_WORLD_CONTIG_ARENA), only for the particles worlds, up to 1.5 GiB.  A parked arena (host_world.hpp: contiguous arenas
-        // are never handed back) is taken first; a NEW contiguous allocation is made only while this process has not freed a paged
-        // arena of its own (include/ggrs_hip.h).  GGRS_ARENA_CONTIG=0|1 forces the choice for every world, =2 for the particles worlds
-        // only (the mix of profiles/r03fc).
-        const bool want = w->knobs.arena_contig == 2 ? w->fused_ok
-                        : w->knobs.arena_contig >= 0 ? w->knobs.arena_contig != 0
-                                                     : ((w->flags & GGRS_WORLD_CONTIG_ARENA) && w->fused_ok && need <= (1536ull << 20));
-        const bool may_allocate = w->knobs.arena_contig >= 0 || g_paged_arena_frees.load(std::memory_order_relaxed) == 0;
-        uint8_t* pa = nullptr; uint64_t got = need;
-        hipError_t me = hipErrorUnknown;
-        if (want) {
-            std::lock_guard<std::mutex> lk(g_parked_mu);
-            size_t best = g_parked.size();
-            for (size_t i = 0; i < g_parked.size(); ++i)
-                if (g_parked[i].device == w->device && g_parked[i].bytes >= need && (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes)) best = i;
-            if (best != g_parked.size()) { pa = g_parked[best].ptr; got = g_parked[best].bytes; g_parked.erase(g_parked.begin() + best); me = hipSuccess; }
-        }
-        if (want && me != hipSuccess && may_allocate) me = hipExtMallocWithFlags((void**)&pa, need, hipDeviceMallocContiguous);
-        w->arena_contiguous = me == hipSuccess;
-        if (me != hipSuccess) { (void)hipGetLastError(); pa = nullptr; me = hipMalloc((void**)&pa, need); }   // no contiguous range free: plain pages
-        if (me != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)need); }
-        if (w->knobs.arena_flush & (w->arena_contiguous ? 1 : 4)) {
-            // GGRS_ARENA_FLUSH=1 (experiment): before the uncached mapping is first used, every XCD's L2 writes back and drops what it
-            // holds -- if lines of an earlier CACHED mapping of these physical pages are what corrupts contiguous arenas, this ends it
-            hipLaunchKernelGGL(k_flush_l2, dim3(8 * 256), dim3(64), 0, w->stream);
-            HIPCHK(w, hipStreamSynchronize(w->stream));
-        }
-        if (w->knobs.debug_arena) fprintf(stderr, "[ggrs arena] %s allocation of %llu bytes at %p, state_bytes=%llu\n", w->arena_contiguous ? "contiguous" : "paged", (unsigned long long)need, (void*)pa, (unsigned long long)w->state_bytes);
-        w->arena = pa; w->arena_bytes = got; w->own_arena = true;
+        // plain hipMalloc pages: the generated kernel is faster on them than on a physically contiguous (write-through) arena
+        // (1 M: 169 vs 149 G entity-frames/s, r03y3) -- the opt-in contiguous arena of rounds 2-4 and its parking list are gone
+        uint8_t* pa = nullptr;
+        if (hipMalloc((void**)&pa, need) != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)need); }
+        w->arena = pa; w->arena_bytes = need; w->own_arena = true;
     }
     // GGRS_DEBUG_POISON=1: fill a library-owned arena with a garbage pattern before anything is initialised -- a read of memory the
     // library never wrote (hidden by whatever a previous allocation left there) then fails the parity tests every time
@@ -227,9 +182,7 @@ int seal_impl(ggrs_world* w) {
     w->d_parts = (uint64_t*)p; p += parts_bytes;
     w->d_units = (UnitDesc*)p; p += units_bytes;
     w->d_maskoffs = (uint64_t*)p; p += ALIGN;
-    w->d_stage = (float*)p; p += stage_bytes;
-    w->d_wg_parts = (uint64_t*)p; p += wg_parts_bytes - ALIGN;
-    w->d_ticket = (uint32_t*)p; p += ALIGN;
+    w->d_stage = p; p += stage_bytes;
     w->cks_args.parts = w->d_parts;
     w->cks_args.part_cnt = w->d_parts + (uint64_t)w->cks_args.n_cks * w->part_stride;
     w->cks_args.part_stride = w->part_stride;
@@ -242,7 +195,7 @@ int seal_impl(ggrs_world* w) {
     memset((void*)w->h_done, 0, ggrs_world::SPIN_TAGS * 8); w->spin_seq = 0; w->spin_n = 0;
     HIPCHK(w, hipHostMalloc((void**)&w->h_stage, stage_bytes, hipHostMallocMapped));       // pinned AND device-mapped: a fused spawn's payload is read by the group's launch straight from here
     HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_hstage, w->h_stage, 0));
-    if (w->jit_fn && w->knobs.host_fold_max_wgs) {
+    if (w->jit_fn) {
         w->rows_cap = 1u << 20;                                    // 8 MiB of partial rows between two collects
         HIPCHK(w, hipHostMalloc((void**)&w->h_rows, w->rows_cap * 8, hipHostMallocMapped));
         HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_rows, w->h_rows, 0));
@@ -255,25 +208,19 @@ int seal_impl(ggrs_world* w) {
         HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
         for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
         HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
-        HIPCHK(w, hipMemsetAsync(w->d_ticket, 0, ALIGN, w->stream));      // tick_fold's arrival counter: zero between launches
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
-        // k_gen_finalize's row buffer [saves][n_cks + 1][one row per 256-slot workgroup]; then, for the group fold (kernel_gen.hpp): one
-        // accumulator row [saves x (n_cks + 1)] per 64 workgroups of the largest grid (zero between launches), the groups' finished rows when
-        // they stay on the device, and one ticket per group (zero between launches)
+        // k_gen_finalize's row buffer [saves][n_cks + 1][one row per 256-slot workgroup]; then the two row buffers of the fold-forward path
+        // ([cap_saves][n_cks + 1][one row per workgroup] each, used alternately by consecutive launches)
         const size_t bytes = align_up((size_t)w->gen_parts_saves * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8, ALIGN);
-        w->gf_groups_max = (w->gen_part_stride + 8 + 63) / 64 + 1;
-        const size_t acc_bytes = align_up((size_t)w->gf_groups_max * MAX_TICK_SAVES * (w->cks_args.n_cks + 1) * 8, ALIGN);
-        const size_t ticket_bytes = align_up((size_t)w->gf_groups_max * 4, ALIGN);
-        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes + 2 * acc_bytes + ticket_bytes));
+        const size_t ff_bytes = align_up((size_t)MAX_TICK_SAVES * (w->cks_args.n_cks + 1) * w->gen_part_stride * 8, ALIGN);
+        HIPCHK(w, hipMalloc((void**)&w->d_gen_parts, bytes + 2 * ff_bytes));
         uint8_t* const base = reinterpret_cast<uint8_t*>(w->d_gen_parts);
-        w->d_gf_acc = reinterpret_cast<uint64_t*>(base + bytes);
-        w->d_gf_out = reinterpret_cast<uint64_t*>(base + bytes + acc_bytes);
-        w->d_gf_tickets = reinterpret_cast<uint32_t*>(base + bytes + 2 * acc_bytes);
-        if (w->knobs.debug_poison) { HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes, w->stream)); HIPCHK(w, hipMemsetAsync(w->d_gf_out, 0xA5, acc_bytes, w->stream)); }
-        HIPCHK(w, hipMemsetAsync(w->d_gf_acc, 0, acc_bytes, w->stream));
-        HIPCHK(w, hipMemsetAsync(w->d_gf_tickets, 0, ticket_bytes, w->stream));
+        w->d_ff_rows[0] = reinterpret_cast<uint64_t*>(base + bytes);
+        w->d_ff_rows[1] = reinterpret_cast<uint64_t*>(base + bytes + ff_bytes);
+        w->ff_cur = 0; w->ff_pending = ggrs_world::FfPending{};
+        if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + 2 * ff_bytes, w->stream));
     }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;

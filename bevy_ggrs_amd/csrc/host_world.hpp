@@ -17,6 +17,10 @@ struct Comp {
     std::vector<uint8_t> defaults;
     uint32_t col_base = 0;               // index of its first column
     bool no_rollback = false;            // GGRS_COMP_NO_ROLLBACK: lives in the side region, outside every snapshot
+    // ggrs_hip_register_component_strategy (strategy.rs:22-40): snapshots hold Strategy::Stored -- s_n_words words of s_word_bytes, in columns of
+    // their own (scol_base..) that only ring slots use -- and the user's ggrs_store / ggrs_load (HIP C++) convert at Save / Load
+    uint32_t s_word_bytes = 0, s_n_words = 0, scol_base = 0;
+    std::string strat_source;
 };
 
 // Row versions.  Every word column of a block carries the version of the bytes it holds; a version names one state of a
@@ -38,102 +42,54 @@ struct Block {                           // one packed state block in the arena
 struct EventPair { hipEvent_t a, b; uint32_t cls; };
 struct JitEntry;                         // kernel_gen.hpp: a cached generated module
 
-// Every environment variable the library reads, in ONE place, read ONCE per world at creation.  They are A/B and debugging
-// aids; none of them changes a result, and tests/test_gpu_knobs.py runs a bit-exact parity case under each of them.
+// Every environment variable the library reads, in ONE place, read ONCE per world at creation (INTEGRATION.md lists them with the
+// measurement that keeps each).  None of them changes a result; tests/test_gpu_knobs.py runs a bit-exact parity case under each.
 // (GGRS_HIP_TRACE / GGRS_HIP_ROCTX, the two tracing switches, and GGRS_RCCL_LIB are process-wide.)
+// Round 5 removed every A/B knob whose losing side is on record in profiles/ (persistent form, group fold, contiguous arena + parking, nt-load /
+// first-Save-cache / lane-fold / depth-parallel / presence-version / dead-group / event-on-kernel switches): their winning side is the fixed policy.
 struct Knobs {
-    bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel (what a deployment without libhiprtc.so gets): one launch per request
-    // The persistent form (one launch, in-kernel fold) is correct at every size but measured slower than the per-tile grid + its
-    // k_gen_finalize launch (1 M: 91.8 vs 87.5 us per tick, 4 M: 308 vs 279): opt-in.
-    uint64_t jit_persist_min_slots = 0;              // GGRS_JIT_PERSIST_MIN_SLOTS    generated kernel: groups covering more slots use its persistent form (in-kernel fold); 0 (default): never
-    int jit_persist_oversub = 1;   // GGRS_JIT_PERSIST_OVERSUB=n  persistent form: grid = up to n x the workgroups the device holds at once
-    int host_fold_max_wgs = 16384;   // GGRS_HOST_FOLD_MAX_WGS=n   generated kernel: groups of up to n workgroups leave their partial rows in pinned memory and the host folds them (0: always k_gen_finalize)
-    bool host_fold_explicit = false;   //                            (set: the limit also applies to blocking calls, which otherwise keep the device fold above 1024 workgroups)
-    int group_fold_min_wgs = 12288; // GGRS_GROUP_FOLD_MIN_WGS=n  generated kernel, per-tile grid: launches of MORE than n workgroups combine their partial rows on the chip,
-                                   //                       64 workgroups per accumulator row and ticket (agent-scope atomics by wave 0; the group's last arriver hands the row on):
-                                   //                       the host -- or k_gen_finalize -- reads 1/64 of the rows, blocking calls included (0: never).  The in-launch hand-off
-                                   //                       costs a constant 3-4.5 us at the end of the launch (profiles/r04b): it pays from ~3 M slots up, where the host's fold of
-                                   //                       one row per workgroup (3 MB per tick at 4 M) no longer hides behind the next tick's kernel
-    uint64_t stage_floats = 1u << 20;   // GGRS_STAGE_FLOATS=n   floats of the spawn-payload staging ring (default 1 M = 4 MB; tests shrink it to exercise the wrap)
-    int jit_nt_loads = -1;         // GGRS_JIT_NT_LOADS=0|1 generated kernel: never / always load the source block non-temporally; default (-1): when the block is not expected in the
-                                   //                       caches -- an HBM-sized rollback group none of whose Saves is kept in the L2 for the next one (profiles/r04n: allhot 4 M -8 %,
-                                   //                       headline 4 M even; it costs 3 % where the loads DO hit, 1 M)
-    bool jit_fuse_spawn = true;    // GGRS_JIT_FUSE_SPAWN=0  a firing spawn system ends the request group (k_spawn_particles + mask edits as their own launches: rounds 1-3)
-    bool dead_groups = true;       // GGRS_DEAD_GROUPS=0    no dead-snapshot elimination / branch batching (every group stores everything)
-    int dp = 1;                    // GGRS_JIT_DP=0         generated kernel without depth-parallel roles; =2..9 A/B: that many outputs per role
-    uint64_t dp_max_slots = 40 * 1024;               // GGRS_JIT_DP_MAX_SLOTS  largest world that uses one output per role (x2: two, x6: three)
-    bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping)
-    int arena_contig = -1;         // GGRS_ARENA_CONTIG=0|1 physically contiguous arena for no / every world; default (-1): worlds created with GGRS_WORLD_CONTIG_ARENA
-    int arena_flush = 0;           // GGRS_ARENA_FLUSH=bits system-scope L2 write-back + invalidate on every XCD (experiment, profiles/r03fc): 1 before a contiguous
-                                   //                       arena is first used, 2 before a contiguous arena is freed, 4 before a paged arena is first used,
-                                   //                       8 a freed contiguous arena's pages are taken back by a paged allocation nobody uses
-    bool debug_arena = false;      // GGRS_DEBUG_ARENA=1    print the arena placement
+    bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel (what a deployment without libhiprtc.so AND without shipped code objects gets): one launch per request
+    int fold_forward_min_wgs = 256; // GGRS_FOLD_FORWARD_MIN_WGS=n  request groups of MORE than n workgroups leave their per-workgroup checksum rows in device memory and the NEXT launch on the
+                                   //                       stream folds them (fold-forward, host_groups.hpp); up to n the rows go to pinned memory and the host XORs them at collect time
+                                   //                       (0: always fold-forward; 1000000: never).  1 M: the host's 30 us fold per tick sat on the collect -> enqueue path (profiles/r05*)
+    uint64_t stage_bytes = 8u << 20; // GGRS_STAGE_BYTES=n   bytes of the spawn-payload staging ring (default 8 MiB: one spawn of 1 M particles = 2 x 1 M floats fits; tests shrink it to exercise the wrap)
+    bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping): the reference's clone-everything cost, measured as bench_fullcopy
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
-    int jit_lane_fold = -1;        // GGRS_JIT_LANE_FOLD=0|1 generated kernel, per-tile form: checksum fold through per-lane LDS rows never / always (default: worlds
-                                   //                       of >= 96 k slots, kernel_gen.hpp jit_lane_fold)
     int jit_specialise_after = 16; // GGRS_JIT_SPECIALISE_AFTER=n  the n-th group of one shape starts the build of a kernel specialised for it (counted
                                    //                       per shape, 16 shapes per world; 0: never); GGRS_JIT_SPECIALISE_SYNC=1 builds on the calling thread (tests)
     bool jit_specialise_sync = false;
-    int jit_spec_shapes = 16;      // GGRS_JIT_SPEC_SHAPES=n    group shapes counted (and specialised kernels kept) per world, 1..64; the least recently used one makes room
-    int spin_wait_us = 200;        // GGRS_SPIN_WAIT_US=0        blocking calls whose last GPU operation is k_gen_finalize poll the tags that kernel leaves in pinned memory for up to this long
-                                   //                            before falling back to hipStreamSynchronize (0: always the stream wait)
-    bool event_on_kernel = true;   // GGRS_EVENT_ON_KERNEL=0     an enqueued list ends with a marker packet (hipEventRecord) even when its last GPU operation is the group kernel
-    bool presence_versions = true; // GGRS_PRESENCE_VERSIONS=0  presence masks are stored with every Save / Load even when the destination holds them already
-    bool jit_cache_first_save = true;   // GGRS_JIT_CACHE_FIRST_SAVE=0  generated kernel: nt stores for every Save of an HBM-sized rollback group (default: the first Save,
-                                        //                       the snapshot the next rollback loads, goes through the L2)
-    uint64_t jit_cached_save_max_bytes = 80ull << 20;   // GGRS_JIT_CACHED_SAVE_MAX_MB=n  ... while that Save's rows are at most this many MiB (default 80: beyond, the rows no longer
-                                        //                       survive in the caches until the next launch reads them, profiles/r03n)
-    bool arena_park = true;        // GGRS_ARENA_PARK=0     hipFree contiguous arenas when their world closes (the hazard above; experiments only)
+    int spin_wait_us = 200;        // GGRS_SPIN_WAIT_US=n        how long a waiting call polls completion tags in pinned memory (k_gen_finalize's for blocking calls, the fold-forward
+                                   //                            role's for collect) before it falls back to hipStreamSynchronize (0: always the stream wait)
     int debug_jit = 0;             // GGRS_DEBUG_JIT=1      say why a generated kernel was rejected; =2 also print its source
     std::string jit_cache_dir;     // GGRS_JIT_CACHE_DIR    code objects of generated kernels on disk ("" = ~/.cache/ggrs_hip; "0": no disk cache)
+    std::string aot_dir;           // GGRS_AOT_DIR          shipped code objects (`make -C bevy_ggrs_amd/csrc aot`): looked up by source hash before the run-time compiler is asked
+                                   //                       ("" = <directory of libggrs_hip.so>/aot; "0": none)
+    bool no_hiprtc = false;        // GGRS_NO_HIPRTC=1      behave as if libhiprtc.so were absent (tests of the shipped-code-object path)
     static Knobs from_env() {
         Knobs k;
         auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
+        k.fold_forward_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_FOLD_FORWARD_MIN_WGS", 256)));
+        k.stage_bytes = (uint64_t)std::max<long long>(4096, std::min<long long>(1ll << 30, num("GGRS_STAGE_BYTES", 8 << 20))) & ~15ull;
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
-        k.jit_persist_min_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_PERSIST_MIN_SLOTS", 0));
-        k.jit_persist_oversub = (int)std::max<long long>(1, std::min<long long>(64, num("GGRS_JIT_PERSIST_OVERSUB", 1)));
-        k.host_fold_max_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 20, num("GGRS_HOST_FOLD_MAX_WGS", 16384)));
-        k.host_fold_explicit = getenv("GGRS_HOST_FOLD_MAX_WGS") != nullptr;
-        k.group_fold_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_GROUP_FOLD_MIN_WGS", 12288)));
-        k.stage_floats = (uint64_t)std::max<long long>(1024, std::min<long long>(1ll << 28, num("GGRS_STAGE_FLOATS", 1 << 20)));
-        k.jit_nt_loads = (int)num("GGRS_JIT_NT_LOADS", -1);
-        k.jit_fuse_spawn = num("GGRS_JIT_FUSE_SPAWN", 1) != 0;
-        k.dead_groups = num("GGRS_DEAD_GROUPS", 1) != 0;
-        k.dp = (int)std::min<long long>(9, std::max<long long>(0, num("GGRS_JIT_DP", 1)));
-        k.dp_max_slots = (uint64_t)std::max<long long>(0, num("GGRS_JIT_DP_MAX_SLOTS", 40 * 1024));
-        k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
-        k.arena_contig = (int)std::min<long long>(2, std::max<long long>(-1, num("GGRS_ARENA_CONTIG", -1)));
-        k.arena_flush = (int)num("GGRS_ARENA_FLUSH", 0);
-        k.jit_lane_fold = (int)num("GGRS_JIT_LANE_FOLD", -1);
         k.jit_specialise_after = (int)num("GGRS_JIT_SPECIALISE_AFTER", 16);
         k.jit_specialise_sync = num("GGRS_JIT_SPECIALISE_SYNC", 0) != 0;
-        k.jit_spec_shapes = (int)std::min<long long>(64, std::max<long long>(1, num("GGRS_JIT_SPEC_SHAPES", 16)));
-        k.event_on_kernel = num("GGRS_EVENT_ON_KERNEL", 1) != 0;
         k.spin_wait_us = (int)num("GGRS_SPIN_WAIT_US", 200);
-        k.presence_versions = num("GGRS_PRESENCE_VERSIONS", 1) != 0;
-        k.jit_cache_first_save = num("GGRS_JIT_CACHE_FIRST_SAVE", 1) != 0;
-        k.jit_cached_save_max_bytes = (uint64_t)std::max<long long>(0, num("GGRS_JIT_CACHED_SAVE_MAX_MB", 80)) << 20;
-        k.arena_park = num("GGRS_ARENA_PARK", 1) != 0;
-        k.debug_arena = num("GGRS_DEBUG_ARENA", 0) != 0;
         k.debug_poison = num("GGRS_DEBUG_POISON", 0) != 0;
         k.debug_jit = (int)num("GGRS_DEBUG_JIT", 0);
+        k.no_hiprtc = num("GGRS_NO_HIPRTC", 0) != 0;
         if (const char* v = getenv("GGRS_JIT_CACHE_DIR")) k.jit_cache_dir = v;
+        if (const char* v = getenv("GGRS_AOT_DIR")) k.aot_dir = v;
         return k;
     }
 };
+// fixed policies that used to be knobs (the measurements are cited where each is applied)
+constexpr uint64_t JIT_DP_MAX_SLOTS = 40 * 1024;            // depth-parallel roles: one output per role up to here, two up to x2, three up to x6 (profiles/r02dp, r02jit)
+constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20; // the group's first Save goes through the L2 while its rows are at most this (profiles/r03n, r04c)
+constexpr int JIT_SPEC_SHAPES = 16;                         // group shapes counted (and specialised kernels kept) per world
+constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;       // blocking calls: larger groups are folded by k_gen_finalize (the host's fold would be serial with the kernel)
 
 }  // namespace
-
-static std::atomic<int> g_paged_arena_frees{0};   // paged (cached) arenas this process has handed back: see GGRS_WORLD_CONTIG_ARENA
-// Contiguous arenas are never handed back while the process lives (profiles/r03fc): after hipFree of a hipDeviceMallocContiguous
-// allocation, kernels of LATER worlds on this device stop being ordered / made coherent with each other by the runtime's direct
-// dispatch (a paged UNFUSED world created next fails 6 of 6 times; HIP_LAUNCH_BLOCKING=1 or AMD_DIRECT_DISPATCH=0 hide it; L2
-// write-back / invalidate kernels, poisoning, keeping the pages away from later allocations do not).  A closed world parks its
-// contiguous arena here and the next world that wants one takes the smallest parked arena that fits.
-struct ParkedArena { uint8_t* ptr; uint64_t bytes; int device; };
-static std::mutex g_parked_mu;
-static std::vector<ParkedArena> g_parked;
 
 // What a specialised request-group kernel hard-codes: the op sequence and every wave-uniform mask of the group.
 struct JitSig {
@@ -155,13 +111,23 @@ struct JitSpec {
 struct JitSpecSlot { JitSig sig; uint32_t seen = 0; uint64_t last_use = 0; JitSpec* spec = nullptr; };
 constexpr uint32_t JIT_SPEC_MAX_BUILDS = 64;               // per world: a session whose shapes never settle stops asking for kernels
 
+namespace { struct JitLayout; }          // kernel_gen.hpp: the device-side layout of this world's argument block
+
+// ggrs_hip_host_timeline: where the HOST spends a tick (microseconds, summed over the calls since it was enabled)
+struct HostTimeline {
+    bool on = false;
+    uint64_t n_enqueue = 0, n_collect = 0, n_launches = 0;
+    double enqueue_us = 0, validate_us = 0, launch_us = 0, collect_us = 0, wait_us = 0, tag_wait_us = 0, fold_us = 0;
+};
+inline double tl_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct ggrs_world {
     // ---- configuration
     int device = 0;
     uint64_t capacity = 0, cap_pad = 0;
     uint32_t max_depth = 0, flags = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
-    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false, arena_contiguous = false;
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0; bool own_arena = false;
 
     std::vector<Comp> comps;
     std::vector<ggrs_system_desc> systems;
@@ -172,19 +138,29 @@ struct ggrs_world {
         uint32_t n_pres = 0, pres_comp[GGRS_CUSTOM_MAX_BINDINGS] = {};
     };
     std::vector<Custom> customs;
-    // the request-group kernel generated for this world (kernel_gen.hpp): one workgroup per 256 slots (small worlds: roles,
-    // batches, host-side fold) and its persistent form (HBM-sized worlds: grid = what the chip holds, checksum fold in-kernel)
-    hipFunction_t jit_fn = nullptr, jit_fn_persist = nullptr;
-    // the per-tile form specialised for the group shapes the session keeps sending (kernel_gen.hpp jit_specialise): its text, the
+    struct SpawnSys {                    // GGRS_SYS_SPAWN_CUSTOM: a user-written spawner (ggrs_hip_add_spawn_system; systems[i].comp[0] indexes this)
+        std::string name, source;
+        uint32_t n_bind = 0, comp[GGRS_CUSTOM_MAX_BINDINGS] = {}, word[GGRS_CUSTOM_MAX_BINDINGS] = {};
+        uint64_t bundle_mask = 0; uint32_t payload_stride = 0;
+    };
+    std::vector<SpawnSys> spawn_customs;
+    uint32_t input_bytes = 1, max_players = GGRS_MAX_PLAYERS;   // ggrs_hip_set_input_layout: bytes of one player's T::Input, players of the session
+    // the request-group kernel generated for this world (kernel_gen.hpp): one workgroup per 256 slots (roles, batches, fold-forward)
+    hipFunction_t jit_fn = nullptr;
+    // the kernel specialised for the group shapes the session keeps sending (kernel_gen.hpp jit_specialise): its text, the
     // shapes being counted and their kernels (built on a worker thread, one at a time; used once `state` says ready)
     std::string jit_src; std::vector<JitSpecSlot> spec_tab; uint64_t spec_clock = 0; uint32_t spec_builds = 0; int spec_last_slot = -1;
-    JitEntry* jit_entry = nullptr; JitEntry* jit_entry_persist = nullptr;   // handed back to the module cache when the world is destroyed
-    uint32_t jit_persist_wgs = 0, jit_persist_tpb = 1024;   // workgroups of the persistent form the device holds at once, and their size
+    int spec_shapes = JIT_SPEC_SHAPES;   // places in spec_tab (a test hook shrinks it to exercise the eviction: ggrs_dbg_set_spec_shapes)
+    JitEntry* jit_entry = nullptr;       // handed back to the module cache when the world is destroyed
+    JitLayout* jl = nullptr;             // device-side layout of the argument block (owned)
+    std::vector<unsigned char> jit_argbuf;   // the packed argument block of the launch being issued
     std::string jit_status = "not attempted";   // why the world has / has not a generated kernel (ggrs_hip_world_kernel_info)
+    std::string jit_origin;              // where the generic kernel's code object came from: "hiprtc", "disk cache", "shipped (aot)"
     bool jit_marks = false;              // the generated kernel keeps the RollbackDespawned markers (a system may defer a despawn)
     bool jit_reads_inputs = false;       // a system reads PlayerInputs (BOX_MOVE, custom): branches with different inputs differ
     int jit_box_sys = -1;                // index of a BOX_MOVE system (its FRICTION.powf(dt) is evaluated per step on the host)
-    int jit_spawn_sys = -1;              // index of the PARTICLES_SPAWN system the generated kernel runs inside request groups (kernel_gen.hpp jit_fused_spawn_system); -1: a firing spawn ends the group
+    int jit_spawn_sys = -1;              // index of the spawn system the generated kernel runs inside request groups (kernel_gen.hpp jit_fused_spawn_system); -1: a firing spawn ends the group
+    uint32_t cap_saves = MAX_TICK_SAVES, cap_steps = MAX_TICK_STEPS;   // a request group of this world ends at this many Saves / steps (kernel_gen.hpp jit_layout)
     uint32_t gen_parts_saves = 0;        // Save rows of d_gen_parts (room for a batch of checksum-only groups in small worlds)
     bool layout_only = false;            // GGRS_WORLD_LAYOUT_ONLY: no device behind this world
     bool sealed = false;
@@ -198,12 +174,14 @@ struct ggrs_world {
     uint64_t side_off = 0, side_bytes = 0;
     DespawnMarks marks{};                // disabled mask + despawned-frame column (despawn.rs:45-46)
     bool has_nr = false;                 // any GGRS_COMP_NO_ROLLBACK component
+    bool has_strategy = false;           // some component's snapshots hold Strategy::Stored (only the generated kernel can serve the world)
     bool marks_possible = false;         // a RollbackDespawned marker may exist in the live world
     int32_t dc_local = 0;                // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
     uint64_t state_bytes = 0, off_alive = 0;
-    std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0
+    std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0 (component words first, then the Stored words of strategy components)
     std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
     std::vector<uint8_t> col_rb;                   // column is part of a rollback component (snapshotted)
+    uint32_t n_tcols = 0;                          // columns of component words (the row-version masks cover exactly these)
     uint32_t ts = 0;                               // tile stride of the rollback word columns: bytes of all their words x 8192 slots
     CopyPlan plan{};                               // every mask + every row (rows carry their column index)
     std::vector<uint32_t> row_col;                 // plan.row[r] belongs to column row_col[r]
@@ -227,10 +205,11 @@ struct ggrs_world {
     uint64_t* d_done = nullptr; volatile uint64_t* h_done = nullptr; uint64_t spin_seq = 0; uint32_t spin_n = 0; uint64_t spin_hits = 0, spin_misses = 0;
     UnitDesc* d_units = nullptr;
     uint64_t* d_maskoffs = nullptr;      // scratch for k_set_mask_range
-    // spawn payloads: a ring of floats in pinned, device-mapped memory (h_stage; d_hstage = the same bytes as the device sees them: fused spawns read
+    // spawn payloads: a ring of bytes in pinned, device-mapped memory (h_stage; d_hstage = the same bytes as the device sees them: fused spawns read
     // them zero-copy) with a device twin (d_stage) for the unfused spawn kernel.  [stage_tail, stage_used) (mod wrap) is what launches of
-    // uncollected batches may still read; a collected batch frees everything up to its stage_end
-    float* d_stage = nullptr; float* h_stage = nullptr; float* d_hstage = nullptr; uint64_t stage_floats = 0, stage_used = 0, stage_tail = 0;
+    // uncollected batches may still read; a collected batch frees everything up to its stage_end.  stage_gen counts resets: whoever remembers
+    // an offset into the ring (a request list's payload dedup) forgets it when the generation changes
+    uint8_t* d_stage = nullptr; uint8_t* h_stage = nullptr; uint8_t* d_hstage = nullptr; uint64_t stage_bytes = 0, stage_used = 0, stage_tail = 0, stage_gen = 0;
 
     // ---- checksum specs (device view)
     std::vector<uint32_t> cks_comp;      // checksummed component ids in id order
@@ -241,11 +220,14 @@ struct ggrs_world {
     int f_T = -1, f_V = -1, f_L = -1, f_spawn = -1; uint32_t f_tw = 0, f_vw = 0, f_lw = 0;
     bool f_cksT = false, f_cksV = false;
     float f_g[3] = {0, 0, 0};
-    uint64_t* d_wg_parts = nullptr; uint32_t* d_ticket = nullptr; int n_cu = 256;
-    uint32_t wg_parts_rows = 0;          // rows (workgroups) d_wg_parts has room for: every grid that uses tick_fold is clamped to it
+    int n_cu = 256;
     uint64_t* d_gen_parts = nullptr; uint32_t gen_part_stride = 0;   // generated kernel: [saves][n_cks + 1][one row per 256-slot workgroup]
-    uint32_t* d_gf_tickets = nullptr; uint64_t* d_gf_acc = nullptr; uint64_t* d_gf_out = nullptr; uint32_t gf_groups_max = 0;   // group fold: ticket and accumulator row per 64 workgroups; the finished rows when they stay on the device
     bool gen_ok = false;                 // the generated kernel serves this world's request lists
+    // fold-forward (host_groups.hpp): two row buffers in device memory, used alternately by consecutive launches; what the LAST launch left in
+    // ff_rows[ff_cur] waits for the next launch (or k_ff_fold) to fold it into the pinned values + tags of the HostFold with id ff_pending_id
+    uint64_t* d_ff_rows[2] = {nullptr, nullptr}; uint32_t ff_cur = 0;
+    struct FfPending { bool valid = false; uint64_t id = 0, seq = 0; uint32_t buf = 0, nvals = 0, g = 0, stride = 0; uint64_t out_off = 0; } ff_pending;
+    uint64_t ff_next_id = 1, ff_done_id = 0, ff_seq = 0;    // ids are handed out in launch order; every id <= ff_done_id has a fold queued on the stream
 
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
@@ -261,10 +243,11 @@ struct ggrs_world {
 
     // ---- asynchronous request batches (ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums)
     struct PendingBatch { hipEvent_t ev; uint32_t first, count; std::vector<uint64_t> host; uint32_t n_folds = 0; uint64_t stage_end = 0; };
-    // Host-side checksum fold of small worlds (generated kernel): its workgroups write their partial rows straight into pinned,
-    // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected -- a
-    // second launch (k_gen_finalize + its dependent-launch gap, ~7 us) costs more than that for worlds of a few hundred workgroups.
-    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off; uint64_t save_len[16]; };   // save_len[k]: RollbackOrdered::len at Save k (a fused spawn grows it inside a group)
+    // Host-side end of the checksum fold (generated kernel).  Small groups: the workgroups write their partial rows straight into pinned,
+    // device-mapped host memory and the HOST finishes each Save (XOR of g rows + three hashes) when the batch is collected.  Fold-forward
+    // groups (ff_id != 0): g == 1 -- the rows were folded on the device, the pinned ring holds one value per (Save, part) followed by one tag
+    // each; collect waits for the tags (ff_seq) before it hashes.
+    struct HostFold { uint32_t res_slot, n_saves, g, n_cks, members; uint64_t rows_off; uint64_t save_len[16]; uint64_t ff_id, ff_seq; };   // save_len[k]: RollbackOrdered::len at Save k (a fused spawn grows it inside a group)
     std::deque<HostFold> folds;          // in submission order; a PendingBatch owns the next n_folds of them
     uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
     hipEvent_t batch_ev = nullptr; bool batch_ev_attached = false;   // enqueue: the batch's event, offered to the list's last kernel launch (launch_jit)
@@ -281,6 +264,7 @@ struct ggrs_world {
     uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
     uint64_t prof_bytes[GGRS_KERNEL_CLASSES] = {};            // algorithmic bytes the launches of a class were asked to move (rows x their extent)
     std::vector<float> prof_launch_us[GGRS_KERNEL_CLASSES];   // every launch since enable, in submission order (ggrs_hip_profile_read_launches)
+    HostTimeline tl;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -339,7 +323,7 @@ inline uint32_t pmask_differs(const ggrs_world* w, const Block& dst, const std::
     uint32_t m = 0;
     for (uint32_t c = 0; c < w->comps.size(); ++c) {
         const uint32_t i = ver_presence(w, c);
-        if (!w->knobs.row_versions || !w->knobs.presence_versions || dst.ver[i] == VER_NONE || want[i] == VER_NONE || dst.ver[i] != want[i]) m |= 1u << c;
+        if (!w->knobs.row_versions || dst.ver[i] == VER_NONE || want[i] == VER_NONE || dst.ver[i] != want[i]) m |= 1u << c;
     }
     return m;
 }
@@ -352,7 +336,11 @@ void build_layout(ggrs_world* w) {
     w->off_present.assign(w->comps.size(), 0); w->col_off.clear(); w->col_wb.clear();
     w->has_nr = false;
     uint32_t ncols = 0;
+    w->has_strategy = false;
     for (auto& c : w->comps) { c.col_base = ncols; ncols += c.n_words; w->has_nr |= c.no_rollback; }
+    w->n_tcols = ncols;
+    // the Stored words of components under a Strategy: columns of their own behind the component words (ring slots use them, the live block does not)
+    for (auto& c : w->comps) if (c.s_n_words && !c.no_rollback) { c.scol_base = ncols; ncols += c.s_n_words; w->has_strategy = true; }
     w->col_off.assign(ncols, 0); w->col_wb.assign(ncols, 4); w->col_rb.assign(ncols, 0);
     for (size_t c = 0; c < w->comps.size(); ++c) if (!w->comps[c].no_rollback) { w->off_present[c] = off; off += mask_bytes; }
     // rollback word columns, TILE-MAJOR: tile t of every column is contiguous (ts bytes per tile).  Inside a
@@ -379,27 +367,32 @@ void build_layout(ggrs_world* w) {
             const ggrs_world::Custom& c = w->customs[sd.comp[0]];
             for (uint32_t b = 0; b < c.n_bind; ++b) mark(c.comp[b], c.word[b], 1, true);      // a bound word may be written
         } break;
-        default: break;     // PARTICLES_SPAWN appends rows through run_spawn_systems, which versions its bundle itself
+        default: break;     // spawn systems append rows: whoever runs them versions the bundle (run_spawn_systems / the fused path in host_groups.hpp)
         }
     }
     uint64_t tcol = 0;
     for (int pass = 0; pass < 4; ++pass)      // 0: hot words (any width >= 4), 1: other 4-/8-byte words, 2: 2-byte words, 3: 1-byte words
         for (auto& c : w->comps) {
-            for (uint32_t k = 0; k < c.n_words; ++k) {
-                const uint32_t col = c.col_base + k;
-                w->col_wb[col] = c.word_bytes; w->col_rb[col] = !c.no_rollback;
+            for (uint32_t k = 0; k < c.n_words + c.s_n_words; ++k) {
+                const bool stored = k >= c.n_words;
+                if (stored && c.no_rollback) continue;
+                const uint32_t col = stored ? c.scol_base + (k - c.n_words) : c.col_base + k;
+                const uint32_t wb = stored ? c.s_word_bytes : c.word_bytes;
+                w->col_wb[col] = wb; w->col_rb[col] = !c.no_rollback && !stored;
                 if (c.no_rollback) continue;
-                const bool wide = c.word_bytes >= 4;
-                const int want = (wide && hot[col]) ? 0 : (wide ? 1 : (c.word_bytes == 2 ? 2 : 3));
+                const bool wide = wb >= 4;
+                const int want = (wide && hot[col]) ? 0 : (wide ? 1 : (wb == 2 ? 2 : 3));
                 if (want != pass) continue;
                 w->col_off[col] = tcol;           // offset inside a tile for now
-                tcol += (uint64_t)LAYOUT_TILE * c.word_bytes;
+                tcol += (uint64_t)LAYOUT_TILE * wb;
             }
         }
     w->ts = (uint32_t)tcol;
     const uint64_t cols_base = align_up(off, 4096);
-    for (auto& c : w->comps) if (!c.no_rollback)
+    for (auto& c : w->comps) if (!c.no_rollback) {
         for (uint32_t k = 0; k < c.n_words; ++k) { w->col_off[c.col_base + k] += cols_base; w->col_ts[c.col_base + k] = w->ts; }
+        for (uint32_t k = 0; k < c.s_n_words; ++k) { w->col_off[c.scol_base + k] += cols_base; w->col_ts[c.scol_base + k] = w->ts; }
+    }
     off = cols_base + (w->cap_pad / LAYOUT_TILE) * (uint64_t)w->ts;
     w->state_bytes = align_up(off, 4096);
     // ---- live-only side region, placed right behind the ring blocks

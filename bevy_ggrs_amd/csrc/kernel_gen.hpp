@@ -7,30 +7,51 @@
 #pragma once
 
 // ---- GGRS_SYS_CUSTOM: user-written per-entity systems, compiled with hiprtc for gfx950 ----------------------------
-// The argument block of the generated kernel.  The SAME text is compiled on the host (below) and pasted into the
+// The argument block of the per-request custom kernel.  The SAME text is compiled on the host (below) and pasted into the
 // generated device source, and the device source static_asserts the host's sizeof: the two cannot drift.
+// fr.in: PlayerInputs of the frame as the library lays them out for the device -- n_inputs x input_bytes bytes of T::Input, then, at
+// max_players x input_bytes, one InputStatus byte per player (src/lib.rs:98, schedule_systems.rs:262-265).
 #define GGRS_CUSTOM_ABI_TEXT \
     "typedef unsigned long long ggrs_u64; typedef unsigned int ggrs_u32;\n" \
-    "struct GgrsFrame { float dt; int frame; ggrs_u32 n_inputs; unsigned char input[16]; float fparam[4]; long long iparam[2]; };\n" \
+    "struct GgrsFrameRaw { float dt; int frame; ggrs_u32 n_inputs, input_bytes, status_off, pad; unsigned char in[272]; float fparam[4]; long long iparam[2]; };\n" \
     "struct GgrsCustomArgs {\n" \
     "    unsigned char* state;\n" \
     "    ggrs_u64 off_alive, off_disabled, off_dframe, len_pad64;\n" \
     "    ggrs_u64 off_present[8], col_off[8];\n" \
     "    ggrs_u32 ts[8];\n" \
     "    int defer, pad;\n" \
-    "    GgrsFrame fr;\n" \
+    "    GgrsFrameRaw fr;\n" \
     "};\n"
 typedef unsigned long long ggrs_u64; typedef unsigned int ggrs_u32;
-struct GgrsFrame { float dt; int frame; ggrs_u32 n_inputs; unsigned char input[16]; float fparam[4]; long long iparam[2]; };
+struct GgrsFrameRaw { float dt; int frame; ggrs_u32 n_inputs, input_bytes, status_off, pad; unsigned char in[272]; float fparam[4]; long long iparam[2]; };
 struct GgrsCustomArgs {
     unsigned char* state;
     ggrs_u64 off_alive, off_disabled, off_dframe, len_pad64;
     ggrs_u64 off_present[8], col_off[8];
     ggrs_u32 ts[8];
     int defer, pad;
-    GgrsFrame fr;
+    GgrsFrameRaw fr;
 };
 static_assert(GGRS_CUSTOM_MAX_BINDINGS == 8, "GgrsCustomArgs is sized for 8 bindings");
+static_assert(sizeof(((GgrsFrameRaw*)nullptr)->in) == GGRS_MAX_PLAYERS * (16 + 1), "GgrsFrameRaw::in holds 16 players x (16 input bytes + 1 status byte)");
+
+// What a user-written system sees of the frame (include/ggrs_hip.h): Time<GgrsTime>, the frame number and PlayerInputs<T> -- the bytes
+// sit in LDS (a handle read from a component may index them), `f.input[h]` is the first byte of player h's input (the whole input of a
+// Config<Input = u8> session), input_u16/u32/u64 assemble wider inputs little-endian, input_status(h) is ggrs's InputStatus.
+#define GGRS_FRAME_TEXT \
+    "#define GGRS_INPUT_CONFIRMED 0\n#define GGRS_INPUT_PREDICTED 1\n#define GGRS_INPUT_DISCONNECTED 2\n" \
+    "struct GgrsInputs { const unsigned char* p; ggrs_u32 ib; __device__ unsigned char operator[](int h) const { return p[(ggrs_u32)h * ib]; } };\n" \
+    "struct GgrsFrame {\n" \
+    "    float dt; int frame; ggrs_u32 n_inputs, input_bytes;\n" \
+    "    GgrsInputs input; const unsigned char* status;\n" \
+    "    float fparam[4]; long long iparam[2];\n" \
+    "    __device__ const unsigned char* input_ptr(int h) const { return input.p + (ggrs_u32)h * input_bytes; }\n" \
+    "    __device__ unsigned char input_u8(int h) const { return input_ptr(h)[0]; }\n" \
+    "    __device__ unsigned short input_u16(int h) const { const unsigned char* q = input_ptr(h); return (unsigned short)(q[0] | (q[1] << 8)); }\n" \
+    "    __device__ ggrs_u32 input_u32(int h) const { const unsigned char* q = input_ptr(h); return (ggrs_u32)q[0] | ((ggrs_u32)q[1] << 8) | ((ggrs_u32)q[2] << 16) | ((ggrs_u32)q[3] << 24); }\n" \
+    "    __device__ ggrs_u64 input_u64(int h) const { const unsigned char* q = input_ptr(h); ggrs_u64 v = 0; for (int b = 0; b < 8; ++b) v |= (ggrs_u64)q[b] << (8 * b); return v; }\n" \
+    "    __device__ int input_status(int h) const { return status[h]; }\n" \
+    "};\n"
 
 struct Hiprtc {
     void* lib = nullptr; bool tried = false; std::string why;
@@ -68,6 +89,14 @@ void hiprtc_load(Hiprtc& r) {
     if (!ok) r.lib = nullptr;
 }
 
+// GGRS_NO_HIPRTC=1: a world that behaves as if libhiprtc.so were absent (what a deployment image without the ROCm compiler gets)
+Hiprtc& hiprtc_for(const ggrs_world* w) {
+    static Hiprtc none;
+    static std::once_flag once;
+    std::call_once(once, [] { none.tried = true; none.why = "the run-time compiler is treated as absent (GGRS_NO_HIPRTC=1)"; });
+    return (w && w->knobs.no_hiprtc) ? none : hiprtc();
+}
+
 // The entity view a custom system sees (include/ggrs_hip.h, ggrs_hip_add_custom_system) -- one text for the per-request
 // kernel of a custom system and for the generated request-group kernel.
 #define GGRS_ENTITY_TEXT \
@@ -89,7 +118,7 @@ void hiprtc_load(Hiprtc& r) {
 static std::mutex g_hiprtc_mu;
 int hiprtc_build(ggrs_world* w, const std::string& src, const char* what, const char* kernel, hipModule_t* mod, hipFunction_t* fn,
                  std::vector<char>* image_out = nullptr) {
-    Hiprtc& rtc = hiprtc();
+    Hiprtc& rtc = hiprtc_for(w);
     if (!rtc.lib) return w->fail(GGRS_E_HIP, "%s: %s", what, rtc.why.c_str());
     std::lock_guard<std::mutex> compile_lock(g_hiprtc_mu);
     hiprtcProgram prog = nullptr;
@@ -135,66 +164,159 @@ static const char kJitPrelude[] =
 #include "device_prelude.hpp"
 #undef GGRS_SHARED_CODE
     ;
-#define GGRS_JIT_ABI_TEXT \
-    "struct GgrsJitArgs {\n" \
-    "    const unsigned char* src; unsigned char* live;\n" \
-    "    unsigned char* save_dst[16]; int save_frame[16];\n" \
-    "    ggrs_u64 save_rows[16]; ggrs_u64 live_rows, load_rows;\n" \
-    "    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, nt_loads;\n" \
-    "    ggrs_u32 dt_bits[24]; ggrs_u32 aux_bits[24];\n" \
-    "    unsigned char inputs[24][16]; unsigned char n_inputs[24];\n" \
-    "    int step_frame[24]; int step_confirmed[24]; unsigned char step_flags[24];\n" \
-    "    ggrs_u64 op_bits; ggrs_u32 n_ops, n_saves, n_steps, src_is_live, skip_live, dp_s;\n" \
-    "    ggrs_u64 len;\n" \
-    "    ggrs_u64* parts; ggrs_u32 part_stride, nt;\n" \
-    "    ggrs_u32 n_units, cached_saves;\n" \
-    "    ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;\n" \
-    "    ggrs_u64* gf_rows; ggrs_u32* gf_tickets;\n" \
-    "    ggrs_u64 save_len[16];\n" \
-    "    const float* spawn_vx[24]; const float* spawn_vy[24]; ggrs_u64 spawn_first[24]; ggrs_u32 spawn_count[24];\n" \
-    "};\n"
+// ---- the argument block ---------------------------------------------------------------------------------------------------
+// HOST side: GgrsJitArgs below, every array at its maximum dimension -- what host_groups.hpp fills while it assembles a group.
+// DEVICE side: a struct of the same field names written FOR THE WORLD (jit_layout / jit_layout_text): only the fields this world's
+// kernel reads (no spawn arrays without a spawn system, no inputs unless a system reads PlayerInputs, no marker flags unless a system can
+// defer a despawn), arrays cut to the world's group caps (cap_saves / cap_steps, from max_depth) and the per-step input block cut to
+// max_players x (input_bytes + 1 status byte).  The launch packs the host struct into that layout (jit_pack): the stress_test world at
+// depth 8 sends 552 bytes per launch where the one-size-fits-all block of rounds 2-4 was 2.1 KB -- on this platform the launch call that
+// carries the batch's completion event costs 2.96 us with 64 B of arguments, 3.26 us with 512 B, 4.05 us with 2.1 KB
+// (scripts/ubench_launch, profiles/r05a).  Every field's offset is static_assert'ed in the generated text: host and device cannot drift.
+constexpr uint32_t JIT_MAX_INPUT_BYTES = 16;                                             // bytes of one player's T::Input (POD)
+constexpr uint32_t JIT_IN_MAX = GGRS_MAX_PLAYERS * (JIT_MAX_INPUT_BYTES + 1);            // per step: inputs, then one InputStatus byte per player
 struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
-    unsigned char* save_dst[16]; int save_frame[16];
-    ggrs_u64 save_rows[16]; ggrs_u64 live_rows, load_rows;   // row versions: bit c = column c is stored with that Save / with the live block / must be loaded at all
-    ggrs_u32 save_pmask[16]; ggrs_u32 live_pmask, nt_loads;   // the same for the presence masks: bit c = component c's mask is stored (the liveness mask always is);
-                                                              // nt_loads: the source block is not expected in the caches (an HBM-sized group whose predecessor cached no Save): its lines are dead after the load
-    ggrs_u32 dt_bits[24]; ggrs_u32 aux_bits[24];
-    unsigned char inputs[24][16]; unsigned char n_inputs[24];
-    int step_frame[24]; int step_confirmed[24]; unsigned char step_flags[24];
-    ggrs_u64 op_bits; ggrs_u32 n_ops, n_saves, n_steps, src_is_live, skip_live, dp_s;
-    ggrs_u64 len;
-    ggrs_u64* parts; ggrs_u32 part_stride, nt;       // nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
+    ggrs_u64* parts;                                 // this launch's partial rows: [saves x (n_cks + 1)][part_stride], one entry per workgroup
+    // FOLD-FORWARD (ff_blocks != 0): the first ff_blocks workgroups of this launch fold the partial rows the PREVIOUS launch of the stream left in
+    // device memory (ff_rows: [ff_nvals][ff_stride], ff_g entries each) -- one row per workgroup: XOR of a component's entity hashes, or the sum of
+    // the live counts -- and write the ff_nvals folded values, then one tag (ff_seq) per value, into pinned host memory (ff_out): the host finishes
+    // the Checksum(u128)s from 24 values instead of XOR-ing 750 KB of rows per tick at 1 M (host_groups.hpp, "fold-forward")
+    const ggrs_u64* ff_rows; ggrs_u64* ff_out; ggrs_u64 ff_seq;
+    ggrs_u64 live_rows, load_rows;                   // row versions: bit c = column c is stored with the live block / must be loaded at all
+    ggrs_u64 op_bits, len;
+    unsigned char* save_dst[16]; ggrs_u64 save_rows[16];   // bit c = column c is stored with that Save
+    // A spawn system that fires inside the group (particles.rs:258-270, or a user-written one: ggrs_hip_add_spawn_system): step j appends
+    // spawn_count[j] rows at slots [spawn_first[j], +count) -- RollbackOrdered's next indices -- from the staged payload, AFTER the step's other
+    // systems (Bevy applies Commands at the end of the schedule).  len therefore grows inside a group: save_len[k] is RollbackOrdered::len at
+    // Save k (Header::len of the snapshot, the second operand of the entity checksum), `len` the source block's.
+    ggrs_u64 save_len[16];
+    const unsigned char* spawn_payload[24]; ggrs_u64 spawn_first[24];
+    int save_frame[16]; ggrs_u32 save_pmask[16];     // presence masks: bit c = component c's mask is stored with that Save (the liveness mask always is)
+    ggrs_u32 live_pmask, nt_loads;                   // nt_loads: the source block is not expected in the caches (an HBM-sized group whose predecessor cached no Save): its lines are dead after the load
+    ggrs_u32 n_ops, n_saves, n_steps, src_is_live, skip_live, dp_s;
+    ggrs_u32 part_stride, nt;                        // nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
-    ggrs_u64* fold_wg_parts; ggrs_u32* fold_ticket; ggrs_u64* fold_out;   // persistent form: tick_fold's row buffer, ticket and result slots
-    // per-tile form, GROUP FOLD (non-null): every workgroup XORs / adds its partials into the accumulator row of its group of 64 workgroups
-    // (dispatch order) in device memory (gf_rows, [group][n_saves x (n_cks + 1)], zero between launches) and takes the group's ticket; the
-    // last arriver hands the row to `parts` (column = group): the consumer -- the host, or k_gen_finalize -- reads 1/64 of the rows
-    ggrs_u64* gf_rows; ggrs_u32* gf_tickets;
-    // A spawn system that fires inside the group (particles.rs:258-270; worlds with exactly one GGRS_SYS_PARTICLES_SPAWN): step j appends
-    // spawn_count[j] rows at slots [spawn_first[j], +count) -- RollbackOrdered's next indices -- with velocities from the staged payload, AFTER
-    // the step's other systems (Bevy applies Commands at the end of the schedule).  len therefore grows inside a group: save_len[k] is
-    // RollbackOrdered::len at Save k (Header::len of the snapshot, the second operand of the entity checksum), `len` the source block's.
-    ggrs_u64 save_len[16];
-    const float* spawn_vx[24]; const float* spawn_vy[24]; ggrs_u64 spawn_first[24]; ggrs_u32 spawn_count[24];
+    ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride;
+    ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
+    unsigned char step_flags[24], n_inputs[24];
+    unsigned char inputs[24][JIT_IN_MAX];            // per step: n_inputs x input_bytes bytes of PlayerInputs, then (at max_players x input_bytes) one InputStatus byte per player
 };
 static_assert(MAX_TICK_SAVES == 16 && MAX_TICK_STEPS == 24, "GgrsJitArgs is sized for 16 Saves / 24 steps per group");
 constexpr uint32_t JIT_MAX_UNITS = 64;       // 4-byte register units per slot the generated kernel may hold
 constexpr uint32_t JIT_MAX_COLS = 64;        // word columns (one bit each in the row-version masks)
-// The persistent form's workgroup: as many waves per SIMD as the world's register need allows.  Few, fat workgroups keep
-// tick_fold's row count (= tickets = rows the last arriver reads) small: 1024 threads x 2 per CU for up to 16 four-byte units per
-// slot (the stress_test: 15), 512-thread workgroups beyond (<= 80 / <= 128 VGPRs).
-struct JitPersistShape { int tpb, min_waves_per_simd; };
-inline JitPersistShape jit_persist_shape(uint32_t units) {
-    if (const char* v = getenv("GGRS_JIT_PERSIST_TPB")) {            // A/B: workgroup size of the persistent form (256 | 512 | 1024), 8 waves per SIMD
-        const int t = atoi(v);
-        if ((t == 256 || t == 512 || t == 1024) && units <= 16) return {t, 8};
+constexpr uint32_t JIT_KERNARG_BUDGET = 3584; // bytes: the device-side block stays under the 4 KiB kernarg segment whatever the input layout
+
+// One field of the argument block: where it sits in the host struct, and -- for this world -- whether the device struct has it and how many
+// elements.  `rows` > 0: a 2-D byte array (inputs[rows][row_dev] on the device, [rows][row_host] on the host).
+struct JitField { const char* type; const char* name; uint32_t elem; uint32_t host_off, host_count, dev_count; bool present; uint32_t dev_off, rows, row_host, row_dev; bool per_step; };
+struct JitLayout {
+    std::vector<JitField> f; uint32_t bytes = 0;
+    uint32_t cap_saves = MAX_TICK_SAVES, cap_steps = MAX_TICK_STEPS;    // a group of this world ends at this many Saves / steps
+    uint32_t in_stride = 0, in_bytes = 1, max_players = GGRS_MAX_PLAYERS;   // bytes of one step's input block on the device (0: no system reads PlayerInputs)
+};
+struct JitNeeds { bool spawn, inputs, marks, box; };
+JitNeeds jit_needs(const ggrs_world* w);
+// the device-side layout of this world's argument block: 8-byte fields first, then 4-byte, then bytes (no padding inside)
+JitLayout jit_layout(const ggrs_world* w) {
+    JitLayout L;
+    const JitNeeds need = jit_needs(w);
+    L.in_bytes = std::max(1u, w->input_bytes); L.max_players = std::max(1u, std::min<uint32_t>(w->max_players, GGRS_MAX_PLAYERS));
+    L.in_stride = need.inputs ? L.max_players * (L.in_bytes + 1) : 0;
+    L.cap_saves = std::min<uint32_t>(MAX_TICK_SAVES, std::max<uint32_t>(2, w->max_depth + 1));
+    L.cap_steps = std::min<uint32_t>(MAX_TICK_STEPS, std::max<uint32_t>(3, w->max_depth + 2));
+    auto add = [&](const char* type, const char* name, uint32_t elem, size_t off, uint32_t host_count, uint32_t dev_count, bool present) {
+        L.f.push_back(JitField{type, name, elem, (uint32_t)off, host_count, dev_count, present, 0, 0, 0, 0, false});
+    };
+    // (type text, field, element bytes, element count on the host, on the device, present)
+#define F1(type, name, present) add(type, #name, (uint32_t)sizeof(GgrsJitArgs::name), offsetof(GgrsJitArgs, name), 1, 1, present)
+#define FA(type, name, n_dev, present) add(type, #name, (uint32_t)sizeof(GgrsJitArgs::name[0]), offsetof(GgrsJitArgs, name), (uint32_t)(sizeof(GgrsJitArgs::name) / sizeof(GgrsJitArgs::name[0])), n_dev, present)
+#define FS(type, name, present) do { FA(type, name, T, present); L.f.back().per_step = true; } while (0)
+    for (int pass = 0; pass < 2; ++pass) {
+        // the step-dimensioned arrays need the step cap, which depends on what is left of the kernarg budget: pass 0 sizes everything else
+        L.f.clear();
+        const uint32_t T = L.cap_steps, S = L.cap_saves;
+        F1("const unsigned char*", src, true); F1("unsigned char*", live, true); F1("ggrs_u64*", parts, true);
+        F1("const ggrs_u64*", ff_rows, true); F1("ggrs_u64*", ff_out, true); F1("ggrs_u64", ff_seq, true);
+        F1("ggrs_u64", live_rows, true); F1("ggrs_u64", load_rows, true); F1("ggrs_u64", op_bits, true); F1("ggrs_u64", len, true);
+        FA("unsigned char*", save_dst, S, true); FA("ggrs_u64", save_rows, S, true); FA("ggrs_u64", save_len, S, true);
+        FS("const unsigned char*", spawn_payload, need.spawn); FS("ggrs_u64", spawn_first, need.spawn);
+        FA("int", save_frame, S, true); FA("ggrs_u32", save_pmask, S, true);
+        F1("ggrs_u32", live_pmask, true); F1("ggrs_u32", nt_loads, true); F1("ggrs_u32", n_ops, true); F1("ggrs_u32", n_saves, true); F1("ggrs_u32", n_steps, true);
+        F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", nt, true);
+        F1("ggrs_u32", n_units, true); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true);
+        FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
+        FS("ggrs_u32", spawn_count, need.spawn);
+        FS("unsigned char", step_flags, need.marks); FS("unsigned char", n_inputs, need.inputs);
+        L.f.push_back(JitField{"unsigned char", "inputs", 1, (uint32_t)offsetof(GgrsJitArgs, inputs), 24 * JIT_IN_MAX, T * L.in_stride, need.inputs, 0, T, JIT_IN_MAX, L.in_stride, true});
+        uint32_t off = 0, per_step = 0;
+        for (auto& fl : L.f) {
+            if (!fl.present) continue;
+            off = (off + fl.elem - 1) / fl.elem * fl.elem;
+            fl.dev_off = off; off += fl.elem * fl.dev_count;
+            if (fl.per_step) per_step += fl.rows ? fl.row_dev : fl.elem;
+        }
+        L.bytes = (off + 7u) & ~7u;
+        if (pass == 0 && L.bytes > JIT_KERNARG_BUDGET && per_step) {
+            const uint32_t over = L.bytes - JIT_KERNARG_BUDGET;
+            L.cap_steps = std::max<uint32_t>(3, T - std::min(T - 3, (over + per_step - 1) / per_step));
+            L.cap_saves = std::min(L.cap_saves, L.cap_steps);
+            continue;
+        }
+        break;
     }
-    if (units <= 16) return {1024, 8};
-    if (units <= 26) return {512, 6};
-    return {512, 4};
+#undef F1
+#undef FA
+#undef FS
+    return L;
 }
+// the struct as the generated kernel sees it + one static_assert per field
+std::string jit_layout_text(const JitLayout& L) {
+    std::string s = "struct GgrsJitArgs {\n";
+    char b[256];
+    for (auto& fl : L.f) {
+        if (!fl.present) continue;
+        if (fl.rows) snprintf(b, sizeof b, "    %s %s[%u][%u];\n", fl.type, fl.name, fl.rows, fl.row_dev);
+        else if (fl.host_count == 1) snprintf(b, sizeof b, "    %s %s;\n", fl.type, fl.name);
+        else snprintf(b, sizeof b, "    %s %s[%u];\n", fl.type, fl.name, fl.dev_count);
+        s += b;
+    }
+    s += "};\n";
+    snprintf(b, sizeof b, "static_assert(sizeof(GgrsJitArgs) == %u, \"host/device argument block mismatch\");\n", L.bytes); s += b;
+    for (auto& fl : L.f) if (fl.present) { snprintf(b, sizeof b, "static_assert(__builtin_offsetof(GgrsJitArgs, %s) == %u, \"argument block: offset of %s\");\n", fl.name, fl.dev_off, fl.name); s += b; }
+    return s;
+}
+// host struct -> the world's device layout (buf: L.bytes bytes)
+inline void jit_pack(const JitLayout& L, const GgrsJitArgs& j, unsigned char* buf) {
+    const unsigned char* h = reinterpret_cast<const unsigned char*>(&j);
+    for (const JitField& fl : L.f) {
+        if (!fl.present) continue;
+        if (!fl.rows) memcpy(buf + fl.dev_off, h + fl.host_off, (size_t)fl.elem * fl.dev_count);
+        else for (uint32_t r = 0; r < fl.rows && r < j.n_steps; ++r) memcpy(buf + fl.dev_off + r * fl.row_dev, h + fl.host_off + r * fl.row_host, fl.row_dev);
+    }
+}
+
+// The words of one value under a Strategy (ggrs_hip_register_component_strategy): Strategy::Target (the component) or
+// Strategy::Stored (what a snapshot holds), strategy.rs:22-40.  The user's source defines
+//     __device__ void ggrs_store(const GgrsWords& target, GgrsWords& stored);      // Strategy::store
+//     __device__ void ggrs_load(const GgrsWords& stored, GgrsWords& target);       // Strategy::load (::update defaults to it, strategy.rs:37-39); target arrives zeroed
+#define GGRS_WORDS_TEXT \
+    "struct GgrsWords {\n" \
+    "    ggrs_u64 w[16];\n" \
+    "    __device__ float& f32(int i) { return *reinterpret_cast<float*>(&w[i]); }\n" \
+    "    __device__ ggrs_u32& u32(int i) { return *reinterpret_cast<ggrs_u32*>(&w[i]); }\n" \
+    "    __device__ int& i32(int i) { return *reinterpret_cast<int*>(&w[i]); }\n" \
+    "    __device__ ggrs_u64& u64(int i) { return w[i]; }\n" \
+    "    __device__ unsigned short& u16(int i) { return *reinterpret_cast<unsigned short*>(&w[i]); }\n" \
+    "    __device__ unsigned char& u8(int i) { return *reinterpret_cast<unsigned char*>(&w[i]); }\n" \
+    "    __device__ float f32(int i) const { return __uint_as_float((ggrs_u32)w[i]); }\n" \
+    "    __device__ ggrs_u32 u32(int i) const { return (ggrs_u32)w[i]; }\n" \
+    "    __device__ int i32(int i) const { return (int)(ggrs_u32)w[i]; }\n" \
+    "    __device__ ggrs_u64 u64(int i) const { return w[i]; }\n" \
+    "    __device__ unsigned short u16(int i) const { return (unsigned short)w[i]; }\n" \
+    "    __device__ unsigned char u8(int i) const { return (unsigned char)w[i]; }\n" \
+    "};\n"
 
 // What a user-written checksum hasher sees (ggrs_hip_checksum_component_custom): the component's words of ONE entity and a
 // SeaHasher -- checksum_hasher() of the reference (snapshot/mod.rs:318-320).
@@ -253,64 +375,88 @@ uint64_t jit_hot_cols(const ggrs_world* w) {
     return m;
 }
 
-// Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
-// back to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
-// Player.handle, too many words for the register file / the 64-bit row masks.
 // The per-tile form of a world of ~100 k slots and more folds checksum values through per-lane LDS rows: 64 cells x 8 B per Save and checksummed component
 // (dynamic LDS, sized by the launch), one ds_xor per lane and Save, the rows folded across lanes once per workgroup -- instead of a
 // 12-step DPP ladder + a single-lane atomic per Save and component.  Small worlds keep the ladder: zeroing and folding the rows costs
-// them more than it saves (profiles/r03n/lane_fold_ab.txt).  GGRS_JIT_LANE_FOLD=0|1 forces the choice.
+// them more than it saves (profiles/r03n/lane_fold_ab.txt; with the specialised kernel in: 100 k -2 %, 300 k -4 %, 50 k even: profiles/r03zg).
 constexpr uint32_t JIT_LANE_FOLD_MAX_CKS = 4;
-constexpr uint64_t JIT_LANE_FOLD_MIN_SLOTS = 96 * 1024;       // (with the specialised kernel in: 100 k -2 %, 300 k -4 %, 50 k even: profiles/r03zg)
-inline bool jit_lane_fold(const ggrs_world* w, uint32_t n_cks) {
-    if (n_cks < 1 || n_cks > JIT_LANE_FOLD_MAX_CKS) return false;
-    return w->knobs.jit_lane_fold >= 0 ? w->knobs.jit_lane_fold != 0 : w->cap_pad >= JIT_LANE_FOLD_MIN_SLOTS;
-}
+constexpr uint64_t JIT_LANE_FOLD_MIN_SLOTS = 96 * 1024;
+inline bool jit_lane_fold(const ggrs_world* w, uint32_t n_cks) { return n_cks >= 1 && n_cks <= JIT_LANE_FOLD_MAX_CKS && w->cap_pad >= JIT_LANE_FOLD_MIN_SLOTS; }
 inline uint32_t jit_lane_fold_bytes(const ggrs_world* w, uint32_t n_cks, uint32_t n_saves) { return jit_lane_fold(w, n_cks) ? n_saves * n_cks * 512u : 0u; }
 // The world's spawn system, when the generated kernel can run it INSIDE a request group (a firing spawn system otherwise ends the
-// group: Bevy applies Commands at the end of the schedule): exactly one GGRS_SYS_PARTICLES_SPAWN over three distinct rollback
-// components -- a Transform-like one whose words take their registered defaults, a Velocity-like one of >= 3 four-byte words, a Ttl of
-// one 8-byte word.  -1: none / not fusable.
+// group: Bevy applies Commands at the end of the schedule): exactly one spawn system in the schedule, either
+//   * GGRS_SYS_PARTICLES_SPAWN over three distinct rollback components -- a Transform-like one whose words take their registered
+//     defaults, a Velocity-like one of >= 3 four-byte words, a Ttl of one 8-byte word -- or
+//   * a user-written one (ggrs_hip_add_spawn_system: rollback.rs:45-59 `commands.spawn((.., Rollback))` from any GgrsSchedule system).
+// -1: none / not fusable.
 int jit_fused_spawn_system(const ggrs_world* w) {
     int found = -1;
-    for (size_t i = 0; i < w->systems.size(); ++i) if (w->systems[i].kind == GGRS_SYS_PARTICLES_SPAWN) { if (found >= 0) return -1; found = (int)i; }
+    for (size_t i = 0; i < w->systems.size(); ++i) if (w->systems[i].kind == GGRS_SYS_PARTICLES_SPAWN || w->systems[i].kind == GGRS_SYS_SPAWN_CUSTOM) { if (found >= 0) return -1; found = (int)i; }
     if (found < 0) return -1;
     const ggrs_system_desc& d = w->systems[found];
     const uint32_t nc = (uint32_t)w->comps.size();
+    if (d.kind == GGRS_SYS_SPAWN_CUSTOM) {
+        const ggrs_world::SpawnSys& sp = w->spawn_customs[d.comp[0]];
+        for (uint32_t c = 0; c < nc; ++c) if (((sp.bundle_mask >> c) & 1ull) && w->comps[c].no_rollback) return -1;
+        return found;
+    }
     for (int k = 0; k < 3; ++k) if (d.comp[k] >= nc || w->comps[d.comp[k]].no_rollback) return -1;
     if (d.comp[0] == d.comp[1] || d.comp[0] == d.comp[2] || d.comp[1] == d.comp[2]) return -1;
     const Comp& V = w->comps[d.comp[1]]; const Comp& L = w->comps[d.comp[2]];
     if (V.word_bytes != 4 || V.n_words < 3 || L.word_bytes != 8 || L.n_words < 1) return -1;
     return found;
 }
-bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
+// which optional parts of the argument block this world's kernel reads
+JitNeeds jit_needs(const ggrs_world* w) {
+    JitNeeds n{false, false, false, false};
+    n.spawn = jit_fused_spawn_system(w) >= 0;
+    for (auto& d : w->systems) {
+        n.inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
+        n.marks |= d.kind == GGRS_SYS_CUSTOM || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
+        n.box |= d.kind == GGRS_SYS_BOX_MOVE;
+    }
+    return n;
+}
+
+// Writes the kernel for this world.  Returns false when the world is outside what the generator covers (the caller falls
+// back to the per-request path): a system that touches a live-only component other than BOX_MOVE's read-only
+// Player.handle, too many words for the register file / the 64-bit row masks.
+bool jit_source(const ggrs_world* w, std::string& s) {
     const uint32_t nc = (uint32_t)w->comps.size();
-    const int spawn_sys = persist ? -1 : jit_fused_spawn_system(w);     // (the persistent form folds with ONE len: a spawn still ends its groups)
+    const int spawn_sys = jit_fused_spawn_system(w);
     uint32_t units = 0, ncols = 0;
     for (auto& c : w->comps) { ncols += c.n_words; if (!c.no_rollback) units += c.n_words * std::max(1u, c.word_bytes / 4); }
     if (units == 0 || units > JIT_MAX_UNITS || ncols > JIT_MAX_COLS) return false;
     auto rb = [&](uint32_t c) { return c < nc && !w->comps[c].no_rollback; };
     auto col = [&](uint32_t c, uint32_t k) { return w->comps[c].col_base + k; };
-    bool marks = false;
+    auto strat = [&](uint32_t c) { return w->comps[c].s_n_words != 0; };                     // snapshots hold Strategy::Stored, not the component (strategy.rs:22-40)
+    auto scol = [&](uint32_t c, uint32_t k) { return w->comps[c].scol_base + k; };
+    bool any_strat = false;
+    for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) any_strat = true;
+    const JitNeeds need = jit_needs(w);
+    const bool marks = need.marks;
+    bool lds_inputs = false;                                         // user code indexes PlayerInputs (possibly by a handle it read from a component): the bytes go through LDS
     for (auto& d : w->systems) {
         switch (d.kind) {
         case GGRS_SYS_PARTICLES_SPAWN: break;
+        case GGRS_SYS_SPAWN_CUSTOM: lds_inputs = true; break;
         case GGRS_SYS_PARTICLES_UPDATE: if (!rb(d.comp[0]) || !rb(d.comp[1])) return false; break;
         case GGRS_SYS_TTL_DESPAWN: case GGRS_SYS_ADD_U32: if (!rb(d.comp[0])) return false; break;
-        case GGRS_SYS_SAT_SUB_DESPAWN: if (!rb(d.comp[0])) return false; marks |= d.iparam[1] == GGRS_DESPAWN_ROLLBACK; break;
+        case GGRS_SYS_SAT_SUB_DESPAWN: if (!rb(d.comp[0])) return false; break;
         case GGRS_SYS_BOX_MOVE: if (!rb(d.comp[0]) || !rb(d.comp[1]) || d.comp[2] >= nc) return false; break;
         case GGRS_SYS_CUSTOM: {
             const ggrs_world::Custom& c = w->customs[d.comp[0]];
             for (uint32_t i = 0; i < c.n_bind; ++i) if (!rb(c.comp[i])) return false;      // may WRITE a live-only word: not replayable
-            marks = true;                                                                  // may call despawn_rollback()
+            lds_inputs = true;
         } break;
         default: return false;
         }
     }
+    if (spawn_sys < 0) for (auto& d : w->systems) if (d.kind == GGRS_SYS_SPAWN_CUSTOM) return false;      // a user-written spawner only exists inside the generated kernel
     std::vector<uint32_t> cks_comp;                                  // checksummed components in id order (== w->cks_comp once sealed)
     for (uint32_t c = 0; c < nc; ++c) if (w->comps[c].checksummed) { if (!rb(c)) return false; cks_comp.push_back(c); }
     const uint32_t n_cks = (uint32_t)cks_comp.size();
-    const bool lane_fold = !persist && jit_lane_fold(w, n_cks);
+    const bool lane_fold = jit_lane_fold(w, n_cks);
     std::string fold_text;
     if (lane_fold) {
         char ft[1024];
@@ -326,8 +472,8 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     }
     if (n_cks > 16) return false;
     const unsigned long long OFF_ALIVE = w->off_alive, OFF_DIS = w->marks.off_disabled, OFF_DF = w->marks.off_dframe;
-    const JitPersistShape shape = jit_persist_shape(units);
-    const int TPB_ = persist ? shape.tpb : 256, WPB = TPB_ / 64;
+    const JitLayout L = jit_layout(w);
+    const uint32_t IB = L.in_bytes, MAXP = L.max_players, IN_STRIDE = L.in_stride;
 
     s.clear();
     s += "typedef unsigned long uint64_t; typedef unsigned int uint32_t; typedef unsigned short uint16_t; typedef unsigned char uint8_t;\n"
@@ -349,11 +495,11 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
-    s += "struct GgrsFrame { float dt; int frame; ggrs_u32 n_inputs; unsigned char input[16]; float fparam[4]; long long iparam[2]; };\n";
+    s += GGRS_FRAME_TEXT;
     s += GGRS_ENTITY_TEXT;
     s += GGRS_COMPONENT_TEXT;
-    s += GGRS_JIT_ABI_TEXT;
-    sfmt(s, "static_assert(sizeof(GgrsJitArgs) == %zu, \"host/device argument block mismatch\");\n", sizeof(GgrsJitArgs));
+    s += GGRS_WORDS_TEXT;
+    s += jit_layout_text(L);
     for (size_t i = 0; i < w->customs.size(); ++i) {
         std::string nm = w->customs[i].name;
         for (char& ch : nm) if (!isalnum((unsigned char)ch) && ch != '_') ch = '_';
@@ -361,17 +507,36 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         s += w->customs[i].source;
         s += "\n}\n";
     }
+    if (spawn_sys >= 0 && w->systems[spawn_sys].kind == GGRS_SYS_SPAWN_CUSTOM) {
+        const ggrs_world::SpawnSys& sp = w->spawn_customs[w->systems[spawn_sys].comp[0]];
+        std::string nm = sp.name;
+        for (char& ch : nm) if (!isalnum((unsigned char)ch) && ch != '_') ch = '_';
+        sfmt(s, "namespace ggrs_spawn_sys {\n#line 1 \"%s\"\n", nm.c_str());
+        s += sp.source;
+        s += "\n}\n";
+    }
     for (uint32_t c : cks_comp) if (!w->comps[c].cks_source.empty()) {
         sfmt(s, "namespace ggrs_hash_%u {\n#line 1 \"checksum_%s\"\n", c, w->comps[c].name.c_str());
         s += w->comps[c].cks_source;
         s += "\n}\n";
     }
+    for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) {
+        sfmt(s, "namespace ggrs_strategy_%u {\n#line 1 \"strategy_%s\"\n", c, w->comps[c].name.c_str());
+        s += w->comps[c].strat_source;
+        s += "\n}\n";
+    }
     s += "#line 1 \"ggrs_jit_tick\"\n";
-    char lb[48];
-    if (persist) snprintf(lb, sizeof lb, "%d, %d", TPB_, shape.min_waves_per_simd); else snprintf(lb, sizeof lb, "%d", TPB_);
-    sfmt(s, "extern \"C\" __global__ __launch_bounds__(%s) void ggrs_jit_tick(GgrsJitArgs a) {\n"
+    sfmt(s, "extern \"C\" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {\n"
             "    const uint32_t tid = threadIdx.x, lane = tid & 63u;\n"
             "    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform, and the compiler knows it\n"
+            "    // FOLD-FORWARD role: the first ff_blocks workgroups (a multiple of 8: the XCD mapping below is unchanged) do not own a tile -- each folds one row\n"
+            "    // of partials the PREVIOUS launch on this stream left in device memory and hands the value, then its tag, to the host\n"
+            "    if (blockIdx.x < a.ff_blocks) {\n"
+            "        if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals)\n"
+            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)blockIdx.x * a.ff_stride, a.ff_g, (blockIdx.x %% %uu) == %uu, (uint64_t*)a.ff_out + blockIdx.x, (uint64_t*)a.ff_out + a.ff_nvals + blockIdx.x, (uint64_t)a.ff_seq);\n"
+            "        return;\n"
+            "    }\n"
+            "    const uint32_t bx = blockIdx.x - a.ff_blocks, gx = gridDim.x - a.ff_blocks;\n"
             "    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;\n"
             "    const uint32_t o_first = a.dp_s ? blockIdx.y * a.dp_s : 0u;          // depth-parallel roles: this workgroup's share of the outputs\n"
             "    const uint32_t o_last = a.dp_s ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;\n"
@@ -379,24 +544,22 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
             "    if (a.dp_s && o_first == a.n_saves && !writes_live) return;\n"
             "    // per-workgroup checksum partials [Save][component .. live count]: the waves fold into LDS\n"
             "    __shared__ ggrs_u64 s_acc[16 * %u];\n"
-            "    __shared__ uint32_t s_last;\n"
-            "    for (uint32_t i = tid; i < 16u * %uu; i += %du) s_acc[i] = 0;\n",
-         lb, n_cks + 1, n_cks + 1, TPB_);
+            "    for (uint32_t i = tid; i < 16u * %uu; i += 256u) s_acc[i] = 0;\n",
+         n_cks + 1, n_cks, n_cks + 1, n_cks + 1);
     if (lane_fold) sfmt(s, "    extern __shared__ ggrs_u64 s_lane[];                                  // [Save][checksummed component][lane]: a.n_saves * %u * 64 cells (dynamic LDS)\n"
-                           "    for (uint32_t i = tid; i < a.n_saves * %uu; i += %du) s_lane[i] = 0;\n", n_cks, n_cks * 64u, TPB_);
-    s += "    __syncthreads();\n";
-    if (persist) sfmt(s, "    for (uint32_t t_ = blockIdx.x; t_ * %du < a.n_units; t_ += gridDim.x) {       // persistent: %d consecutive slots per workgroup and trip\n"
-                         "    const uint32_t gu = t_ * %du + wave;                                  // this wave's 64-slot unit == its mask word\n"
-                         "    if (gu >= a.n_units) continue;\n", WPB, TPB_, WPB);
-    else s += "    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed placement; used for speed only), and each XCD has its own\n"
-              "    // L2.  Handing XCD x the x-th CONTIGUOUS eighth of the tiles makes the workgroups that write neighbouring 1 KiB pieces of a\n"
-              "    // row share one L2, which merges them into long runs before they go to memory -- instead of every L2 seeing every 8th piece.\n"
-              "    const uint32_t g8 = gridDim.x >> 3;                                       // the grid is 8 x ceil(tiles / 8) workgroups\n"
-              "    const uint32_t tile = (blockIdx.x & 7u) * g8 + (blockIdx.x >> 3);\n"
-              "    const bool pad_wg = tile * 4u >= a.n_units;                               // padding workgroup of the last eighth\n"
-              "    if (pad_wg && !a.gf_rows) return;                                         // (group fold: it still hands in its -- empty -- row and takes its ticket)\n"
-              "    if (!pad_wg) {\n"
-              "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
+                           "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) s_lane[i] = 0;\n", n_cks, n_cks * 64u);
+    if (lds_inputs && IN_STRIDE)
+        sfmt(s, "    __shared__ unsigned char s_in[%u * %u];                                  // PlayerInputs of every step of the group: [step][%u players x %u bytes | %u status bytes]\n"
+                "    for (uint32_t i = tid; i < a.n_steps * %uu; i += 256u) s_in[i] = a.inputs[i / %uu][i %% %uu];\n", L.cap_steps, IN_STRIDE, MAXP, IB, MAXP, IN_STRIDE, IN_STRIDE, IN_STRIDE);
+    s += "    __syncthreads();\n"
+         "    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed placement; used for speed only), and each XCD has its own\n"
+         "    // L2.  Handing XCD x the x-th CONTIGUOUS eighth of the tiles makes the workgroups that write neighbouring 1 KiB pieces of a\n"
+         "    // row share one L2, which merges them into long runs before they go to memory -- instead of every L2 seeing every 8th piece.\n"
+         "    const uint32_t g8 = gx >> 3;                                              // the grid is 8 x ceil(tiles / 8) workgroups (+ the fold-forward ones)\n"
+         "    const uint32_t tile = (bx & 7u) * g8 + (bx >> 3);\n"
+         "    if (tile * 4u >= a.n_units) return;                                       // padding workgroup of the last eighth\n"
+         "    {\n"
+         "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
             "    %sbool in_len = (uint64_t)gu * 64u < a.len;                                 // wave-uniform%s\n"
             "    // word c of slot e lives at col_off[c] + (e >> 13) * tile_stride + (e & 8191) * word_bytes: the layout tile is the\n"
@@ -413,24 +576,65 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
     for (uint32_t c = 0; c < nc; ++c) if (rb(c))
         sfmt(s, "    const uint64_t mk%u = *reinterpret_cast<const uint64_t*>(a.src + %lluull + wi8);\n"
                 "    %sbool p%u_0 = (mk%u >> sh) & 1ull;\n", c, (unsigned long long)w->off_present[c], spawn_sys >= 0 ? "" : "const ", c, c);
-    auto wtype = [&](uint32_t c) { return w->comps[c].word_bytes == 8 ? "uint64_t" : "uint32_t"; };                    // register type
-    auto mtype = [&](uint32_t c) { const uint32_t b = w->comps[c].word_bytes; return b == 8 ? "uint64_t" : (b == 4 ? "uint32_t" : (b == 2 ? "uint16_t" : "uint8_t")); };   // memory type
-    for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
-        const uint32_t cl = col(c, k), wb = w->comps[c].word_bytes;
-        if (w->col_ts[cl] != w->ts) return false;                    // every rollback column shares the tile stride
-        sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n#define b%u(blk) ((blk) + (%lluull + tbase))\n    %s w%u_0 = 0;\n",
-             cl, (unsigned long long)w->col_off[cl], wb, cl, (unsigned long long)w->col_off[cl], wtype(c), cl);
+    auto wtype_b = [](uint32_t b) { return b == 8 ? "uint64_t" : "uint32_t"; };                                      // register type of a word of b bytes
+    auto mtype_b = [](uint32_t b) { return b == 8 ? "uint64_t" : (b == 4 ? "uint32_t" : (b == 2 ? "uint16_t" : "uint8_t")); };   // its memory type
+    auto wtype = [&](uint32_t c) { return wtype_b(w->comps[c].word_bytes); };
+    auto mtype = [&](uint32_t c) { return mtype_b(w->comps[c].word_bytes); };
+    for (uint32_t c = 0; c < nc; ++c) if (rb(c)) {
+        for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
+            const uint32_t cl = col(c, k), wb = w->comps[c].word_bytes;
+            if (w->col_ts[cl] != w->ts) return false;                    // every rollback column shares the tile stride
+            sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n#define b%u(blk) ((blk) + (%lluull + tbase))\n    %s w%u_0 = 0;\n",
+                 cl, (unsigned long long)w->col_off[cl], wb, cl, (unsigned long long)w->col_off[cl], wtype(c), cl);
+        }
+        // a component under a Strategy: its Stored words have columns of their own (ring slots hold them, the live block holds the component)
+        for (uint32_t k = 0; k < w->comps[c].s_n_words; ++k) {
+            const uint32_t cl = scol(c, k), wb = w->comps[c].s_word_bytes;
+            if (w->col_ts[cl] != w->ts) return false;
+            sfmt(s, "#define o%u(blk) (sgpr_base((blk) + (%lluull + tbase)) + lo%u)\n#define b%u(blk) ((blk) + (%lluull + tbase))\n",
+                 cl, (unsigned long long)w->col_off[cl], wb, cl, (unsigned long long)w->col_off[cl]);
+        }
     }
     // loads / stores of the words of the lane's slot from / to a block, each guarded by its bit of a wave-uniform row mask
     // Row masks are wave-uniform.  The masks of a steady-state tick are known when the kernel is written -- a SaveWorld stores
     // exactly the columns some system writes (HOT), the source block is read for those plus what steps and checksums read -- so
     // each access block is emitted twice: straight-line for that mask (one scalar compare), column-by-column guards otherwise.
+    // A component under a Strategy moves as a whole: any of its columns in the mask means `store` / `load` runs and all Stored words move.
     const uint64_t HOT = jit_hot_cols(w), LOADHOT = HOT | jit_static_reads(w);
-    auto each_col = [&](uint64_t only, const std::function<void(uint32_t, uint32_t)>& fn) {
-        for (uint32_t c = 0; c < nc; ++c) if (rb(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k)
+    auto comp_mask = [&](uint32_t c) { uint64_t m = 0; for (uint32_t k = 0; k < w->comps[c].n_words; ++k) m |= 1ull << col(c, k); return m; };
+    auto each_col = [&](uint64_t only, const std::function<void(uint32_t, uint32_t)>& fn) {          // plain columns (not under a Strategy)
+        for (uint32_t c = 0; c < nc; ++c) if (rb(c) && !strat(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k)
             if ((only >> col(c, k)) & 1ull) fn(c, col(c, k));
     };
+    auto each_strat = [&](uint64_t only, const std::function<void(uint32_t)>& fn) { for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c) && (only & comp_mask(c))) fn(c); };
+    // Strategy::load / update (strategy.rs:31-39): the Stored words of the snapshot -> the component's registers
+    auto emit_strat_load = [&](uint32_t c, const char* blk, const char* indent, bool nt, const char* guard_mask) {
+        const Comp& cc = w->comps[c];
+        std::string g;
+        if (guard_mask) { char b[96]; snprintf(b, sizeof b, "if (%s & 0x%llxull) ", guard_mask, (unsigned long long)comp_mask(c)); g = b; }
+        sfmt(s, "%s%s{ GgrsWords st_, tg_;\n", indent, g.c_str());
+        for (uint32_t k = 0; k < cc.s_n_words; ++k)
+            sfmt(s, nt ? "%s    st_.w[%u] = __builtin_nontemporal_load((const GGRS_G %s*)o%u(%s));\n" : "%s    st_.w[%u] = *(const GGRS_G %s*)o%u(%s);\n", indent, k, mtype_b(cc.s_word_bytes), scol(c, k), blk);
+        for (uint32_t k = 0; k < cc.n_words; ++k) sfmt(s, "%s    tg_.w[%u] = 0;\n", indent, k);
+        sfmt(s, "%s    ggrs_strategy_%u::ggrs_load(st_, tg_);\n", indent, c);
+        for (uint32_t k = 0; k < cc.n_words; ++k) sfmt(s, "%s    w%u_0 = (%s)(%s)tg_.w[%u];\n", indent, col(c, k), wtype(c), mtype(c), k);
+        sfmt(s, "%s}\n", indent);
+    };
+    // Strategy::store (strategy.rs:28-29): the component's registers -> the Stored words of a snapshot
+    auto emit_strat_store = [&](uint32_t c, const char* dst, const char* indent, bool nt, const char* guard_mask) {
+        const Comp& cc = w->comps[c];
+        std::string g;
+        if (guard_mask) { char b[96]; snprintf(b, sizeof b, "if (%s & 0x%llxull) ", guard_mask, (unsigned long long)comp_mask(c)); g = b; }
+        sfmt(s, "%s%s{ GgrsWords tg_, st_;\n", indent, g.c_str());
+        for (uint32_t k = 0; k < cc.n_words; ++k) sfmt(s, "%s    tg_.w[%u] = w%u_0;\n", indent, k, col(c, k));
+        for (uint32_t k = 0; k < cc.s_n_words; ++k) sfmt(s, "%s    st_.w[%u] = 0;\n", indent, k);
+        sfmt(s, "%s    ggrs_strategy_%u::ggrs_store(tg_, st_);\n", indent, c);
+        for (uint32_t k = 0; k < cc.s_n_words; ++k)
+            sfmt(s, "%s    st%u%s(b%u(%s), lo%u, (%s)st_.w[%u]);\n", indent, cc.s_word_bytes, nt ? "nt" : "", scol(c, k), dst, cc.s_word_bytes, wtype_b(cc.s_word_bytes), k);
+        sfmt(s, "%s}\n", indent);
+    };
     auto emit_load = [&](const char* blk, const char* mask, const char* indent) {
+        const std::string in2 = std::string(indent) + "    ", in3 = in2 + "    ";
         sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)LOADHOT);
         sfmt(s, "%s  if (a.nt_loads) {\n", indent);
         each_col(LOADHOT, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    w%u_0 = __builtin_nontemporal_load((const GGRS_G %s*)o%u(%s));\n", indent, cl, mtype(c), cl, blk); });
@@ -440,8 +644,19 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         sfmt(s, "%s} else {\n", indent);
         each_col(~0ull, [&](uint32_t c, uint32_t cl) { sfmt(s, "%s    if ((%s >> %uu) & 1ull) w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", indent, mask, cl, cl, mtype(c), cl, blk); });
         sfmt(s, "%s}\n", indent);
+        if (any_strat) {
+            // the live block holds the component itself, a ring slot its Stored form
+            sfmt(s, "%sif (a.src_is_live) {\n", indent);
+            for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k)
+                sfmt(s, "%sif ((%s >> %uu) & 1ull) w%u_0 = *(const GGRS_G %s*)o%u(%s);\n", in2.c_str(), mask, col(c, k), col(c, k), mtype(c), col(c, k), blk);
+            sfmt(s, "%s} else if (a.nt_loads) {\n", indent);
+            each_strat(~0ull, [&](uint32_t c) { emit_strat_load(c, blk, in2.c_str(), true, mask); });
+            sfmt(s, "%s} else {\n", indent);
+            each_strat(~0ull, [&](uint32_t c) { emit_strat_load(c, blk, in2.c_str(), false, mask); });
+            sfmt(s, "%s}\n", indent);
+        }
     };
-    auto emit_words_out = [&](const char* dst, const char* mask, const char* indent, bool nt) {
+    auto emit_words_out = [&](const char* dst, const char* mask, const char* indent, bool nt, bool to_ring) {
         auto one = [&](uint32_t c, uint32_t cl, const char* ind, bool guard) {
             char g[64] = "";
             if (guard) snprintf(g, sizeof g, "if ((%s >> %uu) & 1ull) ", mask, cl);
@@ -451,21 +666,24 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         const std::string in2 = std::string(indent) + "    ";
         sfmt(s, "%sif (%s == 0x%llxull) {\n", indent, mask, (unsigned long long)HOT);
         each_col(HOT, [&](uint32_t c, uint32_t cl) { one(c, cl, in2.c_str(), false); });
+        if (to_ring) each_strat(HOT, [&](uint32_t c) { emit_strat_store(c, dst, in2.c_str(), nt, nullptr); });
+        else for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) if ((HOT >> col(c, k)) & 1ull) one(c, col(c, k), in2.c_str(), false);
         sfmt(s, "%s} else {\n", indent);
         each_col(~0ull, [&](uint32_t c, uint32_t cl) { one(c, cl, in2.c_str(), true); });
+        if (to_ring) each_strat(~0ull, [&](uint32_t c) { emit_strat_store(c, dst, in2.c_str(), nt, mask); });
+        else for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) one(c, col(c, k), in2.c_str(), true);
         sfmt(s, "%s}\n", indent);
     };
     auto emit_store = [&](const char* dst, const char* mask, const char* pmask, const char* alive_word, const char* indent, bool nt_variant) {
         std::string in2 = std::string(indent) + "    ", in3 = in2 + "    ";
         sfmt(s, "%sif (in_len) {\n", indent);
-        if (nt_variant && persist) emit_words_out(dst, mask, in2.c_str(), true);      // the persistent form only serves HBM-sized groups: snapshots are written once, read a tick later
-        else if (nt_variant) {
+        if (nt_variant) {
             sfmt(s, "%sif (a.nt && !((a.cached_saves >> si) & 1u)) {\n", in2.c_str());
-            emit_words_out(dst, mask, in3.c_str(), true);
+            emit_words_out(dst, mask, in3.c_str(), true, true);
             sfmt(s, "%s} else {\n", in2.c_str());
-            emit_words_out(dst, mask, in3.c_str(), false);
+            emit_words_out(dst, mask, in3.c_str(), false, true);
             sfmt(s, "%s}\n", in2.c_str());
-        } else emit_words_out(dst, mask, in2.c_str(), false);
+        } else emit_words_out(dst, mask, in2.c_str(), false, false);
         sfmt(s, "%s}\n", indent);
         // a spawn inside the group sets presence bits of its bundle: the mask words are then rebuilt from the lanes (as the liveness word
         // always is); without a fusable spawn system only the host changes them and the word read from the source is what is stored
@@ -581,14 +799,17 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
              "            const bool defer = sflags & 2u;                                            // despawn_rollback() defers (despawn.rs:129-137)\n"
              "            if ((sflags & 1u) && dis_0 && df_0 <= a.step_confirmed[sj]) dis_0 = false;   // DespawnConfirmed (despawn.rs:89-112)\n";
     }
+    // PlayerInputs<T> of the step as user code sees it (src/lib.rs:98): bytes in LDS
+    auto emit_frame = [&](const char* name, const float* fparam, const int64_t* iparam) {
+        sfmt(s, "            GgrsFrame %s; %s.dt = dt; %s.frame = a.step_frame[sj]; %s.n_inputs = a.n_inputs[sj]; %s.input_bytes = %uu;\n"
+                "            %s.input.p = s_in + sj * %uu; %s.input.ib = %uu; %s.status = s_in + sj * %uu + %uu;\n",
+             name, name, name, name, name, IB, name, IN_STRIDE, name, IB, name, IN_STRIDE, MAXP * IB);
+        for (int k = 0; k < 4; ++k) sfmt(s, "            %s.fparam[%d] = %s;\n", name, k, f32_lit(fparam[k]).c_str());
+        sfmt(s, "            %s.iparam[0] = %lldll; %s.iparam[1] = %lldll;\n", name, (long long)iparam[0], name, (long long)iparam[1]);
+    };
     for (size_t i = 0; i < w->systems.size(); ++i) {
         const ggrs_system_desc& d = w->systems[i];
-        if (d.kind == GGRS_SYS_CUSTOM) {
-            sfmt(s, "            GgrsFrame fr%zu; fr%zu.dt = dt; fr%zu.frame = a.step_frame[sj]; fr%zu.n_inputs = a.n_inputs[sj];\n"
-                    "            for (int k = 0; k < 16; ++k) fr%zu.input[k] = a.inputs[sj][k];\n", i, i, i, i, i);
-            for (int k = 0; k < 4; ++k) sfmt(s, "            fr%zu.fparam[%d] = %s;\n", i, k, f32_lit(d.fparam[k]).c_str());
-            sfmt(s, "            fr%zu.iparam[0] = %lldll; fr%zu.iparam[1] = %lldll;\n", i, (long long)d.iparam[0], i, (long long)d.iparam[1]);
-        }
+        if (d.kind == GGRS_SYS_CUSTOM) { char nm[24]; snprintf(nm, sizeof nm, "fr%zu", i); emit_frame(nm, d.fparam, d.iparam); }
         switch (d.kind) {
         case GGRS_SYS_PARTICLES_UPDATE: {
             sfmt(s, "            if (alive_0 && p%u_0 && p%u_0) {                                     // particles.rs:272-280\n", d.comp[0], d.comp[1]);
@@ -625,11 +846,11 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                     "                float x = __uint_as_float(w%u_0), y = __uint_as_float(w%u_0), z = __uint_as_float(w%u_0);\n"
                     "                float vx = __uint_as_float(w%u_0), vy = __uint_as_float(w%u_0), vz = __uint_as_float(w%u_0);\n",
                  d.comp[0], d.comp[1], hp, hv, x, x + 1, x + 2, v, v + 1, v + 2);
-            sfmt(s, "                box_move_math(x, y, z, vx, vy, vz, a.inputs[sj][%s], dt, __uint_as_float(a.aux_bits[sj]), %s, %s, %s);\n"
+            sfmt(s, "                box_move_math(x, y, z, vx, vy, vz, a.inputs[sj][%s * %uu], dt, __uint_as_float(a.aux_bits[sj]), %s, %s, %s);\n"
                     "                w%u_0 = __float_as_uint(x); w%u_0 = __float_as_uint(y); w%u_0 = __float_as_uint(z);\n"
                     "                w%u_0 = __float_as_uint(vx); w%u_0 = __float_as_uint(vy); w%u_0 = __float_as_uint(vz);\n"
                     "            }\n",
-                 hv, f32_lit(d.fparam[0]).c_str(), f32_lit(d.fparam[1]).c_str(), f32_lit(d.fparam[3]).c_str(), x, x + 1, x + 2, v, v + 1, v + 2);
+                 hv, IB, f32_lit(d.fparam[0]).c_str(), f32_lit(d.fparam[1]).c_str(), f32_lit(d.fparam[3]).c_str(), x, x + 1, x + 2, v, v + 1, v + 2);
         } break;
         case GGRS_SYS_CUSTOM: {
             const ggrs_world::Custom& c = w->customs[d.comp[0]];
@@ -648,24 +869,41 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
         }
     }
     if (spawn_sys >= 0) {
-        // spawn_particles (particles.rs:258-270), applied where Bevy applies its Commands: after the step's other systems.  The new rows are
-        // RollbackOrdered's next indices == the next slots; a lane whose slot falls into the range takes the bundle: Transform's registered
-        // defaults, Velocity (vx, vy, 0) from the staged payload, Ttl = iparam[0]; liveness and the bundle's presence bits are set
+        // The spawn system, applied where Bevy applies its Commands: after the step's other systems.  The new rows are RollbackOrdered's next
+        // indices == the next slots; a lane whose slot falls into the range takes the bundle -- every component of it at its registered
+        // default, then what the spawner writes -- and its liveness and the bundle's presence bits are set.
         const ggrs_system_desc& d = w->systems[spawn_sys];
-        const Comp& T = w->comps[d.comp[0]];
+        const bool custom = d.kind == GGRS_SYS_SPAWN_CUSTOM;
+        uint64_t bundle = 0;
+        if (custom) bundle = w->spawn_customs[d.comp[0]].bundle_mask; else bundle = (1ull << d.comp[0]) | (1ull << d.comp[1]) | (1ull << d.comp[2]);
+        if (custom) emit_frame("fr_spawn", d.fparam, d.iparam);
         s += "            if (a.spawn_count[sj]) {                                                   // wave-uniform\n"
              "                const uint64_t sf_ = a.spawn_first[sj], sn_ = a.spawn_count[sj];\n"
              "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
              "                    alive_0 = true;\n";
-        sfmt(s, "                    p%u_0 = true; p%u_0 = true; p%u_0 = true;\n", d.comp[0], d.comp[1], d.comp[2]);
-        for (uint32_t k = 0; k < T.n_words; ++k) {
-            unsigned long long v = 0;
-            if (T.defaults.size() >= (size_t)(k + 1) * T.word_bytes) memcpy(&v, &T.defaults[(size_t)k * T.word_bytes], T.word_bytes);
-            sfmt(s, "                    w%u_0 = (%s)0x%llxull;\n", col(d.comp[0], k), wtype(d.comp[0]), v);
+        for (uint32_t c = 0; c < nc; ++c) if (rb(c)) sfmt(s, "                    p%u_0 = %s;\n", c, ((bundle >> c) & 1ull) ? "true" : "false");
+        for (uint32_t c = 0; c < nc; ++c) if (rb(c) && ((bundle >> c) & 1ull)) {
+            const Comp& T = w->comps[c];
+            for (uint32_t k = 0; k < T.n_words; ++k) {
+                unsigned long long v = 0;
+                if (T.defaults.size() >= (size_t)(k + 1) * T.word_bytes) memcpy(&v, &T.defaults[(size_t)k * T.word_bytes], T.word_bytes);
+                sfmt(s, "                    w%u_0 = (%s)0x%llxull;\n", col(c, k), wtype(c), v);
+            }
         }
-        sfmt(s, "                    w%u_0 = __float_as_uint(a.spawn_vx[sj][e0 - sf_]); w%u_0 = __float_as_uint(a.spawn_vy[sj][e0 - sf_]); w%u_0 = 0u;\n",
-             col(d.comp[1], 0), col(d.comp[1], 1), col(d.comp[1], 2));
-        sfmt(s, "                    w%u_0 = %lluull;\n", col(d.comp[2], 0), (unsigned long long)d.iparam[0]);
+        if (!custom) {
+            // spawn_particles (particles.rs:258-270): Velocity (vx, vy, 0) from the staged payload -- count f32 of vx, then count f32 of vy --, Ttl = iparam[0]
+            sfmt(s, "                    const float* pv_ = reinterpret_cast<const float*>(a.spawn_payload[sj]);          // spawn_particles, particles.rs:258-270\n"
+                    "                    w%u_0 = __float_as_uint(pv_[e0 - sf_]); w%u_0 = __float_as_uint(pv_[sn_ + (e0 - sf_)]); w%u_0 = 0u;\n",
+                 col(d.comp[1], 0), col(d.comp[1], 1), col(d.comp[1], 2));
+            sfmt(s, "                    w%u_0 = %lluull;\n", col(d.comp[2], 0), (unsigned long long)d.iparam[0]);
+        } else {
+            const ggrs_world::SpawnSys& sp = w->spawn_customs[d.comp[0]];
+            s += "                    GgrsEntity ent; ent.slot = e0; ent.kill = 0;\n";
+            for (uint32_t b = 0; b < sp.n_bind; ++b) sfmt(s, "                    ent.w[%u] = w%u_0;\n", b, col(sp.comp[b], sp.word[b]));
+            sfmt(s, "                    ggrs_spawn_sys::ggrs_spawn(ent, e0 - sf_, fr_spawn, a.spawn_payload[sj] + (e0 - sf_) * %uull);\n", sp.payload_stride);
+            for (uint32_t b = 0; b < sp.n_bind; ++b)
+                sfmt(s, "                    w%u_0 = (%s)(%s)ent.w[%u];\n", col(sp.comp[b], sp.word[b]), wtype(sp.comp[b]), mtype(sp.comp[b]), b);
+        }
         if (marks) s += "                    dis_0 = false;\n";
         s += "                }\n"
              "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n"
@@ -686,52 +924,16 @@ bool jit_source(const ggrs_world* w, std::string& s, bool persist) {
                 "        *reinterpret_cast<int*>(a.live + %lluull + e0 * 4u) = df_0;\n", OFF_DIS, OFF_DF);
         s += "    }\n";
     }
-    s += "    }   // the wave's unit(s)\n";
-    if (persist) {
-        sfmt(s, "    // ---- every Save's Checksum(u128), folded in this launch (tick_fold, device_prelude.hpp)\n"
-                "    FoldArgs f; f.wg_parts = (uint64_t*)a.fold_wg_parts; f.ticket = a.fold_ticket; f.out = (uint64_t*)a.fold_out; f.n_comp = %uu; f.comp_mask = %uu;\n"
-                "    tick_fold<%d, 8>(f, a.n_saves, a.len, (uint64_t*)s_acc, &s_last);\n", n_cks, n_cks ? ((1u << n_cks) - 1u) : 0u, TPB_);
-    } else {
-        sfmt(s, "    // ---- this workgroup's partial rows (blockIdx.z: member of a batch of identical checksum-only groups)\n"
-                "    __syncthreads();\n"
-                "%s", fold_text.c_str());
-        sfmt(s,
-                "    if (a.gf_rows) {\n"
-                "        // GROUP FOLD (HBM-sized groups; no roles, no batch).  64 workgroups in dispatch order share one accumulator row in device memory and\n"
-                "        // one ticket.  Wave 0 of every workgroup XORs / adds the workgroup's partials into the row with agent-scope atomics (performed at the\n"
-                "        // memory side: coherent across the XCDs' L2s), drains them -- an explicit vmcnt(0): the atomics are in memory before the ticket is\n"
-                "        // taken -- and takes the ticket; the other waves are gone by then, so a workgroup waiting for its stores to drain holds one wave\n"
-                "        // slot, not four.  The group's last arriver takes the row with atomic exchanges (read + clear), hands it to `parts` (column = group).\n"
-                "        // component_checksum.rs:88-89 is an XOR and the live count a sum: any grouping and any order give the same result.\n"
-                "        if (wave != 0u) return;\n"
-                "        const uint32_t nv = a.n_saves * %uu;                                   // values per row (<= 256: the host checks)\n"
-                "        const uint32_t grp = blockIdx.x >> 6, members = min(64u, gridDim.x - (grp << 6));\n"
-                "        uint64_t* row = (uint64_t*)a.gf_rows + (uint64_t)grp * nv;\n"
-                "        for (uint32_t i = lane; i < nv; i += 64u) {\n"
-                "            const uint64_t v = (uint64_t)s_acc[i];\n"
-                "            if (v == 0ull) continue;                                            // (a padding workgroup, a tile without live entities)\n"
-                "            if ((i %% %uu) == %uu) (void)__hip_atomic_fetch_add(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-                "            else (void)__hip_atomic_fetch_xor(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-                "        }\n"
-                "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
-                "        uint32_t t_ = 0;\n"
-                "        if (lane == 0) t_ = __hip_atomic_fetch_add(a.gf_tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-                "        t_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_);\n"
-                "        if (t_ != members - 1u) return;                                         // wave-uniform\n"
-                "        // read AND clear each accumulator with one agent-scope exchange: it is performed where the producers' atomics were (never served\n"
-                "        // from a cache line that predates them) and leaves the row zero for the next launch on this stream\n"
-                "        for (uint32_t i = lane; i < nv; i += 64u)\n"
-                "            a.parts[(uint64_t)i * a.part_stride + grp] = __hip_atomic_exchange(row + i, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-                "        if (lane == 0) a.gf_tickets[grp] = 0;\n"
-                "        return;\n"
-                "    }\n", n_cks + 1, n_cks + 1, n_cks);
-        sfmt(s,
-                "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
-                "        const uint32_t sv = i / %uu;\n"
-                "        if (sv >= o_first && sv < o_last)\n"
-                "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
-                "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
-    }
+    s += "    }   // the wave's unit\n";
+    sfmt(s, "    // ---- this workgroup's partial rows (blockIdx.z: member of a batch of identical checksum-only groups)\n"
+            "    __syncthreads();\n"
+            "%s", fold_text.c_str());
+    sfmt(s,
+            "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
+            "        const uint32_t sv = i / %uu;\n"
+            "        if (sv >= o_first && sv < o_last)\n"
+            "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
+            "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     s += "}\n";
     return true;
 }
@@ -760,34 +962,64 @@ std::string jit_disk_path_in(std::string dir, const std::string& src) {
     (void)mkdir(dir.c_str(), 0755);
     return dir + name;
 }
+// SHIPPED code objects (`make -C bevy_ggrs_amd/csrc aot`, scripts/aot_build.py): a deployment without libhiprtc.so still gets the generated kernel --
+// and its specialised copies -- for every world whose generated text hashes to a shipped file.  The name is the hash of target + ABI + text (no
+// run-time version: a code object outlives runtime updates); GGRS_AOT_DIR, default <directory of libggrs_hip.so>/aot.
+std::string jit_aot_name(const std::string& src) {
+    const std::string key = "gfx950|aot|" + std::to_string(GGRS_HIP_ABI_VERSION) + "|" + src;
+    char name[64];
+    snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(key, 0xcbf29ce484222325ull), (unsigned long long)fnv1a(key, 0x9e3779b97f4a7c15ull));
+    return name;
+}
+std::string jit_aot_dir(const std::string& knob) {
+    if (knob == "0" || knob == "off") return "";
+    if (!knob.empty()) return knob;
+    Dl_info info;
+    if (!dladdr((const void*)&jit_aot_name, &info) || !info.dli_fname) return "";
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/aot";
+}
+bool jit_read_file(const std::string& path, std::vector<char>& image) {
+    image.clear();
+    if (path.empty()) return false;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    if (n > 0) { image.resize((size_t)n); if (fread(image.data(), 1, (size_t)n, f) != (size_t)n) image.clear(); }
+    fclose(f);
+    return !image.empty();
+}
+// disk cache, then the shipped objects: a module + kernel handle, or false
+bool jit_load_cached(const std::string& cache_dir, const std::string& aot_knob, const std::string& src, hipModule_t* mod, hipFunction_t* fn, std::string* origin) {
+    const std::string aot = jit_aot_dir(aot_knob);
+    const std::string paths[2] = {jit_disk_path_in(cache_dir, src), aot.empty() ? std::string() : aot + "/" + jit_aot_name(src)};
+    for (int k = 0; k < 2; ++k) {
+        std::vector<char> image;
+        if (!jit_read_file(paths[k], image)) continue;
+        if (hipModuleLoadData(mod, image.data()) == hipSuccess) {
+            if (hipModuleGetFunction(fn, *mod, "ggrs_jit_tick") == hipSuccess) { if (origin) *origin = k == 0 ? "disk cache" : "shipped code object (aot)"; return true; }
+            (void)hipModuleUnload(*mod); *mod = nullptr;
+        }
+        (void)hipGetLastError();                                     // a stale / truncated file: go on as if it were not there
+    }
+    return false;
+}
 // *entry_out: what the world hands back to jit_release when it is destroyed
-int jit_cached(ggrs_world* w, const std::string& src, hipFunction_t* fn, JitEntry** entry_out) {
+int jit_cached(ggrs_world* w, const std::string& src, hipFunction_t* fn, JitEntry** entry_out, std::string* origin = nullptr) {
     JitCache& jc = jit_cache();
     std::lock_guard<std::mutex> lk(jc.mu);
     auto& cache = jc.map; uint64_t& clock_ = jc.clock;
     const auto key = std::make_pair(w->device, src);
     auto it = cache.find(key);
-    if (it != cache.end()) { it->second.last_use = ++clock_; ++it->second.refs; *fn = it->second.fn; *entry_out = &it->second; return GGRS_OK; }
+    if (it != cache.end()) { it->second.last_use = ++clock_; ++it->second.refs; *fn = it->second.fn; *entry_out = &it->second; if (origin) *origin = "in-process module cache"; return GGRS_OK; }
     hipModule_t mod = nullptr;
-    int rc = GGRS_E_HIP;
-    const std::string path = jit_disk_path(w, src);
-    if (!path.empty()) {                                             // a code object of exactly this source for this target?
-        FILE* f = fopen(path.c_str(), "rb");
-        if (f) {
-            std::vector<char> image;
-            fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
-            if (n > 0) { image.resize((size_t)n); if (fread(image.data(), 1, (size_t)n, f) != (size_t)n) image.clear(); }
-            fclose(f);
-            if (!image.empty() && hipModuleLoadData(&mod, image.data()) == hipSuccess) {
-                if (hipModuleGetFunction(fn, mod, "ggrs_jit_tick") == hipSuccess) rc = GGRS_OK;
-                else { (void)hipModuleUnload(mod); mod = nullptr; }
-            }
-            if (rc != GGRS_OK) (void)hipGetLastError();              // a stale / truncated file: compile as if it were not there
-        }
-    }
+    int rc = jit_load_cached(w->knobs.jit_cache_dir, w->knobs.aot_dir, src, &mod, fn, origin) ? GGRS_OK : GGRS_E_HIP;
     if (rc != GGRS_OK) {
         std::vector<char> image;
         rc = hiprtc_build(w, src, "generated request-group kernel", "ggrs_jit_tick", &mod, fn, &image);
+        const std::string path = jit_disk_path(w, src);
+        if (rc == GGRS_OK && origin) *origin = "hiprtc";
         if (rc == GGRS_OK && !path.empty() && !image.empty()) {
             const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
             FILE* f = fopen(tmp.c_str(), "wb");
@@ -872,28 +1104,21 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     if (lp == std::string::npos) return "";
     body.insert(lp, "#pragma unroll\n");
     char note[256];
-    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u\n", g.n_ops,
-             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads);
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u\n", g.n_ops,
+             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads, g.dp_s);
     return head + note + body;
 }
-// Build (or load from the disk cache) without touching a world: runs on a worker thread
-void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_dir) {
+// Build (or load from the disk cache / the shipped objects) without touching a world: runs on a worker thread
+void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_dir, std::string aot_knob, bool no_hiprtc) {
     auto done = [&](int st, const std::string& why) { sp->why = why; sp->state.store(st, std::memory_order_release); };
     if (hipSetDevice(device) != hipSuccess) return done(3, "hipSetDevice failed");
+    std::string origin;
+    if (jit_load_cached(cache_dir, aot_knob, src, &sp->mod, &sp->fn, &origin)) return done(2, origin);
+    sp->mod = nullptr; sp->fn = nullptr;
     Hiprtc& rtc = hiprtc();
-    if (!rtc.lib) return done(3, rtc.why);
+    if (no_hiprtc || !rtc.lib) return done(3, no_hiprtc ? "no shipped code object for this shape, and the run-time compiler is treated as absent (GGRS_NO_HIPRTC=1)" : rtc.why);
     std::vector<char> image;
-    const std::string path = jit_disk_path_in(cache_dir, src);
-    if (!path.empty()) if (FILE* f = fopen(path.c_str(), "rb")) {
-        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
-        if (n > 0) { image.resize((size_t)n); if (fread(image.data(), 1, (size_t)n, f) != (size_t)n) image.clear(); }
-        fclose(f);
-        if (!image.empty() && !(hipModuleLoadData(&sp->mod, image.data()) == hipSuccess && hipModuleGetFunction(&sp->fn, sp->mod, "ggrs_jit_tick") == hipSuccess)) {
-            if (sp->mod) { (void)hipModuleUnload(sp->mod); sp->mod = nullptr; }
-            sp->fn = nullptr; image.clear(); (void)hipGetLastError();
-        }
-    }
-    if (!sp->fn) {
+    {
         std::lock_guard<std::mutex> compile_lock(g_hiprtc_mu);
         hiprtcProgram prog = nullptr;
         if (rtc.create(&prog, src.c_str(), "ggrs_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return done(3, "hiprtcCreateProgram failed");
@@ -915,12 +1140,13 @@ void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_
             sp->fn = nullptr; (void)hipGetLastError();
             return done(3, "the specialised kernel's code object does not load");
         }
-        if (!path.empty()) {
-            const std::string tmp = path + ".tmp" + std::to_string((long long)getpid()) + "s";
-            if (FILE* f = fopen(tmp.c_str(), "wb")) { const bool w_ok = fwrite(image.data(), 1, image.size(), f) == image.size(); fclose(f); if (w_ok) (void)rename(tmp.c_str(), path.c_str()); else (void)remove(tmp.c_str()); }
-        }
     }
-    done(2, "");
+    const std::string path = jit_disk_path_in(cache_dir, src);
+    if (!path.empty()) {
+        const std::string tmp = path + ".tmp" + std::to_string((long long)getpid()) + "s";
+        if (FILE* f = fopen(tmp.c_str(), "wb")) { const bool w_ok = fwrite(image.data(), 1, image.size(), f) == image.size(); fclose(f); if (w_ok) (void)rename(tmp.c_str(), path.c_str()); else (void)remove(tmp.c_str()); }
+    }
+    done(2, "hiprtc");
 }
 // Worker threads still building when the PROCESS exits (a host that never destroyed its world; Python's interpreter shutdown without
 // World.close) would run hiprtc and the HIP runtime into static destruction.  Every spec that owns a thread is listed here and an atexit

@@ -699,4 +699,12 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
     }
 }
 
+// ------------------------------------------------------------------ k_ff_fold
+// Fold-forward without a following request-group launch (ff_flush): one 256-thread workgroup per partial row of the LAST launch
+// (device_prelude.hpp ff_fold_row) -- the value, then its tag, into pinned host memory.
+struct FfArgs { const uint64_t* rows; uint64_t* out; uint64_t seq; uint32_t nvals, g, stride, nc1; };
+__global__ __launch_bounds__(TPB) void k_ff_fold(FfArgs f) {
+    if (blockIdx.x < f.nvals) ff_fold_row(f.rows + (uint64_t)blockIdx.x * f.stride, f.g, (blockIdx.x % f.nc1) == f.nc1 - 1u, f.out + blockIdx.x, f.out + f.nvals + blockIdx.x, f.seq);
+}
+
 }  // namespace ggrs

@@ -190,7 +190,7 @@ class WorldBase:
         self._check(self._fn("load")(self._p, frame))
 
     def advance(self, inputs: Iterable[int] = (), dt_bits: int = 0, spawn_vx=None, spawn_vy=None):
-        inp = bytes(inputs)
+        inp, n_players = self._input_bytes(tuple(inputs))
         ia = (C.c_uint8 * max(1, len(inp)))(*inp)
         n = 0
         vx = vy = None
@@ -198,9 +198,27 @@ class WorldBase:
             vx = np.ascontiguousarray(spawn_vx, dtype=np.float32); vy = np.ascontiguousarray(spawn_vy, dtype=np.float32)
             n = vx.size
         self._check(self._fn("advance")(
-            self._p, dt_bits, ia, len(inp), n,
+            self._p, dt_bits, ia, n_players, n,
             vx.ctypes.data_as(C.POINTER(C.c_float)) if n else None,
             vy.ctypes.data_as(C.POINTER(C.c_float)) if n else None))
+
+    input_bytes = 1
+
+    def _input_bytes(self, inputs):
+        """PlayerInputs -> (the bytes the ABI wants, number of players): one int per player for one-byte inputs, else `input_bytes` bytes per
+        player as bytes objects / int sequences."""
+        ib = self.input_bytes
+        if ib == 1 and all(isinstance(x, (int, np.integer)) for x in inputs):
+            b = bytes(int(x) & 0xFF for x in inputs)
+            return b, len(b)
+        out = b"".join(bytes(x) if not isinstance(x, (int, np.integer)) else int(x).to_bytes(ib, "little") for x in inputs)
+        assert len(out) == ib * len(inputs), f"every player's input must be {ib} bytes"
+        return out, len(inputs)
+
+    def set_input_layout(self, input_bytes: int, max_players: int = 16):
+        """PlayerInputs<T>: size_of::<T::Input>() and the players of the session (ggrs_hip_set_input_layout); before the first custom system."""
+        self._check(self._fn("set_input_layout")(self._p, input_bytes, max_players))
+        self.input_bytes = input_bytes
 
     def build_requests(self, requests):
         """Python request objects -> (ctypes array, keep-alive list, number of saves)."""
@@ -218,16 +236,28 @@ class WorldBase:
             elif isinstance(r, AdvanceFrame):
                 q.kind = _ffi.REQ_ADVANCE
                 q.dt_bits = r.dt_bits
-                inp = bytes(r.inputs)
+                inp, n_players = self._input_bytes(r.inputs)
                 if inp:
                     ia = (C.c_uint8 * len(inp))(*inp); keep.append(ia)
-                    q.inputs = C.cast(ia, C.POINTER(C.c_uint8)); q.n_inputs = len(inp)
+                    q.inputs = C.cast(ia, C.POINTER(C.c_uint8)); q.n_inputs = n_players
+                if r.status is not None and n_players:
+                    st = bytes(r.status); assert len(st) == n_players, "one InputStatus per player"
+                    sa = (C.c_uint8 * len(st))(*st); keep.append(sa)
+                    q.status = C.cast(sa, C.POINTER(C.c_uint8))
                 if r.spawn_vx is not None and len(r.spawn_vx):
                     vx = np.ascontiguousarray(r.spawn_vx, dtype=np.float32); vy = np.ascontiguousarray(r.spawn_vy, dtype=np.float32)
                     keep += [vx, vy]
                     q.spawn_count = vx.size
                     q.spawn_vx = vx.ctypes.data_as(C.POINTER(C.c_float))
                     q.spawn_vy = vy.ctypes.data_as(C.POINTER(C.c_float))
+                if r.spawn_count:
+                    q.spawn_count = int(r.spawn_count)
+                if r.spawn_payload is not None:
+                    pl = np.ascontiguousarray(np.frombuffer(r.spawn_payload, dtype=np.uint8) if isinstance(r.spawn_payload, (bytes, bytearray)) else np.asarray(r.spawn_payload)).view(np.uint8).reshape(-1)
+                    if pl.size:
+                        keep.append(pl)
+                        q.spawn_payload = pl.ctypes.data
+                        q.spawn_payload_bytes = pl.size
             else:
                 raise TypeError(r)
         return arr, keep, n_save
@@ -280,11 +310,39 @@ class World(WorldBase):
         for i, v in enumerate(fparam): d.fparam[i] = v
         self._check(self._lib.ggrs_hip_add_custom_system(self._p, C.byref(d)))
 
-    def generated_kernel_source(self, compile: bool = False, persistent: bool = False, steady: bool = False) -> str:
-        """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source), in its
-        per-tile form or its persistent form; with compile=True it is also built for gfx950 with hiprtc.  Works on a
+    def add_spawn_system(self, source: str, bundle: Sequence[int], bindings: Sequence[tuple] = (), payload_stride: int = 0, iparam=(), fparam=(), name: str = "spawn"):
+        """add_systems(GgrsSchedule, <a system that spawns Rollback entities>) (ggrs_hip_add_spawn_system): `source` defines
+        `__device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload)`, `bundle` = the
+        components a spawned entity has, `bindings` = [(comp, word), ..] the words the spawner writes (e.f32(i) ..); how many
+        entities a frame spawns is AdvanceFrame.spawn_count, what they read AdvanceFrame.spawn_payload."""
+        d = _ffi.SpawnSystemDesc()
+        d.name, d.source, d.n_bindings, d.payload_stride = name.encode(), source.encode(), len(bindings), payload_stride
+        d.bundle_mask = sum(1 << c for c in bundle)
+        for i, (c, w) in enumerate(bindings): d.comp[i], d.word[i] = c, w
+        for i, v in enumerate(iparam): d.iparam[i] = v
+        for i, v in enumerate(fparam): d.fparam[i] = v
+        self._check(self._lib.ggrs_hip_add_spawn_system(self._p, C.byref(d)))
+
+    def register_component_strategy(self, comp: int, stored_word_bytes: int, stored_n_words: int, source: str):
+        """ComponentSnapshotPlugin<S: Strategy> with a user-written S (ggrs_hip_register_component_strategy): snapshots hold
+        stored_n_words words of stored_word_bytes; `source` defines ggrs_store(const GgrsWords& target, GgrsWords& stored) and
+        ggrs_load(const GgrsWords& stored, GgrsWords& target)."""
+        self._check(self._lib.ggrs_hip_register_component_strategy(self._p, comp, stored_word_bytes, stored_n_words, source.encode()))
+
+    def host_timeline(self, enable: int = -1) -> dict:
+        """ggrs_hip_host_timeline: where the host spends a tick (microseconds since the timeline was enabled); enable 1 = reset + start, 0 = stop."""
+        us = (C.c_double * _ffi.TIMELINE_FIELDS)(); cnt = (C.c_uint64 * 3)()
+        self._check(self._lib.ggrs_hip_host_timeline(self._p, enable, us, cnt))
+        names = ["enqueue_us", "validate_us", "launch_call_us", "collect_us", "event_wait_us", "tag_wait_us", "host_fold_us"]
+        out = {n: float(us[i]) for i, n in enumerate(names)}
+        out.update(enqueue_calls=int(cnt[0]), collect_calls=int(cnt[1]), launches=int(cnt[2]))
+        return out
+
+    def generated_kernel_source(self, compile: bool = False, steady: bool = False) -> str:
+        """The request-group kernel the library writes for this world at seal (ggrs_hip_generated_kernel_source); steady=True: the copy
+        specialised for the world's steady SyncTest tick; with compile=True it is also built for gfx950 with hiprtc.  Works on a
         GGRS_WORLD_LAYOUT_ONLY world (no GPU)."""
-        form = _ffi.KERNEL_FORM_STEADY if steady else _ffi.KERNEL_FORM_PERSISTENT if persistent else _ffi.KERNEL_FORM_TILES   # steady: the copy specialised for the SyncTest tick
+        form = _ffi.KERNEL_FORM_STEADY if steady else _ffi.KERNEL_FORM_TILES
         need = C.c_uint64(0)
         self._check(self._lib.ggrs_hip_generated_kernel_source(self._p, form, None, 0, C.byref(need), 0))
         buf = C.create_string_buffer(need.value)

@@ -392,6 +392,7 @@ struct HipBackend {
     int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
     int set_confirmed(int has, int32_t f) { return ggrs_hip_set_confirmed(w, has, f); }
     int set_synctest_check_distance(int32_t cd) { return ggrs_hip_set_synctest_check_distance(w, cd); }
+    int set_input_layout(uint32_t input_bytes, uint32_t max_players) { return ggrs_hip_set_input_layout(w, input_bytes, max_players); }
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) { return ggrs_hip_handle_requests(w, r, n, out); }
     int enqueue_requests(const ggrs_request* r, uint32_t n) { return ggrs_hip_enqueue_requests(w, r, n, nullptr); }
     int collect_checksums(uint64_t* out, uint32_t max_saves) { return ggrs_hip_collect_checksums(w, out, max_saves, nullptr); }
@@ -422,7 +423,12 @@ class App {
     // after `RollbackFrameCount += 1` (schedule_systems.rs:254-268).
     using HostSystem = std::function<void(App&, const PlayerInputs<C>&)>;
 
-    explicit App(uint64_t capacity, uint32_t max_depth = 16, int device = 0) : be_(capacity, max_depth, device), max_depth_(max_depth) {}
+    explicit App(uint64_t capacity, uint32_t max_depth = 16, int device = 0) : be_(capacity, max_depth, device), max_depth_(max_depth) {
+        // PlayerInputs<C>: size_of::<C::Input>() plain bytes + one InputStatus byte per player reach the device systems (src/lib.rs:98)
+        using Input = typename C::Input;
+        static_assert(std::is_trivially_copyable<Input>::value && sizeof(Input) <= GGRS_MAX_INPUT_BYTES, "T::Input reaches the device as its plain bytes (ggrs_hip_set_input_layout)");
+        if (sizeof(Input) != 1 && be_.set_input_layout((uint32_t)sizeof(Input), GGRS_MAX_PLAYERS) != GGRS_OK) throw std::runtime_error(be_.last_error());
+    }
 
     // ---- App::add_plugins(GgrsPlugin::<C>::default())
     App& add_plugins(GgrsPlugin<C>) { plugin_ = true; return *this; }
@@ -628,7 +634,8 @@ class App {
     // ---- handle_requests (src/schedule_systems.rs:170-289): the whole list is ONE device submission
     void handle_requests(std::vector<GgrsRequest<C>>& requests) {
         std::vector<ggrs_request> reqs(requests.size());
-        std::vector<std::vector<uint8_t>> input_bytes; input_bytes.reserve(requests.size());
+        std::vector<std::vector<uint8_t>> input_bytes; input_bytes.reserve(2 * requests.size());     // per AdvanceFrame: the inputs' bytes, then the status bytes
+        using Input = typename C::Input;
         std::vector<std::vector<float>> payload; payload.reserve(2 * requests.size());
         std::vector<GgrsRequest<C>*> saves;
         Frame cur = be_.frame();
@@ -655,10 +662,16 @@ class App {
                 load_resources(cur);
                 break;
             case GgrsRequest<C>::AdvanceFrame: {
-                input_bytes.emplace_back();
+                // PlayerInputs<T>(Vec<(T::Input, InputStatus)>) (src/lib.rs:98): every player's input bytes, then every player's status
+                input_bytes.emplace_back(); input_bytes.emplace_back();
+                auto& ibytes = input_bytes[input_bytes.size() - 2]; auto& sbytes = input_bytes[input_bytes.size() - 1];
                 bool pressed = false;
-                for (auto& in : r.inputs) { uint8_t b; std::memcpy(&b, &in.first, 1); input_bytes.back().push_back(b); pressed |= (b & spawn_mask_) != 0; }
-                q.inputs = input_bytes.back().data(); q.n_inputs = (uint32_t)input_bytes.back().size();
+                for (auto& in : r.inputs) {
+                    uint8_t b[sizeof(Input)]; std::memcpy(b, &in.first, sizeof(Input));
+                    ibytes.insert(ibytes.end(), b, b + sizeof(Input)); sbytes.push_back((uint8_t)in.second);
+                    pressed |= (b[0] & spawn_mask_) != 0;
+                }
+                q.inputs = ibytes.data(); q.status = sbytes.data(); q.n_inputs = (uint32_t)r.inputs.size();
                 if (has_spawn_system_ && pressed && spawn_source_) {
                     payload.emplace_back(); payload.emplace_back();
                     auto& vx = payload[payload.size() - 2]; auto& vy = payload[payload.size() - 1];

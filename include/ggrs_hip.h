@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 7
+#define GGRS_HIP_ABI_VERSION 8
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 16
@@ -40,6 +40,7 @@ extern "C" {
 #define GGRS_MAX_CKS_UNITS  32
 #define GGRS_MAX_SYSTEMS    16
 #define GGRS_MAX_PLAYERS    16
+#define GGRS_MAX_INPUT_BYTES 16   /* bytes of one player's T::Input (POD) */
 
 /* error codes */
 #define GGRS_OK             0
@@ -70,19 +71,6 @@ typedef struct {
 #define GGRS_WORLD_UNFUSED      2u   /* one kernel per reference system (save/checksum split)  */
 #define GGRS_WORLD_NT_COPY      4u   /* snapshot copies use non-temporal loads/stores           */
 #define GGRS_WORLD_NO_GROUPS    8u   /* one launch per request: no [Load?](Save|Advance)* fusion  */
-#define GGRS_WORLD_CONTIG_ARENA 32u  /* allocate the library-owned arena physically contiguous (hipDeviceMallocContiguous; the
-                                        particles worlds, up to 1.5 GiB): write-through memory.  It paid +2-3 % for
-                                        round 3's hand-written k_tick3 (removed in round 4); the generated kernel that serves every
-                                        world now is FASTER on plain pages (1 M: 169 vs 149 G entity-frames/s), so nothing in the
-                                        library asks for it any more.  OPT-IN, with two rules the library enforces itself
-                                        (profiles/README.md r03fc, tests/test_gpu_contig_arena.py):
-                                        - a contiguous arena is never handed back while the process lives.  After hipFree of
-                                          such an allocation the runtime stops ordering the kernels of LATER worlds on the
-                                          device (a paged world opened next computed on stale state on 6 of 6 fresh boxes;
-                                          HIP_LAUNCH_BLOCKING=1 / AMD_DIRECT_DISPATCH=0 hide it, cache flushes do not).  A
-                                          closed world parks its arena; the next world that asks for one reuses it;
-                                        - a NEW contiguous allocation is made only while the process has not freed a paged
-                                          arena of its own (round 2's reading of the same failures; kept as a second net).   */
 #define GGRS_WORLD_LAYOUT_ONLY 16u   /* no device: registration, layout and ggrs_hip_generated_kernel_source only (every
                                         call that would touch the GPU returns GGRS_E_NO_DEVICE) -- a build machine can check
                                         that a schema and its custom systems compile for gfx950 before they are deployed   */
@@ -186,17 +174,20 @@ int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* desc);
  *                                               4-byte words as f32/u32/i32, 8-byte words as u64), written back afterwards
  *   e.slot                                      the entity's RollbackOrdered index (snapshot/rollback.rs:69-74)
  *   e.despawn() / e.despawn_rollback()          commands.entity(e).despawn() / .despawn_rollback() (snapshot/despawn.rs:114-143)
- *   f.dt  f.frame  f.n_inputs  f.input[16]      Time<GgrsTime>::delta_secs (time.rs), the frame being simulated,
- *                                               PlayerInputs (one byte per handle; schedule_systems.rs:262-265)
+ *   f.dt  f.frame  f.n_inputs                   Time<GgrsTime>::delta_secs (time.rs), the frame being simulated, PlayerInputs::len()
+ *   f.input[h]                                  first byte of player h's input (the whole input of a Config<Input = u8> session)
+ *   f.input_u8(h) / _u16(h) / _u32(h) / _u64(h) player h's T::Input, little-endian (ggrs_hip_set_input_layout: 1..16 bytes); f.input_ptr(h): its bytes
+ *   f.input_status(h)                           GGRS_INPUT_CONFIRMED / _PREDICTED / _DISCONNECTED (PlayerInputs<T>: (T::Input, InputStatus), src/lib.rs:98)
  *   f.fparam[4]  f.iparam[2]                    the desc's constants
  *
  * The system runs for every live entity that has all bound components, in registration order with the other systems;
  * despawns take effect before the next system, as with the built-in kinds.  The code is compiled with -ffp-contract=off
  * and correctly rounded fp32 divide/sqrt: what the source says is what runs, bit for bit, on every rank and every replay
  * -- determinism is the author's contract exactly as it is for a Bevy system (no atomics, no cross-entity reads).
- * A world with a custom system is stepped request by request (one launch per system; the fused k_tick* kernels only
- * know the built-in kinds).  A compile error returns GGRS_E_INVALID with the compiler log in ggrs_hip_last_error. */
+ * The system is inlined into the request-group kernel the library generates for the world (and compiled as a kernel of its own for the
+ * one-launch-per-request path).  A compile error returns GGRS_E_INVALID with the compiler log in ggrs_hip_last_error. */
 #define GGRS_SYS_CUSTOM 7u
+#define GGRS_SYS_SPAWN_CUSTOM 8u   /* a user-written spawn system: ggrs_hip_add_spawn_system below (not a kind for ggrs_hip_add_system) */
 #define GGRS_CUSTOM_MAX_BINDINGS 8
 typedef struct {
     const char* name;                               /* for error messages and traces; may be NULL               */
@@ -209,22 +200,76 @@ typedef struct {
 } ggrs_custom_system_desc;
 int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* desc);
 
-/* The request-group kernel the library WRITES for a world when it is sealed (DESIGN.md 4.2): one slot per lane, every
+/* ComponentSnapshotPlugin<S: Strategy> (snapshot/strategy.rs:22-40, component_snapshot.rs:42-63): what a snapshot HOLDS of a component is
+ * S::Stored, produced by S::store and turned back by S::load / S::update -- CopyStrategy / CloneStrategy (Stored == the component, bitwise for
+ * POD) are what ggrs_hip_register_component gives; this is the open door next to them: quantised, packed or partial snapshots.
+ * `source` is HIP C++ defining BOTH
+ *
+ *     __device__ void ggrs_store(const GgrsWords& target, GgrsWords& stored);    // Strategy::store(&Target) -> Stored
+ *     __device__ void ggrs_load(const GgrsWords& stored, GgrsWords& target);     // Strategy::load (::update defaults to `*target = load(stored)`, strategy.rs:37-39): `target` arrives zeroed
+ *
+ *   GgrsWords: w.f32(i) / .u32(i) / .i32(i) / .u64(i) / .u16(i) / .u8(i) -- word i of the value (references on the non-const side)
+ *
+ * The ring slots then hold stored_n_words words of stored_word_bytes per entity for this component instead of its own words (bytes per SaveWorld
+ * drop accordingly: ggrs_hip_profile_read_bytes counts the Stored form), the live block holds the component; checksums hash the live component,
+ * as the reference's do.  store / load run inside the generated request-group kernel under the library's floating-point contract; a world with
+ * such a component needs that kernel (GGRS_E_INVALID at seal without it).  Row versions treat the component as a whole: it is stored
+ * when any of its words may have changed. */
+int ggrs_hip_register_component_strategy(ggrs_world* w, uint32_t comp_id, uint32_t stored_word_bytes, uint32_t stored_n_words, const char* source);
+
+/* PlayerInputs<T>(Vec<(T::Input, InputStatus)>) (src/lib.rs:98, inserted before every AdvanceWorld: schedule_systems.rs:262-265).
+ * input_bytes = size_of::<T::Input>() (POD, 1..16; default 1: Config<Input = u8>), max_players = players of the session (1..16; default 16).
+ * Must precede the first custom / spawn system. */
+#define GGRS_INPUT_CONFIRMED    0   /* ggrs::InputStatus::Confirmed    */
+#define GGRS_INPUT_PREDICTED    1   /* ggrs::InputStatus::Predicted    */
+#define GGRS_INPUT_DISCONNECTED 2   /* ggrs::InputStatus::Disconnected */
+int ggrs_hip_set_input_layout(ggrs_world* w, uint32_t input_bytes, uint32_t max_players);
+
+/* A user-written GgrsSchedule system that SPAWNS Rollback entities -- `commands.spawn((.., Rollback))` from any system of the schedule
+ * (snapshot/rollback.rs:45-59; examples/stress_tests/particles.rs:254-270 is the built-in GGRS_SYS_PARTICLES_SPAWN).  How many entities a frame
+ * spawns is decided on the host, per AdvanceFrame (ggrs_request::spawn_count: the host sees the inputs the system would look at); what they are
+ * is `source`, HIP C++ defining
+ *
+ *     __device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload);
+ *
+ *   e            the k-th entity of this frame's spawn (0 <= k < spawn_count), every component of the bundle at its registered default
+ *                (ggrs_hip_set_component_default); e.f32(i) / e.u32(i) / .. = bound word i, written back afterwards; e.slot = its RollbackOrdered index
+ *   payload      the request's spawn_payload blob as the device sees it: + k * payload_stride when payload_stride != 0 (one record per entity),
+ *                the whole blob (spawn_payload_bytes) otherwise
+ *   f            as for ggrs_system: dt, frame, PlayerInputs, fparam / iparam
+ *
+ * The new entities are RollbackOrdered's next indices (== the next slots), appended after the frame's other systems ran (Bevy applies Commands
+ * at the end of the schedule), inside the request group's launch.  One spawn system per world.  Needs the generated kernel (GGRS_E_INVALID at
+ * seal without it). */
+typedef struct {
+    const char* name;                               /* for error messages and traces; may be NULL                                  */
+    const char* source;                             /* HIP C++ defining ggrs_spawn (NUL-terminated)                                */
+    uint64_t bundle_mask;                           /* bit c: the spawned entity has component c                                   */
+    uint32_t payload_stride;                        /* bytes of payload per spawned entity; 0: one blob per AdvanceFrame           */
+    uint32_t n_bindings;                            /* words the spawner writes (all of components in bundle_mask)                 */
+    uint32_t comp[GGRS_CUSTOM_MAX_BINDINGS];
+    uint32_t word[GGRS_CUSTOM_MAX_BINDINGS];
+    int64_t  iparam[2];
+    float    fparam[4];
+} ggrs_spawn_system_desc;
+int ggrs_hip_add_spawn_system(ggrs_world* w, const ggrs_spawn_system_desc* desc);
+
+/* The request-group kernel the library WRITES for a world when it is sealed (DESIGN.md 4.1): one slot per lane, every
  * registered word of the slot in a register, the GgrsSchedule systems -- built-in kinds and custom sources alike -- inlined
- * in registration order, every checksum spec (word lists and custom hashers) unrolled; compiled with hiprtc in two forms:
- * GGRS_KERNEL_FORM_TILES (one 256-slot workgroup per tile: worlds that live in cache; roles, batches, host-side fold) and
- * GGRS_KERNEL_FORM_PERSISTENT (as many 1024-thread workgroups as the device holds, checksum fold in the same launch:
- * HBM-sized worlds).  This returns that HIP C++ source (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed)
+ * in registration order, every checksum spec (word lists and custom hashers) unrolled, one 256-slot workgroup per tile (roles, batches,
+ * fold-forward); compiled with hiprtc -- or loaded from a shipped code object (`make -C bevy_ggrs_amd/csrc aot`; GGRS_AOT_DIR) when its text
+ * hashes to one.  This returns that HIP C++ source (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed)
  * bytes are copied.  compile != 0 also builds it for gfx950 (no device needed) and fails with the compiler log in
  * ggrs_hip_last_error if it does not build.  GGRS_E_INVALID: the world is outside what the generator covers (a system that
  * writes a live-only component, more than 64 four-byte register units or 64 words per entity).  Registration must be
- * complete; on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU. */
+ * complete; on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU.  docs/generated/ holds the text of the headline world in both forms. */
 #define GGRS_KERNEL_FORM_TILES      1u
-#define GGRS_KERNEL_FORM_PERSISTENT 2u
-#define GGRS_KERNEL_FORM_STEADY     3u   /* the per-tile form specialised for the steady SyncTest tick of this world ([Load, (Advance,
-                                            Save) x (max_depth - 1)], the rows its systems write, nt stores, first Save cached): what
-                                            ggrs_hip_specialise_wait waits for, here for inspection / a build-machine compile check */
+#define GGRS_KERNEL_FORM_STEADY     3u   /* the same kernel specialised for the steady SyncTest tick of this world at full length ([Load, Advance, (Save,
+                                            Advance) x (max_depth - 1)], the rows its systems write, the store / load / role policies of that size): what
+                                            ggrs_hip_specialise_wait waits for and what `make aot` ships, here for inspection / a build-machine compile check */
 int ggrs_hip_generated_kernel_source(ggrs_world* w, uint32_t form, char* buf, uint64_t cap, uint64_t* needed, int compile);
+/* the file name a shipped code object of `source` carries in the aot directory (scripts/aot_build.py): at least 40 bytes of buf */
+int ggrs_hip_aot_object_name(const char* source, char* buf, uint64_t cap);
 
 /* RollbackFrameRate (time.rs:20); default 60 (lib.rs:62). */
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps);
@@ -312,11 +357,14 @@ typedef struct {
     uint32_t kind;            /* GGRS_REQ_*                                                    */
     int32_t  frame;           /* SAVE: frame handed to cell.save; LOAD: frame to restore       */
     uint32_t dt_bits;         /* ADVANCE: f32 bits of Time::delta_secs, 0 = derive (time.rs)   */
-    uint32_t n_inputs;        /* ADVANCE: PlayerInputs length                                  */
-    const uint8_t* inputs;    /* ADVANCE: one input byte per player (status ignored)           */
-    uint64_t spawn_count;     /* ADVANCE: rows the PARTICLES_SPAWN system appends if pressed   */
-    const float* spawn_vx;    /*   host arrays of spawn_count f32 (host-side ParticleRng draw) */
+    uint32_t n_inputs;        /* ADVANCE: PlayerInputs length (players)                        */
+    const uint8_t* inputs;    /* ADVANCE: n_inputs x input_bytes bytes: T::Input of every player (ggrs_hip_set_input_layout; default 1 byte each) */
+    const uint8_t* status;    /* ADVANCE: n_inputs InputStatus bytes (GGRS_INPUT_*), NULL = every input Confirmed                                  */
+    uint64_t spawn_count;     /* ADVANCE: entities the world's spawn system appends in this frame (PARTICLES_SPAWN: if its input bit is held)     */
+    const float* spawn_vx;    /*   GGRS_SYS_PARTICLES_SPAWN: host arrays of spawn_count f32 (host-side ParticleRng draw)                          */
     const float* spawn_vy;
+    const void* spawn_payload;     /* a user-written spawn system's payload (ggrs_hip_add_spawn_system): spawn_count x payload_stride bytes, or  */
+    uint64_t spawn_payload_bytes;  /*   one blob of this many bytes when payload_stride == 0                                                       */
 } ggrs_request;
 
 /* Executes a whole request list as one device submission (one stream sync at the end).
@@ -409,11 +457,17 @@ int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t kernel_class, float* 
  * versions) x the slots it covers -- the numerator of bench.py's roofline; size GGRS_KERNEL_CLASSES */
 int ggrs_hip_profile_read_bytes(ggrs_world* w, uint64_t* bytes_out);
 
+/* Where the HOST spends a tick: microseconds summed over the calls since the timeline was enabled.  enable: 1 = reset and start, 0 = stop, -1 = leave.
+ * us_out[GGRS_TIMELINE_FIELDS] = {enqueue calls, of them: request validation, of them: the launch calls into the HIP runtime, collect calls, of them: waiting
+ * for the batch's event, of them: waiting for fold-forward tags, of them: hashing / folding on the host}; counts_out[3] = {enqueue calls, collect calls, launches}. */
+#define GGRS_TIMELINE_FIELDS 7
+int ggrs_hip_host_timeline(ggrs_world* w, int enable, double* us_out, uint64_t* counts_out);
+
 /* -------------------------------------------------------------------------------------------
  * Introspection: which kernel serves this world's request lists right now and why, what kind of arena
  * it lives on, whether the run-time compiler (libhiprtc.so, dlopen'ed) is available.  `key=value` lines,
  * NUL-terminated; *needed = bytes incl. the NUL, min(cap, *needed) are copied.  Keys: sealed, arena,
- * arena_bytes, hiprtc, generated_kernel, request_group_kernel, specialised_kernel, slots_covered, row_versions.
+ * arena_bytes, hiprtc, generated_kernel, generated_kernel_origin, request_group_kernel, checksum_fold, kernarg_bytes, group_caps, specialised_kernel, slots_covered, row_versions.
  * ------------------------------------------------------------------------------------------- */
 int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t* needed);
 

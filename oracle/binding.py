@@ -21,6 +21,22 @@ FLAT, REFSHAPED = 0, 1
 HASH_FN = C.CFUNCTYPE(C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_void_p)
 
 
+class FrameView(C.Structure):
+    """What a user-written system sees of the frame (oracle/ggrs_oracle.cpp FrameView): dt, frame, PlayerInputs<T> bytes + InputStatus bytes, constants."""
+    _fields_ = [("dt", C.c_float), ("frame", C.c_int32), ("n_inputs", C.c_uint32), ("input_bytes", C.c_uint32),
+                ("inputs", C.POINTER(C.c_uint8)), ("status", C.POINTER(C.c_uint8)), ("fparam", C.c_float * 4), ("iparam", C.c_int64 * 2)]
+
+    def input(self, h: int) -> bytes:
+        ib = self.input_bytes
+        return bytes(self.inputs[h * ib:(h + 1) * ib])
+
+
+CUSTOM_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(FrameView), C.POINTER(C.c_int32), C.c_void_p)
+SPAWN_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(FrameView), C.POINTER(C.c_uint8), C.c_void_p)
+STORE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+LOAD_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+
+
 def build(force: bool = False):
     src = os.path.join(_HERE, "ggrs_oracle.cpp")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
@@ -84,6 +100,10 @@ def _load():
         "gor_advance": (C.c_int, [P, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint64,
                                   C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "gor_handle_requests": (C.c_int, [P, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64)]),
+        "gor_set_input_layout": (C.c_int, [P, C.c_uint32, C.c_uint32]),
+        "gor_add_custom_system": (C.c_int, [P, CUSTOM_FN, P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
+        "gor_add_spawn_system": (C.c_int, [P, SPAWN_FN, P, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
+        "gor_register_component_strategy": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, STORE_FN, LOAD_FN, P]),
         "gor_bench_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32]),
         "gor_replay_synctest": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
         "gor_replay_synctest_from": (C.c_double, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -134,6 +154,53 @@ class OracleWorld(WorldBase):
         cb = HASH_FN(lambda p, slot, _u: int(fn(bytes(p[:nbytes]), int(slot))) & 0xFFFFFFFFFFFFFFFF)
         self._keep = getattr(self, "_keep", []) + [cb]
         self._check(lib.gor_checksum_component_custom(self._p, comp, cb, None))
+
+    # ---- user-written systems / spawners / strategies as Python callbacks (one call per entity: small worlds only)
+    def _params(self, iparam, fparam):
+        ip = (C.c_int64 * 2)(*(list(iparam) + [0, 0])[:2]); fp = (C.c_float * 4)(*(list(fparam) + [0, 0, 0, 0])[:4])
+        return ip, fp
+
+    def add_custom_system(self, fn, bindings, iparam=(), fparam=(), name: str = "custom"):
+        """fn(words: list[int], slot: int, frame: FrameView) -> (new words, kill) with kill 0 / 1 = despawn() / 2 = despawn_rollback()."""
+        n = len(bindings)
+
+        def thunk(words, slot, f, kill, _u):
+            new, k = fn([int(words[i]) for i in range(n)], int(slot), f.contents)
+            for i in range(n): words[i] = int(new[i]) & 0xFFFFFFFFFFFFFFFF
+            kill[0] = int(k)
+        cb = CUSTOM_FN(thunk)
+        self._keep = getattr(self, "_keep", []) + [cb]
+        comp = (C.c_uint32 * n)(*[c for c, _ in bindings]); word = (C.c_uint32 * n)(*[w for _, w in bindings])
+        ip, fp = self._params(iparam, fparam)
+        self._check(lib.gor_add_custom_system(self._p, cb, None, n, comp, word, ip, fp))
+
+    def add_spawn_system(self, fn, bundle, bindings=(), payload_stride: int = 0, iparam=(), fparam=(), name: str = "spawn"):
+        """fn(words: list[int], slot: int, k: int, frame: FrameView, payload: ctypes pointer to the entity's record) -> new words."""
+        n = len(bindings)
+
+        def thunk(words, slot, k, f, payload, _u):
+            new = fn([int(words[i]) for i in range(n)], int(slot), int(k), f.contents, payload)
+            for i in range(n): words[i] = int(new[i]) & 0xFFFFFFFFFFFFFFFF
+        cb = SPAWN_FN(thunk)
+        self._keep = getattr(self, "_keep", []) + [cb]
+        comp = (C.c_uint32 * max(1, n))(*[c for c, _ in bindings]); word = (C.c_uint32 * max(1, n))(*[w for _, w in bindings])
+        ip, fp = self._params(iparam, fparam)
+        self._check(lib.gor_add_spawn_system(self._p, cb, None, sum(1 << c for c in bundle), payload_stride, n, comp, word, ip, fp))
+
+    def register_component_strategy(self, comp: int, stored_word_bytes: int, stored_n_words: int, store, load):
+        """store(target words: list[int]) -> stored words; load(stored words: list[int]) -> target words (Strategy::store / ::load)."""
+        _, _wb, nw = self._comps[comp]
+
+        def st(tg, out, _u):
+            r = store([int(tg[i]) for i in range(nw)])
+            for i in range(stored_n_words): out[i] = int(r[i]) & 0xFFFFFFFFFFFFFFFF
+
+        def ld(sv, out, _u):
+            r = load([int(sv[i]) for i in range(stored_n_words)])
+            for i in range(nw): out[i] = int(r[i]) & 0xFFFFFFFFFFFFFFFF
+        cbs, cbl = STORE_FN(st), LOAD_FN(ld)
+        self._keep = getattr(self, "_keep", []) + [cbs, cbl]
+        self._check(lib.gor_register_component_strategy(self._p, comp, stored_word_bytes, stored_n_words, cbs, cbl, None))
 
     @staticmethod
     def sea_hasher():

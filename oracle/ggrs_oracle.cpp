@@ -195,7 +195,22 @@ enum SystemKind : uint32_t {
     SYS_ADD_U32 = 4,            // benches/bench.rs:30-46, tests/component_rollback.rs:24-28
     SYS_SAT_SUB_DESPAWN = 5,    // tests/synctest.rs:37-44
     SYS_BOX_MOVE = 6,           // examples/box_game/box_game.rs:154-206
+    SYS_CUSTOM = 7,             // any per-entity GgrsSchedule system the test hands in as a C callback (lib.rs:76, 247-251)
+    SYS_SPAWN_CUSTOM = 8,       // a system that spawns Rollback entities (rollback.rs:45-59), as a C callback
 };
+
+// What a user-written system sees of the frame: Time<GgrsTime>::delta_secs, RollbackFrameCount, PlayerInputs<T> (src/lib.rs:98:
+// (T::Input, InputStatus) per player -- `inputs` = n_inputs x input_bytes bytes, `status` = n_inputs bytes, never NULL here), the system's constants
+struct FrameView { float dt; int32_t frame; uint32_t n_inputs, input_bytes; const uint8_t* inputs; const uint8_t* status; float fparam[4]; int64_t iparam[2]; };
+// words: the bound words of ONE entity widened to u64 (written back narrowed to the word's width); *kill = 1: despawn(), 2: despawn_rollback()
+typedef void (*CustomSysFn)(uint64_t* words, uint64_t slot, const FrameView* f, int32_t* kill, void* user);
+// the k-th entity of this frame's spawn: words = the bound words, holding the bundle's registered defaults; payload = the request's blob (+ k * stride)
+typedef void (*SpawnSysFn)(uint64_t* words, uint64_t slot, uint64_t k, const FrameView* f, const uint8_t* payload, void* user);
+// Strategy::store / Strategy::load (strategy.rs:22-40) over words widened to u64; `target` of load arrives zeroed
+typedef void (*StoreFn)(const uint64_t* target, uint64_t* stored, void* user);
+typedef void (*LoadFn)(const uint64_t* stored, uint64_t* target, void* user);
+struct CustomSys { CustomSysFn fn = nullptr; void* user = nullptr; uint32_t n_bind = 0, comp[8] = {}, word[8] = {}; };
+struct SpawnSys { SpawnSysFn fn = nullptr; void* user = nullptr; uint64_t bundle_mask = 0; uint32_t payload_stride = 0, n_bind = 0, comp[8] = {}, word[8] = {}; };
 
 struct SystemDesc {            // must match include/ggrs_hip.h ggrs_system_desc
     uint32_t kind;
@@ -215,6 +230,9 @@ struct Comp {
     bool checksummed = false;
     std::vector<uint8_t> defaults;            // n_words*word_bytes default value (zeros unless set)
     bool no_rollback = false;                 // not registered for rollback: outside every snapshot (despawn.rs:3-6)
+    // ComponentSnapshotPlugin<S: Strategy> with a user-written S (strategy.rs:22-40): snapshots hold Stored = s_n_words words of s_word_bytes
+    uint32_t s_word_bytes = 0, s_n_words = 0;
+    StoreFn store_fn = nullptr; LoadFn load_fn = nullptr; void* strat_user = nullptr;
 };
 
 static inline bool bit(const std::vector<uint64_t>& m, uint64_t i) { return (m[i >> 6] >> (i & 63)) & 1ULL; }
@@ -226,6 +244,7 @@ static inline void setbit(std::vector<uint64_t>& m, uint64_t i, bool v) {
 // lock-step -- same push/rollback/confirm/depth -- so one ring of world snapshots is
 // equivalent; mod.rs:340-345, component_snapshot.rs:133-146, entity.rs:103-118) ----
 struct FlatSnap {
+    std::vector<std::vector<uint64_t>> stored;  // per component under a Strategy: len * s_n_words Stored words (narrowed to s_word_bytes), else empty
     std::vector<std::vector<uint8_t>> cols;   // per (comp,word) column, len*word_bytes bytes
     std::vector<uint64_t> alive;
     std::vector<std::vector<uint64_t>> present;
@@ -284,6 +303,9 @@ struct World {
     uint64_t capacity = 0;
     std::vector<Comp> comps;
     std::vector<SystemDesc> systems;
+    std::vector<CustomSys> customs;            // SYS_CUSTOM: systems[i].comp[0] indexes this
+    std::vector<SpawnSys> spawn_customs;       // SYS_SPAWN_CUSTOM: likewise
+    uint32_t input_bytes = 1, max_players = 16;   // PlayerInputs<T>: size_of::<T::Input>()
     bool sealed = false;
 
     // live state (FLAT layout is authoritative in both modes for download/compare;
@@ -492,7 +514,46 @@ struct AdvanceArgs {
     uint32_t dt_bits;
     const uint8_t* inputs; uint32_t n_inputs;
     uint64_t spawn_count; const float* spawn_vx; const float* spawn_vy;
+    const uint8_t* status = nullptr;                       // InputStatus per player; NULL: all Confirmed
+    const uint8_t* spawn_payload = nullptr; uint64_t spawn_payload_bytes = 0;
 };
+static inline uint64_t word_mask(uint32_t wb) { return wb >= 8 ? ~0ULL : ((1ULL << (8 * wb)) - 1ULL); }
+static inline uint64_t load_word(const World& w, uint32_t c, uint32_t k, uint64_t i) {
+    uint64_t v = 0; memcpy(&v, &w.cols[w.col_base[c] + k][i * w.comps[c].word_bytes], w.comps[c].word_bytes); return v;
+}
+static inline void store_word(World& w, uint32_t c, uint32_t k, uint64_t i, uint64_t v) {
+    memcpy(&w.cols[w.col_base[c] + k][i * w.comps[c].word_bytes], &v, w.comps[c].word_bytes);
+}
+static void ref_sync_to_flat(World& w);
+static void ref_sync_from_flat(World& w, uint64_t first, uint64_t count);
+static inline void despawn_rollback_one(World& w, uint64_t i);
+static FrameView frame_view(const World& w, const AdvanceArgs& a, const SystemDesc& s, const uint8_t* zero_status) {
+    FrameView f; memset(&f, 0, sizeof f);
+    memcpy(&f.dt, &a.dt_bits, 4); f.frame = w.frame; f.n_inputs = a.n_inputs; f.input_bytes = w.input_bytes;
+    f.inputs = a.inputs; f.status = a.status ? a.status : zero_status;
+    for (int k = 0; k < 4; ++k) f.fparam[k] = s.fparam[k];
+    f.iparam[0] = s.iparam[0]; f.iparam[1] = s.iparam[1];
+    return f;
+}
+// a user-written per-entity system: Query<(&mut A, &mut B, ..), With<Rollback>> + Commands, one entity at a time, in slot order
+static void run_custom_system(World& w, const AdvanceArgs& a, const SystemDesc& s) {
+    static const uint8_t zero_status[16] = {0};
+    const CustomSys& cs = w.customs[s.comp[0]];
+    const FrameView f = frame_view(w, a, s, zero_status);
+    if (w.mode == 1) ref_sync_to_flat(w);
+    for (uint64_t i = 0; i < w.len; ++i) {
+        if (!bit(w.alive, i)) continue;
+        bool has = true;
+        for (uint32_t b = 0; b < cs.n_bind; ++b) has = has && bit(w.present[cs.comp[b]], i);
+        if (!has) continue;
+        uint64_t words[8]; int32_t kill = 0;
+        for (uint32_t b = 0; b < cs.n_bind; ++b) words[b] = load_word(w, cs.comp[b], cs.word[b], i);
+        cs.fn(words, i, &f, &kill, cs.user);
+        for (uint32_t b = 0; b < cs.n_bind; ++b) store_word(w, cs.comp[b], cs.word[b], i, words[b]);
+        if (kill == 2) despawn_rollback_one(w, i); else if (kill) setbit(w.alive, i, false);
+    }
+    if (w.mode == 1) ref_sync_from_flat(w, 0, w.len);
+}
 
 template <class GetW, class SetW>
 static inline void particles_update_one(float dt, const float g[3], GetW get, SetW set) {
@@ -601,6 +662,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
                 if (p[i] == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
             }
         } break;
+        case SYS_CUSTOM: run_custom_system(w, a, s); break;
         case SYS_BOX_MOVE: {
             uint32_t ct = s.comp[0], cv = s.comp[1], cp = s.comp[2];
             float dt = f32_of(a.dt_bits);
@@ -614,7 +676,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
                 uint64_t i = (uint64_t)ii;
                 if (!bit(w.alive, i) || !bit(w.present[ct], i) || !bit(w.present[cv], i) || !bit(w.present[cp], i)) continue;
                 if (handle[i] >= a.n_inputs) continue;          // inputs[p.handle] out of range: the reference panics
-                box_move_one(dt, s.fparam, a.inputs[handle[i]],
+                box_move_one(dt, s.fparam, a.inputs[handle[i] * w.input_bytes],
                     [&](int which, int k) { return which ? vv[k][i] : tx[k][i]; },
                     [&](int which, int k, float v) { (which ? vv[k][i] : tx[k][i]) = v; });
             }
@@ -627,7 +689,7 @@ static void advance_flat(World& w, const AdvanceArgs& a) {
     for (const SystemDesc& s : w.systems) {
         if (s.kind != SYS_PARTICLES_SPAWN) continue;
         bool pressed = false;                       // spawn_pressed, particles.rs:254-256
-        for (uint32_t k = 0; k < a.n_inputs; ++k) pressed |= (a.inputs[k] & (uint8_t)s.iparam[1]) != 0;
+        for (uint32_t k = 0; k < a.n_inputs; ++k) pressed |= (a.inputs[(size_t)k * w.input_bytes] & (uint8_t)s.iparam[1]) != 0;
         if (!pressed || a.spawn_count == 0) continue;
         uint32_t ct = s.comp[0], cv = s.comp[1], cl = s.comp[2];
         uint64_t first = 0;
@@ -688,6 +750,7 @@ static void advance_ref(World& w, const AdvanceArgs& a) {
                 if (*p == 0) { if (s.iparam[1] == 1) despawn_rollback_one(w, i); else setbit(w.alive, i, false); }
             }
         } break;
+        case SYS_CUSTOM: run_custom_system(w, a, s); break;
         case SYS_BOX_MOVE: {
             uint32_t ct = s.comp[0], cv = s.comp[1], cp = s.comp[2];
             float dt = f32_of(a.dt_bits);
@@ -698,7 +761,7 @@ static void advance_ref(World& w, const AdvanceArgs& a) {
                 float* v = (float*)&w.aos[cv][i * st_v] + s.word[1];
                 const uint64_t handle = *((const uint64_t*)&w.aos[cp][i * st_p] + s.word[2]);
                 if (handle >= a.n_inputs) continue;
-                box_move_one(dt, s.fparam, a.inputs[handle],
+                box_move_one(dt, s.fparam, a.inputs[handle * w.input_bytes],
                     [&](int which, int k) { return which ? v[k] : t[k]; },
                     [&](int which, int k, float x) { (which ? v[k] : t[k]) = x; });
             }
@@ -709,7 +772,7 @@ static void advance_ref(World& w, const AdvanceArgs& a) {
     for (const SystemDesc& s : w.systems) {
         if (s.kind != SYS_PARTICLES_SPAWN) continue;
         bool pressed = false;
-        for (uint32_t k = 0; k < a.n_inputs; ++k) pressed |= (a.inputs[k] & (uint8_t)s.iparam[1]) != 0;
+        for (uint32_t k = 0; k < a.n_inputs; ++k) pressed |= (a.inputs[(size_t)k * w.input_bytes] & (uint8_t)s.iparam[1]) != 0;
         if (!pressed || a.spawn_count == 0) continue;
         uint32_t ct = s.comp[0], cv = s.comp[1], cl = s.comp[2];
         uint64_t first = 0;
@@ -784,8 +847,22 @@ static void world_save(World& w, uint64_t out[2]) {
         FlatSnap s;
         s.len = w.len;
         s.cols.resize(w.cols.size());
+        s.stored.resize(w.comps.size());
         for (uint32_t c = 0; c < w.comps.size(); ++c) {
             if (w.comps[c].no_rollback) continue;
+            if (w.comps[c].store_fn) {
+                // ComponentSnapshotPlugin<S>::save with a user-written Strategy (component_snapshot.rs:66-84): Stored = S::store(component)
+                const Comp& cc = w.comps[c];
+                s.stored[c].assign((size_t)w.len * cc.s_n_words, 0);
+                for (uint64_t i = 0; i < w.len; ++i) {
+                    if (!bit(w.alive, i) || !bit(w.present[c], i)) continue;
+                    uint64_t tg[MAX_WORDS], st[MAX_WORDS] = {0};
+                    for (uint32_t k = 0; k < cc.n_words; ++k) tg[k] = load_word(w, c, k, i);
+                    cc.store_fn(tg, st, cc.strat_user);
+                    for (uint32_t k = 0; k < cc.s_n_words; ++k) s.stored[c][i * cc.s_n_words + k] = st[k] & word_mask(cc.s_word_bytes);
+                }
+                continue;
+            }
             for (uint32_t k = 0; k < w.comps[c].n_words; ++k) {
                 auto& src = w.cols[w.col_base[c] + k];
                 s.cols[w.col_base[c] + k].assign(src.begin(), src.begin() + (size_t)w.len * w.comps[c].word_bytes);
@@ -835,6 +912,18 @@ static int world_load(World& w, int32_t frame) {
         resurrect_and_reconcile(w, s.len, [&](uint64_t i) { return bit(s.alive, i); });
         // entity.rs:55-99 + component_snapshot.rs:95-123 collapse to: masks and columns := snapshot
         for (size_t k = 0; k < s.cols.size(); ++k) if (!s.cols[k].empty()) memcpy(w.cols[k].data(), s.cols[k].data(), s.cols[k].size());
+        for (uint32_t c = 0; c < w.comps.size(); ++c) {
+            // ComponentSnapshotPlugin<S>::load with a user-written Strategy (component_snapshot.rs:95-123): component = S::load(Stored)
+            const Comp& cc = w.comps[c];
+            if (!cc.load_fn || cc.no_rollback || s.stored.size() <= c) continue;
+            for (uint64_t i = 0; i < s.len; ++i) {
+                if (!bit(s.alive, i) || !bit(s.present[c], i)) continue;
+                uint64_t tg[MAX_WORDS] = {0}, st[MAX_WORDS];
+                for (uint32_t k = 0; k < cc.s_n_words; ++k) st[k] = s.stored[c][i * cc.s_n_words + k];
+                cc.load_fn(st, tg, cc.strat_user);
+                for (uint32_t k = 0; k < cc.n_words; ++k) store_word(w, c, k, i, tg[k]);
+            }
+        }
         std::fill(w.alive.begin(), w.alive.end(), 0);
         memcpy(w.alive.data(), s.alive.data(), s.alive.size() * 8);
         for (uint32_t c = 0; c < w.comps.size(); ++c) {
@@ -905,6 +994,24 @@ static void world_advance(World& w, const AdvanceArgs& a_in) {
     if (a.dt_bits == 0) a.dt_bits = dt_bits_for_frame(w.fps, w.frame);   // GgrsTimePlugin::update, time.rs:63-87
     despawn_confirmed(w);                                         // AdvanceWorldSystems::DespawnConfirmed, set.rs:68-70
     if (w.mode == 0) advance_flat(w, a); else advance_ref(w, a);
+    // a user-written spawn system: its Commands are applied with the others, after every system of the frame ran (set.rs:118-134); the
+    // entities take RollbackOrdered's next indices (rollback.rs:69-74), the bundle's components their registered defaults, then what the spawner writes
+    for (const SystemDesc& s : w.systems) {
+        if (s.kind != SYS_SPAWN_CUSTOM || a.spawn_count == 0) continue;
+        static const uint8_t zero_status[16] = {0};
+        const SpawnSys& sp = w.spawn_customs[s.comp[0]];
+        const FrameView f = frame_view(w, a, s, zero_status);
+        uint64_t first = 0;
+        if (world_spawn(w, a.spawn_count, sp.bundle_mask, nullptr, &first) != 0) continue;
+        if (w.mode == 1) ref_sync_to_flat(w);
+        for (uint64_t k = 0; k < a.spawn_count; ++k) {
+            uint64_t words[8];
+            for (uint32_t b = 0; b < sp.n_bind; ++b) words[b] = load_word(w, sp.comp[b], sp.word[b], first + k);
+            sp.fn(words, first + k, k, &f, a.spawn_payload ? a.spawn_payload + (size_t)sp.payload_stride * k : nullptr, sp.user);
+            for (uint32_t b = 0; b < sp.n_bind; ++b) store_word(w, sp.comp[b], sp.word[b], first + k, words[b]);
+        }
+        if (w.mode == 1) ref_sync_from_flat(w, first, a.spawn_count);
+    }
 }
 
 // ===========================================================================
@@ -1096,6 +1203,45 @@ int gor_advance(void* wp, uint32_t dt_bits, const uint8_t* inputs, uint32_t n_in
     world_advance(*(World*)wp, a);
     return 0;
 }
+int gor_set_input_layout(void* wp, uint32_t input_bytes, uint32_t max_players) {
+    World& w = *(World*)wp;
+    if (input_bytes == 0 || input_bytes > 16 || max_players == 0 || max_players > 16) { w.err = "bad input layout"; return -1; }
+    w.input_bytes = input_bytes; w.max_players = max_players;
+    return 0;
+}
+int gor_add_custom_system(void* wp, CustomSysFn fn, void* user, uint32_t n_bind, const uint32_t* comp, const uint32_t* word, const int64_t* iparam, const float* fparam) {
+    World& w = *(World*)wp;
+    if (w.sealed || !fn || n_bind == 0 || n_bind > 8) { w.err = "bad custom system"; return -1; }
+    CustomSys cs; cs.fn = fn; cs.user = user; cs.n_bind = n_bind;
+    for (uint32_t b = 0; b < n_bind; ++b) { if (comp[b] >= w.comps.size() || word[b] >= w.comps[comp[b]].n_words) { w.err = "bad binding"; return -1; } cs.comp[b] = comp[b]; cs.word[b] = word[b]; }
+    SystemDesc d; memset(&d, 0, sizeof d);
+    d.kind = SYS_CUSTOM; d.comp[0] = (uint32_t)w.customs.size();
+    if (iparam) { d.iparam[0] = iparam[0]; d.iparam[1] = iparam[1]; }
+    if (fparam) for (int k = 0; k < 4; ++k) d.fparam[k] = fparam[k];
+    w.customs.push_back(cs); w.systems.push_back(d);
+    return 0;
+}
+int gor_add_spawn_system(void* wp, SpawnSysFn fn, void* user, uint64_t bundle_mask, uint32_t payload_stride, uint32_t n_bind, const uint32_t* comp, const uint32_t* word,
+                         const int64_t* iparam, const float* fparam) {
+    World& w = *(World*)wp;
+    if (w.sealed || !fn || n_bind > 8 || bundle_mask == 0) { w.err = "bad spawn system"; return -1; }
+    SpawnSys sp; sp.fn = fn; sp.user = user; sp.bundle_mask = bundle_mask; sp.payload_stride = payload_stride; sp.n_bind = n_bind;
+    for (uint32_t b = 0; b < n_bind; ++b) { if (comp[b] >= w.comps.size() || word[b] >= w.comps[comp[b]].n_words) { w.err = "bad binding"; return -1; } sp.comp[b] = comp[b]; sp.word[b] = word[b]; }
+    SystemDesc d; memset(&d, 0, sizeof d);
+    d.kind = SYS_SPAWN_CUSTOM; d.comp[0] = (uint32_t)w.spawn_customs.size();
+    if (iparam) { d.iparam[0] = iparam[0]; d.iparam[1] = iparam[1]; }
+    if (fparam) for (int k = 0; k < 4; ++k) d.fparam[k] = fparam[k];
+    w.spawn_customs.push_back(sp); w.systems.push_back(d);
+    return 0;
+}
+int gor_register_component_strategy(void* wp, uint32_t c, uint32_t stored_word_bytes, uint32_t stored_n_words, StoreFn store, LoadFn load, void* user) {
+    World& w = *(World*)wp;
+    if (w.sealed || c >= w.comps.size() || !store || !load || stored_n_words == 0 || stored_n_words > MAX_WORDS) { w.err = "bad strategy"; return -1; }
+    if (w.mode != 0) { w.err = "strategies: FLAT oracle only"; return -1; }
+    Comp& cc = w.comps[c];
+    cc.s_word_bytes = stored_word_bytes; cc.s_n_words = stored_n_words; cc.store_fn = store; cc.load_fn = load; cc.strat_user = user;
+    return 0;
+}
 
 // Batched request list (handle_requests, schedule_systems.rs:170-289).  Layout must match
 // include/ggrs_hip.h ggrs_request.
@@ -1105,9 +1251,12 @@ struct Request {
     uint32_t dt_bits;
     uint32_t n_inputs;
     const uint8_t* inputs;
+    const uint8_t* status;
     uint64_t spawn_count;
     const float* spawn_vx;
     const float* spawn_vy;
+    const void* spawn_payload;
+    uint64_t spawn_payload_bytes;
 };
 int gor_handle_requests(void* wp, const Request* reqs, uint32_t n, uint64_t* checksums_out) {
     World& w = *(World*)wp;
@@ -1116,7 +1265,11 @@ int gor_handle_requests(void* wp, const Request* reqs, uint32_t n, uint64_t* che
         const Request& r = reqs[i];
         if (r.kind == 1) { world_save(w, checksums_out + 2 * ns); ++ns; }
         else if (r.kind == 2) { int rc = world_load(w, r.frame); if (rc) return rc; }
-        else if (r.kind == 3) { AdvanceArgs a{r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy}; world_advance(w, a); }
+        else if (r.kind == 3) {
+            AdvanceArgs a{r.dt_bits, r.inputs, r.n_inputs, r.spawn_count, r.spawn_vx, r.spawn_vy};
+            a.status = r.status; a.spawn_payload = (const uint8_t*)r.spawn_payload; a.spawn_payload_bytes = r.spawn_payload_bytes;
+            world_advance(w, a);
+        }
         else return -1;
     }
     return 0;

@@ -1,9 +1,9 @@
-//! Raw bindings to `include/ggrs_hip.h` (ABI version 4) -- what `bindgen` emits, by hand.
+//! Raw bindings to `include/ggrs_hip.h` (ABI version 8) -- what `bindgen` emits, by hand.
 //! UN-BUILT SOURCE: kept in lock-step with the header by tests/test_abi.py.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 7;
+pub const GGRS_HIP_ABI_VERSION: c_int = 8;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -17,7 +17,6 @@ pub const GGRS_WORLD_UNFUSED: u32 = 2;
 pub const GGRS_WORLD_NT_COPY: u32 = 4;
 pub const GGRS_WORLD_NO_GROUPS: u32 = 8;
 pub const GGRS_WORLD_LAYOUT_ONLY: u32 = 16;
-pub const GGRS_WORLD_CONTIG_ARENA: u32 = 32;
 
 pub const GGRS_COMP_ROLLBACK: u32 = 0;
 pub const GGRS_COMP_NO_ROLLBACK: u32 = 1;
@@ -29,6 +28,13 @@ pub const GGRS_SYS_ADD_U32: u32 = 4;
 pub const GGRS_SYS_SAT_SUB_DESPAWN: u32 = 5;
 pub const GGRS_SYS_BOX_MOVE: u32 = 6;
 pub const GGRS_SYS_CUSTOM: u32 = 7;
+pub const GGRS_SYS_SPAWN_CUSTOM: u32 = 8;
+pub const GGRS_MAX_PLAYERS: usize = 16;
+pub const GGRS_MAX_INPUT_BYTES: usize = 16;
+pub const GGRS_INPUT_CONFIRMED: u8 = 0;
+pub const GGRS_INPUT_PREDICTED: u8 = 1;
+pub const GGRS_INPUT_DISCONNECTED: u8 = 2;
+pub const GGRS_TIMELINE_FIELDS: usize = 7;
 pub const GGRS_CUSTOM_MAX_BINDINGS: usize = 8;
 pub const GGRS_DESPAWN_IMMEDIATE: i64 = 0;
 pub const GGRS_DESPAWN_ROLLBACK: i64 = 1;
@@ -85,20 +91,38 @@ pub struct ggrs_custom_system_desc {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct ggrs_spawn_system_desc {
+    pub name: *const c_char,
+    pub source: *const c_char,
+    pub bundle_mask: u64,
+    pub payload_stride: u32,
+    pub n_bindings: u32,
+    pub comp: [u32; GGRS_CUSTOM_MAX_BINDINGS],
+    pub word: [u32; GGRS_CUSTOM_MAX_BINDINGS],
+    pub iparam: [i64; 2],
+    pub fparam: [f32; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct ggrs_request {
     pub kind: u32,
     pub frame: i32,
     pub dt_bits: u32,
     pub n_inputs: u32,
     pub inputs: *const u8,
+    pub status: *const u8,
     pub spawn_count: u64,
     pub spawn_vx: *const f32,
     pub spawn_vy: *const f32,
+    pub spawn_payload: *const c_void,
+    pub spawn_payload_bytes: u64,
 }
 
 impl ggrs_request {
     pub const fn zeroed() -> Self {
-        Self { kind: 0, frame: 0, dt_bits: 0, n_inputs: 0, inputs: core::ptr::null(), spawn_count: 0, spawn_vx: core::ptr::null(), spawn_vy: core::ptr::null() }
+        Self { kind: 0, frame: 0, dt_bits: 0, n_inputs: 0, inputs: core::ptr::null(), status: core::ptr::null(), spawn_count: 0, spawn_vx: core::ptr::null(), spawn_vy: core::ptr::null(),
+               spawn_payload: core::ptr::null(), spawn_payload_bytes: 0 }
     }
 }
 
@@ -119,7 +143,11 @@ unsafe extern "C" {
     pub fn ggrs_hip_checksum_component_custom(w: *mut ggrs_world, comp_id: u32, source: *const c_char) -> c_int;
     pub fn ggrs_hip_add_system(w: *mut ggrs_world, desc: *const ggrs_system_desc) -> c_int;
     pub fn ggrs_hip_add_custom_system(w: *mut ggrs_world, desc: *const ggrs_custom_system_desc) -> c_int;
+    pub fn ggrs_hip_register_component_strategy(w: *mut ggrs_world, comp_id: u32, stored_word_bytes: u32, stored_n_words: u32, source: *const c_char) -> c_int;
+    pub fn ggrs_hip_set_input_layout(w: *mut ggrs_world, input_bytes: u32, max_players: u32) -> c_int;
+    pub fn ggrs_hip_add_spawn_system(w: *mut ggrs_world, desc: *const ggrs_spawn_system_desc) -> c_int;
     pub fn ggrs_hip_generated_kernel_source(w: *mut ggrs_world, form: u32, buf: *mut c_char, cap: u64, needed: *mut u64, compile: c_int) -> c_int;
+    pub fn ggrs_hip_aot_object_name(source: *const c_char, buf: *mut c_char, cap: u64) -> c_int;
     pub fn ggrs_hip_set_frame_rate(w: *mut ggrs_world, fps: u64) -> c_int;
     // ---- entities and host <-> device column traffic
     pub fn ggrs_hip_spawn(w: *mut ggrs_world, count: u64, comp_mask: u64, cols: *const *const c_void, first_slot: *mut u64) -> c_int;
@@ -172,6 +200,7 @@ unsafe extern "C" {
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;
     pub fn ggrs_hip_profile_read_launches(w: *mut ggrs_world, kernel_class: u32, us_out: *mut f32, cap: u32, n_out: *mut u32) -> c_int;
     pub fn ggrs_hip_profile_read_bytes(w: *mut ggrs_world, bytes_out: *mut u64) -> c_int;
+    pub fn ggrs_hip_host_timeline(w: *mut ggrs_world, enable: c_int, us_out: *mut f64, counts_out: *mut u64) -> c_int;
     pub fn ggrs_hip_specialise_wait(w: *mut ggrs_world) -> c_int;
     pub fn ggrs_hip_world_kernel_info(w: *mut ggrs_world, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
 }

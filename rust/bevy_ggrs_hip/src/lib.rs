@@ -50,7 +50,7 @@ use std::marker::PhantomData;
 
 pub mod prelude {
     pub use crate::{
-        hip_component, systems, GgrsPlugin, HipComponent, HipSlot, HipWorld, HipWorldConfig, KernelSystem, Rollback, RollbackApp, SpawnPayload,
+        hip_component, systems, DeviceInput, GgrsPlugin, HipComponent, HipSlot, HipWorld, HipWorldConfig, KernelSystem, Rollback, RollbackApp, SpawnBlob, SpawnPayload,
     };
     pub use bevy_ggrs::prelude::{
         GgrsConfig, GgrsSchedule, GgrsTime, LocalInputs, LocalPlayers, PlayerInputs, ReadInputs, RollbackFrameRate, Session, SyncTestMismatch,
@@ -441,6 +441,34 @@ pub struct SpawnPayload {
     pub draw: Box<dyn Fn(i32) -> (Vec<f32>, Vec<f32>) + Send + Sync>,
 }
 
+/// Host side of a user-written spawn system (`ggrs_hip_add_spawn_system`; `commands.spawn((.., Rollback))` from a GgrsSchedule system,
+/// src/snapshot/rollback.rs:45-59): a PURE function of (frame being advanced, that frame's PlayerInputs bytes, their InputStatus bytes) ->
+/// how many entities the frame spawns and the payload blob the device-side `ggrs_spawn` reads.  Pure, so that a resimulated frame
+/// spawns the same entities.
+#[derive(Resource)]
+pub struct SpawnBlob {
+    pub draw: Box<dyn Fn(i32, &[u8], &[u8]) -> (u64, Vec<u8>) + Send + Sync>,
+}
+
+/// `T::Input` as the device sees it: `BYTES` little-endian bytes per player (`ggrs_hip_set_input_layout`).  ggrs only asks inputs to be
+/// `Copy + Serialize`; the device path needs their plain bytes, so a game's input type says how (one line for a newtype over an integer).
+pub trait DeviceInput: Copy {
+    const BYTES: usize;
+    fn write_device_bytes(&self, out: &mut [u8]);
+}
+macro_rules! device_input_int { ($($t:ty),*) => { $(impl DeviceInput for $t {
+    const BYTES: usize = core::mem::size_of::<$t>();
+    fn write_device_bytes(&self, out: &mut [u8]) { out.copy_from_slice(&self.to_le_bytes()); }
+})* } }
+device_input_int!(u8, u16, u32, u64, i8, i16, i32, i64);
+impl<const N: usize> DeviceInput for [u8; N] {
+    const BYTES: usize = N;
+    fn write_device_bytes(&self, out: &mut [u8]) { out.copy_from_slice(self); }
+}
+fn status_byte(s: InputStatus) -> u8 {
+    match s { InputStatus::Confirmed => ffi::GGRS_INPUT_CONFIRMED, InputStatus::Predicted => ffi::GGRS_INPUT_PREDICTED, InputStatus::Disconnected => ffi::GGRS_INPUT_DISCONNECTED }
+}
+
 // ------------------------------------------------------------------------------------------------ registration
 
 /// Same method names as `bevy_ggrs::RollbackApp` (src/snapshot/rollback_app.rs:31-133) for the component kinds the
@@ -576,7 +604,7 @@ impl<C: Config> Default for GgrsPlugin<C> {
 /// Ordering anchor for systems that must run after the tick (`mirror_component`).
 fn drive_session_marker() {}
 
-impl<C: Config<Input = u8>> Plugin for GgrsPlugin<C> {
+impl<C: Config> Plugin for GgrsPlugin<C> where C::Input: DeviceInput {
     fn build(&self, app: &mut App) {
         // What src/lib.rs:227-259 registers, minus everything that lives on the device now (SnapshotPlugin's
         // component / entity snapshots, ChecksumPlugin, EntityChecksumPlugin) and with GgrsTimePlugin's dt rule
@@ -590,7 +618,10 @@ impl<C: Config<Input = u8>> Plugin for GgrsPlugin<C> {
             .init_schedule(ReadInputs)
             .init_schedule(GgrsSchedule) // host systems may still be added; they run after the device tick (see handle_requests)
             .add_systems(PreUpdate, (drive_session::<C>, drive_session_marker, mirror_despawns).chain().after(bevy::input::InputSystems));
-        let _ = hip_world(app); // creates the device world now so that component registration can follow in any order
+        let hip = hip_world(app); // creates the device world now so that component registration can follow in any order
+        // PlayerInputs<C>: size_of::<C::Input>() bytes + one InputStatus byte per player reach every user-written device system (src/lib.rs:98)
+        const { assert!(<C::Input as DeviceInput>::BYTES >= 1 && <C::Input as DeviceInput>::BYTES <= ffi::GGRS_MAX_INPUT_BYTES) };
+        hip.check(unsafe { ffi::ggrs_hip_set_input_layout(hip.raw, <C::Input as DeviceInput>::BYTES as u32, ffi::GGRS_MAX_PLAYERS as u32) });
     }
 }
 
@@ -636,7 +667,7 @@ fn feed_local_inputs<C: Config>(world: &mut World, mut add: impl FnMut(usize, C:
     }
 }
 
-fn step_session<C: Config<Input = u8>>(world: &mut World, session: &mut Session<C>, pacer: &mut Pacer) -> Step<C> {
+fn step_session<C: Config>(world: &mut World, session: &mut Session<C>, pacer: &mut Pacer) -> Step<C> {
     let classify = |r: Result<Vec<GgrsRequest<C>>, GgrsError>, skip_note: &'static str| match r {
         Ok(reqs) => Step::Requests(reqs),
         Err(GgrsError::MismatchedChecksum { current_frame, mismatched_frames }) => Step::Mismatch { current_frame, mismatched_frames },
@@ -669,7 +700,7 @@ fn step_session<C: Config<Input = u8>>(world: &mut World, session: &mut Session<
 
 /// The system `GgrsPlugin` installs: pending spawns -> device, poll the session, then one [`handle_requests`] per
 /// elapsed simulation period.
-pub fn drive_session<C: Config<Input = u8>>(world: &mut World) {
+pub fn drive_session<C: Config>(world: &mut World) where C::Input: DeviceInput {
     upload_pending_spawns(world);
     let fps: usize = **world.get_resource_or_insert_with::<RollbackFrameRate>(default);
     let delta = world.get_resource::<Time>().expect("Time resource not found, did you remove it?").delta();
@@ -733,7 +764,7 @@ pub fn drive_session<C: Config<Input = u8>>(world: &mut World) {
 /// by [`drive_session`] at the top of the NEXT simulation step, right before that step's `advance_frame()`: the GPU
 /// tick overlaps the rest of the host's frame (rendering, networking).  Build with `--features sync-checksums` to
 /// block inside this call instead.
-pub fn handle_requests<T: Config<Input = u8>>(requests: Vec<GgrsRequest<T>>, world: &mut World) {
+pub fn handle_requests<T: Config>(requests: Vec<GgrsRequest<T>>, world: &mut World) where T::Input: DeviceInput {
     // 1. nothing may still be in flight here (drive_session collected it before advance_frame)
     debug_assert!(world.resource::<HipWorld>().in_flight.is_none());
 
@@ -772,7 +803,10 @@ pub fn handle_requests<T: Config<Input = u8>>(requests: Vec<GgrsRequest<T>>, wor
     //    each AdvanceFrame simulates (a pure function of the frame: resimulation redraws the same values).
     let mut frame = hip.frame();
     let mut input_bytes: Vec<Vec<u8>> = Vec::new();       // keep-alive for the pointers below
+    let mut status_bytes: Vec<Vec<u8>> = Vec::new();
     let mut payloads: Vec<(Vec<f32>, Vec<f32>)> = Vec::new();
+    let mut blobs: Vec<Vec<u8>> = Vec::new();
+    let ib = <T::Input as DeviceInput>::BYTES;
     let mut reqs: Vec<ffi::ggrs_request> = Vec::with_capacity(requests.len());
     let mut cells = Vec::new();
     for r in &requests {
@@ -786,12 +820,26 @@ pub fn handle_requests<T: Config<Input = u8>>(requests: Vec<GgrsRequest<T>>, wor
                 reqs.push(ffi::ggrs_request { kind: ffi::GGRS_REQ_LOAD, frame: *f, ..ffi::ggrs_request::zeroed() });
             }
             GgrsRequest::AdvanceFrame { inputs } => {
-                // InputStatus is not forwarded: no kernel system reads it (PlayerInputs consumers that need it stay host systems)
-                input_bytes.push(inputs.iter().map(|(b, _status): &(u8, InputStatus)| *b).collect());
+                // PlayerInputs<T>(Vec<(T::Input, InputStatus)>) (src/lib.rs:98): the input's bytes and its status, per player
+                let mut bytes = vec![0u8; ib * inputs.len()];
+                for (k, (inp, _)) in inputs.iter().enumerate() { inp.write_device_bytes(&mut bytes[k * ib..(k + 1) * ib]); }
+                input_bytes.push(bytes);
+                status_bytes.push(inputs.iter().map(|(_, st)| status_byte(*st)).collect());
                 let bytes = input_bytes.last().unwrap();
-                let mut q = ffi::ggrs_request { kind: ffi::GGRS_REQ_ADVANCE, inputs: bytes.as_ptr(), n_inputs: bytes.len() as u32, ..ffi::ggrs_request::zeroed() };
+                let status = status_bytes.last().unwrap();
+                let mut q = ffi::ggrs_request { kind: ffi::GGRS_REQ_ADVANCE, inputs: bytes.as_ptr(), status: status.as_ptr(), n_inputs: inputs.len() as u32, ..ffi::ggrs_request::zeroed() };
+                if let Some(blob) = world.get_resource::<SpawnBlob>() {
+                    let (count, payload) = (blob.draw)(frame, bytes, status);
+                    if count > 0 {
+                        blobs.push(payload);
+                        let p = blobs.last().unwrap();
+                        q.spawn_count = count;
+                        q.spawn_payload = p.as_ptr() as *const core::ffi::c_void;
+                        q.spawn_payload_bytes = p.len() as u64;
+                    }
+                }
                 if let Some((rate, mask)) = payload_rate {
-                    if bytes.iter().any(|b| b & mask != 0) {
+                    if bytes.iter().step_by(ib).any(|b| b & mask != 0) {
                         let draw = &world.resource::<SpawnPayload>().draw;
                         payloads.push(draw(frame));
                         let (vx, vy) = payloads.last().unwrap();

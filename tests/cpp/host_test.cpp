@@ -37,6 +37,7 @@ void gor_set_confirmed(void*, int, int32_t);
 int gor_has_snapshot(void*, int32_t);
 uint64_t gor_snapshot_count(void*);
 int gor_handle_requests(void*, const ggrs_request*, uint32_t, uint64_t*);
+int gor_set_input_layout(void*, uint32_t, uint32_t);
 }
 struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to oracle/_build/libggrs_oracle.so
     void* w; int32_t cd = -1;
@@ -53,6 +54,7 @@ struct OracleBackend {       // same surface as bevy_ggrs::HipBackend, bound to 
     int set_depth(uint32_t d) { gor_set_depth(w, d); return 0; }
     int set_confirmed(int has, int32_t f) { gor_set_confirmed(w, has, f); return 0; }
     int set_synctest_check_distance(int32_t c) { cd = c; return 0; }
+    int set_input_layout(uint32_t ib, uint32_t mp) { return gor_set_input_layout(w, ib, mp); }
     int handle_requests(const ggrs_request* r, uint32_t n, uint64_t* out) {
         uint32_t ns = 0;
         for (uint32_t i = 0; i < n; ++i) {        // schedule_systems.rs:204-220, applied per request

@@ -2,7 +2,8 @@
 (examples/stress_tests/particles.rs:254-270) fires through Commands, which Bevy applies at the end of the schedule; rounds 1-3 ended the
 request group there and ran the spawn as its own launches, round 4 lets the group's launch append the rows.  Everything below is compared
 with the CPU oracle bit for bit -- checksums of every Save, the final live state incl. the presence masks of components the spawn bundle
-does NOT carry -- with the spawn fused (default) and with GGRS_JIT_FUSE_SPAWN=0."""
+does NOT carry -- with the spawn fused (the default), on the one-launch-per-request path, and in a world whose schedule holds TWO spawn
+systems (the generator fuses one: the firing spawn then ends its group and runs as its own launches, as in rounds 1-3)."""
 import numpy as np
 import pytest
 
@@ -13,8 +14,9 @@ from oracle.binding import FLAT, OracleWorld
 pytestmark = pytest.mark.gpu
 
 
-def _session(world, n, ticks, D, schema, rate, hold):
+def _session(world, n, ticks, D, schema, rate, hold, two_systems=False):
     ids = cm.build_particles(world, with_spawn=True, ttl_init=37, schema=schema)
+    if two_systems: world.add_system(bg.SYS_PARTICLES_SPAWN, comp=ids[:3], iparam=(11, 1 << 6))      # a second spawner on another input bit (never held here)
     vel, ttl = cm.synthetic_particles(n, ttl="despawn")
     cm.spawn_particles(world, ids, n, vel, ttl)
     drv = cm.SyncTestDriver(world, D, max_prediction=D + 1)
@@ -24,22 +26,25 @@ def _session(world, n, ticks, D, schema, rate, hold):
     return drv.all_checksums, cm.snapshot_state(world, ids)
 
 
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("mode", ["fused", "per_request", "two_spawn_systems"])
 @pytest.mark.parametrize("n,schema,rate,D", [(3000, "headline", 100, 8), (3000, "full", 70, 5), (300_000, "full", 100, 8), (700_000, "headline", 130, 8),
                                              (5000, "allhot", 100, 8), (450_000, "allhot", 100, 8)])
-def test_spawn_key_held_matches_the_oracle(n, schema, rate, D, fuse, monkeypatch):
+def test_spawn_key_held_matches_the_oracle(n, schema, rate, D, mode, monkeypatch):
     """The stress_test with the spawn key down: every frame of every tick -- resimulated ones included -- spawns `rate` particles, Ttl despawns
     run beside them, the world grows across 64-slot, 256-slot and layout-tile boundaries.  `full`: the spawn bundle carries Transform,
     Velocity and Ttl only, so spawned entities must come out WITHOUT GlobalTransform / the visibility bytes (presence masks)."""
-    if not fuse: monkeypatch.setenv("GGRS_JIT_FUSE_SPAWN", "0")
+    if mode == "per_request": monkeypatch.setenv("GGRS_TICK_JIT", "0")
+    two = mode == "two_spawn_systems"
     ticks = 14
     cap = n + rate * (ticks + 2 * D + 4)
     g = bg.World(cap, max_depth=D + 1)
-    a = _session(g, n, ticks, D, schema, rate, lambda t: True)
+    a = _session(g, n, ticks, D, schema, rate, lambda t: True, two)
     info = g.kernel_info()
     o = OracleWorld(cap, D + 1, FLAT)
-    b = _session(o, n, ticks, D, schema, rate, lambda t: True)
-    assert info["spawn_system"].startswith("runs inside" if fuse else "ends the request group"), info
+    b = _session(o, n, ticks, D, schema, rate, lambda t: True, two)
+    if mode == "per_request": assert info["request_group_kernel"].startswith("per-request"), info
+    else: assert info["spawn_system"].startswith("ends the request group" if two else "runs inside"), info
+    fuse = mode
     assert len(a[0]) == len(b[0]) > ticks
     for (fa, ca), (fb, cb) in zip(a[0], b[0]):
         assert fa == fb and ca == cb, f"frame {fa}: gpu {ca:#x} oracle {cb:#x}"
@@ -100,11 +105,12 @@ def test_spawn_beyond_capacity_is_an_error_not_a_corruption():
 
 @pytest.mark.parametrize("stage_floats", [1024, 4096, 1 << 20])
 def test_payload_ring_wraps_and_falls_back_under_the_pipelined_api(stage_floats, monkeypatch):
-    """Spawn payloads live in a ring that a collected batch frees (host_world.hpp).  With the ring shrunk (GGRS_STAGE_FLOATS) a session that
-    holds the spawn key through enqueue / collect with one tick in flight wraps it every other tick (4096 floats) or overflows it inside one
-    list (1024: the spawn then ends its group and runs unfused after a stream wait) -- the checksums must not care."""
+    """Spawn payloads live in a ring that a collected batch frees (host_world.hpp).  With the ring shrunk (GGRS_STAGE_BYTES) a session that
+    holds the spawn key through enqueue / collect with one tick in flight wraps it every other tick (16 KiB) or fills it inside one
+    list (4 KiB: the enqueue then waits for the stream, starts the ring over -- and forgets which payloads it had staged, ADVICE r4 -- ) --
+    the checksums must not care."""
     from bevy_ggrs_amd.session import SyncTestSession
-    monkeypatch.setenv("GGRS_STAGE_FLOATS", str(stage_floats))
+    monkeypatch.setenv("GGRS_STAGE_BYTES", str(4 * stage_floats))
     n, D, rate, ticks = 5000, 8, 100, 40
     cap = n + rate * (ticks + 2 * D + 4)
     fn = cm.frame_spawn_fn(rate)

@@ -226,11 +226,11 @@ def test_every_rollback_length_of_a_p2p_session_gets_its_own_kernel(n, table, mo
     every Save's checksum and the final state against the oracle, across all the kernel switches.  table = 3: eight lengths fight for
     three places -- kernels are unloaded (after the stream has drained) and built again tick after tick until the per-world build
     budget (host_world.hpp JIT_SPEC_MAX_BUILDS) is spent."""
-    monkeypatch.setenv("GGRS_JIT_SPEC_SHAPES", str(table))
     monkeypatch.setenv("GGRS_JIT_SPECIALISE_AFTER", "2")
     monkeypatch.setenv("GGRS_JIT_SPECIALISE_SYNC", "1")
     res, info = [], None
     for name, w in [("gen", bg.World(n + 4000, max_depth=9)), ("oracle", OracleWorld(n + 4000, 9))]:
+        if name == "gen": assert w._lib.ggrs_dbg_set_spec_shapes(w._p, table) == 0       # test hook: places in the shape table (default 16)
         ids = cm.build_particles(w, with_spawn=True, ttl_init=50)
         vel, ttl = cm.synthetic_particles(n, ttl="despawn")
         cm.spawn_particles(w, ids, n, vel, ttl)

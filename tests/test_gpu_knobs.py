@@ -1,10 +1,9 @@
-"""Every environment knob the library reads (csrc/host_world.hpp `Knobs`) selects among kernels / policies that must all
-produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU oracle under each setting, so the
-driver-run suite covers every kernel that ships -- the generated kernel in its per-tile and persistent forms with the fold
-on the host / in k_gen_finalize / in the launch (tick_fold) / per group of 64 workgroups, with and without depth-parallel
-roles, dead-snapshot elimination and row versions, the per-request kernels (no run-time compiler), on paged and contiguous arenas.  (Two knobs have no case: GGRS_ARENA_PARK=0
-re-enables the runtime hazard of profiles/r03fc and exists for that experiment only; GGRS_HIP_ROCTX=1 needs the roctx library of a
-profiler session.)"""
+"""Every environment knob the library reads (csrc/host_world.hpp `Knobs`; INTEGRATION.md lists them with the measurement that keeps each)
+selects among kernels / policies that must all produce the same bits: one small and one HBM-sized bit-exact parity case against the CPU
+oracle under each setting -- blocking lists AND pipelined (enqueue / collect) ticks -- so the driver-run suite covers every kernel that
+ships: the generated kernel with its rows folded by the host / forwarded to the next launch (fold-forward) / by k_gen_finalize, with and
+without row versions and specialised copies, and the per-request kernels (no run-time compiler, no shipped code object).
+(GGRS_HIP_ROCTX=1 needs the roctx library of a profiler session and has no case; GGRS_AOT_DIR's positive case is tests/test_gpu_aot.py.)"""
 import numpy as np
 import pytest
 
@@ -16,38 +15,18 @@ pytestmark = pytest.mark.gpu
 
 KNOBS = [
     {},                                                     # the defaults
-    {"GGRS_TICK_JIT": "0"},                                 # no generated kernel (a deployment without libhiprtc.so): one launch per request
-    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1"},                    # generated kernel, persistent form + in-launch fold even for small worlds
-    {"GGRS_HOST_FOLD_MAX_WGS": "0"},                        # every group folded on the device (k_gen_finalize)
-    {"GGRS_HOST_FOLD_MAX_WGS": "256"},                      # only small groups folded by the host (the round-2 default)
-    {"GGRS_GROUP_FOLD_MIN_WGS": "0"},                       # no group fold: one row per workgroup leaves the kernel at every size
-    {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0"},   # group fold even for the 10 k world (one group of 56 workgroups incl. a padding one)
-    {"GGRS_GROUP_FOLD_MIN_WGS": "8", "GGRS_JIT_DP": "0", "GGRS_HOST_FOLD_MAX_WGS": "0"},   # ... with the groups' rows staying on the device (k_gen_finalize over rows / 64)
-    {"GGRS_JIT_NT_LOADS": "1"},                            # the source block is always loaded non-temporally (default: only when it is not expected in the caches)
-    {"GGRS_JIT_NT_LOADS": "0"},
-    {"GGRS_JIT_FUSE_SPAWN": "0"},                          # a firing spawn system ends the request group (rounds 1-3: k_spawn_particles + mask edits as their own launches)
-    {"GGRS_DEAD_GROUPS": "0"},
-    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "4", "GGRS_JIT_PERSIST_TPB": "512"},   # persistent form, another grid shape
-    {"GGRS_JIT_PERSIST_MIN_SLOTS": "1", "GGRS_JIT_PERSIST_OVERSUB": "64", "GGRS_JIT_PERSIST_TPB": "256"},  # ... and one whose grid must be clamped to tick_fold's row buffer
-    {"GGRS_JIT_DP_MAX_SLOTS": "400000"},                    # depth-parallel roles far above their default range
-    {"GGRS_HIP_TRACE": "1", "GGRS_DEBUG_JIT": "1", "GGRS_DEBUG_ARENA": "1"},   # the diagnostic prints change nothing
-    {"GGRS_JIT_DP": "0"},
-    {"GGRS_JIT_DP": "3"},
+    {"GGRS_TICK_JIT": "0"},                                 # no generated kernel: one launch per request
+    {"GGRS_NO_HIPRTC": "1", "GGRS_AOT_DIR": "0", "GGRS_JIT_CACHE_DIR": "0"},   # a deployment without libhiprtc.so and without shipped objects: the same fallback, found by itself
+    {"GGRS_FOLD_FORWARD_MIN_WGS": "0"},                     # every enqueued group's rows are folded by the next launch (even the 10 k world's 40)
+    {"GGRS_FOLD_FORWARD_MIN_WGS": "1000000"},               # never: the host folds one row per workgroup at collect time (rounds 3-4), blocking calls above 1024 workgroups k_gen_finalize
+    {"GGRS_STAGE_BYTES": "4096"},                           # a spawn-payload ring of 4 KiB: the lists' spawns wrap it (a full ring waits for the stream)
+    {"GGRS_HIP_TRACE": "1", "GGRS_DEBUG_JIT": "1"},         # the diagnostic prints change nothing
     {"GGRS_ROW_VERSIONS": "0"},
-    {"GGRS_JIT_SPECIALISE_AFTER": "1", "GGRS_JIT_SPECIALISE_SYNC": "1"},   # every HBM-sized group shape gets its own kernel at once (built on the calling thread)
+    {"GGRS_JIT_SPECIALISE_AFTER": "1", "GGRS_JIT_SPECIALISE_SYNC": "1"},   # every group shape gets its own kernel at once (built on the calling thread)
     {"GGRS_JIT_SPECIALISE_AFTER": "0"},                     # never
-    {"GGRS_JIT_SPECIALISE_AFTER": "1", "GGRS_JIT_SPECIALISE_SYNC": "1", "GGRS_JIT_SPEC_SHAPES": "1"},   # one place in the shape table: every new shape unloads the previous kernel
-    {"GGRS_JIT_LANE_FOLD": "1"},                            # checksum fold through per-lane LDS rows even for small worlds
-    {"GGRS_JIT_LANE_FOLD": "0"},                            # ... and the per-Save DPP ladder even for big ones
-    {"GGRS_EVENT_ON_KERNEL": "0"},                          # an enqueued list ends with a marker packet again
-    {"GGRS_HOST_FOLD_MAX_WGS": "0", "GGRS_SPIN_WAIT_US": "0"},   # every fold by k_gen_finalize (blocking calls then poll its completion tags, default 200 us) with the poll off:
-                                                                 # hipStreamSynchronize per blocking call, as in rounds 1-3
-    {"GGRS_HOST_FOLD_MAX_WGS": "0", "GGRS_SPIN_WAIT_US": "1"},   # ... and a poll that gives up at once (falls back to the stream wait mid-flight)
-    {"GGRS_PRESENCE_VERSIONS": "0"},                        # presence masks stored with every Save
-    {"GGRS_JIT_CACHE_FIRST_SAVE": "0"},                     # every Save of an HBM-sized rollback group streams past the caches
-    {"GGRS_ARENA_CONTIG": "0"},
-    {"GGRS_ARENA_CONTIG": "1"},                             # every world on a physically contiguous arena (parked when its world closes, reused by the next)
-    {"GGRS_ARENA_CONTIG": "2", "GGRS_ARENA_FLUSH": "7"},    # particles worlds contiguous + the L2 write-back / invalidate kernels of the r03fc experiment
+    {"GGRS_SPIN_WAIT_US": "0"},                             # no polling of completion tags / events: the runtime's waits, as in rounds 1-3
+    {"GGRS_SPIN_WAIT_US": "1"},                             # ... and polls that give up at once (fall back to the runtime's wait mid-flight)
+    {"GGRS_JIT_CACHE_DIR": "0"},                            # no code objects on disk
     {"GGRS_DEBUG_POISON": "1"},
 ]
 
@@ -74,6 +53,27 @@ def _case(world, n):
         reqs.append(bg.AdvanceFrame((0,)))
     out += world.handle_requests(reqs)
     out += world.handle_requests([bg.SaveGameState(world.frame)])
+    # pipelined ticks (one in flight): rollbacks of 3 frames with a spawn in every second tick -- the enqueue / collect API, i.e. the fold-forward path on
+    # the device side; the oracle runs the same lists synchronously
+    def tick(F, k):
+        reqs = [bg.LoadGameState(F - 3)]
+        for i in range(3):
+            a = bg.AdvanceFrame((cm.INPUT_SPAWN if (k % 2 == 0 and i == 1) else 0,))
+            if a.inputs[0]: a.spawn_vx, a.spawn_vy = fn(F - 3 + i)
+            reqs += [a, bg.SaveGameState(F - 2 + i)]
+        return reqs + [bg.AdvanceFrame((0,))]
+    F = world.frame
+    out += world.handle_requests([bg.AdvanceFrame((0,)), bg.SaveGameState(F + 1), bg.AdvanceFrame((0,)), bg.SaveGameState(F + 2), bg.AdvanceFrame((0,)), bg.SaveGameState(F + 3)])
+    F = world.frame
+    world.set_confirmed(F - 3)
+    if hasattr(world, "enqueue_requests"):
+        world.enqueue_requests(tick(F, 0))
+        for k in range(1, 9):
+            world.enqueue_requests(tick(F + k, k)); out += world.collect_checksums()
+        out += world.collect_checksums()
+    else:
+        for k in range(9): out += world.handle_requests(tick(F + k, k))
+    out += world.handle_requests([bg.SaveGameState(world.frame)])
     return out, cm.snapshot_state(world, ids)
 
 
@@ -96,19 +96,17 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     cm.assert_states_equal(got[1], _ORACLE[n][1], f"{env} n={n}")
     # the knob actually selected what it names
     k = info["request_group_kernel"]
-    if env.get("GGRS_TICK_JIT") == "0": assert k.startswith("per-request"), k
-    if env.get("GGRS_JIT_PERSIST_MIN_SLOTS") == "1": assert "persistent" in k, k
-    if not env: assert k.startswith("ggrs_jit_tick") and "persistent" not in k, k        # the default at every size (host_world.hpp: measured)
-    if not env: assert info["checksum_fold"].startswith("the host folds"), info           # (the group fold's default range starts at 12288 workgroups: test_group_fold_default_range)
-    if env.get("GGRS_TICK_JIT") != "0" and "GGRS_JIT_PERSIST_MIN_SLOTS" not in env:
-        assert info["spawn_system"].startswith("ends the request group" if env.get("GGRS_JIT_FUSE_SPAWN") == "0" else "runs inside"), info
-    if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "0": assert "group fold" not in info["checksum_fold"], info
-    if env.get("GGRS_GROUP_FOLD_MIN_WGS") == "8": assert info["checksum_fold"].startswith("group fold") and (("k_gen_finalize" in info["checksum_fold"]) == ("GGRS_HOST_FOLD_MAX_WGS" in env)), info
-    if env == {"GGRS_HOST_FOLD_MAX_WGS": "0"}: assert " 0 calls so far" not in info["blocking_wait"] and info["blocking_wait"].startswith("polls"), info
+    per_request = env.get("GGRS_TICK_JIT") == "0" or env.get("GGRS_NO_HIPRTC") == "1"
+    if per_request: assert k.startswith("per-request"), k
+    else: assert k.startswith("ggrs_jit_tick"), k
+    if not per_request:
+        big = n > 300_000
+        want = "fold-forward" if (env.get("GGRS_FOLD_FORWARD_MIN_WGS") == "0" or (big and "GGRS_FOLD_FORWARD_MIN_WGS" not in env)) else "the host folds"
+        assert info["checksum_fold"].startswith(want), info
+        assert info["spawn_system"].startswith("runs inside"), info
+        assert int(info["kernarg_bytes"]) < 1000, info                                       # the per-world argument block (the one-size block of rounds 2-4 was 2112 bytes)
+    if env.get("GGRS_NO_HIPRTC") == "1": assert info["hiprtc"].startswith("missing") and "no shipped code object" in info["generated_kernel"], info
     if env.get("GGRS_SPIN_WAIT_US") == "0": assert info["blocking_wait"].startswith("hipStreamSynchronize"), info
-    if env.get("GGRS_ARENA_CONTIG") in ("1", "2"): assert info["arena"].startswith("contiguous"), info
-    if env.get("GGRS_ARENA_CONTIG") == "0": assert info["arena"].startswith("paged"), info
-    if env == {"GGRS_ROW_VERSIONS": "0"}: assert k.startswith("ggrs_jit_tick"), k
 
 
 def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
@@ -131,10 +129,10 @@ def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
     assert res[0] == res[1]
 
 
-def test_group_fold_default_range():
-    """Default policy of the checksum fold by world size (host_world.hpp Knobs::group_fold_min_wgs, profiles/r04b): one row per workgroup to the
-    host up to 12288 workgroups, the on-chip group fold beyond (4 M slots: 245 rows of 15625 leave the kernel)."""
-    for n, want in ((1_000_000, "the host folds"), (3_300_000, "group fold on the chip")):
+def test_fold_placement_by_world_size():
+    """Default policy of the checksum fold by world size (host_world.hpp Knobs::fold_forward_min_wgs): up to 256 workgroups (65 k slots) one row per workgroup goes
+    to the host, beyond the next launch folds the rows (fold-forward) -- at every size, 4 M slots included (the on-chip group fold of round 4 is gone)."""
+    for n, want in ((60_000, "the host folds"), (100_000, "fold-forward"), (1_000_000, "fold-forward"), (3_300_000, "fold-forward")):
         w = bg.World(n, max_depth=2)
         ids = cm.build_particles(w)
         vel, ttl = cm.synthetic_particles(n, ttl="throughput")

@@ -484,13 +484,13 @@ def test_big_world_with_extra_untouched_components(extra_words, n):
 def test_long_pipelined_run_wraps_the_host_fold_row_ring(monkeypatch):
     """Small worlds leave their per-workgroup checksum partials in a pinned row ring and the host folds them at collect time.
     With one batch always in flight the ring never drains: 1400 pipelined depth-8 ticks at 10 k entities wrap it (~1090 ticks
-    of rows fit).  Every checksum must equal the same run with the fold kept on the device (GGRS_HOST_FOLD_MAX_WGS=0), and
-    the first ticks the oracle's."""
+    of rows fit).  Every checksum must equal the same run with the rows folded forward by the next launch
+    (GGRS_FOLD_FORWARD_MIN_WGS=0: two values + two tags per Save and part in the same ring), and the first ticks the oracle's."""
     n, D, ticks = 10_000, 8, 1400
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     out = []
     for host_fold in (True, False):
-        if not host_fold: monkeypatch.setenv("GGRS_HOST_FOLD_MAX_WGS", "0")
+        if not host_fold: monkeypatch.setenv("GGRS_FOLD_FORWARD_MIN_WGS", "0")
         w = bg.World(n, max_depth=D + 1)
         ids = cm.build_particles(w)
         cm.spawn_particles(w, ids, n, vel, ttl)
