@@ -12,10 +12,13 @@ needs.  Default host API: ggrs_hip_enqueue_requests / ggrs_hip_collect_checksums
 flight (a shim collects right before the next advance_frame()); `--sync` blocks on every tick.
 
   value     = entities x 9 advances x steps / seconds      (whole job, all ranks)
-  roofline  = dominant kernel k_tick (the fused request group: read one snapshot, write D snapshots,
-              write live once): compulsory 60 x (D + 2) B x entities per launch / its mean duration
-              from HIP events recorded on the world's stream inside libggrs_hip.so; `traffic` = HBM
+  roofline  = dominant kernel ggrs_jit_tick (the fused request group: read one snapshot, write D snapshots,
+              write live once): the bytes the library counts per launch / its mean duration
+              from HIP events riding on the dispatch inside libggrs_hip.so; `traffic` = HBM
               bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/roofline_traffic.json).
+  extra_configs = (default N = 1 headline run only) BASELINE configs 2 / 4 / 5 (+ its spawning variant) and the all-columns-hot
+              world, each measured in this process AFTER the headline's clock has stopped, each with its own in-run oracle
+              parity; configs 2 / 4 also through a C loop (benches/tick_loop.c) next to this file's Python loop.
               SURVEY 8d's one-kernel-per-request figure (1656 B/entity-tick) is reported as
               per_request_equiv_*; `--no-groups` measures that path itself.
   cpu_baseline = the oracle's REFERENCE-SHAPED variant (kind "port"), 1 thread, bounded sample.
@@ -122,7 +125,7 @@ def warm_ring(bg, w, depth):
         w.handle_requests([bg.SaveGameState(w.frame), bg.AdvanceFrame((0,))])
 
 
-def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs, parity_ticks, schema="headline"):
+def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs, parity_ticks, schema="headline", time_refshaped=True):
     """The CPU path timed beside the GPU line, and the parity check of the same run.
 
     * reference-shaped oracle (per-save hash-map rebuild, per-entity lookups: the reference's cost structure) on ONE
@@ -144,14 +147,16 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs,
         return w
     cores = os.cpu_count() or 1
     ef = n * (depth + 1)                       # entity-frames per tick
-    w = world(REFSHAPED)
-    lib.gor_set_num_threads(1)
-    secs = w.bench_synctest(depth, depth + 1, budget_ticks)
-    lib.gor_set_ref_component_threads(3)
-    lib.gor_set_num_threads(3)
-    secs3 = w.bench_synctest(depth, 0, budget_ticks)
-    lib.gor_set_ref_component_threads(1)
-    del w
+    secs = secs3 = None
+    if time_refshaped:                         # (extra_configs: parity only -- the CPU timing legs belong to the headline)
+        w = world(REFSHAPED)
+        lib.gor_set_num_threads(1)
+        secs = w.bench_synctest(depth, depth + 1, budget_ticks)
+        lib.gor_set_ref_component_threads(3)
+        lib.gor_set_num_threads(3)
+        secs3 = w.bench_synctest(depth, 0, budget_ticks)
+        lib.gor_set_ref_component_threads(1)
+        del w
     # ---- flat port == parity replay: ring warm-up (D + 1 plain ticks) + the bench's warm-up ticks + P timed ticks
     P = max(0, min(parity_ticks, len(gpu_cs)))
     flat_threads = max(1, min(64, cores))
@@ -176,6 +181,7 @@ def cpu_baseline_and_parity(n, depth, budget_ticks, frames_before_timed, gpu_cs,
     # 48.7 M at 64 threads on the 256-core gpurun host (profiles/r02a/bench.json) -- more threads than memory channels hurt
     flat["threads_note"] = f"{flat_threads} of {cores} host cores: measured faster than a {cores}-thread team (profiles/r02a)"
     lib.gor_set_num_threads(1)
+    if not time_refshaped: return None, parity
     base = {"value": ef * budget_ticks / secs, "unit": "entity-frames/s", "cores": 1,
             "kind": "port",
             "sample": f"{budget_ticks} steady-state SyncTest ticks (depth {depth}) of the same {n}-entity x 3-component "
@@ -341,14 +347,14 @@ def spawn_ranks(args, argv):
     return rc
 
 
-def measure_single(bg, cm, torch, args, contig, light=False):
-    """One single-GPU measurement in this process: world on a paged (library default) or physically contiguous arena; warm-up,
-    pre-heat, K timed ticks, then the HIP-event pass for the per-kernel roofline.  light: no telemetry, no checksum capture."""
+def measure_single(bg, cm, torch, args, contig=False, light=False):
+    """One single-GPU measurement in this process: warm-up, pre-heat, K timed ticks, then the host-timeline pass and the HIP-event pass for the
+    per-kernel roofline.  light: no telemetry, no checksum capture."""
     n, D, K, W = args.entities, args.depth, args.steps, args.warmup
     stream = torch.cuda.current_stream().cuda_stream
     flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
     w, ids = build_world(bg, cm, n, D, stream=stream, flags=flags, checksum=not args.no_checksum, schema=args.schema)
-    m = {"contig_requested": bool(contig)}
+    m = {}
     warm_ring(bg, w, D)
     run, _keep = tick_requests(bg, w, D)
     m["clocks_start"] = None if light else read_clocks()
@@ -416,6 +422,8 @@ def measure_single(bg, cm, torch, args, contig, light=False):
                              "after_last_collect": round((t0 + secs - stamps[-1]) * 1e6, 1),      # the two synchronize calls that close the region
                              "note": "host interval between consecutive collects in the timed region (tick k+1 is already enqueued when tick k is collected)"}
     m["f_end"] = w.frame
+    if not args.sync and not light:
+        m["host_timeline"] = timeline_pass(w, run, min(K, 50))
     # ---- instrumented pass for the per-kernel roofline: HIP events riding on every dispatch (kernel begin / end, what rocprofv3's kernel
     # trace reports), through the SAME host API as the timed region -- pipelined ticks run back to back on a busy device with the previous
     # tick's first Save still in the caches, exactly the conditions of the timed ticks (the pass used to go through the
@@ -555,6 +563,463 @@ def measure_p2p(bg, cm, torch, args):
             "mean_rollback": sum(r for _f, r, _s in script[first:first + K]) / K, "settle": settle, "tick_wall_us": tick_wall}
 
 
+def timeline_pass(w, run, ticks):
+    """Where the HOST spends a tick (ggrs_hip_host_timeline), measured over `ticks` pipelined ticks after the timed region -- per tick, microseconds."""
+    w.synchronize()
+    w.host_timeline(1)
+    run.enqueue(w.frame)
+    for _ in range(ticks - 1):
+        run.enqueue(w.frame); run.collect()
+    run.collect()
+    t = w.host_timeline(0)
+    n = max(1, t["collect_calls"])
+    per = {k: round(v / n, 3) for k, v in t.items() if k.endswith("_us")}
+    per["enqueue_bookkeeping_us"] = round(per["enqueue_us"] - per["validate_us"] - per["launch_call_us"], 3)
+    per["ticks"] = n; per["launches_per_tick"] = round(t["launches"] / n, 3)
+    per["note"] = ("library time inside ggrs_hip_enqueue_requests (validation + group bookkeeping + the HIP launch call) and ggrs_hip_collect_checksums (batch event + fold-forward tags + "
+                   "hashing) per tick; what the bench's own loop adds on top is the difference to tick_wall_us")
+    return per
+
+
+_TICK_LOOP = None
+
+
+def tick_loop_lib():
+    """benches/libtick_loop.so: the bench's ticks driven from C through the public C ABI (benches/tick_loop.c)."""
+    global _TICK_LOOP
+    if _TICK_LOOP is None:
+        lib = C.CDLL(os.path.join(ROOT, "benches", "libtick_loop.so"))
+        P = C.c_void_p
+        lib.ggrs_bench_synctest_loop.restype = C.c_int
+        lib.ggrs_bench_synctest_loop.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.ggrs_bench_p2p_loop.restype = C.c_int
+        lib.ggrs_bench_p2p_loop.argtypes = [P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _TICK_LOOP = lib
+    return _TICK_LOOP
+
+
+def c_loop_synctest(bg, cm, torch, n, D, K, schema="headline", inflight=1, kernel_us=None, parity_ticks=8):
+    """The SyncTest tick of `measure_single` with NO Python between enqueue and collect: benches/tick_loop.c drives the C ABI (what a Rust / C++ shim costs).
+    Own world, ring warm-up, 400 untimed ticks (the specialised kernel comes in), K timed ticks whose checksums are all kept; the first `parity_ticks` timed
+    ticks are replayed on the CPU oracle."""
+    lib = tick_loop_lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    w, _ids = build_world(bg, cm, n, D, stream=stream, schema=schema)
+    warm_ring(bg, w, D)
+    secs = C.c_double(0)
+    warm = 400
+    rc = lib.ggrs_bench_synctest_loop(w._p, D, warm // 2, inflight, None, C.byref(secs), None); assert rc == 0, rc
+    w.specialise_wait()
+    rc = lib.ggrs_bench_synctest_loop(w._p, D, warm // 2, inflight, None, C.byref(secs), None); assert rc == 0, rc
+    frames_before = w.frame
+    cs = (C.c_uint64 * (2 * D * K))(); tick_us = (C.c_double * K)()
+    gc.collect(); gc.disable()
+    rc = lib.ggrs_bench_synctest_loop(w._p, D, K, inflight, cs, C.byref(secs), tick_us)
+    gc.enable()
+    assert rc == 0, rc
+    live = w.active_count(); w.close()
+    t = sorted(tick_us)
+    out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": inflight, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * (D + 1) * K / secs.value, "unit": "entity-frames/s",
+           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2), "first": round(tick_us[0], 2)}}
+    if kernel_us: out["latency_floor"] = latency_floor(kernel_us, 1.0, secs.value / K * 1e6)
+    P = min(parity_ticks, K)
+    if P:
+        from oracle.binding import FLAT, OracleWorld, lib as olib
+        o = OracleWorld(n, D + 1, FLAT)
+        ids = cm.build_particles(o, schema=schema)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(o, ids, n, vel, ttl); o.set_depth(D + 1)
+        olib.gor_set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+        _s, ocs = o.replay_synctest_from(D, frames_before - (D + 1), P)
+        olib.gor_set_num_threads(1)
+        got = [int(cs[2 * i]) | (int(cs[2 * i + 1]) << 64) for i in range(P * D)]
+        out["parity"] = {"checked_ticks": P, "checked_saves": P * D, "equal": got == ocs[len(ocs) - P * D:]}
+    return out
+
+
+def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
+    """BASELINE config 4 through the C loop: the same rollback script generator as measure_p2p, one list per tick, one tick in flight; every Save checked against the oracle."""
+    lib = tick_loop_lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    w = bg.World(n, max_depth=R + 1, stream=stream)
+    ids = cm.build_particles(w)
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    w.set_depth(R); w.set_synctest_check_distance(-1)
+    rng = np.random.default_rng(4)
+    warm = 480
+    total = warm + K
+    rl = np.zeros(total, dtype=np.uint8)
+    for F in range(total): rl[F] = min(int(rng.integers(0, R + 1)), F, R - 1)
+    cs = (C.c_uint64 * (2 * R * total))(); ncs = (C.c_uint32 * total)(); secs = C.c_double(0); tick_us = (C.c_double * K)()
+    rlp = rl.ctypes.data_as(C.POINTER(C.c_uint8))
+    half = warm // 2
+    rc = lib.ggrs_bench_p2p_loop(w._p, R, half, rlp, cs, ncs, C.byref(secs), None); assert rc == 0, rc
+    w.specialise_wait()
+    off = lambda k: (C.cast(C.byref(cs, 16 * R * k), C.POINTER(C.c_uint64)), C.cast(C.byref(ncs, 4 * k), C.POINTER(C.c_uint32)), C.cast(C.byref(rl.ctypes.data_as(C.POINTER(C.c_uint8)).contents, k), C.POINTER(C.c_uint8)))
+    c2, n2, r2 = off(half)
+    rc = lib.ggrs_bench_p2p_loop(w._p, R, warm - half, r2, c2, n2, C.byref(secs), None); assert rc == 0, rc
+    w.specialise_wait()
+    c3, n3, r3 = off(warm)
+    gc.collect(); gc.disable()
+    rc = lib.ggrs_bench_p2p_loop(w._p, R, K, r3, c3, n3, C.byref(secs), tick_us)
+    gc.enable()
+    assert rc == 0, rc
+    live = w.active_count(); w.close()
+    advances = int(sum(int(r) + 1 for r in rl[warm:]))
+    t = sorted(tick_us)
+    out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": 1, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * advances / secs.value, "unit": "entity-frames/s",
+           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)}}
+    if kernel_us: out["latency_floor"] = latency_floor(kernel_us, launches_per_tick, secs.value / K * 1e6)
+    # every Save of every tick (warm-up included) against the oracle under the same script
+    from oracle.binding import FLAT, OracleWorld
+    o = OracleWorld(n, R + 1, FLAT)
+    oids = cm.build_particles(o); cm.spawn_particles(o, oids, n, vel, ttl); o.set_depth(R)
+    ok, checked = True, 0
+    for f in range(total):
+        r = int(rl[f])
+        reqs = ([bg.LoadGameState(f - r)] + [x for i in range(r) for x in (([bg.SaveGameState(f - r + i)] if i else []) + [bg.AdvanceFrame((0,))])]) if r else []
+        reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
+        if f - R >= 0: o.set_confirmed(f - R)
+        want = o.handle_requests(reqs)
+        got = [int(cs[2 * R * f + 2 * i]) | (int(cs[2 * R * f + 2 * i + 1]) << 64) for i in range(int(ncs[f]))]
+        ok &= got == want; checked += len(want)
+    out["parity"] = {"checked_ticks": total, "checked_saves": checked, "equal": bool(ok)}
+    return out
+
+
+def single_line(bg, cm, torch, args, dev):
+    """One N = 1 SyncTest measurement (BASELINE configs 2 / 3 and the --schema / --entities variants) -> (JSON line, parity failed?)."""
+    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+    bps = cm.schema_bytes_per_entity(args.schema)
+    m = measure_single(bg, cm, torch, args, contig=False)
+    secs, live, gpu_cs, prof = m["secs"], m["live"], m["gpu_cs"], m["prof"]
+    # SyncTest's own check over ALL timed ticks (ggrs SyncTestSession: a resimulated frame's checksum must equal the first
+    # one recorded for that frame, else MismatchedChecksum): timed tick k at frame F saved frames F-D+1 .. F
+    first_seen, resim_ok, f_end = {}, True, m["f_end"]
+    for k, tick in enumerate(gpu_cs):
+        F = f_end - (len(gpu_cs) - k)
+        for j, c in enumerate(tick):
+            resim_ok &= first_seen.setdefault(F - D + 1 + j, c) == c
+    info = m["info"]
+    value = live * (D + 1) * K / secs
+    save_ms, save_n = prof["save"]; adv_ms, adv_n = prof["advance"]; load_ms, load_n = prof["load"]; tick_ms, tick_n = prof["tick"]; fin_ms, fin_n = prof["checksum"]
+    per = lambda ms, cnt: ms / max(cnt, 1) * 1e-3
+    # PMC-derived HBM bytes per launch: only valid for the exact workload the counters were collected on
+    traffic = traffic_source = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    grouped = tick_n > 0
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if "k_tick_hbm_bytes_per_launch" not in tj: tj = tj.get(args.schema, {})     # one entry per schema (scripts/pmc_summary.py)
+            if tj.get("entities") == n and tj.get("depth") == D and not args.no_checksum and tj.get("schema", "headline") == args.schema:
+                traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = f"{tj.get('source', 'profiles/roofline_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's box; NOT measured in this run)"
+        except Exception:
+            traffic = None
+    save_bytes, tick_bytes = 2 * bps, 2 * bps + 2 * bps * D + ADV_BYTES * (D + 1)
+    launches_per_step = 1.0
+    if grouped:
+        launches_per_step = tick_n / max(min(K, 50), 1)
+        full_copy_bytes = bps * (1 + D + 1) * live
+        bytes_per_launch = m["prof_bytes"]["tick"] / max(tick_n, 1) if m.get("prof_bytes") else full_copy_bytes
+        avg_s = per(tick_ms, tick_n)
+        achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
+        kname = info.get("request_group_kernel", "?")
+        roof = {"bound": "hbm", "kernel": kname + " -- fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch; checksum rows: " + str(info.get("checksum_fold")),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "frac_compulsory": achieved / HBM_PEAK_GBS,
+                "frac_per_request": (tick_bytes * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_entity": bytes_per_launch / max(live, 1),
+                "full_copy_bytes_per_launch": full_copy_bytes, "row_versions": info.get("row_versions"),
+                "algorithmic_bytes_note": f"rows the fused launch loads and stores x slots, counted by the library per launch: with row versions only columns whose bytes "
+                                          f"differ from the destination's move (every snapshot is complete; the never-written rotation / scale rows are already in every ring slot; HBM traffic can be BELOW this figure: the group's first Save is stored through the L2 and the next launch's loads hit there); "
+                                          f"a full copy would move {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write = {bps * (D + 2)} B/entity "
+                                          f"(SURVEY 8d's one-kernel-per-request model, {tick_bytes} B/entity-tick, is reported as *_per_request)",
+                "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step, "launch_us": m.get("launch_us"),
+                "kernarg_bytes": int(info.get("kernarg_bytes", 0) or 0),
+                "other_kernels": ({"k_gen_finalize": {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
+                "per_request_equiv_GBps": tick_bytes * live * K / secs / 1e9, "per_request_equiv_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
+        if tick_n and not args.no_checksum:
+            try: roof["alu"] = alu_view(6.0 * 2 * live * D, avg_s)
+            except Exception: pass
+    else:
+        save_avg_s = per(save_ms, save_n)
+        counted = (m.get("prof_bytes") or {}).get("save", 0)
+        save_launch_bytes = counted / max(save_n, 1) if counted else save_bytes * live
+        achieved = save_launch_bytes / save_avg_s / 1e9 if save_n else 0.0
+        roof = {"bound": "hbm", "kernel": "k_copy_state (SaveWorld)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": save_launch_bytes, "full_copy_bytes_per_launch": save_bytes * live,
+                "avg_launch_us": save_avg_s * 1e6, "launches_timed": save_n,
+                "other_kernels": {"k_particles_step (AdvanceWorld)": {"avg_launch_us": per(adv_ms, adv_n) * 1e6, "achieved_GBps": ADV_BYTES * live / per(adv_ms, adv_n) / 1e9 if adv_n else 0.0},
+                                  "k_copy_state (LoadWorld)": {"avg_launch_us": per(load_ms, load_n) * 1e6, "achieved_GBps": save_bytes * live / per(load_ms, load_n) / 1e9 if load_n else 0.0}},
+                "whole_tick_achieved_GBps": tick_bytes * live * K / secs / 1e9, "whole_tick_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
+    headline = n == 1_000_000 and D == 8 and args.schema == "headline"
+    line = {
+        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak" if headline else
+                  f"rollback-resim entity-frames/sec at {n} entities, depth {D}, schema {args.schema}; HBM GB/s vs peak",
+        "value": value, "unit": "entity-frames/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": secs / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+        "config": {"workload": f"stress_test {n} entities x {cm.schema_description(args.schema)}, SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
+                   "entities_per_gpu": live, "depth": D, "spawn_system": False, "parallelism": "single GPU",
+                   "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
+                   "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"), "specialised_kernel": info.get("specialised_kernel"),
+                   "generated_kernel_origin": info.get("generated_kernel_origin"), "checksum_fold": info.get("checksum_fold"),
+                   "hiprtc": info.get("hiprtc"), "device": dev, "nt_stores": bool(args.nt),
+                   "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
+        "preheat": m.get("preheat"), "roofline": roof,
+    }
+    if grouped and n * bps * (D + 1) <= (256 << 20):
+        # the whole ring fits the 256 MB Infinity Cache: launch / latency bound (SURVEY 8d: "report it but do not judge it against HBM peak")
+        line["latency_floor"] = latency_floor(per(tick_ms, tick_n) * 1e6, launches_per_step, secs / K * 1e6)
+    line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us"), "host_timeline_us_per_tick": m.get("host_timeline"), "rss_mb": m.get("rss_mb")}
+    line["parity"] = {"synctest_resim_consistent_over_timed_ticks": bool(resim_ok), "timed_ticks": len(gpu_cs)}
+    parity_failed = not resim_ok
+    if not args.no_cpu_baseline:
+        base, par = cpu_baseline_and_parity(n, D, args.cpu_ticks, m["frames_before_timed"], gpu_cs, 0 if args.no_checksum else args.parity_ticks, schema=args.schema, time_refshaped=not getattr(args, "parity_only", False))
+        if base is not None: line["cpu_baseline"] = base
+        line["parity"].update(par)
+        parity_failed |= par["equal"] is False
+    else:
+        line["cpu_baseline"] = None
+    return line, parity_failed
+
+
+def p2p_line(bg, cm, torch, args):
+    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+    m4 = measure_p2p(bg, cm, torch, args)
+    t_ms, t_n = m4["prof"]["tick"]
+    avg_s = t_ms / max(t_n, 1) * 1e-3
+    bpl = m4["prof_bytes"]["tick"] / max(t_n, 1)
+    line = {"metric": f"rollback-resim entity-frames/sec, P2P-shaped rollbacks (0..{D} frames per tick) at {n} entities; GB/s vs HBM peak",
+            "value": m4["live"] * m4["advances"] / m4["secs"], "unit": "entity-frames/s", "n_gpus": 1, "steps": K, "warmup": W,
+            "ms_per_step": m4["secs"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: p2p-shaped session, {n} entities x 3 registered components, a rollback of 0..{D - 1} frames every tick "
+                                   f"(mean {m4['mean_rollback']:.2f}), ring depth {D}", "request_group_kernel": m4["info"].get("request_group_kernel"),
+                       "specialised_kernel": m4["info"].get("specialised_kernel"), "specialise_settle": m4["settle"], "checksum_fold": m4["info"].get("checksum_fold"),
+                       "arena_actual": m4["info"].get("arena"), "host_api": "enqueue/collect, 1 tick in flight"},
+            "roofline": {"bound": "hbm", "kernel": m4["info"].get("request_group_kernel"), "achieved": bpl / avg_s / 1e9 if t_n else 0.0, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bpl / avg_s / 1e9 / HBM_PEAK_GBS if t_n else 0.0, "traffic": None,
+                         "avg_launch_us": avg_s * 1e6, "launches_timed": t_n, "algorithmic_bytes_per_launch": bpl,
+                         "note": f"the whole ring ({n} x 60 B x {D + 1} blocks = {n * 60 * (D + 1) / 1e6:.0f} MB) lives in the 256 MB Infinity Cache: this line is launch / latency bound, "
+                                 "the HBM fraction is reported for completeness, not as its roofline"},
+            "latency_floor": latency_floor(avg_s * 1e6, t_n / max(min(K, 50), 1), m4["secs"] / K * 1e6),
+            "telemetry": {"tick_wall_us": m4["tick_wall_us"]}, "parity": m4["parity"], "cpu_baseline": m4["cpu_baseline"]}
+    return line, not m4["parity"]["equal"]
+
+
+def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
+    """The N > 1 / --fanout / config 5 measurement: speculative fan-out, branches sharded over the ranks (collectives inside libggrs_hip.so)."""
+    from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
+    # every rank provisions the same world shape; only rank 0 owns the confirmed world, the others receive it through
+    # ONE ncclBroadcast of the packed state block.  --spawn (config 5 as SURVEY 8d words it): inputs with INPUT_SPAWN set spawn `rate` particles per
+    # frame (particles.rs:258-270), so branches whose predicted input byte carries the bit really diverge from the others
+    spawn_rate = 100 if args.spawn else 0
+    w = bg.World(n + 2 * spawn_rate * (D + 2), max_depth=D + 2, device=dev, stream=stream, flags=flags)
+    ids = cm.build_particles(w, with_spawn=bool(spawn_rate))
+    if rank == 0:
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+    else:
+        w.spawn(0, {})                                   # seals the world (layout fixed)
+    box = [RcclFanout.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    native = RcclFanout(w, rank, world_size, box[0])
+    c_rank, comm_size, c_dev = native.comm_info()        # what the communicator says, not what the environment says
+    assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
+    fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
+                            desync_detection_interval=10 if args.branches == 1 else 1,   # the reference stress_test's default (particles.rs:49, README.md:84)
+                            share_prefix=not args.no_share_prefix, spawn_fn=cm.frame_spawn_fn(spawn_rate) if spawn_rate else None)
+    fan.sync_confirmed(0)
+    gc.collect(); gc.disable()                           # see measure_single
+    for _ in range(W):
+        fan.step_pipelined(want_result=False)
+    fan.drain(want_result=False)
+    # pre-heat: EVERY rank must run the same number of steps -- the all-gathers pair up by order (round 4 found the bug a clock-based loop makes)
+    pre_t0 = time.perf_counter(); pre_n = 0
+    if args.preheat_ms > 0:
+        calib = 20
+        tc = time.perf_counter()
+        for _ in range(calib):
+            fan.step_pipelined(want_result=False)
+        fan.drain(want_result=False)
+        tstep = torch.tensor([(time.perf_counter() - tc) / calib], dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(tstep, op=dist.ReduceOp.MAX)
+        pre_n = calib + int(min(200_000, max(0, args.preheat_ms * 1e-3 / max(float(tstep.item()), 1e-6) - calib)))
+        for _ in range(pre_n - calib):
+            fan.step_pipelined(want_result=False)
+        fan.drain(want_result=False)
+    m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "same_step_count_on_every_rank": True}}
+    P_fan = 0 if (args.no_cpu_baseline or args.no_checksum) else max(0, min(K, args.parity_steps if args.parity_steps >= 0 else max(1, 16 // max(1, world_size * args.branches))))
+    c_timed = fan.confirmed
+    cf = torch.tensor([c_timed, -c_timed], dtype=torch.int64, device=ctl_dev)
+    dist.all_reduce(cf, op=dist.ReduceOp.MAX)                # max(C) == -max(-C): every rank enters the timed region at the same confirmed frame
+    if int(cf[0].item()) != -int(cf[1].item()):
+        print(f"bench.py: rank {rank} is at confirmed frame {c_timed}, another rank at {int(cf[0].item())} / {-int(cf[1].item())}: the ranks ran different step counts", file=sys.stderr)
+        sys.exit(3)
+    fan.raw, fan.raw_keep = [], (P_fan if rank == 0 else 0)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        fan.step_pipelined(want_result=False)            # enqueue step k+1, collect + all-gather step k
+    fan.drain(want_result=False)                                          # every one of the K steps is collected inside the timed region
+    w.synchronize()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    gc.enable()
+    raw = list(fan.raw)
+    fan.raw_keep = 0
+    t = torch.tensor([secs], dtype=torch.float64, device=ctl_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    secs = float(t.item())
+    live = w.active_count()
+    cnt = torch.tensor([live * args.branches], dtype=torch.int64, device=ctl_dev)   # every branch resimulates the whole world
+    dist.all_reduce(cnt)
+    total_entities = int(cnt.item())
+    w.profile_enable(True)
+    for _ in range(min(K, 20)):
+        fan.step(want_result=False)
+    prof = w.profile_read()
+    prof_bytes = w.profile_bytes()
+    w.profile_enable(False)
+    info = w.kernel_info()
+    value = total_entities * (D + 1) * K / secs
+    tick_ms, tick_n = prof["tick"]
+    avg_s = tick_ms / max(tick_n, 1) * 1e-3
+    bytes_per_launch = prof_bytes["tick"] / max(tick_n, 1)
+    # what crosses xGMI per step when N > 1: the all-gather of every rank's Checksum(u128)s (+ a 16-byte tag per step); the confirmed snapshot
+    # crossed once, at start-up
+    saves_per_rank = fan.saves_per_step
+    xgmi = {"all_gather_bytes_per_step_per_rank_sent": 16 * saves_per_rank + 16, "all_gather_bytes_per_step_received": (16 * saves_per_rank + 16) * max(comm_size - 1, 0),
+            "steps_per_all_gather": fan.interval, "broadcast_once_bytes": w.state_bytes() if comm_size > 1 else 0,
+            "note": "expected collective payload, from the request shapes (no link counters are read): per-link bound only at start-up (flat broadcast of the packed state block)"}
+    line = {
+        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak" if (n == 1_000_000 and D == 8 and args.branches == 1) else
+                  f"rollback-resim entity-frames/sec at {n} entities, depth {D}, {args.branches} predicted-input branches per rank; GB/s vs peak",
+        "value": value, "unit": "entity-frames/s", "n_gpus": comm_size, "steps": K, "warmup": W,
+        "ms_per_step": secs / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
+        "config": {"workload": f"stress_test {n} entities x {cm.schema_description(args.schema)}, speculative fan-out: per step and branch 1 load + {D} saves + {D + 1} advances",
+                   "entities_per_gpu": live, "depth": D, "spawn_system": bool(args.spawn),
+                   "parallelism": f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per {fan.interval} step(s) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
+                   "kernels": "request-group", "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"), "specialised_kernel": info.get("specialised_kernel"),
+                   "hiprtc": info.get("hiprtc"), "device": dev, "host_api": "ggrs_hip_fanout_step, 2 steps in flight"},
+        "preheat": m.get("preheat"),
+        "roofline": {"bound": "hbm", "kernel": str(info.get("request_group_kernel")) + " (rank 0)", "achieved": bytes_per_launch / avg_s / 1e9 if tick_n else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_per_launch / avg_s / 1e9 / HBM_PEAK_GBS if tick_n else 0.0, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n,
+                     "launches_per_step": tick_n / max(min(K, 20), 1), "algorithmic_bytes_per_launch": bytes_per_launch},
+        "xgmi_expected": xgmi,
+    }
+    if args.branches > 1:
+        # checksum-only branches (dead-snapshot elimination): integer-multiply bound, not HBM bound.  Roofline = SeaHash `diffuse`
+        # per second against the chip's measured ceiling (scripts/ubench_alu.hip -> profiles/alu_ceiling.json).
+        try: ceil = json.load(open(os.path.join(ROOT, "profiles", "alu_ceiling.json")))
+        except Exception: ceil = None
+        diffuses = 6.0 * 2 * live * D * args.branches * comm_size * K
+        line["roofline_alu"] = {"bound": "valu-int (u64 multiply)", "achieved": diffuses / secs / 1e9, "unit": "G diffuse/s",
+                                "peak": (ceil or {}).get("diffuse_G_per_s"), "frac": (diffuses / secs / 1e9 / ceil["diffuse_G_per_s"]) if ceil else None,
+                                "peak_source": (ceil or {}).get("source"), "shared_prefix": not args.no_share_prefix,
+                                "note": "algorithmic diffuses: 6 per entity per checksummed component per SaveWorld, 2 components, D SaveWorlds per branch -- every branch's D "
+                                        "Checksum(u128)s are delivered.  The kernel hoists the order hash and memoises unchanged tails, and the step computes the "
+                                        "branch-invariant Save(C+1) once per rank instead of once per branch (shared_prefix), so fewer are executed"}
+    parity_failed = False
+    if rank == 0 and not args.no_cpu_baseline:
+        if not getattr(args, "parity_only", False):
+            base, _ = cpu_baseline_and_parity(n, D, args.cpu_ticks, D + 1, [], 0)
+            line["cpu_baseline"] = base
+        from bevy_ggrs_amd.fanout import default_branch_input
+        par = fanout_parity(n, D, c_timed, raw, comm_size, args.branches, default_branch_input, lambda f: 0,
+                            threads=max(1, min(64, os.cpu_count() or 1)), spawn_rate=100 if args.spawn else 0)
+        par["cross_rank_confirmed_frames_agree"] = True     # SpeculativeFanout raises DesyncDetected otherwise (every step, every rank)
+        line["parity"] = par
+        parity_failed = par["equal"] is not True
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    native.close() if hasattr(native, "close") else None
+    w.close()
+    return line, parity_failed
+
+
+def compact(line, keep=("value", "unit", "ms_per_step", "steps", "warmup", "parity", "latency_floor", "roofline_alu", "c_loop", "xgmi_expected")):
+    """An extra_configs entry: the figures and their evidence, without the headline's long notes."""
+    out = {k: line[k] for k in keep if k in line}
+    out["workload"] = line.get("config", {}).get("workload")
+    r = line.get("roofline") or {}
+    out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_timed", "launches_per_step", "algorithmic_bytes_per_launch", "kernarg_bytes") if k in r}
+    if "alu" in r: out["roofline"]["alu_frac"] = (r["alu"] or {}).get("frac")
+    tw = (line.get("telemetry") or {}).get("tick_wall_us") or {}
+    out["tick_wall_us_median"] = tw.get("median")
+    ht = (line.get("telemetry") or {}).get("host_timeline_us_per_tick")
+    if ht: out["host_timeline_us_per_tick"] = ht
+    return out
+
+
+def extra_configs(bg, cm, torch, base_args, dev, budget_s=60.0):
+    """every other BASELINE config + the all-columns-hot world in the driver's record -- measured in this process AFTER the headline's clock has
+    stopped, each with its own in-run oracle parity.  Short forms (fewer steps, 40 ms pre-heat, parity on the first timed ticks only, no CPU timing legs)."""
+    import copy
+    import torch.distributed as dist
+    out, failed = {}, False
+    t0 = time.perf_counter()
+
+    def mk(**over):
+        a = copy.copy(base_args)
+        a.preheat_ms, a.parity_ticks, a.cpu_ticks, a.parity_only, a.schema, a.sync, a.no_cpu_baseline = 40.0, 6, 1, True, "headline", False, False
+        for k, v in over.items(): setattr(a, k, v)
+        return a
+
+    def guard(name, fn):
+        nonlocal failed
+        if time.perf_counter() - t0 > budget_s:
+            out[name] = {"skipped": f"extra_configs budget of {budget_s:.0f} s spent"}; return
+        t1 = time.perf_counter()
+        try:
+            line, bad = fn()
+            c = compact(line); c["seconds"] = round(time.perf_counter() - t1, 1)
+            out[name] = c; failed |= bool(bad)
+        except Exception as e:              # noqa: BLE001 -- an extra line must not take the headline down; its absence is visible
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # ---- config 2: 10 k entities (launch / latency bound) -- bench.py's own loop and the C loop
+    def cfg2():
+        a = mk(entities=10_000, steps=400, warmup=16)
+        line, bad = single_line(bg, cm, torch, a, dev)
+        kus = line["roofline"]["avg_launch_us"]
+        line["c_loop"] = c_loop_synctest(bg, cm, torch, a.entities, a.depth, 2000, kernel_us=kus)
+        line["c_loop"]["two_in_flight"] = {k: v for k, v in c_loop_synctest(bg, cm, torch, a.entities, a.depth, 2000, inflight=2, kernel_us=kus, parity_ticks=0).items() if k in ("ms_per_step", "value", "latency_floor", "ticks_in_flight")}
+        return line, bad or line["c_loop"]["parity"]["equal"] is not True
+    guard("config2", cfg2)
+    # ---- config 4: P2P-shaped rollbacks at 100 k
+    def cfg4():
+        a = mk(entities=100_000, steps=400, warmup=16, cpu_ticks=0, no_cpu_baseline=True)
+        line, bad = p2p_line(bg, cm, torch, a)
+        r = line["roofline"]
+        line["c_loop"] = c_loop_p2p(bg, cm, torch, a.entities, a.depth, 2000, kernel_us=r["avg_launch_us"], launches_per_tick=line["latency_floor"]["launches_per_tick"])
+        return line, bad or line["c_loop"]["parity"]["equal"] is not True
+    guard("config4", cfg4)
+    # ---- the all-columns-hot world: every Save moves all 15 rows (what the reference's clone-everything save always does)
+    guard("allhot", lambda: single_line(bg, cm, torch, mk(schema="allhot", steps=40, warmup=8), dev))
+    # ---- config 5 on this GPU: 256 predicted-input branches x 100 k x 8 frames (world size 1 over the real RCCL), without and with the spawn system
+    if dist.is_available():
+        own = not dist.is_initialized()
+        try:
+            if own:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 90))
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+            guard("config5_1gpu", lambda: fanout_line(bg, cm, torch, mk(entities=100_000, branches=256, steps=10, warmup=2, parity_steps=1, spawn=False, fanout=True), dist, 0, 1, dev, f"cuda:{dev}"))
+            guard("config5_spawn", lambda: fanout_line(bg, cm, torch, mk(entities=100_000, branches=256, steps=6, warmup=2, parity_steps=1, spawn=True, fanout=True, preheat_ms=0.0), dist, 0, 1, dev, f"cuda:{dev}"))
+        except Exception as e:              # noqa: BLE001
+            out.setdefault("config5_1gpu", {"error": f"{type(e).__name__}: {e}"[:300]})
+        finally:
+            if own and dist.is_initialized(): dist.destroy_process_group()
+    out["seconds_total"] = round(time.perf_counter() - t0, 1)
+    return out, failed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -572,11 +1037,6 @@ def main():
     ap.add_argument("--nt", action="store_true", help="non-temporal snapshot copies (A/B knob)")
     ap.add_argument("--sync", action="store_true", help="synchronous ggrs_hip_handle_requests per step (host blocks on every tick) "
                     "instead of the default enqueue/collect pipeline (tick N+1 is enqueued before tick N's checksums are collected)")
-    ap.add_argument("--arena", choices=["both", "paged", "contig"], default="paged",
-                    help="single-GPU path: `value` is measured on the library's default paged arena unless 'contig' is forced; 'both' also "
-                         "measures the opt-in physically contiguous arena first (it must be the process's first device allocation) and reports it "
-                         "as roofline.contig_arena_variant (round 3: it paid for k_tick3's 16-byte store streams; the generated kernel is faster on paged memory)")
-    ap.add_argument("--paged-arena", action="store_true", help="same as --arena paged")
     ap.add_argument("--schema", choices=["headline", "full", "allhot"], default="headline",
                     help="headline: BASELINE's 3 registered components (60 B/entity); full: the reference stress_test's POD schema "
                          "(+ GlobalTransform 12 x f32, three 1-byte visibilities: examples/stress_tests/particles.rs:190-199); allhot: the headline "
@@ -584,8 +1044,8 @@ def main():
     ap.add_argument("--fanout", action="store_true", help="run the N > 1 code path (RCCL broadcast + all-gather inside the library) even at world size 1")
     ap.add_argument("--branches", type=int, default=1, help="fan-out path: predicted-input branches per rank (BASELINE config 5: 256 over all ranks)")
     ap.add_argument("--spawn", action="store_true", help="fan-out: register the stress_test's spawn system (100 particles per frame while INPUT_SPAWN is held): the "
-                    "branches whose predicted input byte carries the bit diverge from the others (SURVEY 8d's wording of config 5).  A firing spawn system "
-                    "ends a request group (Bevy Commands flush), so those branches run frame by frame and are not batched")
+                    "branches whose predicted input byte carries the bit diverge from the others (SURVEY 8d's wording of config 5).  The spawn runs INSIDE the branch's "
+                    "request group (fused), and identical spawning branches -- same frames, same staged payload -- still ride in one launch")
     ap.add_argument("--no-share-prefix", action="store_true", help="fan-out A/B: every branch replays [Load(C), Advance(confirmed input), Save(C+1)] itself "
                     "(the round-3 request lists) instead of starting from the ONE saved C+1")
     ap.add_argument("--parity-steps", type=int, default=-1, help="N > 1 / --fanout: timed steps whose gathered checksum table rank 0 replays on the CPU oracle "
@@ -597,9 +1057,13 @@ def main():
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=3,
                     help="BASELINE.json config: 3 (default) = the headline, stress_test 1 M x depth 8; 2 = 10 k entities; 4 = P2P-shaped rollbacks "
                          "(0..8 frames per tick) at 100 k; 5 = 256 predicted-input branches x 100 k x 8 frames (all on this node's GPUs)")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: skip `extra_configs` (configs 2 / 4 / 5, the all-columns-hot world), which the default N = 1 headline run "
+                    "measures after its clock has stopped")
+    ap.add_argument("--extra-budget-s", type=float, default=75.0, help="wall-time budget of `extra_configs`: configs that would start beyond it are reported as skipped")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
-    if args.paged_arena: args.arena = "paged"
+    default_headline = (args.config == 3 and args.entities == 1_000_000 and args.depth == 8 and args.schema == "headline" and not (args.fanout or args.sync or args.unfused or args.no_groups
+                        or args.nt or args.no_checksum or args.no_cpu_baseline or args.branches != 1))
     if args.config == 2: args.entities = 10_000
     if args.config == 4: args.entities = 100_000
     if args.config == 5:
@@ -647,296 +1111,24 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
             ctl_dev = "cpu"
-    n, D, K, W = args.entities, args.depth, args.steps, args.warmup
-    bps = cm.schema_bytes_per_entity(args.schema)          # registered payload R (60 B for the headline schema)
-    comm_size = world_size
 
-    variant = None
-    if args.config == 4 and not distributed:
-        import torch  # noqa: F811
-        m4 = measure_p2p(bg, cm, torch, args)
-        t_ms, t_n = m4["prof"]["tick"]
-        avg_s = t_ms / max(t_n, 1) * 1e-3
-        bpl = m4["prof_bytes"]["tick"] / max(t_n, 1)
-        line = {"metric": f"rollback-resim entity-frames/sec, P2P-shaped rollbacks (0..{D} frames per tick) at {n} entities; GB/s vs HBM peak",
-                "value": m4["live"] * m4["advances"] / m4["secs"], "unit": "entity-frames/s", "n_gpus": 1, "steps": K, "warmup": W,
-                "ms_per_step": m4["secs"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
-                "config": {"workload": f"BASELINE config 4: p2p-shaped session, {n} entities x 3 registered components, a rollback of 0..{D - 1} frames every tick "
-                                       f"(mean {m4['mean_rollback']:.2f}), ring depth {D}", "request_group_kernel": m4["info"].get("request_group_kernel"),
-                           "specialised_kernel": m4["info"].get("specialised_kernel"), "specialise_settle": m4["settle"],
-                           "arena_actual": m4["info"].get("arena"), "host_api": "enqueue/collect, 1 tick in flight"},
-                "roofline": {"bound": "hbm", "kernel": m4["info"].get("request_group_kernel"), "achieved": bpl / avg_s / 1e9 if t_n else 0.0, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": bpl / avg_s / 1e9 / HBM_PEAK_GBS if t_n else 0.0, "traffic": None,
-                             "avg_launch_us": avg_s * 1e6, "launches_timed": t_n, "algorithmic_bytes_per_launch": bpl,
-                             "note": f"the whole ring ({n} x 60 B x {D + 1} blocks = {n * 60 * (D + 1) / 1e6:.0f} MB) lives in the 256 MB Infinity Cache: this line is launch / latency bound, "
-                                     "the HBM fraction is reported for completeness, not as its roofline"},
-                "latency_floor": latency_floor(avg_s * 1e6, t_n / max(min(K, 50), 1), m4["secs"] / K * 1e6),
-                "telemetry": {"tick_wall_us": m4["tick_wall_us"]}, "parity": m4["parity"], "cpu_baseline": m4["cpu_baseline"]}
-        print(json.dumps(line))
-        if not m4["parity"]["equal"]:
-            print("bench.py: PARITY FAILURE (config 4)", file=sys.stderr); sys.exit(1)
-        return
-    if not distributed:
-        # order-safe: the contiguous arena must be this process's FIRST device allocation (include/ggrs_hip.h,
-        # GGRS_WORLD_CONTIG_ARENA), and freeing it leaves nothing cached behind -- so it is measured first, destroyed, and the
-        # headline (library default: paged) after it
-        m = measure_single(bg, cm, torch, args, contig=False)
-        secs, live, gpu_cs, prof = m["secs"], m["live"], m["gpu_cs"], m["prof"]
-        # SyncTest's own check over ALL timed ticks (ggrs SyncTestSession: a resimulated frame's checksum must equal the first
-        # one recorded for that frame, else MismatchedChecksum): timed tick k at frame F saved frames F-D+1 .. F
-        first_seen, resim_ok, f_end = {}, True, m["f_end"]
-        for k, tick in enumerate(gpu_cs):
-            F = f_end - (len(gpu_cs) - k)
-            for j, c in enumerate(tick):
-                resim_ok &= first_seen.setdefault(F - D + 1 + j, c) == c
-        total_entities = live
-        info = m["info"]
-    else:
-        from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
-        stream = torch.cuda.current_stream().cuda_stream
-        flags = (bg.GGRS_WORLD_UNFUSED if args.unfused else 0) | (bg.GGRS_WORLD_NT_COPY if args.nt else 0) | (bg.GGRS_WORLD_NO_GROUPS if args.no_groups else 0)
-        # every rank provisions the same world shape; only rank 0 owns the confirmed world, the others receive it through
-        # ONE ncclBroadcast of the packed state block.  The collectives are issued INSIDE libggrs_hip.so
-        # (ggrs_hip_fanout_*, RCCL dlopen'ed there); torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier.
-        # --spawn (config 5 as SURVEY 8d words it): inputs with INPUT_SPAWN set spawn `rate` particles per frame (particles.rs:258-270), so
-        # branches whose predicted input byte carries the bit really diverge from the others; room for the spawns of one branch's D frames
-        spawn_rate = 100 if args.spawn else 0
-        w = bg.World(n + 2 * spawn_rate * (D + 2), max_depth=D + 2, device=dev, stream=stream, flags=flags)
-        ids = cm.build_particles(w, with_spawn=bool(spawn_rate))
-        if rank == 0:
-            vel, ttl = cm.synthetic_particles(n, ttl="throughput")
-            cm.spawn_particles(w, ids, n, vel, ttl)
-        else:
-            w.spawn(0, {})                                   # seals the world (layout fixed)
-        box = [RcclFanout.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        native = RcclFanout(w, rank, world_size, box[0])
-        c_rank, comm_size, c_dev = native.comm_info()        # what the communicator says, not what the environment says
-        assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
-        fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
-                                desync_detection_interval=10 if args.branches == 1 else 1,   # the reference stress_test's default (particles.rs:49, README.md:84)
-                                share_prefix=not args.no_share_prefix, spawn_fn=cm.frame_spawn_fn(spawn_rate) if spawn_rate else None)
-        fan.sync_confirmed(0)
-        gc.collect(); gc.disable()                           # see measure_single
-        for _ in range(W):
-            fan.step_pipelined(want_result=False)
-        fan.drain(want_result=False)
-        # pre-heat: EVERY rank must run the same number of steps -- the all-gathers pair up by order, and a rank that left a clock-based loop
-        # a few steps early would pair its closing (partial) group with another rank's full one (found by the two-rank GPU test in round 4:
-        # a DesyncDetected whose "wrong" checksum was the right one of a frame 8 steps later).  So: time a short calibration run, agree on
-        # the slowest rank's step time, and derive ONE step count from the requested wall time.
-        pre_t0 = time.perf_counter(); pre_n = 0
-        if args.preheat_ms > 0:
-            calib = 20
-            tc = time.perf_counter()
-            for _ in range(calib):
-                fan.step_pipelined(want_result=False)
-            fan.drain(want_result=False)
-            tstep = torch.tensor([(time.perf_counter() - tc) / calib], dtype=torch.float64, device=ctl_dev)
-            dist.all_reduce(tstep, op=dist.ReduceOp.MAX)
-            pre_n = calib + int(min(200_000, max(0, args.preheat_ms * 1e-3 / max(float(tstep.item()), 1e-6) - calib)))
-            for _ in range(pre_n - calib):
-                fan.step_pipelined(want_result=False)
-            fan.drain(want_result=False)
-        m = {"preheat": {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "same_step_count_on_every_rank": True}}
-        # parity gate: the gathered table (every rank's every branch) of the first P timed steps stays as raw u64 arrays and is
-        # compared on rank 0, after the clock stops, with a serial walk of the same branches on the CPU oracle
-        P_fan = 0 if (args.no_cpu_baseline or args.no_checksum) else max(0, min(K, args.parity_steps if args.parity_steps >= 0 else max(1, 16 // max(1, world_size * args.branches))))
-        c_timed = fan.confirmed
-        cf = torch.tensor([c_timed, -c_timed], dtype=torch.int64, device=ctl_dev)
-        dist.all_reduce(cf, op=dist.ReduceOp.MAX)                # max(C) == -max(-C): every rank enters the timed region at the same confirmed frame
-        if int(cf[0].item()) != -int(cf[1].item()):
-            print(f"bench.py: rank {rank} is at confirmed frame {c_timed}, another rank at {int(cf[0].item())} / {-int(cf[1].item())}: the ranks ran different step counts", file=sys.stderr)
-            sys.exit(3)
-        fan.raw, fan.raw_keep = [], (P_fan if rank == 0 else 0)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            fan.step_pipelined(want_result=False)            # enqueue step k+1, collect + all-gather step k
-        fan.drain(want_result=False)                                          # every one of the K steps is collected inside the timed region
-        w.synchronize()
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        secs = time.perf_counter() - t0
-        gc.enable()
-        m["fanout"] = {"c_timed": c_timed, "raw": list(fan.raw), "parity_steps": P_fan}
-        fan.raw_keep = 0
-        t = torch.tensor([secs], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        secs = float(t.item())
-        live = w.active_count()
-        cnt = torch.tensor([live * args.branches], dtype=torch.int64, device=ctl_dev)   # every branch resimulates the whole world
-        dist.all_reduce(cnt)
-        total_entities = int(cnt.item())
-        w.profile_enable(True)
-        for _ in range(min(K, 20)):
-            fan.step(want_result=False)
-        prof = w.profile_read()
-        m["prof_bytes"] = w.profile_bytes()
-        w.profile_enable(False)
-        info = w.kernel_info()
-
-    value = total_entities * (D + 1) * K / secs
-    save_ms, save_n = prof["save"]
-    adv_ms, adv_n = prof["advance"]
-    load_ms, load_n = prof["load"]
-    tick_ms, tick_n = prof["tick"]
-    fin_ms, fin_n = prof["checksum"]
-
-    def per(ms, cnt):
-        return ms / max(cnt, 1) * 1e-3
-
-    # PMC-derived HBM bytes per launch: only valid for the exact workload the counters were collected on
-    traffic = None
-    traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    grouped = tick_n > 0
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if "k_tick_hbm_bytes_per_launch" not in tj: tj = tj.get(args.schema, {})     # one entry per schema (scripts/pmc_summary.py); the round-3 file was flat
-            same = (tj.get("entities") == n and tj.get("depth") == D and not distributed and not args.no_checksum and tj.get("schema", "headline") == args.schema)
-            if same:
-                traffic = tj.get("k_tick_hbm_bytes_per_launch" if grouped else "k_copy_state_hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic_source = f"{tj.get('source', 'profiles/roofline_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's box; NOT measured in this run)"
-        except Exception:
-            traffic = None
-
-    save_bytes, tick_bytes = 2 * bps, 2 * bps + 2 * bps * D + ADV_BYTES * (D + 1)
-    if grouped:
-        # one fused launch per step (N = 1): read the snapshot once, write D snapshots, write live once
-        launches_per_step = tick_n / max(min(K, 20 if distributed else 50), 1)
-        # algorithmic bytes of a launch = the rows it loads and stores x the slots it covers, as the library counted them when it
-        # built the launch (ggrs_hip_profile_read_bytes).  With row versions a SaveWorld moves only the columns whose bytes in the
-        # ring slot differ from the live ones (the untouched rotation / scale rows reach every slot once); with GGRS_ROW_VERSIONS=0
-        # every copy moves every row: bps x (D + 2) per entity (600 B at D = 8 for the headline schema).
-        full_copy_bytes = bps * (1 + D + 1) * live
-        bytes_per_launch = m["prof_bytes"]["tick"] / max(tick_n, 1) if m.get("prof_bytes") else full_copy_bytes
-        avg_s = per(tick_ms, tick_n)
-        achieved = bytes_per_launch / avg_s / 1e9 if tick_n else 0.0
-        kname = info.get("request_group_kernel", "?")
-        fin_name = "k_gen_finalize / k_tick_finalize"
-        roof = {"bound": "hbm", "kernel": kname + " -- fused request group: LoadWorld + D x SaveWorld incl. checksums + (D+1) x AdvanceWorld in one launch"
-                                           + ("; the per-workgroup checksum rows are folded by the host at collect time" if fin_n == 0 else f"; + {fin_name}"),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_source,
-                # the two accountings, named so they cannot be confused: `frac` == frac_compulsory
-                "frac_compulsory": achieved / HBM_PEAK_GBS,
-                "frac_per_request": (tick_bytes * live / avg_s / 1e9 / HBM_PEAK_GBS) if tick_n else 0.0,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_per_entity": bytes_per_launch / max(live, 1),
-                "full_copy_bytes_per_launch": full_copy_bytes,
-                "row_versions": info.get("row_versions"),
-                "algorithmic_bytes_note": f"rows the fused launch loads and stores x slots, counted by the library per launch: with row versions only columns whose bytes "
-                                          f"differ from the destination's move (every snapshot is complete; the never-written rotation / scale rows are already in every ring slot; HBM traffic can be BELOW this figure: the group's first Save is stored through the L2 and the next launch's loads hit there); "
-                                          f"a full copy would move {bps} B/entity snapshot read + {bps} B x saves + {bps} B live write = {bps * (D + 2)} B/entity "
-                                          f"(SURVEY 8d's one-kernel-per-request model, {tick_bytes} B/entity-tick, is reported as *_per_request)",
-                "avg_launch_us": avg_s * 1e6, "launches_timed": tick_n, "launches_per_step": launches_per_step,
-                "launch_us": m.get("launch_us"),
-                "other_kernels": ({fin_name: {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
-                "per_request_equiv_GBps": tick_bytes * live * K / secs / 1e9,
-                "per_request_equiv_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
-        if tick_n and not distributed and not args.no_checksum:
-            # (the particles schemas checksum two components: Velocity and Transform.translation, tests/common.py build_particles)
-            try: roof["alu"] = alu_view(6.0 * 2 * live * D, avg_s)
-            except Exception: pass
-        if variant is not None:
-            v_ms, v_n = variant["prof"]["tick"]
-            v_avg = per(v_ms, v_n)
-            roof["contig_arena_variant"] = {
-                "what": "the same measurement on a physically contiguous arena (GGRS_WORLD_CONTIG_ARENA, opt-in: see include/ggrs_hip.h), "
-                        "measured first in this process; NOT the headline",
-                "arena_actual": variant["info"].get("arena"), "value": variant["live"] * (D + 1) * K / variant["secs"],
-                "ms_per_step": variant["secs"] / K * 1e3, "avg_launch_us": v_avg * 1e6,
-                "frac": (variant["prof_bytes"]["tick"] / max(v_n, 1) / v_avg / 1e9 / HBM_PEAK_GBS) if v_n else 0.0}
-    else:
-        save_avg_s = per(save_ms, save_n)
-        # a SaveWorld as its own launch moves the rows whose versions differ (row versions filter k_copy_state's plan too): the library's count,
-        # not the full 2 x R per entity, is the numerator (with GGRS_ROW_VERSIONS=0 the two coincide)
-        counted = (m.get("prof_bytes") or {}).get("save", 0)
-        save_launch_bytes = counted / max(save_n, 1) if counted else save_bytes * live
-        achieved = save_launch_bytes / save_avg_s / 1e9 if save_n else 0.0
-        roof = {"bound": "hbm", "kernel": "k_copy_state (SaveWorld)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": save_launch_bytes, "full_copy_bytes_per_launch": save_bytes * live,
-                "avg_launch_us": save_avg_s * 1e6, "launches_timed": save_n,
-                "other_kernels": {
-                    "k_particles_step (AdvanceWorld)": {"avg_launch_us": per(adv_ms, adv_n) * 1e6,
-                                                       "achieved_GBps": ADV_BYTES * live / per(adv_ms, adv_n) / 1e9 if adv_n else 0.0},
-                    "k_copy_state (LoadWorld)": {"avg_launch_us": per(load_ms, load_n) * 1e6,
-                                                "achieved_GBps": save_bytes * live / per(load_ms, load_n) / 1e9 if load_n else 0.0}},
-                "whole_tick_achieved_GBps": tick_bytes * live * K / secs / 1e9,
-                "whole_tick_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
-
-    headline = n == 1_000_000 and D == 8 and args.schema == "headline"
-    line = {
-        "metric": "rollback-resim entity-frames/sec at 1M entities, depth 8; HBM GB/s vs peak" if headline else
-                  f"rollback-resim entity-frames/sec at {n} entities, depth {D}, schema {args.schema}; HBM GB/s vs peak",
-        "value": value, "unit": "entity-frames/s", "n_gpus": comm_size, "steps": K, "warmup": W,
-        "ms_per_step": secs / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32+u64", "data": "synthetic",
-        "config": {"workload": f"stress_test {n} entities x {cm.schema_description(args.schema)}, "
-                               f"SyncTest depth {D}: 1 load + {D} saves + {D + 1} advances per step",
-                   "entities_per_gpu": live, "depth": D,
-                   "spawn_system": bool(args.spawn), "parallelism": "single GPU" if not distributed else f"speculative fan-out, {args.branches} predicted-input branch(es) per rank x {comm_size} ranks (ncclCommCount) (ncclBroadcast of the confirmed snapshot once, one ncclAllGather of the checksums per 10 steps (the reference's --desync-detection-interval default) on a side stream -- both inside libggrs_hip.so, ggrs_hip_fanout_*)",
-                   "kernels": "unfused" if args.unfused else ("per-request" if args.no_groups else "request-group"),
-                   "arena_actual": info.get("arena"), "request_group_kernel": info.get("request_group_kernel"), "specialised_kernel": info.get("specialised_kernel"),
-                   "hiprtc": info.get("hiprtc"), "device": dev,
-                   "nt_stores": bool(args.nt), "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
-        "preheat": m.get("preheat"),
-        "roofline": roof,
-    }
-    if not distributed and grouped and n * bps * (D + 1) <= (256 << 20):
-        # the whole ring fits the 256 MB Infinity Cache: launch / latency bound ("report it but do not judge it against HBM peak")
-        line["latency_floor"] = latency_floor(per(tick_ms, tick_n) * 1e6, launches_per_step, secs / K * 1e6)
-    if distributed and args.branches > 1:
-        # checksum-only branches (dead-snapshot elimination): integer-multiply bound, not HBM bound.  Roofline = SeaHash `diffuse`
-        # per second against the chip's measured ceiling (scripts/ubench_alu.hip -> profiles/alu_ceiling.json).  Algorithmic
-        # count per SURVEY 8d: 12 u64 multiplies = 6 diffuse per entity per checksummed component per SaveWorld.
-        try:
-            ceil = json.load(open(os.path.join(ROOT, "profiles", "alu_ceiling.json")))
-        except Exception:
-            ceil = None
-        diffuses = 6.0 * 2 * live * D * args.branches * comm_size * K
-        line["roofline_alu"] = {"bound": "valu-int (u64 multiply)", "achieved": diffuses / secs / 1e9, "unit": "G diffuse/s",
-                                "peak": (ceil or {}).get("diffuse_G_per_s"), "frac": (diffuses / secs / 1e9 / ceil["diffuse_G_per_s"]) if ceil else None,
-                                "peak_source": (ceil or {}).get("source"),
-                                "shared_prefix": not args.no_share_prefix,
-                                "note": "algorithmic diffuses: 6 per entity per checksummed component per SaveWorld, 2 components, D SaveWorlds per branch -- every branch's D "
-                                        "Checksum(u128)s are delivered.  The kernel hoists the order hash and memoises unchanged tails, and the step computes the "
-                                        "branch-invariant Save(C+1) once per rank instead of once per branch (shared_prefix), so fewer are executed"}
-    if not distributed:
-        line["telemetry"] = {"clocks_start": m.get("clocks_start"), "clocks_end": m.get("clocks_end"), "tick_wall_us": m.get("tick_wall_us"), "rss_mb": m.get("rss_mb")}
-    parity_failed = False
-    if rank == 0 and not distributed:
-        line["parity"] = {"synctest_resim_consistent_over_timed_ticks": bool(resim_ok), "timed_ticks": len(gpu_cs)}
-        parity_failed = not resim_ok
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
-        base, par = cpu_baseline_and_parity(n, D, args.cpu_ticks, m["frames_before_timed"], gpu_cs, 0 if args.no_checksum else args.parity_ticks, schema=args.schema)
-        line["cpu_baseline"] = base
-        line["parity"].update(par)
-        parity_failed |= par["equal"] is False
-    elif rank == 0 and not args.no_cpu_baseline:
-        # N > 1 (and --fanout): the same CPU figures as the N = 1 line, timed once on rank 0 after the clock stopped (the other ranks
-        # wait at the closing barrier), and the parity gate over the gathered table
-        fo = m["fanout"]
-        base, _ = cpu_baseline_and_parity(n, D, args.cpu_ticks, D + 1, [], 0)
-        line["cpu_baseline"] = base
-        from bevy_ggrs_amd.fanout import default_branch_input
-        par = fanout_parity(n, D, fo["c_timed"], fo["raw"], comm_size, args.branches, default_branch_input, lambda f: 0,
-                            threads=max(1, min(64, os.cpu_count() or 1)), spawn_rate=100 if args.spawn else 0)
-        par["cross_rank_confirmed_frames_agree"] = True     # SpeculativeFanout raises DesyncDetected otherwise (every step, every rank)
-        line["parity"] = par
-        parity_failed = par["equal"] is not True
-    elif rank == 0:
-        line["cpu_baseline"] = None
-    if dist is not None:
+    if distributed:
+        line, parity_failed = fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev)
         dist.barrier()
         dist.destroy_process_group()
+    elif args.config == 4:
+        line, parity_failed = p2p_line(bg, cm, torch, args)
+    else:
+        line, parity_failed = single_line(bg, cm, torch, args, dev)
+        if default_headline and not args.no_extra:
+            # every other BASELINE config, measured AFTER the headline's timed region (and its parity / CPU legs) in the same process
+            extra, extra_failed = extra_configs(bg, cm, torch, args, dev, budget_s=args.extra_budget_s)
+            line["extra_configs"] = extra
+            parity_failed |= extra_failed
     if rank == 0:
         print(json.dumps(line))
         if parity_failed:
-            print("bench.py: PARITY FAILURE -- GPU checksums differ from the CPU oracle's (see \"parity\")", file=sys.stderr)
+            print("bench.py: PARITY FAILURE -- GPU checksums differ from the CPU oracle's (see \"parity\" of the line / of its extra_configs)", file=sys.stderr)
             sys.exit(1)
 
 

@@ -133,21 +133,24 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
 }
 
 // ------------------------------------------------------------------ fold-forward (host_groups.hpp)
-// One row of per-workgroup checksum partials -- n values the PREVIOUS launch of the stream left in device memory -- becomes one value in
-// pinned host memory, followed by its tag: XOR for a component's entity hashes (component_checksum.rs:88-89), the sum for the live counts
-// (entity_checksum.rs:40).  Run by the first workgroups of the next request-group launch (256 threads), or by k_ff_fold when no launch follows.
-// The value first, then the tag the collecting host polls (same pinned allocation; a system-scope release orders them).
-__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t n, bool is_cnt, uint64_t* out, uint64_t* tag, uint64_t seq) {
+// One CHUNK of one row of per-workgroup checksum partials -- entries [lo, hi) (entry e at p[e * istride]) of what the PREVIOUS launch of the
+// stream left in device memory -- becomes one value in pinned host memory, followed by its tag: XOR for a component's entity hashes (component_checksum.rs:88-89),
+// the sum for the live counts (entity_checksum.rs:40).  Run by the first workgroups of the next request-group launch (256 threads), or by
+// k_ff_fold when no launch follows.  A chunk is at most 1024 values: 4 eight-byte loads in flight per lane, ONE trip -- the role must not cost
+// the tile role registers (the kernel's allocation is the maximum over both: with 16 loads in flight it grew from 28 to 41 VGPRs and the
+// 1 M launch from 48.9 to 50.1 us, profiles/r05b).  The value first, then the tag the collecting host polls (same pinned allocation).
+constexpr uint32_t FF_CHUNK = 1024;
+__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* out, uint64_t* tag, uint64_t seq) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     __shared__ unsigned long long ff_acc;
     if (tid == 0) ff_acc = 0ull;
     __syncthreads();
     uint64_t x = 0, sum = 0;
-    constexpr int INFL = 16;                                       // loads in flight per lane and trip: a 1 M-entity world's row (3907 values) is ONE trip
-    for (uint32_t i0 = tid; i0 < n; i0 += (uint32_t)INFL * 256u) {
+    constexpr int INFL = 4;
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) {
         uint64_t v[INFL];
 _Pragma("unroll")
-        for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < n ? p[i] : 0ULL; }
+        for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < hi ? p[(uint64_t)i * istride] : 0ULL; }
 _Pragma("unroll")
         for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; }
     }
@@ -155,8 +158,13 @@ _Pragma("unroll")
     else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); }
     __syncthreads();
     if (tid == 0) {
+        // Both stores are relaxed system-scope atomics (write-through, no cache maintenance) with an explicit vmcnt(0) between them: the value has
+        // left for host memory before the tag is issued, and the two posted writes reach the host in order.  NOT a system-scope release: that is a
+        // write-back of the XCD's whole L2 (buffer_wbl2) -- issued here by 12 workgroups per XCD while the tile workgroups of the same launch stream
+        // their first Save THROUGH that L2, it cost the 1 M launch 2.5 us (48.9 -> 51.4 us, profiles/r05d).
         __hip_atomic_store(out, (uint64_t)ff_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(tag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 )

@@ -68,6 +68,11 @@ struct ggrs_fanout {
     uint32_t head = 0, tail = 0;         // tail: slot being filled, head: oldest uncollected
     uint32_t cap_u128 = 4096;            // checksums per rank a slot can hold (steps x saves)
     uint32_t interval = 1;               // steps per all-gather
+    // The shape every all-gather of this fan-out has: `interval` steps of `agreed_saves` Checksum(u128)s (+ one tag per step) from EVERY rank -- agreed
+    // by ONE small all-gather at the first step after init / set_interval (fanout_agree_shape) and used as the send count of every later one, a closing
+    // partial group included (zero-padded): ranks can no longer hand RCCL mismatched counts (DESIGN 9.8 of round 4) -- a rank whose lists have
+    // another shape is refused before anything is enqueued, a rank that ran fewer steps shows up in the tags (collect: "ranks are out of step")
+    bool shape_agreed = false; uint32_t agreed_saves = 0;
     bool owns_results_flag = false;      // this object switched its world to device-side folds (ggrs_world::device_results_only)
     std::string err;
     int fail(int code, const char* fmt, ...) {
@@ -81,11 +86,31 @@ struct ggrs_fanout {
 #define FANCHK_NCCL(f, call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) return (f)->fail(GGRS_E_HIP, "%s failed: %s", #call, rccl().GetErrorString(e_)); } while (0)
 
 namespace {
-// closes the slot being filled: ONE all-gather of everything it holds, then device -> pinned, on the side stream
+// {steps per all-gather, SaveGameState requests per step} of every rank, exchanged ONCE (blocking: a start-up cost) through the buffers of the empty
+// slot being filled; every rank sees the whole table, so every rank fails the same way when they differ
+int fanout_agree_shape(ggrs_fanout* f, uint32_t saves) {
+    ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
+    if ((uint64_t)f->interval * saves > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u steps x %u checksums per rank in one all-gather (at most %u)", f->interval, saves, f->cap_u128);
+    s.h_tags[0] = f->interval; s.h_tags[1] = saves;
+    FANCHK_HIP(f, hipMemcpyAsync(s.d_send, s.h_tags, 16, hipMemcpyHostToDevice, f->comm_stream));
+    FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, 2, ncclUint64, f->comm, f->comm_stream));
+    FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, (size_t)16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
+    FANCHK_HIP(f, hipStreamSynchronize(f->comm_stream));
+    for (int r = 0; r < f->size; ++r)
+        if (s.h_recv[2 * r] != f->interval || s.h_recv[2 * r + 1] != saves)
+            return f->fail(GGRS_E_INVALID, "ranks disagree on the shape of an all-gather group: %u steps x %u saves on rank %d, %llu steps x %llu saves on rank %d "
+                                           "(every rank must use the same interval and pass lists with the same number of SaveGameState requests)",
+                           f->interval, saves, f->rank, (unsigned long long)s.h_recv[2 * r], (unsigned long long)s.h_recv[2 * r + 1], r);
+    f->shape_agreed = true; f->agreed_saves = saves;
+    return GGRS_OK;
+}
+// closes the slot being filled: ONE all-gather of the agreed size -- interval x agreed_saves checksums + interval tags per rank, zero beyond the steps the
+// group really holds --, then device -> pinned, on the side stream
 int fanout_close_slot(ggrs_fanout* f) {
     ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
     if (s.n_steps == 0 || s.closed) return GGRS_OK;
     const size_t n = (size_t)s.n_steps * s.n_saves;
+    const size_t n_full = (size_t)f->interval * f->agreed_saves;             // checksums per rank of a full group: the fixed layout of every all-gather
     ggrs_world* w = f->w;
     // everything of the group happens here, once per `interval` steps and on the side stream: wait for the group's last
     // tick, pinned result ring -> device (consecutive steps sit in consecutive ring slots unless the ring wrapped),
@@ -98,9 +123,11 @@ int fanout_close_slot(ggrs_fanout* f) {
         FANCHK_HIP(f, hipMemcpyAsync(s.d_send + (size_t)k * s.n_saves * 2, w->h_results + 2 * (size_t)s.first[k], (size_t)run * s.n_saves * 16, hipMemcpyHostToDevice, f->comm_stream));
         k += run;
     }
-    // the steps' tags ride behind the checksums (one small pinned -> device copy per group)
-    const size_t per_rank = n + s.n_steps;
-    FANCHK_HIP(f, hipMemcpyAsync(s.d_send + n * 2, s.h_tags, (size_t)s.n_steps * 16, hipMemcpyHostToDevice, f->comm_stream));
+    // the steps' tags ride behind the checksums (one small pinned -> device copy per group); a partial group (the closing one) is padded with zeros
+    const size_t per_rank = n_full + f->interval;
+    for (uint32_t k = s.n_steps; k < f->interval; ++k) { s.h_tags[2 * k] = 0; s.h_tags[2 * k + 1] = 0; }
+    if (n < n_full) FANCHK_HIP(f, hipMemsetAsync(s.d_send + n * 2, 0, (n_full - n) * 16, f->comm_stream));
+    FANCHK_HIP(f, hipMemcpyAsync(s.d_send + n_full * 2, s.h_tags, (size_t)f->interval * 16, hipMemcpyHostToDevice, f->comm_stream));
     FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, per_rank * 2, ncclUint64, f->comm, f->comm_stream));
     FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, per_rank * 16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
     FANCHK_HIP(f, hipEventRecord(s.done, f->comm_stream));
@@ -192,6 +219,7 @@ int ggrs_hip_fanout_set_interval(ggrs_fanout* f, uint32_t steps_per_all_gather) 
     if (!f || steps_per_all_gather == 0 || steps_per_all_gather > 16) return GGRS_E_INVALID;
     if (f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps) return f->fail(GGRS_E_INVALID, "interval changed inside a partly filled group");
     f->interval = steps_per_all_gather;
+    f->shape_agreed = false;                                     // the next step exchanges {interval, saves per step} again
     return GGRS_OK;
 }
 
@@ -223,8 +251,9 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
     // would shift every later collect by one
     uint32_t want = 0;
     for (uint32_t i = 0; i < n; ++i) want += reqs[i].kind == GGRS_REQ_SAVE;
-    if (s.n_steps && want != s.n_saves) return f->fail(GGRS_E_INVALID, "steps of one all-gather group must hold the same number of SaveGameState requests (%u vs %u)", want, s.n_saves);
-    if ((uint64_t)(s.n_steps + 1) * want > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u checksums per rank in one all-gather (at most %u)", (s.n_steps + 1) * want, f->cap_u128);
+    if (!f->shape_agreed) { const int arc = fanout_agree_shape(f, want); if (arc) return arc; }
+    if (want != f->agreed_saves) return f->fail(GGRS_E_INVALID, "every step of this fan-out holds %u SaveGameState requests (agreed by all ranks at the first step); this list has %u -- "
+                                                              "ggrs_hip_fanout_set_interval starts a new agreement", f->agreed_saves, want);
     uint32_t ns = 0;
     int rc = ggrs_hip_enqueue_requests(w, reqs, n, &ns);
     if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
@@ -257,16 +286,18 @@ int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t ma
         int rc = ggrs_hip_collect_checksums(w, own.data(), s.n_saves, &got);
         if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
     }
-    // every rank must have gathered the SAME steps: compare the tags, then hand out the checksums without them
-    const size_t stride = ((size_t)per_rank + s.n_steps) * 2;                    // u64 per rank in h_recv
-    const uint64_t* mine = s.h_recv + (size_t)f->rank * stride + (size_t)per_rank * 2;
+    // every rank must have gathered the SAME steps: compare the tags of all `interval` places (a rank that ran fewer steps left zeros), then hand out the
+    // checksums without them
+    const size_t n_full = (size_t)f->interval * f->agreed_saves;
+    const size_t stride = (n_full + f->interval) * 2;                            // u64 per rank in h_recv: the agreed layout
+    const uint64_t* mine = s.h_recv + (size_t)f->rank * stride + n_full * 2;
     int out_of_step = -1; uint32_t bad_step = 0;
     for (int r = 0; r < f->size && out_of_step < 0; ++r) {
-        const uint64_t* theirs = s.h_recv + (size_t)r * stride + (size_t)per_rank * 2;
-        for (uint32_t k = 0; k < s.n_steps; ++k) if (theirs[2 * k] != mine[2 * k] || theirs[2 * k + 1] != mine[2 * k + 1]) { out_of_step = r; bad_step = k; break; }
+        const uint64_t* theirs = s.h_recv + (size_t)r * stride + n_full * 2;
+        for (uint32_t k = 0; k < f->interval; ++k) if (theirs[2 * k] != mine[2 * k] || theirs[2 * k + 1] != mine[2 * k + 1]) { out_of_step = r; bad_step = k; break; }
     }
     if (out_of_step >= 0) {
-        const uint64_t* theirs = s.h_recv + (size_t)out_of_step * stride + (size_t)per_rank * 2;
+        const uint64_t* theirs = s.h_recv + (size_t)out_of_step * stride + n_full * 2;
         const int rc = f->fail(GGRS_E_INVALID, "ranks are out of step: step %u of this all-gather starts at frame %d with %llu saves on rank %d, at frame %d with %llu saves on rank %d "
                                "(every rank must call ggrs_hip_fanout_step the same number of times with lists of the same shape)", bad_step,
                                (int32_t)(uint32_t)mine[2 * bad_step], (unsigned long long)mine[2 * bad_step + 1], f->rank,

@@ -30,6 +30,9 @@ int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState&
     int rc = launch_load_reconcile(w, *g.src); if (rc) return rc;        // EntityResurrect: before the group rewrites live liveness
     w->len = g.src->len;
     w->cur_ver = g.src->ver;                                              // the logical live state is the snapshot from here on
+    // ... except for components under a Strategy: what LoadWorld puts into the world is load(store(x)), which need not be the x the live
+    // block (or any other slot) holds under the same version (a lossy Stored form) -- the loaded words are NEW values
+    if (w->has_strategy) for (uint32_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].s_n_words && !w->comps[c].no_rollback) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) ver_touch(w, w->comps[c].col_base + k);
     g.cover = std::max(g.cover, g.src->dirty_len);
     g.src_is_live = 0;
     ++i;
@@ -154,7 +157,7 @@ inline void ff_attach(ggrs_world* w, GgrsJitArgs& j) {
     ggrs_world::FfPending& p = w->ff_pending;
     if (!p.valid) return;
     j.ff_rows = reinterpret_cast<const ggrs_u64*>(w->d_ff_rows[p.buf]); j.ff_out = reinterpret_cast<ggrs_u64*>(w->d_rows + p.out_off); j.ff_seq = p.seq;
-    j.ff_nvals = p.nvals; j.ff_blocks = (p.nvals + 7u) & ~7u; j.ff_g = p.g; j.ff_stride = p.stride;
+    j.ff_nvals = p.nvals; j.ff_blocks = (p.nvals + 7u) & ~7u; j.ff_g = p.g; j.ff_stride = p.stride; j.ff_istride = p.istride; j.ff_split = p.split;
     w->ff_done_id = p.id; p.valid = false;
 }
 
@@ -425,7 +428,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows, false); }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
-        j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride;
+        j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
         j.nt = (w->nt_copy || cover > JIT_NT_MIN_SLOTS) ? 1u : 0u;
@@ -465,12 +468,16 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             // GGRS_FOLD_FORWARD_MIN_WGS workgroups), the host from pinned rows (smaller groups), or k_gen_finalize (blocking calls of more than 1024
             // workgroups, results that stay on the device, no room in the pinned ring)
             uint64_t rows_off = 0;
-            const uint32_t nvals = j.n_saves * (n_cks + 1);
+            const uint32_t ff_split = (g + FF_CHUNK - 1u) / FF_CHUNK;                      // chunks of <= 1024 entries per row: one fold-forward workgroup each
+            const uint32_t nvals = j.n_saves * (n_cks + 1) * ff_split;
             bool ff = launch && j.n_saves && !wait && !w->device_results_only && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
                       rows_ring_alloc(w, 2ull * nvals, &rows_off);
             const bool host_fold = !ff && launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
             uint32_t ff_buf = 0;
-            if (ff) { ff_buf = w->ff_cur; w->ff_cur ^= 1u; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[ff_buf]); j.part_stride = g; }
+            const uint32_t rows_n = j.n_saves * (n_cks + 1);
+            // fold-forward rows are TILE-major: a workgroup's values of all its Saves and parts sit side by side (one coalesced store of 192 B for the
+            // stress_test; row-major they were 24 eight-byte stores into 24 different lines, and the 1 M launch took 51 us instead of 48.9: profiles/r05c)
+            if (ff) { ff_buf = w->ff_cur; w->ff_cur ^= 1u; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[ff_buf]); j.part_stride = 1; j.part_tstride = rows_n; }
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (launch) {
                 hipFunction_t fn = jit_spec_for(w, j);
@@ -484,12 +491,12 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (ff) {
-                ggrs_world::HostFold f = make_host_fold(j, res_base + ns, 1u, n_cks, 1u, rows_off);
+                ggrs_world::HostFold f = make_host_fold(j, res_base + ns, ff_split, n_cks, 1u, rows_off);   // (the host XORs / adds the row's chunks)
                 f.ff_id = w->ff_next_id++; f.ff_seq = (0xA5ull << 56) | ++w->ff_seq;      // (a tag no live count and -- but for 2^-64 -- no hash equals)
                 memset(w->h_rows + rows_off + nvals, 0, (size_t)nvals * 8);              // the tag cells: whatever an earlier fold left there is gone
                 w->folds.push_back(f);
                 ggrs_world::FfPending& p = w->ff_pending;
-                p.valid = true; p.id = f.ff_id; p.seq = f.ff_seq; p.buf = ff_buf; p.nvals = nvals; p.g = g; p.stride = g; p.out_off = rows_off;
+                p.valid = true; p.id = f.ff_id; p.seq = f.ff_seq; p.buf = ff_buf; p.nvals = nvals; p.g = g; p.stride = 1; p.istride = rows_n; p.split = ff_split; p.out_off = rows_off;
                 ns += j.n_saves;
             } else if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, g, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {

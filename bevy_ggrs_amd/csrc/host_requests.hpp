@@ -559,7 +559,7 @@ int ff_flush(ggrs_world* w) {
     ggrs_world::FfPending& p = w->ff_pending;
     if (!p.valid) return GGRS_OK;
     FfArgs f; memset(&f, 0, sizeof f);
-    f.rows = w->d_ff_rows[p.buf]; f.out = w->d_rows + p.out_off; f.seq = p.seq; f.nvals = p.nvals; f.g = p.g; f.stride = p.stride; f.nc1 = w->cks_args.n_cks + 1;
+    f.rows = w->d_ff_rows[p.buf]; f.out = w->d_rows + p.out_off; f.seq = p.seq; f.nvals = p.nvals / p.split; f.g = p.g; f.stride = p.stride; f.istride = p.istride; f.nc1 = w->cks_args.n_cks + 1; f.split = p.split;
     hipLaunchKernelGGL(k_ff_fold, dim3(p.nvals), dim3(TPB), 0, w->stream, f);
     HIPCHK(w, hipGetLastError());
     w->ff_done_id = p.id; p.valid = false;
@@ -577,7 +577,7 @@ int run_host_folds(ggrs_world* w, uint32_t n) {
             // the values arrive with the launch (or k_ff_fold) that follows this group's on the stream
             if (f.ff_id > w->ff_done_id) { const int rc = ff_flush(w); if (rc) return rc; }
             const double t0 = w->tl.on ? tl_now_us() : 0;
-            const uint32_t nvals = f.n_saves * nc;
+            const uint32_t nvals = f.n_saves * nc * f.g;              // g = chunks per row here: one value (and one tag) per chunk
             if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, std::max(w->knobs.spin_wait_us, 0))) {
                 HIPCHK(w, hipStreamSynchronize(w->stream));
                 if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, 1000000)) return w->fail(GGRS_E_HIP, "fold-forward: the tags of group %llu never arrived", (unsigned long long)f.ff_id);
@@ -619,8 +619,8 @@ bool rows_ring_alloc(ggrs_world* w, uint64_t need, uint64_t* off) {
 // `blocking`: the caller waits for this group's checksums right away (the synchronous API) -- the host's fold is then serial with the
 // kernel instead of hidden behind the next tick's, so only small groups take it.
 bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off, bool blocking = false) {
-    if (!w->h_rows || w->device_results_only || !n_saves || g > (uint32_t)w->knobs.fold_forward_min_wgs) return false;
-    if (blocking && g > HOST_FOLD_MAX_WGS_BLOCKING) return false;
+    if (!w->h_rows || w->device_results_only || !n_saves) return false;
+    if (blocking ? g > HOST_FOLD_MAX_WGS_BLOCKING : g > (uint32_t)w->knobs.fold_forward_min_wgs) return false;
     return rows_ring_alloc(w, (uint64_t)g * n_saves * (n_cks + 1) * members, off);
 }
 

@@ -179,9 +179,10 @@ struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
     ggrs_u64* parts;                                 // this launch's partial rows: [saves x (n_cks + 1)][part_stride], one entry per workgroup
     // FOLD-FORWARD (ff_blocks != 0): the first ff_blocks workgroups of this launch fold the partial rows the PREVIOUS launch of the stream left in
-    // device memory (ff_rows: [ff_nvals][ff_stride], ff_g entries each) -- one row per workgroup: XOR of a component's entity hashes, or the sum of
-    // the live counts -- and write the ff_nvals folded values, then one tag (ff_seq) per value, into pinned host memory (ff_out): the host finishes
-    // the Checksum(u128)s from 24 values instead of XOR-ing 750 KB of rows per tick at 1 M (host_groups.hpp, "fold-forward")
+    // device memory (ff_rows: [rows][ff_stride], ff_g entries each, ff_split chunks of <= 1024 entries per row) -- one chunk per workgroup: XOR of a
+    // component's entity hashes, or the sum of the live counts -- and write the ff_nvals = rows x ff_split folded values, then one tag (ff_seq) per
+    // value, into pinned host memory (ff_out): the host finishes the Checksum(u128)s from 96 values instead of XOR-ing 750 KB of rows per tick at 1 M
+    // (host_groups.hpp, "fold-forward")
     const ggrs_u64* ff_rows; ggrs_u64* ff_out; ggrs_u64 ff_seq;
     ggrs_u64 live_rows, load_rows;                   // row versions: bit c = column c is stored with the live block / must be loaded at all
     ggrs_u64 op_bits, len;
@@ -195,10 +196,10 @@ struct GgrsJitArgs {
     int save_frame[16]; ggrs_u32 save_pmask[16];     // presence masks: bit c = component c's mask is stored with that Save (the liveness mask always is)
     ggrs_u32 live_pmask, nt_loads;                   // nt_loads: the source block is not expected in the caches (an HBM-sized group whose predecessor cached no Save): its lines are dead after the load
     ggrs_u32 n_ops, n_saves, n_steps, src_is_live, skip_live, dp_s;
-    ggrs_u32 part_stride, nt;                        // nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
+    ggrs_u32 part_stride, part_tstride, nt;          // parts[i * part_stride + tile * part_tstride] (row-major: g, 1; tile-major -- fold-forward --: 1, values per workgroup); nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
-    ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride;
+    ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
     ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
     unsigned char step_flags[24], n_inputs[24];
     unsigned char inputs[24][JIT_IN_MAX];            // per step: n_inputs x input_bytes bytes of PlayerInputs, then (at max_players x input_bytes) one InputStatus byte per player
@@ -244,8 +245,8 @@ JitLayout jit_layout(const ggrs_world* w) {
         FS("const unsigned char*", spawn_payload, need.spawn); FS("ggrs_u64", spawn_first, need.spawn);
         FA("int", save_frame, S, true); FA("ggrs_u32", save_pmask, S, true);
         F1("ggrs_u32", live_pmask, true); F1("ggrs_u32", nt_loads, true); F1("ggrs_u32", n_ops, true); F1("ggrs_u32", n_saves, true); F1("ggrs_u32", n_steps, true);
-        F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", nt, true);
-        F1("ggrs_u32", n_units, true); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true);
+        F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", part_tstride, true); F1("ggrs_u32", nt, true);
+        F1("ggrs_u32", n_units, true); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
         FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
         FS("ggrs_u32", spawn_count, need.spawn);
         FS("unsigned char", step_flags, need.marks); FS("unsigned char", n_inputs, need.inputs);
@@ -532,8 +533,11 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    // FOLD-FORWARD role: the first ff_blocks workgroups (a multiple of 8: the XCD mapping below is unchanged) do not own a tile -- each folds one row\n"
             "    // of partials the PREVIOUS launch on this stream left in device memory and hands the value, then its tag, to the host\n"
             "    if (blockIdx.x < a.ff_blocks) {\n"
-            "        if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals)\n"
-            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)blockIdx.x * a.ff_stride, a.ff_g, (blockIdx.x %% %uu) == %uu, (uint64_t*)a.ff_out + blockIdx.x, (uint64_t*)a.ff_out + a.ff_nvals + blockIdx.x, (uint64_t)a.ff_seq);\n"
+            "        if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals) {                   // ff_nvals = rows x chunks per row (ff_split)\n"
+            "            const uint32_t row = blockIdx.x / a.ff_split, ck = blockIdx.x %% a.ff_split, per = (a.ff_g + a.ff_split - 1u) / a.ff_split;\n"
+            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride, a.ff_istride, ck * per, min(a.ff_g, (ck + 1u) * per), (row %% %uu) == %uu, (uint64_t*)a.ff_out + blockIdx.x,\n"
+            "                        (uint64_t*)a.ff_out + a.ff_nvals + blockIdx.x, (uint64_t)a.ff_seq);\n"
+            "        }\n"
             "        return;\n"
             "    }\n"
             "    const uint32_t bx = blockIdx.x - a.ff_blocks, gx = gridDim.x - a.ff_blocks;\n"
@@ -932,7 +936,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
             "        const uint32_t sv = i / %uu;\n"
             "        if (sv >= o_first && sv < o_last)\n"
-            "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + tile] = s_acc[i];\n"
+            "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + (uint64_t)tile * a.part_tstride] = s_acc[i];\n"
             "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     s += "}\n";
     return true;

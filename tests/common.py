@@ -135,21 +135,24 @@ class SyncTestDriver:
         if c >= 0:
             self.world.set_confirmed(c)
 
-    def tick(self, inputs=(0,), spawn_fn=None):
+    def tick(self, inputs=(0,), spawn_fn=None, patch=None):
         """spawn_fn(frame) -> (vx, vy): the ParticleRng draw of the frame being advanced.  It must
         be a pure function of the frame: ParticleRng is a rollback resource
-        (particles.rs:201), so a resimulated frame redraws the same values."""
+        (particles.rs:201), so a resimulated frame redraws the same values.
+        patch(frame, advance_request): any other per-frame decoration of an AdvanceFrame (spawn_count / spawn_payload of a
+        user-written spawn system, InputStatus, wider inputs) -- a pure function of the frame and its inputs for the same reason."""
         for h, v in enumerate(inputs):
             self.sess.add_local_input(h, v)
         reqs = self.sess.advance_frame()
-        if spawn_fn is not None:
+        if spawn_fn is not None or patch is not None:
             cur = self.world.frame
             for r in reqs:
                 if isinstance(r, bg.LoadGameState):
                     cur = r.frame
                 elif isinstance(r, bg.AdvanceFrame):
-                    if any(i & INPUT_SPAWN for i in r.inputs):
+                    if spawn_fn is not None and any(i & INPUT_SPAWN for i in r.inputs):
                         r.spawn_vx, r.spawn_vy = spawn_fn(cur)
+                    if patch is not None: patch(cur, r)
                     cur += 1
         if self.lib_rule:
             cs = self.world.handle_requests(reqs)

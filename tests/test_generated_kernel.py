@@ -239,8 +239,8 @@ def test_narrow_words_and_custom_hashers_generate():
 # ---- register / scratch budget of the kernels the library writes (static: hiprtc cross-compiles, the code object's metadata says what the
 # kernel needs).  The generated kernel is HBM-bound and hides latency with occupancy: 8 waves per SIMD need <= 64 VGPRs, and a spill to
 # scratch would add HBM traffic of its own.  VGPRs of the tile role when this test was written (steady / generic): headline 28 / 43, allhot 38 / 47, full 28 / 63 (the
-# steady copy of the full schema does not even load the rows no system writes); since round 5 the kernel's allocation is at least the 41 of the fold-forward role
-# (16 eight-byte loads in flight per lane: one trip over a 1 M-entity world's row), still 8 waves per SIMD.
+# steady copy of the full schema does not even load the rows no system writes); the fold-forward role (round 5) keeps 4 eight-byte loads in flight per lane so that it
+# stays below the tile role's need (with 16 the headline's steady copy went from 28 to 41 VGPRs and its launch from 48.9 to 50.1 us).
 def _resources(src: str) -> dict:
     import ctypes as C, subprocess, tempfile
     rtc = C.CDLL("libhiprtc.so")
@@ -257,7 +257,7 @@ def _resources(src: str) -> dict:
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="no llvm-readelf")
-@pytest.mark.parametrize("schema,steady_vgprs", [("headline", 48), ("allhot", 48), ("full", 64)])
+@pytest.mark.parametrize("schema,steady_vgprs", [("headline", 32), ("allhot", 48), ("full", 64)])
 def test_generated_kernels_keep_their_register_budget(schema, steady_vgprs):
     w = dry(1_000_000, 9)
     cm.build_particles(w, schema=schema)

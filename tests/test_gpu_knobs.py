@@ -96,7 +96,7 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
     cm.assert_states_equal(got[1], _ORACLE[n][1], f"{env} n={n}")
     # the knob actually selected what it names
     k = info["request_group_kernel"]
-    per_request = env.get("GGRS_TICK_JIT") == "0" or env.get("GGRS_NO_HIPRTC") == "1"
+    per_request = env.get("GGRS_TICK_JIT") == "0" or (env.get("GGRS_NO_HIPRTC") == "1" and info["generated_kernel"] != "ok")   # (a module another world of this process built serves a world of the same shape)
     if per_request: assert k.startswith("per-request"), k
     else: assert k.startswith("ggrs_jit_tick"), k
     if not per_request:
@@ -105,7 +105,7 @@ def test_every_knob_keeps_the_bits(env, n, monkeypatch):
         assert info["checksum_fold"].startswith(want), info
         assert info["spawn_system"].startswith("runs inside"), info
         assert int(info["kernarg_bytes"]) < 1000, info                                       # the per-world argument block (the one-size block of rounds 2-4 was 2112 bytes)
-    if env.get("GGRS_NO_HIPRTC") == "1": assert info["hiprtc"].startswith("missing") and "no shipped code object" in info["generated_kernel"], info
+    if env.get("GGRS_NO_HIPRTC") == "1": assert info["hiprtc"].startswith("missing") and ("no shipped code object" in info["generated_kernel"] or info.get("generated_kernel_origin", "").startswith("in-process")), info
     if env.get("GGRS_SPIN_WAIT_US") == "0": assert info["blocking_wait"].startswith("hipStreamSynchronize"), info
 
 

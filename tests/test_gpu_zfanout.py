@@ -248,6 +248,26 @@ def test_native_fanout_ranks_over_the_transport_double(size):
             assert (np.asarray(state[k]) == np.asarray(v)).all(), (r, k)
 
 
+def test_eight_ranks_config5_partition_over_the_transport_double():
+    """BASELINE config 5's REAL partition -- 256 predicted-input branches over 8 ranks, 32 per rank -- run as eight processes on the one GPU of this box
+    (collectives over the shared-memory stand-in; control plane: none needed, the unique id travels through a queue): every rank receives rank 0's
+    confirmed snapshot, walks its 32 branches per step, and the gathered table of 256 branches must equal the oracle's serial walk on every rank
+    (no N > 1 hardware exists for this build, so this is the multi-rank evidence)."""
+    from test_fanout_gloo import _serial_reference
+    size, n, D, steps, bpr = 8, 500, 4, 3, 32
+    res = _run_native(size, n, D, steps, bpr, env={"GGRS_RCCL_LIB": _double_lib()})
+    assert all(r[0] == "ok" for r in res.values()), {k: v[:2] for k, v in res.items() if v[0] != "ok"}
+    ref, ref_state = _serial_reference(n, D, size * bpr, steps)
+    for r in range(size):
+        out, state = res[r][1], res[r][2]
+        assert len(out) == steps
+        for got, want in zip(out, ref):
+            assert got["confirmed_checksum"] == want["confirmed_checksum"]
+            assert len(got["branch_checksums"]) == 256 and got["branch_checksums"] == want["branch_checksums"]
+        for k, v in ref_state.items():
+            assert (np.asarray(state[k]) == np.asarray(v)).all(), (r, k)
+
+
 def test_native_fanout_two_ranks_over_rccl():
     """World size 2 over the real RCCL, rank r on device r % devices: on a box with >= 2 GPUs this is the real thing; with both
     ranks on the one visible GPU, RCCL builds that refuse two ranks per device make this a skip, not a failure (the transport
@@ -330,7 +350,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert line["preheat"]["same_step_count_on_every_rank"] is True and line["preheat"]["ticks"] >= 20
 
 
-def _skewed_rank(rank, size, id_q, q):
+def _skewed_rank(rank, size, id_q, q, mode="frame"):
     """Rank 1 advances its confirmed frame once on its own before the common step: the ranks' lists then start at different frames."""
     try:
         import bevy_ggrs_amd as bg
@@ -354,6 +374,16 @@ def _skewed_rank(rank, size, id_q, q):
         else:
             w.spawn(0, {})
         native = RcclFanout(w, rank, size, id_bytes)
+        if mode == "shape":                                           # rank 1 walks three branches per step, rank 0 two: the lists hold different numbers of Saves
+            fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=3 if rank == 1 else 2, native=native)
+            fan.sync_confirmed(0)
+            try:
+                fan.step(); verdict = "no error"
+            except bg.GgrsHipError as e:
+                verdict = f"GgrsHipError {e.code}: {e}"
+            native.close()
+            q.put((rank, "ok", True, verdict))
+            return
         fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=2, native=native)
         fan.sync_confirmed(0)
         first = fan.step()                                            # in step: fine
@@ -376,17 +406,20 @@ def _skewed_rank(rank, size, id_q, q):
         q.put((rank, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
 
 
-def test_ranks_out_of_step_are_refused_by_the_library():
+@pytest.mark.parametrize("mode", ["frame", "shape"])
+def test_ranks_out_of_step_are_refused_by_the_library(mode):
     """Collectives pair up by order: a rank that ran ahead would gather ANOTHER frame's checksums into the table (bench.py's clock-based
-    pre-heat did, round 4).  Every step now carries a tag {frame of its first request, saves} behind its checksums through the all-gather,
-    and ggrs_hip_fanout_collect refuses a table whose ranks disagree -- on every rank, naming both frames."""
+    pre-heat did, round 4).  Every step carries a tag {frame of its first request, saves} behind its checksums through the all-gather,
+    and ggrs_hip_fanout_collect refuses a table whose ranks disagree -- on every rank, naming both frames ("frame").
+    "shape": ranks whose lists hold different numbers of SaveGameState requests used to hand RCCL mismatched counts (undefined: DESIGN 9.8 of
+    round 4); the first step now exchanges {interval, saves per step} in one small all-gather of its own and every rank refuses."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q, id_q = ctx.Queue(), ctx.Queue()
     old = os.environ.get("GGRS_RCCL_LIB")
     os.environ["GGRS_RCCL_LIB"] = _double_lib()
     try:
-        procs = [ctx.Process(target=_skewed_rank, args=(r, 2, id_q, q)) for r in range(2)]
+        procs = [ctx.Process(target=_skewed_rank, args=(r, 2, id_q, q, mode)) for r in range(2)]
         for p in procs: p.start()
     finally:
         if old is None: os.environ.pop("GGRS_RCCL_LIB", None)
@@ -401,4 +434,5 @@ def test_ranks_out_of_step_are_refused_by_the_library():
             if p.is_alive(): p.kill()
     for r in (0, 1):
         assert res[r][0] == "ok" and res[r][1] is True, res[r]
-        assert "GgrsHipError" in res[r][2] and "out of step" in res[r][2] and "frame" in res[r][2], res[r]
+        if mode == "frame": assert "GgrsHipError" in res[r][2] and "out of step" in res[r][2] and "frame" in res[r][2], res[r]
+        else: assert "GgrsHipError" in res[r][2] and "disagree on the shape" in res[r][2], res[r]
