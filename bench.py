@@ -531,7 +531,8 @@ def measure_p2p(bg, cm, torch, args):
     live = w.active_count(); w.close()
     got = [[int.from_bytes(b[16 * i:16 * i + 16], "little") for i in range(len(b) // 16)] for b in got]
     # ---- the CPU oracle under the same script
-    from oracle.binding import FLAT, OracleWorld
+    from oracle.binding import FLAT, OracleWorld, lib as olib0
+    olib0.gor_set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     o = OracleWorld(n, R + 1, FLAT)
     oids = cm.build_particles(o); cm.spawn_particles(o, oids, n, vel, ttl); o.set_depth(R)
     want = []
@@ -540,6 +541,7 @@ def measure_p2p(bg, cm, torch, args):
         reqs += [bg.SaveGameState(f), bg.AdvanceFrame((0,))]
         if f - R >= 0: o.set_confirmed(f - R)
         want.append(o.handle_requests(reqs))
+    olib0.gor_set_num_threads(1)
     # ---- the CPU path beside it: the oracle's reference-shaped storage, one thread, the first ticks of the same script
     cpu = None
     if not args.no_cpu_baseline:
@@ -617,11 +619,19 @@ def c_loop_synctest(bg, cm, torch, n, D, K, schema="headline", inflight=1, kerne
     rc = lib.ggrs_bench_synctest_loop(w._p, D, K, inflight, cs, C.byref(secs), tick_us)
     gc.enable()
     assert rc == 0, rc
+    # the kernel's own duration UNDER THIS LOOP (HIP events riding on the dispatches of 200 more ticks): a small world's kernel is only as fast as the rocprofv3
+    # trace says (5.6 us at 10 k) while the GPU is kept busy -- behind a host-bound loop it starts from an idle, clock-gated chip and reads 8 us
+    w.profile_enable(True)
+    s2 = C.c_double(0)
+    rc = lib.ggrs_bench_synctest_loop(w._p, D, 200, inflight, None, C.byref(s2), None); assert rc == 0, rc
+    lus = sorted(w.profile_launches("tick")); w.profile_enable(False)
+    k_us = lus[len(lus) // 2] if lus else (kernel_us or 0.0)
     live = w.active_count(); w.close()
     t = sorted(tick_us)
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": inflight, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * (D + 1) * K / secs.value, "unit": "entity-frames/s",
-           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2), "first": round(tick_us[0], 2)}}
-    if kernel_us: out["latency_floor"] = latency_floor(kernel_us, 1.0, secs.value / K * 1e6)
+           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2), "first": round(tick_us[0], 2)},
+           "kernel_us": {"median_under_this_loop": round(k_us, 2), "min": round(lus[0], 2) if lus else None, "launches": len(lus), "under_the_python_loop": kernel_us}}
+    if k_us: out["latency_floor"] = latency_floor(k_us, 1.0, secs.value / K * 1e6)
     P = min(parity_ticks, K)
     if P:
         from oracle.binding import FLAT, OracleWorld, lib as olib
@@ -647,32 +657,43 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
     cm.spawn_particles(w, ids, n, vel, ttl)
     w.set_depth(R); w.set_synctest_check_distance(-1)
     rng = np.random.default_rng(4)
-    warm = 480
-    total = warm + K
+    warm, n_prof = 480, 200
+    total = warm + K + n_prof
     rl = np.zeros(total, dtype=np.uint8)
     for F in range(total): rl[F] = min(int(rng.integers(0, R + 1)), F, R - 1)
     cs = (C.c_uint64 * (2 * R * total))(); ncs = (C.c_uint32 * total)(); secs = C.c_double(0); tick_us = (C.c_double * K)()
     rlp = rl.ctypes.data_as(C.POINTER(C.c_uint8))
-    half = warm // 2
-    rc = lib.ggrs_bench_p2p_loop(w._p, R, half, rlp, cs, ncs, C.byref(secs), None); assert rc == 0, rc
-    w.specialise_wait()
     off = lambda k: (C.cast(C.byref(cs, 16 * R * k), C.POINTER(C.c_uint64)), C.cast(C.byref(ncs, 4 * k), C.POINTER(C.c_uint32)), C.cast(C.byref(rl.ctypes.data_as(C.POINTER(C.c_uint8)).contents, k), C.POINTER(C.c_uint8)))
-    c2, n2, r2 = off(half)
-    rc = lib.ggrs_bench_p2p_loop(w._p, R, warm - half, r2, c2, n2, C.byref(secs), None); assert rc == 0, rc
-    w.specialise_wait()
+    # warm-up in rounds of 40 ticks: every rollback length gets its own specialised kernel after 16 sightings, built one at a time on a worker thread
+    # (measure_p2p's settle loop; the code objects are on disk by now, this world only has to see the shapes and load them)
+    done = 0
+    while done < warm:
+        cc, nn, rr = off(done)
+        rc = lib.ggrs_bench_p2p_loop(w._p, R, 40, rr, cc, nn, C.byref(secs), None); assert rc == 0, rc
+        w.specialise_wait()
+        done += 40
     c3, n3, r3 = off(warm)
     gc.collect(); gc.disable()
     rc = lib.ggrs_bench_p2p_loop(w._p, R, K, r3, c3, n3, C.byref(secs), tick_us)
     gc.enable()
     assert rc == 0, rc
+    # the kernels' own durations under this loop (see c_loop_synctest): the script's next 200 ticks with HIP events riding on the dispatches
+    w.profile_enable(True)
+    c4, n4, r4 = off(warm + K); s2 = C.c_double(0)
+    rc = lib.ggrs_bench_p2p_loop(w._p, R, n_prof, r4, c4, n4, C.byref(s2), None); assert rc == 0, rc
+    lus = w.profile_launches("tick"); w.profile_enable(False)
+    k_us = (sum(lus) / len(lus)) if lus else (kernel_us or 0.0)
+    lpt = (len(lus) / n_prof) if lus else launches_per_tick
     live = w.active_count(); w.close()
-    advances = int(sum(int(r) + 1 for r in rl[warm:]))
+    advances = int(sum(int(r) + 1 for r in rl[warm:warm + K]))
     t = sorted(tick_us)
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": 1, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * advances / secs.value, "unit": "entity-frames/s",
-           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)}}
-    if kernel_us: out["latency_floor"] = latency_floor(kernel_us, launches_per_tick, secs.value / K * 1e6)
+           "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)},
+           "kernel_us": {"mean_under_this_loop": round(k_us, 2), "launches_per_tick": round(lpt, 3), "under_the_python_loop": kernel_us}}
+    if k_us: out["latency_floor"] = latency_floor(k_us, lpt, secs.value / K * 1e6)
     # every Save of every tick (warm-up included) against the oracle under the same script
-    from oracle.binding import FLAT, OracleWorld
+    from oracle.binding import FLAT, OracleWorld, lib as olib
+    olib.gor_set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     o = OracleWorld(n, R + 1, FLAT)
     oids = cm.build_particles(o); cm.spawn_particles(o, oids, n, vel, ttl); o.set_depth(R)
     ok, checked = True, 0
@@ -684,6 +705,7 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
         want = o.handle_requests(reqs)
         got = [int(cs[2 * R * f + 2 * i]) | (int(cs[2 * R * f + 2 * i + 1]) << 64) for i in range(int(ncs[f]))]
         ok &= got == want; checked += len(want)
+    olib.gor_set_num_threads(1)
     out["parity"] = {"checked_ticks": total, "checked_saves": checked, "equal": bool(ok)}
     return out
 
@@ -990,15 +1012,15 @@ def extra_configs(bg, cm, torch, base_args, dev, budget_s=60.0):
         line, bad = single_line(bg, cm, torch, a, dev)
         kus = line["roofline"]["avg_launch_us"]
         line["c_loop"] = c_loop_synctest(bg, cm, torch, a.entities, a.depth, 2000, kernel_us=kus)
-        line["c_loop"]["two_in_flight"] = {k: v for k, v in c_loop_synctest(bg, cm, torch, a.entities, a.depth, 2000, inflight=2, kernel_us=kus, parity_ticks=0).items() if k in ("ms_per_step", "value", "latency_floor", "ticks_in_flight")}
+        line["c_loop"]["two_in_flight"] = {k: v for k, v in c_loop_synctest(bg, cm, torch, a.entities, a.depth, 2000, inflight=2, kernel_us=kus, parity_ticks=0).items() if k in ("ms_per_step", "value", "latency_floor", "ticks_in_flight", "kernel_us")}
         return line, bad or line["c_loop"]["parity"]["equal"] is not True
     guard("config2", cfg2)
     # ---- config 4: P2P-shaped rollbacks at 100 k
     def cfg4():
-        a = mk(entities=100_000, steps=400, warmup=16, cpu_ticks=0, no_cpu_baseline=True)
+        a = mk(entities=100_000, steps=200, warmup=16, cpu_ticks=0, no_cpu_baseline=True)
         line, bad = p2p_line(bg, cm, torch, a)
         r = line["roofline"]
-        line["c_loop"] = c_loop_p2p(bg, cm, torch, a.entities, a.depth, 2000, kernel_us=r["avg_launch_us"], launches_per_tick=line["latency_floor"]["launches_per_tick"])
+        line["c_loop"] = c_loop_p2p(bg, cm, torch, a.entities, a.depth, 600, kernel_us=r["avg_launch_us"], launches_per_tick=line["latency_floor"]["launches_per_tick"])
         return line, bad or line["c_loop"]["parity"]["equal"] is not True
     guard("config4", cfg4)
     # ---- the all-columns-hot world: every Save moves all 15 rows (what the reference's clone-everything save always does)
@@ -1059,7 +1081,7 @@ def main():
                          "(0..8 frames per tick) at 100 k; 5 = 256 predicted-input branches x 100 k x 8 frames (all on this node's GPUs)")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip `extra_configs` (configs 2 / 4 / 5, the all-columns-hot world), which the default N = 1 headline run "
                     "measures after its clock has stopped")
-    ap.add_argument("--extra-budget-s", type=float, default=75.0, help="wall-time budget of `extra_configs`: configs that would start beyond it are reported as skipped")
+    ap.add_argument("--extra-budget-s", type=float, default=150.0, help="wall-time budget of `extra_configs`: configs that would start beyond it are reported as skipped")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
     default_headline = (args.config == 3 and args.entities == 1_000_000 and args.depth == 8 and args.schema == "headline" and not (args.fanout or args.sync or args.unfused or args.no_groups

@@ -121,8 +121,9 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead, bool
 // anything could load them, and LoadWorld overwrites the live world.  Only the group's Checksum(u128)s are observable --
 // exactly what a speculative branch of the fan-out is ([Load(C), Adv, Save, ...] x B in one list: every branch but the last).
 // Such a group runs checksum-only: no snapshot stores, no live write.  The host ring bookkeeping is done as usual.
-// Not applied when something else reads the live world in between (a firing spawn system, live-only components or
-// RollbackDespawned markers, whose reconcile pass reads the live liveness mask).
+// Not applied when something else reads the live world in between: a spawn system the generator could NOT fuse (it then fires as its own
+// launches on the live block; a fused spawn runs inside the group and does not count), live-only components or RollbackDespawned markers,
+// whose reconcile pass reads the live liveness mask.
 bool group_is_dead(const ggrs_world* w, const ggrs_request* reqs, uint32_t i, uint32_t n, const int32_t* save_frame, uint32_t n_saves, bool spawn_pending) {
     if (spawn_pending || n_saves == 0 || i >= n || reqs[i].kind != GGRS_REQ_LOAD || w->has_nr || w->marks_possible) return false;
     bool present = false;

@@ -49,9 +49,10 @@ struct JitEntry;                         // kernel_gen.hpp: a cached generated m
 // first-Save-cache / lane-fold / depth-parallel / presence-version / dead-group / event-on-kernel switches): their winning side is the fixed policy.
 struct Knobs {
     bool tick_jit = true;          // GGRS_TICK_JIT=0       no run-time generated kernel (what a deployment without libhiprtc.so AND without shipped code objects gets): one launch per request
-    int fold_forward_min_wgs = 256; // GGRS_FOLD_FORWARD_MIN_WGS=n  request groups of MORE than n workgroups leave their per-workgroup checksum rows in device memory and the NEXT launch on the
+    int fold_forward_min_wgs = 1024; // GGRS_FOLD_FORWARD_MIN_WGS=n  request groups of MORE than n workgroups leave their per-workgroup checksum rows in device memory and the NEXT launch on the
                                    //                       stream folds them (fold-forward, host_groups.hpp); up to n the rows go to pinned memory and the host XORs them at collect time
-                                   //                       (0: always fold-forward; 1000000: never).  1 M: the host's 30 us fold per tick sat on the collect -> enqueue path (profiles/r05*)
+                                   //                       (0: always fold-forward; 1000000: never).  1 M: the host's 30 us fold per tick sat on the collect -> enqueue path; 100 k (391
+                                   //                       workgroups): the tags arrive 6-9 us after the batch's event, the host's fold of 75 KB takes 4 -- 14.4 vs 16.5 us per P2P tick (profiles/r05f)
     uint64_t stage_bytes = 8u << 20; // GGRS_STAGE_BYTES=n   bytes of the spawn-payload staging ring (default 8 MiB: one spawn of 1 M particles = 2 x 1 M floats fits; tests shrink it to exercise the wrap)
     bool row_versions = true;      // GGRS_ROW_VERSIONS=0   every SaveWorld / LoadWorld moves every row (no version bookkeeping): the reference's clone-everything cost, measured as bench_fullcopy
     bool debug_poison = false;     // GGRS_DEBUG_POISON=1   fill fresh arenas / scratch with 0xA5 (uninitialised-read hunting)
@@ -69,7 +70,7 @@ struct Knobs {
         Knobs k;
         auto num = [](const char* n, long long dflt) { const char* v = getenv(n); return v ? atoll(v) : dflt; };
         k.tick_jit = num("GGRS_TICK_JIT", 1) != 0;
-        k.fold_forward_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_FOLD_FORWARD_MIN_WGS", 256)));
+        k.fold_forward_min_wgs = (int)std::max<long long>(0, std::min<long long>(1 << 24, num("GGRS_FOLD_FORWARD_MIN_WGS", 1024)));
         k.stage_bytes = (uint64_t)std::max<long long>(4096, std::min<long long>(1ll << 30, num("GGRS_STAGE_BYTES", 8 << 20))) & ~15ull;
         k.row_versions = num("GGRS_ROW_VERSIONS", 1) != 0;
         k.jit_specialise_after = (int)num("GGRS_JIT_SPECIALISE_AFTER", 16);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A SyncTest session that holds INPUT_SPAWN (the stress_test with the spawn key down: 100 particles per frame, particles.rs:258-270), depth 8,
-100 k entities to start with: per-tick time with the spawn fused into the request group (default) and with GGRS_JIT_FUSE_SPAWN=0 (a firing
+100 k entities to start with: per-tick time with the spawn fused into the request group (default) and on the one-launch-per-request path, GGRS_TICK_JIT=0 (a firing
 spawn system ends the group: every resimulated frame is its own launches).  Every checksum is compared with the CPU oracle."""
 import os, subprocess, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +33,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(json.dumps(run()))
     else:
-        for env in ({}, {"GGRS_JIT_FUSE_SPAWN": "0"}):
+        for env in ({}, {"GGRS_TICK_JIT": "0"}):                     # the spawn inside the request group's launch / one launch per request
             r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env={**os.environ, **env})
             print(env or "default", r.stdout.strip().splitlines()[-1] if r.returncode == 0 else r.stderr[-2000:])

@@ -130,9 +130,9 @@ def test_missing_runtime_compiler_is_a_queryable_state(monkeypatch):
 
 
 def test_fold_placement_by_world_size():
-    """Default policy of the checksum fold by world size (host_world.hpp Knobs::fold_forward_min_wgs): up to 256 workgroups (65 k slots) one row per workgroup goes
+    """Default policy of the checksum fold by world size (host_world.hpp Knobs::fold_forward_min_wgs): up to 1024 workgroups (262 k slots) one row per workgroup goes
     to the host, beyond the next launch folds the rows (fold-forward) -- at every size, 4 M slots included (the on-chip group fold of round 4 is gone)."""
-    for n, want in ((60_000, "the host folds"), (100_000, "fold-forward"), (1_000_000, "fold-forward"), (3_300_000, "fold-forward")):
+    for n, want in ((100_000, "the host folds"), (300_000, "fold-forward"), (1_000_000, "fold-forward"), (3_300_000, "fold-forward")):
         w = bg.World(n, max_depth=2)
         ids = cm.build_particles(w)
         vel, ttl = cm.synthetic_particles(n, ttl="throughput")
