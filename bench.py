@@ -53,6 +53,7 @@ ADV_BYTES = 64                 # AdvanceWorld as its own kernel: r/w translation
 
 def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="headline"):
     w = bg.World(n, max_depth=depth + 1, stream=stream, flags=flags)
+    if os.environ.get("BENCH_NO_LAZY_LIVE") == "1": w._lib.ggrs_dbg_set_lazy_live(w._p, 0)        # A/B only (the library's test hook; --no-lazy-live)
     ids = cm.build_particles(w, checksum=checksum, schema=schema)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)
@@ -684,12 +685,19 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
     lus = w.profile_launches("tick"); w.profile_enable(False)
     k_us = (sum(lus) / len(lus)) if lus else (kernel_us or 0.0)
     lpt = (len(lus) / n_prof) if lus else launches_per_tick
+    if len(lus) == n_prof:
+        # one launch per tick: price the TIMED ticks' rollback lengths with the per-length kernel means of the instrumented ticks (the script draws a length per
+        # tick; 200 other ticks have another mix, which read as a floor fraction above 1 in profiles/r05g)
+        by_r = {}
+        for r, us in zip(rl[warm + K:warm + K + n_prof], lus): by_r.setdefault(int(r), []).append(us)
+        mean_r = {r: sum(v) / len(v) for r, v in by_r.items()}
+        k_us = sum(mean_r.get(int(r), k_us) for r in rl[warm:warm + K]) / K
     live = w.active_count(); w.close()
     advances = int(sum(int(r) + 1 for r in rl[warm:warm + K]))
     t = sorted(tick_us)
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": 1, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * advances / secs.value, "unit": "entity-frames/s",
            "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)},
-           "kernel_us": {"mean_under_this_loop": round(k_us, 2), "launches_per_tick": round(lpt, 3), "under_the_python_loop": kernel_us}}
+           "kernel_us": {"mean_under_this_loop": round(k_us, 2), "priced": "per rollback length, weighted by the timed ticks' lengths", "launches_per_tick": round(lpt, 3), "under_the_python_loop": kernel_us}}
     if k_us: out["latency_floor"] = latency_floor(k_us, lpt, secs.value / K * 1e6)
     # every Save of every tick (warm-up included) against the oracle under the same script
     from oracle.binding import FLAT, OracleWorld, lib as olib
@@ -1082,8 +1090,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip `extra_configs` (configs 2 / 4 / 5, the all-columns-hot world), which the default N = 1 headline run "
                     "measures after its clock has stopped")
     ap.add_argument("--extra-budget-s", type=float, default=150.0, help="wall-time budget of `extra_configs`: configs that would start beyond it are reported as skipped")
+    ap.add_argument("--no-lazy-live", action="store_true", help="A/B: every tick writes the live block (the library's test hook ggrs_dbg_set_lazy_live)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
+    if args.no_lazy_live: os.environ["BENCH_NO_LAZY_LIVE"] = "1"
     default_headline = (args.config == 3 and args.entities == 1_000_000 and args.depth == 8 and args.schema == "headline" and not (args.fanout or args.sync or args.unfused or args.no_groups
                         or args.nt or args.no_checksum or args.no_cpu_baseline or args.branches != 1))
     if args.config == 2: args.entities = 10_000

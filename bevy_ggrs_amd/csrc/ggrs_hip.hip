@@ -320,13 +320,17 @@ int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, c
 }
 // Test hook (no ggrs_hip_ prefix, not in the header): places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight
 // rollback lengths exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
+int ggrs_dbg_set_lazy_live(ggrs_world* w, int on) { if (!w) return -1; w->lazy_live_on = on; return 0; }
 int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
+
+// entry points that read or edit the live block's BYTES: a lazily skipped live block (host_groups.hpp) is materialised first
+static int seal_live(ggrs_world* w) { int rc = seal(w); if (rc) return rc; return materialise_live(w); }
 
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (!range_ok(w->len, count, w->capacity)) return w->fail(GGRS_E_CAPACITY, "spawn of %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)w->capacity);
     const uint64_t first = w->len;
     if (first_slot) *first_slot = first;
@@ -356,7 +360,7 @@ int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void
 int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_alive, slot, 0);
     HIPCHK(w, hipGetLastError());
@@ -366,7 +370,7 @@ int ggrs_hip_despawn(ggrs_world* w, uint64_t slot) {
 int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (slot >= w->len) return w->fail(GGRS_E_INVALID, "slot out of range");
     if (w->confirmed < w->frame) {                 // despawn.rs:129-137: insert RollbackDespawned(frame)
         w->marks_possible = true;
@@ -381,7 +385,7 @@ int ggrs_hip_despawn_rollback(ggrs_world* w, uint64_t slot) {
 int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const void* words) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size() || slot >= w->len || !words) return w->fail(GGRS_E_INVALID, "bad insert_component arguments");
     const Comp& cc = w->comps[c];
     for (uint32_t k = 0; k < cc.n_words; ++k)
@@ -396,7 +400,7 @@ int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const vo
 int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size() || slot >= w->len) return w->fail(GGRS_E_INVALID, "bad remove_component arguments");
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 0);
     HIPCHK(w, hipGetLastError());
@@ -407,7 +411,7 @@ int ggrs_hip_remove_component(ggrs_world* w, uint32_t c, uint64_t slot) {
 int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, const void* src) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words || !range_ok(first, count, w->capacity) || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
     const Comp& cc = w->comps[c];
     rc = copy_column(w, cc.col_base + word, first, count, const_cast<void*>(src), true); if (rc) return rc;
@@ -419,7 +423,7 @@ int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t firs
 int ggrs_hip_download_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t first, uint64_t count, void* dst) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words || !range_ok(first, count, w->capacity) || !dst) return w->fail(GGRS_E_INVALID, "bad download_word arguments");
     const Comp& cc = w->comps[c];
     rc = copy_column(w, cc.col_base + word, first, count, dst, false); if (rc) return rc;
@@ -437,13 +441,13 @@ static int download_mask(ggrs_world* w, uint64_t off, uint64_t* dst, uint64_t n)
 int ggrs_hip_download_alive(ggrs_world* w, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     return download_mask(w, w->off_alive, dst, n);
 }
 int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size()) return w->fail(GGRS_E_INVALID, "bad component");
     rc = download_mask(w, w->off_present[c], dst, n); if (rc) return rc;
     if (w->comps[c].no_rollback && n) {
@@ -459,13 +463,13 @@ int ggrs_hip_download_present(ggrs_world* w, uint32_t c, uint64_t* dst, uint64_t
 int ggrs_hip_download_disabled(ggrs_world* w, uint64_t* dst, uint64_t n) {
     if (!w || !dst) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     return download_mask(w, w->marks.off_disabled, dst, n);
 }
 int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t count, int32_t* frames) {
     if (!w || !frames) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (!range_ok(first, count, w->capacity)) return w->fail(GGRS_E_INVALID, "bad download_despawned_frames range");
     if (count) HIPCHK(w, hipMemcpyAsync(frames, w->live.ptr + w->marks.off_dframe + first * 4, (size_t)count * 4, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -474,7 +478,7 @@ int ggrs_hip_download_despawned_frames(ggrs_world* w, uint64_t first, uint64_t c
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** p, uint64_t* tile_stride) {
     if (!w || !p) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     if (c >= w->comps.size() || word >= w->comps[c].n_words) return w->fail(GGRS_E_INVALID, "bad column");
     *p = w->live.ptr + w->col_off[w->comps[c].col_base + word];
     w->col_ext[w->comps[c].col_base + word] = 1;                   // whoever holds this pointer may write the column at any time: no row-version shortcuts for it
@@ -485,7 +489,7 @@ uint64_t ggrs_hip_len(ggrs_world* w) { return w ? w->len : 0; }
 int ggrs_hip_active_count(ggrs_world* w, uint64_t* out) {
     if (!w || !out) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     const uint64_t n = (w->live.dirty_len + 63) / 64;
     std::vector<uint64_t> m(n ? n : 1, 0);
     if (n) { rc = download_mask(w, w->off_alive, m.data(), n); if (rc) return rc; }
@@ -703,18 +707,19 @@ uint64_t ggrs_hip_state_bytes(ggrs_world* w) { if (!w) return 0; DeviceGuard dg(
 int ggrs_hip_live_state_ptr(ggrs_world* w, void** p) {
     if (!w || !p) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     // keep the header current so an exported block is self-describing
     Header h = header_of(w);
     HIPCHK(w, hipMemcpyAsync(w->live.ptr, &h, 16, hipMemcpyHostToDevice, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     *p = w->live.ptr;
+    w->live_handed_out = true;                                      // the caller may read the block after any later tick: it is written by every tick from now on
     return GGRS_OK;
 }
 int ggrs_hip_adopt_live_state(ggrs_world* w) {
     if (!w) return GGRS_E_INVALID;
     DeviceGuard dg(w);
-    int rc = seal(w); if (rc) return rc;
+    int rc = seal_live(w); if (rc) return rc;
     Header h;
     HIPCHK(w, hipMemcpyAsync(&h, w->live.ptr, sizeof h, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -774,6 +779,10 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
                              : "k_gen_finalize";
         add("checksum_fold", f);
         add("kernarg_bytes", std::to_string(w->jl ? w->jl->bytes : 0));
+        add("lazy_live_block", !lazy_live_possible(w) ? "off (live-only state, a handed-out pointer, results on the device, or per-request launches)"
+                                   : cover <= JIT_NT_MIN_SLOTS ? "off (the world fits the caches: the live block's bytes are not what bounds the launch)"
+                                   : "on after " + std::to_string(LAZY_LIVE_STREAK) + " lists in a row that open with a LoadGameState: " + std::to_string(w->lazy_skips) + " lists left it unwritten, " +
+                                     std::to_string(w->lazy_materialised) + " materialised on demand");
         add("group_caps", std::to_string(w->cap_saves) + " saves / " + std::to_string(w->cap_steps) + " steps");
         bool any_spawn = false;
         for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN || sd.kind == GGRS_SYS_SPAWN_CUSTOM;

@@ -27,6 +27,7 @@ int group_open(ggrs_world* w, const ggrs_request* reqs, uint32_t& i, GroupState&
     if (!ring_rollback(w, reqs[i].frame))
         return w->fail(GGRS_E_NO_SNAPSHOT, "Could not rollback to %d: no snapshot at that moment could be found.", reqs[i].frame);
     g.src = &w->slots[w->ring_slot.front()];
+    w->live_stale.valid = false;                                          // LoadWorld overwrites the live world: what a lazy group left unwritten is never needed
     int rc = launch_load_reconcile(w, *g.src); if (rc) return rc;        // EntityResurrect: before the group rewrites live liveness
     w->len = g.src->len;
     w->cur_ver = g.src->ver;                                              // the logical live state is the snapshot from here on
@@ -166,6 +167,7 @@ inline void ff_attach(ggrs_world* w, GgrsJitArgs& j) {
 // slot live, the rows the systems write -- under the same store / load / role policies run_request_groups_gen applies: what
 // ggrs_hip_generated_kernel_source(GGRS_KERNEL_FORM_STEADY) specialises for and what `make aot` ships, so that a session's 16th steady tick finds its kernel
 // among the shipped objects when there is no run-time compiler.
+inline bool lazy_live_allowed(const ggrs_world* w);
 JitSig jit_steady_sig(const ggrs_world* w) {
     const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, std::min<uint32_t>(w->cap_saves, w->cap_steps - 1));
     const uint64_t cover = w->capacity;
@@ -178,6 +180,8 @@ JitSig jit_steady_sig(const ggrs_world* w) {
     g.nt_loads = (g.nt && !g.cached_saves) ? 1u : 0u;
     const JitNeeds need = jit_needs(w);
     if (d >= 2 && !need.marks) g.dp_s = cover <= JIT_DP_MAX_SLOTS ? 1u : (cover <= 2 * JIT_DP_MAX_SLOTS ? 2u : (cover <= 6 * JIT_DP_MAX_SLOTS ? 3u : 0u));
+    // an HBM-sized steady session leaves the live block unwritten (lazy live block, below): the next tick's LoadGameState never reads it
+    if (g.nt && !need.marks && lazy_live_allowed(w)) { g.skip_live = 1; g.live_rows = 0; }
     return g;
 }
 
@@ -316,6 +320,45 @@ struct JitBatch {
     }
 };
 
+// ---- lazy live block -------------------------------------------------------------------------------------------------------
+// A SyncTest tick ends  [.., Save(F), Advance]  and the next one opens with LoadGameState(F + 1 - d): the live block the tick would write
+// (frame F + 1: 32 of the stress_test's 320 B per entity-tick) is never read -- the next group's source is a ring slot.  A session whose lists keep
+// opening with a Load (LAZY_LIVE_STREAK in a row) therefore stops writing it at the end of a list: the live world is then DEFINED as
+// Advance(slot of F) with the recorded inputs, and whoever needs its bytes -- a list that opens without a Load, a download, a spawn, a despawn,
+// an upload, a handed-out column pointer, the fan-out -- gets them from ONE launch first (materialise_live: load the slot, one step, store live).
+// Only for HBM-sized worlds (bytes are what bounds them), worlds without live-only state (markers, non-rollback components) and without
+// externally held column pointers.  Snapshots, checksums, ring and frame counters are untouched: every Save of the tick was made.
+constexpr uint32_t LAZY_LIVE_STREAK = 8;
+inline bool lazy_live_allowed(const ggrs_world* w) {                 // (what a layout-only world -- `make aot` on a machine without a GPU -- can tell)
+    if (!w->lazy_live_on || w->live_handed_out || w->has_nr || w->marks_possible || w->device_results_only) return false;
+    for (uint8_t e : w->col_ext) if (e) return false;
+    return true;
+}
+inline bool lazy_live_possible(const ggrs_world* w) { return w->gen_ok && !w->jit_marks && lazy_live_allowed(w); }
+int materialise_live(ggrs_world* w) {
+    ggrs_world::LiveStale& st = w->live_stale;
+    if (!st.valid) return GGRS_OK;
+    GgrsJitArgs j; memset(&j, 0, offsetof(GgrsJitArgs, inputs));
+    j.src = st.src->ptr; j.live = w->live.ptr; j.len = st.len; j.src_is_live = 0;
+    j.n_ops = 1; j.op_bits = 1; j.n_steps = 1;
+    j.dt_bits[0] = st.dt_bits; j.aux_bits[0] = st.aux_bits; j.step_frame[0] = st.step_frame; j.step_confirmed[0] = st.step_confirmed; j.n_inputs[0] = st.n_inputs;
+    memcpy(j.inputs[0], st.inputs, sizeof st.inputs);
+    j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver);
+    j.load_rows = jit_static_reads(w) | j.live_rows;
+    const uint64_t cover = std::max(std::max(st.src->dirty_len, w->live.dirty_len), w->len);
+    j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
+    j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
+    const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
+    j.nt = 0;                                                        // (the live block is read again by whoever asked for it)
+    j.nt_loads = cover > JIT_NT_MIN_SLOTS ? 1u : 0u;                  // the slot was stored around the caches one launch ago
+    const int rc = launch_jit(w, w->jit_fn, jit_grid(g), 1, 1, 0, j, (rows_bytes_per_slot(w, j.load_rows, true) + rows_bytes_per_slot(w, j.live_rows, false)) * w->len);
+    if (rc) return rc;
+    w->live.dirty_len = std::max(st.src->dirty_len, w->len);
+    ver_sync_live(w);
+    st.valid = false; ++w->lazy_materialised;
+    return GGRS_OK;
+}
+
 int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint64_t* checksums_out,
                            uint32_t res_base = 0, bool wait = true, uint32_t* n_saves_out = nullptr) {
     uint32_t i = 0, ns = 0;
@@ -328,6 +371,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     std::vector<Staged> staged; uint64_t staged_gen = w->stage_gen;
     const uint32_t n_cks = w->cks_args.n_cks;
     const uint64_t static_reads = jit_static_reads(w);
+    if (n) {
+        // a list that opens with a LoadGameState replaces the live world: a lazily skipped live block needs no bytes; any other list reads it first
+        if (reqs[0].kind == GGRS_REQ_LOAD) ++w->load_open_streak; else { w->load_open_streak = 0; rc = materialise_live(w); if (rc) return rc; }
+    }
     while (i < n) {
         w->batch_ev_attached = false;                                   // only the list's LAST launch may carry the batch event
         GgrsJitArgs j; memset(&j, 0, offsetof(GgrsJitArgs, inputs));
@@ -415,8 +462,20 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         }
         const bool dead = group_is_dead(w, reqs, i, n, j.save_frame, j.n_saves, spawn_req != nullptr);
         if (dead) { for (uint32_t k = 0; k < j.n_saves; ++k) j.save_dst[k] = nullptr; j.skip_live = 1; }
-        const bool wrote_live = (!j.src_is_live || j.n_steps) && !j.skip_live;
         const uint64_t cover = std::max(gs.cover, w->len);
+        // lazy live block: the LAST group of a list that ends [.., Save(F), Advance] in a session whose lists keep opening with a Load
+        if (!dead && !spawn_req && i >= n && ((w->load_open_streak >= LAZY_LIVE_STREAK && cover > JIT_NT_MIN_SLOTS) || w->lazy_live_on == 2) && j.n_ops >= 2 && j.n_saves && j.n_steps &&
+            ((j.op_bits >> (j.n_ops - 1)) & 1ull) && !((j.op_bits >> (j.n_ops - 2)) & 1ull) && gs.dsts[j.n_saves - 1] && !j.spawn_count[j.n_steps - 1] &&
+            gs.dsts[j.n_saves - 1] != gs.src && lazy_live_possible(w)) {
+            j.skip_live = 1;
+            ggrs_world::LiveStale& st = w->live_stale;
+            const uint32_t q = j.n_steps - 1;
+            st.valid = true; st.src = gs.dsts[j.n_saves - 1]; st.len = j.save_len[j.n_saves - 1];
+            st.dt_bits = j.dt_bits[q]; st.aux_bits = j.aux_bits[q]; st.step_frame = j.step_frame[q]; st.step_confirmed = j.step_confirmed[q]; st.n_inputs = j.n_inputs[q];
+            if (w->jit_reads_inputs) memcpy(st.inputs, j.inputs[q], sizeof st.inputs); else memset(st.inputs, 0, sizeof st.inputs);
+            ++w->lazy_skips;
+        }
+        const bool wrote_live = (!j.src_is_live || j.n_steps) && !j.skip_live;
         // ---- row versions -> store masks; what must be in registers = everything stored + everything a step or checksum reads
         uint64_t bytes_slot = 0;
         j.load_rows = j.n_ops ? static_reads : 0;

@@ -230,6 +230,16 @@ struct ggrs_world {
     struct FfPending { bool valid = false; uint64_t id = 0, seq = 0; uint32_t buf = 0, nvals = 0, g = 0, stride = 0, istride = 1, split = 1; uint64_t out_off = 0; } ff_pending;   // nvals = rows x split
     uint64_t ff_next_id = 1, ff_done_id = 0, ff_seq = 0;    // ids are handed out in launch order; every id <= ff_done_id has a fold queued on the stream
 
+    // LAZY LIVE BLOCK (host_groups.hpp): the last group of the previous list ended  [.., Save(F), Advance]  and did not write the live block -- the
+    // live world (frame F + 1) IS Advance(ring slot of F) until somebody needs its bytes: a list that opens with a LoadGameState never does (a SyncTest
+    // session, a P2P session in steady rollback), everything else materialises it first (materialise_live: one small launch)
+    struct LiveStale { bool valid = false; Block* src = nullptr; uint64_t len = 0; uint32_t dt_bits = 0, aux_bits = 0; int step_frame = 0, step_confirmed = 0;
+                       unsigned char n_inputs = 0; unsigned char inputs[GGRS_MAX_PLAYERS * (GGRS_MAX_INPUT_BYTES + 1)] = {}; } live_stale;
+    int lazy_live_on = 1;                // (ggrs_dbg_set_lazy_live: 0 = the A/B of profiles/r05h; 2 = every eligible list whatever its size and streak: the fuzzer)
+    bool live_handed_out = false;        // ggrs_hip_live_state_ptr gave the block away: it is kept current from then on
+    uint32_t load_open_streak = 0;       // consecutive request lists that opened with a LoadGameState
+    uint64_t lazy_skips = 0, lazy_materialised = 0;
+
     // pending partials produced by the last advance (valid for the live state as-is)
     bool pending_valid = false; uint32_t pending_parts = 0;
 

@@ -1107,9 +1107,10 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const size_t lp = body.find(loop);
     if (lp == std::string::npos) return "";
     body.insert(lp, "#pragma unroll\n");
-    char note[256];
-    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u\n", g.n_ops,
-             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads, g.dp_s);
+    char note[320];
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u, live block %s\n", g.n_ops,
+             (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads, g.dp_s,
+             g.skip_live ? "left unwritten" : "written");
     return head + note + body;
 }
 // Build (or load from the disk cache / the shipped objects) without touching a world: runs on a worker thread

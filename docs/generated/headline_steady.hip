@@ -155,7 +155,7 @@ static_assert(__builtin_offsetof(GgrsJitArgs, ff_split) == 472, "argument block:
 static_assert(__builtin_offsetof(GgrsJitArgs, dt_bits) == 476, "argument block: offset of dt_bits");
 static_assert(__builtin_offsetof(GgrsJitArgs, step_frame) == 520, "argument block: offset of step_frame");
 #line 1 "ggrs_jit_tick"
-// specialised: 17 ops (bits 15555), 8 Saves, rows 3c07 / live 3c07 / load 3c07, masks 0 / 0, nt 1, cached 1, nt loads 0, roles of 0
+// specialised: 17 ops (bits 15555), 8 Saves, rows 3c07 / live 0 / load 3c07, masks 0 / 0, nt 1, cached 1, nt loads 0, roles of 0, live block left unwritten
 extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform, and the compiler knows it
@@ -170,7 +170,7 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
         return;
     }
     const uint32_t bx = blockIdx.x - a.ff_blocks, gx = gridDim.x - a.ff_blocks;
-    const bool writes_live = (!0u || 9u) && !0u;
+    const bool writes_live = (!0u || 9u) && !1u;
     const uint32_t o_first = 0u ? blockIdx.y * 0u : 0u;          // depth-parallel roles: this workgroup's share of the outputs
     const uint32_t o_last = 0u ? min(o_first + 0u, 8u + 1u) : 8u + 1u;
     const bool my_live = o_last == 8u + 1u;
@@ -400,7 +400,7 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     if (my_live && writes_live) {
         const uint64_t alive_now = __ballot(alive_0);
         if (in_len) {
-            if (0x3c07ull == 0x3c07ull) {
+            if (0x0ull == 0x3c07ull) {
                 st4(b0(a.live), lo4, w0_0);
                 st4(b1(a.live), lo4, w1_0);
                 st4(b2(a.live), lo4, w2_0);
@@ -409,20 +409,20 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
                 st4(b12(a.live), lo4, w12_0);
                 st8(b13(a.live), lo8, w13_0);
             } else {
-                if ((0x3c07ull >> 0u) & 1ull) st4(b0(a.live), lo4, w0_0);
-                if ((0x3c07ull >> 1u) & 1ull) st4(b1(a.live), lo4, w1_0);
-                if ((0x3c07ull >> 2u) & 1ull) st4(b2(a.live), lo4, w2_0);
-                if ((0x3c07ull >> 3u) & 1ull) st4(b3(a.live), lo4, w3_0);
-                if ((0x3c07ull >> 4u) & 1ull) st4(b4(a.live), lo4, w4_0);
-                if ((0x3c07ull >> 5u) & 1ull) st4(b5(a.live), lo4, w5_0);
-                if ((0x3c07ull >> 6u) & 1ull) st4(b6(a.live), lo4, w6_0);
-                if ((0x3c07ull >> 7u) & 1ull) st4(b7(a.live), lo4, w7_0);
-                if ((0x3c07ull >> 8u) & 1ull) st4(b8(a.live), lo4, w8_0);
-                if ((0x3c07ull >> 9u) & 1ull) st4(b9(a.live), lo4, w9_0);
-                if ((0x3c07ull >> 10u) & 1ull) st4(b10(a.live), lo4, w10_0);
-                if ((0x3c07ull >> 11u) & 1ull) st4(b11(a.live), lo4, w11_0);
-                if ((0x3c07ull >> 12u) & 1ull) st4(b12(a.live), lo4, w12_0);
-                if ((0x3c07ull >> 13u) & 1ull) st8(b13(a.live), lo8, w13_0);
+                if ((0x0ull >> 0u) & 1ull) st4(b0(a.live), lo4, w0_0);
+                if ((0x0ull >> 1u) & 1ull) st4(b1(a.live), lo4, w1_0);
+                if ((0x0ull >> 2u) & 1ull) st4(b2(a.live), lo4, w2_0);
+                if ((0x0ull >> 3u) & 1ull) st4(b3(a.live), lo4, w3_0);
+                if ((0x0ull >> 4u) & 1ull) st4(b4(a.live), lo4, w4_0);
+                if ((0x0ull >> 5u) & 1ull) st4(b5(a.live), lo4, w5_0);
+                if ((0x0ull >> 6u) & 1ull) st4(b6(a.live), lo4, w6_0);
+                if ((0x0ull >> 7u) & 1ull) st4(b7(a.live), lo4, w7_0);
+                if ((0x0ull >> 8u) & 1ull) st4(b8(a.live), lo4, w8_0);
+                if ((0x0ull >> 9u) & 1ull) st4(b9(a.live), lo4, w9_0);
+                if ((0x0ull >> 10u) & 1ull) st4(b10(a.live), lo4, w10_0);
+                if ((0x0ull >> 11u) & 1ull) st4(b11(a.live), lo4, w11_0);
+                if ((0x0ull >> 12u) & 1ull) st4(b12(a.live), lo4, w12_0);
+                if ((0x0ull >> 13u) & 1ull) st8(b13(a.live), lo8, w13_0);
             }
         }
         if (lane == 0) {

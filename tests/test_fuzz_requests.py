@@ -73,6 +73,21 @@ def test_hip_matches_the_oracle_on_random_request_lists_generic_worlds_hbm_sized
     fuzz_util.run(2000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), lambda sc: bg.World(sc.capacity, max_depth=8), n_lists=10, big=True, state_every=10, generic=True)
 
 
+def _lazy_world(sc):
+    """The lazy live block forced on for every eligible list (test hook: no size or streak condition): whatever the fuzzer does between two lists --
+    downloads, spawns, despawns, inserts, lists that open without a Load -- must find the live world the oracle has."""
+    w = bg.World(sc.capacity, max_depth=8)
+    assert w._lib.ggrs_dbg_set_lazy_live(w._p, 2) == 0
+    return w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True], ids=["particles", "generic"])
+@pytest.mark.parametrize("seed", seeds(60))
+def test_hip_matches_the_oracle_on_random_request_lists_lazy_live_block_forced(seed, generic):
+    fuzz_util.run(3000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _lazy_world, n_lists=30, generic=generic)
+
+
 @pytest.mark.parametrize("seed", seeds(60))
 def test_restatements_agree_across_the_i32_frame_wrap(seed):
     """A session whose RollbackFrameCount passes i32::MAX while it runs (Frame = i32: the counters wrap, `GgrsSnapshots::push` decides

@@ -133,10 +133,10 @@ def test_specialiser_substitutes_whole_tokens_and_nothing_else(name):
     assert not left & (set(SHAPE_SCALARS) | set(SHAPE_ARRAYS)), left & (set(SHAPE_SCALARS) | set(SHAPE_ARRAYS))
     assert {"src", "live", "save_dst", "save_frame", "dt_bits", "len", "parts", "part_stride", "n_units", "ff_rows", "ff_blocks"} <= left, left
     # (b) the literals, as the specialised text's own header line states them
-    m = re.search(r"// specialised: (\d+) ops \(bits ([0-9a-f]+)\), (\d+) Saves, rows ([0-9a-f]+) / live ([0-9a-f]+) / load ([0-9a-f]+), masks ([0-9a-f]+) / ([0-9a-f]+), nt (\d+), cached ([0-9a-f]+), nt loads (\d+), roles of (\d+)", spec)
+    m = re.search(r"// specialised: (\d+) ops \(bits ([0-9a-f]+)\), (\d+) Saves, rows ([0-9a-f]+) / live ([0-9a-f]+) / load ([0-9a-f]+), masks ([0-9a-f]+) / ([0-9a-f]+), nt (\d+), cached ([0-9a-f]+), nt loads (\d+), roles of (\d+), live block (written|left unwritten)", spec)
     n_ops, op_bits, n_saves, rows, live, load, pm, lpm, nt, cached, ntl, dps = (int(m.group(i), 16 if i in (2, 4, 5, 6, 7, 8, 10) else 10) for i in range(1, 13))
     assert n_ops == 2 * n_saves + 1 and op_bits == sum(1 << (2 * k) for k in range(n_saves + 1)), "the steady SyncTest tick: Advance, (Save, Advance) x D"
-    lit = {"op_bits": f"0x{op_bits:x}ull", "n_ops": f"{n_ops}u", "n_saves": f"{n_saves}u", "n_steps": f"{bin(op_bits).count('1')}u", "src_is_live": "0u", "skip_live": "0u", "dp_s": f"{dps}u",
+    lit = {"op_bits": f"0x{op_bits:x}ull", "n_ops": f"{n_ops}u", "n_saves": f"{n_saves}u", "n_steps": f"{bin(op_bits).count('1')}u", "src_is_live": "0u", "skip_live": "1u" if m.group(13) == "left unwritten" else "0u", "dp_s": f"{dps}u",
            "nt": f"{nt}u", "cached_saves": f"{cached}u", "live_rows": f"0x{live:x}ull", "load_rows": f"0x{load:x}ull", "live_pmask": f"{lpm}u", "nt_loads": f"{ntl}u"}
     want = gbody
     want = re.sub(r"(?<![\w.])a\.save_rows\[si\]", f"0x{rows:x}ull", want)

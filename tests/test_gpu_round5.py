@@ -325,3 +325,102 @@ def test_shipped_code_objects_serve_a_world_without_the_runtime_compiler(tmp_pat
         res.append((drv.all_checksums, cm.snapshot_state(w, ids)))
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], "aot")
+
+
+# ------------------------------------------------------------------------------------------------ lazy live block
+def _lazy_counts(w):
+    import re
+    m = re.search(r"(\d+) lists left it unwritten, (\d+) materialised", w.kernel_info().get("lazy_live_block", ""))
+    return (int(m.group(1)), int(m.group(2))) if m else None
+
+
+@pytest.mark.parametrize("enqueue", [False, True])
+def test_lazy_live_block_is_materialised_for_whoever_reads_it(enqueue):
+    """An HBM-sized session whose lists keep opening with a LoadGameState stops writing the live block at the end of a tick (nobody reads it:
+    the next LoadWorld replaces it).  Everything that DOES read or edit its bytes gets them first: a download, a host-side spawn, a list that
+    opens without a Load (a P2P tick with no rollback), a despawn.  Checksums, snapshots and the final world are the oracle's throughout."""
+    n, D = 450_000, 3
+    cap = n + 64
+    lib, orc = bg.World(cap, max_depth=D + 1), OracleWorld(cap, D + 1, FLAT)
+    st = []
+    for w in (lib, orc):
+        ids = cm.build_particles(w)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+        st.append({"w": w, "ids": ids, "F": 0, "cs": []})
+
+    def run(s, reqs):
+        w = s["w"]
+        if enqueue and isinstance(w, bg.World):
+            w.enqueue_requests(reqs); s["cs"] += w.collect_checksums()
+        else:
+            s["cs"] += w.handle_requests(reqs)
+
+    def synctest_tick(s):
+        F = s["F"]; reqs = []
+        s["w"].set_confirmed(max(0, F - D))
+        if F >= D:
+            reqs.append(bg.LoadGameState(F - D))
+            for i in range(D): reqs += [bg.AdvanceFrame((0,))] + ([bg.SaveGameState(F - D + 1 + i)] if i < D - 1 else [])
+        reqs += [bg.SaveGameState(F), bg.AdvanceFrame((0,))]
+        run(s, reqs); s["F"] += 1
+
+    def plain_tick(s):                                                  # no rollback this tick: the list reads the live world
+        run(s, [bg.SaveGameState(s["F"]), bg.AdvanceFrame((0,))]); s["F"] += 1
+
+    def both(fn, k=1):
+        for _ in range(k):
+            for s in st: fn(s)
+
+    def same(ctx):
+        assert st[0]["cs"] == st[1]["cs"], ctx
+        cm.assert_states_equal(cm.snapshot_state(lib, st[0]["ids"]), cm.snapshot_state(orc, st[1]["ids"]), ctx)
+
+    both(synctest_tick, D + 12)
+    skips, mats = _lazy_counts(lib)
+    assert skips >= 3 and mats == 0, (skips, mats)                      # the streak of Load-opening lists is long enough: the live block is no longer written
+    assert lib.active_count() == orc.active_count()                     # ... until somebody asks
+    assert _lazy_counts(lib)[1] == 1
+    same("after the first materialisation")
+    both(synctest_tick, 3)
+    assert _lazy_counts(lib)[0] > skips                                 # (the streak is not broken by reading the world)
+    # a host-side spawn edits the live world between two lists
+    for s in st:
+        w, ids = s["w"], s["ids"]
+        vel, ttl = cm.synthetic_particles(16, ttl="throughput", seed=7)
+        cm.spawn_particles(w, ids, 16, vel, ttl)
+    both(plain_tick, 2)                                                 # snapshots of the grown world (the ring's older frames predate the spawn)
+    same("after a host-side spawn")
+    both(synctest_tick, LAZY := 10)
+    m0 = _lazy_counts(lib)[1]
+    both(plain_tick)                                                    # opens with a Save of the live world the last tick did not write
+    assert _lazy_counts(lib)[1] == m0 + 1
+    both(synctest_tick, 9)
+    for s in st: s["w"].despawn(5)
+    both(synctest_tick, 2)
+    same("at the end")
+    lib.close()
+
+
+def test_lazy_live_block_is_off_where_the_live_world_holds_more_than_the_snapshots():
+    """A handed-out column pointer or a world that fits the caches: every tick writes the live block."""
+    for n, hand_out in ((450_000, True), (100_000, False)):
+        D = 3
+        w = bg.World(n, max_depth=D + 1)
+        ids = cm.build_particles(w)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        w.set_depth(D + 1)
+        if hand_out: w.column_device_ptr(ids[0], 0)
+        F = 0
+        for _ in range(D + 12):
+            reqs = []
+            if F >= D:
+                reqs.append(bg.LoadGameState(F - D))
+                for i in range(D): reqs += [bg.AdvanceFrame((0,))] + ([bg.SaveGameState(F - D + 1 + i)] if i < D - 1 else [])
+            reqs += [bg.SaveGameState(F), bg.AdvanceFrame((0,))]
+            w.handle_requests(reqs); F += 1
+        c = _lazy_counts(w)
+        assert c is None or c[0] == 0, (n, hand_out, w.kernel_info().get("lazy_live_block"))
+        w.close()
