@@ -115,6 +115,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->fanout_backref) *w->fanout_backref = nullptr;          // a ggrs_fanout destroyed after its world (interpreter shutdown order) finds no world
     for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : w->prof_pool) (void)hipEventDestroy(e);
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
     for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
@@ -801,7 +802,9 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
 int ggrs_hip_profile_enable(ggrs_world* w, int on) {
     if (!w) return GGRS_E_INVALID;
     w->prof = on != 0;
-    if (on) { for (auto& e : w->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } w->prof_events.clear();
+    if (on) { DeviceGuard dg(w);
+              for (auto& e : w->prof_events) { w->prof_pool.push_back(e.a); w->prof_pool.push_back(e.b); } w->prof_events.clear();
+              while (w->prof_pool.size() < 128) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; w->prof_pool.push_back(e); }     // (outside whatever the caller times)
               for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; w->prof_bytes[i] = 0; w->prof_launch_us[i].clear(); } }
     return GGRS_OK;
 }
@@ -812,7 +815,7 @@ static int profile_drain(ggrs_world* w) {
         float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b);
         w->prof_ms[e.cls] += ms; w->prof_n[e.cls] += 1;
         if (w->prof_launch_us[e.cls].size() < 65536) w->prof_launch_us[e.cls].push_back(ms * 1e3f);
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        if (w->prof_pool.size() < 4096) { w->prof_pool.push_back(e.a); w->prof_pool.push_back(e.b); } else { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     w->prof_events.clear();
     return GGRS_OK;

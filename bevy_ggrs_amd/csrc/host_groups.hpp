@@ -200,8 +200,8 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
         if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * TPB, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
         else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr));
     } else {
-        hipEvent_t a = nullptr, b = nullptr;
-        HIPCHK(w, hipEventCreate(&a)); HIPCHK(w, hipEventCreate(&b));
+        hipEvent_t a = w->prof_event(), b = w->prof_event();
+        if (!a || !b) return w->fail(GGRS_E_HIP, "hipEventCreate failed");
         w->prof_bytes[GGRS_KERNEL_TICK] += bytes;
         HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * TPB, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr, a, b, 0));
         w->prof_events.push_back({a, b, GGRS_KERNEL_TICK});

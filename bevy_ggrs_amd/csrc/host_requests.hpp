@@ -531,8 +531,9 @@ int do_advance(ggrs_world* w, const ggrs_request& r) {
     return run_spawn_systems(w, inputs, n_inputs, spawn_count, spawn_vx, spawn_vy);
 }
 
-// Bounded poll of tags in pinned host memory: true once tags[0..n) all equal seq.  The producer writes each value, then its tag with a
-// system-scope release (k_gen_finalize, ff_fold_row); seeing every tag means the values are in host memory.
+// Bounded poll of tags in pinned host memory: true once tags[0..n) all equal seq.  The producer writes each value and, once that store has
+// completed, its tag (k_gen_finalize: a system-scope release; ff_fold_row: relaxed system-scope stores with s_waitcnt vmcnt(0) between them,
+// device_prelude.hpp); seeing every tag means the values are in host memory.
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();

@@ -271,6 +271,9 @@ struct ggrs_world {
     bool nt_copy = false;               // non-temporal loads/stores in k_copy_state (A/B knob)
     bool prof = false;
     std::vector<EventPair> prof_events;
+    std::vector<hipEvent_t> prof_pool;   // timing events of drained pairs, reused: creating two events per launch kept the HOST behind the device in an instrumented pass
+                                         // (idle gaps between ticks; the 1 M launch then read 49 us instead of 45: profiles/r05j)
+    hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e; }
     double prof_ms[GGRS_KERNEL_CLASSES] = {};
     uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
     uint64_t prof_bytes[GGRS_KERNEL_CLASSES] = {};            // algorithmic bytes the launches of a class were asked to move (rows x their extent)
@@ -298,7 +301,7 @@ namespace {
 struct ProfScope {
     ggrs_world* w; uint32_t cls; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(ggrs_world* w_, uint32_t c, uint64_t bytes = 0) : w(w_), cls(c) {
-        if (w->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, w->stream); w->prof_bytes[c] += bytes; }
+        if (w->prof) { a = w->prof_event(); b = w->prof_event(); (void)hipEventRecord(a, w->stream); w->prof_bytes[c] += bytes; }
     }
     ~ProfScope() {
         if (w->prof) { (void)hipEventRecord(b, w->stream); w->prof_events.push_back({a, b, cls}); }

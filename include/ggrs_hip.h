@@ -311,7 +311,8 @@ int ggrs_hip_download_present(ggrs_world* w, uint32_t comp_id, uint64_t* host_ds
  * of the column lives at dev_ptr + (e / 8192) * tile_stride + (e % 8192) * word_bytes; *tile_stride (may be
  * NULL) is 8192 * word_bytes for a plain array (non-rollback components) and the bytes of all rollback words
  * of 8192 slots otherwise (8192-slot layout tiles).  Whoever holds such a pointer may write the column
- * behind the library's back, so from this call on the column takes no row-version shortcut: every SaveWorld / LoadWorld moves it. */
+ * behind the library's back, so from this call on the column takes no row-version shortcut: every SaveWorld / LoadWorld moves it,
+ * and every tick writes the live block (no lazy live block). */
 int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t comp_id, uint32_t word, void** dev_ptr,
                                uint64_t* tile_stride);
 
@@ -396,7 +397,8 @@ int ggrs_hip_synchronize(ggrs_world* w);
  * ------------------------------------------------------------------------------------------- */
 /* bytes of one packed world state (all columns [0,capacity), masks, header) */
 uint64_t ggrs_hip_state_bytes(ggrs_world* w);
-/* device pointer of the LIVE packed state block (contiguous; valid until destroy) */
+/* device pointer of the LIVE packed state block (contiguous; valid until destroy).  The block is brought up to date first (a session in
+ * steady rollback leaves it unwritten between ticks: DESIGN.md section 3 "lazy live block") and is written by every tick from this call on. */
 int ggrs_hip_live_state_ptr(ggrs_world* w, void** dev_ptr);
 /* after bytes were written into the live state block by an external producer (collective),
  * re-read its header so host-side bookkeeping (len, frame) matches */
