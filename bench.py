@@ -51,9 +51,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ADV_BYTES = 64                 # AdvanceWorld as its own kernel: r/w translation 12 + velocity 12 + ttl 8
 
 
+def dbg_hooks(w):
+    """A/B switches of the library's test hooks (experiments behind profiles/r05h, r05k; none is set in a bench line that counts)."""
+    if os.environ.get("BENCH_DBG_SKIP_ROWS"): w._lib.ggrs_dbg_set_skip_rows(w._p, C.c_uint64(int(os.environ["BENCH_DBG_SKIP_ROWS"], 0)))
+    if os.environ.get("BENCH_NO_LAZY_LIVE") == "1": w._lib.ggrs_dbg_set_lazy_live(w._p, 0)
+
+
 def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="headline"):
     w = bg.World(n, max_depth=depth + 1, stream=stream, flags=flags)
-    if os.environ.get("BENCH_NO_LAZY_LIVE") == "1": w._lib.ggrs_dbg_set_lazy_live(w._p, 0)        # A/B only (the library's test hook; --no-lazy-live)
+    dbg_hooks(w)
     ids = cm.build_particles(w, checksum=checksum, schema=schema)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)
@@ -482,6 +488,7 @@ def measure_p2p(bg, cm, torch, args):
     n, R, K, W = args.entities, args.depth, args.steps, args.warmup
     stream = torch.cuda.current_stream().cuda_stream
     w = bg.World(n, max_depth=R + 1, stream=stream)
+    dbg_hooks(w)
     ids = cm.build_particles(w)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)
@@ -677,6 +684,7 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
     lib = tick_loop_lib()
     stream = torch.cuda.current_stream().cuda_stream
     w = bg.World(n, max_depth=R + 1, stream=stream)
+    dbg_hooks(w)
     ids = cm.build_particles(w)
     vel, ttl = cm.synthetic_particles(n, ttl="throughput")
     cm.spawn_particles(w, ids, n, vel, ttl)

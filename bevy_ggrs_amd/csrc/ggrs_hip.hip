@@ -321,6 +321,7 @@ int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, c
 }
 // Test hook (no ggrs_hip_ prefix, not in the header): places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight
 // rollback lengths exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
+int ggrs_dbg_set_skip_rows(ggrs_world* w, uint64_t mask) { if (!w) return -1; w->dbg_skip_rows = mask; return 0; }
 int ggrs_dbg_set_lazy_live(ggrs_world* w, int on) { if (!w) return -1; w->lazy_live_on = on; return 0; }
 int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }

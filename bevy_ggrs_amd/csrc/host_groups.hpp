@@ -481,6 +481,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         j.load_rows = j.n_ops ? static_reads : 0;
         for (uint32_t k = 0; k < j.n_saves; ++k) {
             j.save_rows[k] = j.save_dst[k] ? gs.save_rows[k] : 0;
+            if (w->dbg_skip_rows && w->load_open_streak >= 64) j.save_rows[k] &= ~w->dbg_skip_rows;
             j.save_pmask[k] = j.save_dst[k] ? gs.save_pmask[k] : 0;
             j.load_rows |= j.save_rows[k];
             bytes_slot += rows_bytes_per_slot(w, j.save_rows[k], true);

@@ -236,6 +236,7 @@ struct ggrs_world {
     struct LiveStale { bool valid = false; Block* src = nullptr; uint64_t len = 0; uint32_t dt_bits = 0, aux_bits = 0; int step_frame = 0, step_confirmed = 0;
                        unsigned char n_inputs = 0; unsigned char inputs[GGRS_MAX_PLAYERS * (GGRS_MAX_INPUT_BYTES + 1)] = {}; } live_stale;
     int lazy_live_on = 1;                // (ggrs_dbg_set_lazy_live: 0 = the A/B of profiles/r05h; 2 = every eligible list whatever its size and streak: the fuzzer)
+    uint64_t dbg_skip_rows = 0;          // EXPERIMENT ONLY (ggrs_dbg_set_skip_rows): columns dropped from every Save of a long-running steady session
     bool live_handed_out = false;        // ggrs_hip_live_state_ptr gave the block away: it is kept current from then on
     uint32_t load_open_streak = 0;       // consecutive request lists that opened with a LoadGameState
     uint64_t lazy_skips = 0, lazy_materialised = 0;
