@@ -89,6 +89,8 @@ def main():
                 json.dump(res, open(os.path.join(d, "resources.json"), "w"), indent=1, sort_keys=True)
         w.close()
     json.dump(index, open(os.path.join(a.out, "index.json"), "w"), indent=1, sort_keys=True)
+    for f in os.listdir(a.out):                                       # objects of earlier generator versions: nothing asks for their names any more
+        if f.endswith(".hsaco") and f not in index.values(): os.remove(os.path.join(a.out, f))
     print(f"{len(index)} code objects under {a.out}")
 
 
