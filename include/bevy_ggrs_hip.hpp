@@ -332,6 +332,22 @@ struct CustomKernelSystem {
     template <class T> CustomKernelSystem& bind(uint32_t word) { bindings.emplace_back(HipComponent<T>::name, word); return *this; }
 };
 
+// add_systems(GgrsSchedule, <a system that spawns Rollback entities>): `commands.spawn((bundle.., Rollback))` (snapshot/rollback.rs:45-59) as HIP C++ source defining
+//   __device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload);
+// (ggrs_hip_add_spawn_system).  How many entities a frame spawns and the payload they are built from come from App::set_spawn_payload_source.
+struct SpawnKernelSystem {
+    std::string name, source;
+    std::vector<std::string> bundle;                              // component names every spawned entity gets
+    std::vector<std::pair<std::string, uint32_t>> bindings;      // (component name, word) the spawner writes
+    uint32_t payload_stride = 0;                                  // bytes of payload per spawned entity; 0: one blob per AdvanceFrame
+    int64_t iparam[2] = {0, 0};
+    float fparam[4] = {0, 0, 0, 0};
+    SpawnKernelSystem(std::string n, std::string src) : name(std::move(n)), source(std::move(src)) {}
+    template <class T> SpawnKernelSystem& with() { bundle.emplace_back(HipComponent<T>::name); return *this; }
+    template <class T> SpawnKernelSystem& bind(uint32_t word) { bindings.emplace_back(HipComponent<T>::name, word); return *this; }
+    SpawnKernelSystem& stride(uint32_t bytes) { payload_stride = bytes; return *this; }
+};
+
 namespace systems {
 // examples/stress_tests/particles.rs:272-280
 template <class TransformT, class VelocityT>
@@ -387,6 +403,8 @@ struct HipBackend {
     int checksum_component_custom(uint32_t c, const char* source) { return ggrs_hip_checksum_component_custom(w, c, source); }
     int add_system(const ggrs_system_desc* d) { return ggrs_hip_add_system(w, d); }
     int add_custom_system(const ggrs_custom_system_desc* d) { return ggrs_hip_add_custom_system(w, d); }
+    int add_spawn_system(const ggrs_spawn_system_desc* d) { return ggrs_hip_add_spawn_system(w, d); }
+    int register_component_strategy(uint32_t c, uint32_t stored_word_bytes, uint32_t stored_n_words, const char* source) { return ggrs_hip_register_component_strategy(w, c, stored_word_bytes, stored_n_words, source); }
     int set_frame_rate(uint64_t fps) { return ggrs_hip_set_frame_rate(w, fps); }
     int spawn(uint64_t count, uint64_t mask, const void* const* cols, uint64_t* first) { return ggrs_hip_spawn(w, count, mask, cols, first); }
     int set_depth(uint32_t d) { return ggrs_hip_set_depth(w, d); }
@@ -472,6 +490,23 @@ class App {
     // host-side stand-in for the rolled-back ParticleRng resource (particles.rs:125,201): must be a
     // pure function of the frame, or SyncTest reports a mismatch -- exactly like a non-deterministic system
     App& set_spawn_source(SpawnSource f) { spawn_source_ = std::move(f); return *this; }
+    // add_systems(GgrsSchedule, <user-written spawner>): a compile error throws with the hiprtc log
+    App& add_systems(GgrsSchedule, const SpawnKernelSystem& s) {
+        if (s.bindings.size() > GGRS_CUSTOM_MAX_BINDINGS) throw std::invalid_argument("a spawn system binds at most 8 words");
+        ggrs_spawn_system_desc d; std::memset(&d, 0, sizeof d);
+        d.name = s.name.c_str(); d.source = s.source.c_str(); d.payload_stride = s.payload_stride; d.n_bindings = (uint32_t)s.bindings.size();
+        for (auto& c : s.bundle) d.bundle_mask |= 1ull << comp_id(c);
+        for (size_t k = 0; k < s.bindings.size(); ++k) { d.comp[k] = comp_id(s.bindings[k].first); d.word[k] = s.bindings[k].second; }
+        for (int k = 0; k < 4; ++k) d.fparam[k] = s.fparam[k];
+        d.iparam[0] = s.iparam[0]; d.iparam[1] = s.iparam[1];
+        check(be_.add_spawn_system(&d));
+        has_custom_spawn_ = true;
+        return *this;
+    }
+    // what the spawner of frame `f` is handed: the number of entities it spawns (0: none this frame) and the payload blob they are built from.  Like the
+    // particles' spawn source it must be a pure function of (frame, inputs): a resimulated frame asks again (ParticleRng is a rollback resource, particles.rs:201)
+    using SpawnPayloadSource = std::function<uint64_t(Frame, const std::vector<std::pair<Input, InputStatus>>&, std::vector<uint8_t>& payload)>;
+    App& set_spawn_payload_source(SpawnPayloadSource f) { spawn_payload_source_ = std::move(f); return *this; }
 
     App& add_systems(GgrsSchedule, HostSystem f) { host_systems_.push_back(std::move(f)); return *this; }
 
@@ -529,6 +564,13 @@ class App {
     }
     template <class T> App& rollback_component_with_copy() { return register_component<T>(); }
     template <class T> App& rollback_component_with_clone() { return register_component<T>(); }   // bitwise for POD (strategy.rs:62-83)
+    // rollback_component_with::<S>() for a Strategy whose Stored differs from the component (strategy.rs:22-40): `source` defines ggrs_store / ggrs_load
+    // (ggrs_hip_register_component_strategy); the ring then holds stored_n_words words of stored_word_bytes per entity for T
+    template <class T> App& rollback_component_with_strategy(uint32_t stored_word_bytes, uint32_t stored_n_words, const std::string& source) {
+        register_component<T>();
+        check(be_.register_component_strategy(comp_id(HipComponent<T>::name), stored_word_bytes, stored_n_words, source.c_str()));
+        return *this;
+    }
     // rollback_immutable_component_with_* (rollback_app.rs:40-44,58-62; ImmutableComponentSnapshotPlugin::load,
     // component_snapshot.rs:218-245): LoadWorld re-INSERTS the stored value instead of updating in place so that
     // component hooks fire.  In a SoA column "insert" is "store the words + set the presence bit", which is what
@@ -606,6 +648,7 @@ class App {
     const std::vector<u128>& last_checksums() const { return last_checksums_; }
     Backend& backend() { return be_; }
     uint64_t active_count() { uint64_t n = 0; check(be_.active_count(&n)); return n; }
+    uint64_t len() { return be_.len(); }                             // RollbackOrdered::len(): every Rollback entity ever spawned (snapshot/rollback.rs:69-88)
     template <class T, class W> std::vector<W> download(uint32_t word) {
         static_assert(sizeof(W) == HipComponent<T>::word_bytes, "word type must match the component's word size");
         std::vector<W> out(be_.len());
@@ -637,6 +680,7 @@ class App {
         std::vector<std::vector<uint8_t>> input_bytes; input_bytes.reserve(2 * requests.size());     // per AdvanceFrame: the inputs' bytes, then the status bytes
         using Input = typename C::Input;
         std::vector<std::vector<float>> payload; payload.reserve(2 * requests.size());
+        std::vector<std::vector<uint8_t>> blobs; blobs.reserve(requests.size());             // (reserved: the requests keep pointers into the elements)
         std::vector<GgrsRequest<C>*> saves;
         Frame cur = be_.frame();
         const SyncTestSession<C>* st = std::get_if<SyncTestSession<C>>(&session_);
@@ -672,6 +716,12 @@ class App {
                     pressed |= (b[0] & spawn_mask_) != 0;
                 }
                 q.inputs = ibytes.data(); q.status = sbytes.data(); q.n_inputs = (uint32_t)r.inputs.size();
+                if (has_custom_spawn_ && spawn_payload_source_) {
+                    blobs.emplace_back();
+                    auto& blob = blobs.back();
+                    q.spawn_count = spawn_payload_source_(cur, r.inputs, blob);
+                    if (q.spawn_count) { q.spawn_payload = blob.data(); q.spawn_payload_bytes = blob.size(); }
+                }
                 if (has_spawn_system_ && pressed && spawn_source_) {
                     payload.emplace_back(); payload.emplace_back();
                     auto& vx = payload[payload.size() - 2]; auto& vy = payload[payload.size() - 1];
@@ -786,6 +836,7 @@ class App {
     Session<C> session_;
     ReadInputsSystem read_inputs_;
     SpawnSource spawn_source_;
+    SpawnPayloadSource spawn_payload_source_; bool has_custom_spawn_ = false;
     bool has_spawn_system_ = false; uint8_t spawn_mask_ = 0;
     std::function<void(const SyncTestMismatch&)> on_mismatch_;
     std::unordered_map<std::string, uint32_t> comp_ids_;

@@ -50,7 +50,7 @@ use std::marker::PhantomData;
 
 pub mod prelude {
     pub use crate::{
-        hip_component, systems, DeviceInput, GgrsPlugin, HipComponent, HipSlot, HipWorld, HipWorldConfig, KernelSystem, Rollback, RollbackApp, SpawnBlob, SpawnPayload,
+        hip_component, systems, DeviceInput, GgrsPlugin, HipComponent, HipSlot, HipWorld, HipWorldConfig, KernelSystem, Rollback, RollbackApp, SpawnBlob, SpawnKernelSystem, SpawnPayload,
     };
     pub use bevy_ggrs::prelude::{
         GgrsConfig, GgrsSchedule, GgrsTime, LocalInputs, LocalPlayers, PlayerInputs, ReadInputs, RollbackFrameRate, Session, SyncTestMismatch,
@@ -473,6 +473,41 @@ fn status_byte(s: InputStatus) -> u8 {
 
 /// Same method names as `bevy_ggrs::RollbackApp` (src/snapshot/rollback_app.rs:31-133) for the component kinds the
 /// device path owns; resources, reflect and hierarchy strategies keep going through bevy_ggrs's own trait.
+/// `add_systems(GgrsSchedule, ..)` for a system that SPAWNS Rollback entities -- `commands.spawn((bundle.., Rollback))`
+/// (src/snapshot/rollback.rs:45-59; examples/stress_tests/particles.rs:254-270) -- as HIP C++ source defining
+/// `__device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload)`
+/// (include/ggrs_hip.h `ggrs_hip_add_spawn_system`).  How many entities a frame spawns and the payload they are built from
+/// come from the [`SpawnBlob`] resource.
+pub struct SpawnKernelSystem {
+    pub name: &'static str,
+    pub source: String,
+    pub bundle: Vec<fn(&HipWorld) -> u32>,
+    pub bindings: Vec<(fn(&HipWorld) -> u32, u32)>,
+    pub payload_stride: u32,
+    pub iparam: [i64; 2],
+    pub fparam: [f32; 4],
+}
+impl SpawnKernelSystem {
+    pub fn new(name: &'static str, source: impl Into<String>) -> Self {
+        SpawnKernelSystem { name, source: source.into(), bundle: Vec::new(), bindings: Vec::new(), payload_stride: 0, iparam: [0; 2], fparam: [0.0; 4] }
+    }
+    /// Every spawned entity gets component `T` (at its registered default unless the spawner writes it).
+    pub fn with<T: HipComponent>(mut self) -> Self {
+        self.bundle.push(HipWorld::comp_id::<T>);
+        self
+    }
+    /// Bind word `word` of component `T` as the next `e.*(i)` the spawner writes.
+    pub fn bind<T: HipComponent>(mut self, word: u32) -> Self {
+        self.bindings.push((HipWorld::comp_id::<T>, word));
+        self
+    }
+    /// Bytes of payload per spawned entity (0: one blob per AdvanceFrame).
+    pub fn stride(mut self, bytes: u32) -> Self {
+        self.payload_stride = bytes;
+        self
+    }
+}
+
 pub trait RollbackApp {
     fn rollback_component_with_copy<T: HipComponent>(&mut self) -> &mut Self;
     fn rollback_component_with_clone<T: HipComponent>(&mut self) -> &mut Self;
@@ -490,6 +525,12 @@ pub trait RollbackApp {
     fn add_kernel_system(&mut self, schedule: GgrsSchedule, system: KernelSystem) -> &mut Self;
     /// `add_systems(GgrsSchedule, ..)` for a user-written per-entity system (HIP C++ source, compiled at registration).
     fn add_custom_kernel_system(&mut self, schedule: GgrsSchedule, system: CustomKernelSystem) -> &mut Self;
+    /// `add_systems(GgrsSchedule, ..)` for a user-written system that spawns Rollback entities (one per world).
+    fn add_spawn_kernel_system(&mut self, schedule: GgrsSchedule, system: SpawnKernelSystem) -> &mut Self;
+    /// `rollback_component_with::<S>()` for a `Strategy` whose `Stored` differs from the component (src/snapshot/strategy.rs:22-40):
+    /// `source` defines `ggrs_store(const GgrsWords& target, GgrsWords& stored)` and `ggrs_load(const GgrsWords& stored, GgrsWords& target)`
+    /// (include/ggrs_hip.h `ggrs_hip_register_component_strategy`); ring slots then hold `stored_n_words` words of `stored_word_bytes`.
+    fn rollback_component_with_strategy<T: HipComponent>(&mut self, stored_word_bytes: u32, stored_n_words: u32, source: &str) -> &mut Self;
     /// Keep the Bevy copy of `T` current for host-side readers (rendering); off by default: it is a device -> host
     /// copy of the whole column every rendered frame.
     fn mirror_component<T: HipComponent>(&mut self) -> &mut Self;
@@ -580,6 +621,41 @@ impl RollbackApp for App {
         }
         let rc = unsafe { ffi::ggrs_hip_add_custom_system(w.raw, &desc) };
         w.check(rc); // a compile error panics with the hiprtc log (ggrs_hip_last_error), like a system that fails to build
+        self
+    }
+    fn add_spawn_kernel_system(&mut self, _schedule: GgrsSchedule, system: SpawnKernelSystem) -> &mut Self {
+        let w = hip_world(self);
+        let name = std::ffi::CString::new(system.name).expect("system name");
+        let source = std::ffi::CString::new(system.source).expect("system source");
+        assert!(system.bindings.len() <= ffi::GGRS_CUSTOM_MAX_BINDINGS, "a spawn system binds at most 8 words");
+        let mut desc = ffi::ggrs_spawn_system_desc {
+            name: name.as_ptr(),
+            source: source.as_ptr(),
+            bundle_mask: 0,
+            payload_stride: system.payload_stride,
+            n_bindings: system.bindings.len() as u32,
+            comp: [0; ffi::GGRS_CUSTOM_MAX_BINDINGS],
+            word: [0; ffi::GGRS_CUSTOM_MAX_BINDINGS],
+            iparam: system.iparam,
+            fparam: system.fparam,
+        };
+        for comp in system.bundle.iter() {
+            desc.bundle_mask |= 1u64 << comp(&w);
+        }
+        for (k, (comp, word)) in system.bindings.iter().enumerate() {
+            desc.comp[k] = comp(&w);
+            desc.word[k] = *word;
+        }
+        let rc = unsafe { ffi::ggrs_hip_add_spawn_system(w.raw, &desc) };
+        w.check(rc);
+        self
+    }
+    fn rollback_component_with_strategy<T: HipComponent>(&mut self, stored_word_bytes: u32, stored_n_words: u32, source: &str) -> &mut Self {
+        register::<T>(self, ffi::GGRS_COMP_ROLLBACK);
+        let w = hip_world(self);
+        let source = std::ffi::CString::new(source).expect("strategy source");
+        let rc = unsafe { ffi::ggrs_hip_register_component_strategy(w.raw, HipWorld::comp_id::<T>(&w), stored_word_bytes, stored_n_words, source.as_ptr()) };
+        w.check(rc);
         self
     }
     fn mirror_component<T: HipComponent>(&mut self) -> &mut Self {

@@ -206,6 +206,87 @@ static void custom_system_equals_builtin() {
     std::puts("ok custom_system_equals_builtin");
 }
 
+// A system of the GgrsSchedule that SPAWNS Rollback entities (snapshot/rollback.rs:45-59) and a Strategy whose Stored is not the component (strategy.rs:22-40),
+// through the plugin mirror: bullets fired every third frame, aged and despawned by a user-written system; an f32 x 3 component snapshotted as f16 x 3
+struct Bullet {};
+struct Accel {};
+namespace bevy_ggrs {
+template <> struct HipComponent<Bullet> { static constexpr const char* name = "Bullet"; static constexpr uint32_t word_bytes = 4, n_words = 3; };   // x, vx, life
+template <> struct HipComponent<Accel> { static constexpr const char* name = "Accel"; static constexpr uint32_t word_bytes = 4, n_words = 3; };
+}
+static void user_written_spawner_and_strategy() {
+#ifndef BACKEND_ORACLE
+    constexpr uint32_t LIFE = 6;
+    {
+        TestApp app(4096);
+        base_synctest_app(app, 5);
+        app.rollback_component_with_copy<Bullet>().checksum_component_with_hash<Bullet>();
+        CustomKernelSystem age("age_bullets",
+            "__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) {\n"
+            "    e.f32(0) = e.f32(0) + e.f32(1) * f.dt;\n"
+            "    if (e.u32(2) <= 1u) e.despawn(); else e.u32(2) -= 1u;\n"
+            "}\n");
+        age.bind<Bullet>(0).bind<Bullet>(1).bind<Bullet>(2);
+        app.add_systems(GgrsSchedule{}, age);
+        SpawnKernelSystem fire("fire",
+            "__device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload) {\n"
+            "    float vx; __builtin_memcpy(&vx, payload, 4);\n"
+            "    e.f32(0) = 0.0f; e.f32(1) = vx; e.u32(2) = (ggrs_u32)f.iparam[0];\n"
+            "}\n");
+        fire.with<Bullet>().bind<Bullet>(0).bind<Bullet>(1).bind<Bullet>(2).stride(4);
+        fire.iparam[0] = LIFE;
+        app.add_systems(GgrsSchedule{}, fire);
+        uint64_t asked = 0;
+        app.set_spawn_payload_source([&](Frame f, const PlayerInputs<Config>&, std::vector<uint8_t>& blob) -> uint64_t {
+            ++asked;
+            if (f % 3 != 0) return 0;                                           // a pure function of the frame: a resimulated frame fires the same shots
+            const float v[2] = {0.5f * (float)f, 0.5f * (float)f + 1.0f};
+            blob.resize(sizeof v); std::memcpy(blob.data(), v, sizeof v);
+            return 2;
+        });
+        int fired = 0;
+        app.add_observer([&](const SyncTestMismatch&) { ++fired; });
+        const int updates = 30;
+        for (int i = 0; i < updates; ++i) app.update();
+        CHECK(fired == 0);
+        CHECK(asked > (uint64_t)updates);                                       // resimulated frames asked again
+        // frames 0 .. updates-1 ran once the session is done: 2 bullets per frame f with f % 3 == 0; a bullet spawned at the end of frame f is aged by
+        // frames f+1 .. and despawned by the LIFE-th of them
+        uint64_t spawned = 0, alive = 0;
+        for (int f = 0; f < updates; ++f) if (f % 3 == 0) { spawned += 2; if (updates - 1 - f < (int)LIFE) alive += 2; }
+        CHECK(app.len() == spawned);
+        CHECK(app.active_count() == alive);
+    }
+    std::vector<uint32_t> got[2];
+    for (int strategy = 0; strategy < 2; ++strategy) {
+        TestApp app(256);
+        base_synctest_app(app, 4);
+        if (strategy)
+            app.rollback_component_with_strategy<Accel>(2, 3,
+                "__device__ unsigned short f2h(float x) { _Float16 h = (_Float16)x; unsigned short b; __builtin_memcpy(&b, &h, 2); return b; }\n"
+                "__device__ float h2f(unsigned short b) { _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }\n"
+                "__device__ void ggrs_store(const GgrsWords& t, GgrsWords& s) { for (int k = 0; k < 3; ++k) s.u16(k) = f2h(t.f32(k)); }\n"
+                "__device__ void ggrs_load(const GgrsWords& s, GgrsWords& t) { for (int k = 0; k < 3; ++k) t.f32(k) = h2f(s.u16(k)); }\n");
+        else
+            app.rollback_component_with_copy<Accel>();
+        app.checksum_component_with_hash<Accel>();
+        CustomKernelSystem drift("drift", "__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame&) { e.f32(0) = e.f32(0) + 0.5f; }\n");
+        drift.bind<Accel>(0);
+        app.add_systems(GgrsSchedule{}, drift);
+        std::vector<float> x(200), y(200), z(200);
+        for (size_t i = 0; i < x.size(); ++i) { x[i] = 0.5f * (float)(i % 64); y[i] = -2.0f; z[i] = 0.25f * (float)(i % 7); }      // exact in f16: store / load are a bijection here
+        app.spawn(x.size(), {"Accel"}, {x.data(), y.data(), z.data()});
+        int fired = 0;
+        app.add_observer([&](const SyncTestMismatch&) { ++fired; });
+        for (int i = 0; i < 20; ++i) app.update();
+        CHECK(fired == 0);
+        got[strategy] = app.download<Accel, uint32_t>(0);
+    }
+    CHECK(got[0] == got[1] && !got[0].empty());
+#endif
+    std::puts("ok user_written_spawner_and_strategy");
+}
+
 // tests/synctest.rs:84-125: something that is NOT rolled back leaks into a checksummed component
 static void mismatch_fires_on_non_determinism() {
     TestApp app(4096);
@@ -562,6 +643,7 @@ int main(int argc, char** argv) {
     print_request_traces();
     despawn_and_rollback_does_not_panic();
     custom_system_equals_builtin();
+    user_written_spawner_and_strategy();
     mismatch_fires_on_non_determinism();
     confirmed_frame_pruning();
     component_rollback_copy();
