@@ -264,10 +264,15 @@ def latency_floor(kernel_us, launches_per_tick, tick_us):
     its kernels plus one dependent same-stream boundary per launch -- 1.45 us between trivial kernels, 1.7-1.9 us between real streaming
     ones (MI355X_MICROARCH.md, price list row `boundary`).  Reported next to `roofline` for BASELINE configs 2 and 4."""
     lo, hi = kernel_us * launches_per_tick + 1.45 * launches_per_tick, kernel_us * launches_per_tick + 1.9 * launches_per_tick
-    return {"bound": "launch latency (dependent same-stream kernel boundary)", "boundary_us": [1.45, 1.9], "source": "MI355X_MICROARCH.md, 'Persistent kernels: synchronisation and hand-off price list', row boundary",
-            "kernel_us_per_tick": kernel_us * launches_per_tick, "launches_per_tick": launches_per_tick,
-            "floor_us_per_tick": [round(lo, 2), round(hi, 2)], "achieved_us_per_tick": tick_us,
-            "frac": [round(lo / tick_us, 3), round(hi / tick_us, 3)] if tick_us else None}
+    out = {"bound": "launch latency (dependent same-stream kernel boundary)", "boundary_us": [1.45, 1.9], "source": "MI355X_MICROARCH.md, 'Persistent kernels: synchronisation and hand-off price list', row boundary",
+           "kernel_us_per_tick": kernel_us * launches_per_tick, "launches_per_tick": launches_per_tick,
+           "floor_us_per_tick": [round(lo, 2), round(hi, 2)], "achieved_us_per_tick": tick_us,
+           "frac": [round(min(1.0, lo / tick_us), 3), round(min(1.0, hi / tick_us), 3)] if tick_us else None}
+    if tick_us and hi > tick_us:
+        # a small world's kernel runs as fast as the chip's clocks are when it starts, and those follow the loop's duty cycle: the kernel time of an instrumented
+        # pass can exceed what the (differently paced) timed ticks had room for.  The fraction is capped; the raw figures stay in the line.
+        out["frac_uncapped"] = [round(lo / tick_us, 3), round(hi / tick_us, 3)]
+    return out
 
 
 def platform_loop_floor(inflight, tick_us, kernel_us=None):
@@ -659,10 +664,9 @@ def c_loop_synctest(bg, cm, torch, n, D, K, schema="headline", inflight=1, kerne
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": inflight, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * (D + 1) * K / secs.value, "unit": "entity-frames/s",
            "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2), "first": round(tick_us[0], 2)},
            "kernel_us": {"median_under_this_loop": round(k_us, 2), "min": round(lus[0], 2) if lus else None, "launches": len(lus), "under_the_python_loop": kernel_us}}
-    # the floor is priced on the instrumented pass ITSELF (its kernel times against its own tick): the kernel of a small world runs as fast as the chip's clocks
-    # are when it starts, and those depend on how long the device idled -- a kernel time from one pass against the tick of another read above 1 (profiles/r05j)
-    if k_us: out["latency_floor"] = dict(latency_floor(k_us, 1.0, s2.value / 200 * 1e6), priced_on="the instrumented pass: its kernels' median against its own tick",
-                                         uninstrumented_tick_us=round(secs.value / K * 1e6, 3))
+    # kernel time: the median of the instrumented pass (timing events ride on the dispatches and come from a pool since profiles/r05j -- creating them per launch
+    # kept the host behind the device and the kernels started from an idle chip: 8.5 instead of 5.3 us); tick: the un-instrumented timed region
+    if k_us: out["latency_floor"] = latency_floor(k_us, 1.0, secs.value / K * 1e6)
     out["platform_floor"] = platform_loop_floor(inflight, secs.value / K * 1e6, k_us)
     P = min(parity_ticks, K)
     if P:
@@ -730,9 +734,8 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": 1, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * advances / secs.value, "unit": "entity-frames/s",
            "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)},
            "kernel_us": {"mean_under_this_loop": round(k_us, 2), "priced": "per rollback length, weighted by the timed ticks' lengths", "launches_per_tick": round(lpt, 3), "under_the_python_loop": kernel_us}}
-    if k_us: out["latency_floor"] = dict(latency_floor(sum(lus) / len(lus) if lus else k_us, lpt, s2.value / n_prof * 1e6), priced_on="the instrumented pass: its kernels' mean against its own tick",
-                                         uninstrumented_tick_us=round(secs.value / K * 1e6, 3))
-    out["platform_floor"] = platform_loop_floor(1, secs.value / K * 1e6, (sum(lus) / len(lus)) if lus else k_us)
+    if k_us: out["latency_floor"] = latency_floor(k_us, lpt, secs.value / K * 1e6)
+    out["platform_floor"] = platform_loop_floor(1, secs.value / K * 1e6, k_us)
     # every Save of every tick (warm-up included) against the oracle under the same script
     from oracle.binding import FLAT, OracleWorld, lib as olib
     olib.gor_set_num_threads(max(1, min(64, os.cpu_count() or 1)))

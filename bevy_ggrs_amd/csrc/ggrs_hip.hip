@@ -805,7 +805,7 @@ int ggrs_hip_profile_enable(ggrs_world* w, int on) {
     w->prof = on != 0;
     if (on) { DeviceGuard dg(w);
               for (auto& e : w->prof_events) { w->prof_pool.push_back(e.a); w->prof_pool.push_back(e.b); } w->prof_events.clear();
-              while (w->prof_pool.size() < 128) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; w->prof_pool.push_back(e); }     // (outside whatever the caller times)
+              while (w->prof_pool.size() < 512) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; w->prof_pool.push_back(e); }     // (outside whatever the caller times)
               for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; w->prof_bytes[i] = 0; w->prof_launch_us[i].clear(); } }
     return GGRS_OK;
 }

@@ -202,8 +202,8 @@ __global__ __launch_bounds__(TPB) void k_copy_state(const uint8_t* __restrict__ 
     }
     // masks: 16 u64 words per tile per mask (copied whole, so stale bits beyond the source's
     // len are cleared in the destination)
-    if (tid < 16u * plan.n_masks) {
-        const uint32_t m = tid >> 4, wi = tid & 15u;
+    for (uint32_t i = tid; i < 16u * plan.n_masks; i += blockDim.x) {      // (16 components + the liveness mask = 272 words: more than one trip of 256 threads)
+        const uint32_t m = i >> 4, wi = i & 15u;
         const uint64_t o = plan.mask_off[m] + ((uint64_t)t * 16 + wi) * 8;
         *reinterpret_cast<uint64_t*>(dst + o) = *reinterpret_cast<const uint64_t*>(src + o);
     }
