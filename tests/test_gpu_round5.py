@@ -427,12 +427,12 @@ def test_lazy_live_block_is_off_where_the_live_world_holds_more_than_the_snapsho
 
 
 # ------------------------------------------------------------------------------------------------ the component limit
-@pytest.mark.parametrize("per_request", [False, True])
-def test_sixteen_components_every_presence_mask_travels(per_request):
+@pytest.mark.parametrize("per_request,n", [(False, 5000), (True, 5000), (False, 300_000)])
+def test_sixteen_components_every_presence_mask_travels(per_request, n):
     """GGRS_MAX_COMPONENTS components + the liveness mask are 17 masks of 16 words per 1024-slot tile = 272 words: the per-request copy kernel moved the
     first 256 (one trip of its 256 threads), i.e. a SaveWorld / LoadWorld lost the LAST component's presence mask.  Both paths against the oracle, with
-    presence edits between the lists so that a LoadWorld has to bring the old masks back."""
-    n = 5000
+    presence edits between the lists so that a LoadWorld has to bring the old masks back.  300 k: 16 checksummed components through the lane-fold rows and,
+    enqueued, the fold-forward role (17 values per Save and workgroup)."""
     res = []
     for w in (bg.World(n, max_depth=4, flags=bg.GGRS_WORLD_NO_GROUPS if per_request else 0), OracleWorld(n, 4, FLAT)):
         comps = [w.register_component(f"C{k}", 4, 1) for k in range(16)]
@@ -450,7 +450,12 @@ def test_sixteen_components_every_presence_mask_travels(per_request):
         w.insert_component(comps[15], 2, np.array([41], dtype=np.uint32))
         cs += w.handle_requests([bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.SaveGameState(3), bg.AdvanceFrame((0,))])
         mid = cm.snapshot_state(w, comps)
-        cs += w.handle_requests([bg.LoadGameState(1), bg.AdvanceFrame((0,)), bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.SaveGameState(3), bg.AdvanceFrame((0,))])
+        roll = [bg.LoadGameState(1), bg.AdvanceFrame((0,)), bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.SaveGameState(3), bg.AdvanceFrame((0,))]
+        if isinstance(w, bg.World) and not per_request:
+            w.enqueue_requests(roll); w.enqueue_requests([bg.LoadGameState(3), bg.AdvanceFrame((0,)), bg.SaveGameState(4), bg.AdvanceFrame((0,))])     # (the second list folds the first one's rows at 300 k)
+            cs += w.collect_checksums(); cs += w.collect_checksums()
+        else:
+            cs += w.handle_requests(roll); cs += w.handle_requests([bg.LoadGameState(3), bg.AdvanceFrame((0,)), bg.SaveGameState(4), bg.AdvanceFrame((0,))])
         res.append((cs, mid, cm.snapshot_state(w, comps)))
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], "before the rollback")
