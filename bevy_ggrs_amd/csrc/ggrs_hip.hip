@@ -145,7 +145,8 @@ const char* ggrs_hip_last_error(ggrs_world* w) { return w ? w->err.c_str() : "nu
 int ggrs_hip_register_component(ggrs_world* w, const char* name, uint32_t word_bytes, uint32_t n_words, uint32_t* comp_id) {
     if (!w || !name) return GGRS_E_INVALID;
     if (w->sealed) return w->fail(GGRS_E_INVALID, "register_component after the world was sealed");
-    if (w->comps.size() >= GGRS_MAX_COMPONENTS || n_words == 0 || n_words > GGRS_MAX_WORDS || (word_bytes != 1 && word_bytes != 2 && word_bytes != 4 && word_bytes != 8))
+    if (w->comps.size() >= GGRS_MAX_COMPONENTS) return w->fail(GGRS_E_INVALID, "at most %d components per world (GGRS_MAX_COMPONENTS)", GGRS_MAX_COMPONENTS);
+    if (n_words == 0 || n_words > GGRS_MAX_WORDS || (word_bytes != 1 && word_bytes != 2 && word_bytes != 4 && word_bytes != 8))
         return w->fail(GGRS_E_INVALID, "bad component shape (word_bytes must be 1, 2, 4 or 8; 1..%d words)", GGRS_MAX_WORDS);
     Comp c; c.name = name; c.word_bytes = word_bytes; c.n_words = n_words;
     c.defaults.assign((size_t)word_bytes * n_words, 0);

@@ -471,7 +471,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
                  "    __syncthreads();\n", n_cks, n_cks, n_cks + 1, n_cks);
         fold_text = ft;
     }
-    if (n_cks > 16) return false;
+    if (n_cks > (uint32_t)GEN_MAX_CKS) return false;
     const unsigned long long OFF_ALIVE = w->off_alive, OFF_DIS = w->marks.off_disabled, OFF_DF = w->marks.off_dframe;
     const JitLayout L = jit_layout(w);
     const uint32_t IB = L.in_bytes, MAXP = L.max_players, IN_STRIDE = L.in_stride;

@@ -30,7 +30,8 @@ constexpr int TILE = 1024;     // slots per workgroup
 // LT_SHIFT = 13 / LAYOUT_TILE = 8192 (slots of a LAYOUT tile = 8 workgroup tiles) are declared in device_prelude.hpp
 constexpr int TPB = 256;       // threads per workgroup (4 waves of 64)
 constexpr int MAX_ROWS = 96;   // 4 KiB copy rows per tile (a 4-byte column = 1 row, 8-byte = 2)
-constexpr int MAX_MASKS = 17;  // alive + one presence mask per component
+constexpr int MAX_COMPS = GGRS_MAX_COMPONENTS;
+constexpr int MAX_MASKS = MAX_COMPS + 1;  // alive + one presence mask per component
 constexpr int MAX_UNITS = 32;
 
 // SeaHash (seahash 4.1), the state-block Header, wave_xor and the box_game step: shared with the run-time generated kernels
@@ -74,9 +75,9 @@ struct CksArgs {          // generic component checksum
     const uint8_t* state;
     uint64_t off_alive;
     uint32_t n_cks; uint32_t part_stride;
-    uint64_t off_present[16];
-    uint32_t n_units[16];
-    uint32_t unit_base[16];
+    uint64_t off_present[MAX_COMPS];
+    uint32_t n_units[MAX_COMPS];
+    uint32_t unit_base[MAX_COMPS];
     uint64_t* parts;      // [n_cks][part_stride]
     uint64_t* part_cnt;   // [part_stride]
 };
@@ -105,7 +106,7 @@ struct FinalizeArgs {
     uint64_t* out;              // {lo, hi} of Checksum(u128)
     Header* live_hdr;
 };
-constexpr int MAX_CKS = 16;
+constexpr int MAX_CKS = MAX_COMPS;
 
 __device__ __forceinline__ void finalize_block(const FinalizeArgs& f, uint64_t* checksum_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(TPB) void k_particles_step(StepArgs a) {
 constexpr int MAX_TICK_OPS = 40, MAX_TICK_SAVES = 16, MAX_TICK_STEPS = 24;
 
 constexpr int FIN_TPB = 1024;
-constexpr int GEN_MAX_CKS = 16;
+constexpr int GEN_MAX_CKS = MAX_COMPS;
 
 // ------------------------------------------------------------------ k_checksum (generic)
 // ComponentChecksumPlugin::update (component_checksum.rs:67-108) for any registered spec,

@@ -35,7 +35,7 @@ extern "C" {
 #define GGRS_HIP_ABI_VERSION 8
 
 /* limits */
-#define GGRS_MAX_COMPONENTS 16
+#define GGRS_MAX_COMPONENTS 32
 #define GGRS_MAX_WORDS      16
 #define GGRS_MAX_CKS_UNITS  32
 #define GGRS_MAX_SYSTEMS    16

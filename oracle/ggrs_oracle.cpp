@@ -186,7 +186,7 @@ struct Ring {
 // ---------------------------------------------------------------------------
 // World model
 // ---------------------------------------------------------------------------
-enum { MAX_COMPS = 16, MAX_WORDS = 16, MAX_UNITS = 32, MAX_SYSTEMS = 16 };
+enum { MAX_COMPS = 32, MAX_WORDS = 16, MAX_UNITS = 32, MAX_SYSTEMS = 16 };
 
 enum SystemKind : uint32_t {
     SYS_PARTICLES_UPDATE = 1,   // examples/stress_tests/particles.rs:272-280

@@ -427,27 +427,28 @@ def test_lazy_live_block_is_off_where_the_live_world_holds_more_than_the_snapsho
 
 
 # ------------------------------------------------------------------------------------------------ the component limit
-@pytest.mark.parametrize("per_request,n", [(False, 5000), (True, 5000), (False, 300_000)])
-def test_sixteen_components_every_presence_mask_travels(per_request, n):
-    """GGRS_MAX_COMPONENTS components + the liveness mask are 17 masks of 16 words per 1024-slot tile = 272 words: the per-request copy kernel moved the
-    first 256 (one trip of its 256 threads), i.e. a SaveWorld / LoadWorld lost the LAST component's presence mask.  Both paths against the oracle, with
-    presence edits between the lists so that a LoadWorld has to bring the old masks back.  300 k: 16 checksummed components through the lane-fold rows and,
-    enqueued, the fold-forward role (17 values per Save and workgroup)."""
+@pytest.mark.parametrize("per_request,n,nc", [(False, 5000, 16), (True, 5000, 16), (False, 300_000, 16), (False, 5000, 32), (True, 5000, 32), (False, 300_000, 32)])
+def test_worlds_at_the_component_limit_every_presence_mask_travels(per_request, n, nc):
+    """16 components + the liveness mask are 17 masks of 16 words per 1024-slot tile = 272 words: the per-request copy kernel moved the first 256 (one trip of
+    its 256 threads), i.e. a SaveWorld / LoadWorld lost the LAST component's presence mask (the limit was 16 then; GGRS_MAX_COMPONENTS is 32 now: 33 masks).
+    Both paths against the oracle, with presence edits between the lists so that a LoadWorld has to bring the old masks back.  300 k: every component
+    checksummed through the wave fold and, enqueued, the fold-forward role (nc + 1 values per Save and workgroup)."""
     res = []
+    last = nc - 1
     for w in (bg.World(n, max_depth=4, flags=bg.GGRS_WORLD_NO_GROUPS if per_request else 0), OracleWorld(n, 4, FLAT)):
-        comps = [w.register_component(f"C{k}", 4, 1) for k in range(16)]
+        comps = [w.register_component(f"C{k}", 4, 1) for k in range(nc)]
         for c in comps: w.checksum_component(c, [0])
-        w.add_system(bg.SYS_ADD_U32, comp=(comps[15],), word=(0,), iparam=(3,))
+        w.add_system(bg.SYS_ADD_U32, comp=(comps[last],), word=(0,), iparam=(3,))
         w.add_system(bg.SYS_ADD_U32, comp=(comps[0],), word=(0,), iparam=(1,))
-        per = n // 16
-        for k in range(16):                                                     # batch k carries components k and (k + 5) % 16
-            a, b = comps[k], comps[(k + 5) % 16]
+        per = n // nc
+        for k in range(nc):                                                     # batch k carries components k and (k + 5) % nc
+            a, b = comps[k], comps[(k + 5) % nc]
             w.spawn(per, {a: [np.arange(per, dtype=np.uint32) + 100 * k], b: [np.full(per, 7 + k, dtype=np.uint32)]})
         w.set_depth(4)
         cs = []
         cs += w.handle_requests([bg.SaveGameState(0), bg.AdvanceFrame((0,)), bg.SaveGameState(1), bg.AdvanceFrame((0,))])
-        w.remove_component(comps[15], 15 * per + 3)                             # live edits after frame 1's snapshot
-        w.insert_component(comps[15], 2, np.array([41], dtype=np.uint32))
+        w.remove_component(comps[last], last * per + 3)                         # live edits after frame 1's snapshot
+        w.insert_component(comps[last], 2, np.array([41], dtype=np.uint32))
         cs += w.handle_requests([bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.SaveGameState(3), bg.AdvanceFrame((0,))])
         mid = cm.snapshot_state(w, comps)
         roll = [bg.LoadGameState(1), bg.AdvanceFrame((0,)), bg.SaveGameState(2), bg.AdvanceFrame((0,)), bg.SaveGameState(3), bg.AdvanceFrame((0,))]
@@ -460,5 +461,5 @@ def test_sixteen_components_every_presence_mask_travels(per_request, n):
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], "before the rollback")
     cm.assert_states_equal(res[0][2], res[1][2], "after the rollback")
-    assert res[0][1]["present15"][2] and not res[0][2]["present15"][2]           # the rollback took the inserted component away again
-    assert res[0][2]["present15"][15 * per + 3]                                  # ... and brought the removed one back
+    assert res[0][1][f"present{last}"][2] and not res[0][2][f"present{last}"][2]     # the rollback took the inserted component away again
+    assert res[0][2][f"present{last}"][last * per + 3]                               # ... and brought the removed one back
