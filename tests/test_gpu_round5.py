@@ -215,7 +215,7 @@ def _f16_world(w, strategy):
     return A, C_
 
 
-@pytest.mark.parametrize("n", [3000, 400_000])
+@pytest.mark.parametrize("n", [3000, 100_000])
 def test_strategy_f32x3_snapshotted_as_f16x3(n):
     """Accel.x holds multiples of 0.5 (exact in f16: store / load are a bijection there -> the session behaves as without the strategy);
     Accel.y drifts by a factor that is NOT representable in f16 (a lossy snapshot: every LoadWorld rounds it, and the SyncTest's resimulated
