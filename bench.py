@@ -416,12 +416,14 @@ def measure_single(bg, cm, torch, args, contig=False, light=False):
         run.collect()
         w.synchronize()
     m["preheat"] = {"ms": (time.perf_counter() - pre_t0) * 1e3, "ticks": pre_n, "requested_ms": args.preheat_ms, "specialised_kernel_ready": spec_ready}
-    torch.cuda.synchronize()
     m["frames_before_timed"] = w.frame
     rss0 = rss_mb()
     gpu_cs = []                                  # per timed tick: its D Checksum(u128)s, what cell.save() receives
     stamps = []
     take = (lambda out: None) if light else (lambda out: (gpu_cs.append(bytes(out)), stamps.append(time.perf_counter())))
+    # the synchronize that opens the timed region is the LAST thing before the clock starts (the bookkeeping above used to sit between the two: a few
+    # hundred microseconds of idle device, after which the first launch took 90-160 us instead of the kernel's 45: profiles/r05o)
+    torch.cuda.synchronize()
     if args.sync:
         t0 = time.perf_counter()
         for _ in range(K):

@@ -682,6 +682,9 @@ int ggrs_hip_collect_checksums(ggrs_world* w, uint64_t* checksums_out, uint32_t 
     w->pending.pop_front();
     // the batch's launches are done: its spawn payloads (and everything staged before them) are free again
     if (w->pending.empty()) stage_ring_reset(w); else if (stage_end) w->stage_tail = stage_end;
+    // Nothing is queued behind this batch and its results were seen through pinned memory: the runtime itself has not looked at the stream yet.  One
+    // non-blocking query lets it retire the finished commands now, so that a device-wide synchronise that follows finds an idle stream
+    if (w->pending.empty() && !w->prof) { (void)hipStreamQuery(w->stream); (void)hipGetLastError(); }
     if (w->tl.on) { w->tl.collect_us += tl_now_us() - t_in; ++w->tl.n_collect; }
     return GGRS_OK;
 }
