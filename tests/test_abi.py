@@ -246,3 +246,19 @@ def test_every_environment_knob_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     assert 8 <= len(names) <= 15, sorted(names)            # at most 15 environment knobs
     assert not [n for n in sorted(names) if n not in doc]
+
+
+def test_limits_agree_between_the_header_the_kernels_and_the_oracle():
+    """GGRS_MAX_* are spelled once in the header; the device code sizes its mask / checksum tables from the header's constant and the CPU oracle carries its own
+    copy of the limits (it links nothing of the product): the three must say the same, or a world at the limit is accepted by one side and refused by the other."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ggrs_hip.h")).read()
+    lim = {k: int(v) for k, v in re.findall(r"#define (GGRS_MAX_[A-Z_]+)\s+(\d+)", hdr)}
+    assert lim["GGRS_MAX_COMPONENTS"] == 32 and lim["GGRS_MAX_WORDS"] == 16 and lim["GGRS_MAX_PLAYERS"] == 16 and lim["GGRS_MAX_INPUT_BYTES"] == 16
+    ker = open(os.path.join(ROOT, "bevy_ggrs_amd", "csrc", "kernels.hpp")).read()
+    assert "constexpr int MAX_COMPS = GGRS_MAX_COMPONENTS;" in ker and "constexpr int MAX_MASKS = MAX_COMPS + 1;" in ker
+    assert "constexpr int MAX_CKS = MAX_COMPS;" in ker and "constexpr int GEN_MAX_CKS = MAX_COMPS;" in ker
+    assert not re.search(r"\b(off_present|n_units|unit_base)\[16\]", ker)
+    ora = open(os.path.join(ROOT, "oracle", "ggrs_oracle.cpp")).read()
+    m = re.search(r"enum \{ MAX_COMPS = (\d+), MAX_WORDS = (\d+), MAX_UNITS = (\d+), MAX_SYSTEMS = (\d+) \}", ora)
+    assert m and [int(x) for x in m.groups()] == [lim["GGRS_MAX_COMPONENTS"], lim["GGRS_MAX_WORDS"], lim["GGRS_MAX_CKS_UNITS"], lim["GGRS_MAX_SYSTEMS"]]
