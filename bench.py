@@ -259,6 +259,24 @@ def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_inp
     return out
 
 
+def oracle_checksum_at(n, depth, frame, confirmed_input, spawn_rate=0):
+    """Checksum(u128) of SaveWorld at `frame` of ONE oracle world that simulated the confirmed inputs frame by frame from the synthetic start (what an adopted
+    branch state must equal)."""
+    from oracle.binding import FLAT, OracleWorld, lib
+    import common as cm
+    lib.gor_set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    o = OracleWorld(n + (2 * spawn_rate * (depth + 2) if spawn_rate else 0), depth + 1, FLAT)
+    ids = cm.build_particles(o, with_spawn=bool(spawn_rate))
+    vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+    cm.spawn_particles(o, ids, n, vel, ttl)
+    for f in range(frame):
+        o.advance((confirmed_input(f),))
+    o.set_depth(2)
+    cs = o.save()
+    lib.gor_set_num_threads(1)
+    return cs
+
+
 def latency_floor(kernel_us, launches_per_tick, tick_us):
     """Small worlds (the whole ring lives in L2 / the Infinity Cache) are bound by launch latency, not by HBM: a tick cannot be shorter than
     its kernels plus one dependent same-stream boundary per launch -- 1.45 us between trivial kernels, 1.7-1.9 us between real streaming
@@ -902,14 +920,21 @@ def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
     native = RcclFanout(w, rank, world_size, box[0])
     c_rank, comm_size, c_dev = native.comm_info()        # what the communicator says, not what the environment says
     assert c_rank == rank and c_dev == dev, (c_rank, rank, c_dev, dev)
-    fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2,
+    from bevy_ggrs_amd.fanout import default_branch_input
+    bi = default_branch_input
+    if os.environ.get("BENCH_BRANCH_INPUT_ZERO") == "1":                 # DIAGNOSTIC: no branch ever holds the spawn key (isolates what the spawn system's presence in the kernel costs)
+        bi = lambda b, f: 0
+        bi.frame_invariant = True
+    fan = SpeculativeFanout(w, dist, depth=D, exchange=None, native=native, branches_per_rank=args.branches, max_inflight=2, branch_input=bi,
                             desync_detection_interval=10 if args.branches == 1 else 1,   # the reference stress_test's default (particles.rs:49, README.md:84)
-                            share_prefix=not args.no_share_prefix, spawn_fn=cm.frame_spawn_fn(spawn_rate) if spawn_rate else None)
+                            share_prefix=not args.no_share_prefix, spawn_fn=cm.frame_spawn_fn(spawn_rate) if spawn_rate else None,
+                            retain=getattr(args, "retain", "none"), compact=not getattr(args, "no_compact", False))
     fan.sync_confirmed(0)
     gc.collect(); gc.disable()                           # see measure_single
-    for _ in range(W):
+    for _ in range(max(W, 18)):                          # (the 16th step of a shape starts the build of the kernel specialised for it)
         fan.step_pipelined(want_result=False)
     fan.drain(want_result=False)
+    if not args.no_specialise_wait: w.specialise_wait()
     # pre-heat: EVERY rank must run the same number of steps -- the all-gathers pair up by order (round 4 found the bug a clock-based loop makes)
     pre_t0 = time.perf_counter(); pre_n = 0
     if args.preheat_ms > 0:
@@ -958,6 +983,20 @@ def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
     prof_bytes = w.profile_bytes()
     w.profile_enable(False)
     info = w.kernel_info()
+    # ---- adoption (--retain): the true inputs of the next D - 1 frames turn out to be what branch 0 predicted (all zero, like the confirmed inputs of this
+    # bench): its retained state becomes the world on every rank -- a ring-slot swap on rank 0, a re-simulation (or nothing, at world size 1) elsewhere --, and
+    # the world's next SaveWorld must give the checksum the oracle computes for that frame by simulating it in a straight line
+    adopt = None
+    if fan.retain:
+        t_a = time.perf_counter()
+        c_before = fan.confirmed
+        k_adopt = D - 1 if fan.retain == 4 else D
+        fan.adopt(0, k_adopt)
+        w.synchronize()
+        adopt_ms = (time.perf_counter() - t_a) * 1e3
+        cs_after = w.save()
+        adopt = {"branch": 0, "from_frame": c_before, "frames_ahead": k_adopt, "frame": fan.confirmed, "ms": round(adopt_ms, 3), "checksum_lo": cs_after & 0xFFFFFFFFFFFFFFFF,
+                 "world_frame": w.frame, "mode": "ring-slot swap on the owning rank, re-simulation with the confirmed inputs on the others"}
     value = total_entities * (D + 1) * K / secs
     tick_ms, tick_n = prof["tick"]
     avg_s = tick_ms / max(tick_n, 1) * 1e-3
@@ -984,6 +1023,11 @@ def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
                      "launches_per_step": tick_n / max(min(K, 20), 1), "algorithmic_bytes_per_launch": bytes_per_launch},
         "xgmi_expected": xgmi,
     }
+    if fan.retain:
+        line["config"]["retain"] = {2: "newest", 4: "all"}[fan.retain]
+        line["config"]["workload"] += f"; every branch's frames are KEPT in private state blocks ({'all ' + str(D) if fan.retain == 4 else 'the newest'} per branch, row versions apply)"
+        line["roofline"]["note"] = ("retained branch states: the launch's algorithmic bytes are the source snapshot read once per branch + every retained frame's hot rows stored "
+                                    "(ggrs_hip_profile_read_bytes); next to roofline_alu, which prices the same launch's hashing")
     if args.branches > 1:
         # checksum-only branches (dead-snapshot elimination): integer-multiply bound, not HBM bound.  Roofline = SeaHash `diffuse`
         # per second against the chip's measured ceiling (scripts/ubench_alu.hip -> profiles/alu_ceiling.json).
@@ -1002,9 +1046,15 @@ def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
             base, _ = cpu_baseline_and_parity(n, D, args.cpu_ticks, D + 1, [], 0)
             line["cpu_baseline"] = base
         from bevy_ggrs_amd.fanout import default_branch_input
-        par = fanout_parity(n, D, c_timed, raw, comm_size, args.branches, default_branch_input, lambda f: 0,
+        par = fanout_parity(n, D, c_timed, raw, comm_size, args.branches, bi, lambda f: 0,
                             threads=max(1, min(64, os.cpu_count() or 1)), spawn_rate=100 if args.spawn else 0)
         par["cross_rank_confirmed_frames_agree"] = True     # SpeculativeFanout raises DesyncDetected otherwise (every step, every rank)
+        if adopt is not None:
+            want = oracle_checksum_at(n, D, adopt["frame"], lambda f: 0, spawn_rate=100 if args.spawn else 0)
+            adopt["equal_to_oracle_straight_line"] = bool(want == cs_after and adopt["world_frame"] == adopt["frame"])
+            adopt["oracle_checksum_lo"] = want & 0xFFFFFFFFFFFFFFFF
+            par["adopt"] = adopt
+            if not adopt["equal_to_oracle_straight_line"]: par["equal"] = False
         line["parity"] = par
         parity_failed = par["equal"] is not True
     elif rank == 0:
@@ -1080,6 +1130,7 @@ def extra_configs(bg, cm, torch, base_args, dev, budget_s=60.0):
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 90))
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
             guard("config5_1gpu", lambda: fanout_line(bg, cm, torch, mk(entities=100_000, branches=256, steps=10, warmup=2, parity_steps=1, spawn=False, fanout=True), dist, 0, 1, dev, f"cuda:{dev}"))
+            guard("config5_retain", lambda: fanout_line(bg, cm, torch, mk(entities=100_000, branches=256, steps=10, warmup=2, parity_steps=1, spawn=False, fanout=True, retain="all"), dist, 0, 1, dev, f"cuda:{dev}"))
             guard("config5_spawn", lambda: fanout_line(bg, cm, torch, mk(entities=100_000, branches=256, steps=6, warmup=2, parity_steps=1, spawn=True, fanout=True, preheat_ms=0.0), dist, 0, 1, dev, f"cuda:{dev}"))
         except Exception as e:              # noqa: BLE001
             out.setdefault("config5_1gpu", {"error": f"{type(e).__name__}: {e}"[:300]})
@@ -1115,6 +1166,9 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="fan-out: register the stress_test's spawn system (100 particles per frame while INPUT_SPAWN is held): the "
                     "branches whose predicted input byte carries the bit diverge from the others (SURVEY 8d's wording of config 5).  The spawn runs INSIDE the branch's "
                     "request group (fused), and identical spawning branches -- same frames, same staged payload -- still ride in one launch")
+    ap.add_argument("--retain", choices=["none", "newest", "all"], default="none", help="fan-out: keep the branches' frames in private state blocks (GGRS_BRANCH_RETAIN_*) so that a "
+                    "matching branch can be ADOPTED when the true input arrives (SURVEY 8e); after the timed region the bench adopts one and checks the adopted world against the oracle")
+    ap.add_argument("--no-compact", action="store_true", help="fan-out A/B: hand the library the step as a request list (rounds 3-5) instead of ggrs_hip_fanout_step_branches")
     ap.add_argument("--no-share-prefix", action="store_true", help="fan-out A/B: every branch replays [Load(C), Advance(confirmed input), Save(C+1)] itself "
                     "(the round-3 request lists) instead of starting from the ONE saved C+1")
     ap.add_argument("--parity-steps", type=int, default=-1, help="N > 1 / --fanout: timed steps whose gathered checksum table rank 0 replays on the CPU oracle "

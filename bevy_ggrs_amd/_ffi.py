@@ -80,6 +80,19 @@ class Request(C.Structure):
                 ("spawn_vy", C.POINTER(C.c_float)), ("spawn_payload", C.c_void_p), ("spawn_payload_bytes", C.c_uint64)]
 
 
+class BranchSpawn(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("vx", C.c_void_p), ("vy", C.c_void_p), ("payload", C.c_void_p), ("payload_bytes", C.c_uint64)]
+
+
+class BranchStep(C.Structure):
+    _fields_ = [("prefix", C.POINTER(Request)), ("n_prefix", C.c_uint32), ("n_branches", C.c_uint32), ("n_frames", C.c_uint32), ("n_inputs", C.c_uint32),
+                ("flags", C.c_uint32), ("n_spawn_table", C.c_uint32), ("inputs", C.c_void_p), ("status", C.c_void_p),
+                ("spawn_table", C.POINTER(BranchSpawn)), ("spawn_sel", C.c_void_p)]
+
+
+BRANCH_SAVE_LAST, BRANCH_RETAIN_NEWEST, BRANCH_RETAIN_ALL = 1, 2, 4
+ADOPT_RECOMPUTE, ADOPT_BROADCAST = 0, 1
+
 KERNEL_FORM_TILES, KERNEL_FORM_STEADY = 1, 3
 
 # every symbol include/ggrs_hip.h declares: name -> (restype, argtypes)
@@ -148,6 +161,8 @@ SIGNATURES = {
     "ggrs_hip_fanout_destroy": (None, [_P]),
     "ggrs_hip_fanout_last_error": (C.c_char_p, [_P]),
     "ggrs_hip_fanout_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ggrs_hip_fanout_step_branches": (C.c_int, [_P, C.POINTER(BranchStep), C.POINTER(C.c_uint32)]),
+    "ggrs_hip_fanout_adopt": (C.c_int, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(Request), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "ggrs_hip_profile_enable": (C.c_int, [_P, C.c_int]),
     "ggrs_hip_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ggrs_hip_profile_read_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

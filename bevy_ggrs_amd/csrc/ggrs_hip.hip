@@ -123,6 +123,8 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     jit_release(w->jit_entry);
     delete w->jl; w->jl = nullptr;
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
+    if (w->d_branch_parts) (void)hipFree(w->d_branch_parts);
+    for (void* p : w->spec_allocs) (void)hipFree(p);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->h_rows) (void)hipHostFree(w->h_rows);
@@ -586,16 +588,20 @@ int ggrs_hip_handle_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n
 // fetched later, oldest batch first.  ggrs reads a SaveGameState cell no earlier than the next
 // advance_frame(), so a host shim collects right before that call and the GPU tick overlaps the rest of
 // the host's frame instead of blocking it.
-int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
+// bs != nullptr: a branch step (ggrs_hip_fanout_step_branches) -- `reqs` is its prefix, the branches' launch and Checksum(u128)s follow in the same batch
+static int enqueue_impl(ggrs_world* w, const ggrs_request* reqs, uint32_t n, const ggrs_branch_step* bs, BranchKeep* keep, uint32_t* n_saves_out) {
     if (!w || (!reqs && n)) return GGRS_E_INVALID;
     TraceRange tr("HandleRequests");
     DeviceGuard dg(w);
     int rc = seal(w); if (rc) return rc;
     const double t_in = w->tl.on ? tl_now_us() : 0;
     rc = validate_requests(w, reqs, n); if (rc) return rc;
+    if (bs) { rc = validate_branch_step(w, *bs); if (rc) return rc; }
     if (w->tl.on) w->tl.validate_us += tl_now_us() - t_in;
     uint32_t n_save = 0;
     for (uint32_t i = 0; i < n; ++i) n_save += reqs[i].kind == GGRS_REQ_SAVE;
+    const uint32_t n_save_prefix = n_save;
+    if (bs) n_save += bs->n_branches * ((bs->flags & GGRS_BRANCH_SAVE_LAST) ? bs->n_frames : bs->n_frames - 1);
     if (n_save > w->max_results / 4 || w->pending_results + n_save > w->max_results / 2 || w->pending.size() >= 16)
         return w->fail(GGRS_E_INVALID, "too many uncollected checksums (%u pending + %u new): call ggrs_hip_collect_checksums", w->pending_results, n_save);
     ggrs_world::PendingBatch b;
@@ -606,9 +612,11 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     if (w->event_pool.empty()) { hipEvent_t e; HIPCHK(w, hipEventCreateWithFlags(&e, hipEventDisableTiming)); w->event_pool.push_back(e); }
     b.ev = w->event_pool.back(); w->event_pool.pop_back();
     w->batch_ev_attached = false;
+    if (w->dev_results_dst) w->dev_results_first = b.first;          // the consumer's device copy starts with this batch's first Checksum(u128)
     if (GroupRunner run = group_runner(w)) {
         w->batch_ev = b.ev;
         rc = run(w, reqs, n, nullptr, b.first, false, nullptr);
+        if (rc == GGRS_OK && bs) rc = run_branch_step(w, *bs, b.first + n_save_prefix, keep);
         w->batch_ev = nullptr;
         if (rc) {
             w->event_pool.push_back(b.ev); (void)hipStreamSynchronize(w->stream);
@@ -642,6 +650,7 @@ int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t 
     if (w->tl.on) { w->tl.enqueue_us += tl_now_us() - t_in; ++w->tl.n_enqueue; }
     return GGRS_OK;
 }
+int ggrs_hip_enqueue_requests(ggrs_world* w, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) { return enqueue_impl(w, reqs, n, nullptr, nullptr, n_saves_out); }
 // the batch's event, waited for by polling (hipEventQuery returns in 0.06 us; hipEventSynchronize on an event that is NOT complete yet costs
 // 0.7 us more per tick of a 5.6 us kernel: scripts/ubench_launch, profiles/r05a) for up to GGRS_SPIN_WAIT_US, then by the runtime's wait
 static int wait_batch_event(ggrs_world* w, hipEvent_t ev) {

@@ -74,6 +74,8 @@ struct ggrs_fanout {
     // another shape is refused before anything is enqueued, a rank that ran fewer steps shows up in the tags (collect: "ranks are out of step")
     bool shape_agreed = false; uint32_t agreed_saves = 0;
     bool owns_results_flag = false;      // this object switched its world to device-side folds (ggrs_world::device_results_only)
+    BranchKeep keep;                     // what the last ggrs_hip_fanout_step_branches retained (ggrs_hip_fanout_adopt's input); invalid after any other step
+    uint32_t last_branches = 0;          // branches per rank of that step: global branch index = rank x last_branches + local index
     std::string err;
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -90,12 +92,16 @@ namespace {
 // slot being filled; every rank sees the whole table, so every rank fails the same way when they differ
 int fanout_agree_shape(ggrs_fanout* f, uint32_t saves) {
     ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
-    if ((uint64_t)f->interval * saves > f->cap_u128) return f->fail(GGRS_E_INVALID, "%u steps x %u checksums per rank in one all-gather (at most %u)", f->interval, saves, f->cap_u128);
+    // (every rank enters the collective whatever its own numbers are -- a rank that bailed out here would leave the others waiting in it for ever -- and every
+    // rank judges the WHOLE table afterwards, so they all fail the same way)
     s.h_tags[0] = f->interval; s.h_tags[1] = saves;
     FANCHK_HIP(f, hipMemcpyAsync(s.d_send, s.h_tags, 16, hipMemcpyHostToDevice, f->comm_stream));
     FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, 2, ncclUint64, f->comm, f->comm_stream));
     FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, (size_t)16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
     FANCHK_HIP(f, hipStreamSynchronize(f->comm_stream));
+    for (int r = 0; r < f->size; ++r)
+        if (s.h_recv[2 * r] * s.h_recv[2 * r + 1] > f->cap_u128)
+            return f->fail(GGRS_E_INVALID, "%llu steps x %llu checksums per rank in one all-gather on rank %d (at most %u)", (unsigned long long)s.h_recv[2 * r], (unsigned long long)s.h_recv[2 * r + 1], r, f->cap_u128);
     for (int r = 0; r < f->size; ++r)
         if (s.h_recv[2 * r] != f->interval || s.h_recv[2 * r + 1] != saves)
             return f->fail(GGRS_E_INVALID, "ranks disagree on the shape of an all-gather group: %u steps x %u saves on rank %d, %llu steps x %llu saves on rank %d "
@@ -112,22 +118,23 @@ int fanout_close_slot(ggrs_fanout* f) {
     const size_t n = (size_t)s.n_steps * s.n_saves;
     const size_t n_full = (size_t)f->interval * f->agreed_saves;             // checksums per rank of a full group: the fixed layout of every all-gather
     ggrs_world* w = f->w;
-    // everything of the group happens here, once per `interval` steps and on the side stream: wait for the group's last
-    // tick, pinned result ring -> device (consecutive steps sit in consecutive ring slots unless the ring wrapped),
-    // all-gather, device -> pinned.  A step itself adds nothing to the world's stream.
+    // everything of the group happens here, once per `interval` steps and on the side stream.  What does not depend on the kernels goes first: the steps' tags
+    // ride behind the checksums (one small pinned -> device copy per group), a partial group (the closing one) is padded with zeros.  Then the wait for the
+    // group's last tick.  The Checksum(u128)s themselves are ALREADY in the send buffer -- k_gen_finalize wrote its second copy there (ggrs_world::dev_results_dst)
+    // -- so between the last kernel and the collective there is no copy at all; a world without the generated kernel (its folds write the pinned ring only) still
+    // takes the pinned -> device hop (consecutive steps sit in consecutive ring slots unless the ring wrapped).  A step itself adds nothing to the world's stream.
+    const size_t per_rank = n_full + f->interval;
+    for (uint32_t k = s.n_steps; k < f->interval; ++k) { s.h_tags[2 * k] = 0; s.h_tags[2 * k + 1] = 0; }
+    if (n < n_full) FANCHK_HIP(f, hipMemsetAsync(s.d_send + n * 2, 0, (n_full - n) * 16, f->comm_stream));
+    FANCHK_HIP(f, hipMemcpyAsync(s.d_send + n_full * 2, s.h_tags, (size_t)f->interval * 16, hipMemcpyHostToDevice, f->comm_stream));
     FANCHK_HIP(f, hipEventRecord(s.ready, w->stream));
     FANCHK_HIP(f, hipStreamWaitEvent(f->comm_stream, s.ready, 0));
-    for (uint32_t k = 0; k < s.n_steps && s.n_saves; ) {
+    for (uint32_t k = 0; k < s.n_steps && s.n_saves && !w->gen_ok; ) {
         uint32_t run = 1;
         while (k + run < s.n_steps && s.first[k + run] == s.first[k] + run * s.n_saves) ++run;
         FANCHK_HIP(f, hipMemcpyAsync(s.d_send + (size_t)k * s.n_saves * 2, w->h_results + 2 * (size_t)s.first[k], (size_t)run * s.n_saves * 16, hipMemcpyHostToDevice, f->comm_stream));
         k += run;
     }
-    // the steps' tags ride behind the checksums (one small pinned -> device copy per group); a partial group (the closing one) is padded with zeros
-    const size_t per_rank = n_full + f->interval;
-    for (uint32_t k = s.n_steps; k < f->interval; ++k) { s.h_tags[2 * k] = 0; s.h_tags[2 * k + 1] = 0; }
-    if (n < n_full) FANCHK_HIP(f, hipMemsetAsync(s.d_send + n * 2, 0, (n_full - n) * 16, f->comm_stream));
-    FANCHK_HIP(f, hipMemcpyAsync(s.d_send + n_full * 2, s.h_tags, (size_t)f->interval * 16, hipMemcpyHostToDevice, f->comm_stream));
     FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, per_rank * 2, ncclUint64, f->comm, f->comm_stream));
     FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, per_rank * 16 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
     FANCHK_HIP(f, hipEventRecord(s.done, f->comm_stream));
@@ -240,7 +247,7 @@ int ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root) {
     return GGRS_OK;
 }
 
-int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) {
+static int fanout_step_impl(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, const ggrs_branch_step* bs, uint32_t* n_saves_out) {
     if (!f || !f->w || (!reqs && n)) return GGRS_E_INVALID;
     ggrs_world* w = f->w;
     DeviceGuard dg(w);
@@ -251,12 +258,21 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
     // would shift every later collect by one
     uint32_t want = 0;
     for (uint32_t i = 0; i < n; ++i) want += reqs[i].kind == GGRS_REQ_SAVE;
+    if (bs) {
+        if (bs->n_branches == 0 || bs->n_branches > BRANCH_MAX || bs->n_frames == 0 || bs->n_frames > (uint32_t)MAX_TICK_STEPS) return f->fail(GGRS_E_INVALID, "a branch step holds 1..%u branches of 1..%d frames", BRANCH_MAX, MAX_TICK_STEPS);
+        want += bs->n_branches * ((bs->flags & GGRS_BRANCH_SAVE_LAST) ? bs->n_frames : bs->n_frames - 1);
+    }
+    f->keep.valid = false;                                              // whatever an earlier step retained is about to be overwritten (or is history)
     if (!f->shape_agreed) { const int arc = fanout_agree_shape(f, want); if (arc) return arc; }
     if (want != f->agreed_saves) return f->fail(GGRS_E_INVALID, "every step of this fan-out holds %u SaveGameState requests (agreed by all ranks at the first step); this list has %u -- "
                                                               "ggrs_hip_fanout_set_interval starts a new agreement", f->agreed_saves, want);
     uint32_t ns = 0;
-    int rc = ggrs_hip_enqueue_requests(w, reqs, n, &ns);
+    // the device copy of this step's Checksum(u128)s lands where the all-gather sends from
+    if (w->gen_ok) w->dev_results_dst = s.d_send + 2 * (size_t)s.n_steps * f->agreed_saves;
+    int rc = enqueue_impl(w, reqs, n, bs, bs ? &f->keep : nullptr, &ns);
+    w->dev_results_dst = nullptr;
     if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    if (bs) f->last_branches = bs->n_branches;
     s.n_saves = ns;
     s.first[s.n_steps] = w->pending.back().first;        // where the kernels write this step's checksums (pinned result ring)
     s.h_tags[2 * s.n_steps] = n ? (uint64_t)(uint32_t)reqs[0].frame | ((uint64_t)reqs[0].kind << 32) : 0;   // (slot not closed: the side stream does not read h_tags yet)
@@ -264,6 +280,84 @@ int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, u
     ++s.n_steps;
     if (n_saves_out) *n_saves_out = ns;
     if (s.n_steps >= f->interval) return fanout_close_slot(f);
+    return GGRS_OK;
+}
+int ggrs_hip_fanout_step(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, uint32_t* n_saves_out) { return fanout_step_impl(f, reqs, n, nullptr, n_saves_out); }
+int ggrs_hip_fanout_step_branches(ggrs_fanout* f, const ggrs_branch_step* step, uint32_t* n_saves_out) {
+    if (!f || !step || (!step->prefix && step->n_prefix)) return GGRS_E_INVALID;
+    return fanout_step_impl(f, step->prefix, step->n_prefix, step, n_saves_out);
+}
+
+// The true inputs matched what `branch` predicted up to `frame`: its retained state becomes the world (include/ggrs_hip.h).  Collective.
+int ggrs_hip_fanout_adopt(ggrs_fanout* f, uint32_t branch, int32_t frame, uint32_t mode, const ggrs_request* replay, uint32_t n_replay, uint64_t* checksums_out, uint32_t* n_checksums_out) {
+    if (!f || !f->w || (mode != GGRS_ADOPT_RECOMPUTE && mode != GGRS_ADOPT_BROADCAST) || (!replay && n_replay)) return GGRS_E_INVALID;
+    ggrs_world* w = f->w;
+    DeviceGuard dg(w);
+    if (n_checksums_out) *n_checksums_out = 0;
+    if (f->head != f->tail || f->slot[f->tail % FANOUT_MAX_INFLIGHT].n_steps || !w->pending.empty())
+        return f->fail(GGRS_E_INVALID, "adopt while steps are in flight: collect them first");
+    if (!f->last_branches) return f->fail(GGRS_E_INVALID, "adopt without a preceding ggrs_hip_fanout_step_branches");
+    if (branch >= f->last_branches * (uint32_t)f->size) return f->fail(GGRS_E_INVALID, "branch %u of %u x %d", branch, f->last_branches, f->size);
+    const int owner = (int)(branch / f->last_branches);
+    const uint32_t local = branch % f->last_branches;
+    const bool mine = owner == f->rank;
+    const int32_t F = w->frame;                                        // where the last step's prefix left every rank
+    // ---- the owner: its retained block trades places with the ring slot a SaveGameState(frame) would have filled
+    int spec_idx = -1;
+    if (mine) {
+        const BranchKeep& k = f->keep;
+        const int64_t o = (int64_t)frame - (int64_t)k.base_frame - 1;
+        if (!k.valid || k.base_frame != F || o < 0 || o >= (int64_t)k.n_out || local >= k.n_branches || k.blk[(size_t)local * k.n_out + (size_t)o] < 0)
+            return f->fail(GGRS_E_NO_SNAPSHOT, "branch %u holds no retained state of frame %d (the last branch step started at frame %d and %s)", branch, frame, k.base_frame,
+                           k.valid ? "kept other frames: GGRS_BRANCH_RETAIN_ALL keeps every one" : "kept none: GGRS_BRANCH_RETAIN_*");
+        spec_idx = k.blk[(size_t)local * k.n_out + (size_t)o];
+    }
+    if (mine || mode == GGRS_ADOPT_BROADCAST) {
+        // RollbackFrameCount = frame; discard_old_snapshots + GgrsSnapshots::push(frame) (mod.rs:147-202) over slot indices -- the slot's block is then the branch's
+        w->frame = frame; w->has_confirmed = true; w->confirmed = frame;
+        ring_confirm(w, w->confirmed);
+        int sl = -1;
+        int rc = ring_push(w, frame, &sl); if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+        if (sl < 0) return f->fail(GGRS_E_INVALID, "adopt needs a ring depth of at least 1");
+        Block& slot = w->slots[sl];
+        if (mine) std::swap(slot, w->spec_blocks[spec_idx]);
+        if (mode == GGRS_ADOPT_BROADCAST && f->size > 1) {
+            // the block describes itself: {len, frame, .., extent of its mask bits} in its header
+            Header h; memset(&h, 0, sizeof h);
+            if (mine) { h.len = slot.len; h.frame = frame; h.active = slot.dirty_len; FANCHK_HIP(f, hipMemcpyAsync(slot.ptr, &h, sizeof h, hipMemcpyHostToDevice, w->stream)); }
+            FANCHK_NCCL(f, rccl().Broadcast(slot.ptr, slot.ptr, (size_t)w->state_bytes, ncclUint8, owner, f->comm, w->stream));
+            if (!mine) {
+                FANCHK_HIP(f, hipMemcpyAsync(&h, slot.ptr, sizeof h, hipMemcpyDeviceToHost, w->stream));
+                FANCHK_HIP(f, hipStreamSynchronize(w->stream));
+                if (h.len > w->capacity || h.frame != frame) return f->fail(GGRS_E_INVALID, "the broadcast block says frame %d, len %llu (expected frame %d, capacity %llu)", h.frame, (unsigned long long)h.len, frame, (unsigned long long)w->capacity);
+                slot.len = h.len; slot.dirty_len = std::min<uint64_t>(std::max<uint64_t>(h.active, h.len), w->cap_pad);
+                for (uint32_t c = 0; c < slot.ver.size(); ++c) slot.ver[c] = ++w->ver_counter;      // bytes from another rank: every column is new
+            }
+        }
+        // LoadWorld from that slot (schedule_systems.rs:238-250): the live world IS the adopted state
+        ggrs_request ld; memset(&ld, 0, sizeof ld); ld.kind = GGRS_REQ_LOAD; ld.frame = frame;
+        rc = ggrs_hip_enqueue_requests(w, &ld, 1, nullptr);
+        if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+        uint32_t got = 0;
+        rc = ggrs_hip_collect_checksums(w, nullptr, 0, &got);
+        if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    } else {
+        // the other ranks re-simulate F -> frame with the confirmed inputs: no bytes cross xGMI, and the checksums are a desync check for free
+        uint32_t ns = 0;
+        for (uint32_t i = 0; i < n_replay; ++i) ns += replay[i].kind == GGRS_REQ_SAVE;
+        if (ns && !checksums_out) return f->fail(GGRS_E_INVALID, "replay holds %u SaveGameState requests but checksums_out is NULL", ns);
+        int rc = ggrs_hip_enqueue_requests(w, replay, n_replay, nullptr);
+        if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+        uint32_t got = 0;
+        rc = ggrs_hip_collect_checksums(w, checksums_out, ns, &got);
+        if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+        if (n_checksums_out) *n_checksums_out = got;
+        if (w->frame != frame || !ggrs_hip_has_snapshot(w, frame))
+            return f->fail(GGRS_E_INVALID, "replay left the world at frame %d %s a snapshot of frame %d: it must re-simulate %d -> %d and end with SaveGameState(%d)", w->frame,
+                           ggrs_hip_has_snapshot(w, frame) ? "with" : "without", frame, F, frame, frame);
+        w->has_confirmed = true; w->confirmed = frame;
+    }
+    f->keep.valid = false;                                              // the speculation is history now
     return GGRS_OK;
 }
 

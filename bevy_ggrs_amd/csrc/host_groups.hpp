@@ -214,11 +214,13 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
 // jit_specialise); nullptr: use the generic kernel.  Plain launches of every size qualify (depth-parallel roles are part of the shape); batches of
 // checksum-only branches and groups with an eliminated Save do not.  Shapes are counted one by one (host_world.hpp JitSpecSlot): a SyncTest
 // session has one, a P2P session one per rollback length; the row masks right after a spawn make a few more that never reach the threshold.
-hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j) {
+// members: the launch carries batch members with records (run_branch_step) -- where a Save lands and which rows it moves are per member, so only the op sequence,
+// the load mask and the store policies are literals of that copy.
+hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j, bool members = false) {
     if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.n_saves || !j.n_ops) return nullptr;
-    for (uint32_t k = 0; k < j.n_saves; ++k)
+    for (uint32_t k = 0; k < j.n_saves && !members; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
-    JitSig g; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
+    JitSig g; g.members = members ? 1u : 0u; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
     g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s; g.nt_loads = j.nt_loads;
     auto building = [](const JitSpecSlot& s) { return s.spec && s.spec->state.load(std::memory_order_acquire) == 1; };
     JitSpecSlot* s = nullptr;
@@ -256,11 +258,13 @@ inline ggrs_world::HostFold make_host_fold(const GgrsJitArgs& j, uint32_t res_sl
     for (uint32_t k = 0; k < j.n_saves && k < (uint32_t)MAX_TICK_SAVES; ++k) f.save_len[k] = j.save_len[k];
     return f;
 }
-inline GenFinArgs make_gen_fin(const GgrsJitArgs& j, uint32_t rows, uint32_t n_cks, uint64_t* out) {
+// res: the result slot of the group's first Save -- the pinned ring's cell and, when a consumer asked for one (ggrs_world::dev_results_dst), the device copy's
+inline GenFinArgs make_gen_fin(const ggrs_world* w, const GgrsJitArgs& j, uint32_t rows, uint32_t n_cks, uint32_t res) {
     GenFinArgs f; memset(&f, 0, sizeof f);
     f.parts = reinterpret_cast<uint64_t*>(j.parts); f.part_stride = j.part_stride; f.n_parts = rows; f.n_cks = n_cks; f.n_saves = std::max(1u, j.n_saves);
     for (uint32_t k = 0; k < j.n_saves && k < (uint32_t)MAX_TICK_SAVES; ++k) f.save_len[k] = j.save_len[k];
-    f.out = out;
+    f.out = w->d_results + 2 * (uint64_t)res;
+    if (w->dev_results_dst && res >= w->dev_results_first) f.out2 = w->dev_results_dst + 2 * (uint64_t)(res - w->dev_results_first);
     return f;
 }
 
@@ -309,7 +313,7 @@ struct JitBatch {
                                          rows_bytes_per_slot(w, j.load_rows, !j.src_is_live) * j.len * k); if (lrc) return lrc; }
         }
         if (host_fold) { w->folds.push_back(make_host_fold(j, res_first, g, n_cks, k, rows_off)); return GGRS_OK; }
-        GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)res_first);   // one row per workgroup
+        GenFinArgs f = make_gen_fin(w, j, g, n_cks, res_first);   // one row per workgroup
         arm_spin(w, f, j.n_saves * k, blocking);
         {
             ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
@@ -561,7 +565,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 ns += j.n_saves;
             } else if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, g, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {
-                GenFinArgs f = make_gen_fin(j, g, n_cks, w->d_results + 2 * (uint64_t)(res_base + ns));   // one row per workgroup
+                GenFinArgs f = make_gen_fin(w, j, g, n_cks, res_base + ns);   // one row per workgroup
                 arm_spin(w, f, j.n_saves, wait);
                 {
                     ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
@@ -588,6 +592,231 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
     if (n_saves_out) *n_saves_out = ns;
     if (!wait) return GGRS_OK;
     return read_back(w, ns, checksums_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BRANCH STEPS (ggrs_hip_fanout_step_branches).  B speculative branches off ONE snapshot, each  (AdvanceFrame, SaveGameState) x n_frames  with its own
+// PlayerInputs and spawns, in ONE launch of the generated kernel: gridDim.z = B, member z's differences in a record in device memory (kernel_gen.hpp
+// JitLayout::Member).  Branches are speculation, not history: nothing here touches the ring, the frame counters or the live block.  What a branch produces is its
+// Checksum(u128)s and -- when asked to be kept -- its frames in blocks of their own (ggrs_world::spec_blocks), under row versions like every other block.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BranchKeep {          // what the last branch step retained: output o of branch b (frame base_frame + 1 + o) lives in spec_blocks[blk[b * n_out + o]] (-1: not kept)
+    bool valid = false; uint32_t n_branches = 0, n_out = 0, n_frames = 0; int32_t base_frame = 0;
+    std::vector<int> blk;
+};
+constexpr uint32_t BRANCH_MAX = 4096;
+// spec_blocks[0 .. n): allocated in chunks, header + masks zeroed (the invariant every block keeps: mask words beyond its dirty_len are zero)
+int spec_blocks_reserve(ggrs_world* w, size_t n) {
+    const uint64_t head = ALIGN + (uint64_t)w->plan.n_masks * align_up(w->cap_pad / 8, ALIGN);
+    while (w->spec_blocks.size() < n) {
+        const size_t want = n - w->spec_blocks.size();
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(want, (1ull << 30) / std::max<uint64_t>(w->state_bytes, 1)));
+        uint8_t* p = nullptr;
+        if (hipMalloc((void**)&p, chunk * w->state_bytes) != hipSuccess) { (void)hipGetLastError(); return w->fail(GGRS_E_HIP, "hipMalloc of %zu branch state blocks (%llu bytes each) failed", chunk, (unsigned long long)w->state_bytes); }
+        w->spec_allocs.push_back(p);
+        for (size_t k = 0; k < chunk; ++k) {
+            Block b; b.ptr = p + k * w->state_bytes; b.ver.assign(w->cur_ver.size(), VER_NONE);
+            if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(b.ptr, 0xA5, w->state_bytes, w->stream));
+            HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
+            w->spec_blocks.push_back(std::move(b));
+        }
+    }
+    return GGRS_OK;
+}
+// everything that can be checked before the prefix runs
+int validate_branch_step(ggrs_world* w, const ggrs_branch_step& st) {
+    if (!w->gen_ok) return w->fail(GGRS_E_INVALID, "branch steps need the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
+    if (w->jit_marks || w->has_nr || w->marks_possible) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds with live-only state (RollbackDespawned markers, non-rollback components): use ggrs_hip_fanout_step");
+    if (st.n_branches == 0 || st.n_branches > BRANCH_MAX) return w->fail(GGRS_E_INVALID, "a branch step holds 1..%u branches, not %u", BRANCH_MAX, st.n_branches);
+    const uint32_t S = (st.flags & GGRS_BRANCH_SAVE_LAST) ? st.n_frames : st.n_frames - 1;
+    if (st.n_frames == 0 || st.n_frames > w->cap_steps || S > w->cap_saves) return w->fail(GGRS_E_INVALID, "a branch covers 1..%u frames (%u SaveGameStates) in this world, not %u", w->cap_steps, w->cap_saves, st.n_frames);
+    if (st.flags & ~(GGRS_BRANCH_SAVE_LAST | GGRS_BRANCH_RETAIN_NEWEST | GGRS_BRANCH_RETAIN_ALL)) return w->fail(GGRS_E_INVALID, "unknown branch step flags %x", st.flags);
+    // the state after the last AdvanceFrame would be kept in the LIVE form (the component itself), a snapshot holds Strategy::Stored: such a block could not become a ring slot
+    if (w->has_strategy && (st.flags & (GGRS_BRANCH_RETAIN_NEWEST | GGRS_BRANCH_RETAIN_ALL)) && !(st.flags & GGRS_BRANCH_SAVE_LAST))
+        return w->fail(GGRS_E_INVALID, "a world with a component under a Strategy keeps branch states only as snapshots: add GGRS_BRANCH_SAVE_LAST");
+    if (st.n_inputs > w->max_players) return w->fail(GGRS_E_INVALID, "%u player inputs (at most %u: ggrs_hip_set_input_layout)", st.n_inputs, w->max_players);
+    if (st.n_inputs && !st.inputs) return w->fail(GGRS_E_INVALID, "n_inputs = %u but inputs is NULL", st.n_inputs);
+    if (st.status) for (uint64_t k = 0; k < (uint64_t)st.n_branches * st.n_frames * st.n_inputs; ++k) if (st.status[k] > GGRS_INPUT_DISCONNECTED) return w->fail(GGRS_E_INVALID, "InputStatus %u is none of Confirmed / Predicted / Disconnected", st.status[k]);
+    if (st.spawn_sel) {
+        if (w->jit_spawn_sys < 0) { for (uint64_t k = 0; k < (uint64_t)st.n_branches * st.n_frames; ++k) if (st.spawn_sel[k]) return w->fail(GGRS_E_INVALID, "spawn_sel names a spawn but the world has no spawn system its generated kernel runs"); }
+        else {
+            const ggrs_system_desc& sd = w->systems[w->jit_spawn_sys];
+            const bool custom = sd.kind == GGRS_SYS_SPAWN_CUSTOM;
+            for (uint64_t k = 0; k < (uint64_t)st.n_branches * st.n_frames; ++k) if (st.spawn_sel[k] > st.n_spawn_table) return w->fail(GGRS_E_INVALID, "spawn_sel[%llu] = %u names no entry of spawn_table (%u entries)", (unsigned long long)k, st.spawn_sel[k], st.n_spawn_table);
+            if (st.n_spawn_table && !st.spawn_table) return w->fail(GGRS_E_INVALID, "spawn_table is NULL");
+            for (uint32_t t = 0; t < st.n_spawn_table; ++t) {
+                const ggrs_branch_spawn& e = st.spawn_table[t];
+                if (e.count > 0xFFFFFFFFull) return w->fail(GGRS_E_CAPACITY, "spawn_table[%u]: %llu entities", t, (unsigned long long)e.count);
+                if (!custom && e.count && (!e.vx || !e.vy)) return w->fail(GGRS_E_INVALID, "spawn_table[%u]: a spawn of %llu but vx / vy is NULL", t, (unsigned long long)e.count);
+                if (custom) {
+                    const ggrs_world::SpawnSys& sp = w->spawn_customs[sd.comp[0]];
+                    const uint64_t need = sp.payload_stride ? (uint64_t)sp.payload_stride * e.count : e.payload_bytes;
+                    if (need && !e.payload) return w->fail(GGRS_E_INVALID, "spawn_table[%u]: the spawn system reads %llu payload bytes but payload is NULL", t, (unsigned long long)need);
+                    if (sp.payload_stride && e.payload_bytes && e.payload_bytes < need) return w->fail(GGRS_E_INVALID, "spawn_table[%u]: payload_bytes = %llu, the spawn of %llu needs %llu", t, (unsigned long long)e.payload_bytes, (unsigned long long)e.count, (unsigned long long)need);
+                }
+            }
+        }
+    }
+    return GGRS_OK;
+}
+// res_first: result slot of branch 0's first Save.  keep (may be null): filled with what was retained.
+int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_first, BranchKeep* keep) {
+    const JitLayout& L = *w->jl;
+    const uint32_t B = st.n_branches, T = st.n_frames, S = (st.flags & GGRS_BRANCH_SAVE_LAST) ? T : T - 1;
+    const bool keep_all = (st.flags & GGRS_BRANCH_RETAIN_ALL) != 0, keep_any = keep_all || (st.flags & GGRS_BRANCH_RETAIN_NEWEST);
+    const bool tail_adv = S < T;                                     // the last AdvanceFrame has no SaveGameState behind it: its result is the branch's "live" output
+    const uint32_t n_out = S + (tail_adv ? 1u : 0u);
+    if (keep) keep->valid = false;
+    if (w->ring_frame.empty() || w->ring_frame.front() != w->frame)
+        return w->fail(GGRS_E_NO_SNAPSHOT, "a branch step starts from the snapshot of the current frame %d, and the ring's newest snapshot is %s (end the prefix with SaveGameState)", w->frame,
+                       w->ring_frame.empty() ? "none" : std::to_string(w->ring_frame.front()).c_str());
+    int rc = materialise_live(w); if (rc) return rc;
+    Block& src = w->slots[w->ring_slot.front()];
+    const int32_t F = w->frame;
+    const uint32_t n_cks = w->cks_args.n_cks, ib = w->input_bytes;
+    const int spawn_sys = w->jit_spawn_sys;
+    const ggrs_system_desc* sd = spawn_sys >= 0 ? &w->systems[spawn_sys] : nullptr;
+    const bool custom = sd && sd->kind == GGRS_SYS_SPAWN_CUSTOM;
+    const ggrs_world::SpawnSys* sp = custom ? &w->spawn_customs[sd->comp[0]] : nullptr;
+    // ---- the shape every member shares
+    GgrsJitArgs j; memset(&j, 0, offsetof(GgrsJitArgs, inputs));
+    j.src = src.ptr; j.live = nullptr; j.len = src.len; j.src_is_live = 0; j.n_steps = T; j.n_saves = S;
+    for (uint32_t i = 0; i < T; ++i) {
+        j.op_bits |= 1ull << j.n_ops; ++j.n_ops;
+        j.dt_bits[i] = dt_bits_for_frame(w->fps, F + 1 + (int32_t)i);
+        j.step_frame[i] = F + 1 + (int32_t)i; j.step_confirmed[i] = w->confirmed;
+        if (w->jit_box_sys >= 0) { float dtf; memcpy(&dtf, &j.dt_bits[i], 4); const float fp = powf(w->systems[w->jit_box_sys].fparam[2], dtf); memcpy(&j.aux_bits[i], &fp, 4); }
+        if (i < S) { j.save_frame[i] = F + 1 + (int32_t)i; ++j.n_ops; }
+    }
+    j.skip_live = (keep_any && tail_adv) ? 0u : 1u;
+    // ---- spawn payloads + member records in the staging ring (pinned; one copy to its device twin below)
+    std::vector<uint64_t> pay_off(st.n_spawn_table, 0), pay_bytes(st.n_spawn_table, 0);
+    uint64_t total = (uint64_t)B * L.m.bytes;
+    for (uint32_t t = 0; t < st.n_spawn_table && st.spawn_sel && sd; ++t) {
+        const ggrs_branch_spawn& e = st.spawn_table[t];
+        pay_bytes[t] = custom ? (sp->payload_stride ? (uint64_t)sp->payload_stride * e.count : e.payload_bytes) : 8 * e.count;
+        pay_off[t] = total; total += (pay_bytes[t] + 15u) & ~15ull;
+    }
+    uint64_t soff = 0;
+    if (!stage_ring_alloc(w, total, &soff)) {
+        if (total > w->stage_bytes) return w->fail(GGRS_E_CAPACITY, "a branch step of %llu bytes of member records and spawn payloads exceeds the staging buffer (%llu bytes: GGRS_STAGE_BYTES)", (unsigned long long)total, (unsigned long long)w->stage_bytes);
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        stage_ring_reset(w);
+        if (!stage_ring_alloc(w, total, &soff)) return w->fail(GGRS_E_CAPACITY, "the staging buffer cannot hold a branch step of %llu bytes", (unsigned long long)total);
+    }
+    for (uint32_t t = 0; t < st.n_spawn_table && st.spawn_sel && sd; ++t) {
+        const ggrs_branch_spawn& e = st.spawn_table[t];
+        if (!pay_bytes[t]) continue;
+        unsigned char* dst = w->h_stage + soff + pay_off[t];
+        if (custom) memcpy(dst, e.payload, pay_bytes[t]);
+        else { memcpy(dst, e.vx, e.count * 4); memcpy(dst + e.count * 4, e.vy, e.count * 4); }
+    }
+    // ---- members: inputs, spawns, lens; with retention the blocks their frames land in and the rows each store moves (row versions)
+    size_t n_keep = 0;
+    if (keep_any) { n_keep = (size_t)B * (keep_all ? n_out : 1u); rc = spec_blocks_reserve(w, n_keep); if (rc) return rc; }
+    if (keep) { keep->n_branches = B; keep->n_out = n_out; keep->n_frames = T; keep->base_frame = F; keep->blk.assign((size_t)B * n_out, -1); }
+    uint64_t cover = std::max(src.dirty_len, src.len), max_len = src.len, load_rows = jit_static_reads(w), store_bytes = 0;
+    if (keep_any) for (size_t k = 0; k < n_keep; ++k) cover = std::max(cover, w->spec_blocks[k].dirty_len);
+    std::vector<uint32_t> cv;
+    std::vector<unsigned char> rec((size_t)B * L.m.bytes);
+    std::vector<Block*> touched;
+    const size_t in_row = (size_t)w->max_players * (ib + 1);
+    size_t next_blk = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        uint64_t len_b = src.len;
+        if (keep_any) {
+            cv = src.ver;
+            if (w->has_strategy) for (uint32_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].s_n_words && !w->comps[c].no_rollback) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) cv[w->comps[c].col_base + k] = ++w->ver_counter;
+        }
+        auto keep_into = [&](uint32_t o, ggrs_u64* rows_out, ggrs_u32* pm_out) -> Block* {
+            if (!keep_any || !(keep_all || o == n_out - 1)) return nullptr;
+            Block* d = &w->spec_blocks[next_blk];
+            if (keep) keep->blk[(size_t)b * n_out + o] = (int)next_blk;
+            ++next_blk;
+            uint64_t m = 0;
+            for (uint32_t c = 0; c < w->n_tcols && c < 64; ++c) if (w->col_rb[c] && ver_differs(w, *d, cv, c)) m |= 1ull << c;
+            *rows_out = m; *pm_out = pmask_differs(w, *d, cv);
+            d->ver = cv; d->len = len_b;
+            load_rows |= m; store_bytes += rows_bytes_per_slot(w, m, o < S) * len_b;
+            touched.push_back(d);
+            return d;
+        };
+        uint32_t k_save = 0;
+        for (uint32_t i = 0; i < T; ++i) {
+            const size_t bi = (size_t)b * T + i;
+            // PlayerInputs of the frame
+            unsigned char* row = j.inputs[i];
+            memset(row, 0, in_row);
+            const uint32_t np = std::min<uint32_t>(st.n_inputs, w->max_players);
+            if (np) memcpy(row, st.inputs + bi * (size_t)st.n_inputs * ib, (size_t)np * ib);
+            if (np && st.status) memcpy(row + (size_t)w->max_players * ib, st.status + bi * st.n_inputs, np);
+            j.n_inputs[i] = (unsigned char)np;
+            if (keep_any) for (auto& cols : w->sys_writes) for (uint32_t c : cols) cv[c] = ++w->ver_counter;       // ver_step on the branch's own versions
+            // the spawn system (the host decided: spawn_sel), after the frame's other systems
+            j.spawn_count[i] = 0; j.spawn_first[i] = 0; j.spawn_payload[i] = nullptr;
+            const uint32_t sel = (st.spawn_sel && sd) ? st.spawn_sel[bi] : 0u;
+            if (sel) {
+                const ggrs_branch_spawn& e = st.spawn_table[sel - 1];
+                const bool fires = e.count && (custom || (np && spawn_pressed(w, *sd, row, np)));                   // spawn_pressed, particles.rs:254-256 (advance_spawns)
+                if (fires) {
+                    if (len_b + e.count > w->capacity) return w->fail(GGRS_E_CAPACITY, "branch %u: spawn of %llu exceeds capacity %llu", b, (unsigned long long)e.count, (unsigned long long)w->capacity);
+                    j.spawn_count[i] = (uint32_t)e.count; j.spawn_first[i] = len_b; j.spawn_payload[i] = pay_bytes[sel - 1] ? w->d_stage + soff + pay_off[sel - 1] : nullptr;
+                    len_b += e.count;
+                    if (keep_any) {
+                        auto touch = [&](uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) cv[w->comps[c].col_base + k] = ++w->ver_counter; cv[ver_presence(w, c)] = ++w->ver_counter; };
+                        if (custom) { for (uint32_t c = 0; c < w->comps.size(); ++c) if ((sp->bundle_mask >> c) & 1ull) touch(c); }
+                        else { touch(sd->comp[0]); touch(sd->comp[1]); touch(sd->comp[2]); }
+                    }
+                }
+            }
+            if (i < S) {
+                j.save_len[k_save] = len_b; j.save_rows[k_save] = 0; j.save_pmask[k_save] = 0;
+                Block* d = keep_into(k_save, &j.save_rows[k_save], &j.save_pmask[k_save]);
+                j.save_dst[k_save] = d ? d->ptr : nullptr;
+                ++k_save;
+            }
+        }
+        j.live = nullptr; j.live_rows = 0; j.live_pmask = 0;
+        if (tail_adv) { Block* d = keep_into(n_out - 1, &j.live_rows, &j.live_pmask); j.live = d ? d->ptr : nullptr; }
+        max_len = std::max(max_len, len_b);
+        jit_pack_member(L, j, rec.data() + (size_t)b * L.m.bytes);
+    }
+    memcpy(w->h_stage + soff, rec.data(), rec.size());
+    HIPCHK(w, hipMemcpyAsync(w->d_stage + soff, w->h_stage + soff, total, hipMemcpyHostToDevice, w->stream));
+    cover = std::max(cover, max_len);
+    for (Block* d : touched) d->dirty_len = std::max(src.dirty_len, max_len);
+    // ---- one launch for all members, one k_gen_finalize for all their Saves
+    const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
+    const uint64_t parts_need = (uint64_t)B * std::max(1u, S) * (n_cks + 1) * g;
+    if (parts_need > w->branch_parts_cap) {
+        if (w->d_branch_parts) { HIPCHK(w, hipStreamSynchronize(w->stream)); (void)hipFree(w->d_branch_parts); w->d_branch_parts = nullptr; w->branch_parts_cap = 0; }
+        HIPCHK(w, hipMalloc((void**)&w->d_branch_parts, parts_need * 8));
+        w->branch_parts_cap = parts_need;
+    }
+    memset(j.save_dst, 0, sizeof j.save_dst); memset(j.save_rows, 0, sizeof j.save_rows); memset(j.save_pmask, 0, sizeof j.save_pmask);
+    j.live = w->live.ptr; j.live_rows = 0; j.live_pmask = 0;           // (never used: every member's record says where its live output goes)
+    j.mtab = w->d_stage + soff;
+    j.load_rows = load_rows;
+    j.parts = reinterpret_cast<ggrs_u64*>(w->d_branch_parts); j.part_stride = g; j.part_tstride = 1;
+    j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
+    // branch blocks are written once and not read before an adoption: past what the caches hold they stream around them
+    j.nt = (cover > JIT_NT_MIN_SLOTS || store_bytes > (128ull << 20)) ? 1u : 0u;
+    j.cached_saves = 0; j.nt_loads = 0; j.dp_s = 0;
+    w->batch_ev_attached = false;
+    hipFunction_t fn = jit_spec_for(w, j, true);                      // the copy of the kernel built for this op sequence, once the session has sent it often enough
+    if (!fn) fn = w->jit_fn;
+    rc = launch_jit(w, fn, jit_grid(g), 1, B, jit_lane_fold_bytes(w, n_cks, S), j, rows_bytes_per_slot(w, load_rows, true) * src.len * B + store_bytes); if (rc) return rc;
+    if (S) {
+        GenFinArgs f = make_gen_fin(w, j, g, n_cks, res_first);
+        f.mtab = w->d_stage + soff; f.mstride = L.m.bytes; f.moff_save_len = L.m.save_len;
+        {
+            ProfScope ps(w, GGRS_KERNEL_CHECKSUM);
+            hipLaunchKernelGGL(k_gen_finalize, dim3(S * B), dim3(FIN_TPB), 0, w->stream, f);
+        }
+        HIPCHK(w, hipGetLastError());
+    }
+    if (keep) keep->valid = keep_any;
+    return GGRS_OK;
 }
 
 // which runner serves this world's request lists right now (nullptr: one launch per request)

@@ -96,8 +96,9 @@ constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;       // blocking calls: l
 struct JitSig {
     uint64_t op_bits = 0, save_rows = 0, live_rows = 0, load_rows = 0;
     uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0, dp_s = 0, nt_loads = 0;
+    uint32_t members = 0;                 // a launch of batch members with records (ggrs_hip_fanout_step_branches): a.mtab stays an argument, the per-member fields are not literals
     bool operator==(const JitSig& o) const {
-        return op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
+        return members == o.members && op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
                n_steps == o.n_steps && src_is_live == o.src_is_live && skip_live == o.skip_live && nt == o.nt && cached_saves == o.cached_saves &&
                save_pmask == o.save_pmask && live_pmask == o.live_pmask && dp_s == o.dp_s && nt_loads == o.nt_loads;
     }
@@ -264,6 +265,13 @@ struct ggrs_world {
     uint64_t* h_rows = nullptr; uint64_t* d_rows = nullptr; uint64_t rows_cap = 0, rows_used = 0, rows_tail = 0;   // ring of partial rows
     hipEvent_t batch_ev = nullptr; bool batch_ev_attached = false;   // enqueue: the batch's event, offered to the list's last kernel launch (launch_jit)
     bool device_results_only = false;    // a consumer reads the result ring in stream order (ggrs_hip_fanout_*): every fold stays on the device
+    // ... and wants the Checksum(u128)s of the list being enqueued in DEVICE memory too (k_gen_finalize's second copy): result slot dev_results_first + i
+    // goes to dev_results_dst[2 i ..] -- the fan-out points this at the all-gather's send buffer for the duration of one step
+    uint64_t* dev_results_dst = nullptr; uint32_t dev_results_first = 0;
+    // SPECULATIVE BRANCH STATES (ggrs_hip_fanout_step_branches with GGRS_BRANCH_RETAIN_*): packed state blocks outside the ring, allocated on demand and kept
+    // until the world goes -- an adopted branch state trades places with a ring slot (ggrs_hip_fanout_adopt), so both sets belong to the world
+    std::vector<Block> spec_blocks; std::vector<void*> spec_allocs;
+    uint64_t* d_branch_parts = nullptr; uint64_t branch_parts_cap = 0;      // partial rows of a member launch: [members x saves x (n_cks + 1)][workgroups]
     ggrs_world** fanout_backref = nullptr;   // the `w` field of the ggrs_fanout driving this world: cleared by world_destroy, so a fan-out object that outlives its world touches nothing
     std::deque<PendingBatch> pending; uint32_t res_head = 0; uint32_t pending_results = 0;
     std::vector<hipEvent_t> event_pool;

@@ -177,6 +177,10 @@ constexpr uint32_t JIT_MAX_INPUT_BYTES = 16;                                    
 constexpr uint32_t JIT_IN_MAX = GGRS_MAX_PLAYERS * (JIT_MAX_INPUT_BYTES + 1);            // per step: inputs, then one InputStatus byte per player
 struct GgrsJitArgs {
     const unsigned char* src; unsigned char* live;
+    // BATCH MEMBERS (blockIdx.z; ggrs_hip_fanout_step_branches): with mtab != nullptr the launch carries gridDim.z request groups of ONE op shape off ONE source
+    // block -- speculative branches -- and everything that differs between them (PlayerInputs, spawns, where a Save lands and which rows it stores, the
+    // branch's live block) comes from member z's record in device memory (JitLayout::m_*: the per-world layout of a record) instead of this block
+    const unsigned char* mtab;
     ggrs_u64* parts;                                 // this launch's partial rows: [saves x (n_cks + 1)][part_stride], one entry per workgroup
     // FOLD-FORWARD (ff_blocks != 0): the first ff_blocks workgroups of this launch fold the partial rows the PREVIOUS launch of the stream left in
     // device memory (ff_rows: [rows][ff_stride], ff_g entries each, ff_split chunks of <= 1024 entries per row) -- one chunk per workgroup: XOR of a
@@ -216,6 +220,9 @@ struct JitLayout {
     std::vector<JitField> f; uint32_t bytes = 0;
     uint32_t cap_saves = MAX_TICK_SAVES, cap_steps = MAX_TICK_STEPS;    // a group of this world ends at this many Saves / steps
     uint32_t in_stride = 0, in_bytes = 1, max_players = GGRS_MAX_PLAYERS;   // bytes of one step's input block on the device (0: no system reads PlayerInputs)
+    // one batch member's record (GgrsJitArgs::mtab): byte offsets inside it, its size (a multiple of 8); absent fields keep offset 0 and are never read
+    struct Member { uint32_t bytes = 0, save_dst = 0, save_rows = 0, save_len = 0, spawn_payload = 0, spawn_first = 0, live = 0, live_rows = 0, save_pmask = 0, live_pmask = 0,
+                    spawn_count = 0, n_inputs = 0, inputs = 0; } m;
 };
 struct JitNeeds { bool spawn, inputs, marks, box; };
 JitNeeds jit_needs(const ggrs_world* w);
@@ -238,7 +245,7 @@ JitLayout jit_layout(const ggrs_world* w) {
         // the step-dimensioned arrays need the step cap, which depends on what is left of the kernarg budget: pass 0 sizes everything else
         L.f.clear();
         const uint32_t T = L.cap_steps, S = L.cap_saves;
-        F1("const unsigned char*", src, true); F1("unsigned char*", live, true); F1("ggrs_u64*", parts, true);
+        F1("const unsigned char*", src, true); F1("unsigned char*", live, true); F1("const unsigned char*", mtab, true); F1("ggrs_u64*", parts, true);
         F1("const ggrs_u64*", ff_rows, true); F1("ggrs_u64*", ff_out, true); F1("ggrs_u64", ff_seq, true);
         F1("ggrs_u64", live_rows, true); F1("ggrs_u64", load_rows, true); F1("ggrs_u64", op_bits, true); F1("ggrs_u64", len, true);
         FA("unsigned char*", save_dst, S, true); FA("ggrs_u64", save_rows, S, true); FA("ggrs_u64", save_len, S, true);
@@ -270,6 +277,17 @@ JitLayout jit_layout(const ggrs_world* w) {
 #undef F1
 #undef FA
 #undef FS
+    {   // the member record: 8-byte fields, then 4-byte ones, then bytes -- arrays at the world's group caps, like the argument block's
+        const uint32_t S = L.cap_saves, T = L.cap_steps;
+        uint32_t o = 0;
+        L.m.save_dst = o; o += 8 * S; L.m.save_rows = o; o += 8 * S; L.m.save_len = o; o += 8 * S;
+        if (need.spawn) { L.m.spawn_payload = o; o += 8 * T; L.m.spawn_first = o; o += 8 * T; }
+        L.m.live = o; o += 8; L.m.live_rows = o; o += 8;
+        L.m.save_pmask = o; o += 4 * S; L.m.live_pmask = o; o += 4;
+        if (need.spawn) { L.m.spawn_count = o; o += 4 * T; }
+        if (need.inputs) { L.m.n_inputs = o; o += T; L.m.inputs = o; o += T * L.in_stride; }
+        L.m.bytes = (o + 7u) & ~7u;
+    }
     return L;
 }
 // the struct as the generated kernel sees it + one static_assert per field
@@ -296,6 +314,18 @@ inline void jit_pack(const JitLayout& L, const GgrsJitArgs& j, unsigned char* bu
         if (!fl.rows) memcpy(buf + fl.dev_off, h + fl.host_off, (size_t)fl.elem * fl.dev_count);
         else for (uint32_t r = 0; r < fl.rows && r < j.n_steps; ++r) memcpy(buf + fl.dev_off + r * fl.row_dev, h + fl.host_off + r * fl.row_host, fl.row_dev);
     }
+}
+
+// one batch member's record from the host-side description of its group (buf: L.m.bytes bytes)
+inline void jit_pack_member(const JitLayout& L, const GgrsJitArgs& j, unsigned char* buf) {
+    const uint32_t S = L.cap_saves, T = L.cap_steps;
+    const JitLayout::Member& m = L.m;
+    memset(buf, 0, m.bytes);
+    memcpy(buf + m.save_dst, j.save_dst, 8 * S); memcpy(buf + m.save_rows, j.save_rows, 8 * S); memcpy(buf + m.save_len, j.save_len, 8 * S);
+    if (m.spawn_first) { memcpy(buf + m.spawn_payload, j.spawn_payload, 8 * T); memcpy(buf + m.spawn_first, j.spawn_first, 8 * T); memcpy(buf + m.spawn_count, j.spawn_count, 4 * T); }
+    memcpy(buf + m.live, &j.live, 8); memcpy(buf + m.live_rows, &j.live_rows, 8);
+    memcpy(buf + m.save_pmask, j.save_pmask, 4 * S); memcpy(buf + m.live_pmask, &j.live_pmask, 4);
+    if (m.inputs) { memcpy(buf + m.n_inputs, j.n_inputs, T); for (uint32_t r = 0; r < T && r < j.n_steps; ++r) memcpy(buf + m.inputs + r * L.in_stride, j.inputs[r], L.in_stride); }
 }
 
 // The words of one value under a Strategy (ggrs_hip_register_component_strategy): Strategy::Target (the component) or
@@ -493,6 +523,12 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "#define GGRS_ST(NAME, INSN, T, C) __device__ __forceinline__ void NAME(const unsigned char* base, uint32_t lo, T v) { const unsigned long b = (unsigned long)base; asm volatile(INSN \" %0, %1, %2 nt\" : : \"v\"(lo), C(v), \"s\"(b) : \"memory\"); }\n"
          "GGRS_ST(st1nt, \"global_store_byte\", uint32_t, \"v\") GGRS_ST(st2nt, \"global_store_short\", uint32_t, \"v\") GGRS_ST(st4nt, \"global_store_dword\", uint32_t, \"v\") GGRS_ST(st8nt, \"global_store_dwordx2\", uint64_t, \"v\")\n"
          "#undef GGRS_ST\n"
+         "// a batch member's record (GgrsJitArgs::mtab): written by the host before the launch, never by a kernel -- read through the constant address space,\n"
+         "// i.e. with scalar loads (the record's address is wave-uniform: blockIdx.z)\n"
+         "#define GGRS_K __attribute__((address_space(4)))\n"
+         "__device__ __forceinline__ uint64_t mb_u64(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint64_t*)(mb + off); }\n"
+         "__device__ __forceinline__ uint32_t mb_u32(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint32_t*)(mb + off); }\n"
+         "__device__ __forceinline__ uint32_t mb_u8(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K unsigned char*)(mb + off); }\n"
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
@@ -541,6 +577,8 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "        return;\n"
             "    }\n"
             "    const uint32_t bx = blockIdx.x - a.ff_blocks, gx = gridDim.x - a.ff_blocks;\n"
+            "    // batch members (blockIdx.z) with records: what differs between the launch's groups comes from member z's record, the rest from the argument block\n"
+            "    const GGRS_K unsigned char* const mb = a.mtab ? (const GGRS_K unsigned char*)(unsigned long)(a.mtab + (uint64_t)blockIdx.z * %uull) : (const GGRS_K unsigned char*)0ul;\n"
             "    const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;\n"
             "    const uint32_t o_first = a.dp_s ? blockIdx.y * a.dp_s : 0u;          // depth-parallel roles: this workgroup's share of the outputs\n"
             "    const uint32_t o_last = a.dp_s ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;\n"
@@ -549,12 +587,12 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    // per-workgroup checksum partials [Save][component .. live count]: the waves fold into LDS\n"
             "    __shared__ ggrs_u64 s_acc[16 * %u];\n"
             "    for (uint32_t i = tid; i < 16u * %uu; i += 256u) s_acc[i] = 0;\n",
-         n_cks + 1, n_cks, n_cks + 1, n_cks + 1);
+         n_cks + 1, n_cks, L.m.bytes, n_cks + 1, n_cks + 1);
     if (lane_fold) sfmt(s, "    extern __shared__ ggrs_u64 s_lane[];                                  // [Save][checksummed component][lane]: a.n_saves * %u * 64 cells (dynamic LDS)\n"
                            "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) s_lane[i] = 0;\n", n_cks, n_cks * 64u);
     if (lds_inputs && IN_STRIDE)
         sfmt(s, "    __shared__ unsigned char s_in[%u * %u];                                  // PlayerInputs of every step of the group: [step][%u players x %u bytes | %u status bytes]\n"
-                "    for (uint32_t i = tid; i < a.n_steps * %uu; i += 256u) s_in[i] = a.inputs[i / %uu][i %% %uu];\n", L.cap_steps, IN_STRIDE, MAXP, IB, MAXP, IN_STRIDE, IN_STRIDE, IN_STRIDE);
+                "    for (uint32_t i = tid; i < a.n_steps * %uu; i += 256u) s_in[i] = mb ? (unsigned char)mb_u8(mb, %uu + i) : a.inputs[i / %uu][i %% %uu];\n", L.cap_steps, IN_STRIDE, MAXP, IB, MAXP, IN_STRIDE, L.m.inputs, IN_STRIDE, IN_STRIDE);
     s += "    __syncthreads();\n"
          "    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed placement; used for speed only), and each XCD has its own\n"
          "    // L2.  Handing XCD x the x-th CONTIGUOUS eighth of the tiles makes the workgroups that write neighbouring 1 KiB pieces of a\n"
@@ -750,16 +788,17 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "            // ---------------- SaveWorld\n"
          "            if (si < o_first) { ++si; continue; }                          // another role's snapshot\n"
          "            if (si >= o_last) break;\n"
-         "            unsigned char* dst = a.save_dst[si];\n"
-         "            const uint64_t alive_now = __ballot(alive_0);\n"
-         "            if (dst) {\n"
-         "                const uint64_t rows = a.save_rows[si];\n";
-    emit_store("dst", "rows", "a.save_pmask[si]", "alive_now", "                ", true);
-    s += "                if (gu == 0 && lane == 0) {\n"
-         "                    Header h; h.len = a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
-         "                    *reinterpret_cast<Header*>(dst) = h;\n"
-         "                }\n"
-         "            }\n";
+         "            const uint64_t alive_now = __ballot(alive_0);\n";
+    sfmt(s, "            unsigned char* dst = mb ? (unsigned char*)mb_u64(mb, %uu + 8u * si) : a.save_dst[si];\n"
+            "            if (dst) {\n"
+            "                const uint64_t rows = mb ? mb_u64(mb, %uu + 8u * si) : a.save_rows[si];\n"
+            "                const uint32_t pmask_s = mb ? mb_u32(mb, %uu + 4u * si) : a.save_pmask[si];\n", L.m.save_dst, L.m.save_rows, L.m.save_pmask);
+    emit_store("dst", "rows", "pmask_s", "alive_now", "                ", true);
+    sfmt(s, "                if (gu == 0 && lane == 0) {\n"
+            "                    Header h; h.len = mb ? mb_u64(mb, %uu + 8u * si) : a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
+            "                    *reinterpret_cast<Header*>(dst) = h;\n"
+            "                }\n"
+            "            }\n", L.m.save_len);
     sfmt(s, "            ggrs_u64* acc = s_acc + si * %uu;                                 // this Save's partials of the workgroup (LDS)\n", n_cks + 1);
     for (uint32_t k = 0; k < n_cks; ++k) {
         const uint32_t c = cks_comp[k];
@@ -805,9 +844,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     }
     // PlayerInputs<T> of the step as user code sees it (src/lib.rs:98): bytes in LDS
     auto emit_frame = [&](const char* name, const float* fparam, const int64_t* iparam) {
-        sfmt(s, "            GgrsFrame %s; %s.dt = dt; %s.frame = a.step_frame[sj]; %s.n_inputs = a.n_inputs[sj]; %s.input_bytes = %uu;\n"
+        sfmt(s, "            GgrsFrame %s; %s.dt = dt; %s.frame = a.step_frame[sj]; %s.n_inputs = mb ? mb_u8(mb, %uu + sj) : a.n_inputs[sj]; %s.input_bytes = %uu;\n"
                 "            %s.input.p = s_in + sj * %uu; %s.input.ib = %uu; %s.status = s_in + sj * %uu + %uu;\n",
-             name, name, name, name, name, IB, name, IN_STRIDE, name, IB, name, IN_STRIDE, MAXP * IB);
+             name, name, name, name, L.m.n_inputs, name, IB, name, IN_STRIDE, name, IB, name, IN_STRIDE, MAXP * IB);
         for (int k = 0; k < 4; ++k) sfmt(s, "            %s.fparam[%d] = %s;\n", name, k, f32_lit(fparam[k]).c_str());
         sfmt(s, "            %s.iparam[0] = %lldll; %s.iparam[1] = %lldll;\n", name, (long long)iparam[0], name, (long long)iparam[1]);
     };
@@ -846,15 +885,15 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             if (h_rb) { snprintf(hp, sizeof hp, "p%u_0", d.comp[2]); snprintf(hv, sizeof hv, "w%u_0", col(d.comp[2], d.word[2])); }
             else { snprintf(hp, sizeof hp, "side_p%zu_0", i); snprintf(hv, sizeof hv, "side_h%zu_0", i); }
             const uint32_t x = col(d.comp[0], d.word[0]), v = col(d.comp[1], d.word[1]);
-            sfmt(s, "            if (alive_0 && p%u_0 && p%u_0 && %s && %s < a.n_inputs[sj]) {               // box_game.rs:154-206\n"
+            sfmt(s, "            if (alive_0 && p%u_0 && p%u_0 && %s && %s < (mb ? mb_u8(mb, %uu + sj) : (uint32_t)a.n_inputs[sj])) {               // box_game.rs:154-206\n"
                     "                float x = __uint_as_float(w%u_0), y = __uint_as_float(w%u_0), z = __uint_as_float(w%u_0);\n"
                     "                float vx = __uint_as_float(w%u_0), vy = __uint_as_float(w%u_0), vz = __uint_as_float(w%u_0);\n",
-                 d.comp[0], d.comp[1], hp, hv, x, x + 1, x + 2, v, v + 1, v + 2);
-            sfmt(s, "                box_move_math(x, y, z, vx, vy, vz, a.inputs[sj][%s * %uu], dt, __uint_as_float(a.aux_bits[sj]), %s, %s, %s);\n"
+                 d.comp[0], d.comp[1], hp, hv, L.m.n_inputs, x, x + 1, x + 2, v, v + 1, v + 2);
+            sfmt(s, "                box_move_math(x, y, z, vx, vy, vz, mb ? (uint8_t)mb_u8(mb, %uu + sj * %uu + (uint32_t)(%s * %uu)) : a.inputs[sj][%s * %uu], dt, __uint_as_float(a.aux_bits[sj]), %s, %s, %s);\n"
                     "                w%u_0 = __float_as_uint(x); w%u_0 = __float_as_uint(y); w%u_0 = __float_as_uint(z);\n"
                     "                w%u_0 = __float_as_uint(vx); w%u_0 = __float_as_uint(vy); w%u_0 = __float_as_uint(vz);\n"
                     "            }\n",
-                 hv, IB, f32_lit(d.fparam[0]).c_str(), f32_lit(d.fparam[1]).c_str(), f32_lit(d.fparam[3]).c_str(), x, x + 1, x + 2, v, v + 1, v + 2);
+                 L.m.inputs, IN_STRIDE, hv, IB, hv, IB, f32_lit(d.fparam[0]).c_str(), f32_lit(d.fparam[1]).c_str(), f32_lit(d.fparam[3]).c_str(), x, x + 1, x + 2, v, v + 1, v + 2);
         } break;
         case GGRS_SYS_CUSTOM: {
             const ggrs_world::Custom& c = w->customs[d.comp[0]];
@@ -881,10 +920,12 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         uint64_t bundle = 0;
         if (custom) bundle = w->spawn_customs[d.comp[0]].bundle_mask; else bundle = (1ull << d.comp[0]) | (1ull << d.comp[1]) | (1ull << d.comp[2]);
         if (custom) emit_frame("fr_spawn", d.fparam, d.iparam);
-        s += "            if (a.spawn_count[sj]) {                                                   // wave-uniform\n"
-             "                const uint64_t sf_ = a.spawn_first[sj], sn_ = a.spawn_count[sj];\n"
-             "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
-             "                    alive_0 = true;\n";
+        sfmt(s, "            const uint64_t sn_ = mb ? mb_u32(mb, %uu + 4u * sj) : a.spawn_count[sj];\n"
+                "            if (sn_) {                                                                 // wave-uniform\n"
+                "                const uint64_t sf_ = mb ? mb_u64(mb, %uu + 8u * sj) : a.spawn_first[sj];\n"
+                "                const unsigned char* const spay_ = mb ? (const unsigned char*)mb_u64(mb, %uu + 8u * sj) : a.spawn_payload[sj];\n"
+                "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
+                "                    alive_0 = true;\n", L.m.spawn_count, L.m.spawn_first, L.m.spawn_payload);
         for (uint32_t c = 0; c < nc; ++c) if (rb(c)) sfmt(s, "                    p%u_0 = %s;\n", c, ((bundle >> c) & 1ull) ? "true" : "false");
         for (uint32_t c = 0; c < nc; ++c) if (rb(c) && ((bundle >> c) & 1ull)) {
             const Comp& T = w->comps[c];
@@ -896,7 +937,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         }
         if (!custom) {
             // spawn_particles (particles.rs:258-270): Velocity (vx, vy, 0) from the staged payload -- count f32 of vx, then count f32 of vy --, Ttl = iparam[0]
-            sfmt(s, "                    const float* pv_ = reinterpret_cast<const float*>(a.spawn_payload[sj]);          // spawn_particles, particles.rs:258-270\n"
+            sfmt(s, "                    const float* pv_ = reinterpret_cast<const float*>(spay_);          // spawn_particles, particles.rs:258-270\n"
                     "                    w%u_0 = __float_as_uint(pv_[e0 - sf_]); w%u_0 = __float_as_uint(pv_[sn_ + (e0 - sf_)]); w%u_0 = 0u;\n",
                  col(d.comp[1], 0), col(d.comp[1], 1), col(d.comp[1], 2));
             sfmt(s, "                    w%u_0 = %lluull;\n", col(d.comp[2], 0), (unsigned long long)d.iparam[0]);
@@ -904,7 +945,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             const ggrs_world::SpawnSys& sp = w->spawn_customs[d.comp[0]];
             s += "                    GgrsEntity ent; ent.slot = e0; ent.kill = 0;\n";
             for (uint32_t b = 0; b < sp.n_bind; ++b) sfmt(s, "                    ent.w[%u] = w%u_0;\n", b, col(sp.comp[b], sp.word[b]));
-            sfmt(s, "                    ggrs_spawn_sys::ggrs_spawn(ent, e0 - sf_, fr_spawn, a.spawn_payload[sj] + (e0 - sf_) * %uull);\n", sp.payload_stride);
+            sfmt(s, "                    ggrs_spawn_sys::ggrs_spawn(ent, e0 - sf_, fr_spawn, spay_ + (e0 - sf_) * %uull);\n", sp.payload_stride);
             for (uint32_t b = 0; b < sp.n_bind; ++b)
                 sfmt(s, "                    w%u_0 = (%s)(%s)ent.w[%u];\n", col(sp.comp[b], sp.word[b]), wtype(sp.comp[b]), mtype(sp.comp[b]), b);
         }
@@ -919,7 +960,10 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "    // ---- the live world, written once\n"
          "    if (my_live && writes_live) {\n"
          "        const uint64_t alive_now = __ballot(alive_0);\n";
-    emit_store("a.live", "a.live_rows", "a.live_pmask", "alive_now", "        ", false);
+    sfmt(s, "        unsigned char* const live_p = mb ? (unsigned char*)mb_u64(mb, %uu) : a.live;\n"
+            "        const uint64_t live_rows_v = mb ? mb_u64(mb, %uu) : a.live_rows;\n"
+            "        const uint32_t live_pm_v = mb ? mb_u32(mb, %uu) : a.live_pmask;\n", L.m.live, L.m.live_rows, L.m.live_pmask);
+    emit_store("live_p", "live_rows_v", "live_pm_v", "alive_now", "        ", false);
     s += "    }\n";
     if (marks) {
         s += "    if (my_live && a.n_steps) {\n"
@@ -1080,7 +1124,7 @@ uint32_t jit_replace_token(std::string& body, const std::string& tok, const std:
 }
 // The shape fields, by name: what jit_specialise turns into literals and what must NOT survive in a specialised body (tests/test_generated_kernel.py
 // checks the same list through ggrs_hip_generated_kernel_source).  `[si]`: the field is an array indexed by the Save counter in the generic text.
-static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads"};
+static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads", "mtab"};
 static const char* const kJitShapeArrays[] = {"save_rows", "save_pmask"};
 std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const size_t k = generic.find("extern \"C\" __global__");
@@ -1091,7 +1135,8 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const std::pair<const char*, std::string> scalars[] = {
         {"op_bits", lit64(g.op_bits)}, {"n_ops", lit32(g.n_ops)}, {"n_saves", lit32(g.n_saves)}, {"n_steps", lit32(g.n_steps)}, {"src_is_live", lit32(g.src_is_live)},
         {"skip_live", lit32(g.skip_live)}, {"dp_s", lit32(g.dp_s)}, {"nt", lit32(g.nt)}, {"cached_saves", lit32(g.cached_saves)}, {"live_rows", lit64(g.live_rows)},
-        {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}, {"nt_loads", lit32(g.nt_loads)}};
+        {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}, {"nt_loads", lit32(g.nt_loads)},
+        {"mtab", g.members ? "a.mtab" : "((const unsigned char*)0)"}};     // a copy for plain launches knows there are no member records; one for member launches (g.members) keeps the pointer
     static_assert(sizeof scalars / sizeof scalars[0] == sizeof kJitShapeScalars / sizeof kJitShapeScalars[0], "every shape scalar has a literal");
     const std::pair<const char*, std::string> arrays[] = {{"save_rows", lit64(g.save_rows)}, {"save_pmask", lit32(g.save_pmask)}};
     for (auto& sb : arrays) (void)jit_replace_token(body, std::string("a.") + sb.first + "[si]", sb.second);
@@ -1101,16 +1146,16 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     }
     // nothing of the shape may be left to the argument block: a surviving token (a new use the generator spells differently, e.g. another
     // index into save_rows) would silently read the RUN-TIME value next to literals of the shape the kernel was built for
-    for (const char* f : kJitShapeScalars) if (jit_find_token(body, std::string("a.") + f, 0) != std::string::npos) return "";
+    for (const char* f : kJitShapeScalars) if (!(g.members && !strcmp(f, "mtab")) && jit_find_token(body, std::string("a.") + f, 0) != std::string::npos) return "";
     for (const char* f : kJitShapeArrays) if (jit_find_token(body, std::string("a.") + f, 0) != std::string::npos) return "";
     const std::string loop = "    for (uint32_t op = 0; op < " + lit32(g.n_ops) + "; ++op) {";
     const size_t lp = body.find(loop);
     if (lp == std::string::npos) return "";
     body.insert(lp, "#pragma unroll\n");
-    char note[320];
-    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u, live block %s\n", g.n_ops,
+    char note[360];
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u, live block %s%s\n", g.n_ops,
              (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads, g.dp_s,
-             g.skip_live ? "left unwritten" : "written");
+             g.skip_live ? "left unwritten" : "written", g.members ? "; batch members with records (destinations, rows, inputs and spawns per member)" : "");
     return head + note + body;
 }
 // Build (or load from the disk cache / the shipped objects) without touching a world: runs on a worker thread

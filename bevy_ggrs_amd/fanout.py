@@ -25,9 +25,16 @@ per GPU (torch.distributed, backend "nccl" == RCCL over xGMI):
                      all-gathered on a side stream, so the collective and the host work overlap
                      the next step's kernel.
 
+  adopt(branch, k)   the true inputs of the next k frames have arrived and equal what `branch` predicted: that branch's
+                     retained state of frame C+k becomes the confirmed world (retain="all" / "newest") -- a ring-slot swap on
+                     the rank that ran the branch; every other rank re-simulates the k frames with the now-confirmed inputs
+                     (one launch, no bytes over xGMI, and a free desync check) or receives the block by ONE broadcast
+                     (ggrs_hip_fanout_adopt; SURVEY.md 8e "the matching branch's state is adopted").
+
 No data-path collective touches entity columns inside step(); per-GPU work is fixed as the
-world size grows (weak scaling).  `exchange` abstracts where the packed state lives so the same
-control flow runs on gloo/CPU worlds in tests/test_fanout_gloo.py.
+world size grows (weak scaling).  The collectives live INSIDE libggrs_hip.so (`native`: RcclFanout); `exchange` is the
+host-side stand-in with the same contract that lets the same control flow run on gloo with CPU test worlds in
+tests/test_fanout_gloo.py.
 """
 from __future__ import annotations
 
@@ -46,61 +53,6 @@ class DesyncDetected(RuntimeError):
         super().__init__(f"confirmed frame {frame}: replica checksums differ: {[hex(c) for c in checksums]}")
         self.frame = frame
         self.checksums = list(checksums)
-
-
-class HipStateExchange:
-    """Packed-state broadcast for a `bevy_ggrs_amd.World` whose arena is a torch CUDA tensor:
-    the live state block is arena[0:state_bytes], so RCCL reads/writes HBM in place."""
-
-    def __init__(self, world, arena):
-        self.world, self.arena = world, arena
-
-    def broadcast(self, dist, src: int):
-        w = self.world
-        nbytes = w.state_bytes()
-        ptr = w.live_state_ptr()            # refreshes the header (len, frame) on every rank
-        assert ptr == self.arena.data_ptr(), "live block must be the head of the torch arena"
-        dist.broadcast(self.arena[:nbytes], src=src)
-        import torch
-        torch.cuda.current_stream().synchronize()
-        w.adopt_live_state()
-
-    def all_gather_u64_start(self, dist, values: np.ndarray):
-        """Checksums come from host memory: the H2D copy, the RCCL all-gather and the D2H copy are queued on a side
-        stream, so they neither wait for nor delay the kernels already enqueued on the world's stream, and the host
-        does not wait for them here.  Staging buffers (pinned host, device) rotate over 4 sets per message size."""
-        import torch
-        n, size = int(values.size), dist.get_world_size()
-        if getattr(self, "_comm", None) is None:
-            self._comm = torch.cuda.Stream(device=self.arena.device)
-            self._bufs, self._turn = {}, 0
-        ring = self._bufs.setdefault(n, [])
-        if len(ring) < 4:
-            h_in = torch.empty(n, dtype=torch.int64).pin_memory()
-            h_out = torch.empty((size, n), dtype=torch.int64).pin_memory()
-            ring.append({"h_in": h_in, "h_in_np": h_in.numpy(), "h_out": h_out, "h_out_np": h_out.numpy(),
-                         "d_in": torch.empty(n, dtype=torch.int64, device=self.arena.device),
-                         "d_out": torch.empty((size, n), dtype=torch.int64, device=self.arena.device),
-                         "done": torch.cuda.Event()})
-            b = ring[-1]
-        else:
-            b = ring[self._turn % 4]
-            b["done"].synchronize()                          # its previous use (4 gathers ago) is long over
-        self._turn += 1
-        b["h_in_np"][:] = values.view(np.int64)
-        with torch.cuda.stream(self._comm):
-            b["d_in"].copy_(b["h_in"], non_blocking=True)
-            dist.all_gather_into_tensor(b["d_out"], b["d_in"])
-            b["h_out"].copy_(b["d_out"], non_blocking=True)
-            b["done"].record(self._comm)
-        return b
-
-    def all_gather_u64_finish(self, token) -> np.ndarray:
-        token["done"].synchronize()
-        return token["h_out_np"].view(np.uint64).copy()
-
-    def all_gather_u64(self, dist, values: np.ndarray) -> np.ndarray:
-        return self.all_gather_u64_finish(self.all_gather_u64_start(dist, values))
 
 
 class RcclFanout:
@@ -148,6 +100,21 @@ class RcclFanout:
     def step_raw(self, arr, n: int):
         self._check(self._lib.ggrs_hip_fanout_step(self._p, arr, n, None))
 
+    def step_branches(self, bs):
+        """ggrs_hip_fanout_step_branches: a prefix request list + n_branches x n_frames predicted inputs (a `_ffi.BranchStep`)."""
+        import ctypes as C
+        self._check(self._lib.ggrs_hip_fanout_step_branches(self._p, C.byref(bs), None))
+
+    def adopt(self, branch: int, frame: int, replay=None, mode: int = 0) -> list:
+        """ggrs_hip_fanout_adopt (collective): `branch`'s retained state of `frame` becomes the world.  replay: the request objects a rank that
+        does NOT own the branch runs instead (mode 0); returns the Checksum(u128)s of its SaveGameStates ([] on the owner)."""
+        import ctypes as C
+        arr, keep, n_save = self.world.build_requests(replay or [])
+        out = (C.c_uint64 * max(2, 2 * n_save))()
+        got = C.c_uint32(0)
+        self._check(self._lib.ggrs_hip_fanout_adopt(self._p, branch, frame, mode, arr if replay else None, len(replay or []), out, C.byref(got)))
+        return [int(out[2 * i]) | (int(out[2 * i + 1]) << 64) for i in range(got.value)]
+
     def comm_info(self):
         """(rank, world size, HIP device) as the communicator itself reports them (ncclCommUserRank / ncclCommCount)."""
         import ctypes as C
@@ -177,74 +144,9 @@ class RcclFanout:
         except Exception: pass
 
 
-class _DeviceSpan:
-    """A raw device allocation presented through __cuda_array_interface__ so torch can alias it without a copy."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
-def make_torch_world(bg, capacity: int, max_depth: int, n_components: int, bytes_per_slot: int,
-                     device, flags: int = 0, library_arena: bool = True):
-    """World whose live state block is addressable as ONE torch uint8 tensor (so collectives can read and write it).
-
-    library_arena (default): the library owns the arena -- so world creation can run its placement probe
-     -- and `late_tensor(world)` aliases the live block through __cuda_array_interface__ once the world
-    is sealed.  Otherwise (or when aliasing is not available) the arena is a torch tensor handed to the library."""
-    import torch
-    from . import _ffi
-    stream = torch.cuda.current_stream(device).cuda_stream
-    dev_index = device.index if hasattr(device, "index") and device.index is not None else 0
-    if library_arena and _aliasing_works(device):
-        w = bg.World(capacity, max_depth=max_depth, device=dev_index, stream=stream, flags=flags)
-        return w, LateArena(w, device)
-    nbytes = int(_ffi.lib.ggrs_hip_arena_bytes(capacity, max_depth, n_components, bytes_per_slot))
-    arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    w = bg.World(capacity, max_depth=max_depth, device=dev_index, stream=stream,
-                 arena_ptr=arena.data_ptr(), arena_bytes=nbytes, flags=flags)
-    return w, arena
-
-
-_ALIAS_OK = {}
-
-
-def _aliasing_works(device) -> bool:
-    """torch.as_tensor over __cuda_array_interface__ must alias (not copy) device memory on this build."""
-    key = str(device)
-    if key not in _ALIAS_OK:
-        try:
-            import torch
-            probe = torch.arange(64, dtype=torch.uint8, device=device)
-            alias = torch.as_tensor(_DeviceSpan(probe.data_ptr(), 64), device=device)
-            alias[3] = 200
-            torch.cuda.synchronize(device)
-            _ALIAS_OK[key] = bool(alias.data_ptr() == probe.data_ptr() and int(probe[3].item()) == 200)
-        except Exception:
-            _ALIAS_OK[key] = False
-    return _ALIAS_OK[key]
-
-
-class LateArena:
-    """Tensor view of a library-owned live state block, materialised on first use (the world must be sealed, i.e. its
-    components registered and at least one spawn issued, before the block's address and size exist)."""
-
-    def __init__(self, world, device):
-        self.world, self.device, self._t = world, device, None
-
-    def tensor(self):
-        if self._t is None:
-            import torch
-            nbytes = self.world.state_bytes()
-            ptr = self.world.live_state_ptr()
-            self._t = torch.as_tensor(_DeviceSpan(ptr, nbytes), device=self.device)
-            assert self._t.data_ptr() == ptr and self._t.numel() == nbytes and self._t.dtype == torch.uint8
-        return self._t
-
-    # the bits of the torch.Tensor surface HipStateExchange and the tests use
-    def data_ptr(self): return self.tensor().data_ptr()
-    def __getitem__(self, k): return self.tensor()[k]
-    @property
-    def device_(self): return self.device
+def C_cast_f32(addr: int):
+    import ctypes as C
+    return C.cast(C.c_void_p(addr), C.POINTER(C.c_float))
 
 
 def default_branch_input(branch: int, frame: int) -> int:
@@ -261,7 +163,7 @@ class SpeculativeFanout:
                  confirmed_input: Callable[[int], int] = lambda frame: 0,
                  spawn_fn: Optional[Callable[[int], tuple]] = None, spawn_mask: int = 1 << 4,
                  num_players: int = 1, max_inflight: int = 1, desync_detection_interval: int = 1, native: "Optional[RcclFanout]" = None,
-                 share_prefix: bool = True):
+                 share_prefix: bool = True, retain: str = "none", compact: bool = True):
         self.w, self.dist, self.D, self.x = world, dist, depth, exchange
         self.native = native                                 # collectives inside libggrs_hip.so instead of torch.distributed (`exchange` unused)
         self.interval = max(1, desync_detection_interval)    # steps whose checksums share one all-gather (pipelined path)
@@ -273,7 +175,13 @@ class SpeculativeFanout:
         self.bpr = branches_per_rank
         # with ONE branch per rank there is nothing to share: the prefix as its own group would cost a second launch and a save / re-load of
         # C+1 (measured: 62.7 -> 87 us per step at 1 M, profiles/r04d/bench_fanout_ws1.json), so the list stays one fused group
-        self.share_prefix = bool(share_prefix) and depth >= 1 and branches_per_rank > 1
+        self.retain = {"none": 0, "newest": 2, "all": 4}[retain]    # GGRS_BRANCH_RETAIN_*: keep the branches' frames for adopt()
+        self.share_prefix = bool(share_prefix) and depth >= 1 and (branches_per_rank > 1 or self.retain != 0)
+        # the native path hands the library ONE compact description of the step (ggrs_hip_fanout_step_branches) instead of a request list of
+        # ~4 x branches x depth entries; compact=False keeps the list (what rounds 3-5 measured; retention needs the compact form)
+        self.compact = bool(compact) and native is not None and self.share_prefix
+        assert not self.retain or self.compact or native is None, "retained branch states need the compact native step"
+        self._bt = None
         # SaveGameState requests of one step's list on this rank == Checksum(u128)s it contributes to the all-gather
         self.saves_per_step = 1 + branches_per_rank * (depth - 1) if self.share_prefix else branches_per_rank * depth
         self.branch_input, self.confirmed_input = branch_input, confirmed_input
@@ -530,7 +438,64 @@ class SpeculativeFanout:
         return self._collect_one(want_result) if len(self._inflight) > self.max_inflight else None
 
     # ---- native path: ggrs_hip_fanout_step (enqueue + all-gather on a side stream inside the library) / _collect
+    # ---- the compact native step: prefix [Load(C), Advance(confirmed), Save(C+1)] + ONE table of predicted inputs [branch][frame][player bytes]
+    def _branch_template(self):
+        import ctypes as C_
+        from . import _ffi
+        D, bpr, ib, npl = self.D, self.bpr, getattr(self.w, "input_bytes", 1), self.num_players
+        spawn_fn, self.spawn_fn = self.spawn_fn, None
+        try: pre = [LoadGameState(0), self._advance(0, 0), SaveGameState(1)]
+        finally: self.spawn_fn = spawn_fn
+        arr, keep, _ = self.w.build_requests(pre)
+        t = {"arr": arr, "keep": keep, "bs": _ffi.BranchStep(), "inputs": np.zeros((bpr, D, npl * ib), dtype=np.uint8), "sel": np.zeros((bpr, D), dtype=np.uint16),
+             "table": (_ffi.BranchSpawn * D)(), "pred": None}
+        bs = t["bs"]
+        bs.prefix, bs.n_prefix, bs.n_branches, bs.n_frames, bs.n_inputs, bs.flags = arr, 3, bpr, D, npl, self.retain
+        bs.inputs = t["inputs"].ctypes.data
+        if spawn_fn is not None:
+            bs.spawn_table, bs.n_spawn_table, bs.spawn_sel = t["table"], D, t["sel"].ctypes.data
+        return t
+
+    def _native_enqueue_compact(self):
+        C = self.confirmed
+        self.w.set_confirmed(C)
+        if self._bt is None:
+            self._bt = self._branch_template()
+        t, D, ib = self._bt, self.D, getattr(self.w, "input_bytes", 1)
+        arr = t["arr"]
+        arr[0].frame, arr[2].frame = C, C + 1
+        c_in = self.confirmed_input(C)
+        q = arr[1]
+        for p in range(q.n_inputs): q.inputs[p * ib] = c_in
+        keep = []
+        if self.spawn_fn is not None:
+            if c_in & self.spawn_mask:
+                cnt, px, py, k = self._payload(C); keep.append(k)
+                q.spawn_count = cnt
+                q.spawn_vx = C_cast_f32(px); q.spawn_vy = C_cast_f32(py)
+            else:
+                q.spawn_count = 0; q.spawn_vx = None; q.spawn_vy = None
+        ids = self.branch_ids()
+        if t["pred"] is None or not getattr(self.branch_input, "frame_invariant", False):
+            # advance i of a branch takes frame C+1+i to C+2+i with the branch's predicted input of frame C+1+i
+            pred = np.array([[self.branch_input(b, C + 1 + i) for i in range(D)] for b in ids], dtype=np.uint8)
+            if t["pred"] is None or not np.array_equal(pred, t["pred"]):
+                t["pred"] = pred
+                t["inputs"][:, :, ::ib] = pred[:, :, None]
+                t["sel"][:] = np.where((pred & self.spawn_mask) != 0, np.arange(1, D + 1, dtype=np.uint16)[None, :], 0) if self.spawn_fn is not None else 0
+        if self.spawn_fn is not None:
+            for i in np.unique(np.nonzero(t["sel"])[1]) if t["sel"].any() else ():
+                cnt, px, py, k = self._payload(C + 1 + int(i)); keep.append(k)
+                e = t["table"][int(i)]
+                e.count, e.vx, e.vy = cnt, px, py
+        t["pay_keep"] = keep
+        self.native.step_branches(t["bs"])
+        self._inflight.append(C)
+        self.confirmed = C + 1
+
     def _native_enqueue(self):
+        if self.compact:
+            return self._native_enqueue_compact()
         C = self.confirmed
         self.w.set_confirmed(C)
         if self._tmpl is None:
@@ -576,7 +541,37 @@ class SpeculativeFanout:
         return out
 
     def settle(self) -> int:
-        """Bring the live world back to the confirmed frame (drops the speculative tail)."""
+        """Bring the live world back to the confirmed frame (drops the speculative tail; the compact native step leaves it there anyway)."""
         self.drain()
         self.w.handle_requests([LoadGameState(self.confirmed)])
+        return self.confirmed
+
+    # ------------------------------------------------------------------ adoption
+    def adopt(self, branch: int, k: int, broadcast: bool = False) -> int:
+        """The true inputs of frames C .. C+k-1 (C = the confirmed frame) have arrived and equal what GLOBAL branch `branch` predicted: its state of
+        frame C+k becomes the confirmed world on every rank.  Native + retain: ggrs_hip_fanout_adopt -- the owning rank swaps a ring slot for the
+        branch's retained block, the others re-simulate the k frames (or, broadcast=True, receive the block).  Worlds without retained branches (the
+        CPU test worlds of the gloo test): every rank re-simulates.  The re-simulated Checksum(u128) of frame C+k is compared with the one the branch
+        delivered through the all-gather (DesyncDetected).  Collective; returns the new confirmed frame."""
+        self.drain()
+        C = self.confirmed
+        assert 1 <= k <= self.D, (k, self.D)
+        replay = [self._advance(C + i, self.branch_input(branch, C + i)) for i in range(k)] + [SaveGameState(C + k)]
+        if self.native is not None and self.retain:
+            cs = self.native.adopt(branch, C + k, replay, mode=1 if broadcast else 0)
+        else:
+            self.w.set_confirmed(C)
+            cs = self.w.handle_requests([LoadGameState(C)] + replay)
+            self.w.set_confirmed(C + k)
+        want = None
+        if self._last_raw is not None and self._last_raw[0] == C - 1 and k <= self.D - 1:
+            # the last step started at confirmed frame C-1: branch entry 0 is frame C, entry k is frame C+k
+            r, j = divmod(branch, self.bpr)
+            p = self._last_raw[1][r, j * self.D + k]
+            want = int(p[0]) | (int(p[1]) << 64)
+        if cs and want is not None and cs[-1] != want:
+            self.synced = False
+            raise DesyncDetected(C + k, [cs[-1], want])
+        self.confirmed = C + k
+        self.adopted_checksum = want if want is not None else (cs[-1] if cs else None)
         return self.confirmed

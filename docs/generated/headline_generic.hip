@@ -14,6 +14,12 @@ GGRS_ST(st1, "global_store_byte", uint32_t, "v") GGRS_ST(st2, "global_store_shor
 #define GGRS_ST(NAME, INSN, T, C) __device__ __forceinline__ void NAME(const unsigned char* base, uint32_t lo, T v) { const unsigned long b = (unsigned long)base; asm volatile(INSN " %0, %1, %2 nt" : : "v"(lo), C(v), "s"(b) : "memory"); }
 GGRS_ST(st1nt, "global_store_byte", uint32_t, "v") GGRS_ST(st2nt, "global_store_short", uint32_t, "v") GGRS_ST(st4nt, "global_store_dword", uint32_t, "v") GGRS_ST(st8nt, "global_store_dwordx2", uint64_t, "v")
 #undef GGRS_ST
+// a batch member's record (GgrsJitArgs::mtab): written by the host before the launch, never by a kernel -- read through the constant address space,
+// i.e. with scalar loads (the record's address is wave-uniform: blockIdx.z)
+#define GGRS_K __attribute__((address_space(4)))
+__device__ __forceinline__ uint64_t mb_u64(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint64_t*)(mb + off); }
+__device__ __forceinline__ uint32_t mb_u32(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint32_t*)(mb + off); }
+__device__ __forceinline__ uint32_t mb_u8(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K unsigned char*)(mb + off); }
 namespace ggrs {
 constexpr int LT_SHIFT = 13; constexpr int LAYOUT_TILE = 1 << LT_SHIFT; constexpr uint64_t SEA_P = 0x6eed0e9da4d94a4fULL; constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cULL, SEA_K2 = 0x6fe2e5aaf078ebc9ULL, SEA_K3 = 0x14f994a4c5259381ULL; __host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) { x *= SEA_P; const uint32_t hi = (uint32_t)(x >> 32); x ^= (uint64_t)(hi >> (hi >> 28)); x *= SEA_P; return x; } __host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, uint32_t z) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_tail3(uint32_t z) { return sea_diffuse(SEA_K1 ^ (uint64_t)z); } __host__ __device__ __forceinline__ uint64_t sea_inner3_with_tail(uint32_t x, uint32_t y, uint64_t a) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) { uint64_t B = sea_diffuse(SEA_K0 ^ order); uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_order_lane(uint64_t order) { return sea_diffuse(SEA_K0 ^ order); } __host__ __device__ __forceinline__ uint64_t sea_pair_pre(uint64_t B, uint64_t inner) { uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) { uint64_t A = sea_diffuse(SEA_K0 ^ x); return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL); } struct SeaStream { uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0, tail = 0; uint32_t ntail = 0; __host__ __device__ __forceinline__ void write(uint64_t v, uint32_t nb) { if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL; tail |= v << (8 * ntail); const uint32_t tot = ntail + nb; if (tot >= 8) { const uint64_t a = sea_diffuse(s0 ^ tail); s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; const uint32_t used = 8 - ntail; tail = used >= 8 ? 0ULL : (v >> (8 * used)); ntail = tot - 8; } else ntail = tot; } __host__ __device__ __forceinline__ void unit(uint32_t u) { write(u, 4); } __host__ __device__ __forceinline__ uint64_t finish() const { const uint64_t a = ntail ? sea_diffuse(s0 ^ tail) : s0; return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + ntail)); } }; struct Header { uint64_t len; int32_t frame; uint32_t pad0; uint64_t active; uint64_t checksum[2]; }; __device__ __forceinline__ uint32_t wave_xor32(uint32_t v) { v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); } __device__ __forceinline__ uint64_t wave_xor(uint64_t v) { return ((uint64_t)wave_xor32((uint32_t)(v >> 32)) << 32) | wave_xor32((uint32_t)v); } constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3; __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in, float dt, float fp, float accel, float max_speed, float half_width) { const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT; const float adt = __fmul_rn(accel, dt); if (up && !down) vz = __fsub_rn(vz, adt); if (!up && down) vz = __fadd_rn(vz, adt); if (left && !right) vx = __fsub_rn(vx, adt); if (!left && right) vx = __fadd_rn(vx, adt); if (!up && !down) vz = __fmul_rn(vz, fp); if (!left && !right) vx = __fmul_rn(vx, fp); vy = __fmul_rn(vy, fp); const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)); if (len_sq > __fmul_rn(max_speed, max_speed)) { const float l = sqrtf(len_sq); vx = __fmul_rn(max_speed, vx / l); vy = __fmul_rn(max_speed, vy / l); vz = __fmul_rn(max_speed, vz / l); } x = __fadd_rn(x, __fmul_rn(vx, dt)); y = __fadd_rn(y, __fmul_rn(vy, dt)); z = __fadd_rn(z, __fmul_rn(vz, dt)); const float lo = -half_width, hi = half_width; if (x < lo) x = lo; if (x > hi) x = hi; if (z < lo) z = lo; if (z > hi) z = hi; } constexpr uint32_t FF_CHUNK = 1024; __device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* out, uint64_t* tag, uint64_t seq) { const uint32_t tid = threadIdx.x, lane = tid & 63u; __shared__ unsigned long long ff_acc; if (tid == 0) ff_acc = 0ull; __syncthreads(); uint64_t x = 0, sum = 0; constexpr int INFL = 4; for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) { uint64_t v[INFL]; _Pragma("unroll") for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < hi ? p[(uint64_t)i * istride] : 0ULL; } _Pragma("unroll") for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; } } if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); } else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); } __syncthreads(); if (tid == 0) { __hip_atomic_store(out, (uint64_t)ff_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(tag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
 }
@@ -82,6 +88,7 @@ struct GgrsWords {
 struct GgrsJitArgs {
     const unsigned char* src;
     unsigned char* live;
+    const unsigned char* mtab;
     ggrs_u64* parts;
     const ggrs_u64* ff_rows;
     ggrs_u64* ff_out;
@@ -117,43 +124,44 @@ struct GgrsJitArgs {
     ggrs_u32 dt_bits[11];
     int step_frame[11];
 };
-static_assert(sizeof(GgrsJitArgs) == 568, "host/device argument block mismatch");
+static_assert(sizeof(GgrsJitArgs) == 576, "host/device argument block mismatch");
 static_assert(__builtin_offsetof(GgrsJitArgs, src) == 0, "argument block: offset of src");
 static_assert(__builtin_offsetof(GgrsJitArgs, live) == 8, "argument block: offset of live");
-static_assert(__builtin_offsetof(GgrsJitArgs, parts) == 16, "argument block: offset of parts");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_rows) == 24, "argument block: offset of ff_rows");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_out) == 32, "argument block: offset of ff_out");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_seq) == 40, "argument block: offset of ff_seq");
-static_assert(__builtin_offsetof(GgrsJitArgs, live_rows) == 48, "argument block: offset of live_rows");
-static_assert(__builtin_offsetof(GgrsJitArgs, load_rows) == 56, "argument block: offset of load_rows");
-static_assert(__builtin_offsetof(GgrsJitArgs, op_bits) == 64, "argument block: offset of op_bits");
-static_assert(__builtin_offsetof(GgrsJitArgs, len) == 72, "argument block: offset of len");
-static_assert(__builtin_offsetof(GgrsJitArgs, save_dst) == 80, "argument block: offset of save_dst");
-static_assert(__builtin_offsetof(GgrsJitArgs, save_rows) == 160, "argument block: offset of save_rows");
-static_assert(__builtin_offsetof(GgrsJitArgs, save_len) == 240, "argument block: offset of save_len");
-static_assert(__builtin_offsetof(GgrsJitArgs, save_frame) == 320, "argument block: offset of save_frame");
-static_assert(__builtin_offsetof(GgrsJitArgs, save_pmask) == 360, "argument block: offset of save_pmask");
-static_assert(__builtin_offsetof(GgrsJitArgs, live_pmask) == 400, "argument block: offset of live_pmask");
-static_assert(__builtin_offsetof(GgrsJitArgs, nt_loads) == 404, "argument block: offset of nt_loads");
-static_assert(__builtin_offsetof(GgrsJitArgs, n_ops) == 408, "argument block: offset of n_ops");
-static_assert(__builtin_offsetof(GgrsJitArgs, n_saves) == 412, "argument block: offset of n_saves");
-static_assert(__builtin_offsetof(GgrsJitArgs, n_steps) == 416, "argument block: offset of n_steps");
-static_assert(__builtin_offsetof(GgrsJitArgs, src_is_live) == 420, "argument block: offset of src_is_live");
-static_assert(__builtin_offsetof(GgrsJitArgs, skip_live) == 424, "argument block: offset of skip_live");
-static_assert(__builtin_offsetof(GgrsJitArgs, dp_s) == 428, "argument block: offset of dp_s");
-static_assert(__builtin_offsetof(GgrsJitArgs, part_stride) == 432, "argument block: offset of part_stride");
-static_assert(__builtin_offsetof(GgrsJitArgs, part_tstride) == 436, "argument block: offset of part_tstride");
-static_assert(__builtin_offsetof(GgrsJitArgs, nt) == 440, "argument block: offset of nt");
-static_assert(__builtin_offsetof(GgrsJitArgs, n_units) == 444, "argument block: offset of n_units");
-static_assert(__builtin_offsetof(GgrsJitArgs, cached_saves) == 448, "argument block: offset of cached_saves");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_blocks) == 452, "argument block: offset of ff_blocks");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_nvals) == 456, "argument block: offset of ff_nvals");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_g) == 460, "argument block: offset of ff_g");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_stride) == 464, "argument block: offset of ff_stride");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_istride) == 468, "argument block: offset of ff_istride");
-static_assert(__builtin_offsetof(GgrsJitArgs, ff_split) == 472, "argument block: offset of ff_split");
-static_assert(__builtin_offsetof(GgrsJitArgs, dt_bits) == 476, "argument block: offset of dt_bits");
-static_assert(__builtin_offsetof(GgrsJitArgs, step_frame) == 520, "argument block: offset of step_frame");
+static_assert(__builtin_offsetof(GgrsJitArgs, mtab) == 16, "argument block: offset of mtab");
+static_assert(__builtin_offsetof(GgrsJitArgs, parts) == 24, "argument block: offset of parts");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_rows) == 32, "argument block: offset of ff_rows");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_out) == 40, "argument block: offset of ff_out");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_seq) == 48, "argument block: offset of ff_seq");
+static_assert(__builtin_offsetof(GgrsJitArgs, live_rows) == 56, "argument block: offset of live_rows");
+static_assert(__builtin_offsetof(GgrsJitArgs, load_rows) == 64, "argument block: offset of load_rows");
+static_assert(__builtin_offsetof(GgrsJitArgs, op_bits) == 72, "argument block: offset of op_bits");
+static_assert(__builtin_offsetof(GgrsJitArgs, len) == 80, "argument block: offset of len");
+static_assert(__builtin_offsetof(GgrsJitArgs, save_dst) == 88, "argument block: offset of save_dst");
+static_assert(__builtin_offsetof(GgrsJitArgs, save_rows) == 168, "argument block: offset of save_rows");
+static_assert(__builtin_offsetof(GgrsJitArgs, save_len) == 248, "argument block: offset of save_len");
+static_assert(__builtin_offsetof(GgrsJitArgs, save_frame) == 328, "argument block: offset of save_frame");
+static_assert(__builtin_offsetof(GgrsJitArgs, save_pmask) == 368, "argument block: offset of save_pmask");
+static_assert(__builtin_offsetof(GgrsJitArgs, live_pmask) == 408, "argument block: offset of live_pmask");
+static_assert(__builtin_offsetof(GgrsJitArgs, nt_loads) == 412, "argument block: offset of nt_loads");
+static_assert(__builtin_offsetof(GgrsJitArgs, n_ops) == 416, "argument block: offset of n_ops");
+static_assert(__builtin_offsetof(GgrsJitArgs, n_saves) == 420, "argument block: offset of n_saves");
+static_assert(__builtin_offsetof(GgrsJitArgs, n_steps) == 424, "argument block: offset of n_steps");
+static_assert(__builtin_offsetof(GgrsJitArgs, src_is_live) == 428, "argument block: offset of src_is_live");
+static_assert(__builtin_offsetof(GgrsJitArgs, skip_live) == 432, "argument block: offset of skip_live");
+static_assert(__builtin_offsetof(GgrsJitArgs, dp_s) == 436, "argument block: offset of dp_s");
+static_assert(__builtin_offsetof(GgrsJitArgs, part_stride) == 440, "argument block: offset of part_stride");
+static_assert(__builtin_offsetof(GgrsJitArgs, part_tstride) == 444, "argument block: offset of part_tstride");
+static_assert(__builtin_offsetof(GgrsJitArgs, nt) == 448, "argument block: offset of nt");
+static_assert(__builtin_offsetof(GgrsJitArgs, n_units) == 452, "argument block: offset of n_units");
+static_assert(__builtin_offsetof(GgrsJitArgs, cached_saves) == 456, "argument block: offset of cached_saves");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_blocks) == 460, "argument block: offset of ff_blocks");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_nvals) == 464, "argument block: offset of ff_nvals");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_g) == 468, "argument block: offset of ff_g");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_stride) == 472, "argument block: offset of ff_stride");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_istride) == 476, "argument block: offset of ff_istride");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_split) == 480, "argument block: offset of ff_split");
+static_assert(__builtin_offsetof(GgrsJitArgs, dt_bits) == 484, "argument block: offset of dt_bits");
+static_assert(__builtin_offsetof(GgrsJitArgs, step_frame) == 528, "argument block: offset of step_frame");
 #line 1 "ggrs_jit_tick"
 extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -169,6 +177,8 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
         return;
     }
     const uint32_t bx = blockIdx.x - a.ff_blocks, gx = gridDim.x - a.ff_blocks;
+    // batch members (blockIdx.z) with records: what differs between the launch's groups comes from member z's record, the rest from the argument block
+    const GGRS_K unsigned char* const mb = a.mtab ? (const GGRS_K unsigned char*)(unsigned long)(a.mtab + (uint64_t)blockIdx.z * 304ull) : (const GGRS_K unsigned char*)0ul;
     const bool writes_live = (!a.src_is_live || a.n_steps) && !a.skip_live;
     const uint32_t o_first = a.dp_s ? blockIdx.y * a.dp_s : 0u;          // depth-parallel roles: this workgroup's share of the outputs
     const uint32_t o_last = a.dp_s ? min(o_first + a.dp_s, a.n_saves + 1u) : a.n_saves + 1u;
@@ -292,10 +302,11 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
             // ---------------- SaveWorld
             if (si < o_first) { ++si; continue; }                          // another role's snapshot
             if (si >= o_last) break;
-            unsigned char* dst = a.save_dst[si];
             const uint64_t alive_now = __ballot(alive_0);
+            unsigned char* dst = mb ? (unsigned char*)mb_u64(mb, 0u + 8u * si) : a.save_dst[si];
             if (dst) {
-                const uint64_t rows = a.save_rows[si];
+                const uint64_t rows = mb ? mb_u64(mb, 80u + 8u * si) : a.save_rows[si];
+                const uint32_t pmask_s = mb ? mb_u32(mb, 256u + 4u * si) : a.save_pmask[si];
                 if (in_len) {
                     if (a.nt && !((a.cached_saves >> si) & 1u)) {
                         if (rows == 0x3c07ull) {
@@ -351,12 +362,12 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
                 }
                 if (lane == 0) {
                     *reinterpret_cast<uint64_t*>(dst + 256ull + wi8) = alive_now;
-                    if ((a.save_pmask[si] >> 0u) & 1u) *reinterpret_cast<uint64_t*>(dst + 126208ull + wi8) = mk0;
-                    if ((a.save_pmask[si] >> 1u) & 1u) *reinterpret_cast<uint64_t*>(dst + 252160ull + wi8) = mk1;
-                    if ((a.save_pmask[si] >> 2u) & 1u) *reinterpret_cast<uint64_t*>(dst + 378112ull + wi8) = mk2;
+                    if ((pmask_s >> 0u) & 1u) *reinterpret_cast<uint64_t*>(dst + 126208ull + wi8) = mk0;
+                    if ((pmask_s >> 1u) & 1u) *reinterpret_cast<uint64_t*>(dst + 252160ull + wi8) = mk1;
+                    if ((pmask_s >> 2u) & 1u) *reinterpret_cast<uint64_t*>(dst + 378112ull + wi8) = mk2;
                 }
                 if (gu == 0 && lane == 0) {
-                    Header h; h.len = a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
+                    Header h; h.len = mb ? mb_u64(mb, 160u + 8u * si) : a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;
                     *reinterpret_cast<Header*>(dst) = h;
                 }
             }
@@ -397,37 +408,40 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     // ---- the live world, written once
     if (my_live && writes_live) {
         const uint64_t alive_now = __ballot(alive_0);
+        unsigned char* const live_p = mb ? (unsigned char*)mb_u64(mb, 240u) : a.live;
+        const uint64_t live_rows_v = mb ? mb_u64(mb, 248u) : a.live_rows;
+        const uint32_t live_pm_v = mb ? mb_u32(mb, 296u) : a.live_pmask;
         if (in_len) {
-            if (a.live_rows == 0x3c07ull) {
-                st4(b0(a.live), lo4, w0_0);
-                st4(b1(a.live), lo4, w1_0);
-                st4(b2(a.live), lo4, w2_0);
-                st4(b10(a.live), lo4, w10_0);
-                st4(b11(a.live), lo4, w11_0);
-                st4(b12(a.live), lo4, w12_0);
-                st8(b13(a.live), lo8, w13_0);
+            if (live_rows_v == 0x3c07ull) {
+                st4(b0(live_p), lo4, w0_0);
+                st4(b1(live_p), lo4, w1_0);
+                st4(b2(live_p), lo4, w2_0);
+                st4(b10(live_p), lo4, w10_0);
+                st4(b11(live_p), lo4, w11_0);
+                st4(b12(live_p), lo4, w12_0);
+                st8(b13(live_p), lo8, w13_0);
             } else {
-                if ((a.live_rows >> 0u) & 1ull) st4(b0(a.live), lo4, w0_0);
-                if ((a.live_rows >> 1u) & 1ull) st4(b1(a.live), lo4, w1_0);
-                if ((a.live_rows >> 2u) & 1ull) st4(b2(a.live), lo4, w2_0);
-                if ((a.live_rows >> 3u) & 1ull) st4(b3(a.live), lo4, w3_0);
-                if ((a.live_rows >> 4u) & 1ull) st4(b4(a.live), lo4, w4_0);
-                if ((a.live_rows >> 5u) & 1ull) st4(b5(a.live), lo4, w5_0);
-                if ((a.live_rows >> 6u) & 1ull) st4(b6(a.live), lo4, w6_0);
-                if ((a.live_rows >> 7u) & 1ull) st4(b7(a.live), lo4, w7_0);
-                if ((a.live_rows >> 8u) & 1ull) st4(b8(a.live), lo4, w8_0);
-                if ((a.live_rows >> 9u) & 1ull) st4(b9(a.live), lo4, w9_0);
-                if ((a.live_rows >> 10u) & 1ull) st4(b10(a.live), lo4, w10_0);
-                if ((a.live_rows >> 11u) & 1ull) st4(b11(a.live), lo4, w11_0);
-                if ((a.live_rows >> 12u) & 1ull) st4(b12(a.live), lo4, w12_0);
-                if ((a.live_rows >> 13u) & 1ull) st8(b13(a.live), lo8, w13_0);
+                if ((live_rows_v >> 0u) & 1ull) st4(b0(live_p), lo4, w0_0);
+                if ((live_rows_v >> 1u) & 1ull) st4(b1(live_p), lo4, w1_0);
+                if ((live_rows_v >> 2u) & 1ull) st4(b2(live_p), lo4, w2_0);
+                if ((live_rows_v >> 3u) & 1ull) st4(b3(live_p), lo4, w3_0);
+                if ((live_rows_v >> 4u) & 1ull) st4(b4(live_p), lo4, w4_0);
+                if ((live_rows_v >> 5u) & 1ull) st4(b5(live_p), lo4, w5_0);
+                if ((live_rows_v >> 6u) & 1ull) st4(b6(live_p), lo4, w6_0);
+                if ((live_rows_v >> 7u) & 1ull) st4(b7(live_p), lo4, w7_0);
+                if ((live_rows_v >> 8u) & 1ull) st4(b8(live_p), lo4, w8_0);
+                if ((live_rows_v >> 9u) & 1ull) st4(b9(live_p), lo4, w9_0);
+                if ((live_rows_v >> 10u) & 1ull) st4(b10(live_p), lo4, w10_0);
+                if ((live_rows_v >> 11u) & 1ull) st4(b11(live_p), lo4, w11_0);
+                if ((live_rows_v >> 12u) & 1ull) st4(b12(live_p), lo4, w12_0);
+                if ((live_rows_v >> 13u) & 1ull) st8(b13(live_p), lo8, w13_0);
             }
         }
         if (lane == 0) {
-            *reinterpret_cast<uint64_t*>(a.live + 256ull + wi8) = alive_now;
-            if ((a.live_pmask >> 0u) & 1u) *reinterpret_cast<uint64_t*>(a.live + 126208ull + wi8) = mk0;
-            if ((a.live_pmask >> 1u) & 1u) *reinterpret_cast<uint64_t*>(a.live + 252160ull + wi8) = mk1;
-            if ((a.live_pmask >> 2u) & 1u) *reinterpret_cast<uint64_t*>(a.live + 378112ull + wi8) = mk2;
+            *reinterpret_cast<uint64_t*>(live_p + 256ull + wi8) = alive_now;
+            if ((live_pm_v >> 0u) & 1u) *reinterpret_cast<uint64_t*>(live_p + 126208ull + wi8) = mk0;
+            if ((live_pm_v >> 1u) & 1u) *reinterpret_cast<uint64_t*>(live_p + 252160ull + wi8) = mk1;
+            if ((live_pm_v >> 2u) & 1u) *reinterpret_cast<uint64_t*>(live_p + 378112ull + wi8) = mk2;
         }
     }
     }   // the wave's unit

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GGRS_HIP_ABI_VERSION 8
+#define GGRS_HIP_ABI_VERSION 9
 
 /* limits */
 #define GGRS_MAX_COMPONENTS 32
@@ -439,6 +439,64 @@ const char* ggrs_hip_fanout_last_error(ggrs_fanout* f);
 /* what the communicator itself says (ncclCommUserRank / ncclCommCount) and the HIP device the world runs on: bench.py prints
  * n_gpus from here, not from the environment. */
 int  ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int* device_out);
+
+/* ---- A step in compact form, branch states that are KEPT, and adoption ("each branch ... on a private scratch copy", "when the true input
+ * arrives, the matching branch's state is adopted (device-local pointer swap on the owning rank + broadcast if ranks must stay replicated)").
+ *
+ * ggrs_hip_fanout_step_branches is ggrs_hip_fanout_step for the list
+ *     prefix[0 .. n_prefix)                                                      any requests: they run first, through the ordinary path (ring, counters), and
+ *                                                                                must leave a snapshot of the frame F the world is then at (end them with SaveGameState)
+ *     per branch b:  LoadGameState(F), (AdvanceFrame(inputs[b][i]), SaveGameState(F+1+i)) x n_frames      -- the last SaveGameState only with GGRS_BRANCH_SAVE_LAST
+ * without ~ 4 x n_branches x n_frames requests crossing the ABI: the library expands it, and ALL branches ride in ONE launch of the world's generated kernel whatever
+ * their inputs and spawns are (one record per branch in device memory).  The branches are speculation, not history: they do not touch the world's ring or its
+ * frame counters -- after the call the world is where the prefix left it (frame F, live world and newest snapshot = F), so no "settle" load is needed.
+ * Checksum order of the step: the prefix's SaveGameStates, then branch 0's, branch 1's, ...  (what the request list above would have produced).
+ *     inputs       [n_branches][n_frames][n_inputs x input_bytes]   predicted PlayerInputs of frame F+i of branch b
+ *     status       [n_branches][n_frames][n_inputs] InputStatus bytes, or NULL (every input Confirmed, as for ggrs_request::status)
+ *     spawn_sel    [n_branches][n_frames] or NULL: 0 = the world's spawn system does not fire in that frame of that branch, j = it appends spawn_table[j - 1]
+ *                  (the host decides, as with ggrs_request::spawn_count; a rolled-back RNG makes the payload a function of the frame, so branches share entries)
+ * GGRS_BRANCH_RETAIN_ALL keeps every frame a branch produces -- each SaveGameState's snapshot and, without GGRS_BRANCH_SAVE_LAST, the state after the last AdvanceFrame --
+ * in private packed state blocks outside the ring (state_bytes each, allocated on first use, owned by the world); GGRS_BRANCH_RETAIN_NEWEST only the last frame (F + n_frames).
+ * Row versions apply: a column no system writes reaches a branch block once.  They stay valid until the next step of this fan-out.
+ * Needs the generated kernel and a world without live-only state (RollbackDespawned markers, GGRS_COMP_NO_ROLLBACK components): GGRS_E_INVALID otherwise.
+ *
+ * ggrs_hip_fanout_adopt: the true inputs of frames F .. frame-1 have arrived and equal what `branch` (GLOBAL index: rank x n_branches + local index of the LAST step)
+ * predicted: that branch's retained state of `frame` becomes the world -- RollbackFrameCount = ConfirmedFrameCount = frame, a snapshot of `frame` in the ring, the live
+ * world loaded from it (what LoadGameState leaves behind, schedule_systems.rs:238-250).  Collective: every rank calls it with the same arguments, no step in flight.
+ *   on the OWNING rank      the retained block trades places with a ring slot (no bytes move) + one LoadWorld launch
+ *   on the other ranks      GGRS_ADOPT_RECOMPUTE (default): `replay` -- the caller's request list that re-simulates F -> frame with the confirmed inputs and ends with
+ *                           SaveGameState(frame), typically [AdvanceFrame x (frame - F), SaveGameState(frame)] -- runs through the ordinary path: no bytes cross xGMI, and
+ *                           its Checksum(u128)s (checksums_out, {lo, hi} per SaveGameState of replay; *n_checksums_out = 0 on the owner) can be compared with the
+ *                           branch's gathered ones: a free desync check.  GGRS_ADOPT_BROADCAST: ONE ncclBroadcast of the owner's packed block (state_bytes) into a ring
+ *                           slot of every other rank, for worlds whose re-simulation costs more than the block's trip over one xGMI link (replay is ignored). */
+typedef struct {
+    uint64_t count;                  /* entities the spawn system appends                                                  */
+    const float* vx;                 /* GGRS_SYS_PARTICLES_SPAWN: count f32 each (as ggrs_request::spawn_vx / _vy)         */
+    const float* vy;
+    const void* payload;             /* a user-written spawn system's payload (as ggrs_request::spawn_payload)             */
+    uint64_t payload_bytes;
+} ggrs_branch_spawn;
+#define GGRS_BRANCH_SAVE_LAST      1u
+#define GGRS_BRANCH_RETAIN_NEWEST  2u
+#define GGRS_BRANCH_RETAIN_ALL     4u
+typedef struct {
+    const ggrs_request* prefix;
+    uint32_t n_prefix;
+    uint32_t n_branches;
+    uint32_t n_frames;
+    uint32_t n_inputs;
+    uint32_t flags;                  /* GGRS_BRANCH_* */
+    uint32_t n_spawn_table;
+    const uint8_t* inputs;
+    const uint8_t* status;
+    const ggrs_branch_spawn* spawn_table;
+    const uint16_t* spawn_sel;
+} ggrs_branch_step;
+int  ggrs_hip_fanout_step_branches(ggrs_fanout* f, const ggrs_branch_step* step, uint32_t* n_saves_out);
+#define GGRS_ADOPT_RECOMPUTE 0u
+#define GGRS_ADOPT_BROADCAST 1u
+int  ggrs_hip_fanout_adopt(ggrs_fanout* f, uint32_t branch, int32_t frame, uint32_t mode, const ggrs_request* replay, uint32_t n_replay,
+                           uint64_t* checksums_out, uint32_t* n_checksums_out);
 
 /* -------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): per-kernel-class HIP-event timing on the world's stream.

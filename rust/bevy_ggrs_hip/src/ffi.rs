@@ -1,9 +1,9 @@
-//! Raw bindings to `include/ggrs_hip.h` (ABI version 8) -- what `bindgen` emits, by hand.
+//! Raw bindings to `include/ggrs_hip.h` (ABI version 9) -- what `bindgen` emits, by hand.
 //! UN-BUILT SOURCE: kept in lock-step with the header by tests/test_abi.py.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
 
-pub const GGRS_HIP_ABI_VERSION: c_int = 8;
+pub const GGRS_HIP_ABI_VERSION: c_int = 9;
 
 pub const GGRS_OK: c_int = 0;
 pub const GGRS_E_INVALID: c_int = -1;
@@ -44,6 +44,12 @@ pub const GGRS_REQ_LOAD: u32 = 2;
 pub const GGRS_REQ_ADVANCE: u32 = 3;
 
 pub const GGRS_KERNEL_CLASSES: usize = 5;
+
+pub const GGRS_BRANCH_SAVE_LAST: u32 = 1;
+pub const GGRS_BRANCH_RETAIN_NEWEST: u32 = 2;
+pub const GGRS_BRANCH_RETAIN_ALL: u32 = 4;
+pub const GGRS_ADOPT_RECOMPUTE: u32 = 0;
+pub const GGRS_ADOPT_BROADCAST: u32 = 1;
 
 #[repr(C)]
 pub struct ggrs_fanout {
@@ -117,6 +123,34 @@ pub struct ggrs_request {
     pub spawn_vy: *const f32,
     pub spawn_payload: *const c_void,
     pub spawn_payload_bytes: u64,
+}
+
+/// One entry of a branch step's spawn table: what the world's spawn system appends in a frame (shared by every branch that spawns there).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ggrs_branch_spawn {
+    pub count: u64,
+    pub vx: *const f32,
+    pub vy: *const f32,
+    pub payload: *const c_void,
+    pub payload_bytes: u64,
+}
+
+/// `ggrs_hip_fanout_step_branches`: a prefix request list + n_branches x n_frames predicted inputs, expanded by the library.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ggrs_branch_step {
+    pub prefix: *const ggrs_request,
+    pub n_prefix: u32,
+    pub n_branches: u32,
+    pub n_frames: u32,
+    pub n_inputs: u32,
+    pub flags: u32,
+    pub n_spawn_table: u32,
+    pub inputs: *const u8,
+    pub status: *const u8,
+    pub spawn_table: *const ggrs_branch_spawn,
+    pub spawn_sel: *const u16,
 }
 
 impl ggrs_request {
@@ -195,6 +229,8 @@ unsafe extern "C" {
     pub fn ggrs_hip_fanout_destroy(f: *mut ggrs_fanout);
     pub fn ggrs_hip_fanout_last_error(f: *mut ggrs_fanout) -> *const c_char;
     pub fn ggrs_hip_fanout_comm_info(f: *mut ggrs_fanout, rank_out: *mut c_int, size_out: *mut c_int, device_out: *mut c_int) -> c_int;
+    pub fn ggrs_hip_fanout_step_branches(f: *mut ggrs_fanout, step: *const ggrs_branch_step, n_saves_out: *mut u32) -> c_int;
+    pub fn ggrs_hip_fanout_adopt(f: *mut ggrs_fanout, branch: u32, frame: i32, mode: u32, replay: *const ggrs_request, n_replay: u32, checksums_out: *mut u64, n_checksums_out: *mut u32) -> c_int;
     // ---- measurement hooks
     pub fn ggrs_hip_profile_enable(w: *mut ggrs_world, on: c_int) -> c_int;
     pub fn ggrs_hip_profile_read(w: *mut ggrs_world, ms_out: *mut f64, launches_out: *mut u64) -> c_int;

@@ -29,10 +29,11 @@ def test_header_symbols_all_exported_and_bound():
 
 
 def test_abi_version_and_struct_sizes():
-    assert _ffi.lib.ggrs_hip_abi_version() == 8
+    assert _ffi.lib.ggrs_hip_abi_version() == 9
     assert C.sizeof(_ffi.Request) == 72 and C.sizeof(_ffi.SpawnSystemDesc) == 128
     assert C.sizeof(_ffi.SystemDesc) == 72
     assert C.sizeof(_ffi.WorldDesc) == 48
+    assert C.sizeof(_ffi.BranchSpawn) == 40 and C.sizeof(_ffi.BranchStep) == 64
 
 
 def test_no_cpu_fallback_without_device():
@@ -74,7 +75,7 @@ def test_rust_ffi_declares_every_header_symbol():
         assert m and int(m.group(1)) == int(const[1]), const
 
 
-_C2RS = {"int": "c_int", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "float": "f32", "double": "f64",
+_C2RS = {"int": "c_int", "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "float": "f32", "double": "f64",
          "char": "c_char", "void": "c_void"}
 
 
@@ -159,7 +160,7 @@ def test_rust_ffi_signatures_and_struct_layouts_match_the_header():
         r_ret, r_params = r_fns[name]
         assert r_ret == ret, f"{name}: returns {r_ret} in ffi.rs, {ret} per the header"
         assert r_params == params, f"{name}: ffi.rs {r_params} vs header {params}"
-    for sname in ("ggrs_world_desc", "ggrs_system_desc", "ggrs_custom_system_desc", "ggrs_spawn_system_desc", "ggrs_request"):
+    for sname in ("ggrs_world_desc", "ggrs_system_desc", "ggrs_custom_system_desc", "ggrs_spawn_system_desc", "ggrs_request", "ggrs_branch_spawn", "ggrs_branch_step"):
         assert sname in c_structs and sname in r_structs, sname
         c = [(n, t.replace("[u32; 4]", "[u32; 4]")) for n, t in c_structs[sname]]
         assert r_structs[sname] == c, f"{sname}: ffi.rs {r_structs[sname]} vs header {c}"

@@ -224,6 +224,55 @@ def test_fanout_two_ranks_matches_serial_walk(bpr, pipelined):
         assert last[0] == last[2] == last[4] and last[1] == last[3] == last[5]
 
 
+def _adopt_worker(rank, world_size, port, n, D, bpr, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        import common as cm
+        import fanout_scenarios as fs
+        from bevy_ggrs_amd.fanout import SpeculativeFanout
+        from oracle.binding import OracleWorld
+        cap = n + 100 * (steps * D + D + 8) * 2
+        w = OracleWorld(cap, D + 1)
+        ids = fs.build_world(w, n, rank == 0)
+        fan = SpeculativeFanout(w, dist, D, HostExchange(w, ids), branches_per_rank=bpr, branch_input=fs.branch_input, confirmed_input=fs.true_input,
+                                spawn_fn=cm.frame_spawn_fn(fs.RATE))
+        seen = fs.run_adopt_session(fan, world_size * bpr, steps)
+        for _ in range(2):
+            o = fan.step(); seen.append((o["confirmed_frame"], o["confirmed_checksum"]))
+        fan.settle()
+        q.put((rank, seen, cm.snapshot_state(w, ids)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_adopt_two_ranks_matches_the_straight_line_simulation():
+    """SpeculativeFanout.adopt's control flow at world size 2 over gloo (oracle worlds keep no branch states: every rank re-simulates the adopted frames,
+    what the non-owning ranks of the C-ABI path do): confirm -- speculate -- adopt rounds under a scripted true-input sequence end, on every rank, in the
+    state and with the checksums of ONE world that simulated the true inputs frame by frame.  tests/test_gpu_zfanout.py runs the same script through
+    ggrs_hip_fanout_adopt at world sizes 1, 2, 3 and 8."""
+    import common as cm
+    import fanout_scenarios as fs
+    n, D, bpr, steps = 500, 5, 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7) % 2000
+    procs = [ctx.Process(target=_adopt_worker, args=(r, 2, port, n, D, bpr, steps, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    seen0 = res[0][1]
+    assert any(b - a > 1 for (a, _), (b, _) in zip(seen0, seen0[1:])), "no adoption jumped more than one frame"
+    cap = n + 100 * (steps * D + D + 8) * 2
+    cs, _, _ = fs.straight_line_reference(n, max(f for f, _ in seen0) - 3 + 1, cap)
+    for rank, seen, state in res:
+        assert seen == seen0
+        for f, c in seen:
+            assert c is None or cs[f] == c, (rank, f)
+        cm.assert_states_equal(state, fs.state_at(n, state["frame"], cap), f"rank {rank}")
+
+
 def test_fanout_detects_replica_desync():
     res = _run(2, n=300, D=3, bpr=1, steps=5, corrupt=2)
     for rank, out, err, _ in res:

@@ -99,7 +99,7 @@ def test_kernel_specialised_for_the_steady_tick_builds(name):
 
 
 # the argument-block fields a specialised kernel turns into literals: kernel_gen.hpp kJitShapeScalars / kJitShapeArrays
-SHAPE_SCALARS = ("op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads")
+SHAPE_SCALARS = ("op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads", "mtab")
 SHAPE_ARRAYS = ("save_rows", "save_pmask")
 
 
@@ -137,7 +137,8 @@ def test_specialiser_substitutes_whole_tokens_and_nothing_else(name):
     n_ops, op_bits, n_saves, rows, live, load, pm, lpm, nt, cached, ntl, dps = (int(m.group(i), 16 if i in (2, 4, 5, 6, 7, 8, 10) else 10) for i in range(1, 13))
     assert n_ops == 2 * n_saves + 1 and op_bits == sum(1 << (2 * k) for k in range(n_saves + 1)), "the steady SyncTest tick: Advance, (Save, Advance) x D"
     lit = {"op_bits": f"0x{op_bits:x}ull", "n_ops": f"{n_ops}u", "n_saves": f"{n_saves}u", "n_steps": f"{bin(op_bits).count('1')}u", "src_is_live": "0u", "skip_live": "1u" if m.group(13) == "left unwritten" else "0u", "dp_s": f"{dps}u",
-           "nt": f"{nt}u", "cached_saves": f"{cached}u", "live_rows": f"0x{live:x}ull", "load_rows": f"0x{load:x}ull", "live_pmask": f"{lpm}u", "nt_loads": f"{ntl}u"}
+           "nt": f"{nt}u", "cached_saves": f"{cached}u", "live_rows": f"0x{live:x}ull", "load_rows": f"0x{load:x}ull", "live_pmask": f"{lpm}u", "nt_loads": f"{ntl}u",
+           "mtab": "((const unsigned char*)0)"}                      # a specialised copy serves plain launches only: no member records
     want = gbody
     want = re.sub(r"(?<![\w.])a\.save_rows\[si\]", f"0x{rows:x}ull", want)
     want = re.sub(r"(?<![\w.])a\.save_pmask\[si\]", f"{pm}u", want)

@@ -1,7 +1,7 @@
-"""RCCL leg of the speculative fan-out on the one GPU a gpurun box has: world_size 1 over the
-nccl backend exercises the torch-arena world, the in-place broadcast of the packed state
-block, adopt_live_state and the all-gather; results must equal the oracle's serial walk
-(tests/test_fanout_gloo.py covers world_size 2 control flow on CPU)."""
+"""The speculative fan-out through the C ABI (ggrs_hip_fanout_*: RCCL is called inside libggrs_hip.so) on the one GPU a gpurun box has: world size 1 over
+the real RCCL, world sizes 2 / 3 / 8 over a shared-memory stand-in for librccl (tests/cpp/rccl_double.cpp; RCCL refuses two ranks per device).  Every
+gathered Checksum(u128) table must equal the oracle's serial walk of every branch; adopted branch states must equal the oracle's straight-line simulation
+with the true inputs (tests/test_fanout_gloo.py covers the world-size-2 control flow on CPU).  torch.distributed carries no data here."""
 import os
 
 import numpy as np
@@ -13,107 +13,44 @@ import common as cm
 pytestmark = pytest.mark.gpu
 
 
-def test_state_block_roundtrip_through_torch_arena_and_nccl():
+class _DeviceSpan:
+    """A raw device allocation presented through __cuda_array_interface__ so torch can alias it without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def test_state_block_roundtrip_library_and_caller_arena():
+    """ggrs_hip_state_bytes / _live_state_ptr / _adopt_live_state: a second world -- on a CALLER-provided arena (a torch tensor) -- adopts the first one's
+    packed live block byte for byte (what a rank does with a block that reached it by other means than the library's own broadcast)."""
     import torch
-    import torch.distributed as dist
-    from bevy_ggrs_amd.fanout import HipStateExchange, SpeculativeFanout, make_torch_world
-    from test_fanout_gloo import _serial_reference
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 50))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        n, D, steps, bpr = 700, 4, 6, 2
-        cap = n + 100 * (steps + D + 2) * 2
-        w, arena = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0))
-        ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
-        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
-        cm.spawn_particles(w, ids, n, vel, ttl)
-        for _ in range(3):
-            w.advance((0,))
-        fan = SpeculativeFanout(w, dist, D, HipStateExchange(w, arena), branches_per_rank=bpr,
-                                branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
-                                confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
-                                spawn_fn=cm.frame_spawn_fn(50))
-        # first half synchronously, second half with one step in flight (enqueue k+1, then collect + all-gather k)
-        out = [fan.step() for _ in range(steps // 2)]
-        fan.results.clear()
-        for _ in range(steps - steps // 2):
-            fan.step_pipelined()
-        fan.drain()
-        out += fan.results                                  # every step the pipelined path completed, in order
-        fan.settle()
-        ref, ref_state = _serial_reference(n, D, bpr, steps)
-        assert len(out) == len(ref) == steps
-        for got, want in zip(out, ref):
-            assert got["confirmed_frame"] == want["confirmed_frame"]
-            assert got["confirmed_checksum"] == want["confirmed_checksum"]
-            assert got["branch_checksums"] == want["branch_checksums"]
-        cm.assert_states_equal(cm.snapshot_state(w, ids), ref_state, "fanout gpu")
-
-        # a second world adopts the first one's packed state block byte-for-byte (what a
-        # receiving rank does after the broadcast)
-        w2, arena2 = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0), library_arena=False)   # the caller-provided arena path
-        ids2 = cm.build_particles(w2, with_spawn=True, ttl_init=25)
-        w2.spawn(0, {})
-        nb = w.state_bytes()
-        assert nb == w2.state_bytes()
-        w.live_state_ptr()
-        arena2[:nb].copy_(arena[:nb])
-        torch.cuda.synchronize()
-        w2.adopt_live_state()
-        assert w2.len == w.len and w2.frame == w.frame
-        cm.assert_states_equal(cm.snapshot_state(w2, ids2), cm.snapshot_state(w, ids), "adopted")
-        assert w2.save() == w.save()
-
-        # ---- the pre-marshalled pipelined path (no spawn payloads: frames and input bytes patched in place)
-        # must reproduce the synchronous path
-        res = []
-        for mode in ("sync", "pipelined", "pipelined3"):
-            wp, arenap = make_torch_world(bg, 5000, D + 2, 3, 60, torch.device("cuda", 0))
-            idsp = cm.build_particles(wp)
-            vel, ttl = cm.synthetic_particles(5000, ttl="despawn")
-            cm.spawn_particles(wp, idsp, 5000, vel, ttl)
-            fp = SpeculativeFanout(wp, dist, D, HipStateExchange(wp, arenap), branches_per_rank=3,
-                                   branch_input=lambda b, f: (b + f) & 0xF, confirmed_input=lambda f: f & 3)
-            if mode == "sync":
-                outp = [fp.step() for _ in range(7)]
-            else:
-                fp.interval = 3 if mode == "pipelined3" else 1   # checksums of 3 steps per all-gather
-                for _ in range(7): fp.step_pipelined()
-                fp.drain()
-                outp = list(fp.results)
-            fp.settle()
-            res.append((outp, cm.snapshot_state(wp, idsp)))
-        for r in res[1:]:
-            assert len(res[0][0]) == len(r[0]) == 7 and res[0][0] == r[0]
-            cm.assert_states_equal(res[0][1], r[1], "pipelined fan-out")
-
-        # ---- BASELINE config 5 on the one GPU of this box: 256 predicted-input branches (branch id = the input
-        # byte repeated every frame), 100k entities, 8 frames each, all on rank 0; inputs with
-        # INPUT_SPAWN set spawn 100 particles per frame so the branches really diverge
-        from bevy_ggrs_amd.fanout import default_branch_input
-        n, D, steps, bpr, rate = 100_000, 8, 2, 256, 100
-        cap = n + 2 * rate * (steps + D + 2) * 2
-        w5, arena5 = make_torch_world(bg, cap, D + 2, 3, 60, torch.device("cuda", 0))
-        ids5 = cm.build_particles(w5, with_spawn=True, ttl_init=300)
-        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
-        cm.spawn_particles(w5, ids5, n, vel, ttl)
-        fan5 = SpeculativeFanout(w5, dist, D, HipStateExchange(w5, arena5), branches_per_rank=bpr,
-                                 confirmed_input=lambda f: 0x13, spawn_fn=cm.frame_spawn_fn(rate))
-        out5 = [fan5.step() for _ in range(steps)]
-        fan5.settle()
-        ref5, state5 = _serial_reference(n, D, bpr, steps, branch_input=default_branch_input,
-                                         confirmed_input=lambda f: 0x13, ttl_init=300, rate=rate, warm=0)
-        for got, want in zip(out5, ref5):
-            assert got["confirmed_checksum"] == want["confirmed_checksum"]
-            assert got["branch_checksums"] == want["branch_checksums"]
-            assert len({v[0] for v in got["branch_checksums"].values()}) == 1          # one confirmed frame
-            assert len({tuple(v) for v in got["branch_checksums"].values()}) == 2      # spawning vs non-spawning predictions
-        cm.assert_states_equal(cm.snapshot_state(w5, ids5), state5, "config 5")
-    finally:
-        dist.destroy_process_group()
+    from bevy_ggrs_amd import _ffi
+    dev = torch.device("cuda", 0)
+    n, D = 700, 6
+    cap = n + 2000
+    w = bg.World(cap, max_depth=D + 2)
+    ids = cm.build_particles(w, with_spawn=True, ttl_init=25)
+    vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+    cm.spawn_particles(w, ids, n, vel, ttl)
+    drv = cm.SyncTestDriver(w, 3)
+    fn = cm.frame_spawn_fn(50)
+    for t in range(9):
+        drv.tick((cm.INPUT_SPAWN if t % 3 == 1 else 0,), spawn_fn=fn)
+    nbytes = int(_ffi.lib.ggrs_hip_arena_bytes(cap, D + 2, 3, 60))
+    arena2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    w2 = bg.World(cap, max_depth=D + 2, arena_ptr=arena2.data_ptr(), arena_bytes=nbytes, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ids2 = cm.build_particles(w2, with_spawn=True, ttl_init=25)
+    w2.spawn(0, {})
+    nb = w.state_bytes()
+    assert nb == w2.state_bytes()
+    src = torch.as_tensor(_DeviceSpan(w.live_state_ptr(), nb), device=dev)
+    assert w2.live_state_ptr() == arena2.data_ptr(), "the live block is the head of a caller-provided arena"
+    arena2[:nb].copy_(src)
+    torch.cuda.synchronize()
+    w2.adopt_live_state()
+    assert w2.len == w.len and w2.frame == w.frame
+    cm.assert_states_equal(cm.snapshot_state(w2, ids2), cm.snapshot_state(w, ids), "adopted")
+    assert w2.save() == w.save()
 
 
 def _n_devices():
@@ -121,7 +58,7 @@ def _n_devices():
     return int(_ffi.lib.ggrs_hip_device_count())
 
 
-def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q):
+def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q, scenario="walk", opt=None):
     """One rank of the C-ABI fan-out (ggrs_hip_fanout_*): RCCL is called inside libggrs_hip.so; torch is not involved.
     Rank r runs on HIP device r % devices (one rank per GPU wherever the box has them); rank 0 creates the ncclUniqueId and
     hands it to the others -- the host's only job in the real thing too."""
@@ -152,10 +89,26 @@ def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q):
             w.spawn(0, {})                                    # seals the world: the layout is fixed, the state arrives by broadcast
         native = RcclFanout(w, rank, size, id_bytes)
         assert native.comm_info() == (rank, size, device)
+        opt = opt or {}
+        if scenario == "adopt":
+            # confirm-speculate-adopt rounds under a scripted true-input sequence (tests/fanout_scenarios.py)
+            import fanout_scenarios as fs
+            fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, branch_input=fs.branch_input, confirmed_input=fs.true_input,
+                                    spawn_fn=cm.frame_spawn_fn(fs.RATE), retain=opt.get("retain", "all"))
+            seen = fs.run_adopt_session(fan, size * bpr, steps, broadcast_every=opt.get("broadcast_every", 0))
+            # ... and the session goes on from the adopted world: two more plain steps, then one more Save of where it stands
+            for _ in range(2):
+                o = fan.step(); seen.append((o["confirmed_frame"], o["confirmed_checksum"]))
+            fan.settle()
+            seen.append((w.frame, w.save()))
+            state = cm.snapshot_state(w, ids)
+            native.close()
+            q.put((rank, "ok", seen, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in state.items()}))
+            return
         fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, max_inflight=2,
                                 branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
                                 confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
-                                spawn_fn=cm.frame_spawn_fn(50))
+                                spawn_fn=cm.frame_spawn_fn(50), compact=opt.get("compact", True), desync_detection_interval=opt.get("interval", 1))
         out = [fan.step() for _ in range(steps // 2)]
         fan.results.clear()
         for _ in range(steps - steps // 2):
@@ -171,12 +124,12 @@ def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q):
         q.put((rank, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
 
 
-def _run_native(size, n=700, D=4, steps=6, bpr=2, env=None):
+def _run_native(size, n=700, D=4, steps=6, bpr=2, env=None, scenario="walk", opt=None):
     import multiprocessing as mp
     import os
     ctx = mp.get_context("spawn")
     q, id_q = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_native_fanout_rank, args=(r, size, id_q, n, D, steps, bpr, q)) for r in range(size)]
+    procs = [ctx.Process(target=_native_fanout_rank, args=(r, size, id_q, n, D, steps, bpr, q, scenario, opt)) for r in range(size)]
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})                              # spawned children inherit the parent's environment at start()
     try:
@@ -212,6 +165,170 @@ def test_native_fanout_world_size_1_matches_serial_reference():
         assert got["branch_checksums"] == want["branch_checksums"]
     for k, v in ref_state.items():
         assert (np.asarray(state[k]) == np.asarray(v)).all(), k
+
+
+@pytest.mark.parametrize("opt", [{"compact": False}, {"compact": True, "interval": 3}, {"compact": False, "interval": 3}])
+def test_native_fanout_request_list_and_compact_step_agree(opt):
+    """The compact step (ggrs_hip_fanout_step_branches: ONE launch for all branches, member records) and the request list it replaces (dead-snapshot
+    elimination + batches of identical groups), with 1 and 3 steps per all-gather: the same tables as the serial reference."""
+    from test_fanout_gloo import _serial_reference
+    n, D, steps, bpr = 700, 4, 7, 3
+    res = _run_native(1, n, D, steps, bpr, opt=opt)
+    assert res[0][0] == "ok", res[0]
+    ref, ref_state = _serial_reference(n, D, bpr, steps)
+    assert len(res[0][1]) == steps
+    for got, want in zip(res[0][1], ref):
+        assert got["confirmed_checksum"] == want["confirmed_checksum"] and got["branch_checksums"] == want["branch_checksums"]
+    for k, v in ref_state.items():
+        assert (np.asarray(res[0][2][k]) == np.asarray(v)).all(), k
+
+
+def _config5_rank(q):
+    try:
+        import bevy_ggrs_amd as bg
+        import common as cm
+        from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout, default_branch_input
+
+        class _Dist:
+            def get_rank(self): return 0
+            def get_world_size(self): return 1
+        n, D, steps, bpr, rate = 100_000, 8, 2, 256, 100
+        cap = n + 2 * rate * (steps + D + 2) * 2
+        w5 = bg.World(cap, max_depth=D + 2)
+        ids5 = cm.build_particles(w5, with_spawn=True, ttl_init=300)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w5, ids5, n, vel, ttl)
+        native = RcclFanout(w5, 0, 1, RcclFanout.unique_id())
+        fan5 = SpeculativeFanout(w5, _Dist(), D, None, branches_per_rank=bpr, native=native, confirmed_input=lambda f: 0x13, spawn_fn=cm.frame_spawn_fn(rate))
+        out5 = [fan5.step() for _ in range(steps)]
+        fan5.settle()
+        state = cm.snapshot_state(w5, ids5)
+        native.close()
+        q.put((0, "ok", out5, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in state.items()}))
+    except Exception as e:                                    # noqa: BLE001
+        import traceback
+        q.put((0, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
+
+
+def test_config5_256_diverging_branches_in_one_launch():
+    """BASELINE config 5 on the one GPU of this box: 256 predicted-input branches (branch id = the input byte repeated every frame), 100 k
+    entities, 8 frames each; inputs with INPUT_SPAWN set spawn 100 particles per frame, so 128 of the branches diverge from the others -- and all 256 ride in
+    ONE launch per step (member records).  Every branch's checksums against the oracle's serial walk."""
+    import multiprocessing as mp
+    from bevy_ggrs_amd.fanout import default_branch_input
+    from test_fanout_gloo import _serial_reference
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_config5_rank, args=(q,)); p.start()
+    try: r = q.get(timeout=600)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive(): p.kill()
+    assert r[1] == "ok", r
+    out5, state = r[2], r[3]
+    n, D, steps, bpr, rate = 100_000, 8, 2, 256, 100
+    ref5, state5 = _serial_reference(n, D, bpr, steps, branch_input=default_branch_input, confirmed_input=lambda f: 0x13, ttl_init=300, rate=rate, warm=0)
+    for got, want in zip(out5, ref5):
+        assert got["confirmed_checksum"] == want["confirmed_checksum"]
+        assert got["branch_checksums"] == want["branch_checksums"]
+        assert len({v[0] for v in got["branch_checksums"].values()}) == 1          # one confirmed frame
+        assert len({tuple(v) for v in got["branch_checksums"].values()}) == 2      # spawning vs non-spawning predictions
+    for k, v in state5.items():
+        assert (np.asarray(state[k]) == np.asarray(v)).all(), k
+
+
+def _check_adopt(res, size, n, D, steps, bpr):
+    import fanout_scenarios as fs
+    assert all(r[0] == "ok" for r in res.values()), {k: v[:2] for k, v in res.items() if v[0] != "ok"}
+    seen0 = res[0][1]
+    last_frame = max(f for f, _ in seen0)
+    cap = n + 100 * (steps * D + D + 8) * 2
+    cs, _, _ = fs.straight_line_reference(n, last_frame - 3 + 1, cap)
+    assert any(b - a > 1 for (a, _), (b, _) in zip(seen0, seen0[1:])), "no adoption ever jumped more than one frame: the scenario tests nothing"
+    for r in range(size):
+        seen, state = res[r][1], res[r][2]
+        assert seen == seen0, f"rank {r} observed other frames / checksums than rank 0"
+        for f, c in seen:
+            assert c is None or cs[f] == c, (r, f, hex(c), hex(cs[f]))
+        want = fs.state_at(n, state["frame"], cap)
+        for k, v in want.items():
+            assert (np.asarray(state[k]) == np.asarray(v)).all(), (r, k)
+
+
+def test_adopt_world_size_1_over_rccl():
+    """ggrs_hip_fanout_adopt at world size 1 (the real RCCL): every branch is this rank's -- adoption is a ring-slot swap + one LoadWorld, no re-simulation.
+    After the scripted session the world equals the oracle's straight-line simulation of the true inputs, as does every checksum seen on the way."""
+    n, D, steps, bpr = 700, 5, 8, 4
+    res = _run_native(1, n, D, steps, bpr, scenario="adopt")
+    _check_adopt(res, 1, n, D, steps, bpr)
+
+
+def test_adopt_newest_only_world_size_1():
+    """GGRS_BRANCH_RETAIN_NEWEST keeps only the last frame of every branch: adopting an earlier one is refused with GGRS_E_NO_SNAPSHOT, the newest one works."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_newest_rank, args=(q,)); p.start()
+    try: r = q.get(timeout=300)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive(): p.kill()
+    assert r[0] == "ok", r
+
+
+def _newest_rank(q):
+    try:
+        import bevy_ggrs_amd as bg
+        import common as cm
+        import fanout_scenarios as fs
+        from bevy_ggrs_amd.fanout import RcclFanout, SpeculativeFanout
+
+        class _Dist:
+            def get_rank(self): return 0
+            def get_world_size(self): return 1
+        n, D, bpr = 500, 4, 3
+        w = bg.World(n + 4000, max_depth=D + 2)
+        ids = fs.build_world(w, n, True)
+        native = RcclFanout(w, 0, 1, RcclFanout.unique_id())
+        always = lambda b, f: cm.INPUT_SPAWN                       # every branch predicts the key held, and so it is
+        fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, branch_input=always, confirmed_input=lambda f: cm.INPUT_SPAWN,
+                                spawn_fn=cm.frame_spawn_fn(fs.RATE), retain="newest")
+        fan.step()
+        try:
+            fan.adopt(1, 2); raise AssertionError("adopting a frame that was not kept must fail")
+        except bg.GgrsHipError as e:
+            assert e.code == bg.GGRS_E_NO_SNAPSHOT and "retained" in str(e), e
+        C = fan.confirmed
+        fan.adopt(1, D)                                            # the newest frame: C + D (the state after the branch's last AdvanceFrame)
+        assert w.frame == C + D and fan.confirmed == C + D
+        got = cm.snapshot_state(w, ids)
+        cs = w.save()
+        # reference: the same inputs in a straight line
+        from oracle.binding import OracleWorld
+        o = OracleWorld(n + 4000, 4)
+        oids = fs.build_world(o, n, True)
+        fn = cm.frame_spawn_fn(fs.RATE)
+        while o.frame < C + D:
+            a = bg.AdvanceFrame((cm.INPUT_SPAWN,)); a.spawn_vx, a.spawn_vy = fn(o.frame)
+            o.handle_requests([a])
+        cm.assert_states_equal(got, cm.snapshot_state(o, oids), "newest adopted")
+        o.set_depth(2)
+        assert cs == o.save()
+        native.close()
+        q.put(("ok",))
+    except Exception as e:                                    # noqa: BLE001
+        import traceback
+        q.put(("error", f"{type(e).__name__}: {e}", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("size,bpr,broadcast_every", [(2, 3, 0), (3, 2, 2), (8, 2, 3)])
+def test_adopt_ranks_over_the_transport_double(size, bpr, broadcast_every):
+    """Adoption ACROSS ranks (collectives over the shared-memory stand-in): the rank that ran the matching branch swaps its retained block into the ring, the
+    others re-simulate with the confirmed inputs -- or, every `broadcast_every`-th round, receive the owner's block by one ncclBroadcast -- and every rank must
+    end in the oracle's straight-line state with the same checksums on the way, whoever owned the adopted branches."""
+    n, D, steps = 600, 5, 8
+    res = _run_native(size, n, D, steps, bpr, env={"GGRS_RCCL_LIB": _double_lib()}, scenario="adopt", opt={"broadcast_every": broadcast_every})
+    _check_adopt(res, size, n, D, steps, bpr)
 
 
 def _double_lib():
