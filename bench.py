@@ -52,8 +52,7 @@ ADV_BYTES = 64                 # AdvanceWorld as its own kernel: r/w translation
 
 
 def dbg_hooks(w):
-    """A/B switches of the library's test hooks (experiments behind profiles/r05h, r05k; none is set in a bench line that counts)."""
-    if os.environ.get("BENCH_DBG_SKIP_ROWS"): w._lib.ggrs_dbg_set_skip_rows(w._p, C.c_uint64(int(os.environ["BENCH_DBG_SKIP_ROWS"], 0)))
+    """A/B switches of the library's test hooks (the experiment behind profiles/r05h; none is set in a bench line that counts)."""
     if os.environ.get("BENCH_NO_LAZY_LIVE") == "1": w._lib.ggrs_dbg_set_lazy_live(w._p, 0)
 
 

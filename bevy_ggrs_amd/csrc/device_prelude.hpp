@@ -138,9 +138,10 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
 // the sum for the live counts (entity_checksum.rs:40).  Run by the first workgroups of the next request-group launch (256 threads), or by
 // k_ff_fold when no launch follows.  A chunk is at most 1024 values: 4 eight-byte loads in flight per lane, ONE trip -- the role must not cost
 // the tile role registers (the kernel's allocation is the maximum over both: with 16 loads in flight it grew from 28 to 41 VGPRs and the
-// 1 M launch from 48.9 to 50.1 us, profiles/r05b).  The value first, then the tag the collecting host polls (same pinned allocation).
+// 1 M launch from 48.9 to 50.1 us, profiles/r05b).  `cell`: 16 bytes, 16-byte aligned, in pinned host memory -- {value, tag} -- written by ONE store.
 constexpr uint32_t FF_CHUNK = 1024;
-__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* out, uint64_t* tag, uint64_t seq) {
+typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     __shared__ unsigned long long ff_acc;
     if (tid == 0) ff_acc = 0ull;
@@ -158,13 +159,15 @@ _Pragma("unroll")
     else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); }
     __syncthreads();
     if (tid == 0) {
-        // Both stores are relaxed system-scope atomics (write-through, no cache maintenance) with an explicit vmcnt(0) between them: the value has
-        // left for host memory before the tag is issued, and the two posted writes reach the host in order.  NOT a system-scope release: that is a
-        // write-back of the XCD's whole L2 (buffer_wbl2) -- issued here by 12 workgroups per XCD while the tile workgroups of the same launch stream
-        // their first Save THROUGH that L2, it cost the 1 M launch 2.5 us (48.9 -> 51.4 us, profiles/r05d).
-        __hip_atomic_store(out, (uint64_t)ff_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(tag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // Value and tag leave as ONE 16-byte system-scope store (global_store_dwordx4 sc0 sc1: write-through to the fabric, no cache maintenance) into one
+        // naturally aligned 16-byte cell: one write transaction on the way to host memory, so there is no order between two stores to rely on -- a host that
+        // sees the tag sees the value that travelled with it.  (Rounds 4-5 issued two relaxed stores with s_waitcnt vmcnt(0) between them, which is ordered
+        // on this PCIe path but not by the HIP memory model.)  NOT a system-scope release either: that is a write-back of the XCD's whole L2 (buffer_wbl2) --
+        // issued here by 12 workgroups per XCD while the tile workgroups of the same launch stream their first Save THROUGH that L2, it cost the 1 M launch
+        // 2.5 us (48.9 -> 51.4 us, profiles/r05d).
+        const uint64_t v = (uint64_t)ff_acc;
+        const ff_u32x4 q = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)seq, (uint32_t)(seq >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(cell), "v"(q) : "memory");
     }
 }
 )

@@ -118,6 +118,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     for (hipEvent_t e : w->prof_pool) (void)hipEventDestroy(e);
     for (auto& b : w->pending) (void)hipEventDestroy(b.ev);
     for (auto& e : w->event_pool) (void)hipEventDestroy(e);
+    for (auto& e : w->ff_events) if (e.ev) (void)hipEventDestroy(e.ev);
     for (auto& c : w->customs) if (c.mod) (void)hipModuleUnload(c.mod);
     jit_spec_retire(w);
     jit_release(w->jit_entry);
@@ -256,7 +257,7 @@ int ggrs_hip_register_component_strategy(ggrs_world* w, uint32_t c, uint32_t sto
 int ggrs_hip_set_input_layout(ggrs_world* w, uint32_t input_bytes, uint32_t max_players) {
     if (!w) return GGRS_E_INVALID;
     if (w->sealed) return w->fail(GGRS_E_INVALID, "set_input_layout after the world was sealed");
-    if (!w->customs.empty()) return w->fail(GGRS_E_INVALID, "set_input_layout must precede the first custom system (its kernel is compiled against the layout)");
+    if (!w->systems.empty()) return w->fail(GGRS_E_INVALID, "set_input_layout must precede the first system of the schedule (custom systems are compiled against the layout when they are added)");
     if (input_bytes == 0 || input_bytes > GGRS_MAX_INPUT_BYTES || max_players == 0 || max_players > GGRS_MAX_PLAYERS)
         return w->fail(GGRS_E_INVALID, "input layout: 1..%d bytes per player, 1..%d players", GGRS_MAX_INPUT_BYTES, GGRS_MAX_PLAYERS);
     w->input_bytes = input_bytes; w->max_players = max_players;
@@ -322,9 +323,11 @@ int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, c
     memcpy(out, b.c_str(), b.size() + 1);
     return (int)n;
 }
-// Test hook (no ggrs_hip_ prefix, not in the header): places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight
-// rollback lengths exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
-int ggrs_dbg_set_skip_rows(ggrs_world* w, uint64_t mask) { if (!w) return -1; w->dbg_skip_rows = mask; return 0; }
+// Test hooks (no ggrs_hip_ prefix, not in the header; neither changes a result):
+//   ggrs_dbg_set_lazy_live     0 = every tick writes the live block (the A/B of profiles/r05h), 2 = every eligible list leaves it unwritten whatever its size and
+//                              streak (the fuzzer: tests/test_fuzz_requests.py), 1 = the default policy
+//   ggrs_dbg_set_spec_shapes   places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight rollback lengths
+//                              exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
 int ggrs_dbg_set_lazy_live(ggrs_world* w, int on) { if (!w) return -1; w->lazy_live_on = on; return 0; }
 int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }

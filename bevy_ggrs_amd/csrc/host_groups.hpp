@@ -161,6 +161,7 @@ inline void ff_attach(ggrs_world* w, GgrsJitArgs& j) {
     j.ff_rows = reinterpret_cast<const ggrs_u64*>(w->d_ff_rows[p.buf]); j.ff_out = reinterpret_cast<ggrs_u64*>(w->d_rows + p.out_off); j.ff_seq = p.seq;
     j.ff_nvals = p.nvals; j.ff_blocks = (p.nvals + 7u) & ~7u; j.ff_g = p.g; j.ff_stride = p.stride; j.ff_istride = p.istride; j.ff_split = p.split;
     w->ff_done_id = p.id; p.valid = false;
+    w->ff_mark_id = p.id;                                             // launch_jit records the group's event right behind this launch
 }
 
 // The shape of a steady SyncTest tick of this world at full length -- [Load(F - D), Advance, (Save, Advance) x D] with D = max_depth - 1, every
@@ -169,7 +170,10 @@ inline void ff_attach(ggrs_world* w, GgrsJitArgs& j) {
 // among the shipped objects when there is no run-time compiler.
 inline bool lazy_live_allowed(const ggrs_world* w);
 JitSig jit_steady_sig(const ggrs_world* w) {
-    const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, std::min<uint32_t>(w->cap_saves, w->cap_steps - 1));
+    // the group caps come from the world's argument-block layout -- computed here, not read from w->cap_*: a GGRS_WORLD_LAYOUT_ONLY world (`make aot` on a
+    // build machine) is never sealed, and the defaults (16 / 24) would describe a tick its device struct has no room for
+    const JitLayout L = jit_layout(w);
+    const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(w->max_depth, 2) - 1, std::min<uint32_t>(L.cap_saves, L.cap_steps - 1));
     const uint64_t cover = w->capacity;
     JitSig g;
     g.n_saves = d; g.n_steps = d + 1; g.n_ops = 2 * d + 1;
@@ -207,6 +211,7 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
         w->prof_events.push_back({a, b, GGRS_KERNEL_TICK});
     }
     if (w->tl.on) { w->tl.launch_us += tl_now_us() - t0; ++w->tl.n_launches; }
+    if (w->ff_mark_id) { const uint64_t id = w->ff_mark_id; w->ff_mark_id = 0; if (w->knobs.spin_wait_us <= 0) return ff_mark_folded(w, id); }   // (polling sessions never wait for it: no marker packet per tick for them)
     return GGRS_OK;
 }
 
@@ -485,7 +490,6 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         j.load_rows = j.n_ops ? static_reads : 0;
         for (uint32_t k = 0; k < j.n_saves; ++k) {
             j.save_rows[k] = j.save_dst[k] ? gs.save_rows[k] : 0;
-            if (w->dbg_skip_rows && w->load_open_streak >= 64) j.save_rows[k] &= ~w->dbg_skip_rows;
             j.save_pmask[k] = j.save_dst[k] ? gs.save_pmask[k] : 0;
             j.load_rows |= j.save_rows[k];
             bytes_slot += rows_bytes_per_slot(w, j.save_rows[k], true);
@@ -558,7 +562,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             if (ff) {
                 ggrs_world::HostFold f = make_host_fold(j, res_base + ns, ff_split, n_cks, 1u, rows_off);   // (the host XORs / adds the row's chunks)
                 f.ff_id = w->ff_next_id++; f.ff_seq = (0xA5ull << 56) | ++w->ff_seq;      // (a tag no live count and -- but for 2^-64 -- no hash equals)
-                memset(w->h_rows + rows_off + nvals, 0, (size_t)nvals * 8);              // the tag cells: whatever an earlier fold left there is gone
+                memset(w->h_rows + rows_off, 0, (size_t)nvals * 16);                    // the {value, tag} cells: whatever an earlier fold left there is gone
                 w->folds.push_back(f);
                 ggrs_world::FfPending& p = w->ff_pending;
                 p.valid = true; p.id = f.ff_id; p.seq = f.ff_seq; p.buf = ff_buf; p.nvals = nvals; p.g = g; p.stride = 1; p.istride = rows_n; p.split = ff_split; p.out_off = rows_off;

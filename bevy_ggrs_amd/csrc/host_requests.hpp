@@ -531,9 +531,9 @@ int do_advance(ggrs_world* w, const ggrs_request& r) {
     return run_spawn_systems(w, inputs, n_inputs, spawn_count, spawn_vx, spawn_vy);
 }
 
-// Bounded poll of tags in pinned host memory: true once tags[0..n) all equal seq.  The producer writes each value and, once that store has
-// completed, its tag (k_gen_finalize: a system-scope release; ff_fold_row: relaxed system-scope stores with s_waitcnt vmcnt(0) between them,
-// device_prelude.hpp); seeing every tag means the values are in host memory.
+// Bounded poll of tags in pinned host memory: true once tags[0], tags[stride], .. (n of them) all equal seq.  k_gen_finalize writes each value and then, with a
+// system-scope release, its tag (stride 1); ff_fold_row writes {value, tag} as ONE 16-byte store into a 16-byte cell (stride 2: tags at the odd u64s,
+// device_prelude.hpp) -- either way seeing every tag means the values are in host memory.
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -543,15 +543,31 @@ inline void cpu_relax() {
     std::this_thread::yield();
 #endif
 }
-bool spin_for_tags(const volatile uint64_t* tags, uint32_t n, uint64_t seq, int budget_us) {
+bool spin_for_tags(const volatile uint64_t* tags, uint32_t n, uint64_t seq, int budget_us, uint32_t stride = 1) {
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t k = 0;
     for (uint32_t it = 1; ; ++it) {
-        while (k < n && tags[k] == seq) ++k;
+        while (k < n && tags[(size_t)k * stride] == seq) ++k;
         if (k == n) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
         if ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget_us)) return false;
         cpu_relax();
     }
+}
+
+// WHEN a fold-forward group's values are on their way: an event recorded right behind the launch (or k_ff_fold) that carries the fold.  A collect whose
+// tag poll times out (or is switched off: GGRS_SPIN_WAIT_US=0) waits for THAT event -- not for the whole stream, which may already hold the next ticks
+// (with nothing but a stream-wide wait, collect(k) stalled behind batch k + 1).  A small ring: only the newest few groups can be uncollected.
+int ff_mark_folded(ggrs_world* w, uint64_t id) {
+    ggrs_world::FfEvent& e = w->ff_events[id % ggrs_world::FF_EVENTS];
+    if (!e.ev) HIPCHK(w, hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+    HIPCHK(w, hipEventRecord(e.ev, w->stream));
+    e.id = id;
+    return GGRS_OK;
+}
+hipError_t ff_wait_event(ggrs_world* w, uint64_t id) {
+    ggrs_world::FfEvent& e = w->ff_events[id % ggrs_world::FF_EVENTS];
+    if (e.ev && e.id == id) return hipEventSynchronize(e.ev);
+    return hipStreamSynchronize(w->stream);                            // (its event was reused by a newer group: that one is behind it on the stream)
 }
 
 // Fold-forward: the rows of the last launch are still unfolded and no later launch took them along -- k_ff_fold does it now (a collect with
@@ -564,7 +580,7 @@ int ff_flush(ggrs_world* w) {
     hipLaunchKernelGGL(k_ff_fold, dim3(p.nvals), dim3(TPB), 0, w->stream, f);
     HIPCHK(w, hipGetLastError());
     w->ff_done_id = p.id; p.valid = false;
-    return GGRS_OK;
+    return ff_mark_folded(w, p.id);
 }
 
 // component_checksum.rs:92-95 (hash the XOR of the entity hashes once more), entity_checksum.rs:29-52, checksum.rs:88-99 (XOR of all
@@ -578,21 +594,22 @@ int run_host_folds(ggrs_world* w, uint32_t n) {
             // the values arrive with the launch (or k_ff_fold) that follows this group's on the stream
             if (f.ff_id > w->ff_done_id) { const int rc = ff_flush(w); if (rc) return rc; }
             const double t0 = w->tl.on ? tl_now_us() : 0;
-            const uint32_t nvals = f.n_saves * nc * f.g;              // g = chunks per row here: one value (and one tag) per chunk
-            if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, std::max(w->knobs.spin_wait_us, 0))) {
-                HIPCHK(w, hipStreamSynchronize(w->stream));
-                if (!spin_for_tags(w->h_rows + f.rows_off + nvals, nvals, f.ff_seq, 1000000)) return w->fail(GGRS_E_HIP, "fold-forward: the tags of group %llu never arrived", (unsigned long long)f.ff_id);
+            const uint32_t nvals = f.n_saves * nc * f.g;              // g = chunks per row here: one {value, tag} cell per chunk
+            if (!spin_for_tags(w->h_rows + f.rows_off + 1, nvals, f.ff_seq, std::max(w->knobs.spin_wait_us, 0), 2)) {
+                HIPCHK(w, ff_wait_event(w, f.ff_id));
+                if (!spin_for_tags(w->h_rows + f.rows_off + 1, nvals, f.ff_seq, 1000000, 2)) return w->fail(GGRS_E_HIP, "fold-forward: the tags of group %llu never arrived", (unsigned long long)f.ff_id);
             }
             if (w->tl.on) w->tl.tag_wait_us += tl_now_us() - t0;
         }
         const double t1 = w->tl.on ? tl_now_us() : 0;
+        const uint32_t vs = f.ff_id ? 2u : 1u;                        // fold-forward cells are {value, tag}: the values sit at the even u64s
         for (uint32_t m = 0; m < f.members; ++m)
             for (uint32_t sv = 0; sv < f.n_saves; ++sv) {
                 uint64_t total = 0;
                 for (uint32_t c = 0; c < nc; ++c) {
-                    const uint64_t* row = w->h_rows + f.rows_off + ((uint64_t)(m * f.n_saves + sv) * nc + c) * f.g;
-                    if (c == f.n_cks) { uint64_t sum = 0; for (uint32_t t = 0; t < f.g; ++t) sum += row[t]; total ^= sea_pair(sum, f.save_len[sv]); }
-                    else { uint64_t x = 0; for (uint32_t t = 0; t < f.g; ++t) x ^= row[t]; total ^= sea_one(x); }
+                    const uint64_t* row = w->h_rows + f.rows_off + ((uint64_t)(m * f.n_saves + sv) * nc + c) * f.g * vs;
+                    if (c == f.n_cks) { uint64_t sum = 0; for (uint32_t t = 0; t < f.g; ++t) sum += row[(size_t)t * vs]; total ^= sea_pair(sum, f.save_len[sv]); }
+                    else { uint64_t x = 0; for (uint32_t t = 0; t < f.g; ++t) x ^= row[(size_t)t * vs]; total ^= sea_one(x); }
                 }
                 uint64_t* out = w->h_results + 2 * (uint64_t)(f.res_slot + m * f.n_saves + sv);
                 out[0] = total; out[1] = 0;

@@ -230,6 +230,9 @@ struct ggrs_world {
     uint64_t* d_ff_rows[2] = {nullptr, nullptr}; uint32_t ff_cur = 0;
     struct FfPending { bool valid = false; uint64_t id = 0, seq = 0; uint32_t buf = 0, nvals = 0, g = 0, stride = 0, istride = 1, split = 1; uint64_t out_off = 0; } ff_pending;   // nvals = rows x split
     uint64_t ff_next_id = 1, ff_done_id = 0, ff_seq = 0;    // ids are handed out in launch order; every id <= ff_done_id has a fold queued on the stream
+    uint64_t ff_mark_id = 0;                                // the group whose fold the launch being issued carries (set by ff_attach, consumed by launch_jit)
+    static constexpr uint32_t FF_EVENTS = 32;
+    struct FfEvent { hipEvent_t ev = nullptr; uint64_t id = 0; } ff_events[FF_EVENTS];   // recorded behind the launch that folds group `id` (host_requests.hpp ff_mark_folded)
 
     // LAZY LIVE BLOCK (host_groups.hpp): the last group of the previous list ended  [.., Save(F), Advance]  and did not write the live block -- the
     // live world (frame F + 1) IS Advance(ring slot of F) until somebody needs its bytes: a list that opens with a LoadGameState never does (a SyncTest
@@ -237,7 +240,6 @@ struct ggrs_world {
     struct LiveStale { bool valid = false; Block* src = nullptr; uint64_t len = 0; uint32_t dt_bits = 0, aux_bits = 0; int step_frame = 0, step_confirmed = 0;
                        unsigned char n_inputs = 0; unsigned char inputs[GGRS_MAX_PLAYERS * (GGRS_MAX_INPUT_BYTES + 1)] = {}; } live_stale;
     int lazy_live_on = 1;                // (ggrs_dbg_set_lazy_live: 0 = the A/B of profiles/r05h; 2 = every eligible list whatever its size and streak: the fuzzer)
-    uint64_t dbg_skip_rows = 0;          // EXPERIMENT ONLY (ggrs_dbg_set_skip_rows): columns dropped from every Save of a long-running steady session
     bool live_handed_out = false;        // ggrs_hip_live_state_ptr gave the block away: it is kept current from then on
     uint32_t load_open_streak = 0;       // consecutive request lists that opened with a LoadGameState
     uint64_t lazy_skips = 0, lazy_materialised = 0;

@@ -184,8 +184,8 @@ struct GgrsJitArgs {
     ggrs_u64* parts;                                 // this launch's partial rows: [saves x (n_cks + 1)][part_stride], one entry per workgroup
     // FOLD-FORWARD (ff_blocks != 0): the first ff_blocks workgroups of this launch fold the partial rows the PREVIOUS launch of the stream left in
     // device memory (ff_rows: [rows][ff_stride], ff_g entries each, ff_split chunks of <= 1024 entries per row) -- one chunk per workgroup: XOR of a
-    // component's entity hashes, or the sum of the live counts -- and write the ff_nvals = rows x ff_split folded values, then one tag (ff_seq) per
-    // value, into pinned host memory (ff_out): the host finishes the Checksum(u128)s from 96 values instead of XOR-ing 750 KB of rows per tick at 1 M
+    // component's entity hashes, or the sum of the live counts -- and write the ff_nvals = rows x ff_split folded values, each with its tag (ff_seq) in one
+    // 16-byte {value, tag} cell, into pinned host memory (ff_out): the host finishes the Checksum(u128)s from 96 values instead of XOR-ing 750 KB of rows per tick at 1 M
     // (host_groups.hpp, "fold-forward")
     const ggrs_u64* ff_rows; ggrs_u64* ff_out; ggrs_u64 ff_seq;
     ggrs_u64 live_rows, load_rows;                   // row versions: bit c = column c is stored with the live block / must be loaded at all
@@ -571,8 +571,8 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    if (blockIdx.x < a.ff_blocks) {\n"
             "        if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals) {                   // ff_nvals = rows x chunks per row (ff_split)\n"
             "            const uint32_t row = blockIdx.x / a.ff_split, ck = blockIdx.x %% a.ff_split, per = (a.ff_g + a.ff_split - 1u) / a.ff_split;\n"
-            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride, a.ff_istride, ck * per, min(a.ff_g, (ck + 1u) * per), (row %% %uu) == %uu, (uint64_t*)a.ff_out + blockIdx.x,\n"
-            "                        (uint64_t*)a.ff_out + a.ff_nvals + blockIdx.x, (uint64_t)a.ff_seq);\n"
+            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride, a.ff_istride, ck * per, min(a.ff_g, (ck + 1u) * per), (row %% %uu) == %uu,\n"
+            "                        (uint64_t*)a.ff_out + 2u * blockIdx.x, (uint64_t)a.ff_seq);                                 // cell blockIdx.x: {value, tag}\n"
             "        }\n"
             "        return;\n"
             "    }\n"

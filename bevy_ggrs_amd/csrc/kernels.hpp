@@ -706,13 +706,13 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
 
 // ------------------------------------------------------------------ k_ff_fold
 // Fold-forward without a following request-group launch (ff_flush): one 256-thread workgroup per chunk of a partial row of the LAST launch
-// (device_prelude.hpp ff_fold_row) -- the value, then its tag, into pinned host memory.  Workgroup b = row b / split, chunk b % split.
+// (device_prelude.hpp ff_fold_row) -- {value, tag} as one 16-byte cell into pinned host memory.  Workgroup b = row b / split, chunk b % split.
 struct FfArgs { const uint64_t* rows; uint64_t* out; uint64_t seq; uint32_t nvals, g, stride, istride, nc1, split; };
 __global__ __launch_bounds__(TPB) void k_ff_fold(FfArgs f) {
     const uint32_t b = blockIdx.x;
     if (b >= f.nvals * f.split) return;
     const uint32_t row = b / f.split, ck = b % f.split, per = (f.g + f.split - 1u) / f.split;
-    ff_fold_row(f.rows + (uint64_t)row * f.stride, f.istride, ck * per, min(f.g, (ck + 1u) * per), (row % f.nc1) == f.nc1 - 1u, f.out + b, f.out + f.nvals * f.split + b, f.seq);
+    ff_fold_row(f.rows + (uint64_t)row * f.stride, f.istride, ck * per, min(f.g, (ck + 1u) * per), (row % f.nc1) == f.nc1 - 1u, f.out + 2u * b, f.seq);
 }
 
 }  // namespace ggrs

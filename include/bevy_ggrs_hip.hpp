@@ -425,6 +425,62 @@ struct HipBackend {
     uint64_t snapshot_count() { return ggrs_hip_snapshot_count(w); }
 };
 
+// ---------------------------------------------------------------- speculative fan-out (no reference analogue: SURVEY.md 8e)
+// RAII over ggrs_fanout: predicted-input branches off the confirmed snapshot, their Checksum(u128)s gathered over RCCL inside the library, branch states kept and
+// the matching one ADOPTED when the true inputs arrive.  One object per rank; the caller carries the 128-byte id from rank 0 to the others.
+class SpeculativeFanout {
+public:
+    static std::vector<uint8_t> unique_id() {
+        std::vector<uint8_t> id(GGRS_FANOUT_ID_BYTES);
+        if (ggrs_hip_fanout_unique_id(id.data()) != GGRS_OK) throw std::runtime_error("ncclGetUniqueId failed (is librccl.so loadable?)");
+        return id;
+    }
+    SpeculativeFanout(HipBackend& be, const std::vector<uint8_t>& id, int rank, int world_size) : w_(be.w) {
+        if (id.size() != GGRS_FANOUT_ID_BYTES) throw std::invalid_argument("the fan-out id is GGRS_FANOUT_ID_BYTES bytes");
+        if (ggrs_hip_fanout_init(be.w, id.data(), rank, world_size, &f_) != GGRS_OK) throw std::runtime_error(std::string("ggrs_hip_fanout_init: ") + ggrs_hip_last_error(be.w));
+    }
+    ~SpeculativeFanout() { if (f_) ggrs_hip_fanout_destroy(f_); }
+    SpeculativeFanout(const SpeculativeFanout&) = delete;
+    void sync_confirmed(int root = 0) { check(ggrs_hip_fanout_sync_confirmed(f_, root)); }
+    void set_interval(uint32_t steps_per_all_gather) { check(ggrs_hip_fanout_set_interval(f_, steps_per_all_gather)); }
+    // prefix requests, then n_branches x n_frames predicted inputs ([branch][frame][player x input bytes]); flags: GGRS_BRANCH_*; returns the step's SaveGameState count
+    uint32_t step_branches(const std::vector<ggrs_request>& prefix, uint32_t n_branches, uint32_t n_frames, uint32_t n_inputs, const std::vector<uint8_t>& inputs,
+                           uint32_t flags = 0, const std::vector<ggrs_branch_spawn>& spawn_table = {}, const std::vector<uint16_t>& spawn_sel = {}) {
+        ggrs_branch_step st; std::memset(&st, 0, sizeof st);
+        st.prefix = prefix.data(); st.n_prefix = (uint32_t)prefix.size(); st.n_branches = n_branches; st.n_frames = n_frames; st.n_inputs = n_inputs; st.flags = flags;
+        st.inputs = inputs.data(); st.spawn_table = spawn_table.empty() ? nullptr : spawn_table.data(); st.n_spawn_table = (uint32_t)spawn_table.size();
+        st.spawn_sel = spawn_sel.empty() ? nullptr : spawn_sel.data();
+        uint32_t ns = 0;
+        check(ggrs_hip_fanout_step_branches(f_, &st, &ns));
+        return ns;
+    }
+    // oldest all-gather group: [rank][step][save] Checksum(u128)s
+    std::vector<u128> collect(uint32_t* n_steps = nullptr, uint32_t* n_saves = nullptr) {
+        int size = 1; check(ggrs_hip_fanout_comm_info(f_, nullptr, &size, nullptr));
+        std::vector<uint64_t> raw((size_t)size * 4096 * 2);
+        uint32_t steps = 0, saves = 0;
+        check(ggrs_hip_fanout_collect(f_, raw.data(), 4096, &steps, &saves));
+        std::vector<u128> out((size_t)size * steps * saves);
+        for (size_t i = 0; i < out.size(); ++i) { out[i].lo = raw[2 * i]; out[i].hi = raw[2 * i + 1]; }
+        if (n_steps) *n_steps = steps;
+        if (n_saves) *n_saves = saves;
+        return out;
+    }
+    // the true inputs matched GLOBAL branch `branch` up to `frame`: its retained state becomes the world on every rank (collective).  replay: what a rank that
+    // does not own the branch runs instead; returns the Checksum(u128)s of its SaveGameStates (empty on the owner)
+    std::vector<u128> adopt(uint32_t branch, Frame frame, const std::vector<ggrs_request>& replay = {}, uint32_t mode = GGRS_ADOPT_RECOMPUTE) {
+        uint32_t ns = 0; for (auto& r : replay) ns += r.kind == GGRS_REQ_SAVE;
+        std::vector<uint64_t> raw(2 * (size_t)ns + 2); uint32_t got = 0;
+        check(ggrs_hip_fanout_adopt(f_, branch, frame, mode, replay.empty() ? nullptr : replay.data(), (uint32_t)replay.size(), raw.data(), &got));
+        std::vector<u128> out(got);
+        for (uint32_t i = 0; i < got; ++i) { out[i].lo = raw[2 * i]; out[i].hi = raw[2 * i + 1]; }
+        return out;
+    }
+private:
+    void check(int rc) { if (rc != GGRS_OK) throw std::runtime_error(std::string("ggrs_hip_fanout: ") + ggrs_hip_fanout_last_error(f_)); }
+    ggrs_world* w_ = nullptr; ggrs_fanout* f_ = nullptr;
+};
+
 // ---------------------------------------------------------------- GgrsPlugin + App
 template <class C> struct GgrsPlugin {};            // src/lib.rs:200-260 (the schedule label argument has no meaning without Bevy)
 

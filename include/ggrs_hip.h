@@ -219,7 +219,8 @@ int ggrs_hip_register_component_strategy(ggrs_world* w, uint32_t comp_id, uint32
 
 /* PlayerInputs<T>(Vec<(T::Input, InputStatus)>) (src/lib.rs:98, inserted before every AdvanceWorld: schedule_systems.rs:262-265).
  * input_bytes = size_of::<T::Input>() (POD, 1..16; default 1: Config<Input = u8>), max_players = players of the session (1..16; default 16).
- * Must precede the first custom / spawn system. */
+ * Must precede the first ggrs_hip_add_system / _add_custom_system / _add_spawn_system call (GGRS_E_INVALID afterwards).  From then on EVERY AdvanceFrame's
+ * `inputs` buffer is read as n_inputs x input_bytes bytes: the library cannot see a buffer's length, so a caller that widens the layout must widen its buffers. */
 #define GGRS_INPUT_CONFIRMED    0   /* ggrs::InputStatus::Confirmed    */
 #define GGRS_INPUT_PREDICTED    1   /* ggrs::InputStatus::Predicted    */
 #define GGRS_INPUT_DISCONNECTED 2   /* ggrs::InputStatus::Disconnected */
@@ -359,7 +360,7 @@ typedef struct {
     int32_t  frame;           /* SAVE: frame handed to cell.save; LOAD: frame to restore       */
     uint32_t dt_bits;         /* ADVANCE: f32 bits of Time::delta_secs, 0 = derive (time.rs)   */
     uint32_t n_inputs;        /* ADVANCE: PlayerInputs length (players)                        */
-    const uint8_t* inputs;    /* ADVANCE: n_inputs x input_bytes bytes: T::Input of every player (ggrs_hip_set_input_layout; default 1 byte each) */
+    const uint8_t* inputs;    /* ADVANCE: EXACTLY n_inputs x input_bytes bytes are read: T::Input of every player (ggrs_hip_set_input_layout; default 1 byte each) */
     const uint8_t* status;    /* ADVANCE: n_inputs InputStatus bytes (GGRS_INPUT_*), NULL = every input Confirmed                                  */
     uint64_t spawn_count;     /* ADVANCE: entities the world's spawn system appends in this frame (PARTICLES_SPAWN: if its input bit is held)     */
     const float* spawn_vx;    /*   GGRS_SYS_PARTICLES_SPAWN: host arrays of spawn_count f32 (host-side ParticleRng draw)                          */

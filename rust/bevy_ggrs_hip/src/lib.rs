@@ -133,6 +133,79 @@ impl Drop for HipWorld {
     }
 }
 
+/// Speculative fan-out across the GPUs of a node (no bevy_ggrs analogue): predicted-input branches off the confirmed snapshot, one
+/// process per GPU, RCCL inside `libggrs_hip.so`.  `step_branches` hands the library ONE compact description of a step -- a prefix request list and
+/// `n_branches x n_frames` predicted inputs -- which it runs as one launch; with `GGRS_BRANCH_RETAIN_*` every branch's frames are kept in private
+/// state blocks, and when the true inputs arrive `adopt` makes the matching branch's state the world: a ring-slot swap on the rank that ran the
+/// branch, a re-simulation with the confirmed inputs (`replay`) or one broadcast on the others.  The C++ twin (`bevy_ggrs::SpeculativeFanout`) is what
+/// tests/cpp/host_test.cpp runs.
+pub struct SpeculativeFanout {
+    raw: *mut ffi::ggrs_fanout,
+    size: i32,
+}
+unsafe impl Send for SpeculativeFanout {}
+
+impl SpeculativeFanout {
+    /// Rank 0 creates the 128-byte id and carries it to the other ranks (any side channel).
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        assert_eq!(unsafe { ffi::ggrs_hip_fanout_unique_id(id.as_mut_ptr()) }, ffi::GGRS_OK, "ncclGetUniqueId failed (is librccl.so loadable?)");
+        id
+    }
+    pub fn new(world: &HipWorld, id: &[u8; 128], rank: i32, world_size: i32) -> Self {
+        let mut raw = core::ptr::null_mut();
+        world.check(unsafe { ffi::ggrs_hip_fanout_init(world.raw, id.as_ptr(), rank, world_size, &mut raw) });
+        Self { raw, size: world_size }
+    }
+    fn check(&self, rc: i32) {
+        if rc != ffi::GGRS_OK {
+            panic!("{}", unsafe { CStr::from_ptr(ffi::ggrs_hip_fanout_last_error(self.raw)) }.to_string_lossy());
+        }
+    }
+    pub fn sync_confirmed(&self, root: i32) {
+        self.check(unsafe { ffi::ggrs_hip_fanout_sync_confirmed(self.raw, root) });
+    }
+    pub fn set_interval(&self, steps_per_all_gather: u32) {
+        self.check(unsafe { ffi::ggrs_hip_fanout_set_interval(self.raw, steps_per_all_gather) });
+    }
+    /// `inputs`: `[branch][frame][player x input bytes]`; returns the step's SaveGameState count.
+    pub fn step_branches(&self, prefix: &[ffi::ggrs_request], n_branches: u32, n_frames: u32, n_inputs: u32, inputs: &[u8], flags: u32,
+                         spawn_table: &[ffi::ggrs_branch_spawn], spawn_sel: &[u16]) -> u32 {
+        let st = ffi::ggrs_branch_step {
+            prefix: prefix.as_ptr(), n_prefix: prefix.len() as u32, n_branches, n_frames, n_inputs, flags, n_spawn_table: spawn_table.len() as u32,
+            inputs: inputs.as_ptr(), status: core::ptr::null(),
+            spawn_table: if spawn_table.is_empty() { core::ptr::null() } else { spawn_table.as_ptr() },
+            spawn_sel: if spawn_sel.is_empty() { core::ptr::null() } else { spawn_sel.as_ptr() },
+        };
+        let mut ns = 0u32;
+        self.check(unsafe { ffi::ggrs_hip_fanout_step_branches(self.raw, &st, &mut ns) });
+        ns
+    }
+    /// Oldest all-gather group: `(steps, saves, [rank][step][save] Checksum(u128))`.
+    pub fn collect(&self) -> (u32, u32, Vec<u128>) {
+        let mut raw = vec![0u64; self.size as usize * 4096 * 2];
+        let (mut steps, mut saves) = (0u32, 0u32);
+        self.check(unsafe { ffi::ggrs_hip_fanout_collect(self.raw, raw.as_mut_ptr(), 4096, &mut steps, &mut saves) });
+        let n = self.size as usize * steps as usize * saves as usize;
+        (steps, saves, (0..n).map(|i| (raw[2 * i] as u128) | ((raw[2 * i + 1] as u128) << 64)).collect())
+    }
+    /// Collective: GLOBAL branch `branch`'s retained state of `frame` becomes the world.  Returns the Checksum(u128)s of `replay`'s SaveGameStates
+    /// on the ranks that re-simulated (empty on the owner): compare them with the branch's gathered ones.
+    pub fn adopt(&self, branch: u32, frame: i32, replay: &[ffi::ggrs_request], broadcast: bool) -> Vec<u128> {
+        let ns = replay.iter().filter(|r| r.kind == ffi::GGRS_REQ_SAVE).count();
+        let mut raw = vec![0u64; 2 * ns + 2];
+        let mut got = 0u32;
+        let mode = if broadcast { ffi::GGRS_ADOPT_BROADCAST } else { ffi::GGRS_ADOPT_RECOMPUTE };
+        self.check(unsafe { ffi::ggrs_hip_fanout_adopt(self.raw, branch, frame, mode, if replay.is_empty() { core::ptr::null() } else { replay.as_ptr() }, replay.len() as u32, raw.as_mut_ptr(), &mut got) });
+        (0..got as usize).map(|i| (raw[2 * i] as u128) | ((raw[2 * i + 1] as u128) << 64)).collect()
+    }
+}
+impl Drop for SpeculativeFanout {
+    fn drop(&mut self) {
+        unsafe { ffi::ggrs_hip_fanout_destroy(self.raw) }
+    }
+}
+
 /// A plain-old-data component whose fields are 4- or 8-byte words, stored as one SoA column per word
 /// (Transform = 10 x f32, Velocity = 3 x f32, Ttl = 1 x u64).  `unsafe`: the layout claim must hold.
 /// Implement it with [`hip_component!`].

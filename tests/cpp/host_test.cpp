@@ -618,6 +618,62 @@ static void particles(uint64_t n, int ticks, size_t cd, bool pipelined) {
 }
 
 
+// bevy_ggrs::SpeculativeFanout (ggrs_hip_fanout_*) from C++ at world size 1: a compact step of 3 branches x 4 frames with every frame KEPT, then the branch
+// whose prediction came true is adopted -- and the world must be what a second world reaches by simulating those frames in a straight line.
+// Product build only (the collectives and the branch blocks live inside libggrs_hip.so).
+static void speculative_fanout_adopts_matching_branch() {
+#ifndef BACKEND_ORACLE
+    auto build = [](TestApp& app, uint64_t n) {
+        app.insert_resource(RollbackFrameRate{60});
+        app.rollback_component_with_clone<Transform>().rollback_component_with_copy<Velocity>().rollback_component_with_copy<Ttl>();
+        app.checksum_component_with_hash<Velocity>();
+        app.checksum_component<Transform>({0, 1, 2});
+        const float tdef[10] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+        app.set_component_default<Transform>(tdef);
+        app.add_systems(GgrsSchedule{}, systems::update_particles<Transform, Velocity>(0, -200, 0));
+        app.add_systems(GgrsSchedule{}, systems::despawn_particles<Ttl>());
+        std::vector<float> vx(n), vy(n), vz(n, 0.0f); std::vector<uint64_t> ttl(n);
+        uint32_t s = 77;
+        for (uint64_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; vx[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f; s = s * 1664525u + 1013904223u; vy[i] = (float)(int32_t)(s >> 8) / 41943.04f - 200.0f; ttl[i] = 2 + i % 5; }
+        std::vector<const void*> cols(10, nullptr);
+        cols.push_back(vx.data()); cols.push_back(vy.data()); cols.push_back(vz.data()); cols.push_back(ttl.data());
+        app.spawn(n, {"Transform", "Velocity", "Ttl"}, cols);
+    };
+    const uint64_t n = 3000;
+    TestApp a(n + 64), b(n + 64);
+    build(a, n); build(b, n);
+    a.backend().set_depth(6); b.backend().set_depth(6);
+    SpeculativeFanout fan(a.backend(), SpeculativeFanout::unique_id(), 0, 1);
+    ggrs_request save0; std::memset(&save0, 0, sizeof save0); save0.kind = GGRS_REQ_SAVE; save0.frame = 0;
+    const uint32_t B = 3, T = 4;
+    std::vector<uint8_t> inputs(B * T, 0);
+    const uint32_t ns = fan.step_branches({save0}, B, T, 1, inputs, GGRS_BRANCH_RETAIN_ALL);
+    CHECK(ns == 1 + B * (T - 1));
+    uint32_t steps = 0, saves = 0;
+    const std::vector<u128> table = fan.collect(&steps, &saves);
+    CHECK(steps == 1 && saves == ns && table.size() == ns);
+    CHECK(a.backend().frame() == 0);                                   // branches are speculation: the world is where the prefix left it
+    // straight line on the second world: three frames, then the snapshot of frame 3
+    ggrs_request adv; std::memset(&adv, 0, sizeof adv); adv.kind = GGRS_REQ_ADVANCE; const uint8_t zero = 0; adv.inputs = &zero; adv.n_inputs = 1;
+    ggrs_request save3 = save0; save3.frame = 3;
+    std::vector<ggrs_request> line = {adv, adv, adv, save3};
+    uint64_t want[2] = {0, 0};
+    CHECK(b.backend().handle_requests(line.data(), (uint32_t)line.size(), want) == GGRS_OK);
+    for (uint32_t br = 0; br < B; ++br) CHECK(table[1 + br * (T - 1) + 2].lo == want[0] && table[1 + br * (T - 1) + 2].hi == want[1]);   // every branch predicted the same inputs here
+    fan.adopt(1, 3, line);
+    CHECK(a.backend().frame() == 3 && a.backend().has_snapshot(3));
+    uint64_t got[2] = {0, 0};
+    CHECK(a.backend().handle_requests(&save3, 1, got) == GGRS_OK);
+    CHECK(got[0] == want[0] && got[1] == want[1]);
+    const auto ya = a.download<Transform, uint32_t>(1), yb = b.download<Transform, uint32_t>(1);
+    CHECK(ya == yb && a.active_count() == b.active_count() && a.active_count() < n);
+    bool threw = false;
+    try { fan.adopt(0, 2, line); } catch (const std::runtime_error&) { threw = true; }      // the speculation is history once a branch was adopted
+    CHECK(threw);
+#endif
+    std::puts("ok speculative_fanout_adopts_matching_branch");
+}
+
 // The two restatements of ggrs's SyncTestSession::advance_frame (this header and bevy_ggrs_amd/session.py) must
 // emit the same requests: printed here, compared by tests/test_cpp_host.py::test_synctest_sessions_agree
 static void print_request_traces() {
@@ -644,6 +700,7 @@ int main(int argc, char** argv) {
     despawn_and_rollback_does_not_panic();
     custom_system_equals_builtin();
     user_written_spawner_and_strategy();
+    speculative_fanout_adopts_matching_branch();
     mismatch_fires_on_non_determinism();
     confirmed_frame_pruning();
     component_rollback_copy();

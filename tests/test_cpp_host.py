@@ -36,14 +36,16 @@ def _build(kind):
 def _run(exe, n):
     # the oracle's OpenMP loops must not spin up one thread per host core of the GPU box (256)
     env = dict(os.environ, OMP_NUM_THREADS="8")
-    return subprocess.run([exe, str(n)], check=True, capture_output=True, text=True, timeout=600, env=env).stdout
+    out = subprocess.run([exe, str(n)], check=True, capture_output=True, text=True, timeout=600, env=env).stdout
+    # librccl prints a banner to stdout when the product build's fan-out test initialises its communicator
+    return "".join(l for l in out.splitlines(keepends=True) if not l.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path")))
 
 
 EXPECTED = ["synctest_request_shape", "despawn_and_rollback_does_not_panic", "mismatch_fires_on_non_determinism",
             "confirmed_frame_pruning", "component_rollback_copy", "immutable_component_copy_strategy_rolls_back", "fixed_timestep_accumulator", "ggrs_time_survives_session_restart", "host_seahasher_known_answers",
             "host_ring_known_answers", "resource_inserted_mid_session_rolls_back", "resource_removed_mid_session_rolls_back",
             "resource_without_rollback_fires_mismatch", "resource_checksum_part_is_folded", "box_game_synctest", "particles",
-            "particles_pipelined"]
+            "particles_pipelined", "speculative_fanout_adopts_matching_branch"]
 
 
 def test_cpp_host_on_oracle_backend():
