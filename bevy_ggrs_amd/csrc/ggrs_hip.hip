@@ -102,7 +102,8 @@ uint64_t ggrs_hip_arena_bytes(uint64_t capacity, uint32_t max_depth, uint32_t n_
     const uint64_t mask = align_up(cap_pad / 8, ALIGN);
     // header + liveness/presence masks, 4 KiB aligned, then the tile-major word columns (bytes_per_slot x 8192 per layout tile; for a component
     // under a Strategy count its Stored words too)
-    const uint64_t state = align_up(align_up(ALIGN + (1 + (uint64_t)n_components) * mask, 4096) + cap_pad * bytes_per_slot, 4096);
+    // ... and the value tags: one u32 per 64-slot unit and word column (at most one column per registered byte)
+    const uint64_t state = align_up(align_up(align_up(ALIGN + (1 + (uint64_t)n_components) * mask, 4096) + cap_pad * bytes_per_slot, ALIGN) + (cap_pad / 64) * 4ull * bytes_per_slot, 4096);
     const uint64_t parts = align_up((uint64_t)(n_components + 1) * (cap_pad / TILE + 4096) * 8, ALIGN);
     const uint64_t side = align_up(mask + align_up(cap_pad * 4, ALIGN) + (uint64_t)n_components * mask + cap_pad * bytes_per_slot + (uint64_t)(bytes_per_slot + 1) * ALIGN, 4096);
     // + checksum units, mask scratch, the spawn staging buffer's device twin (GGRS_STAGE_BYTES, default 8 MiB; at most 1 GiB is accounted for here)
@@ -125,6 +126,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     delete w->jl; w->jl = nullptr;
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->d_branch_parts) (void)hipFree(w->d_branch_parts);
+    if (w->d_skip) (void)hipFree(w->d_skip);
     for (void* p : w->spec_allocs) (void)hipFree(p);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -328,6 +330,9 @@ int ggrs_dbg_replace_token(const char* body, const char* tok, const char* val, c
 //                              streak (the fuzzer: tests/test_fuzz_requests.py), 1 = the default policy
 //   ggrs_dbg_set_spec_shapes   places in the table of group shapes / specialised kernels (default 16), so that a P2P session's eight rollback lengths
 //                              exercise the least-recently-used eviction (tests/test_gpu_gen_groups.py)
+//   ggrs_dbg_set_value_tags    0 = no Save skips a column on its value tags, 1 = every world does, -1 = by size (the default: host_world.hpp VTAGS_MIN_BYTES);
+//                              before the world is sealed
+int ggrs_dbg_set_value_tags(ggrs_world* w, int mode) { if (!w || w->sealed) return -1; w->vtags_mode = mode; return 0; }
 int ggrs_dbg_set_lazy_live(ggrs_world* w, int on) { if (!w) return -1; w->lazy_live_on = on; return 0; }
 int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
@@ -354,7 +359,7 @@ int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void
             const void* src = cols ? cols[ci + k] : nullptr;
             if (src) { rc = copy_column(w, cc.col_base + k, first, count, const_cast<void*>(src), true); if (rc) return rc; }
         }
-        ver_touch_comp(w, c);                                       // new rows in every column of the bundle
+        ver_touch_comp(w, c); live_tags_lost_comp(w, c);            // new rows in every column of the bundle
         ci += cc.n_words;
     }
     ver_sync_live(w);
@@ -398,7 +403,7 @@ int ggrs_hip_insert_component(ggrs_world* w, uint32_t c, uint64_t slot, const vo
     const Comp& cc = w->comps[c];
     for (uint32_t k = 0; k < cc.n_words; ++k)
         { rc = copy_column(w, cc.col_base + k, slot, 1, const_cast<uint8_t*>((const uint8_t*)words + (size_t)k * cc.word_bytes), true); if (rc) return rc; }
-    ver_touch_comp(w, c); ver_sync_live(w);
+    ver_touch_comp(w, c); live_tags_lost_comp(w, c); ver_sync_live(w);
     hipLaunchKernelGGL(k_edit_mask_bit, dim3(1), dim3(1), 0, w->stream, w->live.ptr, w->off_present[c], slot, 1);
     HIPCHK(w, hipGetLastError());
     w->pending_valid = false;
@@ -423,7 +428,7 @@ int ggrs_hip_upload_word(ggrs_world* w, uint32_t c, uint32_t word, uint64_t firs
     if (c >= w->comps.size() || word >= w->comps[c].n_words || !range_ok(first, count, w->capacity) || !src) return w->fail(GGRS_E_INVALID, "bad upload_word arguments");
     const Comp& cc = w->comps[c];
     rc = copy_column(w, cc.col_base + word, first, count, const_cast<void*>(src), true); if (rc) return rc;
-    ver_touch(w, cc.col_base + word); ver_sync_live(w);
+    ver_touch(w, cc.col_base + word); live_tags_lost(w, cc.col_base + word); ver_sync_live(w);
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->pending_valid = false;
     return GGRS_OK;
@@ -744,7 +749,7 @@ int ggrs_hip_adopt_live_state(ggrs_world* w) {
     if (h.len > w->capacity) return w->fail(GGRS_E_INVALID, "adopted state has len %llu > capacity", (unsigned long long)h.len);
     w->len = h.len; w->frame = h.frame;
     w->live.dirty_len = std::max(w->live.dirty_len, w->len);
-    ver_touch_all(w); ver_sync_live(w);                            // every column is new
+    ver_touch_all(w); w->live.tag_ok = 0; ver_sync_live(w);        // every column is new
     w->pending_valid = false;
     return GGRS_OK;
 }
@@ -811,6 +816,8 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
                                                     : "hipStreamSynchronize (GGRS_SPIN_WAIT_US=0)");
     add("slots_covered", std::to_string(cover));
     add("row_versions", w->knobs.row_versions ? "on" : "off (GGRS_ROW_VERSIONS=0)");
+    add("value_tags", !w->sealed ? "unknown (not sealed)" : w->vtags ? "on: a Save skips the columns whose 64 values per unit the destination already holds (" + std::to_string(w->prof_skipped) + " bytes not stored in profiled launches)"
+                                 : "off (the world's steady Save moves less than " + std::to_string(VTAGS_MIN_BYTES >> 20) + " MB, or row versions are off)");
     if (needed) *needed = s.size() + 1;
     if (buf && cap) { const uint64_t n = std::min<uint64_t>(cap, s.size() + 1); memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }
     return GGRS_OK;
@@ -822,7 +829,8 @@ int ggrs_hip_profile_enable(ggrs_world* w, int on) {
     if (on) { DeviceGuard dg(w);
               for (auto& e : w->prof_events) { w->prof_pool.push_back(e.a); w->prof_pool.push_back(e.b); } w->prof_events.clear();
               while (w->prof_pool.size() < 512) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; w->prof_pool.push_back(e); }     // (outside whatever the caller times)
-              for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; w->prof_bytes[i] = 0; w->prof_launch_us[i].clear(); } }
+              for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) { w->prof_ms[i] = 0; w->prof_n[i] = 0; w->prof_bytes[i] = 0; w->prof_launch_us[i].clear(); }
+              w->prof_skipped = 0; if (w->d_skip) { (void)hipStreamSynchronize(w->stream); (void)hipMemset(w->d_skip, 0, 8); } }
     return GGRS_OK;
 }
 // drains the recorded event pairs into the per-class totals and per-launch lists
@@ -835,6 +843,12 @@ static int profile_drain(ggrs_world* w) {
         if (w->prof_pool.size() < 4096) { w->prof_pool.push_back(e.a); w->prof_pool.push_back(e.b); } else { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     w->prof_events.clear();
+    // value tags: what the profiled launches did NOT store comes off the bytes they were asked to move
+    if (w->d_skip) {
+        uint64_t skipped = 0;
+        HIPCHK(w, hipMemcpy(&skipped, w->d_skip, 8, hipMemcpyDeviceToHost));
+        if (skipped) { HIPCHK(w, hipMemset(w->d_skip, 0, 8)); w->prof_bytes[GGRS_KERNEL_TICK] -= std::min<uint64_t>(skipped, w->prof_bytes[GGRS_KERNEL_TICK]); w->prof_skipped += skipped; }
+    }
     return GGRS_OK;
 }
 int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t cls, float* us_out, uint32_t cap, uint32_t* n_out) {
@@ -849,6 +863,7 @@ int ggrs_hip_profile_read_launches(ggrs_world* w, uint32_t cls, float* us_out, u
 }
 int ggrs_hip_profile_read_bytes(ggrs_world* w, uint64_t* bytes_out) {
     if (!w || !bytes_out) return GGRS_E_INVALID;
+    if (w->d_skip && w->sealed) { DeviceGuard dg(w); const int rc = profile_drain(w); if (rc) return rc; }     // value tags: what the launches did not store is known once they ran
     for (int i = 0; i < (int)GGRS_KERNEL_CLASSES; ++i) bytes_out[i] = w->prof_bytes[i];
     return GGRS_OK;
 }

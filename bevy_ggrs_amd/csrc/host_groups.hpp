@@ -10,11 +10,29 @@
 
 namespace {
 
+// value tags: the ids a launch of `members` groups of `n_steps` steps may hand out (tag_base of its argument block); a wrap makes every block's tags invalid
+inline uint32_t vtags_reserve(ggrs_world* w, uint32_t n_steps, uint32_t members) {
+    const uint64_t need = (uint64_t)members * (n_steps + 2u);          // per member: one id for "unknown at the load", one per possible count of steps before a store (0 .. n_steps)
+    if ((uint64_t)w->tag_counter + need >= 0xFFFFFFF0ull) {
+        w->live.tag_ok = 0; for (auto& b : w->slots) b.tag_ok = 0; for (auto& b : w->spec_blocks) b.tag_ok = 0;
+        w->tag_counter = 1;
+    }
+    const uint32_t base = w->tag_counter; w->tag_counter += (uint32_t)need;
+    return base;
+}
+// the tags of a block as a SOURCE / DESTINATION of a launch: columns somebody else may write behind the library's back never count
+inline uint64_t block_tagok(const ggrs_world* w, const Block& b) {
+    uint64_t m = b.tag_ok & w->tag_cols;
+    if (&b == &w->live && w->live_handed_out) m = 0;
+    for (uint32_t c = 0; c < w->n_tcols && c < 64; ++c) if (w->col_ext[c]) m &= ~(1ull << c);
+    return m;
+}
 struct GroupState {
     Block* src; uint64_t cover; uint32_t src_is_live;
     Block* dsts[MAX_TICK_SAVES];
     uint64_t save_rows[MAX_TICK_SAVES];               // bit c: column c is stored with Save k (row versions)
     uint32_t save_pmask[MAX_TICK_SAVES];              // bit c: component c's presence mask is stored with Save k
+    uint64_t live_rows = 0;                           // columns the group's live write handles
     // (the versions Save k's slot holds once the group has run live in w->group_save_ver, [k][column]: no allocation per group)
 };
 // LoadGameState opens a group: the ring slot becomes the source (schedule_systems.rs:238-250)
@@ -113,8 +131,10 @@ void group_close(ggrs_world* w, GroupState& g, uint32_t n_saves, bool dead, bool
     for (uint32_t k = 0; k < n_saves; ++k) if (g.dsts[k]) {
         g.dsts[k]->dirty_len = new_dirty;
         std::copy(w->group_save_ver.begin() + (size_t)k * nc, w->group_save_ver.begin() + (size_t)(k + 1) * nc, g.dsts[k]->ver.begin());
+        // value tags: every column this Save handled now carries the tag of what it holds (stored with it, or found equal); without the feature a store leaves stale tags behind
+        if (w->vtags) g.dsts[k]->tag_ok |= g.save_rows[k] & w->tag_cols; else g.dsts[k]->tag_ok &= ~g.save_rows[k];
     }
-    if (wrote_live) { w->live.dirty_len = new_dirty; ver_sync_live(w); }
+    if (wrote_live) { w->live.dirty_len = new_dirty; ver_sync_live(w); if (w->vtags) w->live.tag_ok |= g.live_rows & w->tag_cols; else w->live.tag_ok &= ~g.live_rows; }
 }
 
 // Dead-snapshot elimination.  A request group whose NEXT request is a LoadGameState of a frame older than everything the
@@ -186,6 +206,7 @@ JitSig jit_steady_sig(const ggrs_world* w) {
     if (d >= 2 && !need.marks) g.dp_s = cover <= JIT_DP_MAX_SLOTS ? 1u : (cover <= 2 * JIT_DP_MAX_SLOTS ? 2u : (cover <= 6 * JIT_DP_MAX_SLOTS ? 3u : 0u));
     // an HBM-sized steady session leaves the live block unwritten (lazy live block, below): the next tick's LoadGameState never reads it
     if (g.nt && !need.marks && lazy_live_allowed(w)) { g.skip_live = 1; g.live_rows = 0; }
+    g.vtags = vtags_policy(w) ? 1u : 0u;
     return g;
 }
 
@@ -196,6 +217,7 @@ JitSig jit_steady_sig(const ggrs_world* w) {
 int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t lds, GgrsJitArgs& j, uint64_t bytes, hipEvent_t done = nullptr) {
     w->spin_n = 0;                                               // a finalize before this launch is no longer the list's last GPU operation (arm_spin)
     ff_attach(w, j);
+    j.skip_count = (w->prof && j.vtags) ? reinterpret_cast<ggrs_u64*>(w->d_skip) : nullptr;
     jit_pack(*w->jl, j, w->jit_argbuf.data());
     void* params[] = {w->jit_argbuf.data()};
     gx += j.ff_blocks;
@@ -225,7 +247,7 @@ hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j, bool members = f
     if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.n_saves || !j.n_ops) return nullptr;
     for (uint32_t k = 0; k < j.n_saves && !members; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
-    JitSig g; g.members = members ? 1u : 0u; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
+    JitSig g; g.members = members ? 1u : 0u; g.vtags = j.vtags; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
     g.n_steps = j.n_steps; g.src_is_live = j.src_is_live; g.skip_live = j.skip_live; g.nt = j.nt; g.cached_saves = j.cached_saves; g.save_pmask = j.save_pmask[0]; g.live_pmask = j.live_pmask; g.dp_s = j.dp_s; g.nt_loads = j.nt_loads;
     auto building = [](const JitSpecSlot& s) { return s.spec && s.spec->state.load(std::memory_order_acquire) == 1; };
     JitSpecSlot* s = nullptr;
@@ -354,6 +376,8 @@ int materialise_live(ggrs_world* w) {
     memcpy(j.inputs[0], st.inputs, sizeof st.inputs);
     j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver);
     j.load_rows = jit_static_reads(w) | j.live_rows;
+    j.vtags = w->vtags ? 1u : 0u;
+    if (j.vtags) { j.tag_base = vtags_reserve(w, 1, 1); j.src_tagok = block_tagok(w, *st.src); j.live_tagok = block_tagok(w, w->live); }
     const uint64_t cover = std::max(std::max(st.src->dirty_len, w->live.dirty_len), w->len);
     j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
     j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
@@ -364,6 +388,7 @@ int materialise_live(ggrs_world* w) {
     if (rc) return rc;
     w->live.dirty_len = std::max(st.src->dirty_len, w->len);
     ver_sync_live(w);
+    if (w->vtags) w->live.tag_ok |= j.live_rows & w->tag_cols; else w->live.tag_ok &= ~j.live_rows;
     st.valid = false; ++w->lazy_materialised;
     return GGRS_OK;
 }
@@ -495,6 +520,14 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             bytes_slot += rows_bytes_per_slot(w, j.save_rows[k], true);
         }
         if (wrote_live) { j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver); j.load_rows |= j.live_rows; bytes_slot += rows_bytes_per_slot(w, j.live_rows, false); }
+        gs.live_rows = j.live_rows;
+        // value tags: a group that stores nothing (a dead branch) has no use for them
+        j.vtags = (w->vtags && !dead) ? 1u : 0u;
+        if (j.vtags) {
+            j.tag_base = vtags_reserve(w, j.n_steps, 1);
+            j.src_tagok = block_tagok(w, *gs.src); j.live_tagok = wrote_live ? block_tagok(w, w->live) : 0;
+            for (uint32_t k = 0; k < j.n_saves; ++k) j.save_tagok[k] = (j.save_dst[k] && gs.dsts[k]) ? block_tagok(w, *gs.dsts[k]) : 0;
+        }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
@@ -622,6 +655,7 @@ int spec_blocks_reserve(ggrs_world* w, size_t n) {
             Block b; b.ptr = p + k * w->state_bytes; b.ver.assign(w->cur_ver.size(), VER_NONE);
             if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(b.ptr, 0xA5, w->state_bytes, w->stream));
             HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
+            HIPCHK(w, hipMemsetAsync(b.ptr + w->off_tags, 0, w->state_bytes - w->off_tags, w->stream));      // value tags: 0 = no identity
             w->spec_blocks.push_back(std::move(b));
         }
     }
@@ -732,7 +766,7 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
             cv = src.ver;
             if (w->has_strategy) for (uint32_t c = 0; c < w->comps.size(); ++c) if (w->comps[c].s_n_words && !w->comps[c].no_rollback) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) cv[w->comps[c].col_base + k] = ++w->ver_counter;
         }
-        auto keep_into = [&](uint32_t o, ggrs_u64* rows_out, ggrs_u32* pm_out) -> Block* {
+        auto keep_into = [&](uint32_t o, ggrs_u64* rows_out, ggrs_u32* pm_out, ggrs_u64* tagok_out) -> Block* {
             if (!keep_any || !(keep_all || o == n_out - 1)) return nullptr;
             Block* d = &w->spec_blocks[next_blk];
             if (keep) keep->blk[(size_t)b * n_out + o] = (int)next_blk;
@@ -740,6 +774,8 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
             uint64_t m = 0;
             for (uint32_t c = 0; c < w->n_tcols && c < 64; ++c) if (w->col_rb[c] && ver_differs(w, *d, cv, c)) m |= 1ull << c;
             *rows_out = m; *pm_out = pmask_differs(w, *d, cv);
+            *tagok_out = block_tagok(w, *d);
+            if (w->vtags) d->tag_ok |= m & w->tag_cols; else d->tag_ok &= ~m;
             d->ver = cv; d->len = len_b;
             load_rows |= m; store_bytes += rows_bytes_per_slot(w, m, o < S) * len_b;
             touched.push_back(d);
@@ -775,13 +811,14 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
             }
             if (i < S) {
                 j.save_len[k_save] = len_b; j.save_rows[k_save] = 0; j.save_pmask[k_save] = 0;
-                Block* d = keep_into(k_save, &j.save_rows[k_save], &j.save_pmask[k_save]);
+                j.save_tagok[k_save] = 0;
+                Block* d = keep_into(k_save, &j.save_rows[k_save], &j.save_pmask[k_save], &j.save_tagok[k_save]);
                 j.save_dst[k_save] = d ? d->ptr : nullptr;
                 ++k_save;
             }
         }
-        j.live = nullptr; j.live_rows = 0; j.live_pmask = 0;
-        if (tail_adv) { Block* d = keep_into(n_out - 1, &j.live_rows, &j.live_pmask); j.live = d ? d->ptr : nullptr; }
+        j.live = nullptr; j.live_rows = 0; j.live_pmask = 0; j.live_tagok = 0;
+        if (tail_adv) { Block* d = keep_into(n_out - 1, &j.live_rows, &j.live_pmask, &j.live_tagok); j.live = d ? d->ptr : nullptr; }
         max_len = std::max(max_len, len_b);
         jit_pack_member(L, j, rec.data() + (size_t)b * L.m.bytes);
     }
@@ -806,6 +843,8 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
     // branch blocks are written once and not read before an adoption: past what the caches hold they stream around them
     j.nt = (cover > JIT_NT_MIN_SLOTS || store_bytes > (128ull << 20)) ? 1u : 0u;
     j.cached_saves = 0; j.nt_loads = 0; j.dp_s = 0;
+    j.vtags = (w->vtags && keep_any) ? 1u : 0u;
+    if (j.vtags) { j.tag_base = vtags_reserve(w, T, B); j.src_tagok = block_tagok(w, src); }
     w->batch_ev_attached = false;
     hipFunction_t fn = jit_spec_for(w, j, true);                      // the copy of the kernel built for this op sequence, once the session has sent it often enough
     if (!fn) fn = w->jit_fn;

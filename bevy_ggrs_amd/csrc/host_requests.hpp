@@ -307,6 +307,7 @@ int run_spawn_systems(ggrs_world* w, const uint8_t* inputs, uint32_t n_inputs, u
         HIPCHK(w, hipGetLastError());
         rc = set_masks_for_range(w, first, spawn_count, (1ULL << cT) | (1ULL << cV) | (1ULL << cL)); if (rc) return rc;
         ver_touch_comp(w, cT); ver_touch_comp(w, cV); ver_touch_comp(w, cL); ver_sync_live(w);   // new rows in every column of the bundle
+        live_tags_lost_comp(w, cT); live_tags_lost_comp(w, cV); live_tags_lost_comp(w, cL);
         w->len += spawn_count;
         w->live.dirty_len = std::max(w->live.dirty_len, w->len);
         if (keep) w->pending_parts += gs; else w->pending_valid = false;
@@ -430,6 +431,7 @@ int do_advance(ggrs_world* w, const ggrs_request& r) {
     if (dt_bits == 0) dt_bits = dt_bits_for_frame(w->fps, w->frame);
     rc = step_despawn_confirmed(w); if (rc) return rc;         // AdvanceWorldSystems::DespawnConfirmed, before Main
     ver_step(w); ver_sync_live(w);                              // the systems write the live block in place
+    w->live.tag_ok = 0;                                         // (per-request kernels keep no value tags)
     const uint32_t g = tiles_for(w->len);
     const uint32_t n_cks = w->cks_args.n_cks;
     uint64_t* part_cnt = w->cks_args.part_cnt;

@@ -24,6 +24,7 @@ int seal(ggrs_world* w) {
     const std::string why = w->err;
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_ff_rows[0] = w->d_ff_rows[1] = nullptr; }
+    if (w->d_skip) { (void)hipFree(w->d_skip); w->d_skip = nullptr; }
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; w->d_hstage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -171,6 +172,8 @@ int seal_impl(ggrs_world* w) {
     if (w->knobs.debug_poison && w->own_arena) HIPCHK(w, hipMemsetAsync(w->arena, 0xA5, need, w->stream));
     uint8_t* p = w->arena;
     const uint32_t ncols = (uint32_t)w->col_off.size();
+    // value tags by default where a steady Save is bound by bytes: what the systems write x the world's slots (the knob: ggrs_dbg_set_value_tags)
+    w->vtags = w->gen_ok && vtags_policy(w);
     w->live.ptr = p; p += w->state_bytes;
     w->live.ver.assign(ncols + w->comps.size(), 0);                                   // == cur_ver: nothing has been written yet
     w->slots.resize(w->max_depth);
@@ -208,6 +211,10 @@ int seal_impl(ggrs_world* w) {
         HIPCHK(w, hipMemsetAsync(w->live.ptr, 0, head, w->stream));
         for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr, 0, head, w->stream));
         HIPCHK(w, hipMemsetAsync(side, 0, w->side_bytes, w->stream));     // no markers, no non-rollback components yet
+        // value tags: 0 = "no identity" in every block (a poisoned or recycled arena must not carry tags that happen to match)
+        const uint64_t tag_bytes = w->state_bytes - w->off_tags;
+        HIPCHK(w, hipMemsetAsync(w->live.ptr + w->off_tags, 0, tag_bytes, w->stream));
+        for (auto& b : w->slots) HIPCHK(w, hipMemsetAsync(b.ptr + w->off_tags, 0, tag_bytes, w->stream));
     }
     if (!units.empty()) HIPCHK(w, hipMemcpyAsync(w->d_units, units.data(), units.size() * sizeof(UnitDesc), hipMemcpyHostToDevice, w->stream));
     if (w->gen_ok) {
@@ -222,6 +229,7 @@ int seal_impl(ggrs_world* w) {
         w->ff_cur = 0; w->ff_pending = ggrs_world::FfPending{};
         if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + 2 * ff_bytes, w->stream));
     }
+    if (w->vtags) { HIPCHK(w, hipMalloc((void**)&w->d_skip, 8)); HIPCHK(w, hipMemsetAsync(w->d_skip, 0, 8, w->stream)); }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;
     return GGRS_OK;

@@ -37,6 +37,7 @@ struct Block {                           // one packed state block in the arena
     uint64_t dirty_len = 0;              // slots that may hold non-zero mask bits
     uint64_t len = 0;                    // host mirror of Header::len for ring slots
     std::vector<uint32_t> ver;           // per column: the version of the bytes this block holds (VER_NONE: unknown)
+    uint64_t tag_ok = 0;                 // bit c: the block's VALUE TAGS of column c (one per 64-slot unit, in the block's tag region) describe its bytes -- see ggrs_world::vtags
 };
 
 struct EventPair { hipEvent_t a, b; uint32_t cls; };
@@ -88,6 +89,7 @@ struct Knobs {
 constexpr uint64_t JIT_DP_MAX_SLOTS = 40 * 1024;            // depth-parallel roles: one output per role up to here, two up to x2, three up to x6 (profiles/r02dp, r02jit)
 constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20; // the group's first Save goes through the L2 while its rows are at most this (profiles/r03n, r04c)
 constexpr int JIT_SPEC_SHAPES = 16;                         // group shapes counted (and specialised kernels kept) per world
+constexpr uint64_t VTAGS_MIN_BYTES = 80ull << 20;           // value tags by default when one steady Save of the whole world moves at least this much: 3 M +16 %, 4 M +18 %, all-columns-hot 2 M +18 %; below (2 M -19 %, all-columns-hot 1 M -3 %) the launch is bound by its vector ALUs and the bookkeeping costs more than the bytes (profiles/r06h)
 constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;       // blocking calls: larger groups are folded by k_gen_finalize (the host's fold would be serial with the kernel)
 
 }  // namespace
@@ -96,9 +98,10 @@ constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;       // blocking calls: l
 struct JitSig {
     uint64_t op_bits = 0, save_rows = 0, live_rows = 0, load_rows = 0;
     uint32_t n_ops = 0, n_saves = 0, n_steps = 0, src_is_live = 0, skip_live = 0, nt = 0, cached_saves = 0, save_pmask = 0, live_pmask = 0, dp_s = 0, nt_loads = 0;
+    uint32_t vtags = 0;                   // value tags: Saves compare tags and skip columns whose bytes the destination already holds
     uint32_t members = 0;                 // a launch of batch members with records (ggrs_hip_fanout_step_branches): a.mtab stays an argument, the per-member fields are not literals
     bool operator==(const JitSig& o) const {
-        return members == o.members && op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
+        return members == o.members && vtags == o.vtags && op_bits == o.op_bits && save_rows == o.save_rows && live_rows == o.live_rows && load_rows == o.load_rows && n_ops == o.n_ops && n_saves == o.n_saves &&
                n_steps == o.n_steps && src_is_live == o.src_is_live && skip_live == o.skip_live && nt == o.nt && cached_saves == o.cached_saves &&
                save_pmask == o.save_pmask && live_pmask == o.live_pmask && dp_s == o.dp_s && nt_loads == o.nt_loads;
     }
@@ -180,6 +183,17 @@ struct ggrs_world {
     bool marks_possible = false;         // a RollbackDespawned marker may exist in the live world
     int32_t dc_local = 0;                // Local<ConfirmedFrameCount> of despawn_confirmed_entities (despawn.rs:92)
     uint64_t state_bytes = 0, off_alive = 0;
+    // VALUE TAGS.  Row versions know which columns a system MAY write; whether a column's values really changed only the kernel can see.  Every block carries,
+    // per 64-slot unit and word column, a 32-bit tag naming the identity of those 64 values: the generated kernel loads the source's tags with the unit, gives a
+    // column a fresh tag in the step that changes any of its 64 values (a wave-uniform __ballot of new != old), and at a Save compares with the tag the
+    // destination holds -- equal (and non-zero) tags mean equal bytes, and the store is skipped.  The stress_test's translation.z and velocity.x / .z never change:
+    // 12 of the 32 bytes a Save moves per entity.  Whoever writes a block's bytes WITHOUT the generated kernel (uploads, host-side spawns, collectives) clears
+    // that block's Block::tag_ok bits; tag 0 never matches; ids are unique per launch, step and batch member (tag_counter; a wrap invalidates every block).
+    uint64_t off_tags = 0; uint32_t tag_row_bytes = 0;     // the tag region of a block: [unit][column] u32
+    uint64_t tag_cols = 0;                                 // columns that carry tags (plain rollback columns; a component under a Strategy is always stored)
+    uint32_t tag_counter = 1;
+    int vtags_mode = -1; bool vtags = false;               // ggrs_dbg_set_value_tags: 0 off, 1 on, -1 by size (seal decides: VTAGS_MIN_BYTES)
+    uint64_t* d_skip = nullptr;                            // profiling: bytes the launches did NOT store thanks to the tags (ggrs_hip_profile_read_bytes stays honest)
     std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0 (component words first, then the Stored words of strategy components)
     std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
     std::vector<uint8_t> col_rb;                   // column is part of a rollback component (snapshotted)
@@ -287,6 +301,7 @@ struct ggrs_world {
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e; }
     double prof_ms[GGRS_KERNEL_CLASSES] = {};
     uint64_t prof_n[GGRS_KERNEL_CLASSES] = {};
+    uint64_t prof_skipped = 0;                                // bytes profiled launches did not store (value tags), already subtracted from prof_bytes
     uint64_t prof_bytes[GGRS_KERNEL_CLASSES] = {};            // algorithmic bytes the launches of a class were asked to move (rows x their extent)
     std::vector<float> prof_launch_us[GGRS_KERNEL_CLASSES];   // every launch since enable, in submission order (ggrs_hip_profile_read_launches)
     HostTimeline tl;
@@ -343,6 +358,9 @@ inline bool ver_differs(const ggrs_world* w, const Block& dst, const std::vector
 }
 // the live block holds exactly the logical live state (no fused group is being assembled)
 inline void ver_sync_live(ggrs_world* w) { w->live.ver = w->cur_ver; }
+// the HOST (or a kernel that keeps no tags) wrote bytes of these live columns: their value tags no longer describe them
+inline void live_tags_lost(ggrs_world* w, uint32_t col) { if (col < 64) w->live.tag_ok &= ~(1ull << col); }
+inline void live_tags_lost_comp(ggrs_world* w, uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) live_tags_lost(w, w->comps[c].col_base + k); }
 // presence masks of `dst` that differ from the ones `want` describes
 inline uint32_t pmask_differs(const ggrs_world* w, const Block& dst, const std::vector<uint32_t>& want) {
     uint32_t m = 0;
@@ -419,6 +437,11 @@ void build_layout(ggrs_world* w) {
         for (uint32_t k = 0; k < c.s_n_words; ++k) { w->col_off[c.scol_base + k] += cols_base; w->col_ts[c.scol_base + k] = w->ts; }
     }
     off = cols_base + (w->cap_pad / LAYOUT_TILE) * (uint64_t)w->ts;
+    // value tags: one u32 per 64-slot unit and component word column, [unit][column]
+    w->off_tags = align_up(off, ALIGN); w->tag_row_bytes = w->n_tcols * 4u;
+    off = w->off_tags + (w->cap_pad / 64) * (uint64_t)w->tag_row_bytes;
+    w->tag_cols = 0;
+    for (auto& c : w->comps) if (!c.no_rollback && !c.s_n_words) for (uint32_t k = 0; k < c.n_words && c.col_base + k < 64; ++k) w->tag_cols |= 1ull << (c.col_base + k);
     w->state_bytes = align_up(off, 4096);
     // ---- live-only side region, placed right behind the ring blocks
     w->side_off = (uint64_t)(w->max_depth + 1) * w->state_bytes;
@@ -468,5 +491,16 @@ uint32_t total_rows(const ggrs_world* w) {
 inline uint32_t bytes_per_slot(const ggrs_world* w) { return w->ts / LAYOUT_TILE; }
 
 inline uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + TILE - 1) / TILE); }
+
+// bytes per slot of the columns some system may write: what a steady SaveWorld moves
+inline uint64_t rows_bytes_hot(const ggrs_world* w) {
+    uint64_t b = 0, seen = 0;
+    for (size_t si = 0; si < w->sys_writes.size(); ++si) for (uint32_t c : w->sys_writes[si]) if (c < 64 && !((seen >> c) & 1ull)) { seen |= 1ull << c; b += w->col_wb[c]; }
+    return b;
+}
+// does this world's kernel keep value tags?  (what a layout-only world -- `make aot` -- can tell as well)
+inline bool vtags_policy(const ggrs_world* w) {
+    return w->knobs.row_versions && w->tag_cols && (w->vtags_mode == 1 || (w->vtags_mode < 0 && rows_bytes_hot(w) * w->capacity >= VTAGS_MIN_BYTES));
+}
 
 }  // namespace

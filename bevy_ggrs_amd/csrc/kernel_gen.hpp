@@ -189,6 +189,9 @@ struct GgrsJitArgs {
     // (host_groups.hpp, "fold-forward")
     const ggrs_u64* ff_rows; ggrs_u64* ff_out; ggrs_u64 ff_seq;
     ggrs_u64 live_rows, load_rows;                   // row versions: bit c = column c is stored with the live block / must be loaded at all
+    // VALUE TAGS (host_world.hpp ggrs_world::vtags): bit c = the block's tags of column c are valid; tag_base = the first of the ids this launch may hand out
+    // (n_steps + 2 per batch member); skip_count (profiling only): the launch adds the bytes it did NOT store
+    ggrs_u64 src_tagok, live_tagok; ggrs_u64* skip_count; ggrs_u64 save_tagok[16];
     ggrs_u64 op_bits, len;
     unsigned char* save_dst[16]; ggrs_u64 save_rows[16];   // bit c = column c is stored with that Save
     // A spawn system that fires inside the group (particles.rs:258-270, or a user-written one: ggrs_hip_add_spawn_system): step j appends
@@ -202,6 +205,7 @@ struct GgrsJitArgs {
     ggrs_u32 n_ops, n_saves, n_steps, src_is_live, skip_live, dp_s;
     ggrs_u32 part_stride, part_tstride, nt;          // parts[i * part_stride + tile * part_tstride] (row-major: g, 1; tile-major -- fold-forward --: 1, values per workgroup); nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
+    ggrs_u32 vtags, tag_base;
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
     ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
     ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
@@ -222,9 +226,9 @@ struct JitLayout {
     uint32_t in_stride = 0, in_bytes = 1, max_players = GGRS_MAX_PLAYERS;   // bytes of one step's input block on the device (0: no system reads PlayerInputs)
     // one batch member's record (GgrsJitArgs::mtab): byte offsets inside it, its size (a multiple of 8); absent fields keep offset 0 and are never read
     struct Member { uint32_t bytes = 0, save_dst = 0, save_rows = 0, save_len = 0, spawn_payload = 0, spawn_first = 0, live = 0, live_rows = 0, save_pmask = 0, live_pmask = 0,
-                    spawn_count = 0, n_inputs = 0, inputs = 0; } m;
+                    spawn_count = 0, n_inputs = 0, inputs = 0, save_tagok = 0, live_tagok = 0; } m;
 };
-struct JitNeeds { bool spawn, inputs, marks, box; };
+struct JitNeeds { bool spawn, inputs, marks, box, vtags; };
 JitNeeds jit_needs(const ggrs_world* w);
 // the device-side layout of this world's argument block: 8-byte fields first, then 4-byte, then bytes (no padding inside)
 JitLayout jit_layout(const ggrs_world* w) {
@@ -248,12 +252,13 @@ JitLayout jit_layout(const ggrs_world* w) {
         F1("const unsigned char*", src, true); F1("unsigned char*", live, true); F1("const unsigned char*", mtab, true); F1("ggrs_u64*", parts, true);
         F1("const ggrs_u64*", ff_rows, true); F1("ggrs_u64*", ff_out, true); F1("ggrs_u64", ff_seq, true);
         F1("ggrs_u64", live_rows, true); F1("ggrs_u64", load_rows, true); F1("ggrs_u64", op_bits, true); F1("ggrs_u64", len, true);
+        F1("ggrs_u64", src_tagok, need.vtags); F1("ggrs_u64", live_tagok, need.vtags); F1("ggrs_u64*", skip_count, need.vtags); FA("ggrs_u64", save_tagok, S, need.vtags);
         FA("unsigned char*", save_dst, S, true); FA("ggrs_u64", save_rows, S, true); FA("ggrs_u64", save_len, S, true);
         FS("const unsigned char*", spawn_payload, need.spawn); FS("ggrs_u64", spawn_first, need.spawn);
         FA("int", save_frame, S, true); FA("ggrs_u32", save_pmask, S, true);
         F1("ggrs_u32", live_pmask, true); F1("ggrs_u32", nt_loads, true); F1("ggrs_u32", n_ops, true); F1("ggrs_u32", n_saves, true); F1("ggrs_u32", n_steps, true);
         F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", part_tstride, true); F1("ggrs_u32", nt, true);
-        F1("ggrs_u32", n_units, true); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
+        F1("ggrs_u32", n_units, true); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
         FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
         FS("ggrs_u32", spawn_count, need.spawn);
         FS("unsigned char", step_flags, need.marks); FS("unsigned char", n_inputs, need.inputs);
@@ -283,6 +288,7 @@ JitLayout jit_layout(const ggrs_world* w) {
         L.m.save_dst = o; o += 8 * S; L.m.save_rows = o; o += 8 * S; L.m.save_len = o; o += 8 * S;
         if (need.spawn) { L.m.spawn_payload = o; o += 8 * T; L.m.spawn_first = o; o += 8 * T; }
         L.m.live = o; o += 8; L.m.live_rows = o; o += 8;
+        if (need.vtags) { L.m.save_tagok = o; o += 8 * S; L.m.live_tagok = o; o += 8; }
         L.m.save_pmask = o; o += 4 * S; L.m.live_pmask = o; o += 4;
         if (need.spawn) { L.m.spawn_count = o; o += 4 * T; }
         if (need.inputs) { L.m.n_inputs = o; o += T; L.m.inputs = o; o += T * L.in_stride; }
@@ -324,6 +330,7 @@ inline void jit_pack_member(const JitLayout& L, const GgrsJitArgs& j, unsigned c
     memcpy(buf + m.save_dst, j.save_dst, 8 * S); memcpy(buf + m.save_rows, j.save_rows, 8 * S); memcpy(buf + m.save_len, j.save_len, 8 * S);
     if (m.spawn_first) { memcpy(buf + m.spawn_payload, j.spawn_payload, 8 * T); memcpy(buf + m.spawn_first, j.spawn_first, 8 * T); memcpy(buf + m.spawn_count, j.spawn_count, 4 * T); }
     memcpy(buf + m.live, &j.live, 8); memcpy(buf + m.live_rows, &j.live_rows, 8);
+    if (m.live_tagok) { memcpy(buf + m.save_tagok, j.save_tagok, 8 * S); memcpy(buf + m.live_tagok, &j.live_tagok, 8); }
     memcpy(buf + m.save_pmask, j.save_pmask, 4 * S); memcpy(buf + m.live_pmask, &j.live_pmask, 4);
     if (m.inputs) { memcpy(buf + m.n_inputs, j.n_inputs, T); for (uint32_t r = 0; r < T && r < j.n_steps; ++r) memcpy(buf + m.inputs + r * L.in_stride, j.inputs[r], L.in_stride); }
 }
@@ -439,7 +446,8 @@ int jit_fused_spawn_system(const ggrs_world* w) {
 }
 // which optional parts of the argument block this world's kernel reads
 JitNeeds jit_needs(const ggrs_world* w) {
-    JitNeeds n{false, false, false, false};
+    JitNeeds n{false, false, false, false, false};
+    n.vtags = vtags_policy(w);
     n.spawn = jit_fused_spawn_system(w) >= 0;
     for (auto& d : w->systems) {
         n.inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
@@ -529,6 +537,12 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "__device__ __forceinline__ uint64_t mb_u64(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint64_t*)(mb + off); }\n"
          "__device__ __forceinline__ uint32_t mb_u32(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K uint32_t*)(mb + off); }\n"
          "__device__ __forceinline__ uint32_t mb_u8(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K unsigned char*)(mb + off); }\n"
+         "// value tags keep one 32-bit tag per COLUMN in lane `column` of a register: a wave-uniform 64-bit column mask therefore IS the set of lanes to touch.  These\n"
+         "// run one instruction under that mask (exec narrowed, the instruction, exec restored) instead of building a per-lane condition from the mask with VALU\n"
+         "// shifts and compares -- the generated kernel is bound by its vector ALUs\n"
+         "__device__ __forceinline__ uint64_t uni64(uint64_t m) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m); }   // wave-uniform by construction: say so\n"
+         "__device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %2\\n\\tv_mov_b32 %1, %3\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_), \"+v\"(v) : \"s\"(lanes), \"s\"(x)); }\n"
+         "__device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %3\\n\\tglobal_store_dword %1, %2, off\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_) : \"v\"(p), \"v\"(v), \"s\"(lanes) : \"memory\"); }\n"
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
@@ -586,8 +600,11 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    if (a.dp_s && o_first == a.n_saves && !writes_live) return;\n"
             "    // per-workgroup checksum partials [Save][component .. live count]: the waves fold into LDS\n"
             "    __shared__ ggrs_u64 s_acc[16 * %u];\n"
+            "%s"
             "    for (uint32_t i = tid; i < 16u * %uu; i += 256u) s_acc[i] = 0;\n",
-         n_cks + 1, n_cks, L.m.bytes, n_cks + 1, n_cks + 1);
+         n_cks + 1, n_cks, L.m.bytes, n_cks + 1,
+         vtags_policy(w) ? "    __shared__ ggrs_u64 s_skip;                                                // value tags, profiling: bytes this workgroup's Saves did not store\n    if (tid == 0) s_skip = 0;\n" : "",
+         n_cks + 1);
     if (lane_fold) sfmt(s, "    extern __shared__ ggrs_u64 s_lane[];                                  // [Save][checksummed component][lane]: a.n_saves * %u * 64 cells (dynamic LDS)\n"
                            "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) s_lane[i] = 0;\n", n_cks, n_cks * 64u);
     if (lds_inputs && IN_STRIDE)
@@ -742,6 +759,59 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     emit_load("a.src", "a.load_rows", "        ");
     s += "    }\n"
          "    const uint64_t ordB_0 = sea_order_lane(e0);\n";
+    // ---- value tags (host_world.hpp ggrs_world::vtags): lane c of `tn` holds the identity of column c's 64 values in this wave's unit.  Only worlds whose
+    // policy keeps tags (vtags_policy: a steady Save bound by bytes) carry the code at all: every other world's kernels are what they were without the feature
+    const bool VT = vtags_policy(w);
+    const uint32_t NTC = w->n_tcols, TAG_ROW = w->tag_row_bytes;
+    const unsigned long long OFF_TAGS = w->off_tags, TAGCOLS = w->tag_cols;
+    uint64_t wb_mask[4] = {0, 0, 0, 0};                              // columns by word size (1, 2, 4, 8 bytes): what a skipped column saves
+    for (uint32_t c = 0; c < nc; ++c) if (rb(c) && !strat(c)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) {
+        const uint32_t wb = w->comps[c].word_bytes; wb_mask[wb == 1 ? 0 : wb == 2 ? 1 : wb == 4 ? 2 : 3] |= 1ull << col(c, k);
+    }
+    if (VT)
+    sfmt(s, "    // VALUE TAGS: lane c of tn = the identity of column c's 64 values in this unit (0: none).  Loaded with the unit, renewed by the step that changes any of\n"
+            "    // the 64 values, compared with the destination's tag at every store: equal non-zero tags mean equal bytes, and the column is not stored again\n"
+            "    uint32_t tn = 0u;\n"
+            "    uint64_t chg = 0ull;                                                        // wave-uniform: bit c = column c changed in this unit since tn was last brought up to date\n"
+            "    const uint32_t tag_mine = a.tag_base + blockIdx.z * (a.n_steps + 2u);        // ids this (member of the) launch may hand out: +0 at the load, +1+j at a store after j steps (j <= n_steps)\n"
+            "    const uint32_t tag_lane = lane < %uu ? lane : 0u;\n"
+            "    if (a.vtags && lane < %uu) {\n"
+            "        if (in_len && ((a.src_tagok >> lane) & 1ull)) tn = *reinterpret_cast<const uint32_t*>(a.src + %lluull + (uint64_t)gu * %uu + tag_lane * 4u);\n"
+            "        if (tn == 0u) tn = tag_mine;\n"
+            "    }\n"
+            "#ifdef GGRS_SPEC\n"
+            "    // A copy built for one op sequence (GGRS_SPEC: the op loop is unrolled, a.n_saves a literal) loads the tags of EVERY destination up front: a load issued\n"
+            "    // inside a Save would sit behind the previous Save's stores and its latency on the wave's critical path, once per Save.  A destination written twice by\n"
+            "    // one launch (a ring shallower than the group) is then compared with the tag it held BEFORE the launch: that can only cost a redundant store, never a\n"
+            "    // wrong skip (the value in hand carries the source's identity or one this launch made).\n"
+            "    uint32_t dtv[%u]; uint32_t dtl = 0u;\n"
+            "    for (uint32_t k_ = 0; k_ < a.n_saves; ++k_) {\n"
+            "        const unsigned char* d_ = mb ? (const unsigned char*)mb_u64(mb, %uu + 8u * k_) : a.save_dst[k_];\n"
+            "        dtv[k_] = (a.vtags && in_len && d_ && lane < %uu) ? *reinterpret_cast<const uint32_t*>(d_ + %lluull + (uint64_t)gu * %uu + tag_lane * 4u) : 0u;\n"
+            "    }\n"
+            "    if (a.vtags && in_len && writes_live && lane < %uu) dtl = *reinterpret_cast<const uint32_t*>((mb ? (const unsigned char*)mb_u64(mb, %uu) : a.live) + %lluull + (uint64_t)gu * %uu + tag_lane * 4u);\n"
+            "#endif\n", NTC, NTC, OFF_TAGS, TAG_ROW, L.cap_saves, L.m.save_dst, NTC, OFF_TAGS, TAG_ROW, NTC, L.m.live, OFF_TAGS, TAG_ROW);
+    // a store into `blk` under the column mask `rows` (a non-const uint64_t in scope): columns whose tag the block already holds drop out of the mask
+    auto emit_tag_filter = [&](const char* blk, const char* rows, const char* tagok_expr, const char* indent, const char* prefetched) {
+        if (!VT) return;
+        std::string weight;                                          // bytes one slot saves when the columns of `same_` are not stored
+        for (int k = 0; k < 4; ++k) if (wb_mask[k]) { char b[96]; snprintf(b, sizeof b, "%s%uu * __popcll(same_ & 0x%llxull)", weight.empty() ? "" : " + ", 1u << k, (unsigned long long)wb_mask[k]); weight += b; }
+        sfmt(s, "%sif (a.vtags && chg) { set_lanes(tn, chg, tag_mine + 1u + sj); chg = 0ull; }      // what changed since the last store: a fresh identity (sj = steps so far)\n", indent);
+        sfmt(s, "%sif (a.vtags && in_len) {\n"
+                "%s    GGRS_G uint32_t* const tp_ = (GGRS_G uint32_t*)(%s + %lluull + (uint64_t)gu * %uu) + tag_lane;\n"
+                "#ifdef GGRS_SPEC\n"
+                "%s    const uint32_t dt_ = %s;\n"
+                "#else\n"
+                "%s    const uint32_t dt_ = *tp_;                                          // (lanes beyond the last column re-read column 0: their result is masked off)\n"
+                "#endif\n"
+                "%s    const uint64_t same_ = __ballot(dt_ == tn && dt_ != 0u) & %s & %s & 0x%llxull;\n"
+                "%s    %s &= ~same_;\n"
+                "%s    store_lanes(tp_, tn, %s & 0x%llxull);                              // what is stored now carries this identity\n"
+                "%s    if (a.skip_count && same_ && lane == 0) atomicAdd(&s_skip, (ggrs_u64)(min((uint64_t)64u, (uint64_t)a.len - (uint64_t)gu * 64u) * (%s)));\n"
+                "%s}\n",
+             indent, indent, blk, OFF_TAGS, TAG_ROW, indent, prefetched, indent, indent, tagok_expr, rows, TAGCOLS, indent, rows, indent, rows,
+             (unsigned long long)(NTC >= 64 ? ~0ull : ((1ull << NTC) - 1ull)), indent, weight.empty() ? "0u" : weight.c_str(), indent);
+    };
     // which word-list specs take the memoised form: 9..12 hashed bytes whose byte 8.. tail is made of whole fields
     std::vector<uint32_t> spec_bytes(n_cks, 0); std::vector<uint8_t> spec_memo(n_cks, 0);
     auto chunk_expr = [&](const Comp& cc, uint32_t c, uint32_t first, uint32_t nbytes) {      // bytes [first, first + nbytes) of the hashed stream as a u64 expression
@@ -791,8 +861,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "            const uint64_t alive_now = __ballot(alive_0);\n";
     sfmt(s, "            unsigned char* dst = mb ? (unsigned char*)mb_u64(mb, %uu + 8u * si) : a.save_dst[si];\n"
             "            if (dst) {\n"
-            "                const uint64_t rows = mb ? mb_u64(mb, %uu + 8u * si) : a.save_rows[si];\n"
+            "                uint64_t rows = mb ? mb_u64(mb, %uu + 8u * si) : a.save_rows[si];\n"
             "                const uint32_t pmask_s = mb ? mb_u32(mb, %uu + 4u * si) : a.save_pmask[si];\n", L.m.save_dst, L.m.save_rows, L.m.save_pmask);
+    { char te[96]; snprintf(te, sizeof te, "(mb ? mb_u64(mb, %uu + 8u * si) : a.save_tagok[si])", L.m.save_tagok); emit_tag_filter("dst", "rows", te, "                ", "dtv[si]"); }
     emit_store("dst", "rows", "pmask_s", "alive_now", "                ", true);
     sfmt(s, "                if (gu == 0 && lane == 0) {\n"
             "                    Header h; h.len = mb ? mb_u64(mb, %uu + 8u * si) : a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
@@ -837,6 +908,18 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "        } else {\n"
             "            // ---------------- AdvanceWorld: the registered systems, in order\n"
             "            const float dt = __uint_as_float(a.dt_bits[sj]);\n", n_cks);
+    // value tags: around every system, the columns IT may write as they were before it ran -- a column whose 64 values are not all what they were carries a
+    // fresh identity from here on (wave-uniform; per system, so that at most one write set of old values is alive at a time)
+    // (a step only RECORDS which columns changed -- one compare per column and scalar bookkeeping; the identities are renewed where they are needed, at the next store)
+    auto sys_det = [&](size_t si) { uint64_t m = 0; for (uint32_t c : w->sys_writes[si]) if (c < 64) m |= 1ull << c; return VT ? (m & w->tag_cols) : 0ull; };
+    // detection around a piece of code that writes `cols`: old values in, comparison out
+    auto det_in = [&](uint64_t cols) { if (!cols) return; s += "            {\n"; each_col(cols, [&](uint32_t c, uint32_t cl) { sfmt(s, "            const %s o%u_ = w%u_0;\n", wtype(c), cl, cl); }); };
+    auto det_out = [&](uint64_t cols) {
+        if (!cols) return;
+        s += "            if (a.vtags) {\n";
+        each_col(cols, [&](uint32_t, uint32_t cl) { sfmt(s, "                chg |= (__ballot(w%u_0 != o%u_) != 0ull) ? 0x%llxull : 0ull;\n", cl, cl, 1ull << cl); });
+        s += "            }\n            }\n";
+    };
     if (marks) {
         s += "            const uint32_t sflags = a.step_flags[sj];\n"
              "            const bool defer = sflags & 2u;                                            // despawn_rollback() defers (despawn.rs:129-137)\n"
@@ -853,15 +936,30 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     for (size_t i = 0; i < w->systems.size(); ++i) {
         const ggrs_system_desc& d = w->systems[i];
         if (d.kind == GGRS_SYS_CUSTOM) { char nm[24]; snprintf(nm, sizeof nm, "fr%zu", i); emit_frame(nm, d.fparam, d.iparam); }
+        const uint64_t det = d.kind == GGRS_SYS_PARTICLES_UPDATE ? 0ull : sys_det(i);      // (update_particles: per axis, below -- two old values alive at a time instead of six)
+        det_in(det);
         switch (d.kind) {
         case GGRS_SYS_PARTICLES_UPDATE: {
-            sfmt(s, "            if (alive_0 && p%u_0 && p%u_0) {                                     // particles.rs:272-280\n", d.comp[0], d.comp[1]);
-            for (uint32_t k = 0; k < 3; ++k) {
-                const uint32_t x = col(d.comp[0], d.word[0] + k), v = col(d.comp[1], d.word[1] + k);
-                sfmt(s, "                { const float nv = __uint_as_float(w%u_0) + %s * dt; w%u_0 = __float_as_uint(nv); w%u_0 = __float_as_uint(__uint_as_float(w%u_0) + nv * dt); }\n",
-                     v, f32_lit(d.fparam[k]).c_str(), v, x, x);
+            if (!sys_det(i)) {
+                sfmt(s, "            if (alive_0 && p%u_0 && p%u_0) {                                     // particles.rs:272-280\n", d.comp[0], d.comp[1]);
+                for (uint32_t k = 0; k < 3; ++k) {
+                    const uint32_t x = col(d.comp[0], d.word[0] + k), v = col(d.comp[1], d.word[1] + k);
+                    sfmt(s, "                { const float nv = __uint_as_float(w%u_0) + %s * dt; w%u_0 = __float_as_uint(nv); w%u_0 = __float_as_uint(__uint_as_float(w%u_0) + nv * dt); }\n",
+                         v, f32_lit(d.fparam[k]).c_str(), v, x, x);
+                }
+                s += "            }\n";
+            } else {
+                // value tags: axis by axis, each with its detection -- two old values alive at a time instead of six (the comparison sits outside the
+                // per-lane branch: __ballot needs every lane)
+                for (uint32_t k = 0; k < 3; ++k) {
+                    const uint32_t x = col(d.comp[0], d.word[0] + k), v = col(d.comp[1], d.word[1] + k);
+                    const uint64_t m = ((1ull << x) | (1ull << v)) & sys_det(i);
+                    det_in(m);
+                    sfmt(s, "            if (alive_0 && p%u_0 && p%u_0) { const float nv = __uint_as_float(w%u_0) + %s * dt; w%u_0 = __float_as_uint(nv); w%u_0 = __float_as_uint(__uint_as_float(w%u_0) + nv * dt); }   // particles.rs:272-280\n",
+                         d.comp[0], d.comp[1], v, f32_lit(d.fparam[k]).c_str(), v, x, x);
+                    det_out(m);
+                }
             }
-            s += "            }\n";
         } break;
         case GGRS_SYS_TTL_DESPAWN: {
             const uint32_t q = col(d.comp[0], d.word[0]);
@@ -910,6 +1008,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         } break;
         default: break;
         }
+        det_out(det);
     }
     if (spawn_sys >= 0) {
         // The spawn system, applied where Bevy applies its Commands: after the step's other systems.  The new rows are RollbackOrdered's next
@@ -950,8 +1049,12 @@ bool jit_source(const ggrs_world* w, std::string& s) {
                 sfmt(s, "                    w%u_0 = (%s)(%s)ent.w[%u];\n", col(sp.comp[b], sp.word[b]), wtype(sp.comp[b]), mtype(sp.comp[b]), b);
         }
         if (marks) s += "                    dis_0 = false;\n";
-        s += "                }\n"
-             "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n"
+        uint64_t bundle_cols = 0;
+        for (uint32_t c = 0; c < nc; ++c) if (rb(c) && ((bundle >> c) & 1ull)) for (uint32_t k = 0; k < w->comps[c].n_words; ++k) bundle_cols |= 1ull << col(c, k);
+        s += "                }\n";
+        if (VT) sfmt(s, "                // value tags: new rows in this unit -- every column of the bundle carries a fresh identity\n"
+                        "                if (a.vtags && __ballot(e0 >= sf_ && e0 < sf_ + sn_) != 0ull) chg |= 0x%llxull;\n", (unsigned long long)bundle_cols);
+        s += "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n"
              "            }\n";
     }
     s += "            ++sj;\n"
@@ -961,8 +1064,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "    if (my_live && writes_live) {\n"
          "        const uint64_t alive_now = __ballot(alive_0);\n";
     sfmt(s, "        unsigned char* const live_p = mb ? (unsigned char*)mb_u64(mb, %uu) : a.live;\n"
-            "        const uint64_t live_rows_v = mb ? mb_u64(mb, %uu) : a.live_rows;\n"
+            "        uint64_t live_rows_v = mb ? mb_u64(mb, %uu) : a.live_rows;\n"
             "        const uint32_t live_pm_v = mb ? mb_u32(mb, %uu) : a.live_pmask;\n", L.m.live, L.m.live_rows, L.m.live_pmask);
+    { char te[96]; snprintf(te, sizeof te, "(mb ? mb_u64(mb, %uu) : a.live_tagok)", L.m.live_tagok); emit_tag_filter("live_p", "live_rows_v", te, "        ", "dtl"); }
     emit_store("live_p", "live_rows_v", "live_pm_v", "alive_now", "        ", false);
     s += "    }\n";
     if (marks) {
@@ -982,6 +1086,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "        if (sv >= o_first && sv < o_last)\n"
             "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + (uint64_t)tile * a.part_tstride] = s_acc[i];\n"
             "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
+    if (VT) s += "    if (a.skip_count && tid == 0 && s_skip) atomicAdd(a.skip_count, s_skip);      // value tags, profiled launches only: bytes this workgroup did not store\n";
     s += "}\n";
     return true;
 }
@@ -1124,7 +1229,7 @@ uint32_t jit_replace_token(std::string& body, const std::string& tok, const std:
 }
 // The shape fields, by name: what jit_specialise turns into literals and what must NOT survive in a specialised body (tests/test_generated_kernel.py
 // checks the same list through ggrs_hip_generated_kernel_source).  `[si]`: the field is an array indexed by the Save counter in the generic text.
-static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads", "mtab"};
+static const char* const kJitShapeScalars[] = {"op_bits", "n_ops", "n_saves", "n_steps", "src_is_live", "skip_live", "dp_s", "nt", "cached_saves", "live_rows", "load_rows", "live_pmask", "nt_loads", "mtab", "vtags"};
 static const char* const kJitShapeArrays[] = {"save_rows", "save_pmask"};
 std::string jit_specialise(const std::string& generic, const JitSig& g) {
     const size_t k = generic.find("extern \"C\" __global__");
@@ -1136,7 +1241,8 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
         {"op_bits", lit64(g.op_bits)}, {"n_ops", lit32(g.n_ops)}, {"n_saves", lit32(g.n_saves)}, {"n_steps", lit32(g.n_steps)}, {"src_is_live", lit32(g.src_is_live)},
         {"skip_live", lit32(g.skip_live)}, {"dp_s", lit32(g.dp_s)}, {"nt", lit32(g.nt)}, {"cached_saves", lit32(g.cached_saves)}, {"live_rows", lit64(g.live_rows)},
         {"load_rows", lit64(g.load_rows)}, {"live_pmask", lit32(g.live_pmask)}, {"nt_loads", lit32(g.nt_loads)},
-        {"mtab", g.members ? "a.mtab" : "((const unsigned char*)0)"}};     // a copy for plain launches knows there are no member records; one for member launches (g.members) keeps the pointer
+        {"mtab", g.members ? "a.mtab" : "((const unsigned char*)0)"},     // a copy for plain launches knows there are no member records; one for member launches (g.members) keeps the pointer
+        {"vtags", lit32(g.vtags)}};
     static_assert(sizeof scalars / sizeof scalars[0] == sizeof kJitShapeScalars / sizeof kJitShapeScalars[0], "every shape scalar has a literal");
     const std::pair<const char*, std::string> arrays[] = {{"save_rows", lit64(g.save_rows)}, {"save_pmask", lit32(g.save_pmask)}};
     for (auto& sb : arrays) (void)jit_replace_token(body, std::string("a.") + sb.first + "[si]", sb.second);
@@ -1153,10 +1259,10 @@ std::string jit_specialise(const std::string& generic, const JitSig& g) {
     if (lp == std::string::npos) return "";
     body.insert(lp, "#pragma unroll\n");
     char note[360];
-    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u, live block %s%s\n", g.n_ops,
+    snprintf(note, sizeof note, "// specialised: %u ops (bits %llx), %u Saves, rows %llx / live %llx / load %llx, masks %x / %x, nt %u, cached %x, nt loads %u, roles of %u, live block %s, value tags %u%s\n", g.n_ops,
              (unsigned long long)g.op_bits, g.n_saves, (unsigned long long)g.save_rows, (unsigned long long)g.live_rows, (unsigned long long)g.load_rows, g.save_pmask, g.live_pmask, g.nt, g.cached_saves, g.nt_loads, g.dp_s,
-             g.skip_live ? "left unwritten" : "written", g.members ? "; batch members with records (destinations, rows, inputs and spawns per member)" : "");
-    return head + note + body;
+             g.skip_live ? "left unwritten" : "written", g.vtags, g.members ? "; batch members with records (destinations, rows, inputs and spawns per member)" : "");
+    return "#define GGRS_SPEC 1\n" + head + note + body;
 }
 // Build (or load from the disk cache / the shipped objects) without touching a world: runs on a worker thread
 void jit_spec_build(JitSpec* sp, int device, std::string src, std::string cache_dir, std::string aot_knob, bool no_hiprtc) {

@@ -88,6 +88,27 @@ def test_hip_matches_the_oracle_on_random_request_lists_lazy_live_block_forced(s
     fuzz_util.run(3000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _lazy_world, n_lists=30, generic=generic)
 
 
+def _tagged_world(sc):
+    """Value tags forced on (test hook: by default only worlds whose steady Save is bound by bytes keep them) AND the lazy live block forced: whatever the fuzzer
+    does between two lists must take the tags of the bytes it wrote with it."""
+    w = bg.World(sc.capacity, max_depth=8)
+    assert w._lib.ggrs_dbg_set_value_tags(w._p, 1) == 0 and w._lib.ggrs_dbg_set_lazy_live(w._p, 2 if sc.seed % 2 else 1) == 0
+    return w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True], ids=["particles", "generic"])
+@pytest.mark.parametrize("seed", seeds(80))
+def test_hip_matches_the_oracle_on_random_request_lists_value_tags_forced(seed, generic):
+    fuzz_util.run(5000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _tagged_world, n_lists=30, generic=generic)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_hip_matches_the_oracle_on_random_request_lists_value_tags_forced_hbm_sized(seed):
+    fuzz_util.run(6000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _tagged_world, n_lists=10, big=True, state_every=10)
+
+
 @pytest.mark.parametrize("seed", seeds(60))
 def test_restatements_agree_across_the_i32_frame_wrap(seed):
     """A session whose RollbackFrameCount passes i32::MAX while it runs (Frame = i32: the counters wrap, `GgrsSnapshots::push` decides
