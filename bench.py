@@ -277,7 +277,7 @@ def oracle_checksum_at(n, depth, frame, confirmed_input, spawn_rate=0):
     return cs
 
 
-def latency_floor(kernel_us, launches_per_tick, tick_us, same_pass=None):
+def latency_floor(kernel_us, launches_per_tick, tick_us, same_pass=None, kernel_min_us=None):
     """Small worlds (the whole ring lives in L2 / the Infinity Cache) are bound by launch latency, not by HBM: a tick cannot be shorter than
     its kernels plus one dependent same-stream boundary per launch -- 1.45 us between trivial kernels, 1.7-1.9 us between real streaming
     ones (MI355X_MICROARCH.md, price list row `boundary`).  Reported next to `roofline` for BASELINE configs 2 and 4.
@@ -293,6 +293,12 @@ def latency_floor(kernel_us, launches_per_tick, tick_us, same_pass=None):
            "frac": [round(lo / t_us, 3), round(hi / t_us, 3)] if t_us else None}
     # the lower boundary figure is the floor: kernels + the shortest dependent hand-off the platform does; the upper one is what streaming kernels usually pay
     out["consistent"] = bool(t_us and lo <= t_us * 1.0005)
+    if same_pass and tick_us:
+        # the timing events themselves slow a small world's tick (the runtime timestamps every dispatch: +10 us per tick at 10 k), so the same-pass fraction prices the
+        # INSTRUMENTED loop.  Against the un-instrumented timed tick only a bound can be given without mixing passes: the fastest kernel any pass has seen + one boundary
+        # cannot be longer than a tick that contains that kernel
+        out["instrumentation_us_per_tick"] = round(t_us - tick_us, 2)
+        if kernel_min_us: out["frac_timed_tick_lower_bound"] = round((kernel_min_us * launches_per_tick + 1.45 * launches_per_tick) / tick_us, 3)
     return out
 
 
@@ -685,7 +691,7 @@ def c_loop_synctest(bg, cm, torch, n, D, K, schema="headline", inflight=1, kerne
     # the kernel's own duration UNDER THIS LOOP (HIP events riding on the dispatches of 200 more ticks): a small world's kernel is only as fast as the rocprofv3
     # trace says (5.6 us at 10 k) while the GPU is kept busy -- behind a host-bound loop it starts from an idle, clock-gated chip and reads 8 us
     w.profile_enable(True)
-    s2 = C.c_double(0); n_prof = 400
+    s2 = C.c_double(0); n_prof = 200                       # (the library's pool holds timing events for 256 launches: beyond it every launch creates two)
     rc = lib.ggrs_bench_synctest_loop(w._p, D, n_prof, inflight, None, C.byref(s2), None); assert rc == 0, rc
     lus_raw = w.profile_launches("tick"); lus = sorted(lus_raw); w.profile_enable(False)
     k_us = lus[len(lus) // 2] if lus else (kernel_us or 0.0)
@@ -697,7 +703,7 @@ def c_loop_synctest(bg, cm, torch, n, D, K, schema="headline", inflight=1, kerne
            "kernel_us": {"median_under_this_loop": round(k_us, 2), "min": round(lus[0], 2) if lus else None, "launches": len(lus), "under_the_python_loop": kernel_us}}
     # kernel time: the median of the instrumented pass (timing events ride on the dispatches and come from a pool since profiles/r05j -- creating them per launch
     # kept the host behind the device and the kernels started from an idle chip: 8.5 instead of 5.3 us); tick: the un-instrumented timed region
-    if k_us: out["latency_floor"] = latency_floor(k_us, 1.0, secs.value / K * 1e6, same_pass=same if inflight == 1 else None)
+    if k_us: out["latency_floor"] = latency_floor(k_us, 1.0, secs.value / K * 1e6, same_pass=same if inflight == 1 else None, kernel_min_us=lus[0] if lus else None)
     out["platform_floor"] = platform_loop_floor(inflight, secs.value / K * 1e6, k_us)
     P = min(parity_ticks, K)
     if P:
@@ -766,7 +772,7 @@ def c_loop_p2p(bg, cm, torch, n, R, K, kernel_us=None, launches_per_tick=1.0):
     out = {"host_loop": "C (benches/tick_loop.c through the C ABI)", "ticks_in_flight": 1, "steps": K, "ms_per_step": secs.value / K * 1e3, "value": live * advances / secs.value, "unit": "entity-frames/s",
            "tick_wall_us": {"median": round(t[K // 2], 2), "p10": round(t[K // 10], 2), "p90": round(t[(9 * K) // 10], 2)},
            "kernel_us": {"mean_under_this_loop": round(k_us, 2), "priced": "per rollback length, weighted by the timed ticks' lengths", "launches_per_tick": round(lpt, 3), "under_the_python_loop": kernel_us}}
-    if k_us: out["latency_floor"] = latency_floor(k_us, lpt, secs.value / K * 1e6, same_pass=same)
+    if k_us: out["latency_floor"] = latency_floor(k_us, lpt, secs.value / K * 1e6, same_pass=same, kernel_min_us=min(lus) if lus else None)
     out["platform_floor"] = platform_loop_floor(1, secs.value / K * 1e6, k_us)
     # every Save of every tick (warm-up included) against the oracle under the same script
     from oracle.binding import FLAT, OracleWorld, lib as olib

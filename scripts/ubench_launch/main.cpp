@@ -83,6 +83,32 @@ int main(int argc, char** argv) {
         }
         for (int q = 0; q < 4; ++q) CK(hipEventDestroy(ev[q]));
     }
+    {   // ---- the resident-kernel mailbox form of the same tick: no launch per tick, the host writes a tick number into pinned memory and polls another
+        hipFunction_t mail; CK(hipModuleGetFunction(&mail, mod, "k_mailbox"));
+        volatile unsigned long long* h; CK(hipHostMalloc((void**)&h, 4096, hipHostMallocMapped));
+        unsigned long long* d_h; CK(hipHostGetDevicePointer((void**)&d_h, (void*)h, 0));
+        unsigned long long* d_flags; CK(hipMalloc((void**)&d_flags, 256));
+        for (int kernel_100ns : {20, 56, 80}) {
+            const int N = 20000;
+            h[0] = 0; h[64] = 0;                                  // cmd and done in different cache lines
+            CK(hipMemset(d_flags, 0, 256));
+            struct { volatile unsigned long long* cmd; volatile unsigned long long* done; unsigned long long* dev; unsigned int n, ticks; } a;
+            a.cmd = d_h; a.done = d_h + 64; a.dev = d_flags; a.n = (unsigned)kernel_100ns * 10; a.ticks = N;
+            void* params[] = {&a};
+            CK(hipModuleLaunchKernel(mail, 40, 1, 1, 256, 1, 1, 0, st, params, nullptr));
+            const double t0 = now_us();
+            bool ok = true;
+            for (unsigned long long k = 1; k <= (unsigned long long)N && ok; ++k) {
+                __atomic_store_n(&h[0], k, __ATOMIC_RELEASE);
+                const double w0 = now_us();
+                while (__atomic_load_n(&h[64], __ATOMIC_ACQUIRE) < k) { __builtin_ia32_pause(); if (now_us() - w0 > 2e6) { ok = false; break; } }
+            }
+            const double per = (now_us() - t0) / N;
+            CK(hipStreamSynchronize(st));
+            printf("  \"resident_mailbox_tick_kernel_%.1fus\": %s%.3f,\n", kernel_100ns / 10.0, ok ? "" : "-", per);
+        }
+        CK(hipFree(d_flags)); CK(hipHostFree((void*)h));
+    }
     {   // what the two waits cost on an event that is already complete
         hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hipFunction_t fn; CK(hipModuleGetFunction(&fn, mod, "k_args_64"));
