@@ -259,6 +259,50 @@ def fanout_parity(n, depth, c_timed, raw, size, bpr, branch_input, confirmed_inp
     return out
 
 
+def measure_traffic_now(args, budget_s=120.0):
+    """HBM bytes per `ggrs_jit_tick` launch, MEASURED in this run: bench.py starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two do not fit
+    one pass on gfx950, MI355X_MICROARCH.md; counters only, no trace domains) around its own short form (76 ticks, no pre-heat, no CPU legs, no extras) and reads the
+    counter CSVs: KiB per dispatch, second half of the dispatches (steady state).  The generated kernel reads 4 bytes per lane: FETCH_SIZE is taken as reported (the
+    guide's x2 correction is calibrated for 16-byte-per-lane reads), WRITE_SIZE is calibrated against a known snapshot copy.  Any failure leaves the figure to the
+    committed profile and says why."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe): return {"error": "rocprofv3 not found"}
+    t0 = time.perf_counter()
+    out = {"passes": {}, "command": "rocprofv3 --pmc <counter> -f csv -- python bench.py --steps 60 --warmup 16 --no-cpu-baseline --preheat-ms 0 --no-extra --no-traffic"}
+    tmp = tempfile.mkdtemp(prefix="ggrs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"): env.pop(key, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            if time.perf_counter() - t0 > budget_s: out["passes"][counter] = {"skipped": "budget"}; continue
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-f", "csv", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "16", "--no-cpu-baseline",
+                   "--preheat-ms", "0", "--no-extra", "--no-traffic", "--entities", str(args.entities), "--depth", str(args.depth), "--schema", args.schema]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=max(30.0, budget_s - (time.perf_counter() - t0)))
+            except subprocess.TimeoutExpired:
+                out["passes"][counter] = {"error": "timeout"}; continue
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and "ggrs_jit_tick" in row.get("Kernel_Name", ""): vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 20:
+                out["passes"][counter] = {"error": f"rc {r.returncode}, {len(vals)} dispatches", "stderr_tail": r.stderr[-300:]}; continue
+            half = vals[len(vals) // 2:]
+            out["passes"][counter] = {"KiB_per_dispatch_mean": sum(half) / len(half), "dispatches": len(vals)}
+        f_, w_ = out["passes"].get("FETCH_SIZE", {}), out["passes"].get("WRITE_SIZE", {})
+        if "KiB_per_dispatch_mean" in f_ and "KiB_per_dispatch_mean" in w_:
+            out["hbm_bytes_per_launch"] = (f_["KiB_per_dispatch_mean"] + w_["KiB_per_dispatch_mean"]) * 1024
+            out["fetch_bytes"], out["write_bytes"] = f_["KiB_per_dispatch_mean"] * 1024, w_["KiB_per_dispatch_mean"] * 1024
+            out["source"] = ("MEASURED IN THIS RUN: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate counter-only passes of this command's short form, started by bench.py "
+                             "after its clock stopped); FETCH as reported (4-byte-per-lane reads), WRITE calibrated (MI355X_MICROARCH.md)")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def oracle_checksum_at(n, depth, frame, confirmed_input, spawn_rate=0):
     """Checksum(u128) of SaveWorld at `frame` of ONE oracle world that simulated the confirmed inputs frame by frame from the synthetic start (what an adopted
     branch state must equal)."""
@@ -824,6 +868,12 @@ def single_line(bg, cm, torch, args, dev):
                     traffic_source = f"{tj.get('source', 'profiles/roofline_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's box; NOT measured in this run)"
         except Exception:
             traffic = None
+    if getattr(args, "measure_traffic", False) and grouped:
+        # the driver's own record carries MEASURED traffic: two rocprofv3 counter passes of this command's short form, started here after the clock stopped
+        live_t = measure_traffic_now(args)
+        if live_t.get("hbm_bytes_per_launch"):
+            traffic, traffic_source = live_t["hbm_bytes_per_launch"], live_t["source"]
+        m["traffic_passes"] = live_t
     save_bytes, tick_bytes = 2 * bps, 2 * bps + 2 * bps * D + ADV_BYTES * (D + 1)
     launches_per_step = 1.0
     if grouped:
@@ -877,6 +927,7 @@ def single_line(bg, cm, torch, args, dev):
                    "host_api": "synchronous handle_requests" if args.sync else "enqueue/collect, 1 tick in flight", **({"DIAGNOSTIC_no_component_checksums": True} if args.no_checksum else {})},
         "preheat": m.get("preheat"), "roofline": roof,
     }
+    if m.get("traffic_passes"): line["roofline"]["traffic_passes"] = m["traffic_passes"]
     if grouped and n * bps * (D + 1) <= (256 << 20):
         # the whole ring fits the 256 MB Infinity Cache: launch / latency bound ("report it but do not judge it against HBM peak")
         n_prof_ = max(min(K, 50), 1)
@@ -1228,12 +1279,14 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip `extra_configs` (configs 2 / 4 / 5, the all-columns-hot world), which the default N = 1 headline run "
                     "measures after its clock has stopped")
     ap.add_argument("--extra-budget-s", type=float, default=150.0, help="wall-time budget of `extra_configs`: configs that would start beyond it are reported as skipped")
+    ap.add_argument("--no-traffic", action="store_true", help="headline: do not start the two rocprofv3 counter passes that put MEASURED HBM bytes per launch into roofline.traffic")
     ap.add_argument("--no-lazy-live", action="store_true", help="A/B: every tick writes the live block (the library's test hook ggrs_dbg_set_lazy_live)")
     ap.add_argument("--no-checksum", action="store_true", help="DIAGNOSTIC ONLY: no component checksums registered (isolates the hash ALU cost; not a valid bench line)")
     args = ap.parse_args()
     if args.no_lazy_live: os.environ["BENCH_NO_LAZY_LIVE"] = "1"
     default_headline = (args.config == 3 and args.entities == 1_000_000 and args.depth == 8 and args.schema == "headline" and not (args.fanout or args.sync or args.unfused or args.no_groups
                         or args.nt or args.no_checksum or args.no_cpu_baseline or args.branches != 1))
+    args.measure_traffic = default_headline and not args.no_traffic and args.gpus == 1
     if args.config == 2: args.entities = 10_000
     if args.config == 4: args.entities = 100_000
     if args.config == 5:
