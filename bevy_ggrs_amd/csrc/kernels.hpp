@@ -29,7 +29,7 @@ namespace ggrs {
 constexpr int TILE = 1024;     // slots per workgroup
 // LT_SHIFT = 13 / LAYOUT_TILE = 8192 (slots of a LAYOUT tile = 8 workgroup tiles) are declared in device_prelude.hpp
 constexpr int TPB = 256;       // threads per workgroup (4 waves of 64)
-constexpr int MAX_ROWS = 96;   // 4 KiB copy rows per tile (a 4-byte column = 1 row, 8-byte = 2)
+constexpr int MAX_ROWS = 128;  // 4 KiB copy rows per tile (a 4-byte column = 1 row, 8-byte = 2): 64 eight-byte words
 constexpr int MAX_COMPS = GGRS_MAX_COMPONENTS;
 constexpr int MAX_MASKS = MAX_COMPS + 1;  // alive + one presence mask per component
 constexpr int MAX_UNITS = 32;

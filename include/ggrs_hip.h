@@ -262,7 +262,7 @@ int ggrs_hip_add_spawn_system(ggrs_world* w, const ggrs_spawn_system_desc* desc)
  * hashes to one.  This returns that HIP C++ source (NUL-terminated): *needed = bytes incl. the NUL, min(cap, *needed)
  * bytes are copied.  compile != 0 also builds it for gfx950 (no device needed) and fails with the compiler log in
  * ggrs_hip_last_error if it does not build.  GGRS_E_INVALID: the world is outside what the generator covers (a system that
- * writes a live-only component, more than 64 four-byte register units or 64 words per entity).  Registration must be
+ * writes a live-only component, more than 64 words per entity).  Registration must be
  * complete; on a GGRS_WORLD_LAYOUT_ONLY world this works without a GPU.  docs/generated/ holds the text of the headline world in both forms. */
 #define GGRS_KERNEL_FORM_TILES      1u
 #define GGRS_KERNEL_FORM_STEADY     3u   /* the same kernel specialised for the steady SyncTest tick of this world at full length ([Load, Advance, (Save,
