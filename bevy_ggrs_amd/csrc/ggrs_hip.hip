@@ -127,6 +127,7 @@ void ggrs_hip_world_destroy(ggrs_world* w) {
     if (w->d_gen_parts) (void)hipFree(w->d_gen_parts);
     if (w->d_branch_parts) (void)hipFree(w->d_branch_parts);
     if (w->d_skip) (void)hipFree(w->d_skip);
+    sp_release(w);
     for (void* p : w->spec_allocs) (void)hipFree(p);
     if (w->h_results) (void)hipHostFree(w->h_results);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -337,8 +338,9 @@ int ggrs_dbg_set_lazy_live(ggrs_world* w, int on) { if (!w) return -1; w->lazy_l
 int ggrs_dbg_set_spec_shapes(ggrs_world* w, int n) { if (!w || n < 1 || n > 64) return -1; w->spec_shapes = n; return 0; }
 int ggrs_hip_set_frame_rate(ggrs_world* w, uint64_t fps) { if (!w || fps == 0) return GGRS_E_INVALID; w->fps = fps; return GGRS_OK; }
 
-// entry points that read or edit the live block's BYTES: a lazily skipped live block (host_groups.hpp) is materialised first
-static int seal_live(ggrs_world* w) { int rc = seal(w); if (rc) return rc; return materialise_live(w); }
+// entry points that read or edit the live block's BYTES: a lazily skipped live block (host_groups.hpp) is materialised first; a world whose systems spawn
+// on the device learns its RollbackOrdered::len from the last launch (len_sync)
+static int seal_live(ggrs_world* w) { int rc = seal(w); if (rc) return rc; rc = len_sync(w); if (rc) return rc; return materialise_live(w); }
 
 int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void* const* cols, uint64_t* first_slot) {
     if (!w) return GGRS_E_INVALID;
@@ -366,6 +368,7 @@ int ggrs_hip_spawn(ggrs_world* w, uint64_t count, uint64_t comp_mask, const void
     rc = set_masks_for_range(w, first, count, comp_mask); if (rc) return rc;
     w->len += count;
     w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+    if (w->dev_spawn) { const uint64_t l = w->len; HIPCHK(w, hipMemcpyAsync(w->live.ptr, &l, 8, hipMemcpyHostToDevice, w->stream)); }   // the kernels read RollbackOrdered::len from the block's header
     w->pending_valid = false;
     HIPCHK(w, hipStreamSynchronize(w->stream));     // host buffers may be freed on return
     return GGRS_OK;
@@ -498,7 +501,7 @@ int ggrs_hip_column_device_ptr(ggrs_world* w, uint32_t c, uint32_t word, void** 
     if (tile_stride) *tile_stride = w->col_ts[w->comps[c].col_base + word];
     return GGRS_OK;
 }
-uint64_t ggrs_hip_len(ggrs_world* w) { return w ? w->len : 0; }
+uint64_t ggrs_hip_len(ggrs_world* w) { if (!w) return 0; if (w->len_stale) { DeviceGuard dg(w); (void)len_sync(w); } return w->len; }
 int ggrs_hip_active_count(ggrs_world* w, uint64_t* out) {
     if (!w || !out) return GGRS_E_INVALID;
     DeviceGuard dg(w);

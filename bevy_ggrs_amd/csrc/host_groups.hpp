@@ -222,7 +222,17 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
     void* params[] = {w->jit_argbuf.data()};
     gx += j.ff_blocks;
     const double t0 = w->tl.on ? tl_now_us() : 0;
-    if (!w->prof) {
+    if (w->dev_spawn) {
+        // spawns decided on the device: grid barriers inside -- a COOPERATIVE launch (every workgroup resident, the runtime lets no second one in beside it); the
+        // barrier counters start from zero
+        HIPCHK(w, hipMemsetAsync(w->d_sp_bar, 0, 2 * (size_t)MAX_TICK_STEPS * 4, w->stream));
+        hipEvent_t a = nullptr, b = nullptr;
+        if (w->prof) { a = w->prof_event(); b = w->prof_event(); if (!a || !b) return w->fail(GGRS_E_HIP, "hipEventCreate failed"); w->prof_bytes[GGRS_KERNEL_TICK] += bytes; HIPCHK(w, hipEventRecord(a, w->stream)); }
+        HIPCHK(w, hipModuleLaunchCooperativeKernel(fn, gx, gy, gz, TPB, 1, 1, lds, w->stream, params));
+        if (w->prof) { HIPCHK(w, hipEventRecord(b, w->stream)); w->prof_events.push_back({a, b, GGRS_KERNEL_TICK}); }
+        if (done) HIPCHK(w, hipEventRecord(done, w->stream));
+        w->len_stale = true;
+    } else if (!w->prof) {
         if (done) HIPCHK(w, hipExtModuleLaunchKernel(fn, gx * TPB, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr, nullptr, done, 0));
         else HIPCHK(w, hipModuleLaunchKernel(fn, gx, gy, gz, TPB, 1, 1, lds, w->stream, params, nullptr));
     } else {
@@ -245,6 +255,7 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
 // the load mask and the store policies are literals of that copy.
 hipFunction_t jit_spec_for(ggrs_world* w, const GgrsJitArgs& j, bool members = false) {
     if (!w->knobs.jit_specialise_after || w->jit_src.empty() || !j.n_saves || !j.n_ops) return nullptr;
+    if (w->dev_spawn) return nullptr;              // (a cooperative launch must be resident as a whole: the world was sized against the GENERAL kernel's occupancy at seal)
     for (uint32_t k = 0; k < j.n_saves && !members; ++k)
         if (!j.save_dst[k] || j.save_rows[k] != j.save_rows[0] || j.save_pmask[k] != j.save_pmask[0]) return nullptr;
     JitSig g; g.members = members ? 1u : 0u; g.vtags = j.vtags; g.op_bits = j.op_bits; g.save_rows = j.save_rows[0]; g.live_rows = j.live_rows; g.load_rows = j.load_rows; g.n_ops = j.n_ops; g.n_saves = j.n_saves;
@@ -292,6 +303,7 @@ inline GenFinArgs make_gen_fin(const ggrs_world* w, const GgrsJitArgs& j, uint32
     for (uint32_t k = 0; k < j.n_saves && k < (uint32_t)MAX_TICK_SAVES; ++k) f.save_len[k] = j.save_len[k];
     f.out = w->d_results + 2 * (uint64_t)res;
     if (w->dev_results_dst && res >= w->dev_results_first) f.out2 = w->dev_results_dst + 2 * (uint64_t)(res - w->dev_results_first);
+    if (w->dev_spawn) f.dev_save_len = w->d_sp_len + 2;
     return f;
 }
 
@@ -361,7 +373,7 @@ struct JitBatch {
 // externally held column pointers.  Snapshots, checksums, ring and frame counters are untouched: every Save of the tick was made.
 constexpr uint32_t LAZY_LIVE_STREAK = 8;
 inline bool lazy_live_allowed(const ggrs_world* w) {                 // (what a layout-only world -- `make aot` on a machine without a GPU -- can tell)
-    if (!w->lazy_live_on || w->live_handed_out || w->has_nr || w->marks_possible || w->device_results_only) return false;
+    if (!w->lazy_live_on || w->live_handed_out || w->has_nr || w->marks_possible || w->device_results_only || jit_dev_spawn(w)) return false;
     for (uint8_t e : w->col_ext) if (e) return false;
     return true;
 }
@@ -468,6 +480,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
                 }
                 uint32_t dtb = 0;
                 rc = group_step(w, r, &dtb, w->jit_marks ? &j.step_flags[j.n_steps] : nullptr); if (rc) return rc;
+                if (w->dev_spawn) {                                            // any frame may append rows of the bundle: its columns and presence masks are new after every step
+                    const ggrs_world::SpawnSys& spd = w->spawn_customs[w->systems[w->jit_spawn_sys].comp[0]];
+                    for (uint32_t c = 0; c < w->comps.size(); ++c) if ((spd.bundle_mask >> c) & 1ull) ver_touch_comp(w, c);
+                }
                 j.dt_bits[j.n_steps] = dtb;
                 j.step_frame[j.n_steps] = w->frame; j.step_confirmed[j.n_steps] = w->confirmed;
                 if (w->jit_box_sys >= 0) {                                     // FRICTION.powf(dt), platform libm (box_game.rs:189-195)
@@ -494,9 +510,9 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             }
             ++i;
         }
-        const bool dead = group_is_dead(w, reqs, i, n, j.save_frame, j.n_saves, spawn_req != nullptr);
+        const bool dead = !w->dev_spawn && group_is_dead(w, reqs, i, n, j.save_frame, j.n_saves, spawn_req != nullptr);
         if (dead) { for (uint32_t k = 0; k < j.n_saves; ++k) j.save_dst[k] = nullptr; j.skip_live = 1; }
-        const uint64_t cover = std::max(gs.cover, w->len);
+        const uint64_t cover = w->dev_spawn ? w->capacity : std::max(gs.cover, w->len);      // (device-decided spawns: the host only knows a bound of len)
         // lazy live block: the LAST group of a list that ends [.., Save(F), Advance] in a session whose lists keep opening with a Load
         if (!dead && !spawn_req && i >= n && ((w->load_open_streak >= LAZY_LIVE_STREAK && cover > JIT_NT_MIN_SLOTS) || w->lazy_live_on == 2) && j.n_ops >= 2 && j.n_saves && j.n_steps &&
             ((j.op_bits >> (j.n_ops - 1)) & 1ull) && !((j.op_bits >> (j.n_ops - 2)) & 1ull) && gs.dsts[j.n_saves - 1] && !j.spawn_count[j.n_steps - 1] &&
@@ -530,6 +546,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         }
         bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
+        if (w->dev_spawn) {
+            j.sp_sums = reinterpret_cast<ggrs_u64*>(w->d_sp_sums); j.sp_bar = w->d_sp_bar; j.sp_prec = w->d_sp_prec; j.sp_link = reinterpret_cast<ggrs_u64*>(w->d_sp_link);
+            j.sp_len = reinterpret_cast<ggrs_u64*>(w->d_sp_len); j.sp_cap = w->capacity; j.sp_tiles = w->sp_tiles;
+        }
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
         j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
         const uint32_t g = std::max<uint32_t>(1, (uint32_t)((cover + 255) / 256));
@@ -549,7 +569,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             // Depth-parallel roles: the group's outputs (Saves + live world) are split over grid.y roles of dp_s outputs.  Every role
             // reads the source block while the others write theirs, so the source must be none of the destinations; below ~2 Saves
             // there is no chain to split.  Crossovers: profiles/r02dp/ab2.txt, profiles/r02jit/jit_dp.txt.
-            if (j.n_saves >= 2 && !w->jit_marks) {
+            if (j.n_saves >= 2 && !w->jit_marks && !w->dev_spawn) {
                 bool ok = !(wrote_live && j.src == j.live);
                 for (uint32_t k = 0; k < j.n_saves; ++k) ok = ok && j.save_dst[k] != j.src;
                 // ... and the destinations pairwise distinct: a ring shallower than the group's Saves hands an evicted slot to a later Save, and two
@@ -572,7 +592,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             uint64_t rows_off = 0;
             const uint32_t ff_split = (g + FF_CHUNK - 1u) / FF_CHUNK;                      // chunks of <= 1024 entries per row: one fold-forward workgroup each
             const uint32_t nvals = j.n_saves * (n_cks + 1) * ff_split;
-            bool ff = launch && j.n_saves && !wait && !w->device_results_only && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
+            bool ff = launch && j.n_saves && !wait && !w->device_results_only && !w->dev_spawn && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
                       rows_ring_alloc(w, 2ull * nvals, &rows_off);
             const bool host_fold = !ff && launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
             uint32_t ff_buf = 0;
@@ -664,6 +684,7 @@ int spec_blocks_reserve(ggrs_world* w, size_t n) {
 // everything that can be checked before the prefix runs
 int validate_branch_step(ggrs_world* w, const ggrs_branch_step& st) {
     if (!w->gen_ok) return w->fail(GGRS_E_INVALID, "branch steps need the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
+    if (w->dev_spawn) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds whose systems spawn on the device (every launch is one cooperative grid): use ggrs_hip_fanout_step");
     if (w->jit_marks || w->has_nr || w->marks_possible) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds with live-only state (RollbackDespawned markers, non-rollback components): use ggrs_hip_fanout_step");
     if (st.n_branches == 0 || st.n_branches > BRANCH_MAX) return w->fail(GGRS_E_INVALID, "a branch step holds 1..%u branches, not %u", BRANCH_MAX, st.n_branches);
     const uint32_t S = (st.flags & GGRS_BRANCH_SAVE_LAST) ? st.n_frames : st.n_frames - 1;

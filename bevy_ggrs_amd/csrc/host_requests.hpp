@@ -639,11 +639,26 @@ bool rows_ring_alloc(ggrs_world* w, uint64_t need, uint64_t* off) {
 // `blocking`: the caller waits for this group's checksums right away (the synchronous API) -- the host's fold is then serial with the
 // kernel instead of hidden behind the next tick's, so only small groups take it.
 bool host_fold_rows(ggrs_world* w, uint32_t g, uint32_t n_saves, uint32_t n_cks, uint32_t members, uint64_t* off, bool blocking = false) {
-    if (!w->h_rows || w->device_results_only || !n_saves) return false;
+    if (!w->h_rows || w->device_results_only || w->dev_spawn || !n_saves) return false;      // (device-decided spawns: RollbackOrdered::len at each Save is only known on the device -- k_gen_finalize)
     if (blocking ? g > HOST_FOLD_MAX_WGS_BLOCKING : g > (uint32_t)w->knobs.fold_forward_min_wgs) return false;
     return rows_ring_alloc(w, (uint64_t)g * n_saves * (n_cks + 1) * members, off);
 }
 
+// Spawns decided on the device: RollbackOrdered::len of the live world as the last launch left it (pinned), and what went wrong inside a launch
+int len_sync(ggrs_world* w) {
+    if (!w->dev_spawn || !w->len_stale || !w->h_sp_len) return GGRS_OK;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->len_stale = false;
+    const uint64_t err = w->h_sp_len[1];
+    const uint64_t l_ = w->h_sp_len[0]; w->len = l_ < w->capacity ? l_ : w->capacity;
+    w->live.dirty_len = std::max(w->live.dirty_len, w->len);
+    if (err) {
+        w->h_sp_len[1] = 0;
+        return err == 1 ? w->fail(GGRS_E_CAPACITY, "entities spawned by the schedule's systems (e.spawn) exceed the world's capacity of %llu: that frame's spawns were dropped", (unsigned long long)w->capacity)
+                        : w->fail(GGRS_E_HIP, "a grid barrier of a device-spawn launch timed out (the launch was not resident as a whole?)");
+    }
+    return GGRS_OK;
+}
 int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
     // When the list's last GPU operation is a k_gen_finalize (arm_spin), its workgroups write a tag behind their results in the same pinned
     // allocation: seeing every tag means every kernel of the list has run (one in-order stream) and the results are in host memory -- the
@@ -661,6 +676,7 @@ int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
     int rc = run_host_folds(w, ~0u); if (rc) return rc;
+    rc = len_sync(w); if (rc) return rc;
     stage_ring_reset(w);
     if (n_results && out) memcpy(out, w->h_results, (size_t)n_results * 16);
     return GGRS_OK;
@@ -676,7 +692,7 @@ void apply_synctest_confirmed(ggrs_world* w) {
 // does a spawn system fire in this AdvanceFrame?  spawn_particles (particles.rs:254-270): a player holds the system's input bit and the host
 // drew spawn_count velocities; a user-written spawner (ggrs_hip_add_spawn_system): the host decided -- spawn_count is what the system spawns
 bool advance_spawns(const ggrs_world* w, const ggrs_request& r) {
-    if (r.spawn_count == 0) return false;
+    if (r.spawn_count == 0 || w->dev_spawn) return false;             // (spawns decided on the device: the request says nothing about them)
     for (auto& s : w->systems) {
         if (s.kind == GGRS_SYS_SPAWN_CUSTOM) return true;
         if (s.kind == GGRS_SYS_PARTICLES_SPAWN && r.inputs && spawn_pressed(w, s, r.inputs, r.n_inputs)) return true;

@@ -15,6 +15,14 @@ void arena_release(ggrs_world* w) {
     w->arena = nullptr; w->arena_bytes = 0; w->own_arena = false;
 }
 
+void sp_release(ggrs_world* w) {
+    if (w->d_sp_sums) (void)hipFree(w->d_sp_sums);
+    if (w->d_sp_bar) (void)hipFree(w->d_sp_bar);
+    if (w->d_sp_prec) (void)hipFree(w->d_sp_prec);
+    if (w->d_sp_link) (void)hipFree(w->d_sp_link);
+    if (w->h_sp_len) (void)hipHostFree((void*)w->h_sp_len);
+    w->d_sp_sums = nullptr; w->d_sp_bar = nullptr; w->d_sp_prec = nullptr; w->d_sp_link = nullptr; w->h_sp_len = nullptr; w->d_sp_len = nullptr;
+}
 int seal(ggrs_world* w) {
     if (w->layout_only) return w->fail(GGRS_E_NO_DEVICE, "GGRS_WORLD_LAYOUT_ONLY world: there is no device behind it");
     if (w->sealed) return GGRS_OK;
@@ -25,6 +33,7 @@ int seal(ggrs_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     if (w->d_gen_parts) { (void)hipFree(w->d_gen_parts); w->d_gen_parts = nullptr; w->d_ff_rows[0] = w->d_ff_rows[1] = nullptr; }
     if (w->d_skip) { (void)hipFree(w->d_skip); w->d_skip = nullptr; }
+    sp_release(w);
     if (w->h_results) { (void)hipHostFree(w->h_results); w->h_results = nullptr; w->d_results = nullptr; }
     if (w->h_stage) { (void)hipHostFree(w->h_stage); w->h_stage = nullptr; w->d_hstage = nullptr; }
     if (w->h_rows) { (void)hipHostFree(w->h_rows); w->h_rows = nullptr; w->d_rows = nullptr; }
@@ -134,6 +143,7 @@ int seal_impl(ggrs_world* w) {
             }
             w->gen_ok = true;
             w->jit_spawn_sys = jit_fused_spawn_system(w);              // the spawn system runs inside request groups
+            w->dev_spawn = jit_dev_spawn(w);
             delete w->jl; w->jl = new JitLayout(jit_layout(w));
             w->cap_saves = w->jl->cap_saves; w->cap_steps = w->jl->cap_steps;
             w->jit_argbuf.assign(w->jl->bytes, 0);
@@ -230,6 +240,24 @@ int seal_impl(ggrs_world* w) {
         if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + 2 * ff_bytes, w->stream));
     }
     if (w->vtags) { HIPCHK(w, hipMalloc((void**)&w->d_skip, 8)); HIPCHK(w, hipMemsetAsync(w->d_skip, 0, 8, w->stream)); }
+    if (w->dev_spawn) {
+        // every launch of such a world covers its whole capacity and must be resident as a whole (grid barriers inside): what the device holds of this kernel bounds the world
+        w->sp_tiles = (uint32_t)(((w->capacity + 63) / 64 + 3) / 4);                 // == the workgroups that own a tile when a launch covers `capacity` slots
+        int per_cu = 0;
+        HIPCHK(w, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, w->jit_fn, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, w->cap_saves)));
+        const uint64_t max_wgs = (uint64_t)std::max(per_cu, 0) * (uint64_t)w->n_cu;
+        const uint32_t grid = 8u * ((w->sp_tiles + 7u) / 8u);
+        if (grid > max_wgs)
+            return w->fail(GGRS_E_CAPACITY, "a world whose systems spawn on the device runs as ONE resident launch: %u workgroups are needed for %llu slots, the device holds %llu of this kernel (at most %llu slots)",
+                           grid, (unsigned long long)w->capacity, (unsigned long long)max_wgs, (unsigned long long)(max_wgs / 8 * 8 * 256));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_sums, (size_t)w->cap_steps * w->sp_tiles * 8));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_bar, 2 * (size_t)MAX_TICK_STEPS * 4));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_prec, (size_t)w->cap_pad * 64));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_link, (size_t)w->cap_pad * 16));
+        HIPCHK(w, hipHostMalloc((void**)&w->h_sp_len, (2 + MAX_TICK_SAVES) * 8, hipHostMallocMapped));
+        HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_sp_len, (void*)w->h_sp_len, 0));
+        for (int k = 0; k < 2 + MAX_TICK_SAVES; ++k) w->h_sp_len[k] = 0;
+    }
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->sealed = true;
     return GGRS_OK;

@@ -194,6 +194,11 @@ struct ggrs_world {
     uint32_t tag_counter = 1;
     int vtags_mode = -1; bool vtags = false;               // ggrs_dbg_set_value_tags: 0 off, 1 on, -1 by size (seal decides: VTAGS_MIN_BYTES)
     uint64_t* d_skip = nullptr;                            // profiling: bytes the launches did NOT store thanks to the tags (ggrs_hip_profile_read_bytes stays honest)
+    // SPAWNS DECIDED ON THE DEVICE (kernel_gen.hpp GgrsJitArgs::sp_*): a system called e.spawn(n).  RollbackOrdered::len then lives on the device -- the host's `len`
+    // is what the last launch it waited for reported (len_sync) -- every launch covers the world's whole capacity and is COOPERATIVE (all workgroups resident)
+    bool dev_spawn = false; bool len_stale = false;
+    uint64_t* d_sp_sums = nullptr; uint32_t* d_sp_bar = nullptr; uint8_t* d_sp_prec = nullptr; uint64_t* d_sp_link = nullptr;
+    volatile uint64_t* h_sp_len = nullptr; uint64_t* d_sp_len = nullptr; uint32_t sp_tiles = 0;
     std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0 (component words first, then the Stored words of strategy components)
     std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
     std::vector<uint8_t> col_rb;                   // column is part of a rollback component (snapshotted)

@@ -101,7 +101,7 @@ Hiprtc& hiprtc_for(const ggrs_world* w) {
 // kernel of a custom system and for the generated request-group kernel.
 #define GGRS_ENTITY_TEXT \
     "struct GgrsEntity {\n" \
-    "    ggrs_u64 slot; ggrs_u64 w[8]; int kill;\n" \
+    "    ggrs_u64 slot; ggrs_u64 w[8]; int kill; int spawn_n;\n" \
     "    __device__ float& f32(int i) { return *reinterpret_cast<float*>(&w[i]); }\n" \
     "    __device__ ggrs_u32& u32(int i) { return *reinterpret_cast<ggrs_u32*>(&w[i]); }\n" \
     "    __device__ int& i32(int i) { return *reinterpret_cast<int*>(&w[i]); }\n" \
@@ -110,6 +110,7 @@ Hiprtc& hiprtc_for(const ggrs_world* w) {
     "    __device__ unsigned char& u8(int i) { return *reinterpret_cast<unsigned char*>(&w[i]); }\n" \
     "    __device__ void despawn() { if (kill == 0) kill = 1; }\n" \
     "    __device__ void despawn_rollback() { kill = 2; }\n" \
+    "    __device__ void spawn(int n) { spawn_n = n < 0 ? 0 : (n > 255 ? 255 : n); }   /* commands.spawn(..) x n from THIS entity's system call: see ggrs_hip_add_spawn_system, GGRS_SPAWN_PAYLOAD_PARENT */\n" \
     "};\n"
 
 // hiprtc: source -> code object -> module + kernel handle.  A compile error fails with the compiler log in w->err.
@@ -206,6 +207,12 @@ struct GgrsJitArgs {
     ggrs_u32 part_stride, part_tstride, nt;          // parts[i * part_stride + tile * part_tstride] (row-major: g, 1; tile-major -- fold-forward --: 1, values per workgroup); nt: snapshot stores are non-temporal (big worlds: written once, read a tick later)
     ggrs_u32 n_units;                                // 64-slot units to walk (covers every dirty mask word)
     ggrs_u32 vtags, tag_base;
+    // SPAWNS DECIDED ON THE DEVICE (a system called e.spawn(n); ggrs_hip_add_spawn_system with GGRS_SPAWN_PAYLOAD_PARENT): RollbackOrdered::len lives on the device
+    // (the blocks' headers; sp_len[0] = the live world's after the launch, [1] = error flags, [2 + k] = len at Save k: pinned), the launch is cooperative (every
+    // workgroup resident: per step one grid barrier over sp_bar to sum the workgroups' counts in sp_sums -- slot order == RollbackOrdered order --, a second one
+    // when anything spawned so that the lanes owning the new slots find their parents' records: sp_prec[parent slot] = the parent's bound words, sp_link[child
+    // slot] = {parent slot, k})
+    ggrs_u64* sp_sums; ggrs_u32* sp_bar; unsigned char* sp_prec; ggrs_u64* sp_link; ggrs_u64* sp_len; ggrs_u64 sp_cap; ggrs_u32 sp_tiles;
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
     ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
     ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
@@ -230,7 +237,7 @@ struct JitLayout {
     struct Member { uint32_t bytes = 0, save_dst = 0, save_rows = 0, save_len = 0, spawn_payload = 0, spawn_first = 0, live = 0, live_rows = 0, save_pmask = 0, live_pmask = 0,
                     spawn_count = 0, n_inputs = 0, inputs = 0, save_tagok = 0, live_tagok = 0; } m;
 };
-struct JitNeeds { bool spawn, inputs, marks, box, vtags; };
+struct JitNeeds { bool spawn, inputs, marks, box, vtags, devspawn; };
 JitNeeds jit_needs(const ggrs_world* w);
 // the device-side layout of this world's argument block: 8-byte fields first, then 4-byte, then bytes (no padding inside)
 JitLayout jit_layout(const ggrs_world* w) {
@@ -260,7 +267,9 @@ JitLayout jit_layout(const ggrs_world* w) {
         FA("int", save_frame, S, true); FA("ggrs_u32", save_pmask, S, true);
         F1("ggrs_u32", live_pmask, true); F1("ggrs_u32", nt_loads, true); F1("ggrs_u32", n_ops, true); F1("ggrs_u32", n_saves, true); F1("ggrs_u32", n_steps, true);
         F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", part_tstride, true); F1("ggrs_u32", nt, true);
-        F1("ggrs_u32", n_units, true); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
+        F1("ggrs_u64*", sp_sums, need.devspawn); F1("ggrs_u32*", sp_bar, need.devspawn); F1("unsigned char*", sp_prec, need.devspawn); F1("ggrs_u64*", sp_link, need.devspawn);
+        F1("ggrs_u64*", sp_len, need.devspawn); F1("ggrs_u64", sp_cap, need.devspawn);
+        F1("ggrs_u32", n_units, true); F1("ggrs_u32", sp_tiles, need.devspawn); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
         FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
         FS("ggrs_u32", spawn_count, need.spawn);
         FS("unsigned char", step_flags, need.marks); FS("unsigned char", n_inputs, need.inputs);
@@ -446,10 +455,17 @@ int jit_fused_spawn_system(const ggrs_world* w) {
     if (V.word_bytes != 4 || V.n_words < 3 || L.word_bytes != 8 || L.n_words < 1) return -1;
     return found;
 }
+// spawns decided on the device: the world's (fusable) spawn system takes its counts and payloads from the entities that called e.spawn(n)
+constexpr uint32_t SPAWN_PAYLOAD_PARENT = 0xFFFFFFFFu;             // == GGRS_SPAWN_PAYLOAD_PARENT
+bool jit_dev_spawn(const ggrs_world* w) {
+    const int sp = jit_fused_spawn_system(w);
+    return sp >= 0 && w->systems[sp].kind == GGRS_SYS_SPAWN_CUSTOM && w->spawn_customs[w->systems[sp].comp[0]].payload_stride == SPAWN_PAYLOAD_PARENT;
+}
 // which optional parts of the argument block this world's kernel reads
 JitNeeds jit_needs(const ggrs_world* w) {
-    JitNeeds n{false, false, false, false, false};
+    JitNeeds n{false, false, false, false, false, false};
     n.vtags = vtags_policy(w);
+    n.devspawn = jit_dev_spawn(w);
     n.spawn = jit_fused_spawn_system(w) >= 0;
     for (auto& d : w->systems) {
         n.inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
@@ -476,6 +492,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     for (uint32_t c = 0; c < nc; ++c) if (rb(c) && strat(c)) any_strat = true;
     const JitNeeds need = jit_needs(w);
     const bool marks = need.marks;
+    const bool DEV = need.devspawn;                                  // spawns decided on the device (GGRS_SPAWN_PAYLOAD_PARENT): len lives on the device, the launch is cooperative
     bool lds_inputs = false;                                         // user code indexes PlayerInputs (possibly by a handle it read from a component): the bytes go through LDS
     for (auto& d : w->systems) {
         switch (d.kind) {
@@ -545,6 +562,16 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "__device__ __forceinline__ uint64_t uni64(uint64_t m) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m); }   // wave-uniform by construction: say so\n"
          "__device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %2\\n\\tv_mov_b32 %1, %3\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_), \"+v\"(v) : \"s\"(lanes), \"s\"(x)); }\n"
          "__device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %3\\n\\tglobal_store_dword %1, %2, off\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_) : \"v\"(p), \"v\"(v), \"s\"(lanes) : \"memory\"); }\n"
+         "// SPAWNS DECIDED ON THE DEVICE: a barrier over every workgroup of a COOPERATIVE launch (all of them are resident): thread 0 of each arrives and waits,\n"
+         "// bounded (a second of wall clock: a launch that cannot make it reports an error instead of hanging the device); and a sum over the 64 lanes\n"
+         "__device__ __forceinline__ bool grid_arrive_wait(ggrs_u32* ctr, ggrs_u32 n) {\n"
+         "    __threadfence();\n"
+         "    atomicAdd(ctr, 1u);\n"
+         "    const unsigned long long t0_ = wall_clock64();\n"
+         "    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) { if (wall_clock64() - t0_ > 100000000ull) return false; __builtin_amdgcn_s_sleep(1); }\n"
+         "    return true;\n"
+         "}\n"
+         "__device__ __forceinline__ ggrs_u64 wave_sum64(ggrs_u64 v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }\n"
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
@@ -622,7 +649,8 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "    {\n"
          "    const uint32_t gu = tile * 4u + wave;                                     // this wave's 64-slot unit == its mask word\n";
     sfmt(s, "    const uint64_t e0 = (uint64_t)gu * 64u + lane;                             // this lane's slot\n"
-            "    %sbool in_len = (uint64_t)gu * 64u < a.len;                                 // wave-uniform%s\n"
+            "%s"
+            "    %sbool in_len = (uint64_t)gu * 64u < %s;                                 // wave-uniform%s\n"
             "    // word c of slot e lives at col_off[c] + (e >> 13) * tile_stride + (e & 8191) * word_bytes: the layout tile is the\n"
             "    // wave's (uniform: SGPRs), the lane contributes one 32-bit offset per word size -> saddr-form accesses\n"
             "    const uint64_t tbase = (uint64_t)(gu >> %d) * %uull;\n"
@@ -630,7 +658,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    (void)lo1; (void)lo2; (void)lo4; (void)lo8;\n"
             "    const uint64_t wi8 = (uint64_t)gu * 8u;                                    // byte offset of this wave's mask word: bit `lane` is this slot\n"
             "    const uint32_t sh = lane;\n",
-         spawn_sys >= 0 ? "" : "const ", spawn_sys >= 0 ? " (a spawn inside the group grows len)" : "", LT_SHIFT - 6, w->ts, (unsigned)(LAYOUT_TILE / 64 - 1));
+         DEV ? "    uint64_t cur_len = *reinterpret_cast<const uint64_t*>(a.src);                // RollbackOrdered::len as the source block's header says: with spawns decided on the device the host only knows a bound\n"
+                   "    __shared__ uint64_t s_sp[8];                                               // the workgroup's spawn bookkeeping of one step\n" : "",
+         spawn_sys >= 0 ? "" : "const ", DEV ? "cur_len" : "a.len", spawn_sys >= 0 ? " (a spawn inside the group grows len)" : "", LT_SHIFT - 6, w->ts, (unsigned)(LAYOUT_TILE / 64 - 1));
     // ---- masks and words of the lane's slot
     sfmt(s, "    const uint64_t mk_alive = *reinterpret_cast<const uint64_t*>(a.src + %lluull + wi8);\n"
             "    bool alive_0 = (mk_alive >> sh) & 1ull;\n", OFF_ALIVE);
@@ -868,10 +898,11 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     { char te[96]; snprintf(te, sizeof te, "(mb ? mb_u64(mb, %uu + 8u * si) : a.save_tagok[si])", L.m.save_tagok); emit_tag_filter("dst", "rows", te, "                ", "dtv[si]"); }
     emit_store("dst", "rows", "pmask_s", "alive_now", "                ", true);
     sfmt(s, "                if (gu == 0 && lane == 0) {\n"
-            "                    Header h; h.len = mb ? mb_u64(mb, %uu + 8u * si) : a.save_len[si]; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
+            "                    Header h; h.len = %s; h.frame = a.save_frame[si]; h.pad0 = 0; h.active = 0; h.checksum[0] = 0; h.checksum[1] = 0;\n"
             "                    *reinterpret_cast<Header*>(dst) = h;\n"
             "                }\n"
-            "            }\n", L.m.save_len);
+            "            }\n", DEV ? "cur_len" : (std::string("mb ? mb_u64(mb, ") + std::to_string(L.m.save_len) + "u + 8u * si) : a.save_len[si]").c_str());
+    if (DEV) s += "            if (gu == 0 && lane == 0) a.sp_len[2u + si] = cur_len;                        // RollbackOrdered::len at this Save: k_gen_finalize's entity checksum and the host read it here\n";
     sfmt(s, "            ggrs_u64* acc = s_acc + si * %uu;                                 // this Save's partials of the workgroup (LDS)\n", n_cks + 1);
     for (uint32_t k = 0; k < n_cks; ++k) {
         const uint32_t c = cks_comp[k];
@@ -910,6 +941,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "        } else {\n"
             "            // ---------------- AdvanceWorld: the registered systems, in order\n"
             "            const float dt = __uint_as_float(a.dt_bits[sj]);\n", n_cks);
+    if (DEV) s += "            uint32_t spn_0 = 0u;                                                       // children this entity's systems asked for in this frame (e.spawn(n))\n";
     // value tags: around every system, the columns IT may write as they were before it ran -- a column whose 64 values are not all what they were carries a
     // fresh identity from here on (wave-uniform; per system, so that at most one write set of old values is alive at a time)
     // (a step only RECORDS which columns changed -- one compare per column and scalar bookkeeping; the identities are renewed where they are needed, at the next store)
@@ -1000,9 +1032,14 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             s += "            if (alive_0";
             for (uint32_t pz = 0; pz < c.n_pres; ++pz) sfmt(s, " && p%u_0", c.pres_comp[pz]);
             sfmt(s, ") {                                                   // user system %u\n"
-                    "                GgrsEntity ent; ent.slot = e0; ent.kill = 0;\n", d.comp[0]);
-            for (uint32_t b = 0; b < c.n_bind; ++b) sfmt(s, "                ent.w[%u] = w%u_0;\n", b, col(c.comp[b], c.word[b]));
+                    "                GgrsEntity ent; ent.slot = e0; ent.kill = 0; ent.spawn_n = 0;\n", d.comp[0]);
+            for (uint32_t b = 0; b < 8; ++b) { if (b < c.n_bind) sfmt(s, "                ent.w[%u] = w%u_0;\n", b, col(c.comp[b], c.word[b])); else if (DEV) sfmt(s, "                ent.w[%u] = 0;\n", b); }
             sfmt(s, "                ggrs_sys_%u::ggrs_system(ent, fr%zu);\n", d.comp[0], i);
+            if (DEV) s += "                if (ent.spawn_n) {                                        // e.spawn(n): the children are made after the frame's systems, from what THIS call left in e\n"
+                          "                    spn_0 = (uint32_t)ent.spawn_n;\n"
+                          "                    GGRS_G ggrs_u64* pr_ = (GGRS_G ggrs_u64*)(a.sp_prec + e0 * 64u);\n"
+                          "                    for (int b_ = 0; b_ < 8; ++b_) pr_[b_] = ent.w[b_];\n"
+                          "                }\n";
             for (uint32_t b = 0; b < c.n_bind; ++b)
                 sfmt(s, "                w%u_0 = (%s)(%s)ent.w[%u];\n", col(c.comp[b], c.word[b]), wtype(c.comp[b]), mtype(c.comp[b]), b);   // narrow words wrap as their memory type does
             s += "                if (ent.kill) { if (ent.kill == 2 && defer) { dis_0 = true; df_0 = a.step_frame[sj]; } alive_0 = false; }\n"
@@ -1021,6 +1058,55 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         uint64_t bundle = 0;
         if (custom) bundle = w->spawn_customs[d.comp[0]].bundle_mask; else bundle = (1ull << d.comp[0]) | (1ull << d.comp[1]) | (1ull << d.comp[2]);
         if (custom) emit_frame("fr_spawn", d.fparam, d.iparam);
+        if (DEV) {
+            // How many, and whose: the entities that called e.spawn(n), in slot order (== RollbackOrdered order, so every rank and every replay numbers the children
+            // alike).  Per step: an exclusive scan over the wave, the workgroup (LDS) and -- behind a barrier over the whole resident grid -- the workgroups' sums
+            // in tile order; a parent then knows its children's slots and leaves {parent slot, k} where the lane that OWNS each new slot will look; a second
+            // barrier (only in steps that spawn anything), and that lane takes the bundle.
+            s += "            uint64_t sn_ = 0, sf_ = cur_len;\n"
+                 "            {\n"
+                 "                uint32_t inc_ = spn_0;                                                 // inclusive scan over the wave's 64 lanes\n"
+                 "                for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t up_ = __shfl_up(inc_, o_, 64); if ((int)lane >= o_) inc_ += up_; }\n"
+                 "                const uint32_t wtot_ = (uint32_t)__builtin_amdgcn_readlane((int)inc_, 63);\n"
+                 "                __syncthreads();                                                       // (s_sp of the previous step has been read by everyone)\n"
+                 "                if (lane == 0) s_sp[wave] = wtot_;\n"
+                 "                __syncthreads();\n"
+                 "                uint32_t wg_excl_ = 0, wg_tot_ = 0;\n"
+                 "                for (uint32_t q_ = 0; q_ < 4u; ++q_) { const uint32_t v_ = (uint32_t)s_sp[q_]; wg_tot_ += v_; if (q_ < wave) wg_excl_ += v_; }\n"
+                 "                if (tid == 0) {\n"
+                 "                    a.sp_sums[(uint64_t)sj * a.sp_tiles + tile] = wg_tot_;\n"
+                 "                    s_sp[4] = grid_arrive_wait(a.sp_bar + 2u * sj, a.sp_tiles) ? 1ull : 0ull;\n"
+                 "                }\n"
+                 "                __syncthreads();\n"
+                 "                const bool ok1_ = s_sp[4] != 0ull;\n"
+                 "                uint64_t bef_ = 0, all_ = 0;                                           // the workgroups before this one (tile order == slot order), and all of them\n"
+                 "                for (uint32_t t_ = tid; t_ < a.sp_tiles; t_ += 256u) { const uint64_t v_ = __hip_atomic_load(a.sp_sums + (uint64_t)sj * a.sp_tiles + t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); all_ += v_; if (t_ < tile) bef_ += v_; }\n"
+                 "                bef_ = wave_sum64(bef_); all_ = wave_sum64(all_);\n"
+                 "                __syncthreads();\n"
+                 "                if (lane == 0) { s_sp[wave] = bef_; s_sp[4u + wave] = all_; }\n"
+                 "                __syncthreads();\n"
+                 "                bef_ = s_sp[0] + s_sp[1] + s_sp[2] + s_sp[3]; all_ = s_sp[4] + s_sp[5] + s_sp[6] + s_sp[7];\n"
+                 "                if (!ok1_ || cur_len + all_ > a.sp_cap) {                               // a barrier that timed out, or children beyond the world's capacity: nothing spawns, the host is told\n"
+                 "                    if (all_ && gu == 0 && lane == 0) a.sp_len[1] = !ok1_ ? 2ull : 1ull;\n"
+                 "                    all_ = 0;\n"
+                 "                }\n"
+                 "                if (all_) {                                                            // uniform over the whole grid\n"
+                 "                    const uint64_t first_ = cur_len + bef_ + wg_excl_ + (inc_ - spn_0);    // this parent's first child\n"
+                 "                    for (uint32_t k_ = 0; k_ < spn_0; ++k_) { GGRS_G ggrs_u64* lk_ = (GGRS_G ggrs_u64*)a.sp_link + 2u * (first_ + k_); lk_[0] = e0; lk_[1] = k_; }\n"
+                 "                    __syncthreads();\n"
+                 "                    if (tid == 0) s_sp[4] = grid_arrive_wait(a.sp_bar + 2u * sj + 1u, a.sp_tiles) ? 1ull : 0ull;\n"
+                 "                    __syncthreads();\n"
+                 "                    if (s_sp[4] == 0ull) { if (gu == 0 && lane == 0) a.sp_len[1] = 2ull; all_ = 0; }\n"
+                 "                }\n"
+                 "                sn_ = all_;\n"
+                 "            }\n"
+                 "            if (sn_) {                                                                 // uniform over the grid\n"
+                 "                unsigned long long par_ = 0, kk_ = 0;\n"
+                 "                if (e0 >= sf_ && e0 < sf_ + sn_) { const GGRS_G ggrs_u64* lk_ = (const GGRS_G ggrs_u64*)a.sp_link + 2u * e0; par_ = __hip_atomic_load(lk_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); kk_ = __hip_atomic_load(lk_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+                 "                const unsigned char* const spay_ = a.sp_prec + par_ * 64u;             // the payload of a child: its parent's record\n"
+                 "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
+                 "                    alive_0 = true;\n";
+        } else
         sfmt(s, "            const uint64_t sn_ = mb ? mb_u32(mb, %uu + 4u * sj) : a.spawn_count[sj];\n"
                 "            if (sn_) {                                                                 // wave-uniform\n"
                 "                const uint64_t sf_ = mb ? mb_u64(mb, %uu + 8u * sj) : a.spawn_first[sj];\n"
@@ -1044,9 +1130,10 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             sfmt(s, "                    w%u_0 = %lluull;\n", col(d.comp[2], 0), (unsigned long long)d.iparam[0]);
         } else {
             const ggrs_world::SpawnSys& sp = w->spawn_customs[d.comp[0]];
-            s += "                    GgrsEntity ent; ent.slot = e0; ent.kill = 0;\n";
+            s += "                    GgrsEntity ent; ent.slot = e0; ent.kill = 0; ent.spawn_n = 0;\n";
             for (uint32_t b = 0; b < sp.n_bind; ++b) sfmt(s, "                    ent.w[%u] = w%u_0;\n", b, col(sp.comp[b], sp.word[b]));
-            sfmt(s, "                    ggrs_spawn_sys::ggrs_spawn(ent, e0 - sf_, fr_spawn, spay_ + (e0 - sf_) * %uull);\n", sp.payload_stride);
+            if (DEV) s += "                    ggrs_spawn_sys::ggrs_spawn(ent, kk_, fr_spawn, spay_);                     // k = which child of its parent; payload = the parent's 8 bound words (u64 each)\n";
+            else sfmt(s, "                    ggrs_spawn_sys::ggrs_spawn(ent, e0 - sf_, fr_spawn, spay_ + (e0 - sf_) * %uull);\n", sp.payload_stride);
             for (uint32_t b = 0; b < sp.n_bind; ++b)
                 sfmt(s, "                    w%u_0 = (%s)(%s)ent.w[%u];\n", col(sp.comp[b], sp.word[b]), wtype(sp.comp[b]), mtype(sp.comp[b]), b);
         }
@@ -1056,8 +1143,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         s += "                }\n";
         if (VT) sfmt(s, "                // value tags: new rows in this unit -- every column of the bundle carries a fresh identity\n"
                         "                if (a.vtags && __ballot(e0 >= sf_ && e0 < sf_ + sn_) != 0ull) chg |= 0x%llxull;\n", (unsigned long long)bundle_cols);
-        s += "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n"
-             "            }\n";
+        s += "                in_len = (uint64_t)gu * 64u < sf_ + sn_;\n";
+        if (DEV) s += "                cur_len = sf_ + sn_;\n";
+        s += "            }\n";
     }
     s += "            ++sj;\n"
          "        }\n"
@@ -1070,6 +1158,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "        const uint32_t live_pm_v = mb ? mb_u32(mb, %uu) : a.live_pmask;\n", L.m.live, L.m.live_rows, L.m.live_pmask);
     { char te[96]; snprintf(te, sizeof te, "(mb ? mb_u64(mb, %uu) : a.live_tagok)", L.m.live_tagok); emit_tag_filter("live_p", "live_rows_v", te, "        ", "dtl"); }
     emit_store("live_p", "live_rows_v", "live_pm_v", "alive_now", "        ", false);
+    if (DEV) s += "        if (gu == 0 && lane == 0) { *reinterpret_cast<uint64_t*>(live_p) = cur_len; a.sp_len[0] = cur_len; }      // the live block's header carries RollbackOrdered::len for whoever loads it next; the host reads it from pinned memory\n";
     s += "    }\n";
     if (marks) {
         s += "    if (my_live && a.n_steps) {\n"

@@ -658,6 +658,7 @@ struct GenFinArgs {
     uint64_t* done; uint64_t seq;                                             // completion tag per workgroup in pinned host memory (nullptr: none), see read_back
     uint64_t* out2;                                                           // a second copy of every Checksum(u128) in DEVICE memory (nullptr: none): what the fan-out's all-gather sends from (host_fanout.hpp)
     const uint8_t* mtab; uint32_t mstride, moff_save_len;                     // batch members with records (kernel_gen.hpp): member m's save_len[k] = *(u64*)(mtab + m * mstride + moff_save_len + 8 k)
+    const uint64_t* dev_save_len;                                             // spawns decided on the device: RollbackOrdered::len at Save k as the launch left it (nullptr: save_len above)
 };
 __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
     // rows = the n_cks component XORs + the live count; the 16 waves split over the rows so that every row's loads are in
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_gen_finalize(GenFinArgs f) {
     if (tid == 0) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < f.n_cks; ++c) total ^= sea_one(acc[c]);      // component_checksum.rs:92-95
-        const uint64_t len_k = f.mtab ? *reinterpret_cast<const uint64_t*>(f.mtab + (uint64_t)(k / f.n_saves) * f.mstride + f.moff_save_len + 8u * (k % f.n_saves)) : f.save_len[k % f.n_saves];
+        const uint64_t len_k = f.dev_save_len ? f.dev_save_len[k % f.n_saves] : f.mtab ? *reinterpret_cast<const uint64_t*>(f.mtab + (uint64_t)(k / f.n_saves) * f.mstride + f.moff_save_len + 8u * (k % f.n_saves)) : f.save_len[k % f.n_saves];
         total ^= sea_pair(acc[f.n_cks], len_k);                               // entity_checksum.rs:29-52; XOR fold checksum.rs:88-99
         f.out[2 * (uint64_t)k] = total; f.out[2 * (uint64_t)k + 1] = 0;
         if (f.out2) { f.out2[2 * (uint64_t)k] = total; f.out2[2 * (uint64_t)k + 1] = 0; }

@@ -174,6 +174,7 @@ int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* desc);
  *                                               4-byte words as f32/u32/i32, 8-byte words as u64), written back afterwards
  *   e.slot                                      the entity's RollbackOrdered index (snapshot/rollback.rs:69-74)
  *   e.despawn() / e.despawn_rollback()          commands.entity(e).despawn() / .despawn_rollback() (snapshot/despawn.rs:114-143)
+ *   e.spawn(n)                                  commands.spawn((.., Rollback)) x n, decided HERE, on the device: see GGRS_SPAWN_PAYLOAD_PARENT below
  *   f.dt  f.frame  f.n_inputs                   Time<GgrsTime>::delta_secs (time.rs), the frame being simulated, PlayerInputs::len()
  *   f.input[h]                                  first byte of player h's input (the whole input of a Config<Input = u8> session)
  *   f.input_u8(h) / _u16(h) / _u32(h) / _u64(h) player h's T::Input, little-endian (ggrs_hip_set_input_layout: 1..16 bytes); f.input_ptr(h): its bytes
@@ -242,11 +243,22 @@ int ggrs_hip_set_input_layout(ggrs_world* w, uint32_t input_bytes, uint32_t max_
  * The new entities are RollbackOrdered's next indices (== the next slots), appended after the frame's other systems ran (Bevy applies Commands
  * at the end of the schedule), inside the request group's launch.  One spawn system per world.  Needs the generated kernel (GGRS_E_INVALID at
  * seal without it). */
+/* SPAWNS DECIDED ON THE DEVICE (payload_stride = GGRS_SPAWN_PAYLOAD_PARENT).  In the reference ANY GgrsSchedule system may `commands.spawn((.., Rollback))`, as many as
+ * its data says -- a particle that splits, a bullet fired when an entity's own cooldown runs out (rollback.rs:45-59).  A user-written system (ggrs_hip_add_custom_system)
+ * asks for it with   e.spawn(n)   (0 <= n <= 255 children of THIS entity in this frame; a later call for the same entity in the same frame replaces it).  After the
+ * frame's systems ran -- where Bevy applies Commands -- the children take RollbackOrdered's next indices in the slot order of their parents (an exclusive scan over
+ * wave, workgroup and grid inside the group's launch), so every rank and every replay numbers them alike; child k of a parent is built by the world's spawn system:
+ *     ggrs_spawn(e, k, f, payload)   with payload = the parent's record: the 8 x ggrs_u64 bound words of the system that called e.spawn(n), as that call left them.
+ * ggrs_request::spawn_count and its payload fields are ignored for such a world.  RollbackOrdered::len then lives on the device: ggrs_hip_len and every entry point that
+ * needs it waits for the world's stream first; children beyond the world's capacity are dropped and reported (GGRS_E_CAPACITY at the next collect / blocking call).
+ * Every launch of such a world covers its whole capacity and is a COOPERATIVE launch (all workgroups resident: grid barriers inside), which bounds the capacity by what
+ * the device holds of the world's kernel (GGRS_E_CAPACITY at seal beyond: 2048 workgroups = 524 288 slots at 8 waves per SIMD); no depth-parallel roles, no branch steps. */
+#define GGRS_SPAWN_PAYLOAD_PARENT 0xFFFFFFFFu
 typedef struct {
     const char* name;                               /* for error messages and traces; may be NULL                                  */
     const char* source;                             /* HIP C++ defining ggrs_spawn (NUL-terminated)                                */
     uint64_t bundle_mask;                           /* bit c: the spawned entity has component c                                   */
-    uint32_t payload_stride;                        /* bytes of payload per spawned entity; 0: one blob per AdvanceFrame           */
+    uint32_t payload_stride;                        /* bytes of payload per spawned entity; 0: one blob per AdvanceFrame; GGRS_SPAWN_PAYLOAD_PARENT: see above */
     uint32_t n_bindings;                            /* words the spawner writes (all of components in bundle_mask)                 */
     uint32_t comp[GGRS_CUSTOM_MAX_BINDINGS];
     uint32_t word[GGRS_CUSTOM_MAX_BINDINGS];

@@ -161,13 +161,15 @@ class OracleWorld(WorldBase):
         return ip, fp
 
     def add_custom_system(self, fn, bindings, iparam=(), fparam=(), name: str = "custom"):
-        """fn(words: list[int], slot: int, frame: FrameView) -> (new words, kill) with kill 0 / 1 = despawn() / 2 = despawn_rollback()."""
+        """fn(words: list[int], slot: int, frame: FrameView) -> (new words, kill[, n_spawn]) with kill 0 / 1 = despawn() / 2 = despawn_rollback() and n_spawn =
+        e.spawn(n): how many Rollback entities this call spawns (a spawn system with payload_stride 0xFFFFFFFF builds them from this call's words)."""
         n = len(bindings)
 
         def thunk(words, slot, f, kill, _u):
-            new, k = fn([int(words[i]) for i in range(n)], int(slot), f.contents)
+            r = fn([int(words[i]) for i in range(n)], int(slot), f.contents)
+            new, k, ns = (r[0], r[1], r[2]) if len(r) > 2 else (r[0], r[1], 0)
             for i in range(n): words[i] = int(new[i]) & 0xFFFFFFFFFFFFFFFF
-            kill[0] = int(k)
+            kill[0] = int(k) | (min(max(int(ns), 0), 255) << 8)
         cb = CUSTOM_FN(thunk)
         self._keep = getattr(self, "_keep", []) + [cb]
         comp = (C.c_uint32 * n)(*[c for c, _ in bindings]); word = (C.c_uint32 * n)(*[w for _, w in bindings])

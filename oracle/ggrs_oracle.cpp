@@ -43,6 +43,7 @@
 #include <cstdio>
 #include <deque>
 #include <string>
+#include <map>
 #include <vector>
 #include <memory>
 #include <chrono>
@@ -305,6 +306,10 @@ struct World {
     std::vector<SystemDesc> systems;
     std::vector<CustomSys> customs;            // SYS_CUSTOM: systems[i].comp[0] indexes this
     std::vector<SpawnSys> spawn_customs;       // SYS_SPAWN_CUSTOM: likewise
+    // `commands.spawn((.., Rollback))` from inside a user-written system, as many as the entity's data says (rollback.rs:45-59): the requests of the frame being
+    // advanced -- parent slot -> {children, the parent's bound words as its system call left them} -- applied after the frame's systems, parents in RollbackOrdered order
+    struct SpawnReq { uint32_t n; uint64_t words[8]; };
+    std::map<uint64_t, SpawnReq> spawn_reqs;
     uint32_t input_bytes = 1, max_players = 16;   // PlayerInputs<T>: size_of::<T::Input>()
     bool sealed = false;
 
@@ -550,6 +555,10 @@ static void run_custom_system(World& w, const AdvanceArgs& a, const SystemDesc& 
         for (uint32_t b = 0; b < cs.n_bind; ++b) words[b] = load_word(w, cs.comp[b], cs.word[b], i);
         cs.fn(words, i, &f, &kill, cs.user);
         for (uint32_t b = 0; b < cs.n_bind; ++b) store_word(w, cs.comp[b], cs.word[b], i, words[b]);
+        // (the callback's int carries two things: bits 0..7 the despawn request -- 0 none, 1 despawn(), 2 despawn_rollback() --, bits 8..15 how many Rollback entities
+        // this call spawns)
+        const uint32_t n_spawn = ((uint32_t)kill >> 8) & 0xFFu; kill &= 0xFF;
+        if (n_spawn) { World::SpawnReq rq; rq.n = n_spawn; memset(rq.words, 0, sizeof rq.words); for (uint32_t b = 0; b < cs.n_bind; ++b) rq.words[b] = words[b]; w.spawn_reqs[i] = rq; }
         if (kill == 2) despawn_rollback_one(w, i); else if (kill) setbit(w.alive, i, false);
     }
     if (w.mode == 1) ref_sync_from_flat(w, 0, w.len);
@@ -993,12 +1002,38 @@ static void world_advance(World& w, const AdvanceArgs& a_in) {
     AdvanceArgs a = a_in;
     if (a.dt_bits == 0) a.dt_bits = dt_bits_for_frame(w.fps, w.frame);   // GgrsTimePlugin::update, time.rs:63-87
     despawn_confirmed(w);                                         // AdvanceWorldSystems::DespawnConfirmed, set.rs:68-70
+    w.spawn_reqs.clear();
     if (w.mode == 0) advance_flat(w, a); else advance_ref(w, a);
     // a user-written spawn system: its Commands are applied with the others, after every system of the frame ran (set.rs:118-134); the
     // entities take RollbackOrdered's next indices (rollback.rs:69-74), the bundle's components their registered defaults, then what the spawner writes
     for (const SystemDesc& s : w.systems) {
-        if (s.kind != SYS_SPAWN_CUSTOM || a.spawn_count == 0) continue;
+        if (s.kind != SYS_SPAWN_CUSTOM) continue;
         static const uint8_t zero_status[16] = {0};
+        if (w.spawn_customs[s.comp[0]].payload_stride == 0xFFFFFFFFu) {
+            // spawns the systems decided (GGRS_SPAWN_PAYLOAD_PARENT): Commands are applied in the order they were queued -- entities are visited in RollbackOrdered
+            // (slot) order, so parents in slot order, each parent's children k = 0 .. n-1; the child's payload is its parent's record
+            const SpawnSys& sp = w.spawn_customs[s.comp[0]];
+            const FrameView f = frame_view(w, a, s, zero_status);
+            const std::map<uint64_t, World::SpawnReq> reqs = w.spawn_reqs;
+            w.spawn_reqs.clear();
+            uint64_t total = 0;
+            for (auto& kv : reqs) total += kv.second.n;
+            if (w.len + total > w.capacity) continue;                  // (the device drops the frame's spawns and reports: tests stay within capacity)
+            for (auto& kv : reqs) {
+                uint64_t first = 0;
+                if (world_spawn(w, kv.second.n, sp.bundle_mask, nullptr, &first) != 0) break;
+                if (w.mode == 1) ref_sync_to_flat(w);
+                for (uint64_t k = 0; k < kv.second.n; ++k) {
+                    uint64_t words[8];
+                    for (uint32_t b = 0; b < sp.n_bind; ++b) words[b] = load_word(w, sp.comp[b], sp.word[b], first + k);
+                    sp.fn(words, first + k, k, &f, (const uint8_t*)kv.second.words, sp.user);
+                    for (uint32_t b = 0; b < sp.n_bind; ++b) store_word(w, sp.comp[b], sp.word[b], first + k, words[b]);
+                }
+                if (w.mode == 1) ref_sync_from_flat(w, first, kv.second.n);
+            }
+            continue;
+        }
+        if (a.spawn_count == 0) continue;
         const SpawnSys& sp = w.spawn_customs[s.comp[0]];
         const FrameView f = frame_view(w, a, s, zero_status);
         uint64_t first = 0;

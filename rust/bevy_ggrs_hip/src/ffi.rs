@@ -50,6 +50,8 @@ pub const GGRS_BRANCH_RETAIN_NEWEST: u32 = 2;
 pub const GGRS_BRANCH_RETAIN_ALL: u32 = 4;
 pub const GGRS_ADOPT_RECOMPUTE: u32 = 0;
 pub const GGRS_ADOPT_BROADCAST: u32 = 1;
+/// `ggrs_spawn_system_desc::payload_stride`: the spawn system's counts and payloads come from the entities that called `e.spawn(n)` on the device.
+pub const GGRS_SPAWN_PAYLOAD_PARENT: u32 = 0xFFFF_FFFF;
 
 #[repr(C)]
 pub struct ggrs_fanout {
