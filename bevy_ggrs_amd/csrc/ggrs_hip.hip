@@ -812,6 +812,7 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
         add("group_caps", std::to_string(w->cap_saves) + " saves / " + std::to_string(w->cap_steps) + " steps");
         bool any_spawn = false;
         for (auto& sd : w->systems) any_spawn |= sd.kind == GGRS_SYS_PARTICLES_SPAWN || sd.kind == GGRS_SYS_SPAWN_CUSTOM;
+        if (w->dev_spawn) { char t[160]; snprintf(t, sizeof t, "one cooperative launch per request group: %u workgroups, %d resident per CU x %d CUs (%d VGPRs, %d SGPRs)", 8u * ((w->sp_tiles + 7u) / 8u), w->sp_per_cu, w->n_cu, w->sp_regs, w->sp_sregs); add("device_spawn", t); }
         if (any_spawn) add("spawn_system", w->jit_spawn_sys >= 0 ? "runs inside the request group (rows appended by the group's launch)" : "ends the request group (its own launches)");
     }
     add("blocking_wait", w->knobs.spin_wait_us > 0 ? "polls k_gen_finalize's completion tags when that kernel ends the list (" + std::to_string(w->spin_hits) + " calls so far, " +

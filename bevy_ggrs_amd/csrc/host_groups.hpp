@@ -223,9 +223,7 @@ int launch_jit(ggrs_world* w, hipFunction_t fn, uint32_t gx, uint32_t gy, uint32
     gx += j.ff_blocks;
     const double t0 = w->tl.on ? tl_now_us() : 0;
     if (w->dev_spawn) {
-        // spawns decided on the device: grid barriers inside -- a COOPERATIVE launch (every workgroup resident, the runtime lets no second one in beside it); the
-        // barrier counters start from zero
-        HIPCHK(w, hipMemsetAsync(w->d_sp_bar, 0, 2 * (size_t)MAX_TICK_STEPS * 4, w->stream));
+        // spawns decided on the device: the workgroups meet inside -- a COOPERATIVE launch (every workgroup resident, the runtime lets no second one in beside it)
         hipEvent_t a = nullptr, b = nullptr;
         if (w->prof) { a = w->prof_event(); b = w->prof_event(); if (!a || !b) return w->fail(GGRS_E_HIP, "hipEventCreate failed"); w->prof_bytes[GGRS_KERNEL_TICK] += bytes; HIPCHK(w, hipEventRecord(a, w->stream)); }
         HIPCHK(w, hipModuleLaunchCooperativeKernel(fn, gx, gy, gz, TPB, 1, 1, lds, w->stream, params));
@@ -547,7 +545,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
         if (w->dev_spawn) {
-            j.sp_sums = reinterpret_cast<ggrs_u64*>(w->d_sp_sums); j.sp_bar = w->d_sp_bar; j.sp_prec = w->d_sp_prec; j.sp_link = reinterpret_cast<ggrs_u64*>(w->d_sp_link);
+            j.sp_sums = reinterpret_cast<ggrs_u64*>(w->d_sp_sums); j.sp_epoch = w->sp_epoch; w->sp_epoch += 2u * MAX_TICK_STEPS + 2u; j.sp_prec = w->d_sp_prec; j.sp_link = reinterpret_cast<ggrs_u64*>(w->d_sp_link);
             j.sp_len = reinterpret_cast<ggrs_u64*>(w->d_sp_len); j.sp_cap = w->capacity; j.sp_tiles = w->sp_tiles;
         }
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;

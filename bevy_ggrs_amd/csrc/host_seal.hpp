@@ -17,11 +17,10 @@ void arena_release(ggrs_world* w) {
 
 void sp_release(ggrs_world* w) {
     if (w->d_sp_sums) (void)hipFree(w->d_sp_sums);
-    if (w->d_sp_bar) (void)hipFree(w->d_sp_bar);
     if (w->d_sp_prec) (void)hipFree(w->d_sp_prec);
     if (w->d_sp_link) (void)hipFree(w->d_sp_link);
     if (w->h_sp_len) (void)hipHostFree((void*)w->h_sp_len);
-    w->d_sp_sums = nullptr; w->d_sp_bar = nullptr; w->d_sp_prec = nullptr; w->d_sp_link = nullptr; w->h_sp_len = nullptr; w->d_sp_len = nullptr;
+    w->d_sp_sums = nullptr; w->d_sp_prec = nullptr; w->d_sp_link = nullptr; w->h_sp_len = nullptr; w->d_sp_len = nullptr;
 }
 int seal(ggrs_world* w) {
     if (w->layout_only) return w->fail(GGRS_E_NO_DEVICE, "GGRS_WORLD_LAYOUT_ONLY world: there is no device behind it");
@@ -245,13 +244,19 @@ int seal_impl(ggrs_world* w) {
         w->sp_tiles = (uint32_t)(((w->capacity + 63) / 64 + 3) / 4);                 // == the workgroups that own a tile when a launch covers `capacity` slots
         int per_cu = 0;
         HIPCHK(w, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, w->jit_fn, TPB, jit_lane_fold_bytes(w, w->cks_args.n_cks, w->cap_saves)));
+        // the occupancy query is not enough (resident_wgs_per_cu): the register files bound it too, by the counts the code object's own note states; when the
+        // note cannot be read, one workgroup per CU less than the query says
+        const uint32_t regs = w->jit_entry ? w->jit_entry->vgprs : 0, sregs = w->jit_entry ? w->jit_entry->sgprs : 0;
+        per_cu = (regs && sregs) ? std::min(per_cu, resident_wgs_per_cu(regs, sregs)) : per_cu - 1;
+        w->sp_sregs = (int)sregs;
+        w->sp_regs = (int)regs; w->sp_per_cu = per_cu;
         const uint64_t max_wgs = (uint64_t)std::max(per_cu, 0) * (uint64_t)w->n_cu;
         const uint32_t grid = 8u * ((w->sp_tiles + 7u) / 8u);
         if (grid > max_wgs)
             return w->fail(GGRS_E_CAPACITY, "a world whose systems spawn on the device runs as ONE resident launch: %u workgroups are needed for %llu slots, the device holds %llu of this kernel (at most %llu slots)",
                            grid, (unsigned long long)w->capacity, (unsigned long long)max_wgs, (unsigned long long)(max_wgs / 8 * 8 * 256));
-        HIPCHK(w, hipMalloc((void**)&w->d_sp_sums, (size_t)w->cap_steps * w->sp_tiles * 8));
-        HIPCHK(w, hipMalloc((void**)&w->d_sp_bar, 2 * (size_t)MAX_TICK_STEPS * 4));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_sums, (3 * (size_t)w->sp_tiles + 32) * 8));                 // the mailbox words {epoch, value}: counts, prefixes, done per tile; total; go
+        HIPCHK(w, hipMemsetAsync(w->d_sp_sums, 0, (3 * (size_t)w->sp_tiles + 32) * 8, w->stream)); w->sp_epoch = 0;
         HIPCHK(w, hipMalloc((void**)&w->d_sp_prec, (size_t)w->cap_pad * 64));
         HIPCHK(w, hipMalloc((void**)&w->d_sp_link, (size_t)w->cap_pad * 16));
         HIPCHK(w, hipHostMalloc((void**)&w->h_sp_len, (2 + MAX_TICK_SAVES) * 8, hipHostMallocMapped));

@@ -197,8 +197,8 @@ struct ggrs_world {
     // SPAWNS DECIDED ON THE DEVICE (kernel_gen.hpp GgrsJitArgs::sp_*): a system called e.spawn(n).  RollbackOrdered::len then lives on the device -- the host's `len`
     // is what the last launch it waited for reported (len_sync) -- every launch covers the world's whole capacity and is COOPERATIVE (all workgroups resident)
     bool dev_spawn = false; bool len_stale = false;
-    uint64_t* d_sp_sums = nullptr; uint32_t* d_sp_bar = nullptr; uint8_t* d_sp_prec = nullptr; uint64_t* d_sp_link = nullptr;
-    volatile uint64_t* h_sp_len = nullptr; uint64_t* d_sp_len = nullptr; uint32_t sp_tiles = 0;
+    uint64_t* d_sp_sums = nullptr; uint8_t* d_sp_prec = nullptr; uint64_t* d_sp_link = nullptr;
+    volatile uint64_t* h_sp_len = nullptr; uint64_t* d_sp_len = nullptr; uint32_t sp_tiles = 0, sp_epoch = 0; int sp_regs = 0, sp_sregs = 0, sp_per_cu = 0;
     std::vector<uint64_t> off_present, col_off;   // col_off: block-relative offset of the column's row in tile 0 (component words first, then the Stored words of strategy components)
     std::vector<uint32_t> col_wb, col_ts;          // word bytes / tile stride of every column (kernels.hpp col_at)
     std::vector<uint8_t> col_rb;                   // column is part of a rollback component (snapshotted)

@@ -209,10 +209,11 @@ struct GgrsJitArgs {
     ggrs_u32 vtags, tag_base;
     // SPAWNS DECIDED ON THE DEVICE (a system called e.spawn(n); ggrs_hip_add_spawn_system with GGRS_SPAWN_PAYLOAD_PARENT): RollbackOrdered::len lives on the device
     // (the blocks' headers; sp_len[0] = the live world's after the launch, [1] = error flags, [2 + k] = len at Save k: pinned), the launch is cooperative (every
-    // workgroup resident: per step one grid barrier over sp_bar to sum the workgroups' counts in sp_sums -- slot order == RollbackOrdered order --, a second one
-    // when anything spawned so that the lanes owning the new slots find their parents' records: sp_prec[parent slot] = the parent's bound words, sp_link[child
-    // slot] = {parent slot, k})
-    ggrs_u64* sp_sums; ggrs_u32* sp_bar; unsigned char* sp_prec; ggrs_u64* sp_link; ggrs_u64* sp_len; ggrs_u64 sp_cap; ggrs_u32 sp_tiles;
+    // workgroup resident: per step the workgroups' counts are gathered, scanned and handed back -- slot order == RollbackOrdered order --, and a second
+    // rendezvous when anything spawned so that the lanes owning the new slots find their parents' records: sp_prec[parent slot] = the parent's bound words,
+    // sp_link[child slot] = {parent slot, k}).  sp_sums = the rendezvous' mailboxes, one {epoch, value} word each: counts[tiles], prefixes[tiles], done[tiles],
+    // total (at 3 x tiles), go (at 3 x tiles + 16); sp_epoch = this launch's first epoch (2 per step): no word is ever reset
+    ggrs_u64* sp_sums; ggrs_u32 sp_epoch; unsigned char* sp_prec; ggrs_u64* sp_link; ggrs_u64* sp_len; ggrs_u64 sp_cap; ggrs_u32 sp_tiles;
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
     ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
     ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
@@ -267,7 +268,7 @@ JitLayout jit_layout(const ggrs_world* w) {
         FA("int", save_frame, S, true); FA("ggrs_u32", save_pmask, S, true);
         F1("ggrs_u32", live_pmask, true); F1("ggrs_u32", nt_loads, true); F1("ggrs_u32", n_ops, true); F1("ggrs_u32", n_saves, true); F1("ggrs_u32", n_steps, true);
         F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", part_tstride, true); F1("ggrs_u32", nt, true);
-        F1("ggrs_u64*", sp_sums, need.devspawn); F1("ggrs_u32*", sp_bar, need.devspawn); F1("unsigned char*", sp_prec, need.devspawn); F1("ggrs_u64*", sp_link, need.devspawn);
+        F1("ggrs_u64*", sp_sums, need.devspawn); F1("ggrs_u32", sp_epoch, need.devspawn); F1("unsigned char*", sp_prec, need.devspawn); F1("ggrs_u64*", sp_link, need.devspawn);
         F1("ggrs_u64*", sp_len, need.devspawn); F1("ggrs_u64", sp_cap, need.devspawn);
         F1("ggrs_u32", n_units, true); F1("ggrs_u32", sp_tiles, need.devspawn); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
         FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
@@ -562,16 +563,19 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "__device__ __forceinline__ uint64_t uni64(uint64_t m) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m); }   // wave-uniform by construction: say so\n"
          "__device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %2\\n\\tv_mov_b32 %1, %3\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_), \"+v\"(v) : \"s\"(lanes), \"s\"(x)); }\n"
          "__device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %3\\n\\tglobal_store_dword %1, %2, off\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_) : \"v\"(p), \"v\"(v), \"s\"(lanes) : \"memory\"); }\n"
-         "// SPAWNS DECIDED ON THE DEVICE: a barrier over every workgroup of a COOPERATIVE launch (all of them are resident): thread 0 of each arrives and waits,\n"
-         "// bounded (a second of wall clock: a launch that cannot make it reports an error instead of hanging the device); and a sum over the 64 lanes\n"
-         "__device__ __forceinline__ bool grid_arrive_wait(ggrs_u32* ctr, ggrs_u32 n) {\n"
-         "    __threadfence();\n"
-         "    atomicAdd(ctr, 1u);\n"
-         "    const unsigned long long t0_ = wall_clock64();\n"
-         "    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) { if (wall_clock64() - t0_ > 100000000ull) return false; __builtin_amdgcn_s_sleep(1); }\n"
-         "    return true;\n"
+         "// SPAWNS DECIDED ON THE DEVICE: the workgroups of a COOPERATIVE launch (all resident) meet through mailbox words {epoch:32 | value:32}, written and polled\n"
+         "// as relaxed agent-scope atomics (sc1: through to where every XCD reads them).  The value travels INSIDE the word it is waited on, so no rendezvous needs a\n"
+         "// release/acquire pair -- on gfx950 those are a writeback / an invalidate of a whole L2 each (measured: ~100 us per barrier with an acquire in the poll loop).\n"
+         "// Bounded: a second of wall clock, then the launch reports an error instead of hanging the device\n"
+         "__device__ __forceinline__ void sp_post(ggrs_u64* p, ggrs_u32 ep, ggrs_u32 v) { __hip_atomic_store(p, ((ggrs_u64)ep << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+         "__device__ __forceinline__ bool sp_await(ggrs_u64* p, ggrs_u32 ep, ggrs_u32& v, unsigned long long t0_) {\n"
+         "    for (;;) {\n"
+         "        const ggrs_u64 x_ = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+         "        if ((ggrs_u32)(x_ >> 32) == ep) { v = (ggrs_u32)x_; return true; }\n"
+         "        if (wall_clock64() - t0_ > 100000000ull) return false;\n"
+         "        __builtin_amdgcn_s_sleep(1);\n"
+         "    }\n"
          "}\n"
-         "__device__ __forceinline__ ggrs_u64 wave_sum64(ggrs_u64 v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }\n"
          "namespace ggrs {\n";
     s += kJitPrelude;
     s += "\n}\nusing namespace ggrs;\n";
@@ -659,7 +663,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    const uint64_t wi8 = (uint64_t)gu * 8u;                                    // byte offset of this wave's mask word: bit `lane` is this slot\n"
             "    const uint32_t sh = lane;\n",
          DEV ? "    uint64_t cur_len = *reinterpret_cast<const uint64_t*>(a.src);                // RollbackOrdered::len as the source block's header says: with spawns decided on the device the host only knows a bound\n"
-                   "    __shared__ uint64_t s_sp[8];                                               // the workgroup's spawn bookkeeping of one step\n" : "",
+                   "    __shared__ uint64_t s_sp[16];                                              // the workgroup's spawn bookkeeping of one step\n" : "",
          spawn_sys >= 0 ? "" : "const ", DEV ? "cur_len" : "a.len", spawn_sys >= 0 ? " (a spawn inside the group grows len)" : "", LT_SHIFT - 6, w->ts, (unsigned)(LAYOUT_TILE / 64 - 1));
     // ---- masks and words of the lane's slot
     sfmt(s, "    const uint64_t mk_alive = *reinterpret_cast<const uint64_t*>(a.src + %lluull + wi8);\n"
@@ -1038,7 +1042,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             if (DEV) s += "                if (ent.spawn_n) {                                        // e.spawn(n): the children are made after the frame's systems, from what THIS call left in e\n"
                           "                    spn_0 = (uint32_t)ent.spawn_n;\n"
                           "                    GGRS_G ggrs_u64* pr_ = (GGRS_G ggrs_u64*)(a.sp_prec + e0 * 64u);\n"
-                          "                    for (int b_ = 0; b_ < 8; ++b_) pr_[b_] = ent.w[b_];\n"
+                          "                    for (int b_ = 0; b_ < 8; ++b_) __hip_atomic_store(pr_ + b_, (ggrs_u64)ent.w[b_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: read by another workgroup, maybe another XCD, later in this launch\n"
                           "                }\n";
             for (uint32_t b = 0; b < c.n_bind; ++b)
                 sfmt(s, "                w%u_0 = (%s)(%s)ent.w[%u];\n", col(c.comp[b], c.word[b]), wtype(c.comp[b]), mtype(c.comp[b]), b);   // narrow words wrap as their memory type does
@@ -1060,9 +1064,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
         if (custom) emit_frame("fr_spawn", d.fparam, d.iparam);
         if (DEV) {
             // How many, and whose: the entities that called e.spawn(n), in slot order (== RollbackOrdered order, so every rank and every replay numbers the children
-            // alike).  Per step: an exclusive scan over the wave, the workgroup (LDS) and -- behind a barrier over the whole resident grid -- the workgroups' sums
-            // in tile order; a parent then knows its children's slots and leaves {parent slot, k} where the lane that OWNS each new slot will look; a second
-            // barrier (only in steps that spawn anything), and that lane takes the bundle.
+            // alike).  Per step: an exclusive scan over the wave and the workgroup (LDS); every workgroup posts its count, workgroup 0 gathers them, scans them in
+            // tile order and hands each workgroup its prefix and everyone the total; a parent then knows its children's slots and leaves {parent slot, k} where the
+            // lane that OWNS each new slot will look; a second rendezvous (only in steps that spawn anything), and that lane takes the bundle.
             s += "            uint64_t sn_ = 0, sf_ = cur_len;\n"
                  "            {\n"
                  "                uint32_t inc_ = spn_0;                                                 // inclusive scan over the wave's 64 lanes\n"
@@ -1073,37 +1077,76 @@ bool jit_source(const ggrs_world* w, std::string& s) {
                  "                __syncthreads();\n"
                  "                uint32_t wg_excl_ = 0, wg_tot_ = 0;\n"
                  "                for (uint32_t q_ = 0; q_ < 4u; ++q_) { const uint32_t v_ = (uint32_t)s_sp[q_]; wg_tot_ += v_; if (q_ < wave) wg_excl_ += v_; }\n"
+                 "                const uint32_t T_ = a.sp_tiles, ep1_ = a.sp_epoch + 2u * sj + 1u, ep2_ = ep1_ + 1u;\n"
+                 "                ggrs_u64* const cnt_ = a.sp_sums; ggrs_u64* const pref_ = cnt_ + T_; ggrs_u64* const done_ = cnt_ + 2u * T_; ggrs_u64* const tot_ = cnt_ + 3u * T_; ggrs_u64* const go_ = tot_ + 16;\n"
+                 "                const unsigned long long tb_ = wall_clock64();\n"
+                 "                if (tid == 0) sp_post(cnt_ + tile, ep1_, wg_tot_);\n"
+                 "                if (tile == 0) {                                                       // workgroup 0: gather, scan in tile order (== slot order), hand back\n"
+                 "                    // thread t takes the tiles [t x per, (t + 1) x per): at most 8 (8 x 256 workgroups are ever resident).  Awaited one after the other: keeping several\n"
+                 "                    // loads in flight, or the counts in LDS, was tried and costs the WHOLE kernel 3..30 VGPRs -- a workgroup per CU of residency, i.e. of capacity\n"
+                 "                    const uint32_t per_ = (T_ + 255u) / 256u, glo_ = tid * per_ < T_ ? tid * per_ : T_, ghi_ = glo_ + per_ < T_ ? glo_ + per_ : T_;\n"
+                 "                    uint32_t mine_ = 0; bool okg_ = true;\n"
+                 "                    for (uint32_t t_ = glo_; t_ < ghi_; ++t_) { uint32_t v_ = 0; okg_ = sp_await(cnt_ + t_, ep1_, v_, tb_) && okg_; mine_ += v_; }\n"
+                 "                    uint32_t sc_ = mine_;\n"
+                 "                    for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t up_ = __shfl_up(sc_, o_, 64); if ((int)lane >= o_) sc_ += up_; }\n"
+                 "                    const uint32_t wt2_ = (uint32_t)__builtin_amdgcn_readlane((int)sc_, 63);\n"
+                 "                    const bool wfail_ = __ballot(!okg_) != 0ull;\n"
+                 "                    if (lane == 0) { s_sp[8u + wave] = wt2_; s_sp[12u + wave] = wfail_ ? 1ull : 0ull; }\n"
+                 "                    __syncthreads();\n"
+                 "                    uint32_t base_ = sc_ - mine_, run_ = 0;\n"
+                 "                    for (uint32_t q_ = 0; q_ < 4u; ++q_) { const uint32_t v_ = (uint32_t)s_sp[8u + q_]; run_ += v_; if (q_ < wave) base_ += v_; }\n"
+                 "                    const bool fail_ = (s_sp[12] | s_sp[13] | s_sp[14] | s_sp[15]) != 0ull;\n"
+                 "                    if (run_ != 0u && !fail_)\n"
+                 "                        for (uint32_t t_ = glo_; t_ < ghi_; ++t_) { const uint32_t v_ = (uint32_t)__hip_atomic_load(cnt_ + t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sp_post(pref_ + t_, ep1_, base_); base_ += v_; }\n"
+                 "                    if (tid == 0) sp_post(tot_, ep1_, fail_ ? 0xFFFFFFFFu : run_);\n"
+                 "                }\n"
                  "                if (tid == 0) {\n"
-                 "                    a.sp_sums[(uint64_t)sj * a.sp_tiles + tile] = wg_tot_;\n"
-                 "                    s_sp[4] = grid_arrive_wait(a.sp_bar + 2u * sj, a.sp_tiles) ? 1ull : 0ull;\n"
+                 "                    uint32_t all32_ = 0xFFFFFFFFu, bef32_ = 0;\n"
+                 "                    bool ok_ = sp_await(tot_, ep1_, all32_, tb_) && all32_ != 0xFFFFFFFFu;\n"
+                 "                    if (ok_ && all32_ != 0u) ok_ = sp_await(pref_ + tile, ep1_, bef32_, tb_);\n"
+                 "                    s_sp[4] = bef32_; s_sp[5] = ok_ ? all32_ : 1ull; s_sp[6] = ok_ ? 1ull : 0ull;\n"
                  "                }\n"
                  "                __syncthreads();\n"
-                 "                const bool ok1_ = s_sp[4] != 0ull;\n"
-                 "                uint64_t bef_ = 0, all_ = 0;                                           // the workgroups before this one (tile order == slot order), and all of them\n"
-                 "                for (uint32_t t_ = tid; t_ < a.sp_tiles; t_ += 256u) { const uint64_t v_ = __hip_atomic_load(a.sp_sums + (uint64_t)sj * a.sp_tiles + t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); all_ += v_; if (t_ < tile) bef_ += v_; }\n"
-                 "                bef_ = wave_sum64(bef_); all_ = wave_sum64(all_);\n"
-                 "                __syncthreads();\n"
-                 "                if (lane == 0) { s_sp[wave] = bef_; s_sp[4u + wave] = all_; }\n"
-                 "                __syncthreads();\n"
-                 "                bef_ = s_sp[0] + s_sp[1] + s_sp[2] + s_sp[3]; all_ = s_sp[4] + s_sp[5] + s_sp[6] + s_sp[7];\n"
-                 "                if (!ok1_ || cur_len + all_ > a.sp_cap) {                               // a barrier that timed out, or children beyond the world's capacity: nothing spawns, the host is told\n"
+                 "                const bool ok1_ = s_sp[6] != 0ull;\n"
+                 "                const uint64_t bef_ = s_sp[4];\n"
+                 "                uint64_t all_ = s_sp[5];\n"
+                 "                if (!ok1_ || cur_len + all_ > a.sp_cap) {                               // a rendezvous that timed out, or children beyond the world's capacity: nothing spawns, the host is told\n"
                  "                    if (all_ && gu == 0 && lane == 0) a.sp_len[1] = !ok1_ ? 2ull : 1ull;\n"
                  "                    all_ = 0;\n"
                  "                }\n"
                  "                if (all_) {                                                            // uniform over the whole grid\n"
                  "                    const uint64_t first_ = cur_len + bef_ + wg_excl_ + (inc_ - spn_0);    // this parent's first child\n"
-                 "                    for (uint32_t k_ = 0; k_ < spn_0; ++k_) { GGRS_G ggrs_u64* lk_ = (GGRS_G ggrs_u64*)a.sp_link + 2u * (first_ + k_); lk_[0] = e0; lk_[1] = k_; }\n"
+                 "                    for (uint32_t k_ = 0; k_ < spn_0; ++k_) {\n"
+                 "                        GGRS_G ggrs_u64* lk_ = (GGRS_G ggrs_u64*)a.sp_link + 2u * (first_ + k_);\n"
+                 "                        __hip_atomic_store(lk_, (ggrs_u64)e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(lk_ + 1, (ggrs_u64)k_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                 "                    }\n"
+                 "                    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");                    // this wave's links and parent records (sc1 stores) have arrived where every XCD reads them\n"
                  "                    __syncthreads();\n"
-                 "                    if (tid == 0) s_sp[4] = grid_arrive_wait(a.sp_bar + 2u * sj + 1u, a.sp_tiles) ? 1ull : 0ull;\n"
+                 "                    if (tid == 0) sp_post(done_ + tile, ep2_, 1u);\n"
+                 "                    if (tile == 0) {\n"
+                 "                        bool okd_ = true;\n"
+                 "                        for (uint32_t t_ = tid; t_ < T_ && okd_; t_ += 256u) { uint32_t v_ = 0; okd_ = sp_await(done_ + t_, ep2_, v_, tb_); }\n"
+                 "                        const bool wfail_ = __ballot(!okd_) != 0ull;\n"
+                 "                        if (lane == 0) s_sp[12u + wave] = wfail_ ? 1ull : 0ull;\n"
+                 "                        __syncthreads();\n"
+                 "                        if (tid == 0) sp_post(go_, ep2_, (s_sp[12] | s_sp[13] | s_sp[14] | s_sp[15]) != 0ull ? 0xFFFFFFFFu : 1u);\n"
+                 "                    }\n"
+                 "                    if (tid == 0) { uint32_t g_ = 0; const bool ok_ = sp_await(go_, ep2_, g_, tb_) && g_ == 1u; s_sp[6] = ok_ ? 1ull : 0ull; }\n"
                  "                    __syncthreads();\n"
-                 "                    if (s_sp[4] == 0ull) { if (gu == 0 && lane == 0) a.sp_len[1] = 2ull; all_ = 0; }\n"
+                 "                    if (s_sp[6] == 0ull) { if (gu == 0 && lane == 0) a.sp_len[1] = 2ull; all_ = 0; }\n"
                  "                }\n"
                  "                sn_ = all_;\n"
                  "            }\n"
                  "            if (sn_) {                                                                 // uniform over the grid\n"
-                 "                unsigned long long par_ = 0, kk_ = 0;\n"
-                 "                if (e0 >= sf_ && e0 < sf_ + sn_) { const GGRS_G ggrs_u64* lk_ = (const GGRS_G ggrs_u64*)a.sp_link + 2u * e0; par_ = __hip_atomic_load(lk_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); kk_ = __hip_atomic_load(lk_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
-                 "                const unsigned char* const spay_ = a.sp_prec + par_ * 64u;             // the payload of a child: its parent's record\n"
+                 "                unsigned long long kk_ = 0;\n"
+                 "                ggrs_u64 prec_[8] = {0, 0, 0, 0, 0, 0, 0, 0};                          // the payload of a child: its parent's record, fetched past this XCD's L2 (sc1)\n"
+                 "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
+                 "                    const GGRS_G ggrs_u64* lk_ = (const GGRS_G ggrs_u64*)a.sp_link + 2u * e0;\n"
+                 "                    const unsigned long long par_ = __hip_atomic_load(lk_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); kk_ = __hip_atomic_load(lk_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                 "                    const GGRS_G ggrs_u64* pp_ = (const GGRS_G ggrs_u64*)(a.sp_prec + par_ * 64u);\n"
+                 "                    for (int b_ = 0; b_ < 8; ++b_) prec_[b_] = __hip_atomic_load(pp_ + b_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                 "                }\n"
+                 "                const unsigned char* const spay_ = (const unsigned char*)prec_;\n"
                  "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
                  "                    alive_0 = true;\n";
         } else
@@ -1185,7 +1228,31 @@ bool jit_source(const ggrs_world* w, std::string& s) {
 // ---- code objects: one compile per distinct (device arch, source) -- in the process (worlds of the same shape and capacity
 // share the module: a session restart, a test suite) and ON DISK (GGRS_JIT_CACHE_DIR, default ~/.cache/ggrs_hip), keyed by a
 // hash of the source, the target and the ROCm runtime version, so that a process does not pay 0.3-0.5 s per world shape again.
-struct JitEntry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; uint64_t last_use = 0; uint32_t refs = 0; };
+struct JitEntry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; uint64_t last_use = 0; uint32_t refs = 0; uint32_t vgprs = 0, sgprs = 0; };
+// What a code object's kernel allocates, as its metadata note says (msgpack: the key, e.g. ".sgpr_count", then a small unsigned integer); 0 = not found.
+// These are the figures the register files are divided by when the device admits workgroups.  The occupancy query is one workgroup per CU high for
+// 256-thread kernels with 97..112 SGPRs (MI355X_MICROARCH.md, "Residency and cooperative launch"), and hipModuleLaunchCooperativeKernel accepts the query's
+// number: measured here as rendezvous over 1536 workgroups completing and over 1568 timing out for a kernel the query admits 7 x 256 of
+// (profiles/r06m/probe.txt).
+uint32_t hsaco_note_uint(const std::vector<char>& image, const char* name) {
+    const size_t n = strlen(name);
+    if (n == 0 || n > 31) return 0;
+    char key[34]; key[0] = (char)(0xA0 | n); memcpy(key + 1, name, n);
+    uint32_t best = 0;
+    for (size_t i = 0; i + n + 1 + 3 <= image.size(); ++i) {
+        if (memcmp(&image[i], key, n + 1) != 0) continue;
+        const unsigned char* v = reinterpret_cast<const unsigned char*>(&image[i + n + 1]);
+        uint32_t x = 0;
+        if (v[0] < 0x80) x = v[0]; else if (v[0] == 0xcc) x = v[1]; else if (v[0] == 0xcd) x = ((uint32_t)v[1] << 8) | v[2];
+        best = std::max(best, x);
+    }
+    return best;
+}
+// 256-thread workgroups one CU admits, by the register files alone: min(8, 512 / VGPRs in granules of 8, 800 / (SGPRs in granules of 16, + 16))
+inline int resident_wgs_per_cu(uint32_t vgprs, uint32_t sgprs) {
+    const int by_v = vgprs ? (int)(512u / (((vgprs + 7u) / 8u) * 8u)) : 8, by_s = sgprs ? (int)(800u / (((sgprs + 15u) / 16u) * 16u + 16u)) : 8;
+    return std::max(0, std::min(8, std::min(by_v, by_s)));
+}
 constexpr size_t JIT_CACHE_MAX_MODULES = 64;     // in-process: beyond this many, modules no live world refers to are unloaded, least recently used first
 struct JitCache { std::mutex mu; std::map<std::pair<int, std::string>, JitEntry> map; uint64_t clock = 0; };
 JitCache& jit_cache() { static JitCache c; return c; }
@@ -1235,14 +1302,14 @@ bool jit_read_file(const std::string& path, std::vector<char>& image) {
     return !image.empty();
 }
 // disk cache, then the shipped objects: a module + kernel handle, or false
-bool jit_load_cached(const std::string& cache_dir, const std::string& aot_knob, const std::string& src, hipModule_t* mod, hipFunction_t* fn, std::string* origin) {
+bool jit_load_cached(const std::string& cache_dir, const std::string& aot_knob, const std::string& src, hipModule_t* mod, hipFunction_t* fn, std::string* origin, uint32_t* vgprs = nullptr, uint32_t* sgprs = nullptr) {
     const std::string aot = jit_aot_dir(aot_knob);
     const std::string paths[2] = {jit_disk_path_in(cache_dir, src), aot.empty() ? std::string() : aot + "/" + jit_aot_name(src)};
     for (int k = 0; k < 2; ++k) {
         std::vector<char> image;
         if (!jit_read_file(paths[k], image)) continue;
         if (hipModuleLoadData(mod, image.data()) == hipSuccess) {
-            if (hipModuleGetFunction(fn, *mod, "ggrs_jit_tick") == hipSuccess) { if (origin) *origin = k == 0 ? "disk cache" : "shipped code object (aot)"; return true; }
+            if (hipModuleGetFunction(fn, *mod, "ggrs_jit_tick") == hipSuccess) { if (origin) *origin = k == 0 ? "disk cache" : "shipped code object (aot)"; if (vgprs) *vgprs = hsaco_note_uint(image, ".vgpr_count"); if (sgprs) *sgprs = hsaco_note_uint(image, ".sgpr_count"); return true; }
             (void)hipModuleUnload(*mod); *mod = nullptr;
         }
         (void)hipGetLastError();                                     // a stale / truncated file: go on as if it were not there
@@ -1258,10 +1325,12 @@ int jit_cached(ggrs_world* w, const std::string& src, hipFunction_t* fn, JitEntr
     auto it = cache.find(key);
     if (it != cache.end()) { it->second.last_use = ++clock_; ++it->second.refs; *fn = it->second.fn; *entry_out = &it->second; if (origin) *origin = "in-process module cache"; return GGRS_OK; }
     hipModule_t mod = nullptr;
-    int rc = jit_load_cached(w->knobs.jit_cache_dir, w->knobs.aot_dir, src, &mod, fn, origin) ? GGRS_OK : GGRS_E_HIP;
+    uint32_t vgprs = 0, sgprs = 0;
+    int rc = jit_load_cached(w->knobs.jit_cache_dir, w->knobs.aot_dir, src, &mod, fn, origin, &vgprs, &sgprs) ? GGRS_OK : GGRS_E_HIP;
     if (rc != GGRS_OK) {
         std::vector<char> image;
         rc = hiprtc_build(w, src, "generated request-group kernel", "ggrs_jit_tick", &mod, fn, &image);
+        vgprs = hsaco_note_uint(image, ".vgpr_count"); sgprs = hsaco_note_uint(image, ".sgpr_count");
         const std::string path = jit_disk_path(w, src);
         if (rc == GGRS_OK && origin) *origin = "hiprtc";
         if (rc == GGRS_OK && !path.empty() && !image.empty()) {
@@ -1272,7 +1341,7 @@ int jit_cached(ggrs_world* w, const std::string& src, hipFunction_t* fn, JitEntr
     }
     if (rc != GGRS_OK) return rc;
     JitEntry& e = cache[key];
-    e.mod = mod; e.fn = *fn; e.last_use = ++clock_; e.refs = 1;
+    e.mod = mod; e.fn = *fn; e.last_use = ++clock_; e.refs = 1; e.vgprs = vgprs; e.sgprs = sgprs;
     *entry_out = &e;                                                 // std::map nodes do not move
     return GGRS_OK;
 }

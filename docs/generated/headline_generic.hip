@@ -26,16 +26,19 @@ __device__ __forceinline__ uint32_t mb_u8(const GGRS_K unsigned char* mb, uint32
 __device__ __forceinline__ uint64_t uni64(uint64_t m) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m); }   // wave-uniform by construction: say so
 __device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, %0" : "=&s"(sv_), "+v"(v) : "s"(lanes), "s"(x)); }
 __device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(sv_) : "v"(p), "v"(v), "s"(lanes) : "memory"); }
-// SPAWNS DECIDED ON THE DEVICE: a barrier over every workgroup of a COOPERATIVE launch (all of them are resident): thread 0 of each arrives and waits,
-// bounded (a second of wall clock: a launch that cannot make it reports an error instead of hanging the device); and a sum over the 64 lanes
-__device__ __forceinline__ bool grid_arrive_wait(ggrs_u32* ctr, ggrs_u32 n) {
-    __threadfence();
-    atomicAdd(ctr, 1u);
-    const unsigned long long t0_ = wall_clock64();
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) { if (wall_clock64() - t0_ > 100000000ull) return false; __builtin_amdgcn_s_sleep(1); }
-    return true;
+// SPAWNS DECIDED ON THE DEVICE: the workgroups of a COOPERATIVE launch (all resident) meet through mailbox words {epoch:32 | value:32}, written and polled
+// as relaxed agent-scope atomics (sc1: through to where every XCD reads them).  The value travels INSIDE the word it is waited on, so no rendezvous needs a
+// release/acquire pair -- on gfx950 those are a writeback / an invalidate of a whole L2 each (measured: ~100 us per barrier with an acquire in the poll loop).
+// Bounded: a second of wall clock, then the launch reports an error instead of hanging the device
+__device__ __forceinline__ void sp_post(ggrs_u64* p, ggrs_u32 ep, ggrs_u32 v) { __hip_atomic_store(p, ((ggrs_u64)ep << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool sp_await(ggrs_u64* p, ggrs_u32 ep, ggrs_u32& v, unsigned long long t0_) {
+    for (;;) {
+        const ggrs_u64 x_ = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((ggrs_u32)(x_ >> 32) == ep) { v = (ggrs_u32)x_; return true; }
+        if (wall_clock64() - t0_ > 100000000ull) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
-__device__ __forceinline__ ggrs_u64 wave_sum64(ggrs_u64 v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 namespace ggrs {
 constexpr int LT_SHIFT = 13; constexpr int LAYOUT_TILE = 1 << LT_SHIFT; constexpr uint64_t SEA_P = 0x6eed0e9da4d94a4fULL; constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cULL, SEA_K2 = 0x6fe2e5aaf078ebc9ULL, SEA_K3 = 0x14f994a4c5259381ULL; __host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) { x *= SEA_P; const uint32_t hi = (uint32_t)(x >> 32); x ^= (uint64_t)(hi >> (hi >> 28)); x *= SEA_P; return x; } __host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, uint32_t z) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_tail3(uint32_t z) { return sea_diffuse(SEA_K1 ^ (uint64_t)z); } __host__ __device__ __forceinline__ uint64_t sea_inner3_with_tail(uint32_t x, uint32_t y, uint64_t a) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) { uint64_t B = sea_diffuse(SEA_K0 ^ order); uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_order_lane(uint64_t order) { return sea_diffuse(SEA_K0 ^ order); } __host__ __device__ __forceinline__ uint64_t sea_pair_pre(uint64_t B, uint64_t inner) { uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) { uint64_t A = sea_diffuse(SEA_K0 ^ x); return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL); } struct SeaStream { uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0, tail = 0; uint32_t ntail = 0; __host__ __device__ __forceinline__ void write(uint64_t v, uint32_t nb) { if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL; tail |= v << (8 * ntail); const uint32_t tot = ntail + nb; if (tot >= 8) { const uint64_t a = sea_diffuse(s0 ^ tail); s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; const uint32_t used = 8 - ntail; tail = used >= 8 ? 0ULL : (v >> (8 * used)); ntail = tot - 8; } else ntail = tot; } __host__ __device__ __forceinline__ void unit(uint32_t u) { write(u, 4); } __host__ __device__ __forceinline__ uint64_t finish() const { const uint64_t a = ntail ? sea_diffuse(s0 ^ tail) : s0; return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + ntail)); } }; struct Header { uint64_t len; int32_t frame; uint32_t pad0; uint64_t active; uint64_t checksum[2]; }; __device__ __forceinline__ uint32_t wave_xor32(uint32_t v) { v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); } __device__ __forceinline__ uint64_t wave_xor(uint64_t v) { return ((uint64_t)wave_xor32((uint32_t)(v >> 32)) << 32) | wave_xor32((uint32_t)v); } constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3; __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in, float dt, float fp, float accel, float max_speed, float half_width) { const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT; const float adt = __fmul_rn(accel, dt); if (up && !down) vz = __fsub_rn(vz, adt); if (!up && down) vz = __fadd_rn(vz, adt); if (left && !right) vx = __fsub_rn(vx, adt); if (!left && right) vx = __fadd_rn(vx, adt); if (!up && !down) vz = __fmul_rn(vz, fp); if (!left && !right) vx = __fmul_rn(vx, fp); vy = __fmul_rn(vy, fp); const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)); if (len_sq > __fmul_rn(max_speed, max_speed)) { const float l = sqrtf(len_sq); vx = __fmul_rn(max_speed, vx / l); vy = __fmul_rn(max_speed, vy / l); vz = __fmul_rn(max_speed, vz / l); } x = __fadd_rn(x, __fmul_rn(vx, dt)); y = __fadd_rn(y, __fmul_rn(vy, dt)); z = __fadd_rn(z, __fmul_rn(vz, dt)); const float lo = -half_width, hi = half_width; if (x < lo) x = lo; if (x > hi) x = hi; if (z < lo) z = lo; if (z > hi) z = hi; } constexpr uint32_t FF_CHUNK = 1024; typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4))); __device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq) { const uint32_t tid = threadIdx.x, lane = tid & 63u; __shared__ unsigned long long ff_acc; if (tid == 0) ff_acc = 0ull; __syncthreads(); uint64_t x = 0, sum = 0; constexpr int INFL = 4; for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) { uint64_t v[INFL]; _Pragma("unroll") for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < hi ? p[(uint64_t)i * istride] : 0ULL; } _Pragma("unroll") for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; } } if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); } else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); } __syncthreads(); if (tid == 0) { const uint64_t v = (uint64_t)ff_acc; const ff_u32x4 q = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)seq, (uint32_t)(seq >> 32)}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(cell), "v"(q) : "memory"); } }
 }

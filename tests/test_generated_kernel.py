@@ -273,3 +273,34 @@ def test_generated_kernels_keep_their_register_budget(schema, n, steady_vgprs):
         assert r[".private_segment_fixed_size"] == 0 and r[".vgpr_spill_count"] == 0, (schema, steady, r)
         assert r[".sgpr_spill_count"] == 0 or (tags and not steady), (schema, steady, r)
         assert r[".vgpr_count"] <= limit, (schema, steady, r)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="no llvm-objdump")
+def test_device_spawn_kernel_meets_without_cache_wide_operations_and_stays_resident():
+    """A world whose systems spawn on the device runs as ONE resident launch (its capacity is bounded by what the device holds of the kernel) whose workgroups meet
+    through {epoch, value} mailbox words.  Static checks of that kernel: 80 VGPRs at most (6 workgroups per CU) and no scratch; no agent-scope release / acquire anywhere
+    (`buffer_wbl2` / `buffer_inv`: a writeback / an invalidate of a whole L2 each -- with an acquire inside the poll loop a rendezvous cost ~100 us,
+    profiles/r06z/device_spawn_session.txt against profiles/r06m); the mailbox words, the children's links and the parents' records go through as sc1."""
+    import ctypes as C, subprocess, tempfile
+    import test_gpu_device_spawn as t
+    w = dry(280_256, 9)
+    cell = w.register_component("Cell", 4, 4)
+    w.checksum_component(cell, [0, 1, 2, 3])
+    w.add_custom_system(t.SPLIT_SRC, [(cell, 0), (cell, 1), (cell, 2), (cell, 3)], iparam=(1,), name="split")
+    w.add_spawn_system(t.CHILD_SRC, [cell], [(cell, 0), (cell, 1), (cell, 2), (cell, 3)], payload_stride=t.PARENT, name="child")
+    src = w.generated_kernel_source()
+    assert "sp_post(" in src and "sp_await(" in src and "__threadfence" not in src.split("extern \"C\" __global__")[1]
+    r = _resources(src)
+    assert r[".vgpr_count"] <= 80 and r[".private_segment_fixed_size"] == 0 and r[".vgpr_spill_count"] == 0, r
+    rtc = C.CDLL("libhiprtc.so")
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-ffp-contract=off", b"-fno-fast-math", b"-fhip-fp32-correctly-rounded-divide-sqrt"]
+    prog = C.c_void_p()
+    assert rtc.hiprtcCreateProgram(C.byref(prog), src.encode(), b"k.hip", 0, None, None) == 0
+    assert rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts)) == 0
+    n = C.c_size_t(); rtc.hiprtcGetCodeSize(prog, C.byref(n)); code = C.create_string_buffer(n.value); rtc.hiprtcGetCode(prog, code)
+    with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
+        f.write(code.raw); f.flush()
+        asm = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", f.name], capture_output=True, text=True, check=True).stdout
+    assert "buffer_wbl2" not in asm and "buffer_inv" not in asm
+    sc1 = [ln for ln in asm.splitlines() if " sc1" in ln]
+    assert sum("global_store" in ln for ln in sc1) >= 12 and sum("global_load" in ln for ln in sc1) >= 12, len(sc1)

@@ -553,3 +553,136 @@ def test_ranks_out_of_step_are_refused_by_the_library(mode):
         assert res[r][0] == "ok" and res[r][1] is True, res[r]
         if mode == "frame": assert "GgrsHipError" in res[r][2] and "out of step" in res[r][2] and "frame" in res[r][2], res[r]
         else: assert "GgrsHipError" in res[r][2] and "disagree on the shape" in res[r][2], res[r]
+
+
+SHOT_SPAWN = """
+struct Shot { float x, y, vx, vy; };
+__device__ void ggrs_spawn(GgrsEntity& e, ggrs_u64 k, const GgrsFrame& f, const unsigned char* payload) {      // commands.spawn((Transform, Velocity, Ttl, Rollback))
+    const Shot* s = reinterpret_cast<const Shot*>(payload);                // this entity's record (payload_stride = 16)
+    e.f32(0) = s->x; e.f32(1) = s->y; e.f32(2) = s->vx; e.f32(3) = s->vy;
+    e.u64(4) = (ggrs_u64)f.iparam[0] + (k & 3ull) + (ggrs_u64)(f.frame & 1);
+}
+"""
+FIRE = 0x10
+
+
+def _shot_world(w, ttl):
+    """particles.rs' update + TTL-despawn systems (built in) and a USER-WRITTEN spawn system that builds each new entity from its own 16-byte record."""
+    import struct
+    import bevy_ggrs_amd as bg
+    import common as cm
+    from oracle.binding import OracleWorld
+    T, V, L = cm.build_particles(w)
+    binds = [(T, 0), (T, 1), (V, 0), (V, 1), (L, 0)]
+    if isinstance(w, OracleWorld):
+        def spawn(words, slot, k, f, payload):
+            x, y, vx, vy = struct.unpack("<4I", bytes(payload[:16]))
+            return [x, y, vx, vy, int(f.iparam[0]) + (k & 3) + (f.frame & 1)]
+        w.add_spawn_system(spawn, bundle=(T, V, L), bindings=binds, payload_stride=16, iparam=(ttl,))
+    else:
+        w.add_spawn_system(SHOT_SPAWN, bundle=(T, V, L), bindings=binds, payload_stride=16, iparam=(ttl,), name="fire")
+    return T, V, L
+
+
+def _shots(frame, fire):
+    import numpy as np
+    n = 5 if fire else 0
+    return n, np.random.default_rng([11, frame]).uniform(-50, 50, (n, 4)).astype(np.float32)
+
+
+def _branch_step_rank(q):
+    """ggrs_hip_fanout_step_branches through ctypes, no Python driver in between: a world with a USER-WRITTEN spawn system (a 16-byte payload record per new entity),
+    5 branches x 4 frames that fire in different frames, one shared spawn table; adoption of a branch that spawned; then the refusals."""
+    try:
+        import ctypes as C
+        import numpy as np
+        import bevy_ggrs_amd as bg
+        import common as cm
+        from bevy_ggrs_amd import _ffi
+        from bevy_ggrs_amd.fanout import RcclFanout
+        from oracle.binding import FLAT, OracleWorld
+        n, B, T = 3000, 5, 4
+        fires = np.array([[1, 0, 1, 0], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=bool)     # [branch][frame]: the player holds FIRE
+        out = {}
+        for name, w in (("gpu", bg.World(n + 200, max_depth=6)), ("oracle", OracleWorld(n + 200, 6, FLAT))):
+            ids = _shot_world(w, ttl=9)
+            vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+            cm.spawn_particles(w, ids, n, vel, ttl)
+            w.set_depth(6)
+            w.handle_requests([bg.AdvanceFrame((0,)), bg.AdvanceFrame((0,))])
+            w.set_confirmed(w.frame)
+            F = w.frame
+            shots = {i: _shots(F + i, True) for i in range(T)}                                                     # the payload of a firing frame: a function of the frame
+            if name == "oracle":
+                cs = w.handle_requests([bg.SaveGameState(F)])
+                for b in range(B):
+                    reqs = [bg.LoadGameState(F)]
+                    for i in range(T):
+                        a = bg.AdvanceFrame((FIRE if fires[b, i] else 0,))
+                        if fires[b, i]: a.spawn_count, a.spawn_payload = shots[i][0], shots[i][1]
+                        reqs += [a, bg.SaveGameState(F + 1 + i)]
+                    cs += w.handle_requests(reqs)
+                out[name] = cs
+                continue
+            native = RcclFanout(w, 0, 1, RcclFanout.unique_id())
+            lib, fp = _ffi.lib, native._p
+            pre, keep, _ = w.build_requests([bg.SaveGameState(F)])
+            table = (_ffi.BranchSpawn * T)()
+            pay = []
+            for i in range(T):
+                cnt, rec = shots[i]
+                rec = np.ascontiguousarray(rec); pay.append(rec)
+                table[i].count, table[i].payload, table[i].payload_bytes = cnt, rec.ctypes.data, rec.nbytes
+            inputs = np.zeros((B, T, 1), dtype=np.uint8); inputs[:, :, 0] = np.where(fires, FIRE, 0)
+            sel = np.where(fires, np.arange(1, T + 1, dtype=np.uint16)[None, :], 0).astype(np.uint16)
+            bs = _ffi.BranchStep()
+            bs.prefix, bs.n_prefix, bs.n_branches, bs.n_frames, bs.n_inputs, bs.flags = pre, 1, B, T, 1, _ffi.BRANCH_SAVE_LAST | _ffi.BRANCH_RETAIN_ALL
+            bs.inputs, bs.spawn_table, bs.n_spawn_table, bs.spawn_sel = inputs.ctypes.data, table, T, sel.ctypes.data
+            ns = C.c_uint32(0)
+            rc = lib.ggrs_hip_fanout_step_branches(fp, C.byref(bs), C.byref(ns))
+            assert rc == 0, lib.ggrs_hip_fanout_last_error(fp)
+            assert ns.value == 1 + B * T, ns.value
+            table_out = native.collect()
+            out[name] = [int(p[0]) | (int(p[1]) << 64) for p in table_out.reshape(-1, 2)]
+            assert w.frame == F and w.len == n                                                                    # speculation: the world did not move
+            # adopt the branch that fired in every frame, at its last frame; the world then holds its new entities
+            native.adopt(2, F + T)
+            assert w.frame == F + T and w.len == n + sum(shots[i][0] for i in range(T)), (w.frame, w.len)
+            out["adopted_save"] = w.save()
+            # ---- refusals: nothing of these may touch the world
+            pre2, keep2, _ = w.build_requests([bg.SaveGameState(w.frame)])                                       # the same shape as the agreed one: 1 + B x T SaveGameStates
+            def refuse(**kw):
+                b2 = _ffi.BranchStep(); C.memmove(C.byref(b2), C.byref(bs), C.sizeof(bs))
+                b2.prefix = pre2
+                for k, v in kw.items(): setattr(b2, k, v)
+                rc = lib.ggrs_hip_fanout_step_branches(fp, C.byref(b2), None)
+                return rc, (lib.ggrs_hip_fanout_last_error(fp) or b"").decode()
+            bad_sel = sel.copy(); bad_sel[1, 1] = T + 3
+            errs = [refuse(flags=64 | _ffi.BRANCH_SAVE_LAST | _ffi.BRANCH_RETAIN_ALL), refuse(n_frames=40), refuse(spawn_sel=bad_sel.ctypes.data), refuse(n_branches=0)]
+            out["errs"] = [(rc, msg[:200]) for rc, msg in errs]
+            out["after_refusals"] = (w.frame, w.len, w.save())
+            native.close()
+        q.put(("ok", out))
+    except Exception as e:                                    # noqa: BLE001
+        import traceback
+        q.put(("error", f"{type(e).__name__}: {e}", traceback.format_exc()))
+
+
+def test_branch_step_with_a_user_written_spawner_through_the_c_abi():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_branch_step_rank, args=(q,)); p.start()
+    try: r = q.get(timeout=600)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive(): p.kill()
+    assert r[0] == "ok", r
+    out = r[1]
+    assert out["gpu"] == out["oracle"], "the branch step's checksums differ from the oracle's request lists"
+    assert out["adopted_save"] == out["oracle"][1 + 2 * 4 + 3]                                   # branch 2's last SaveGameState
+    assert len(set(out["gpu"][1 + b * 4 + 3] for b in range(5))) == 5                            # five different futures
+    e = out["errs"]
+    assert all(rc == bg.GGRS_E_INVALID for rc, _ in e), e
+    assert "flags" in e[0][1] and "spawn_sel" in e[2][1] and "branches" in e[3][1], e
+    assert out["after_refusals"][2] == out["adopted_save"], "a refused branch step moved the world"
