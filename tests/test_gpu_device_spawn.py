@@ -132,3 +132,68 @@ def test_children_beyond_the_capacity_are_reported():
     with pytest.raises(bg.GgrsHipError) as e:
         for _ in range(12): drv.tick((0,))
     assert e.value.code == bg.GGRS_E_CAPACITY and "capacity" in str(e.value)
+
+
+# ---- fuzz: the number of children is a hash of the parent's slot and generation (0 .. maxk, so some parents call e.spawn(0) and leave none), a second component
+# outside the children's bundle, host-side spawns / despawns between ticks, random check distances
+FUZZ_SPLIT_SRC = r"""
+__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) {
+    e.f32(0) = e.f32(0) + e.f32(1) * f.dt;
+    if (e.u32(2) > 0u) e.u32(2) -= 1u;
+    if (e.u32(2) == 0u) {
+        if (e.u32(3) < (unsigned)f.iparam[0]) e.spawn((int)((((unsigned)e.slot * 2654435761u) >> 27) + e.u32(3) * 3u) % ((unsigned)f.iparam[1] + 1u));
+        e.despawn();
+    }
+}
+"""
+
+
+def fuzz_oracle_split(words, slot, f):
+    x, v, fuse, gen = unbits(words[0]), unbits(words[1]), words[2] & 0xFFFFFFFF, words[3] & 0xFFFFFFFF
+    x = f32(x + f32(v * f32(f.dt)))
+    if fuse > 0: fuse -= 1
+    kill, ns = 0, 0
+    if fuse == 0:
+        if gen < f.iparam[0]: ns = ((((slot * 2654435761) & 0xFFFFFFFF) >> 27) + gen * 3) % (f.iparam[1] + 1)
+        kill = 1
+    return [bits(x), words[1], fuse, gen], kill, ns
+
+
+@pytest.mark.parametrize("seed", [9001, 9002, 9003, 9004, 9005, 9006])
+def test_device_spawns_fuzzed(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([500, 5000, 30_000])); cd = int(rng.integers(2, 6)); ticks = cd + 6 + int(rng.integers(0, 7))
+    max_gen, maxk = int(rng.integers(1, 3)), int(rng.integers(1, 5))
+    cap = n * (1 + maxk + (maxk * maxk if max_gen > 1 else 0)) + 512
+    fuse = (2 + rng.integers(0, ticks + cd, n)).astype(np.uint32)
+    x = rng.uniform(-50, 50, n).astype(np.float32).view(np.uint32); v = rng.uniform(-9, 9, n).astype(np.float32).view(np.uint32)
+    events = {int(t): (int(rng.integers(1, 20)), int(rng.integers(0, n))) for t in rng.choice(np.arange(cd + 2, ticks), size=2, replace=False)}
+    # tick -> (host spawns, host despawn of a slot), once the session rolls back every tick: the next tick's LoadGameState drops them again (a mutation outside the
+    # schedule is not part of any snapshot -- before that, SyncTest itself reports it as a MismatchedChecksum), but len, masks and the device-side len must follow
+    res = []
+    for w in (bg.World(cap, max_depth=cd + 2), OracleWorld(cap, cd + 2, FLAT)):
+        cell = w.register_component("Cell", 4, 4)
+        tag = w.register_component("Tag", 1, 1)                                 # NOT in the children's bundle: they must come out without it
+        w.checksum_component(cell, [0, 1, 2, 3]); w.checksum_component(tag, [0])
+        binds = [(cell, 0), (cell, 1), (cell, 2), (cell, 3)]
+        if isinstance(w, bg.World):
+            w.add_custom_system(FUZZ_SPLIT_SRC, binds, iparam=(max_gen, maxk), name="split")
+            w.add_spawn_system(CHILD_SRC, [cell], binds, payload_stride=PARENT, name="child")
+        else:
+            w.add_custom_system(fuzz_oracle_split, binds, iparam=(max_gen, maxk))
+            w.add_spawn_system(oracle_child, [cell], binds, payload_stride=PARENT)
+        w.spawn(n, {cell: [x, v, fuse, np.zeros(n, dtype=np.uint32)], tag: [(np.arange(n) % 7).astype(np.uint8)]})
+        drv = cm.SyncTestDriver(w, cd, max_prediction=cd + 1)
+        for t in range(ticks):
+            if t in events:
+                k, victim = events[t]
+                first = w.spawn(k, {cell: [np.full(k, bits(0.5), dtype=np.uint32), np.full(k, bits(1.25), dtype=np.uint32), np.full(k, 3 + t, dtype=np.uint32), np.zeros(k, dtype=np.uint32)],
+                                    tag: [np.full(k, 9, dtype=np.uint8)]})
+                assert first == w.len - k
+                w.despawn(victim)
+            drv.tick((0,))
+        res.append((list(drv.all_checksums), cm.snapshot_state(w, [cell, tag]), w.len))
+    assert res[0][2] == res[1][2], (res[0][2], res[1][2])
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], f"device spawns, seed {seed}")
+    assert res[0][2] > n                                                        # something split
