@@ -109,3 +109,18 @@ def test_alu_view_prices_a_launch_against_the_measured_ceiling():
     assert abs(v["achieved"] - 96e6 / 49.2e-6 / 1e9) < 1e-6 and v["peak"] == peak and abs(v["frac"] - v["achieved"] / peak) < 1e-12
     assert 0.5 < v["frac"] < 0.8
     assert b.alu_view(1.0, 0.0)["achieved"] == 0.0
+
+
+def test_latency_floor_reports_a_lower_bound_against_the_timed_tick_and_keeps_the_same_pass_check():
+    """Configs 2 / 4: the timing events slow the loop they ride on, so the same-pass fraction (consistent by construction) prices the instrumented loop; `frac` is the
+    bound against the UN-instrumented tick -- (fastest kernel + one boundary) / tick -- and a bound above 1 or a same-pass floor above its tick fails the line."""
+    import bench
+    lf = bench.latency_floor(6.7, 1.0, 7.77, same_pass=(6.7, 19.39), kernel_min_us=4.52)              # profiles/r06z, config 2 through the C loop
+    assert lf["frac_same_pass"] == [round(8.15 / 19.39, 3), round(8.6 / 19.39, 3)] and lf["consistent"]
+    assert lf["frac"] == lf["frac_timed_tick_lower_bound"] == round((4.52 + 1.45) / 7.77, 3) and "lower bound" in lf["frac_basis"]
+    assert lf["frac_mixed_passes"][0] > 1.0                                                            # the instrumented pass's MEAN kernel does not fit the timed tick: informational
+    assert abs(lf["instrumentation_us_per_tick"] - (19.39 - 7.77)) < 0.01
+    bad = bench.latency_floor(6.7, 1.0, 5.0, same_pass=(6.7, 19.39), kernel_min_us=4.52)              # a tick shorter than its fastest kernel + boundary
+    assert not bad["consistent"] and bench.floors_inconsistent({"latency_floor": bad})
+    plain = bench.latency_floor(6.7, 1.0, 10.0)                                                        # no same-pass figures: priced against the tick given
+    assert plain["frac"] == [round(8.15 / 10.0, 3), round(8.6 / 10.0, 3)] and "frac_same_pass" not in plain
