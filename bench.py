@@ -1308,6 +1308,12 @@ def main():
         print(json.dumps({"env": {}, "cmd": [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]}))
         return
 
+    # stdout carries ONE JSON line and nothing else.  Native libraries write there too -- RCCL prints a version banner through C stdio, which leaves its buffer at
+    # exit, i.e. AFTER the line (seen in profiles/r06o): from here on file descriptor 1 is stderr, and the line goes to the descriptor stdout was.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import __graft_entry__ as ge
     ge.build()
@@ -1357,7 +1363,7 @@ def main():
             line["extra_configs"] = extra
             parity_failed |= extra_failed
     if rank == 0:
-        print(json.dumps(line))
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
         if parity_failed:
             print("bench.py: PARITY FAILURE -- GPU checksums differ from the CPU oracle's (see \"parity\" of the line / of its extra_configs)", file=sys.stderr)
             sys.exit(1)

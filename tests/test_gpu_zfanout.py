@@ -415,8 +415,8 @@ def _bench_line(args, env=None, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
                        env={**os.environ, **(env or {})}, cwd=root)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]                   # stdout is the line and NOTHING else (no library banner before or after it)
+    assert r.returncode == 0 and len(lines) == 1 and lines[0].startswith("{"), (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     return json.loads(lines[0])
 
 
