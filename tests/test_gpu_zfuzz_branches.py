@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = list(range(7100, 7124))
+SEEDS = list(range(7100, 7136))
 
 
 def _fuzz_rank(q, seeds):
@@ -37,7 +37,7 @@ def _fuzz_rank(q, seeds):
             n_spawn = int(rng.integers(1, 40))
             steps = 3
             cap = n + n_spawn * (T + 2) * (steps + 2) + 64
-            what = dict(seed=seed, n=n, depth=depth, T=T, B=B, schema=schema, with_spawn=with_spawn, flags=flags)
+            what = dict(seed=seed, n=n, depth=depth, T=T, B=B, schema=schema, with_spawn=with_spawn, flags=flags, value_tags=bool(seed % 2))
 
             def payload(frame):                                      # a pure function of the frame: every branch that spawns in it draws the same entities
                 r = np.random.default_rng([seed, frame])
@@ -45,6 +45,8 @@ def _fuzz_rank(q, seeds):
 
             ttl_init = int(rng.integers(2, 30))
             gw, ow = bg.World(cap, max_depth=depth + 2), OracleWorld(cap, depth + 2, FLAT)
+            if seed % 2:                                             # value tags forced on (by default only worlds whose Save is bound by bytes keep them), lazy live block forced
+                assert lib.ggrs_dbg_set_value_tags(gw._p, 1) == 0 and lib.ggrs_dbg_set_lazy_live(gw._p, 2 if seed % 4 == 1 else 1) == 0
             ids = None
             for w in (gw, ow):
                 ids = cm.build_particles(w, with_spawn=with_spawn, ttl_init=ttl_init, schema=schema)
