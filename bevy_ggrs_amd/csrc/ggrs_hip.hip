@@ -232,6 +232,7 @@ int ggrs_hip_add_custom_system(ggrs_world* w, const ggrs_custom_system_desc* d) 
     }
     DeviceGuard dg(w);
     c.source = d->source;
+    c.may_defer = source_has_token(c.source, "despawn_rollback") || source_has_token(c.source, "kill");
     const std::string src = custom_source(w, c, d->source);
     const std::string what = "custom system '" + c.name + "'";
     const int rc = hiprtc_build(w, src, what.c_str(), "ggrs_custom_kernel", w->layout_only ? nullptr : &c.mod, &c.fn);

@@ -683,7 +683,7 @@ int spec_blocks_reserve(ggrs_world* w, size_t n) {
 int validate_branch_step(ggrs_world* w, const ggrs_branch_step& st) {
     if (!w->gen_ok) return w->fail(GGRS_E_INVALID, "branch steps need the generated request-group kernel, which this world does not have: %s", w->jit_status.c_str());
     if (w->dev_spawn) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds whose systems spawn on the device (every launch is one cooperative grid): use ggrs_hip_fanout_step");
-    if (w->jit_marks || w->has_nr || w->marks_possible) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds with live-only state (RollbackDespawned markers, non-rollback components): use ggrs_hip_fanout_step");
+    if (w->jit_marks || w->has_nr || w->marks_possible) return w->fail(GGRS_E_INVALID, "branch steps are not available for worlds with live-only state (RollbackDespawned markers -- a system that can call despawn_rollback() --, non-rollback components): use ggrs_hip_fanout_step");
     if (st.n_branches == 0 || st.n_branches > BRANCH_MAX) return w->fail(GGRS_E_INVALID, "a branch step holds 1..%u branches, not %u", BRANCH_MAX, st.n_branches);
     const uint32_t S = (st.flags & GGRS_BRANCH_SAVE_LAST) ? st.n_frames : st.n_frames - 1;
     if (st.n_frames == 0 || st.n_frames > w->cap_steps || S > w->cap_saves) return w->fail(GGRS_E_INVALID, "a branch covers 1..%u frames (%u SaveGameStates) in this world, not %u", w->cap_steps, w->cap_saves, st.n_frames);

@@ -404,9 +404,9 @@ int launch_custom(ggrs_world* w, const ggrs_system_desc& s, uint32_t dt_bits, co
         const uint32_t col = w->comps[c.comp[i]].col_base + c.word[i];
         a.col_off[i] = w->col_off[col]; a.ts[i] = w->col_ts[col];
     }
-    // despawn_rollback (despawn.rs:129-142): only an unconfirmed frame defers the despawn.  Whether the source calls it is
-    // not known to the host, so the markers are assumed possible whenever deferral is on.
-    a.defer = (w->confirmed < w->frame) ? 1 : 0;
+    // despawn_rollback (despawn.rs:129-142): only an unconfirmed frame defers the despawn.  Whether the source REACHES the call is
+    // not known to the host, so the markers are assumed possible whenever deferral is on and the source names it (Custom::may_defer).
+    a.defer = (w->confirmed < w->frame && c.may_defer) ? 1 : 0;
     if (a.defer) w->marks_possible = true;
     memcpy(&a.fr.dt, &dt_bits, 4);
     a.fr.frame = w->frame;

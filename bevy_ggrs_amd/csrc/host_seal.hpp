@@ -137,7 +137,7 @@ int seal_impl(ggrs_world* w) {
             for (size_t i = 0; i < w->systems.size(); ++i) {
                 const ggrs_system_desc& d = w->systems[i];
                 w->jit_reads_inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
-                w->jit_marks |= d.kind == GGRS_SYS_CUSTOM || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
+                w->jit_marks |= (d.kind == GGRS_SYS_CUSTOM && w->customs[d.comp[0]].may_defer) || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
                 if (d.kind == GGRS_SYS_BOX_MOVE) w->jit_box_sys = (int)i;
             }
             w->gen_ok = true;

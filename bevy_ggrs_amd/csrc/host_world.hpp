@@ -126,6 +126,15 @@ struct HostTimeline {
 };
 inline double tl_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Does `src` contain `tok` as a whole identifier?  (Used to decide whether a user-written system can defer a despawn: GgrsEntity::despawn_rollback() is the only
+// way to do so besides writing the `kill` field itself.  Comments count -- a false positive costs speed, never correctness.)
+inline bool source_has_token(const std::string& src, const char* tok) {
+    const size_t n = strlen(tok);
+    auto idc = [](char c) { return isalnum((unsigned char)c) || c == '_'; };
+    for (size_t p = src.find(tok); p != std::string::npos; p = src.find(tok, p + 1))
+        if ((p == 0 || !idc(src[p - 1])) && (p + n >= src.size() || !idc(src[p + n]))) return true;
+    return false;
+}
 struct ggrs_world {
     // ---- configuration
     int device = 0;
@@ -138,6 +147,7 @@ struct ggrs_world {
     std::vector<ggrs_system_desc> systems;
     struct Custom {                      // GGRS_SYS_CUSTOM: a hiprtc-compiled per-entity system (systems[i].comp[0] indexes this)
         std::string name, source;
+        bool may_defer = true;           // the source names despawn_rollback() or the `kill` field: it can leave RollbackDespawned markers (source_has_token)
         hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
         uint32_t n_bind = 0, comp[GGRS_CUSTOM_MAX_BINDINGS] = {}, word[GGRS_CUSTOM_MAX_BINDINGS] = {};
         uint32_t n_pres = 0, pres_comp[GGRS_CUSTOM_MAX_BINDINGS] = {};

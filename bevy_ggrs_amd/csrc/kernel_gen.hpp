@@ -470,7 +470,7 @@ JitNeeds jit_needs(const ggrs_world* w) {
     n.spawn = jit_fused_spawn_system(w) >= 0;
     for (auto& d : w->systems) {
         n.inputs |= d.kind == GGRS_SYS_CUSTOM || d.kind == GGRS_SYS_BOX_MOVE || d.kind == GGRS_SYS_SPAWN_CUSTOM;
-        n.marks |= d.kind == GGRS_SYS_CUSTOM || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
+        n.marks |= (d.kind == GGRS_SYS_CUSTOM && w->customs[d.comp[0]].may_defer) || (d.kind == GGRS_SYS_SAT_SUB_DESPAWN && d.iparam[1] == GGRS_DESPAWN_ROLLBACK);
         n.box |= d.kind == GGRS_SYS_BOX_MOVE;
     }
     return n;
@@ -1046,7 +1046,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
                           "                }\n";
             for (uint32_t b = 0; b < c.n_bind; ++b)
                 sfmt(s, "                w%u_0 = (%s)(%s)ent.w[%u];\n", col(c.comp[b], c.word[b]), wtype(c.comp[b]), mtype(c.comp[b]), b);   // narrow words wrap as their memory type does
-            s += "                if (ent.kill) { if (ent.kill == 2 && defer) { dis_0 = true; df_0 = a.step_frame[sj]; } alive_0 = false; }\n"
+            if (marks) s += "                if (ent.kill) { if (ent.kill == 2 && defer) { dis_0 = true; df_0 = a.step_frame[sj]; } alive_0 = false; }\n";
+            else       s += "                if (ent.kill) alive_0 = false;                            // (no system of this world can defer a despawn: its sources name neither despawn_rollback() nor `kill`)\n";
+            s += ""
                  "            }\n";
         } break;
         default: break;

@@ -173,7 +173,9 @@ int ggrs_hip_add_system(ggrs_world* w, const ggrs_system_desc* desc);
  *   e.f32(i) / e.u32(i) / e.i32(i) / e.u64(i)   reference to bound word i  (binding i = word `word[i]` of component `comp[i]`;
  *                                               4-byte words as f32/u32/i32, 8-byte words as u64), written back afterwards
  *   e.slot                                      the entity's RollbackOrdered index (snapshot/rollback.rs:69-74)
- *   e.despawn() / e.despawn_rollback()          commands.entity(e).despawn() / .despawn_rollback() (snapshot/despawn.rs:114-143)
+ *   e.despawn() / e.despawn_rollback()          commands.entity(e).despawn() / .despawn_rollback() (snapshot/despawn.rs:114-143).  A world in which some system's
+ *                                               source names despawn_rollback (or the `kill` field) can hold RollbackDespawned markers -- live-only state --: it
+ *                                               keeps its live block written every tick and is closed to ggrs_hip_fanout_step_branches; other worlds are not
  *   e.spawn(n)                                  commands.spawn((.., Rollback)) x n, decided HERE, on the device: see GGRS_SPAWN_PAYLOAD_PARENT below
  *   f.dt  f.frame  f.n_inputs                   Time<GgrsTime>::delta_secs (time.rs), the frame being simulated, PlayerInputs::len()
  *   f.input[h]                                  first byte of player h's input (the whole input of a Config<Input = u8> session)
@@ -471,7 +473,8 @@ int  ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int
  * GGRS_BRANCH_RETAIN_ALL keeps every frame a branch produces -- each SaveGameState's snapshot and, without GGRS_BRANCH_SAVE_LAST, the state after the last AdvanceFrame --
  * in private packed state blocks outside the ring (state_bytes each, allocated on first use, owned by the world); GGRS_BRANCH_RETAIN_NEWEST only the last frame (F + n_frames).
  * Row versions apply: a column no system writes reaches a branch block once.  They stay valid until the next step of this fan-out.
- * Needs the generated kernel and a world without live-only state (RollbackDespawned markers, GGRS_COMP_NO_ROLLBACK components): GGRS_E_INVALID otherwise.
+ * Needs the generated kernel and a world without live-only state (RollbackDespawned markers: a system that can call despawn_rollback(), or a host-issued
+ * ggrs_hip_despawn_rollback on an unconfirmed frame; GGRS_COMP_NO_ROLLBACK components): GGRS_E_INVALID otherwise.
  *
  * ggrs_hip_fanout_adopt: the true inputs of frames F .. frame-1 have arrived and equal what `branch` (GLOBAL index: rank x n_branches + local index of the LAST step)
  * predicted: that branch's retained state of `frame` becomes the world -- RollbackFrameCount = ConfirmedFrameCount = frame, a snapshot of `frame` in the ring, the live

@@ -590,7 +590,7 @@ def _shots(frame, fire):
     return n, np.random.default_rng([11, frame]).uniform(-50, 50, (n, 4)).astype(np.float32)
 
 
-def _branch_step_rank(q):
+def _branch_step_rank(q, kind="shots"):
     """ggrs_hip_fanout_step_branches through ctypes, no Python driver in between: a world with a USER-WRITTEN spawn system (a 16-byte payload record per new entity),
     5 branches x 4 frames that fire in different frames, one shared spawn table; adoption of a branch that spawned; then the refusals."""
     try:
@@ -605,9 +605,18 @@ def _branch_step_rank(q):
         fires = np.array([[1, 0, 1, 0], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=bool)     # [branch][frame]: the player holds FIRE
         out = {}
         for name, w in (("gpu", bg.World(n + 200, max_depth=6)), ("oracle", OracleWorld(n + 200, 6, FLAT))):
-            ids = _shot_world(w, ttl=9)
-            vel, ttl = cm.synthetic_particles(n, ttl="despawn")
-            cm.spawn_particles(w, ids, n, vel, ttl)
+            if kind == "shots":
+                ids = _shot_world(w, ttl=9)
+                vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+                cm.spawn_particles(w, ids, n, vel, ttl)
+            else:
+                # the bullets world of test_gpu_round5: a USER-WRITTEN system (moves, counts a life down, despawns) next to the user-written spawner.  Its source names
+                # neither despawn_rollback() nor `kill`, so it can leave no RollbackDespawned marker and the world is open to branch steps
+                import test_gpu_round5 as r5
+                P, V, L, K = r5._bullet_world(w, life=9)
+                rng = np.random.default_rng(3)
+                pos = rng.uniform(-10, 10, (n, 2)).astype(np.float32); vel = rng.uniform(-5, 5, (n, 2)).astype(np.float32)
+                w.spawn(n, {P: [cm.f32bits(pos[:, 0]), cm.f32bits(pos[:, 1])], V: [cm.f32bits(vel[:, 0]), cm.f32bits(vel[:, 1])], L: [(2 + np.arange(n) % 23).astype(np.uint32)], K: [(np.arange(n) % 5).astype(np.uint8)]})
             w.set_depth(6)
             w.handle_requests([bg.AdvanceFrame((0,)), bg.AdvanceFrame((0,))])
             w.set_confirmed(w.frame)
@@ -668,11 +677,12 @@ def _branch_step_rank(q):
         q.put(("error", f"{type(e).__name__}: {e}", traceback.format_exc()))
 
 
-def test_branch_step_with_a_user_written_spawner_through_the_c_abi():
+@pytest.mark.parametrize("kind", ["shots", "bullets"])
+def test_branch_step_with_a_user_written_spawner_through_the_c_abi(kind):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_branch_step_rank, args=(q,)); p.start()
+    p = ctx.Process(target=_branch_step_rank, args=(q, kind)); p.start()
     try: r = q.get(timeout=600)
     finally:
         p.join(timeout=30)
