@@ -545,7 +545,11 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         bytes_slot += rows_bytes_per_slot(w, j.load_rows, !j.src_is_live);
         j.src = gs.src->ptr; j.live = w->live.ptr; j.len = len_start;
         if (w->dev_spawn) {
-            j.sp_sums = reinterpret_cast<ggrs_u64*>(w->d_sp_sums); j.sp_epoch = w->sp_epoch; w->sp_epoch += 2u * MAX_TICK_STEPS + 2u; j.sp_prec = w->d_sp_prec; j.sp_link = reinterpret_cast<ggrs_u64*>(w->d_sp_link);
+            if (w->sp_epoch > 0xF0000000u) {         // epochs never repeat: long before the 32-bit counter wraps (~65 M launches) the mailboxes start over, in stream order
+                HIPCHK(w, hipMemsetAsync(w->d_sp_sums, 0, (3 * (size_t)w->sp_tiles + 32) * 8, w->stream)); w->sp_epoch = 0;
+            }
+            j.sp_sums = reinterpret_cast<ggrs_u64*>(w->d_sp_sums); j.sp_epoch = w->sp_epoch; w->sp_epoch += 2u * MAX_TICK_STEPS + 2u;
+            j.sp_prec = w->d_sp_prec; j.sp_link = reinterpret_cast<ggrs_u64*>(w->d_sp_link);
             j.sp_len = reinterpret_cast<ggrs_u64*>(w->d_sp_len); j.sp_cap = w->capacity; j.sp_tiles = w->sp_tiles;
         }
         j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;

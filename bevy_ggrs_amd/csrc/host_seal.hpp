@@ -256,7 +256,8 @@ int seal_impl(ggrs_world* w) {
             return w->fail(GGRS_E_CAPACITY, "a world whose systems spawn on the device runs as ONE resident launch: %u workgroups are needed for %llu slots, the device holds %llu of this kernel (at most %llu slots)",
                            grid, (unsigned long long)w->capacity, (unsigned long long)max_wgs, (unsigned long long)(max_wgs / 8 * 8 * 256));
         HIPCHK(w, hipMalloc((void**)&w->d_sp_sums, (3 * (size_t)w->sp_tiles + 32) * 8));                 // the mailbox words {epoch, value}: counts, prefixes, done per tile; total; go
-        HIPCHK(w, hipMemsetAsync(w->d_sp_sums, 0, (3 * (size_t)w->sp_tiles + 32) * 8, w->stream)); w->sp_epoch = 0;
+        HIPCHK(w, hipMemsetAsync(w->d_sp_sums, 0, (3 * (size_t)w->sp_tiles + 32) * 8, w->stream));
+        w->sp_epoch = 0xF0000000u - 8u * (2u * MAX_TICK_STEPS + 2u) + 1u;      // (like jiffies: every world crosses the epochs' start-over on its 9th launch, so that path is run by every test and session)
         HIPCHK(w, hipMalloc((void**)&w->d_sp_prec, (size_t)w->cap_pad * 64));
         HIPCHK(w, hipMalloc((void**)&w->d_sp_link, (size_t)w->cap_pad * 16));
         HIPCHK(w, hipHostMalloc((void**)&w->h_sp_len, (2 + MAX_TICK_SAVES) * 8, hipHostMallocMapped));

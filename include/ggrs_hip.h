@@ -254,7 +254,8 @@ int ggrs_hip_set_input_layout(ggrs_world* w, uint32_t input_bytes, uint32_t max_
  * ggrs_request::spawn_count and its payload fields are ignored for such a world.  RollbackOrdered::len then lives on the device: ggrs_hip_len and every entry point that
  * needs it waits for the world's stream first; children beyond the world's capacity are dropped and reported (GGRS_E_CAPACITY at the next collect / blocking call).
  * Every launch of such a world covers its whole capacity and is a COOPERATIVE launch (all workgroups resident: grid barriers inside), which bounds the capacity by what
- * the device holds of the world's kernel (GGRS_E_CAPACITY at seal beyond: 2048 workgroups = 524 288 slots at 8 waves per SIMD); no depth-parallel roles, no branch steps. */
+ * the device holds of the world's kernel (GGRS_E_CAPACITY at seal beyond: 256 slots per workgroup x the workgroups resident per CU -- bounded by the kernel's VGPRs and SGPRs, 6 for the
+ * splitting-cells world of the tests = 393 216 slots -- x 256 CUs); no depth-parallel roles, no branch steps. */
 #define GGRS_SPAWN_PAYLOAD_PARENT 0xFFFFFFFFu
 typedef struct {
     const char* name;                               /* for error messages and traces; may be NULL                                  */

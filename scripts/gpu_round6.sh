@@ -29,6 +29,7 @@ for n in 100000 300000 600000 2000000 3000000; do $B --entities $n --no-cpu-base
 $B --entities 4000000 --cpu-ticks 1 2>> $OUT/bench.err | J > $OUT/bench_4000000.json
 BENCH_VALUE_TAGS=0 $B --entities 4000000 --no-cpu-baseline 2>> $OUT/bench.err | J > $OUT/bench_4000000_no_value_tags.json
 $B --schema allhot --entities 2000000 --no-cpu-baseline 2>> $OUT/bench.err | J > $OUT/bench_allhot_2000000.json
+$B --entities 16000000 --steps 30 --warmup 20 --no-cpu-baseline --no-extra --no-traffic 2>> $OUT/bench.err | J > $OUT/bench_16000000.json
 $B --config 2 2>> $OUT/bench.err | J > $OUT/bench_config2.json
 $B --config 4 2>> $OUT/bench.err | J > $OUT/bench_config4.json
 $B --config 5 --steps 20 --warmup 3 2>> $OUT/bench.err | J > $OUT/bench_config5_1gpu.json
@@ -38,7 +39,7 @@ $B --config 5 --steps 20 --warmup 3 --retain newest 2>> $OUT/bench.err | J > $OU
 $B --config 5 --spawn --steps 8 --warmup 2 --preheat-ms 0 2>> $OUT/bench.err | J > $OUT/bench_config5_1gpu_spawn.json
 $B --config 5 --spawn --steps 8 --warmup 2 --preheat-ms 0 --retain all 2>> $OUT/bench.err | J > $OUT/bench_config5_1gpu_spawn_retain_all.json
 python scripts/spawn_session_bench.py > $OUT/spawn_session.txt 2>&1
-timeout 300 python scripts/device_spawn_bench.py 70000 120000 > $OUT/device_spawn_session.txt 2>&1
+timeout 300 python scripts/device_spawn_bench.py 70000 95000 > $OUT/device_spawn_session.txt 2>&1
 g++ -shared -fPIC -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/rccl_double.cpp -o tests/cpp/_build/librccl_double.so -L/opt/rocm/lib -lamdhip64 -lrt 2>> $OUT/bench.err
 GGRS_RCCL_LIB=$PWD/tests/cpp/_build/librccl_double.so $B --gpus 2 --oversubscribe --steps 20 --warmup 5 2>> $OUT/bench.err | J > $OUT/bench_gpus2_oversubscribed.json; echo "bench --gpus 2 rc=$?"
 timeout 600 python scripts/adopt_ab.py 100000 7 > $OUT/adopt_ab_100k.json 2>> $OUT/bench.err
