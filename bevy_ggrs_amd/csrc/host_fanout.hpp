@@ -110,6 +110,19 @@ int fanout_agree_shape(ggrs_fanout* f, uint32_t saves) {
     f->shape_agreed = true; f->agreed_saves = saves;
     return GGRS_OK;
 }
+// One status word per rank, seen by all (blocking; through the buffers of the empty slot): a collective that only SOME ranks can take part in -- the broadcast of
+// an adopted block, whose owner alone knows whether it kept that frame -- is entered by all of them or by none.  *bad_rank: the first rank whose status is not 0.
+int fanout_agree_status(ggrs_fanout* f, int status, int* bad_rank, int* bad_status) {
+    ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
+    s.h_tags[0] = (uint64_t)(int64_t)status;
+    FANCHK_HIP(f, hipMemcpyAsync(s.d_send, s.h_tags, 8, hipMemcpyHostToDevice, f->comm_stream));
+    FANCHK_NCCL(f, rccl().AllGather(s.d_send, s.d_recv, 1, ncclUint64, f->comm, f->comm_stream));
+    FANCHK_HIP(f, hipMemcpyAsync(s.h_recv, s.d_recv, (size_t)8 * f->size, hipMemcpyDeviceToHost, f->comm_stream));
+    FANCHK_HIP(f, hipStreamSynchronize(f->comm_stream));
+    *bad_rank = -1; *bad_status = 0;
+    for (int r = 0; r < f->size; ++r) if (s.h_recv[r] != 0) { *bad_rank = r; *bad_status = (int)(int64_t)s.h_recv[r]; break; }
+    return GGRS_OK;
+}
 // closes the slot being filled: ONE all-gather of the agreed size -- interval x agreed_saves checksums + interval tags per rank, zero beyond the steps the
 // group really holds --, then device -> pinned, on the side stream
 int fanout_close_slot(ggrs_fanout* f) {
@@ -303,15 +316,24 @@ int ggrs_hip_fanout_adopt(ggrs_fanout* f, uint32_t branch, int32_t frame, uint32
     const bool mine = owner == f->rank;
     const int32_t F = w->frame;                                        // where the last step's prefix left every rank
     // ---- the owner: its retained block trades places with the ring slot a SaveGameState(frame) would have filled
-    int spec_idx = -1;
+    int spec_idx = -1, pre = GGRS_OK;
     if (mine) {
         const BranchKeep& k = f->keep;
         const int64_t o = (int64_t)frame - (int64_t)k.base_frame - 1;
         if (!k.valid || k.base_frame != F || o < 0 || o >= (int64_t)k.n_out || local >= k.n_branches || k.blk[(size_t)local * k.n_out + (size_t)o] < 0)
-            return f->fail(GGRS_E_NO_SNAPSHOT, "branch %u holds no retained state of frame %d (the last branch step started at frame %d and %s)", branch, frame, k.base_frame,
-                           k.valid ? "kept other frames: GGRS_BRANCH_RETAIN_ALL keeps every one" : "kept none: GGRS_BRANCH_RETAIN_*");
-        spec_idx = k.blk[(size_t)local * k.n_out + (size_t)o];
+            pre = f->fail(GGRS_E_NO_SNAPSHOT, "branch %u holds no retained state of frame %d (the last branch step started at frame %d and %s)", branch, frame, k.base_frame,
+                          k.valid ? "kept other frames: GGRS_BRANCH_RETAIN_ALL keeps every one" : "kept none: GGRS_BRANCH_RETAIN_*");
+        else spec_idx = k.blk[(size_t)local * k.n_out + (size_t)o];
     }
+    if (mode == GGRS_ADOPT_BROADCAST && f->size > 1) {
+        // only the owner knows whether it kept that frame; the broadcast below is entered by every rank or by none (a rank that bailed out alone would leave the
+        // others waiting in the collective for ever)
+        const std::string mine_err = f->err;
+        int bad_rank = -1, bad_status = 0;
+        const int arc = fanout_agree_status(f, pre, &bad_rank, &bad_status); if (arc) return arc;
+        if (pre) { f->err = mine_err; return pre; }
+        if (bad_rank >= 0) return f->fail(bad_status, "rank %d cannot hand over branch %u at frame %d (its error %d): no rank adopted anything", bad_rank, branch, frame, bad_status);
+    } else if (pre) return pre;
     if (mine || mode == GGRS_ADOPT_BROADCAST) {
         // RollbackFrameCount = frame; discard_old_snapshots + GgrsSnapshots::push(frame) (mod.rs:147-202) over slot indices -- the slot's block is then the branch's
         w->frame = frame; w->has_confirmed = true; w->confirmed = frame;

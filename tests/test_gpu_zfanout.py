@@ -105,6 +105,29 @@ def _native_fanout_rank(rank, size, id_q, n, D, steps, bpr, q, scenario="walk", 
             native.close()
             q.put((rank, "ok", seen, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in state.items()}))
             return
+        if scenario == "adopt_refused":
+            # GGRS_ADOPT_BROADCAST of a frame the owner did NOT keep (newest-only retention, an older frame asked for): only the owner can know -- every rank must come
+            # back with the error (nobody may be left waiting in the broadcast), nothing is adopted anywhere, and the next, valid adoption works
+            import fanout_scenarios as fs
+            from bevy_ggrs_amd import _ffi
+            fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, branch_input=fs.branch_input, confirmed_input=fs.true_input,
+                                    spawn_fn=cm.frame_spawn_fn(fs.RATE), retain="newest")
+            fan.step(); fan.drain()
+            C = fan.confirmed
+            before = (w.frame, w.len)
+            errs = []
+            for owner_branch in (0, bpr):                                        # a branch of rank 0, then one of rank 1
+                try:
+                    native.adopt(owner_branch, C + 1, None, _ffi.ADOPT_BROADCAST)
+                    errs.append(None)
+                except bg.GgrsHipError as e:
+                    errs.append((e.code, str(e)[:160]))
+            assert (w.frame, w.len) == before, ((w.frame, w.len), before)
+            native.adopt(bpr, C + D, None, _ffi.ADOPT_BROADCAST)                   # the newest frame of rank 1's first branch IS kept
+            after = (w.frame, w.save())
+            native.close()
+            q.put((rank, "ok", errs, after))
+            return
         fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=bpr, native=native, max_inflight=2,
                                 branch_input=lambda b, f: cm.INPUT_SPAWN if b % 2 == 0 else 0,
                                 confirmed_input=lambda f: cm.INPUT_SPAWN if f % 2 == 1 else 0,
@@ -329,6 +352,17 @@ def test_adopt_ranks_over_the_transport_double(size, bpr, broadcast_every):
     n, D, steps = 600, 5, 8
     res = _run_native(size, n, D, steps, bpr, env={"GGRS_RCCL_LIB": _double_lib()}, scenario="adopt", opt={"broadcast_every": broadcast_every})
     _check_adopt(res, size, n, D, steps, bpr)
+
+
+def test_broadcast_adoption_is_refused_on_every_rank_when_the_owner_kept_no_such_frame():
+    res = _run_native(2, 600, 4, 1, 2, env={"GGRS_RCCL_LIB": _double_lib()}, scenario="adopt_refused")
+    assert all(res[r][0] == "ok" for r in (0, 1)), res
+    e0, e1 = res[0][1], res[1][1]
+    # branch 0 lives on rank 0: rank 0 reports what it lacks, rank 1 that rank 0 could not hand it over; and the other way round for branch 2
+    assert e0[0] and e0[0][0] == bg.GGRS_E_NO_SNAPSHOT and "holds no retained state" in e0[0][1], e0
+    assert e1[0] and e1[0][0] == bg.GGRS_E_NO_SNAPSHOT and "rank 0 cannot hand over" in e1[0][1], e1
+    assert e1[1] and "holds no retained state" in e1[1][1] and e0[1] and "rank 1 cannot hand over" in e0[1][1], (e0, e1)
+    assert res[0][2] == res[1][2], "the ranks differ after the valid adoption that followed"
 
 
 def _double_lib():
