@@ -485,7 +485,10 @@ int  ggrs_hip_fanout_comm_info(ggrs_fanout* f, int* rank_out, int* size_out, int
  *                           SaveGameState(frame), typically [AdvanceFrame x (frame - F), SaveGameState(frame)] -- runs through the ordinary path: no bytes cross xGMI, and
  *                           its Checksum(u128)s (checksums_out, {lo, hi} per SaveGameState of replay; *n_checksums_out = 0 on the owner) can be compared with the
  *                           branch's gathered ones: a free desync check.  GGRS_ADOPT_BROADCAST: ONE ncclBroadcast of the owner's packed block (state_bytes) into a ring
- *                           slot of every other rank, for worlds whose re-simulation costs more than the block's trip over one xGMI link (replay is ignored). */
+ *                           slot of every other rank, for worlds whose re-simulation costs more than the block's trip over one xGMI link (replay is ignored).
+ * Errors: GGRS_E_NO_SNAPSHOT when the owner did not keep that frame (GGRS_BRANCH_RETAIN_*).  Only the owner can know: with GGRS_ADOPT_BROADCAST the ranks exchange one
+ * status word first, so EVERY rank returns the error and none waits in the broadcast; with GGRS_ADOPT_RECOMPUTE there is no collective inside the call -- the owner
+ * returns the error, the other ranks have re-simulated (they hold the right state; the owner's caller re-simulates too). */
 typedef struct {
     uint64_t count;                  /* entities the spawn system appends                                                  */
     const float* vx;                 /* GGRS_SYS_PARTICLES_SPAWN: count f32 each (as ggrs_request::spawn_vx / _vy)         */
