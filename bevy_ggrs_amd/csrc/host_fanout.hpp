@@ -260,6 +260,21 @@ int ggrs_hip_fanout_sync_confirmed(ggrs_fanout* f, int root) {
     return GGRS_OK;
 }
 
+// A step this rank REFUSES after the fan-out's shape was agreed still takes part in the group's all-gather: its place carries the tag {~0, error code} and the group is
+// closed at once (a partial group is padded to the agreed size), so that the other ranks -- whose steps went through -- find "rank r refused step k" in their collect
+// instead of waiting in the collective for a rank that has stopped calling.  Returns the error the step is refused with.
+static int fanout_refuse_step(ggrs_fanout* f, int code) {
+    if (!f->shape_agreed || f->size == 1) return code;
+    const std::string why = f->err;
+    ggrs_fanout::Slot& s = f->slot[f->tail % FANOUT_MAX_INFLIGHT];
+    s.n_saves = f->agreed_saves;
+    s.first[s.n_steps] = 0;
+    s.h_tags[2 * s.n_steps] = ~0ull; s.h_tags[2 * s.n_steps + 1] = (uint64_t)(int64_t)code;
+    ++s.n_steps;
+    (void)fanout_close_slot(f);
+    f->err = why;
+    return code;
+}
 static int fanout_step_impl(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n, const ggrs_branch_step* bs, uint32_t* n_saves_out) {
     if (!f || !f->w || (!reqs && n)) return GGRS_E_INVALID;
     ggrs_world* w = f->w;
@@ -277,14 +292,14 @@ static int fanout_step_impl(ggrs_fanout* f, const ggrs_request* reqs, uint32_t n
     }
     f->keep.valid = false;                                              // whatever an earlier step retained is about to be overwritten (or is history)
     if (!f->shape_agreed) { const int arc = fanout_agree_shape(f, want); if (arc) return arc; }
-    if (want != f->agreed_saves) return f->fail(GGRS_E_INVALID, "every step of this fan-out holds %u SaveGameState requests (agreed by all ranks at the first step); this list has %u -- "
-                                                              "ggrs_hip_fanout_set_interval starts a new agreement", f->agreed_saves, want);
+    if (want != f->agreed_saves) return fanout_refuse_step(f, f->fail(GGRS_E_INVALID, "every step of this fan-out holds %u SaveGameState requests (agreed by all ranks at the first step); this list has %u -- "
+                                                              "ggrs_hip_fanout_set_interval starts a new agreement", f->agreed_saves, want));
     uint32_t ns = 0;
     // the device copy of this step's Checksum(u128)s lands where the all-gather sends from
     if (w->gen_ok) w->dev_results_dst = s.d_send + 2 * (size_t)s.n_steps * f->agreed_saves;
     int rc = enqueue_impl(w, reqs, n, bs, bs ? &f->keep : nullptr, &ns);
     w->dev_results_dst = nullptr;
-    if (rc) return f->fail(rc, "%s", ggrs_hip_last_error(w));
+    if (rc) return fanout_refuse_step(f, f->fail(rc, "%s", ggrs_hip_last_error(w)));
     if (bs) f->last_branches = bs->n_branches;
     s.n_saves = ns;
     s.first[s.n_steps] = w->pending.back().first;        // where the kernels write this step's checksums (pinned result ring)
@@ -411,6 +426,14 @@ int ggrs_hip_fanout_collect(ggrs_fanout* f, uint64_t* checksums_out, uint32_t ma
     for (int r = 0; r < f->size && out_of_step < 0; ++r) {
         const uint64_t* theirs = s.h_recv + (size_t)r * stride + n_full * 2;
         for (uint32_t k = 0; k < f->interval; ++k) if (theirs[2 * k] != mine[2 * k] || theirs[2 * k + 1] != mine[2 * k + 1]) { out_of_step = r; bad_step = k; break; }
+    }
+    for (int r = 0; r < f->size; ++r) {                                            // a rank that refused a step of this group says so (fanout_refuse_step)
+        const uint64_t* theirs = s.h_recv + (size_t)r * stride + n_full * 2;
+        for (uint32_t k = 0; k < f->interval; ++k) if (theirs[2 * k] == ~0ull) {
+            const int rc = f->fail(GGRS_E_INVALID, "rank %d refused step %u of this all-gather (its error %d): the group's table is incomplete on every rank", r, k, (int)(int64_t)theirs[2 * k + 1]);
+            s.n_steps = 0; s.closed = false; ++f->head;
+            return rc;
+        }
     }
     if (out_of_step >= 0) {
         const uint64_t* theirs = s.h_recv + (size_t)out_of_step * stride + n_full * 2;

@@ -440,7 +440,10 @@ int ggrs_hip_adopt_live_state(ggrs_world* w);
  *                    Collectives pair up by ORDER: every rank must call step the same number of times, with the same group
  *                    boundaries.  Each step therefore carries a tag {frame of its first request, number of saves} behind its
  *                    checksums through the all-gather, and collect fails with GGRS_E_INVALID ("ranks are out of step", naming
- *                    both frames) instead of handing out a table whose rows belong to different frames.
+ *                    both frames) instead of handing out a table whose rows belong to different frames.  A step that ONE rank
+ *                    refuses after the first (a list of another shape, a spawn beyond its capacity ..) still takes that rank through
+ *                    the group's all-gather, with a tag that says so and the group closed at once: the call returns its error there,
+ *                    and the other ranks' collect fails with "rank r refused step k" instead of waiting for a rank that stopped calling.
  * At most 8 groups may be in flight. */
 #define GGRS_FANOUT_ID_BYTES 128
 typedef struct ggrs_fanout ggrs_fanout;

@@ -538,6 +538,21 @@ def _skewed_rank(rank, size, id_q, q, mode="frame"):
         fan = SpeculativeFanout(w, _Dist(), D, None, branches_per_rank=2, native=native)
         fan.sync_confirmed(0)
         first = fan.step()                                            # in step: fine
+        if mode == "refuse":
+            # ... then rank 1 hands the library a list of another shape (one SaveGameState where the agreed step has 1 + 2 x D): refused on rank 1 at once; rank 0's step
+            # goes through, and its collect must come back with "rank 1 refused" -- not wait in the all-gather for a rank that has stopped calling
+            try:
+                if rank == 1:
+                    C = fan.confirmed
+                    native.step([bg.LoadGameState(C), bg.AdvanceFrame((0,)), bg.SaveGameState(C + 1)])
+                else:
+                    fan.step()
+                verdict = "no error"
+            except bg.GgrsHipError as e:
+                verdict = f"GgrsHipError {e.code}: {e}"
+            native.close()
+            q.put((rank, "ok", first is not None, verdict))
+            return
         if rank == 1:                                                 # ... then rank 1 runs ahead by one confirmed frame
             C = fan.confirmed
             w.set_confirmed(C)
@@ -557,13 +572,15 @@ def _skewed_rank(rank, size, id_q, q, mode="frame"):
         q.put((rank, "error", f"{type(e).__name__}: {e}", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["frame", "shape"])
+@pytest.mark.parametrize("mode", ["frame", "shape", "refuse"])
 def test_ranks_out_of_step_are_refused_by_the_library(mode):
     """Collectives pair up by order: a rank that ran ahead would gather ANOTHER frame's checksums into the table (bench.py's clock-based
     pre-heat did, round 4).  Every step carries a tag {frame of its first request, saves} behind its checksums through the all-gather,
     and ggrs_hip_fanout_collect refuses a table whose ranks disagree -- on every rank, naming both frames ("frame").
     "shape": ranks whose lists hold different numbers of SaveGameState requests used to hand RCCL mismatched counts (undefined: DESIGN 9.8 of
-    round 4); the first step now exchanges {interval, saves per step} in one small all-gather of its own and every rank refuses."""
+    round 4); the first step now exchanges {interval, saves per step} in one small all-gather of its own and every rank refuses.
+    "refuse": a rank whose step is refused AFTER the agreement (a list of another shape, a spawn beyond its capacity ..) still takes part in the group's all-gather, with
+    a tag that says so: the other ranks' collect names it instead of waiting for ever."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q, id_q = ctx.Queue(), ctx.Queue()
@@ -586,7 +603,8 @@ def test_ranks_out_of_step_are_refused_by_the_library(mode):
     for r in (0, 1):
         assert res[r][0] == "ok" and res[r][1] is True, res[r]
         if mode == "frame": assert "GgrsHipError" in res[r][2] and "out of step" in res[r][2] and "frame" in res[r][2], res[r]
-        else: assert "GgrsHipError" in res[r][2] and "disagree on the shape" in res[r][2], res[r]
+        elif mode == "shape": assert "GgrsHipError" in res[r][2] and "disagree on the shape" in res[r][2], res[r]
+        else: assert "GgrsHipError" in res[r][2] and ("every step of this fan-out holds" if r == 1 else "rank 1 refused step 0") in res[r][2], res[r]
 
 
 SHOT_SPAWN = """
