@@ -172,6 +172,8 @@ def test_device_spawns_fuzzed(seed):
     # schedule is not part of any snapshot -- before that, SyncTest itself reports it as a MismatchedChecksum), but len, masks and the device-side len must follow
     res = []
     for w in (bg.World(cap, max_depth=cd + 2), OracleWorld(cap, cd + 2, FLAT)):
+        if isinstance(w, bg.World) and seed % 3 == 0:                           # value tags forced on (test hook; by size such a world never keeps them)
+            assert w._lib.ggrs_dbg_set_value_tags(w._p, 1) == 0
         cell = w.register_component("Cell", 4, 4)
         tag = w.register_component("Tag", 1, 1)                                 # NOT in the children's bundle: they must come out without it
         w.checksum_component(cell, [0, 1, 2, 3]); w.checksum_component(tag, [0])
