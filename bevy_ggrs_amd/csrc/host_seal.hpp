@@ -258,7 +258,7 @@ int seal_impl(ggrs_world* w) {
         HIPCHK(w, hipMalloc((void**)&w->d_sp_sums, (3 * (size_t)w->sp_tiles + 32) * 8));                 // the mailbox words {epoch, value}: counts, prefixes, done per tile; total; go
         HIPCHK(w, hipMemsetAsync(w->d_sp_sums, 0, (3 * (size_t)w->sp_tiles + 32) * 8, w->stream));
         w->sp_epoch = 0xF0000000u - 8u * (2u * MAX_TICK_STEPS + 2u) + 1u;      // (like jiffies: every world crosses the epochs' start-over on its 9th launch, so that path is run by every test and session)
-        HIPCHK(w, hipMalloc((void**)&w->d_sp_prec, (size_t)w->cap_pad * 64));
+        HIPCHK(w, hipMalloc((void**)&w->d_sp_prec, 2 * (size_t)std::max<uint64_t>(w->cap_pad, (uint64_t)w->sp_tiles * 256u) * 64));       // the parents' records, one set per step parity
         HIPCHK(w, hipMalloc((void**)&w->d_sp_link, (size_t)w->cap_pad * 16));
         HIPCHK(w, hipHostMalloc((void**)&w->h_sp_len, (2 + MAX_TICK_SAVES) * 8, hipHostMallocMapped));
         HIPCHK(w, hipHostGetDevicePointer((void**)&w->d_sp_len, (void*)w->h_sp_len, 0));

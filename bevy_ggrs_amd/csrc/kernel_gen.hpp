@@ -210,7 +210,7 @@ struct GgrsJitArgs {
     // SPAWNS DECIDED ON THE DEVICE (a system called e.spawn(n); ggrs_hip_add_spawn_system with GGRS_SPAWN_PAYLOAD_PARENT): RollbackOrdered::len lives on the device
     // (the blocks' headers; sp_len[0] = the live world's after the launch, [1] = error flags, [2 + k] = len at Save k: pinned), the launch is cooperative (every
     // workgroup resident: per step the workgroups' counts are gathered, scanned and handed back -- slot order == RollbackOrdered order --, and a second
-    // rendezvous when anything spawned so that the lanes owning the new slots find their parents' records: sp_prec[parent slot] = the parent's bound words,
+    // rendezvous when anything spawned so that the lanes owning the new slots find their parents' records: sp_prec[step parity][parent slot] = the parent's bound words,
     // sp_link[child slot] = {parent slot, k}).  sp_sums = the rendezvous' mailboxes, one {epoch, value} word each: counts[tiles], prefixes[tiles], done[tiles],
     // total (at 3 x tiles), go (at 3 x tiles + 16); sp_epoch = this launch's first epoch (2 per step): no word is ever reset
     ggrs_u64* sp_sums; ggrs_u32 sp_epoch; unsigned char* sp_prec; ggrs_u64* sp_link; ggrs_u64* sp_len; ggrs_u64 sp_cap; ggrs_u32 sp_tiles;
@@ -1041,7 +1041,7 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             sfmt(s, "                ggrs_sys_%u::ggrs_system(ent, fr%zu);\n", d.comp[0], i);
             if (DEV) s += "                if (ent.spawn_n) {                                        // e.spawn(n): the children are made after the frame's systems, from what THIS call left in e\n"
                           "                    spn_0 = (uint32_t)ent.spawn_n;\n"
-                          "                    GGRS_G ggrs_u64* pr_ = (GGRS_G ggrs_u64*)(a.sp_prec + e0 * 64u);\n"
+                          "                    GGRS_G ggrs_u64* pr_ = (GGRS_G ggrs_u64*)(a.sp_prec + ((uint64_t)(sj & 1u) * a.sp_tiles * 256u + e0) * 64u);   // two sets of records, by step parity: see the children's read\n"
                           "                    for (int b_ = 0; b_ < 8; ++b_) __hip_atomic_store(pr_ + b_, (ggrs_u64)ent.w[b_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: read by another workgroup, maybe another XCD, later in this launch\n"
                           "                }\n";
             for (uint32_t b = 0; b < c.n_bind; ++b)
@@ -1145,7 +1145,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
                  "                if (e0 >= sf_ && e0 < sf_ + sn_) {\n"
                  "                    const GGRS_G ggrs_u64* lk_ = (const GGRS_G ggrs_u64*)a.sp_link + 2u * e0;\n"
                  "                    const unsigned long long par_ = __hip_atomic_load(lk_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); kk_ = __hip_atomic_load(lk_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-                 "                    const GGRS_G ggrs_u64* pp_ = (const GGRS_G ggrs_u64*)(a.sp_prec + par_ * 64u);\n"
+                 "                    // (this step's set: a parent that spawns again in the NEXT step writes the other one -- its workgroup may be a step ahead of this one, but not two: the next\n"
+                 "                    // step's rendezvous waits for this workgroup)\n"
+                 "                    const GGRS_G ggrs_u64* pp_ = (const GGRS_G ggrs_u64*)(a.sp_prec + ((uint64_t)(sj & 1u) * a.sp_tiles * 256u + par_) * 64u);\n"
                  "                    for (int b_ = 0; b_ < 8; ++b_) prec_[b_] = __hip_atomic_load(pp_ + b_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
                  "                }\n"
                  "                const unsigned char* const spay_ = (const unsigned char*)prec_;\n"

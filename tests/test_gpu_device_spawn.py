@@ -199,3 +199,55 @@ def test_device_spawns_fuzzed(seed):
     assert res[0][0] == res[1][0]
     cm.assert_states_equal(res[0][1], res[1][1], f"device spawns, seed {seed}")
     assert res[0][2] > n                                                        # something split
+
+
+# ---- parents that spawn AGAIN AND AGAIN: a gun fires every few frames and stays; its record is read by its children's lanes in other workgroups while the gun's own
+# workgroup may already be a step ahead -- the records are kept per step parity (kernel_gen.hpp), this session makes the same parents write them in consecutive frames
+GUN_SRC = r"""
+__device__ void ggrs_system(GgrsEntity& e, const GgrsFrame& f) {
+    if (e.u32(3) == 0u) {                                                      // a gun: drifts, fires one or two bullets on its frames, never goes away
+        e.f32(0) = e.f32(0) + e.f32(1) * f.dt;
+        if (((unsigned)f.frame + (unsigned)e.slot) % (unsigned)f.iparam[0] == 0u) e.spawn(1 + (int)(e.slot & 1u));
+    } else {                                                                   // a bullet: flies, burns out
+        e.f32(0) = e.f32(0) + e.f32(1) * f.dt;
+        if (e.u32(2) > 0u) e.u32(2) -= 1u;
+        if (e.u32(2) == 0u) e.despawn();
+    }
+}
+"""
+
+
+def oracle_gun(words, slot, f):
+    x, v, fuse, gen = unbits(words[0]), unbits(words[1]), words[2] & 0xFFFFFFFF, words[3] & 0xFFFFFFFF
+    x = f32(x + f32(v * f32(f.dt)))
+    if gen == 0:
+        ns = (1 + (slot & 1)) if ((f.frame & 0xFFFFFFFF) + (slot & 0xFFFFFFFF)) % f.iparam[0] == 0 else 0
+        return [bits(x), words[1], fuse, gen], 0, ns
+    if fuse > 0: fuse -= 1
+    return [bits(x), words[1], fuse, gen], (1 if fuse == 0 else 0), 0
+
+
+@pytest.mark.parametrize("n,period,cd", [(3000, 1, 3), (20_000, 3, 4)])
+def test_parents_that_spawn_in_consecutive_frames(n, period, cd):
+    ticks = 10
+    cap = n + 2 * n * ((ticks + cd) // period + 2) + 256
+    res = []
+    for w in (bg.World(cap, max_depth=cd + 2), OracleWorld(cap, cd + 2, FLAT)):
+        cell = w.register_component("Cell", 4, 4)
+        w.checksum_component(cell, [0, 1, 2, 3])
+        binds = [(cell, 0), (cell, 1), (cell, 2), (cell, 3)]
+        if isinstance(w, bg.World):
+            w.add_custom_system(GUN_SRC, binds, iparam=(period,), name="guns")
+            w.add_spawn_system(CHILD_SRC, [cell], binds, payload_stride=PARENT, name="child")
+        else:
+            w.add_custom_system(oracle_gun, binds, iparam=(period,))
+            w.add_spawn_system(oracle_child, [cell], binds, payload_stride=PARENT)
+        rng = np.random.default_rng(5)
+        w.spawn(n, {cell: [rng.uniform(-50, 50, n).astype(np.float32).view(np.uint32), rng.uniform(-9, 9, n).astype(np.float32).view(np.uint32),
+                           np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)]})
+        drv = cm.SyncTestDriver(w, cd, max_prediction=cd + 1)
+        for _ in range(ticks): drv.tick((0,))
+        res.append((list(drv.all_checksums), cm.snapshot_state(w, [cell]), w.len))
+    assert res[0][2] == res[1][2] and res[1][2] > n + n * (ticks // period - 1), (res[0][2], res[1][2])
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], "guns")
