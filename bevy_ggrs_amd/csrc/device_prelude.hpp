@@ -141,12 +141,42 @@ __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, floa
 // 1 M launch from 48.9 to 50.1 us, profiles/r05b).  `cell`: 16 bytes, 16-byte aligned, in pinned host memory -- {value, tag} -- written by ONE store.
 constexpr uint32_t FF_CHUNK = 1024;
 typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq) {
+// self_seq != 0 (SELF-FOLD: the rows are the running launch's own): an entry is a 16-byte cell {value, self_seq} that its tile workgroup wrote with ONE sc1 store;
+// a cell whose tag is not there yet is read again (bounded: *ok = false after 2 s) -- the value travels with its tag, so neither side waits for a store to be
+// acknowledged or touches a cache as a whole.
+__device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq, uint64_t self_seq = 0) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     __shared__ unsigned long long ff_acc;
-    if (tid == 0) ff_acc = 0ull;
+    __shared__ uint32_t ff_bad;
+    if (tid == 0) { ff_acc = 0ull; ff_bad = 0u; }
     __syncthreads();
     uint64_t x = 0, sum = 0;
+    if (self_seq) {
+        const unsigned long long t0 = wall_clock64();
+        // The fold workgroups are resident from the launch's start: until the chunk's LAST entry is there -- the tile workgroup dispatched last of the chunk's -- only
+        // one lane looks, at that one cell, every ~1.7 us (all lanes polling all cells from the start cost a 4 M launch 80 us: profiles/r06w); then every lane reads its
+        // cells, again until each tag is there (dispatch order is not completion order)
+        if (tid == 0 && hi > lo) {
+            const ff_u32x4* const c = reinterpret_cast<const ff_u32x4*>(p) + (uint64_t)(hi - 1u) * istride;
+            for (;;) {
+                ff_u32x4 q;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(c) : "memory");
+                if ((((uint64_t)q.w << 32) | q.z) == self_seq || wall_clock64() - t0 > 200000000ull) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = lo + tid; i < hi; i += 256u) {
+            const ff_u32x4* const c = reinterpret_cast<const ff_u32x4*>(p) + (uint64_t)i * istride;
+            for (;;) {
+                ff_u32x4 q;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(c) : "memory");
+                if ((((uint64_t)q.w << 32) | q.z) == self_seq) { const uint64_t v = ((uint64_t)q.y << 32) | q.x; x ^= v; sum += v; break; }
+                if (wall_clock64() - t0 > 200000000ull) { ff_bad = 1u; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    } else {
     constexpr int INFL = 4;
     for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) {
         uint64_t v[INFL];
@@ -155,10 +185,11 @@ _Pragma("unroll")
 _Pragma("unroll")
         for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; }
     }
+    }
     if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); }          // workgroup-uniform branch
     else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !ff_bad) {                                                       // (a self-fold that timed out publishes nothing: the host reports the missing tags)
         // Value and tag leave as ONE 16-byte system-scope store (global_store_dwordx4 sc0 sc1: write-through to the fabric, no cache maintenance) into one
         // naturally aligned 16-byte cell: one write transaction on the way to host memory, so there is no order between two stores to rely on -- a host that
         // sees the tag sees the value that travelled with it.  (Rounds 4-5 issued two relaxed stores with s_waitcnt vmcnt(0) between them, which is ordered

@@ -801,7 +801,7 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
         const bool ff = w->h_rows && !w->device_results_only && g > (uint32_t)w->knobs.fold_forward_min_wgs;
         const bool host = w->h_rows && !w->device_results_only && !ff;
         std::string f = ff ? "fold-forward: the next launch on the stream folds the rows (k_ff_fold when nothing follows) and the host hashes one value per Save and part; blocking calls: " +
-                             std::string(g <= HOST_FOLD_MAX_WGS_BLOCKING && g <= (uint32_t)w->knobs.fold_forward_min_wgs ? "the host folds the rows" : "k_gen_finalize")
+                             std::string(g <= HOST_FOLD_MAX_WGS_BLOCKING && g <= (uint32_t)w->knobs.fold_forward_min_wgs ? "the host folds the rows" : "the launch folds its own rows (self-fold; k_gen_finalize for lists it does not cover)")
                       : host ? (g <= HOST_FOLD_MAX_WGS_BLOCKING ? "the host folds the rows at collect time (blocking calls too)" : "the host folds the rows at collect time (blocking calls: k_gen_finalize)")
                              : "k_gen_finalize";
         add("checksum_fold", f);

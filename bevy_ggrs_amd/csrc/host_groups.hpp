@@ -589,19 +589,35 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             rc = batch.flush(w); if (rc) return rc;
             if (batchable) { batch.start(j, g, res_base + ns, n_cks); group_close(w, gs, j.n_saves, dead, wrote_live); ns += j.n_saves; goto group_done; }
             // who folds this launch's partial rows: the next launch on the stream (fold-forward: enqueued lists of more than
-            // GGRS_FOLD_FORWARD_MIN_WGS workgroups), the host from pinned rows (smaller groups), or k_gen_finalize (blocking calls of more than 1024
+            // GGRS_FOLD_FORWARD_MIN_WGS workgroups), the launch itself (self-fold: blocking calls of that size), the host from pinned rows (smaller groups), or k_gen_finalize (blocking calls of more than 1024
             // workgroups, results that stay on the device, no room in the pinned ring)
             uint64_t rows_off = 0;
             const uint32_t ff_split = (g + FF_CHUNK - 1u) / FF_CHUNK;                      // chunks of <= 1024 entries per row: one fold-forward workgroup each
             const uint32_t nvals = j.n_saves * (n_cks + 1) * ff_split;
             bool ff = launch && j.n_saves && !wait && !w->device_results_only && !w->dev_spawn && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
                       rows_ring_alloc(w, 2ull * nvals, &rows_off);
+            // a BLOCKING call of that size: the launch folds its own rows (self-fold: its fold workgroups read the tile workgroups' tagged cells as they arrive) -- no k_gen_finalize
+            // between the kernel and the caller.  Not beside a pending fold-forward (the role folds one set of rows), not with depth-parallel roles (plain grids only)
+            const bool ffs = !ff && launch && j.n_saves && wait && !w->device_results_only && !w->dev_spawn && !j.dp_s && !w->ff_pending.valid &&
+                             g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] && !spawn_req && rows_ring_alloc(w, 2ull * nvals, &rows_off);
+            if (ffs) ff = true;
             const bool host_fold = !ff && launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);
             uint32_t ff_buf = 0;
             const uint32_t rows_n = j.n_saves * (n_cks + 1);
             // fold-forward rows are TILE-major: a workgroup's values of all its Saves and parts sit side by side (one coalesced store of 192 B for the
             // stress_test; row-major they were 24 eight-byte stores into 24 different lines, and the 1 M launch took 51 us instead of 48.9: profiles/r05c)
-            if (ff) { ff_buf = w->ff_cur; w->ff_cur ^= 1u; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[ff_buf]); j.part_stride = 1; j.part_tstride = rows_n; }
+            if (ff && !ffs) { ff_buf = w->ff_cur; w->ff_cur ^= 1u; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[ff_buf]); j.part_stride = 1; j.part_tstride = rows_n; }
+            // (self-fold: 16-byte cells {value, tag} instead of 8-byte entries -- the two fold-forward buffers, which lie side by side and hold nothing pending, as one)
+            if (ffs) { ff_buf = 0; j.parts = reinterpret_cast<ggrs_u64*>(w->d_ff_rows[0]); j.part_stride = 1; j.part_tstride = rows_n; }
+            uint64_t ffs_id = 0, ffs_seq = 0;
+            if (ffs) {
+                ffs_id = w->ff_next_id++; ffs_seq = (0xA5ull << 56) | ++w->ff_seq;
+                memset(w->h_rows + rows_off, 0, (size_t)nvals * 16);
+                j.ff_rows = reinterpret_cast<const ggrs_u64*>(w->d_ff_rows[ff_buf]); j.ff_out = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.ff_seq = ffs_seq;
+                j.ff_nvals = nvals; j.ff_blocks = (nvals + 7u) & ~7u; j.ff_g = g; j.ff_stride = 1; j.ff_istride = rows_n; j.ff_split = ff_split;
+                j.ff_self = 1;
+                w->ff_done_id = ffs_id; w->ff_mark_id = ffs_id;       // the fold is on the stream with this very launch; launch_jit records its event behind it
+            }
             if (host_fold) { j.parts = reinterpret_cast<ggrs_u64*>(w->d_rows + rows_off); j.part_stride = g; }
             if (launch) {
                 hipFunction_t fn = jit_spec_for(w, j);
@@ -616,12 +632,15 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             group_close(w, gs, j.n_saves, dead, wrote_live);
             if (ff) {
                 ggrs_world::HostFold f = make_host_fold(j, res_base + ns, ff_split, n_cks, 1u, rows_off);   // (the host XORs / adds the row's chunks)
+                if (ffs) { f.ff_id = ffs_id; f.ff_seq = ffs_seq; w->folds.push_back(f); ns += j.n_saves; }
+                else {
                 f.ff_id = w->ff_next_id++; f.ff_seq = (0xA5ull << 56) | ++w->ff_seq;      // (a tag no live count and -- but for 2^-64 -- no hash equals)
                 memset(w->h_rows + rows_off, 0, (size_t)nvals * 16);                    // the {value, tag} cells: whatever an earlier fold left there is gone
                 w->folds.push_back(f);
                 ggrs_world::FfPending& p = w->ff_pending;
                 p.valid = true; p.id = f.ff_id; p.seq = f.ff_seq; p.buf = ff_buf; p.nvals = nvals; p.g = g; p.stride = 1; p.istride = rows_n; p.split = ff_split; p.out_off = rows_off;
                 ns += j.n_saves;
+                }
             } else if (host_fold) { w->folds.push_back(make_host_fold(j, res_base + ns, g, n_cks, 1u, rows_off)); ns += j.n_saves; }
             else if (j.n_saves) {
                 GenFinArgs f = make_gen_fin(w, j, g, n_cks, res_base + ns);   // one row per workgroup

@@ -671,6 +671,12 @@ int read_back(ggrs_world* w, uint32_t n_results, uint64_t* out) {
         ++(seen ? w->spin_hits : w->spin_misses);
     }
     w->spin_n = 0;
+    // ... and a list whose every group folded ITSELF (self-fold: the launch's fold workgroups write {value, tag} cells once all of its tiles are done) needs no
+    // stream wait either: run_host_folds polls those tags.  (Every 256th call it is the stream wait all the same.)
+    if (!seen && !w->folds.empty() && !w->ff_pending.valid && w->knobs.spin_wait_us > 0 && (++w->self_fold_calls & 255u) != 0) {
+        seen = true;
+        for (const auto& f : w->folds) if (!f.ff_id || f.ff_id > w->ff_done_id) { seen = false; break; }
+    }
     if (!seen) {
         int rc = ff_flush(w); if (rc) return rc;                     // (nothing is pending in the synchronous API: a no-op there)
         HIPCHK(w, hipStreamSynchronize(w->stream));

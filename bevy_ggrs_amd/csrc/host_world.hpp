@@ -257,6 +257,7 @@ struct ggrs_world {
     // fold-forward (host_groups.hpp): two row buffers in device memory, used alternately by consecutive launches; what the LAST launch left in
     // ff_rows[ff_cur] waits for the next launch (or k_ff_fold) to fold it into the pinned values + tags of the HostFold with id ff_pending_id
     uint64_t* d_ff_rows[2] = {nullptr, nullptr}; uint32_t ff_cur = 0;
+    uint64_t self_fold_calls = 0;                           // blocking calls whose groups folded themselves (read_back: every 256th takes the stream wait)
     struct FfPending { bool valid = false; uint64_t id = 0, seq = 0; uint32_t buf = 0, nvals = 0, g = 0, stride = 0, istride = 1, split = 1; uint64_t out_off = 0; } ff_pending;   // nvals = rows x split
     uint64_t ff_next_id = 1, ff_done_id = 0, ff_seq = 0;    // ids are handed out in launch order; every id <= ff_done_id has a fold queued on the stream
     uint64_t ff_mark_id = 0;                                // the group whose fold the launch being issued carries (set by ff_attach, consumed by launch_jit)

@@ -189,6 +189,10 @@ struct GgrsJitArgs {
     // 16-byte {value, tag} cell, into pinned host memory (ff_out): the host finishes the Checksum(u128)s from 96 values instead of XOR-ing 750 KB of rows per tick at 1 M
     // (host_groups.hpp, "fold-forward")
     const ggrs_u64* ff_rows; ggrs_u64* ff_out; ggrs_u64 ff_seq;
+    // SELF-FOLD (ff_self != 0; blocking calls): ff_rows are THIS launch's own rows, as 16-byte cells {value, ff_seq} that each tile workgroup writes with ONE sc1
+    // store per value at its end; the fold workgroups read a cell until its tag is there (device_prelude.hpp ff_fold_row) -- no second launch between the kernel
+    // and the blocking caller (k_gen_finalize: 7 us at 1 M), no store waited for, no counter (3907 device-scope atomic adds on one address cost the launch 15 us,
+    // polled by the fold workgroups 240 us: profiles/r06w)
     ggrs_u64 live_rows, load_rows;                   // row versions: bit c = column c is stored with the live block / must be loaded at all
     // VALUE TAGS (host_world.hpp ggrs_world::vtags): bit c = the block's tags of column c are valid; tag_base = the first of the ids this launch may hand out
     // (n_steps + 2 per batch member); skip_count (profiling only): the launch adds the bytes it did NOT store
@@ -215,7 +219,7 @@ struct GgrsJitArgs {
     // total (at 3 x tiles), go (at 3 x tiles + 16); sp_epoch = this launch's first epoch (2 per step): no word is ever reset
     ggrs_u64* sp_sums; ggrs_u32 sp_epoch; unsigned char* sp_prec; ggrs_u64* sp_link; ggrs_u64* sp_len; ggrs_u64 sp_cap; ggrs_u32 sp_tiles;
     ggrs_u32 cached_saves;                           // with nt: bit i = Save i is stored through the L2 all the same (the snapshot the NEXT group is expected to load)
-    ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
+    ggrs_u32 ff_blocks, ff_nvals, ff_g, ff_stride, ff_istride, ff_split, ff_self;   // entry e of row r: ff_rows[r * ff_stride + e * ff_istride]
     ggrs_u32 dt_bits[24], aux_bits[24]; int step_frame[24], step_confirmed[24]; ggrs_u32 spawn_count[24];
     unsigned char step_flags[24], n_inputs[24];
     unsigned char inputs[24][JIT_IN_MAX];            // per step: n_inputs x input_bytes bytes of PlayerInputs, then (at max_players x input_bytes) one InputStatus byte per player
@@ -270,7 +274,7 @@ JitLayout jit_layout(const ggrs_world* w) {
         F1("ggrs_u32", src_is_live, true); F1("ggrs_u32", skip_live, true); F1("ggrs_u32", dp_s, true); F1("ggrs_u32", part_stride, true); F1("ggrs_u32", part_tstride, true); F1("ggrs_u32", nt, true);
         F1("ggrs_u64*", sp_sums, need.devspawn); F1("ggrs_u32", sp_epoch, need.devspawn); F1("unsigned char*", sp_prec, need.devspawn); F1("ggrs_u64*", sp_link, need.devspawn);
         F1("ggrs_u64*", sp_len, need.devspawn); F1("ggrs_u64", sp_cap, need.devspawn);
-        F1("ggrs_u32", n_units, true); F1("ggrs_u32", sp_tiles, need.devspawn); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true);
+        F1("ggrs_u32", n_units, true); F1("ggrs_u32", sp_tiles, need.devspawn); F1("ggrs_u32", vtags, need.vtags); F1("ggrs_u32", tag_base, need.vtags); F1("ggrs_u32", cached_saves, true); F1("ggrs_u32", ff_blocks, true); F1("ggrs_u32", ff_nvals, true); F1("ggrs_u32", ff_g, true); F1("ggrs_u32", ff_stride, true); F1("ggrs_u32", ff_istride, true); F1("ggrs_u32", ff_split, true); F1("ggrs_u32", ff_self, true);
         FS("ggrs_u32", dt_bits, true); FS("ggrs_u32", aux_bits, need.box); FS("int", step_frame, true); FS("int", step_confirmed, need.marks);
         FS("ggrs_u32", spawn_count, need.spawn);
         FS("unsigned char", step_flags, need.marks); FS("unsigned char", n_inputs, need.inputs);
@@ -618,8 +622,9 @@ bool jit_source(const ggrs_world* w, std::string& s) {
             "    if (blockIdx.x < a.ff_blocks) {\n"
             "        if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals) {                   // ff_nvals = rows x chunks per row (ff_split)\n"
             "            const uint32_t row = blockIdx.x / a.ff_split, ck = blockIdx.x %% a.ff_split, per = (a.ff_g + a.ff_split - 1u) / a.ff_split;\n"
-            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride, a.ff_istride, ck * per, min(a.ff_g, (ck + 1u) * per), (row %% %uu) == %uu,\n"
-            "                        (uint64_t*)a.ff_out + 2u * blockIdx.x, (uint64_t)a.ff_seq);                                 // cell blockIdx.x: {value, tag}\n"
+            "            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride * (a.ff_self ? 2u : 1u), a.ff_istride,     // (self-fold: 16-byte cells)\n"
+            "                        ck * per, min(a.ff_g, (ck + 1u) * per), (row %% %uu) == %uu,\n"
+            "                        (uint64_t*)a.ff_out + 2u * blockIdx.x, (uint64_t)a.ff_seq, a.ff_self ? (uint64_t)a.ff_seq : 0ull);   // cell blockIdx.x: {value, tag}\n"
             "        }\n"
             "        return;\n"
             "    }\n"
@@ -1221,8 +1226,14 @@ bool jit_source(const ggrs_world* w, std::string& s) {
     sfmt(s,
             "    for (uint32_t i = tid; i < a.n_saves * %uu; i += 256u) {\n"
             "        const uint32_t sv = i / %uu;\n"
-            "        if (sv >= o_first && sv < o_last)\n"
-            "            a.parts[((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + (uint64_t)tile * a.part_tstride] = s_acc[i];\n"
+            "        if (sv >= o_first && sv < o_last) {\n"
+            "            const uint64_t at_ = ((uint64_t)blockIdx.z * a.n_saves * %uu + i) * a.part_stride + (uint64_t)tile * a.part_tstride;\n"
+            "            if (a.ff_self) {                                                  // self-fold: a 16-byte cell {value, tag} in ONE sc1 store, read by a fold workgroup of THIS launch\n"
+            "                const uint64_t v_ = s_acc[i], sq_ = (uint64_t)a.ff_seq;\n"
+            "                const ff_u32x4 q_ = {(uint32_t)v_, (uint32_t)(v_ >> 32), (uint32_t)sq_, (uint32_t)(sq_ >> 32)};\n"
+            "                asm volatile(\"global_store_dwordx4 %%0, %%1, off sc1\" : : \"v\"(reinterpret_cast<ff_u32x4*>(a.parts) + at_), \"v\"(q_) : \"memory\");\n"
+            "            } else a.parts[at_] = s_acc[i];\n"
+            "        }\n"
             "    }\n", n_cks + 1, n_cks + 1, n_cks + 1);
     if (VT) s += "    if (a.skip_count && tid == 0 && s_skip) atomicAdd(a.skip_count, s_skip);      // value tags, profiled launches only: bytes this workgroup did not store\n";
     s += "}\n";

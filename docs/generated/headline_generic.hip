@@ -40,7 +40,7 @@ __device__ __forceinline__ bool sp_await(ggrs_u64* p, ggrs_u32 ep, ggrs_u32& v, 
     }
 }
 namespace ggrs {
-constexpr int LT_SHIFT = 13; constexpr int LAYOUT_TILE = 1 << LT_SHIFT; constexpr uint64_t SEA_P = 0x6eed0e9da4d94a4fULL; constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cULL, SEA_K2 = 0x6fe2e5aaf078ebc9ULL, SEA_K3 = 0x14f994a4c5259381ULL; __host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) { x *= SEA_P; const uint32_t hi = (uint32_t)(x >> 32); x ^= (uint64_t)(hi >> (hi >> 28)); x *= SEA_P; return x; } __host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, uint32_t z) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_tail3(uint32_t z) { return sea_diffuse(SEA_K1 ^ (uint64_t)z); } __host__ __device__ __forceinline__ uint64_t sea_inner3_with_tail(uint32_t x, uint32_t y, uint64_t a) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) { uint64_t B = sea_diffuse(SEA_K0 ^ order); uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_order_lane(uint64_t order) { return sea_diffuse(SEA_K0 ^ order); } __host__ __device__ __forceinline__ uint64_t sea_pair_pre(uint64_t B, uint64_t inner) { uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) { uint64_t A = sea_diffuse(SEA_K0 ^ x); return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL); } struct SeaStream { uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0, tail = 0; uint32_t ntail = 0; __host__ __device__ __forceinline__ void write(uint64_t v, uint32_t nb) { if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL; tail |= v << (8 * ntail); const uint32_t tot = ntail + nb; if (tot >= 8) { const uint64_t a = sea_diffuse(s0 ^ tail); s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; const uint32_t used = 8 - ntail; tail = used >= 8 ? 0ULL : (v >> (8 * used)); ntail = tot - 8; } else ntail = tot; } __host__ __device__ __forceinline__ void unit(uint32_t u) { write(u, 4); } __host__ __device__ __forceinline__ uint64_t finish() const { const uint64_t a = ntail ? sea_diffuse(s0 ^ tail) : s0; return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + ntail)); } }; struct Header { uint64_t len; int32_t frame; uint32_t pad0; uint64_t active; uint64_t checksum[2]; }; __device__ __forceinline__ uint32_t wave_xor32(uint32_t v) { v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); } __device__ __forceinline__ uint64_t wave_xor(uint64_t v) { return ((uint64_t)wave_xor32((uint32_t)(v >> 32)) << 32) | wave_xor32((uint32_t)v); } constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3; __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in, float dt, float fp, float accel, float max_speed, float half_width) { const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT; const float adt = __fmul_rn(accel, dt); if (up && !down) vz = __fsub_rn(vz, adt); if (!up && down) vz = __fadd_rn(vz, adt); if (left && !right) vx = __fsub_rn(vx, adt); if (!left && right) vx = __fadd_rn(vx, adt); if (!up && !down) vz = __fmul_rn(vz, fp); if (!left && !right) vx = __fmul_rn(vx, fp); vy = __fmul_rn(vy, fp); const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)); if (len_sq > __fmul_rn(max_speed, max_speed)) { const float l = sqrtf(len_sq); vx = __fmul_rn(max_speed, vx / l); vy = __fmul_rn(max_speed, vy / l); vz = __fmul_rn(max_speed, vz / l); } x = __fadd_rn(x, __fmul_rn(vx, dt)); y = __fadd_rn(y, __fmul_rn(vy, dt)); z = __fadd_rn(z, __fmul_rn(vz, dt)); const float lo = -half_width, hi = half_width; if (x < lo) x = lo; if (x > hi) x = hi; if (z < lo) z = lo; if (z > hi) z = hi; } constexpr uint32_t FF_CHUNK = 1024; typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4))); __device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq) { const uint32_t tid = threadIdx.x, lane = tid & 63u; __shared__ unsigned long long ff_acc; if (tid == 0) ff_acc = 0ull; __syncthreads(); uint64_t x = 0, sum = 0; constexpr int INFL = 4; for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) { uint64_t v[INFL]; _Pragma("unroll") for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < hi ? p[(uint64_t)i * istride] : 0ULL; } _Pragma("unroll") for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; } } if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); } else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); } __syncthreads(); if (tid == 0) { const uint64_t v = (uint64_t)ff_acc; const ff_u32x4 q = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)seq, (uint32_t)(seq >> 32)}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(cell), "v"(q) : "memory"); } }
+constexpr int LT_SHIFT = 13; constexpr int LAYOUT_TILE = 1 << LT_SHIFT; constexpr uint64_t SEA_P = 0x6eed0e9da4d94a4fULL; constexpr uint64_t SEA_K0 = 0x16f11fe89b0d677cULL, SEA_K1 = 0xb480a793d8e6c86cULL, SEA_K2 = 0x6fe2e5aaf078ebc9ULL, SEA_K3 = 0x14f994a4c5259381ULL; __host__ __device__ __forceinline__ uint64_t sea_diffuse(uint64_t x) { x *= SEA_P; const uint32_t hi = (uint32_t)(x >> 32); x ^= (uint64_t)(hi >> (hi >> 28)); x *= SEA_P; return x; } __host__ __device__ __forceinline__ uint64_t sea_inner3(uint32_t x, uint32_t y, uint32_t z) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); uint64_t a = sea_diffuse(SEA_K1 ^ (uint64_t)z); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_tail3(uint32_t z) { return sea_diffuse(SEA_K1 ^ (uint64_t)z); } __host__ __device__ __forceinline__ uint64_t sea_inner3_with_tail(uint32_t x, uint32_t y, uint64_t a) { uint64_t A = sea_diffuse(SEA_K0 ^ ((uint64_t)x | ((uint64_t)y << 32))); return sea_diffuse(a ^ SEA_K2 ^ SEA_K3 ^ A ^ 12ULL); } __host__ __device__ __forceinline__ uint64_t sea_pair(uint64_t order, uint64_t inner) { uint64_t B = sea_diffuse(SEA_K0 ^ order); uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_order_lane(uint64_t order) { return sea_diffuse(SEA_K0 ^ order); } __host__ __device__ __forceinline__ uint64_t sea_pair_pre(uint64_t B, uint64_t inner) { uint64_t C = sea_diffuse(SEA_K1 ^ inner); return sea_diffuse(SEA_K2 ^ SEA_K3 ^ B ^ C ^ 16ULL); } __host__ __device__ __forceinline__ uint64_t sea_one(uint64_t x) { uint64_t A = sea_diffuse(SEA_K0 ^ x); return sea_diffuse(SEA_K1 ^ SEA_K2 ^ SEA_K3 ^ A ^ 8ULL); } struct SeaStream { uint64_t s0 = SEA_K0, s1 = SEA_K1, s2 = SEA_K2, s3 = SEA_K3, written = 0, tail = 0; uint32_t ntail = 0; __host__ __device__ __forceinline__ void write(uint64_t v, uint32_t nb) { if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL; tail |= v << (8 * ntail); const uint32_t tot = ntail + nb; if (tot >= 8) { const uint64_t a = sea_diffuse(s0 ^ tail); s0 = s1; s1 = s2; s2 = s3; s3 = a; written += 8; const uint32_t used = 8 - ntail; tail = used >= 8 ? 0ULL : (v >> (8 * used)); ntail = tot - 8; } else ntail = tot; } __host__ __device__ __forceinline__ void unit(uint32_t u) { write(u, 4); } __host__ __device__ __forceinline__ uint64_t finish() const { const uint64_t a = ntail ? sea_diffuse(s0 ^ tail) : s0; return sea_diffuse(a ^ s1 ^ s2 ^ s3 ^ (written + ntail)); } }; struct Header { uint64_t len; int32_t frame; uint32_t pad0; uint64_t active; uint64_t checksum[2]; }; __device__ __forceinline__ uint32_t wave_xor32(uint32_t v) { v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); } __device__ __forceinline__ uint64_t wave_xor(uint64_t v) { return ((uint64_t)wave_xor32((uint32_t)(v >> 32)) << 32) | wave_xor32((uint32_t)v); } constexpr uint8_t BOX_INPUT_UP = 1 << 0, BOX_INPUT_DOWN = 1 << 1, BOX_INPUT_LEFT = 1 << 2, BOX_INPUT_RIGHT = 1 << 3; __device__ __forceinline__ void box_move_math(float& x, float& y, float& z, float& vx, float& vy, float& vz, uint8_t in, float dt, float fp, float accel, float max_speed, float half_width) { const bool up = in & BOX_INPUT_UP, down = in & BOX_INPUT_DOWN, left = in & BOX_INPUT_LEFT, right = in & BOX_INPUT_RIGHT; const float adt = __fmul_rn(accel, dt); if (up && !down) vz = __fsub_rn(vz, adt); if (!up && down) vz = __fadd_rn(vz, adt); if (left && !right) vx = __fsub_rn(vx, adt); if (!left && right) vx = __fadd_rn(vx, adt); if (!up && !down) vz = __fmul_rn(vz, fp); if (!left && !right) vx = __fmul_rn(vx, fp); vy = __fmul_rn(vy, fp); const float len_sq = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)); if (len_sq > __fmul_rn(max_speed, max_speed)) { const float l = sqrtf(len_sq); vx = __fmul_rn(max_speed, vx / l); vy = __fmul_rn(max_speed, vy / l); vz = __fmul_rn(max_speed, vz / l); } x = __fadd_rn(x, __fmul_rn(vx, dt)); y = __fadd_rn(y, __fmul_rn(vy, dt)); z = __fadd_rn(z, __fmul_rn(vz, dt)); const float lo = -half_width, hi = half_width; if (x < lo) x = lo; if (x > hi) x = hi; if (z < lo) z = lo; if (z > hi) z = hi; } constexpr uint32_t FF_CHUNK = 1024; typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4))); __device__ __forceinline__ void ff_fold_row(const uint64_t* p, uint32_t istride, uint32_t lo, uint32_t hi, bool is_cnt, uint64_t* cell, uint64_t seq, uint64_t self_seq = 0) { const uint32_t tid = threadIdx.x, lane = tid & 63u; __shared__ unsigned long long ff_acc; __shared__ uint32_t ff_bad; if (tid == 0) { ff_acc = 0ull; ff_bad = 0u; } __syncthreads(); uint64_t x = 0, sum = 0; if (self_seq) { const unsigned long long t0 = wall_clock64(); if (tid == 0 && hi > lo) { const ff_u32x4* const c = reinterpret_cast<const ff_u32x4*>(p) + (uint64_t)(hi - 1u) * istride; for (;;) { ff_u32x4 q; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(c) : "memory"); if ((((uint64_t)q.w << 32) | q.z) == self_seq || wall_clock64() - t0 > 200000000ull) break; __builtin_amdgcn_s_sleep(64); } } __syncthreads(); for (uint32_t i = lo + tid; i < hi; i += 256u) { const ff_u32x4* const c = reinterpret_cast<const ff_u32x4*>(p) + (uint64_t)i * istride; for (;;) { ff_u32x4 q; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(c) : "memory"); if ((((uint64_t)q.w << 32) | q.z) == self_seq) { const uint64_t v = ((uint64_t)q.y << 32) | q.x; x ^= v; sum += v; break; } if (wall_clock64() - t0 > 200000000ull) { ff_bad = 1u; break; } __builtin_amdgcn_s_sleep(8); } } } else { constexpr int INFL = 4; for (uint32_t i0 = lo + tid; i0 < hi; i0 += (uint32_t)INFL * 256u) { uint64_t v[INFL]; _Pragma("unroll") for (int u = 0; u < INFL; ++u) { const uint32_t i = i0 + (uint32_t)u * 256u; v[u] = i < hi ? p[(uint64_t)i * istride] : 0ULL; } _Pragma("unroll") for (int u = 0; u < INFL; ++u) { x ^= v[u]; sum += v[u]; } } } if (is_cnt) { if (sum) atomicAdd(&ff_acc, (unsigned long long)sum); } else { x = wave_xor(x); if (lane == 0) atomicXor(&ff_acc, (unsigned long long)x); } __syncthreads(); if (tid == 0 && !ff_bad) { const uint64_t v = (uint64_t)ff_acc; const ff_u32x4 q = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)seq, (uint32_t)(seq >> 32)}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(cell), "v"(q) : "memory"); } }
 }
 using namespace ggrs;
 #define GGRS_INPUT_CONFIRMED 0
@@ -141,6 +141,7 @@ struct GgrsJitArgs {
     ggrs_u32 ff_stride;
     ggrs_u32 ff_istride;
     ggrs_u32 ff_split;
+    ggrs_u32 ff_self;
     ggrs_u32 dt_bits[11];
     int step_frame[11];
 };
@@ -180,8 +181,9 @@ static_assert(__builtin_offsetof(GgrsJitArgs, ff_g) == 468, "argument block: off
 static_assert(__builtin_offsetof(GgrsJitArgs, ff_stride) == 472, "argument block: offset of ff_stride");
 static_assert(__builtin_offsetof(GgrsJitArgs, ff_istride) == 476, "argument block: offset of ff_istride");
 static_assert(__builtin_offsetof(GgrsJitArgs, ff_split) == 480, "argument block: offset of ff_split");
-static_assert(__builtin_offsetof(GgrsJitArgs, dt_bits) == 484, "argument block: offset of dt_bits");
-static_assert(__builtin_offsetof(GgrsJitArgs, step_frame) == 528, "argument block: offset of step_frame");
+static_assert(__builtin_offsetof(GgrsJitArgs, ff_self) == 484, "argument block: offset of ff_self");
+static_assert(__builtin_offsetof(GgrsJitArgs, dt_bits) == 488, "argument block: offset of dt_bits");
+static_assert(__builtin_offsetof(GgrsJitArgs, step_frame) == 532, "argument block: offset of step_frame");
 #line 1 "ggrs_jit_tick"
 extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -191,8 +193,9 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     if (blockIdx.x < a.ff_blocks) {
         if (blockIdx.y == 0u && blockIdx.z == 0u && blockIdx.x < a.ff_nvals) {                   // ff_nvals = rows x chunks per row (ff_split)
             const uint32_t row = blockIdx.x / a.ff_split, ck = blockIdx.x % a.ff_split, per = (a.ff_g + a.ff_split - 1u) / a.ff_split;
-            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride, a.ff_istride, ck * per, min(a.ff_g, (ck + 1u) * per), (row % 3u) == 2u,
-                        (uint64_t*)a.ff_out + 2u * blockIdx.x, (uint64_t)a.ff_seq);                                 // cell blockIdx.x: {value, tag}
+            ff_fold_row((const uint64_t*)a.ff_rows + (uint64_t)row * a.ff_stride * (a.ff_self ? 2u : 1u), a.ff_istride,     // (self-fold: 16-byte cells)
+                        ck * per, min(a.ff_g, (ck + 1u) * per), (row % 3u) == 2u,
+                        (uint64_t*)a.ff_out + 2u * blockIdx.x, (uint64_t)a.ff_seq, a.ff_self ? (uint64_t)a.ff_seq : 0ull);   // cell blockIdx.x: {value, tag}
         }
         return;
     }
@@ -476,7 +479,13 @@ extern "C" __global__ __launch_bounds__(256) void ggrs_jit_tick(GgrsJitArgs a) {
     __syncthreads();
     for (uint32_t i = tid; i < a.n_saves * 3u; i += 256u) {
         const uint32_t sv = i / 3u;
-        if (sv >= o_first && sv < o_last)
-            a.parts[((uint64_t)blockIdx.z * a.n_saves * 3u + i) * a.part_stride + (uint64_t)tile * a.part_tstride] = s_acc[i];
+        if (sv >= o_first && sv < o_last) {
+            const uint64_t at_ = ((uint64_t)blockIdx.z * a.n_saves * 3u + i) * a.part_stride + (uint64_t)tile * a.part_tstride;
+            if (a.ff_self) {                                                  // self-fold: a 16-byte cell {value, tag} in ONE sc1 store, read by a fold workgroup of THIS launch
+                const uint64_t v_ = s_acc[i], sq_ = (uint64_t)a.ff_seq;
+                const ff_u32x4 q_ = {(uint32_t)v_, (uint32_t)(v_ >> 32), (uint32_t)sq_, (uint32_t)(sq_ >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(reinterpret_cast<ff_u32x4*>(a.parts) + at_), "v"(q_) : "memory");
+            } else a.parts[at_] = s_acc[i];
+        }
     }
 }

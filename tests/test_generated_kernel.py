@@ -71,7 +71,7 @@ def test_generated_kernel_builds_for_gfx950(name):
     else:
         assert "dis_0" not in src
     body = src.split('#line 1 "ggrs_jit_tick"')[1]
-    assert "a.parts[" in body and "ff_fold_row(" in body and "__launch_bounds__(256)" in body, "one 256-slot workgroup per tile; the first workgroups fold the previous launch's rows forward"
+    assert "a.parts[at_]" in body and "ff_fold_row(" in body and "__launch_bounds__(256)" in body, "one 256-slot workgroup per tile; the first workgroups fold the previous launch's rows forward"
     assert "static_assert(sizeof(GgrsJitArgs) == " in src and src.count("static_assert(__builtin_offsetof(GgrsJitArgs, ") >= 30, "the per-world argument block is pinned field by field"
     # the argument block carries only what this world's kernel reads
     args = src[src.index("struct GgrsJitArgs {"):src.index("static_assert(sizeof(GgrsJitArgs)")]

@@ -529,3 +529,31 @@ def test_long_pipelined_run_wraps_the_host_fold_row_ring(monkeypatch):
         reqs += [bg.SaveGameState(F), bg.AdvanceFrame((0,))]
         F += 1
         assert o.handle_requests(reqs) == out[0][0][t], f"tick {t}"
+
+
+@pytest.mark.parametrize("n,depth,with_spawn", [(30_000, 6, False), (70_000, 8, True), (300_000, 4, False)])
+def test_blocking_calls_fold_their_own_rows(monkeypatch, n, depth, with_spawn):
+    """A BLOCKING ggrs_hip_handle_requests of an HBM-sized group (here: every group, GGRS_FOLD_FORWARD_MIN_WGS=0) is ONE launch: the tile workgroups leave their
+    partial rows as 16-byte {value, tag} cells, the launch's own fold workgroups read each cell until its tag is there and publish the folded values -- no
+    k_gen_finalize behind the kernel.  Every Checksum(u128) of a SyncTest session and the final state against the oracle, and the launch counts of ten ticks."""
+    monkeypatch.setenv("GGRS_FOLD_FORWARD_MIN_WGS", "0")
+    res = []
+    for w in (bg.World(n + 4000, max_depth=depth + 2), OracleWorld(n + 4000, depth + 2, FLAT)):
+        ids = cm.build_particles(w, with_spawn=with_spawn, ttl_init=40)
+        vel, ttl = cm.synthetic_particles(n, ttl="despawn")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        drv = cm.SyncTestDriver(w, depth, max_prediction=depth + 1)
+        gpu = isinstance(w, bg.World)
+        spawn = cm.frame_spawn_fn(30) if with_spawn else None
+        inp = (lambda t: (cm.INPUT_SPAWN if (with_spawn and t % 3 == 0) else 0,))
+        for t in range(depth + 4): drv.tick(inp(t), spawn_fn=spawn)
+        if gpu:
+            assert "fold-forward" in w.kernel_info()["checksum_fold"], w.kernel_info()
+            w.profile_enable(True)
+        for t in range(depth + 4, depth + 14): drv.tick(inp(t), spawn_fn=spawn)
+        if gpu:
+            prof = w.profile_read(); w.profile_enable(False)
+            assert prof["tick"][1] == 10 and prof["checksum"][1] == 0, prof                # ten blocking ticks: ten launches, no finalize
+        res.append((list(drv.all_checksums), cm.snapshot_state(w, ids)))
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], "self-fold")
