@@ -597,8 +597,10 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
             bool ff = launch && j.n_saves && !wait && !w->device_results_only && !w->dev_spawn && g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] &&
                       rows_ring_alloc(w, 2ull * nvals, &rows_off);
             // a BLOCKING call of that size: the launch folds its own rows (self-fold: its fold workgroups read the tile workgroups' tagged cells as they arrive) -- no k_gen_finalize
-            // between the kernel and the caller.  Not beside a pending fold-forward (the role folds one set of rows), not with depth-parallel roles (plain grids only)
-            const bool ffs = !ff && launch && j.n_saves && wait && !w->device_results_only && !w->dev_spawn && !j.dp_s && !w->ff_pending.valid &&
+            // between the kernel and the caller.  Not beside a pending fold-forward (the role folds one set of rows), not with depth-parallel roles (plain grids only),
+            // and only while the fold workgroups -- resident and waiting from the launch's start -- are few beside the 2048 the device holds (8 M entities and more
+            // keep k_gen_finalize: thousands of waiting workgroups would leave the tiles no room, at 32 M none at all)
+            const bool ffs = !ff && launch && j.n_saves && wait && nvals <= SELF_FOLD_MAX_WGS && !w->device_results_only && !w->dev_spawn && !j.dp_s && !w->ff_pending.valid &&
                              g > (uint32_t)w->knobs.fold_forward_min_wgs && w->d_ff_rows[0] && !spawn_req && rows_ring_alloc(w, 2ull * nvals, &rows_off);
             if (ffs) ff = true;
             const bool host_fold = !ff && launch && host_fold_rows(w, g, j.n_saves, n_cks, 1, &rows_off, wait);

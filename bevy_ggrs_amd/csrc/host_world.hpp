@@ -90,6 +90,7 @@ constexpr uint64_t JIT_DP_MAX_SLOTS = 40 * 1024;            // depth-parallel ro
 constexpr uint64_t JIT_CACHED_SAVE_MAX_BYTES = 80ull << 20; // the group's first Save goes through the L2 while its rows are at most this (profiles/r03n, r04c)
 constexpr int JIT_SPEC_SHAPES = 16;                         // group shapes counted (and specialised kernels kept) per world
 constexpr uint64_t VTAGS_MIN_BYTES = 80ull << 20;           // value tags by default when one steady Save of the whole world moves at least this much: 3 M +16 %, 4 M +18 %, all-columns-hot 2 M +18 %; below (2 M -19 %, all-columns-hot 1 M -3 %) the launch is bound by its vector ALUs and the bookkeeping costs more than the bytes (profiles/r06h)
+constexpr uint32_t SELF_FOLD_MAX_WGS = 512;                // self-fold (blocking calls): at most this many fold workgroups wait inside the launch for its tiles
 constexpr uint32_t HOST_FOLD_MAX_WGS_BLOCKING = 1024;       // blocking calls: larger groups are folded by k_gen_finalize (the host's fold would be serial with the kernel)
 
 }  // namespace
