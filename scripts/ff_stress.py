@@ -3,7 +3,9 @@
 rows and publishes every value as ONE 16-byte {value, tag} store into pinned memory, which the collecting host polls at full speed) next to a SHADOW world that
 runs the same ticks with the fold on the host (GGRS_FOLD_FORWARD_MIN_WGS=1000000: no tags, no polling of device-published cells): every Checksum(u128) of
 every tick must be equal, and -- SyncTest -- every frame's checksum equal in every tick that re-simulates it.  A torn or reordered publication is a mismatch.
-usage: ff_stress.py [entities] [ticks]      prints one JSON line"""
+With --sync every tick is a BLOCKING ggrs_hip_handle_requests instead: the fold-forward world then folds its own rows inside the launch (self-fold: the tile
+workgroups' 16-byte {value, tag} cells, read by the launch's own fold workgroups as they arrive), the shadow uses k_gen_finalize.
+usage: ff_stress.py [entities] [ticks] [--sync]      prints one JSON line"""
 import ctypes as C
 import json
 import os
@@ -31,8 +33,10 @@ def world(n, D, host_fold):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
-    ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    sync = "--sync" in sys.argv
+    argv = [a for a in sys.argv if a != "--sync"]
+    n = int(argv[1]) if len(argv) > 1 else 300_000
+    ticks = int(argv[2]) if len(argv) > 2 else 1_000_000
     D = 8
     ws = [world(n, D, False), world(n, D, True)]
     assert "fold-forward" in ws[0].kernel_info()["checksum_fold"], ws[0].kernel_info()["checksum_fold"]
@@ -58,15 +62,17 @@ def main():
     bad = None
     inflight = []
     for t in range(ticks):
+        got = []
         for w, (arr, keep, nreq, ns, fv, idx, rel, out, out_np) in zip(ws, T):
             fv[idx] = rel + (F - D)
-            w.enqueue_requests_raw(arr, nreq)
+            if sync: w.handle_requests_raw(arr, nreq, out); got.append(out_np.copy())
+            else: w.enqueue_requests_raw(arr, nreq)
         inflight.append(F)
         F += 1
-        if len(inflight) > 1:
+        if sync or len(inflight) > 1:
             f0 = inflight.pop(0)
-            got = []
             for w, (arr, keep, nreq, ns, fv, idx, rel, out, out_np) in zip(ws, T):
+                if sync: break
                 w.collect_checksums_raw(out, ns)
                 got.append(out_np.copy())
             if not np.array_equal(got[0], got[1]):
@@ -83,7 +89,7 @@ def main():
         while w.pending_batches(): w.collect_checksums(64)
     secs = time.perf_counter() - t0
     print(json.dumps({"entities": n, "ticks": ticks if not bad else bad["tick"], "seconds": round(secs, 1), "us_per_tick_both_worlds": round(secs / max(1, t + 1) * 1e6, 2),
-                      "equal": bad is None, "first_mismatch": bad, "checksum_fold": ws[0].kernel_info()["checksum_fold"][:60], "shadow": "host fold (GGRS_FOLD_FORWARD_MIN_WGS=1000000)"}))
+                      "equal": bad is None, "first_mismatch": bad, "api": "blocking handle_requests (self-fold vs k_gen_finalize)" if sync else "enqueue / collect, one tick in flight", "checksum_fold": ws[0].kernel_info()["checksum_fold"][:60], "shadow": "host fold (GGRS_FOLD_FORWARD_MIN_WGS=1000000)"}))
     sys.exit(0 if bad is None else 1)
 
 
