@@ -68,7 +68,7 @@ def build_world(bg, cm, n, depth, stream=0, flags=0, checksum=True, schema="head
     return w, ids
 
 
-def alu_view(diffuses_per_launch, launch_s):
+def alu_view(diffuses_per_launch, launch_s, depth=8):
     """The dominant kernel priced against the chip's OTHER ceiling: SeaHash `diffuse` (two u64 multiplies) per second against what
     scripts/ubench_alu.hip measured on every CU (profiles/alu_ceiling.json).  Informational next to `roofline` (the kernel is bound by
     HBM): it says how far the hashing is from becoming the bound.  Never raises: a missing ceiling file gives frac None."""
@@ -78,9 +78,21 @@ def alu_view(diffuses_per_launch, launch_s):
     except Exception:
         ceil, peak = {}, None
     ach = diffuses_per_launch / launch_s / 1e9 if launch_s > 0 else 0.0
-    return {"bound": "valu-int (u64 multiply)", "achieved": ach, "unit": "G diffuse/s", "peak": peak, "frac": (ach / peak) if peak else None,
-            "peak_source": ceil.get("source"),
-            "note": "algorithmic count (SURVEY 8d): 6 diffuse per entity per checksummed component per SaveWorld; the kernel executes fewer (hoisted order hash, memoised tails)"}
+    out = {"bound": "valu-int (u64 multiply)", "achieved": ach, "unit": "G diffuse/s", "peak": peak, "frac": (ach / peak) if peak else None,
+           "peak_source": ceil.get("source"),
+           "note": "algorithmic count (SURVEY 8d): 6 diffuse per entity per checksummed component per SaveWorld; the kernel executes fewer (hoisted order hash, memoised tails)"}
+    out.update(alu_executed(out["frac"], depth))
+    return out
+
+
+def alu_executed(frac_algorithmic, depth, components=2):
+    """What the generated kernel EXECUTES of the algorithmic 6 diffuses per entity, checksummed component and SaveWorld (stress_test: Transform.translation and Velocity,
+    12 bytes each): 4 -- the full word, the finish of the inner hash, write_u64(inner) and the finish of the pair; the tail word's diffuse is memoised while the value stays
+    (z never changes in this workload) and the order hash diffuse(K0 ^ order) is computed once per entity and launch.  `frac` counts the algorithm (and can exceed 1: the
+    ceiling is diffuses per second); `frac_executed` is the share of the multiplier the launch really keeps busy with hashing."""
+    if frac_algorithmic is None or not depth: return {}
+    ratio = (4.0 * components * depth + 1.0) / (6.0 * components * depth)
+    return {"executed_over_algorithmic": round(ratio, 4), "frac_executed": frac_algorithmic * ratio}
 
 
 def rss_mb():
@@ -905,7 +917,7 @@ def single_line(bg, cm, torch, args, dev):
                 "other_kernels": ({"k_gen_finalize": {"avg_launch_us": per(fin_ms, fin_n) * 1e6, "launches_timed": fin_n}} if fin_n else {}),
                 "per_request_equiv_GBps": tick_bytes * live * K / secs / 1e9, "per_request_equiv_frac": tick_bytes * live * K / secs / 1e9 / HBM_PEAK_GBS}
         if tick_n and not args.no_checksum:
-            try: roof["alu"] = alu_view(6.0 * 2 * live * D, avg_s)
+            try: roof["alu"] = alu_view(6.0 * 2 * live * D, avg_s, D)
             except Exception: pass
     else:
         save_avg_s = per(save_ms, save_n)
@@ -1118,6 +1130,7 @@ def fanout_line(bg, cm, torch, args, dist, rank, world_size, dev, ctl_dev):
                                 "note": "algorithmic diffuses: 6 per entity per checksummed component per SaveWorld, 2 components, D SaveWorlds per branch -- every branch's D "
                                         "Checksum(u128)s are delivered.  The kernel hoists the order hash and memoises unchanged tails, and the step computes the "
                                         "branch-invariant Save(C+1) once per rank instead of once per branch (shared_prefix), so fewer are executed"}
+        line["roofline_alu"].update(alu_executed(line["roofline_alu"]["frac"], D))
     parity_failed = False
     if rank == 0 and not args.no_cpu_baseline:
         if not getattr(args, "parity_only", False):

@@ -46,6 +46,7 @@ timeout 600 python scripts/adopt_ab.py 100000 7 > $OUT/adopt_ab_100k.json 2>> $O
 timeout 600 python scripts/adopt_ab.py 1000000 7 > $OUT/adopt_ab_1m.json 2>> $OUT/bench.err
 timeout 600 python scripts/ff_stress.py 300000 1000000 > $OUT/ff_stress_300k.json 2>> $OUT/bench.err
 timeout 120 ./scripts/ubench_launch/ubench_launch scripts/ubench_launch/kernels.hsaco > $OUT/ubench_launch.json 2>&1
+[ -x scripts/ubench_alu ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench_alu.hip -o scripts/ubench_alu 2>> $OUT/bench.err
 ./scripts/ubench_alu > $OUT/ubench_alu.txt 2>&1
 # ---- profiles: the DEFAULT command's timed launches (kernel trace), then the counter passes on a shorter form of it
 BENCH="python bench.py --steps 100 --warmup 16 --no-cpu-baseline --preheat-ms 0 --no-extra --no-traffic"

@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <vector>
 constexpr uint64_t P = 0x6eed0e9da4d94a4fULL;
-__device__ __forceinline__ uint64_t diffuse(uint64_t x) { x *= P; x ^= (x >> 32) >> (x >> 60); x *= P; return x; }
+// the kernels' own spelling (bevy_ggrs_amd/csrc/device_prelude.hpp sea_diffuse): the variable shift in 32-bit terms -- a ceiling measured with the 64-bit form
+// (v_lshrrev_b64 per diffuse: rounds 4-5) was one the kernels could exceed (config 5 read 1.02 of it in profiles/r06final)
+__device__ __forceinline__ uint64_t diffuse(uint64_t x) { x *= P; const uint32_t hi = (uint32_t)(x >> 32); x ^= (uint64_t)(hi >> (hi >> 28)); x *= P; return x; }
 
 template <int CH>
 __global__ __launch_bounds__(256) void k_diffuse(uint64_t* out, int iters) {

@@ -109,6 +109,7 @@ def test_alu_view_prices_a_launch_against_the_measured_ceiling():
     assert abs(v["achieved"] - 96e6 / 49.2e-6 / 1e9) < 1e-6 and v["peak"] == peak and abs(v["frac"] - v["achieved"] / peak) < 1e-12
     assert 0.5 < v["frac"] < 0.8
     assert b.alu_view(1.0, 0.0)["achieved"] == 0.0
+    assert abs(v["executed_over_algorithmic"] - 65 / 96) < 1e-4 and abs(v["frac_executed"] - v["frac"] * 65 / 96) < 1e-6          # 4 of the 6 per component-save + the hoisted order hash
 
 
 def test_latency_floor_reports_a_lower_bound_against_the_timed_tick_and_keeps_the_same_pass_check():
