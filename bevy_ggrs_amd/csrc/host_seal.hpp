@@ -237,6 +237,10 @@ int seal_impl(ggrs_world* w) {
         w->d_ff_rows[1] = reinterpret_cast<uint64_t*>(base + bytes + ff_bytes);
         w->ff_cur = 0; w->ff_pending = ggrs_world::FfPending{};
         if (w->knobs.debug_poison) HIPCHK(w, hipMemsetAsync(w->d_gen_parts, 0xA5, bytes + 2 * ff_bytes, w->stream));
+        // self-fold reads these buffers as {value, tag} cells WHILE the launch that writes them runs: a cell must never carry a tag this world will use before the
+        // launch that owns it has written it.  Tags count up per world, so memory recycled from an earlier world of the process could (the fuzz under
+        // GGRS_FOLD_FORWARD_MIN_WGS=0 found it: stale cells of the previous test's world, same tags) -- the buffers start zeroed (no tag is 0)
+        else HIPCHK(w, hipMemsetAsync(w->d_ff_rows[0], 0, 2 * ff_bytes, w->stream));
     }
     if (w->vtags) { HIPCHK(w, hipMalloc((void**)&w->d_skip, 8)); HIPCHK(w, hipMemsetAsync(w->d_skip, 0, 8, w->stream)); }
     if (w->dev_spawn) {

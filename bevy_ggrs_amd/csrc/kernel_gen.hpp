@@ -563,10 +563,11 @@ bool jit_source(const ggrs_world* w, std::string& s) {
          "__device__ __forceinline__ uint32_t mb_u8(const GGRS_K unsigned char* mb, uint32_t off) { return *(const GGRS_K unsigned char*)(mb + off); }\n"
          "// value tags keep one 32-bit tag per COLUMN in lane `column` of a register: a wave-uniform 64-bit column mask therefore IS the set of lanes to touch.  These\n"
          "// run one instruction under that mask (exec narrowed, the instruction, exec restored) instead of building a per-lane condition from the mask with VALU\n"
-         "// shifts and compares -- the generated kernel is bound by its vector ALUs\n"
+         "// shifts and compares -- the generated kernel is bound by its vector ALUs.  (`s_and_b64` writes SCC and the statements SAY so: without the clobber the compiler\n"
+         "// kept a condition in SCC across them -- s_bitcmp1 before the asm, s_cselect behind it -- in copies specialised for some shapes: profiles/r06ff)\n"
          "__device__ __forceinline__ uint64_t uni64(uint64_t m) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m); }   // wave-uniform by construction: say so\n"
-         "__device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %2\\n\\tv_mov_b32 %1, %3\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_), \"+v\"(v) : \"s\"(lanes), \"s\"(x)); }\n"
-         "__device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %3\\n\\tglobal_store_dword %1, %2, off\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_) : \"v\"(p), \"v\"(v), \"s\"(lanes) : \"memory\"); }\n"
+         "__device__ __forceinline__ void set_lanes(uint32_t& v, uint64_t lanes_, uint32_t x_) { const uint64_t lanes = uni64(lanes_); const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %2\\n\\tv_mov_b32 %1, %3\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_), \"+v\"(v) : \"s\"(lanes), \"s\"(x) : \"scc\"); }\n"
+         "__device__ __forceinline__ void store_lanes(GGRS_G uint32_t* p, uint32_t v, uint64_t lanes_) { const uint64_t lanes = uni64(lanes_); uint64_t sv_; asm volatile(\"s_mov_b64 %0, exec\\n\\ts_and_b64 exec, exec, %3\\n\\tglobal_store_dword %1, %2, off\\n\\ts_mov_b64 exec, %0\" : \"=&s\"(sv_) : \"v\"(p), \"v\"(v), \"s\"(lanes) : \"memory\", \"scc\"); }\n"
          "// SPAWNS DECIDED ON THE DEVICE: the workgroups of a COOPERATIVE launch (all resident) meet through mailbox words {epoch:32 | value:32}, written and polled\n"
          "// as relaxed agent-scope atomics (sc1: through to where every XCD reads them).  The value travels INSIDE the word it is waited on, so no rendezvous needs a\n"
          "// release/acquire pair -- on gfx950 those are a writeback / an invalidate of a whole L2 each (measured: ~100 us per barrier with an acquire in the poll loop).\n"

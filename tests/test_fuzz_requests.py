@@ -104,6 +104,17 @@ def test_hip_matches_the_oracle_on_random_request_lists_value_tags_forced(seed, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [13, 16, 43, 2, 29, 58, 71])
+def test_hip_matches_the_oracle_on_random_request_lists_value_tags_forced_every_shape_specialised(seed, monkeypatch):
+    """The same worlds with a kernel specialised for EVERY group shape at first sight (by default a shape earns one after 16 groups, built on a worker thread): the
+    literals give the compiler other schedules than the generic text has.  Seeds 13, 16 and 43 differed from the oracle (profiles/r06ee) until set_lanes / store_lanes
+    listed SCC among their clobbers (tests/test_generated_kernel.py has the static half); the whole file runs in this mode in profiles/r06gg."""
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_AFTER", "1")
+    monkeypatch.setenv("GGRS_JIT_SPECIALISE_SYNC", "1")
+    fuzz_util.run(5000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _tagged_world, n_lists=30, generic=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3))
 def test_hip_matches_the_oracle_on_random_request_lists_value_tags_forced_hbm_sized(seed):
     fuzz_util.run(6000 + seed, lambda sc: OracleWorld(sc.capacity, 8, FLAT), _tagged_world, n_lists=10, big=True, state_every=10)
