@@ -821,7 +821,7 @@ int ggrs_hip_world_kernel_info(ggrs_world* w, char* buf, uint64_t cap, uint64_t*
                                                     : "hipStreamSynchronize (GGRS_SPIN_WAIT_US=0)");
     add("slots_covered", std::to_string(cover));
     add("row_versions", w->knobs.row_versions ? "on" : "off (GGRS_ROW_VERSIONS=0)");
-    add("value_tags", !w->sealed ? "unknown (not sealed)" : w->vtags ? "on: a Save skips the columns whose 64 values per unit the destination already holds (" + std::to_string(w->prof_skipped) + " bytes not stored in profiled launches)"
+    add("value_tags", !w->sealed ? "unknown (not sealed)" : w->vtags ? "on: a Save skips the columns whose 64 values per unit the destination already holds (" + std::to_string(w->prof_skipped) + " bytes not stored in profiled launches; the ids' numbering has started over " + std::to_string(w->tag_wraps) + " times)"
                                  : "off (the world's steady Save moves less than " + std::to_string(VTAGS_MIN_BYTES >> 20) + " MB, or row versions are off)");
     if (needed) *needed = s.size() + 1;
     if (buf && cap) { const uint64_t n = std::min<uint64_t>(cap, s.size() + 1); memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }

@@ -10,15 +10,22 @@
 
 namespace {
 
-// value tags: the ids a launch of `members` groups of `n_steps` steps may hand out (tag_base of its argument block); a wrap makes every block's tags invalid
-inline uint32_t vtags_reserve(ggrs_world* w, uint32_t n_steps, uint32_t members) {
+// value tags: the ids a launch of `members` groups of `n_steps` steps may hand out (tag_base of its argument block).  When the 32-bit counter starts over, no tag of the
+// old numbering survives anywhere: every block's tags are ZEROED on the stream (0 = no identity) and its tag_ok bits cleared -- a tag left in a unit that no launch covers
+// for a while (a LoadWorld of a frame before a spawn shortens the world) must not meet the same number again.  Callers reserve BEFORE they read any block's tag_ok.
+// (Every world crosses its first start-over within its first few dozen launches -- host_seal.hpp, like jiffies -- so the path is run by every test of a tag-keeping world.)
+inline int vtags_reserve(ggrs_world* w, uint32_t n_steps, uint32_t members, uint32_t* base) {
     const uint64_t need = (uint64_t)members * (n_steps + 2u);          // per member: one id for "unknown at the load", one per possible count of steps before a store (0 .. n_steps)
     if ((uint64_t)w->tag_counter + need >= 0xFFFFFFF0ull) {
-        w->live.tag_ok = 0; for (auto& b : w->slots) b.tag_ok = 0; for (auto& b : w->spec_blocks) b.tag_ok = 0;
-        w->tag_counter = 1;
+        const uint64_t tag_bytes = w->state_bytes - w->off_tags;
+        auto forget = [&](Block& b) -> hipError_t { b.tag_ok = 0; return (b.ptr && tag_bytes) ? hipMemsetAsync(b.ptr + w->off_tags, 0, tag_bytes, w->stream) : hipSuccess; };
+        HIPCHK(w, forget(w->live));
+        for (auto& b : w->slots) HIPCHK(w, forget(b));
+        for (auto& b : w->spec_blocks) HIPCHK(w, forget(b));
+        w->tag_counter = 1; ++w->tag_wraps;
     }
-    const uint32_t base = w->tag_counter; w->tag_counter += (uint32_t)need;
-    return base;
+    *base = w->tag_counter; w->tag_counter += (uint32_t)need;
+    return GGRS_OK;
 }
 // the tags of a block as a SOURCE / DESTINATION of a launch: columns somebody else may write behind the library's back never count
 inline uint64_t block_tagok(const ggrs_world* w, const Block& b) {
@@ -387,7 +394,7 @@ int materialise_live(ggrs_world* w) {
     j.live_rows = rows_to_store(w, w->live); j.live_pmask = pmask_differs(w, w->live, w->cur_ver);
     j.load_rows = jit_static_reads(w) | j.live_rows;
     j.vtags = w->vtags ? 1u : 0u;
-    if (j.vtags) { j.tag_base = vtags_reserve(w, 1, 1); j.src_tagok = block_tagok(w, *st.src); j.live_tagok = block_tagok(w, w->live); }
+    if (j.vtags) { const int trc = vtags_reserve(w, 1, 1, &j.tag_base); if (trc) return trc; j.src_tagok = block_tagok(w, *st.src); j.live_tagok = block_tagok(w, w->live); }
     const uint64_t cover = std::max(std::max(st.src->dirty_len, w->live.dirty_len), w->len);
     j.parts = reinterpret_cast<ggrs_u64*>(w->d_gen_parts); j.part_stride = w->gen_part_stride; j.part_tstride = 1;
     j.n_units = std::max<uint32_t>(1, (uint32_t)((cover + 63) / 64));
@@ -538,7 +545,7 @@ int run_request_groups_gen(ggrs_world* w, const ggrs_request* reqs, uint32_t n, 
         // value tags: a group that stores nothing (a dead branch) has no use for them
         j.vtags = (w->vtags && !dead) ? 1u : 0u;
         if (j.vtags) {
-            j.tag_base = vtags_reserve(w, j.n_steps, 1);
+            rc = vtags_reserve(w, j.n_steps, 1, &j.tag_base); if (rc) return rc;
             j.src_tagok = block_tagok(w, *gs.src); j.live_tagok = wrote_live ? block_tagok(w, w->live) : 0;
             for (uint32_t k = 0; k < j.n_saves; ++k) j.save_tagok[k] = (j.save_dst[k] && gs.dsts[k]) ? block_tagok(w, *gs.dsts[k]) : 0;
         }
@@ -796,6 +803,8 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
     // ---- members: inputs, spawns, lens; with retention the blocks their frames land in and the rows each store moves (row versions)
     size_t n_keep = 0;
     if (keep_any) { n_keep = (size_t)B * (keep_all ? n_out : 1u); rc = spec_blocks_reserve(w, n_keep); if (rc) return rc; }
+    // value tags: the launch's ids are reserved BEFORE any block's tag_ok is read or set below (a start-over of the numbering clears them all)
+    if (w->vtags && keep_any) { rc = vtags_reserve(w, T, B, &j.tag_base); if (rc) return rc; }
     if (keep) { keep->n_branches = B; keep->n_out = n_out; keep->n_frames = T; keep->base_frame = F; keep->blk.assign((size_t)B * n_out, -1); }
     uint64_t cover = std::max(src.dirty_len, src.len), max_len = src.len, load_rows = jit_static_reads(w), store_bytes = 0;
     if (keep_any) for (size_t k = 0; k < n_keep; ++k) cover = std::max(cover, w->spec_blocks[k].dirty_len);
@@ -888,7 +897,7 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
     j.nt = (cover > JIT_NT_MIN_SLOTS || store_bytes > (128ull << 20)) ? 1u : 0u;
     j.cached_saves = 0; j.nt_loads = 0; j.dp_s = 0;
     j.vtags = (w->vtags && keep_any) ? 1u : 0u;
-    if (j.vtags) { j.tag_base = vtags_reserve(w, T, B); j.src_tagok = block_tagok(w, src); }
+    if (j.vtags) j.src_tagok = block_tagok(w, src);
     w->batch_ev_attached = false;
     hipFunction_t fn = jit_spec_for(w, j, true);                      // the copy of the kernel built for this op sequence, once the session has sent it often enough
     if (!fn) fn = w->jit_fn;

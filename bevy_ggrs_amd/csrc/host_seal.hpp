@@ -183,6 +183,9 @@ int seal_impl(ggrs_world* w) {
     const uint32_t ncols = (uint32_t)w->col_off.size();
     // value tags by default where a steady Save is bound by bytes: what the systems write x the world's slots (the knob: ggrs_dbg_set_value_tags)
     w->vtags = w->gen_ok && vtags_policy(w);
+    // (like jiffies: the ids' 32-bit numbering starts over within a world's first few dozen launches -- host_groups.hpp vtags_reserve --, so that path is run by every
+    // test of a tag-keeping world instead of once per ~4e8 launches)
+    if (w->vtags) w->tag_counter = 0xFFFFFFF0u - 400u;
     w->live.ptr = p; p += w->state_bytes;
     w->live.ver.assign(ncols + w->comps.size(), 0);                                   // == cur_ver: nothing has been written yet
     w->slots.resize(w->max_depth);

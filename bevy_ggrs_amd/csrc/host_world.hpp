@@ -202,7 +202,7 @@ struct ggrs_world {
     // that block's Block::tag_ok bits; tag 0 never matches; ids are unique per launch, step and batch member (tag_counter; a wrap invalidates every block).
     uint64_t off_tags = 0; uint32_t tag_row_bytes = 0;     // the tag region of a block: [unit][column] u32
     uint64_t tag_cols = 0;                                 // columns that carry tags (plain rollback columns; a component under a Strategy is always stored)
-    uint32_t tag_counter = 1;
+    uint32_t tag_counter = 1, tag_wraps = 0;
     int vtags_mode = -1; bool vtags = false;               // ggrs_dbg_set_value_tags: 0 off, 1 on, -1 by size (seal decides: VTAGS_MIN_BYTES)
     uint64_t* d_skip = nullptr;                            // profiling: bytes the launches did NOT store thanks to the tags (ggrs_hip_profile_read_bytes stays honest)
     // SPAWNS DECIDED ON THE DEVICE (kernel_gen.hpp GgrsJitArgs::sp_*): a system called e.spawn(n).  RollbackOrdered::len then lives on the device -- the host's `len`

@@ -162,6 +162,32 @@ def test_value_tags_skip_the_columns_whose_values_never_change():
     for f in res[1][2]: assert res[0][2][f] == res[1][2][f], f"ring frame {f}"
 
 
+@pytest.mark.parametrize("n", [3000, 300_000])
+def test_value_tag_ids_start_over_without_leaving_a_tag_behind(n):
+    """The ids are 32-bit and count up per launch: when they start over, every block's tags are zeroed on the stream and its tag_ok bits cleared (host_groups.hpp
+    vtags_reserve) -- a tag of the old numbering left in a unit no launch covers for a while must not meet the same number again.  Every world crosses its FIRST
+    start-over within its first few dozen launches (host_seal.hpp), so the path runs here (and in every other test of a tag-keeping world): a SyncTest session with an
+    upload into a constant column on either side of it, checksums / live state / every ring frame equal to the oracle's."""
+    D = 8
+    res = []
+    for w in (_tagged(n, D + 1), OracleWorld(n, D + 1, FLAT)):
+        ids = cm.build_particles(w)
+        vel, ttl = cm.synthetic_particles(n, ttl="throughput")
+        cm.spawn_particles(w, ids, n, vel, ttl)
+        drv = cm.SyncTestDriver(w, D, max_prediction=D + 1)
+        for k in range(70):
+            if k in (20, 45): w.upload_word(ids[1], 2, 64 * (k % 7), np.full(min(n, 1000), 0x40400000 + k, dtype=np.uint32))
+            drv.tick((0,))
+        if isinstance(w, bg.World):
+            info = w.kernel_info()["value_tags"]
+            assert info.startswith("on") and "has started over 1 times" in info, info
+        res.append((list(drv.all_checksums), cm.snapshot_state(w, ids), _ring_contents(w, ids, list(range(w.frame - D, w.frame)))))
+    assert res[0][0] == res[1][0]
+    cm.assert_states_equal(res[0][1], res[1][1], "live")
+    assert sorted(res[0][2]) == sorted(res[1][2]) and len(res[1][2]) >= D - 1
+    for f in res[1][2]: assert res[0][2][f] == res[1][2][f], f"ring frame {f}"
+
+
 def test_steady_state_tick_moves_only_what_systems_write():
     """The point of it: in a steady SyncTest tick of the stress_test the library asks its kernel for 320 B per entity (32 loaded +
     8 x 32 + 32 stored), not 600 -- as counted by ggrs_hip_profile_read_bytes, the numerator of bench.py's roofline."""
