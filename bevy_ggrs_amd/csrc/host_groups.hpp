@@ -808,7 +808,7 @@ int run_branch_step(ggrs_world* w, const ggrs_branch_step& st, uint32_t res_firs
     if (keep) { keep->n_branches = B; keep->n_out = n_out; keep->n_frames = T; keep->base_frame = F; keep->blk.assign((size_t)B * n_out, -1); }
     uint64_t cover = std::max(src.dirty_len, src.len), max_len = src.len, load_rows = jit_static_reads(w), store_bytes = 0;
     if (keep_any) for (size_t k = 0; k < n_keep; ++k) cover = std::max(cover, w->spec_blocks[k].dirty_len);
-    std::vector<uint32_t> cv;
+    std::vector<ver_t> cv;
     std::vector<unsigned char> rec((size_t)B * L.m.bytes);
     std::vector<Block*> touched;
     const size_t in_row = (size_t)w->max_players * (ib + 1);

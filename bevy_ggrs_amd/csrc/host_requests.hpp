@@ -14,7 +14,7 @@ FinalizeArgs no_finalize() { FinalizeArgs f; memset(&f, 0, sizeof f); return f; 
 
 // `want`: the versions of the state being copied (src's own, or the logical live state's).  Only the rows whose column differs
 // in dst move; the masks and the header always do.  dst holds `want` afterwards.
-int launch_copy(ggrs_world* w, const Block& src, Block& dst, const std::vector<uint32_t>& want, uint64_t len, uint32_t cls, const FinalizeArgs& fin) {
+int launch_copy(ggrs_world* w, const Block& src, Block& dst, const std::vector<ver_t>& want, uint64_t len, uint32_t cls, const FinalizeArgs& fin) {
     const uint64_t cover = std::max(std::max(src.dirty_len, dst.dirty_len), len);
     const uint32_t g = std::max(1u, tiles_for(cover));
     CopyPlan plan = w->plan;

@@ -30,13 +30,16 @@ struct Comp {
 // rotation and scale of the stress_test's Transform) therefore reaches every ring slot once and is never stored again:
 // the snapshot bytes are identical by construction, only the redundant store is gone.  GGRS_ROW_VERSIONS=0 turns the
 // bookkeeping off (every copy moves every row).
-constexpr uint32_t VER_NONE = 0xFFFFFFFFu;   // "nothing known": never equal to a live version
+// Row versions are 64-bit: a 32-bit counter started over after ~55 minutes of 1 M-entity ticks (~63 versions per depth-8 tick; minutes for small worlds), and a block
+// column left alone that long -- the lazy live block, an idle branch block -- could then meet its own old number on other bytes
+using ver_t = uint64_t;
+constexpr ver_t VER_NONE = ~0ull;             // "nothing known": never equal to a live version
 
 struct Block {                           // one packed state block in the arena
     uint8_t* ptr = nullptr;
     uint64_t dirty_len = 0;              // slots that may hold non-zero mask bits
     uint64_t len = 0;                    // host mirror of Header::len for ring slots
-    std::vector<uint32_t> ver;           // per column: the version of the bytes this block holds (VER_NONE: unknown)
+    std::vector<ver_t> ver;              // per column: the version of the bytes this block holds (VER_NONE: unknown)
     uint64_t tag_ok = 0;                 // bit c: the block's VALUE TAGS of column c (one per 64-slot unit, in the block's tag region) describe its bytes -- see ggrs_world::vtags
 };
 
@@ -219,9 +222,9 @@ struct ggrs_world {
     std::vector<uint32_t> row_col;                 // plan.row[r] belongs to column row_col[r]
 
     // ---- row versions (see Block::ver)
-    uint32_t ver_counter = 0;
-    std::vector<uint32_t> cur_ver;                 // the LOGICAL live state's version per column (ahead of live.ver inside a fused group)
-    std::vector<uint32_t> group_save_ver;          // scratch of the group being assembled: [Save k][column] = the versions slot k will hold
+    ver_t ver_counter = 0xFFFFFF00ull;   // (starts just below 2^32: every world's versions cross that line within its first ticks, so a 32-bit copy of one anywhere would show in the tests)
+    std::vector<ver_t> cur_ver;                    // the LOGICAL live state's version per column (ahead of live.ver inside a fused group)
+    std::vector<ver_t> group_save_ver;             // scratch of the group being assembled: [Save k][column] = the versions slot k will hold
     std::vector<uint8_t> col_ext;                  // a device pointer to this live column was handed out: assume it changes between any two calls
     std::vector<std::vector<uint32_t>> sys_writes; // per system: the columns it may write (one fresh version per AdvanceWorld)
 
@@ -370,7 +373,7 @@ inline void ver_touch_all(ggrs_world* w) { for (uint32_t c = 0; c < w->cur_ver.s
 // AdvanceWorld: every registered system may have written its write set
 inline void ver_step(ggrs_world* w) { for (auto& cols : w->sys_writes) for (uint32_t c : cols) ver_touch(w, c); }
 // must `dst` receive column `col` to hold the state whose versions are `want`?  (yes also when nothing is known)
-inline bool ver_differs(const ggrs_world* w, const Block& dst, const std::vector<uint32_t>& want, uint32_t col) {
+inline bool ver_differs(const ggrs_world* w, const Block& dst, const std::vector<ver_t>& want, uint32_t col) {
     return !w->knobs.row_versions || w->col_ext[col] || dst.ver[col] == VER_NONE || want[col] == VER_NONE || dst.ver[col] != want[col];
 }
 // the live block holds exactly the logical live state (no fused group is being assembled)
@@ -379,7 +382,7 @@ inline void ver_sync_live(ggrs_world* w) { w->live.ver = w->cur_ver; }
 inline void live_tags_lost(ggrs_world* w, uint32_t col) { if (col < 64) w->live.tag_ok &= ~(1ull << col); }
 inline void live_tags_lost_comp(ggrs_world* w, uint32_t c) { for (uint32_t k = 0; k < w->comps[c].n_words; ++k) live_tags_lost(w, w->comps[c].col_base + k); }
 // presence masks of `dst` that differ from the ones `want` describes
-inline uint32_t pmask_differs(const ggrs_world* w, const Block& dst, const std::vector<uint32_t>& want) {
+inline uint32_t pmask_differs(const ggrs_world* w, const Block& dst, const std::vector<ver_t>& want) {
     uint32_t m = 0;
     for (uint32_t c = 0; c < w->comps.size(); ++c) {
         const uint32_t i = ver_presence(w, c);
