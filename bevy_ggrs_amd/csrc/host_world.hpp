@@ -33,6 +33,7 @@ struct Comp {
 // Row versions are 64-bit: a 32-bit counter started over after ~55 minutes of 1 M-entity ticks (~63 versions per depth-8 tick; minutes for small worlds), and a block
 // column left alone that long -- the lazy live block, an idle branch block -- could then meet its own old number on other bytes
 using ver_t = uint64_t;
+static_assert(sizeof(ver_t) == 8, "row versions never start over");
 constexpr ver_t VER_NONE = ~0ull;             // "nothing known": never equal to a live version
 
 struct Block {                           // one packed state block in the arena
