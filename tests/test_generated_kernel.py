@@ -329,12 +329,14 @@ def test_inline_asm_that_runs_an_scc_writing_instruction_says_so():
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="no llvm-objdump")
-def test_no_condition_is_carried_in_scc_across_the_exec_narrowing_asm():
+@pytest.mark.parametrize("schema,n", [("headline", 4_000_000), ("allhot", 2_000_000), ("full", 4_000_000)])
+def test_no_condition_is_carried_in_scc_across_the_exec_narrowing_asm(schema, n):
     """The same on the ISA of a value-tag kernel (the 4 M headline world's steady tick and its generic kernel): between the `s_and_b64 exec, exec, ..` of
     set_lanes / store_lanes and the next instruction that READS SCC there is one that writes it."""
     import ctypes as C, subprocess, tempfile
-    w = dry(4_000_000, 9)
-    cm.build_particles(w, schema="headline")
+    w = dry(n, 9)
+    cm.build_particles(w, schema=schema)
+    assert "value tags 1" in w.generated_kernel_source(steady=True), "a tag-keeping world"
     rtc = C.CDLL("libhiprtc.so")
     readers = re.compile(r"\bs_(cselect_b(32|64)|cbranch_scc[01]|addc_u32|subb_u32|cmov_b(32|64))\b")
     for steady in (True, False):
